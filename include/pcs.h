@@ -1,0 +1,130 @@
+/* pcs.h -- C ABI of libpcs_hip.so: the MI355X (gfx950) implementation of the PCSeqLearning
+ * hot path (per-frame voxelization + sparse-conv backbone; radius-graph / connected-component
+ * cluster proposal; per-component ICP registration and cluster tracking).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless the parameter is documented "host".
+ *  - Every function returns 0 (PCS_OK) or a negative PCS_ERR_* code. Nothing exits, throws or
+ *    allocates device memory: scratch comes from the caller's workspace (`*_workspace_bytes`
+ *    queries are host-only and cheap), outputs are caller-allocated at their documented capacity.
+ *  - Data-dependent output counts are written to a device scalar (`d_num*`, int64); the caller
+ *    decides when to read it back (the reference syncs at the same places with `.item()`).
+ *  - `stream` is a hipStream_t; kernels are enqueued, never synchronised.
+ *  - Arrays are row-major and contiguous. Index outputs are int64 where the reference returns
+ *    int64 tensors and int32 where it returns int32 (rulebooks, voxel coords).
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef PCS_H_
+#define PCS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* pcs_stream_t; /* == hipStream_t */
+
+#define PCS_OK 0
+#define PCS_ERR_ARG (-1)
+#define PCS_ERR_WORKSPACE (-2)
+#define PCS_ERR_HIP (-3)
+#define PCS_ERR_RANGE (-4)
+
+/* ------------------------------------------------------------------ voxel keys / grid sampling */
+
+/* out8 = {min over rows (4), max over rows (4)} of a [n,4] f32 array.
+ * Replaces points.min(0)/max(0) in pcdet/models/model_utils/grid_sampling.py:32-35 and
+ * graph_utils.py:171-173. */
+int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, pcs_stream_t stream);
+
+/* torch_cluster.grid_cluster(points, size, start, end) as called by
+ * pcdet/models/model_utils/grid_sampling.py:37 with start[0]-=margin0, end[0]+=margin0 applied to
+ * bounds8 (= pcs_minmax4_f32 output). size4 is a host array. ids[n] int64. */
+int pcs_grid_cluster_ids(const float* pts, int64_t n, const float* bounds8, const float* size4,
+                         float margin0, int64_t* ids, pcs_stream_t stream);
+
+/* torch.unique(ids, sorted=True, return_inverse=True) (grid_sampling.py:38) plus the segment
+ * structure the callers rebuild with scatter ops: order[n] = original indices sorted by
+ * (id, index); seg_start[v+1] = segment boundaries in `order`; uniq[v]; inv[n]; *d_num = v.
+ * uniq / inv / order may be NULL. ids must be non-negative; key_bits = significant bits (64 if
+ * unknown). Capacities: uniq[n], seg_start[n+1]. */
+size_t pcs_unique_i64_workspace_bytes(int64_t n);
+int pcs_unique_i64(const int64_t* ids, int64_t n, int key_bits, int64_t* uniq, int64_t* inv,
+                   int32_t* order, int32_t* seg_start, int64_t* d_num, void* ws, size_t ws_bytes,
+                   pcs_stream_t stream);
+
+/* torch_scatter.scatter(data, inv, reduce='mean'|'sum') (grid_sampling.py:42,
+ * cluster_tracking.py:44) over the segments of pcs_unique_i64, summed in ascending original
+ * index (deterministic). data [n,d] f32 -> out [v,d]. */
+int pcs_segment_reduce_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start,
+                           int64_t v, int mean, float* out, pcs_stream_t stream);
+
+/* scatter(arange(n), inv, reduce='max') of pcdet/models/registration/simple_reg.py:122-124
+ * (pick_last=1) or the min variant (pick_last=0). out[v] int64. */
+int pcs_segment_pick(const int32_t* order, const int32_t* seg_start, int64_t v, int pick_last,
+                     int64_t* out, pcs_stream_t stream);
+
+/* DynamicMeanVFE.forward, pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:51-76.
+ * pts [n,ncol] = (batch, x, y, z, feat...); range6/voxel3/grid3 host arrays (x,y,z order).
+ * voxel_feat [n,ncol-1] capacity, voxel_coords [n,4] int32 (b,z,y,x), inv[n] (-1 = out of range,
+ * may be NULL), *d_num = voxel count. Voxels come out in ascending b*XYZ + x*YZ + y*Z + z. */
+size_t pcs_dynamic_voxelize_workspace_bytes(int64_t n);
+int pcs_dynamic_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                         const float* voxel3, const int32_t* grid3, float* voxel_feat,
+                         int32_t* voxel_coords, int64_t* inv, int64_t* d_num, void* ws,
+                         size_t ws_bytes, pcs_stream_t stream);
+
+/* points_to_voxel_3d_np, pcdet/ops/spconv/include/spconv/point2voxel.h:33-92 (the spconv-1.x
+ * VoxelGeneratorV2 used by pcdet/datasets/processor/data_processor.py:23-68).
+ * pts [n,ncol] = (x, y, z, feat...). voxels [max_voxels,max_points,ncol], coords [max_voxels,3]
+ * (z,y,x), num [max_voxels]; rows past *d_num are zero. First-come voxel order. */
+size_t pcs_hard_voxelize_workspace_bytes(int64_t n);
+int pcs_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                      const float* voxel3, int max_points, int max_voxels, float* voxels,
+                      int32_t* coords, int32_t* num, int64_t* d_num, void* ws, size_t ws_bytes,
+                      pcs_stream_t stream);
+
+/* ------------------------------------------------------------------ sparse-conv rulebook + conv */
+
+/* sparse_conv_ext.get_indice_pairs_3d, pcdet/ops/spconv/src/all.cc:21-23 ->
+ * getIndicePair<3>, include/spconv/spconv_ops.h:27-141. indices [V,4] int32 (b,z,y,x).
+ * pairs [KV,2,V] int32 (filled with -1 then written), num [KV]; strided conv also writes
+ * out_ids [out_cap,4] with out_cap >= pcs_indice_pairs_out_capacity() and *d_num_out.
+ * Pair order per offset = ascending input index; output voxel order = first encounter
+ * (the reference CPU functor order, geometry.h:145-194). transpose (deconv) is rejected.
+ * All *3 arrays are host int[3] in (z,y,x) order. KV <= 32. */
+int64_t pcs_indice_pairs_out_capacity(int64_t V, const int* ksize3, const int* stride3, int subm);
+size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const int* stride3,
+                                            int subm);
+int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
+                         const int* spatial_shape3, const int* ksize3, const int* stride3,
+                         const int* pad3, const int* dil3, int subm, int transpose,
+                         int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
+                         int64_t* d_num_out, void* ws, size_t ws_bytes, pcs_stream_t stream);
+
+/* sparse_conv_ext.indice_conv_fp32, src/all.cc:30-33 -> indiceConv<float>,
+ * spconv_ops.h:260-361. features [num_in,cin], filters [kv,cin,cout], out [num_out,cout].
+ * ws >= pcs_neighbor_table_bytes(num_out, kv). */
+size_t pcs_neighbor_table_bytes(int64_t num_out, int kv);
+int pcs_indice_conv_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                        const int32_t* pairs, int64_t pair_stride, const int32_t* num,
+                        int64_t num_out, int inverse, int subm, float* out, void* ws,
+                        size_t ws_bytes, pcs_stream_t stream);
+
+/* The two halves of the above, so a rulebook cached under an indice_key
+ * (pcdet/ops/spconv/conv.py:146-171) keeps its output-major table too, and bias / eval-mode
+ * BatchNorm / ReLU (fused_spconv_ops.h:29-132, modules.py:125-187) fold into the epilogue. */
+int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
+                             int inverse, int64_t num_out, int32_t* table, pcs_stream_t stream);
+int pcs_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv,
+                              int cout, int centre, const int32_t* table, int64_t num_out,
+                              const float* bias, const float* scale, const float* shift, int relu,
+                              float* out, pcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCS_H_ */

@@ -1,0 +1,194 @@
+"""numpy front-end of the CPU oracle (oracle/libpcs_oracle.so) and of the compiled reference
+builders (oracle/_ref/*).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. Nothing under pcseqlearning_amd/ imports this module.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF_SPCONV = None
+
+
+def build():
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "libpcs_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        for name in ("orc_unique_i64", "orc_dynamic_voxelize", "orc_hard_voxelize",
+                     "orc_get_indice_pairs"):
+            getattr(_LIB, name).restype = ctypes.c_int64
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else ctypes.c_void_p(0)
+
+
+def _ints(v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def _floats(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------
+def grid_cluster_ids(points, size4, margin0=0.5):
+    pts = _c(points, np.float32)
+    ids = np.empty(pts.shape[0], np.int64)
+    bounds = np.empty(8, np.float32)
+    lib().orc_grid_cluster_ids(_p(pts), ctypes.c_int64(pts.shape[0]), _floats(size4),
+                               ctypes.c_float(margin0), _p(ids), _p(bounds))
+    return ids, bounds
+
+
+def unique_i64(ids):
+    ids = _c(ids, np.int64)
+    n = ids.shape[0]
+    uniq = np.empty(n, np.int64)
+    inv = np.empty(n, np.int64)
+    order = np.empty(n, np.int32)
+    seg = np.empty(n + 1, np.int32)
+    v = lib().orc_unique_i64(_p(ids), ctypes.c_int64(n), _p(uniq), _p(inv), _p(order), _p(seg))
+    return uniq[:v].copy(), inv, order, seg[:v + 1].copy()
+
+
+def segment_reduce(data, order, seg_start, mean=True):
+    data = _c(data, np.float32)
+    squeeze = data.ndim == 1
+    d2 = data.reshape(data.shape[0], -1)
+    v = seg_start.shape[0] - 1
+    out = np.empty((v, d2.shape[1]), np.float32)
+    lib().orc_segment_reduce_f32(_p(d2), ctypes.c_int(d2.shape[1]), _p(_c(order, np.int32)),
+                                 _p(_c(seg_start, np.int32)), ctypes.c_int64(v),
+                                 ctypes.c_int(int(mean)), _p(out))
+    return out[:, 0] if squeeze else out
+
+
+def grid_sample(points, grid_size3):
+    """GridSampling3D.forward(points, return_inverse=True) -> (means [v,4], inv [n], order, seg)."""
+    ids, _ = grid_cluster_ids(points, [1.0] + list(grid_size3), 0.5)
+    uniq, inv, order, seg = unique_i64(ids)
+    means = segment_reduce(points, order, seg, mean=True)
+    return means, inv, order, seg
+
+
+def dynamic_voxelize(points, pc_range, voxel_size, grid_size):
+    pts = _c(points, np.float32)
+    n, ncol = pts.shape
+    feat = np.empty((n, ncol - 1), np.float32)
+    coords = np.empty((n, 4), np.int32)
+    inv = np.empty(n, np.int64)
+    v = lib().orc_dynamic_voxelize(_p(pts), ctypes.c_int64(n), ctypes.c_int(ncol),
+                                   _floats(pc_range), _floats(voxel_size),
+                                   _p(_c(grid_size, np.int32)), _p(feat), _p(coords), _p(inv))
+    return feat[:v].copy(), coords[:v].copy(), inv
+
+
+def hard_voxelize(points, pc_range, voxel_size, max_points, max_voxels):
+    pts = _c(points, np.float32)
+    n, ncol = pts.shape
+    voxels = np.zeros((max_voxels, max_points, ncol), np.float32)
+    coords = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros(max_voxels, np.int32)
+    v = lib().orc_hard_voxelize(_p(pts), ctypes.c_int64(n), ctypes.c_int(ncol), _floats(pc_range),
+                                _floats(voxel_size), ctypes.c_int(max_points),
+                                ctypes.c_int(max_voxels), _p(voxels), _p(coords), _p(num))
+    return voxels[:v].copy(), coords[:v].copy(), num[:v].copy()
+
+
+def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
+    """get_conv_output_size, pcdet/ops/spconv/ops.py:20-30."""
+    return [(spatial_shape[i] + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1
+            for i in range(3)]
+
+
+def get_indice_pairs(indices, out_shape, ksize, stride, padding, dilation, subm):
+    idx = _c(indices, np.int32)
+    V = idx.shape[0]
+    kv = int(np.prod(ksize))
+    pairs = np.empty((kv, 2, V), np.int32)
+    num = np.empty(kv, np.int32)
+    out_ids = np.zeros((max(V * kv, 1), 4), np.int32)
+    n = lib().orc_get_indice_pairs(_p(idx), ctypes.c_int64(V), _ints(out_shape), _ints(ksize),
+                                   _ints(stride), _ints(padding), _ints(dilation),
+                                   ctypes.c_int(int(subm)), _p(out_ids), _p(pairs), _p(num))
+    return (idx if subm else out_ids[:n].copy()), pairs, num
+
+
+def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=False):
+    feat = _c(features, np.float32)
+    kv = pairs.shape[0]
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    W = _c(filters, np.float32).reshape(kv, cin, cout)
+    pairs = _c(pairs, np.int32)
+    out = np.empty((num_out, cout), np.float32)
+    lib().orc_indice_conv_f32(_p(feat), ctypes.c_int64(feat.shape[0]), ctypes.c_int(cin), _p(W),
+                              ctypes.c_int(kv), ctypes.c_int(cout), _p(pairs),
+                              ctypes.c_int64(pairs.shape[2]), _p(_c(num, np.int32)),
+                              ctypes.c_int64(num_out), ctypes.c_int(int(inverse)),
+                              ctypes.c_int(int(subm)), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# compiled reference (only where oracle/_ref was built, i.e. where /root/reference exists or the
+# prebuilt .so travelled with the repo snapshot)
+def ref_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_spconv.so"))
+
+
+def ref_get_indice_pairs(indices, batch, out_shape, ksize, stride, padding, dilation, subm):
+    global _REF_SPCONV
+    if _REF_SPCONV is None:
+        _REF_SPCONV = ctypes.CDLL(os.path.join(HERE, "_ref", "libref_spconv.so"))
+    idx = _c(indices, np.int32)
+    V = idx.shape[0]
+    kv = int(np.prod(ksize))
+    pairs = np.empty((kv, 2, V), np.int32)
+    num = np.empty(kv, np.int32)
+    out_ids = np.zeros((max(V * kv, 1), 4), np.int32)
+    n = _REF_SPCONV.ref_get_indice_pairs(_p(idx), ctypes.c_int(V), ctypes.c_int(batch),
+                                         _ints(out_shape), _ints(ksize), _ints(stride),
+                                         _ints(padding), _ints(dilation), ctypes.c_int(int(subm)),
+                                         _p(out_ids), _p(pairs), _p(num))
+    return (idx if subm else out_ids[:n].copy()), pairs, num
+
+
+def ref_hard_voxelize(points, pc_range, voxel_size, max_points, max_voxels):
+    """The reference's points_to_voxel_3d_np<float,3> with the VoxelGeneratorV2 calling
+    convention (zero-filled outputs, coor_to_voxelidx grid of -1)."""
+    import glob
+    so = glob.glob(os.path.join(HERE, "_ref", "ref_point2voxel*.so"))[0]
+    spec = importlib.util.spec_from_file_location("ref_point2voxel", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pts = _c(points, np.float32)
+    ncol = pts.shape[1]
+    vs = np.asarray(voxel_size, np.float32)
+    rng = np.asarray(pc_range, np.float32)
+    grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int32)
+    voxels = np.zeros((max_voxels, max_points, ncol), np.float32)
+    coors = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros(max_voxels, np.int32)
+    c2v = -np.ones(tuple(grid[::-1]), np.int32)
+    v = mod.points_to_voxel_3d_np(pts, voxels, coors, num, c2v, vs.tolist(), rng.tolist(),
+                                  max_points, max_voxels)
+    return voxels[:v].copy(), coors[:v].copy(), num[:v].copy()

@@ -1,0 +1,314 @@
+// pcs_oracle.cpp -- CPU restatement of the reference algorithms on the hot path.
+//
+// TEST INFRASTRUCTURE ONLY. Nothing under pcseqlearning_amd/ may import, link or call this file;
+// it exists so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can check and
+// time the HIP path against a serial implementation of what the reference computes.
+//
+// Pinning (see DESIGN.md "Oracle"):
+//  - rulebooks are checked against the reference's own CPU builders compiled from
+//    /root/reference (oracle/_ref/libref_spconv.so, built by oracle/Makefile) and against golden
+//    vectors generated from them (tests/golden/rulebook_*.npz);
+//  - the hard voxelizer against the reference's point2voxel.h compiled the same way;
+//  - the radius graph against brute force / sklearn in the reference's own protocol
+//    (pcdet/ops/torch_hash/torch_hash_utils.py:365-431) and its hand case
+//    (torch_hash_modules.py:146-151);
+//  - connected components against scipy.sparse.csgraph (the reference's call, graph_utils.py:52);
+//  - registration maths against the imported reference Python (tests/golden/reg_*.npz).
+//  - grid_cluster / torch_scatter orderings restate upstream documentation only:
+//    "parity unpinned" for those two third-party leaves.
+//
+// Plain serial C++ (no torch, no OpenMP), compiled with -ffp-contract=off so fp32 expressions
+// round exactly as written.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// GridSampling3D ids: pcdet/models/model_utils/grid_sampling.py:32-37 + torch_cluster.grid_cluster
+// (upstream semantics: c_d = (int64)((p_d - start_d) / size_d), strides from
+// (int64)((end_d - start_d) / size_d) + 1, dim 0 fastest).
+void orc_grid_cluster_ids(const float* pts, int64_t n, const float* size4, float margin0,
+                          int64_t* ids, float* bounds8_out) {
+  float st[4], en[4];
+  for (int d = 0; d < 4; ++d) { st[d] = INFINITY; en[d] = -INFINITY; }
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 4; ++d) {
+      st[d] = std::fmin(st[d], pts[i * 4 + d]);
+      en[d] = std::fmax(en[d], pts[i * 4 + d]);
+    }
+  if (bounds8_out) for (int d = 0; d < 4; ++d) { bounds8_out[d] = st[d]; bounds8_out[4 + d] = en[d]; }
+  st[0] = st[0] - margin0;
+  en[0] = en[0] + margin0;
+  int64_t stride[4];
+  stride[0] = 1;
+  for (int d = 0; d < 3; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / size4[d]) + 1);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t id = 0;
+    for (int d = 0; d < 4; ++d) id += (int64_t)((pts[i * 4 + d] - st[d]) / size4[d]) * stride[d];
+    ids[i] = id;
+  }
+}
+
+// torch.unique(sorted=True, return_inverse=True) (grid_sampling.py:38) + segment structure.
+// Returns the number of unique ids.
+int64_t orc_unique_i64(const int64_t* ids, int64_t n, int64_t* uniq, int64_t* inv, int32_t* order,
+                       int32_t* seg_start) {
+  std::vector<int32_t> ord(n);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return ids[a] < ids[b]; });
+  int64_t v = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (i == 0 || ids[ord[i]] != ids[ord[i - 1]]) {
+      if (uniq) uniq[v] = ids[ord[i]];
+      seg_start[v] = (int32_t)i;
+      ++v;
+    }
+    if (inv) inv[ord[i]] = v - 1;
+    if (order) order[i] = ord[i];
+  }
+  seg_start[v] = (int32_t)n;
+  return v;
+}
+
+// scatter(data, inv, reduce='mean'|'sum') in ascending original index per segment.
+void orc_segment_reduce_f32(const float* data, int d, const int32_t* order,
+                            const int32_t* seg_start, int64_t v, int mean, float* out) {
+  for (int64_t s = 0; s < v; ++s)
+    for (int c = 0; c < d; ++c) {
+      float acc = 0.f;
+      for (int p = seg_start[s]; p < seg_start[s + 1]; ++p) acc = acc + data[(int64_t)order[p] * d + c];
+      if (mean) acc = acc / (float)(seg_start[s + 1] - seg_start[s]);
+      out[s * d + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DynamicMeanVFE.forward, pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:51-76.
+// Returns the number of voxels; feat [*, ncol-1], coords [*,4] (b,z,y,x), inv[n] (-1 dropped).
+int64_t orc_dynamic_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                             const float* voxel3, const int32_t* grid3, float* feat,
+                             int32_t* coords, int64_t* inv) {
+  int64_t gx = grid3[0], gy = grid3[1], gz = grid3[2];
+  std::vector<int64_t> key(n);
+  std::vector<int32_t> keep;
+  for (int64_t i = 0; i < n; ++i) {
+    const float* p = pts + i * ncol;
+    int c[3];
+    bool ok = true;
+    for (int d = 0; d < 3; ++d) {
+      c[d] = (int)std::floor((p[1 + d] - range6[d]) / voxel3[d]);
+      if (c[d] < 0 || c[d] >= grid3[d]) ok = false;
+    }
+    key[i] = -1;
+    if (ok) {
+      key[i] = (int64_t)(int)p[0] * gx * gy * gz + (int64_t)c[0] * gy * gz + (int64_t)c[1] * gz + c[2];
+      keep.push_back((int32_t)i);
+    }
+    if (inv) inv[i] = -1;
+  }
+  std::stable_sort(keep.begin(), keep.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  int64_t v = 0;
+  size_t i = 0;
+  int d = ncol - 1;
+  while (i < keep.size()) {
+    size_t j = i;
+    while (j < keep.size() && key[keep[j]] == key[keep[i]]) ++j;
+    for (int c = 0; c < d; ++c) {
+      float acc = 0.f;
+      for (size_t q = i; q < j; ++q) acc = acc + pts[(int64_t)keep[q] * ncol + 1 + c];
+      feat[v * d + c] = acc / (float)(j - i);
+    }
+    int64_t k = key[keep[i]];
+    int64_t xyz = gx * gy * gz, yz = gy * gz;
+    coords[v * 4 + 0] = (int32_t)(k / xyz);
+    coords[v * 4 + 3] = (int32_t)((k % xyz) / yz);
+    coords[v * 4 + 2] = (int32_t)((k % yz) / gz);
+    coords[v * 4 + 1] = (int32_t)(k % gz);
+    if (inv) for (size_t q = i; q < j; ++q) inv[keep[q]] = v;
+    ++v;
+    i = j;
+  }
+  return v;
+}
+
+// points_to_voxel_3d_np, pcdet/ops/spconv/include/spconv/point2voxel.h:33-92 (serial scan,
+// first-come voxel ids, max_points per voxel, max_voxels). The dense coor_to_voxelidx grid of the
+// reference is a hash map here. voxels/coords/num must be zero-initialised by the caller.
+int64_t orc_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                          const float* voxel3, int max_points, int max_voxels, float* voxels,
+                          int32_t* coords, int32_t* num) {
+  int grid[3];
+  for (int d = 0; d < 3; ++d) grid[d] = (int)std::round((range6[3 + d] - range6[d]) / voxel3[d]);
+  std::unordered_map<int64_t, int> cell2vox;
+  int voxel_num = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int coor[3];
+    bool failed = false;
+    for (int j = 0; j < 3; ++j) {
+      int c = (int)std::floor((pts[i * ncol + j] - range6[j]) / voxel3[j]);
+      if (c < 0 || c >= grid[j]) { failed = true; break; }
+      coor[2 - j] = c;
+    }
+    if (failed) continue;
+    int64_t key = ((int64_t)coor[0] * grid[1] + coor[1]) * grid[0] + coor[2];
+    auto it = cell2vox.find(key);
+    int voxelidx;
+    if (it == cell2vox.end()) {
+      voxelidx = voxel_num;
+      if (voxel_num >= max_voxels) continue;
+      voxel_num += 1;
+      cell2vox.emplace(key, voxelidx);
+      for (int k = 0; k < 3; ++k) coords[voxelidx * 3 + k] = coor[k];
+    } else {
+      voxelidx = it->second;
+    }
+    int cnt = num[voxelidx];
+    if (cnt < max_points) {
+      for (int k = 0; k < ncol; ++k) voxels[((int64_t)voxelidx * max_points + cnt) * ncol + k] = pts[i * ncol + k];
+      num[voxelidx] += 1;
+    }
+  }
+  return voxel_num;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rulebook. getValidOutPos (geometry.h:25-85) restated: for one input position enumerate output
+// positions from `uppers` downward, last dim fastest; offset = kernel offset id.
+static int valid_out_pos(const int* in, const int* ks, const int* st, const int* pd, const int* dl,
+                         const int* oshape, int* out /* [kv][4] */) {
+  int lowers[3], uppers[3], counter[3], csize[3];
+  int npts = 1, cnt = 0;
+  for (int i = 0; i < 3; ++i) {
+    lowers[i] = (in[i] - (ks[i] - 1) * dl[i] - 1 + st[i] + pd[i]) / st[i];
+    uppers[i] = (in[i] + pd[i]) / st[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    csize[i] = (uppers[i] - lowers[i]) / dl[i] + 1;
+    npts *= csize[i];
+    counter[i] = 0;
+  }
+  for (int i = 0; i < npts; ++i) {
+    bool valid = true;
+    int m = 1, offset = 0;
+    for (int j = 2; j >= 0; --j) {
+      int val = uppers[j] - counter[j] * dl[j];
+      out[cnt * 4 + j] = val;
+      if (val < 0 || val > oshape[j] - 1) valid = false;
+      offset += m * (in[j] - val * st[j] + pd[j]) / dl[j];
+      m *= ks[j];
+    }
+    out[cnt * 4 + 3] = offset;
+    if (valid) ++cnt;
+    counter[2] += 1;
+    for (int c = 2; c >= 0; --c)
+      if (counter[c] == csize[c] && c > 0) { counter[c - 1] += 1; counter[c] = 0; }
+  }
+  return cnt;
+}
+
+// getIndicePairsSubM (geometry.h:248-297) / getIndicePairsConv (geometry.h:145-194) with the
+// parameter handling of getIndicePair (spconv_ops.h:73-85). pairs [KV,2,V] pre-filled with -1,
+// num [KV] zeroed here. Returns the number of output voxels; out_ids [*,4] for conv.
+int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_shape3,
+                             const int* ksize3, const int* stride3, const int* pad3,
+                             const int* dil3, int subm, int32_t* out_ids, int32_t* pairs,
+                             int32_t* num) {
+  int ks[3], st[3], pd[3], dl[3];
+  int kv = 1;
+  for (int d = 0; d < 3; ++d) {
+    ks[d] = ksize3[d];
+    dl[d] = dil3[d];
+    st[d] = subm ? 1 : stride3[d];
+    pd[d] = subm ? ksize3[d] / 2 : pad3[d];
+    kv *= ks[d];
+  }
+  for (int64_t i = 0; i < (int64_t)kv * 2 * V; ++i) pairs[i] = -1;
+  for (int k = 0; k < kv; ++k) num[k] = 0;
+  int64_t vol = (int64_t)out_shape3[0] * out_shape3[1] * out_shape3[2];
+  std::unordered_map<int64_t, int32_t> grid;
+  grid.reserve((size_t)V * 2);
+  std::vector<int> vp((size_t)kv * 4);
+  auto flat = [&](const int* p, int b) {
+    return ((int64_t)p[0] * out_shape3[1] + p[1]) * out_shape3[2] + p[2] + vol * b;
+  };
+  if (subm) {
+    for (int64_t j = 0; j < V; ++j) grid[flat(indices + j * 4 + 1, indices[j * 4])] = (int32_t)j;
+    for (int64_t j = 0; j < V; ++j) {
+      int cnt = valid_out_pos(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data());
+      for (int i = 0; i < cnt; ++i) {
+        const int* p = vp.data() + i * 4;
+        auto it = grid.find(flat(p, indices[j * 4]));
+        if (it != grid.end()) {
+          int off = p[3];
+          pairs[((int64_t)off * 2 + 0) * V + num[off]] = (int32_t)j;
+          pairs[((int64_t)off * 2 + 1) * V + num[off]++] = it->second;
+        }
+      }
+    }
+    return V;
+  }
+  int32_t num_act = 0;
+  for (int64_t j = 0; j < V; ++j) {
+    int b = indices[j * 4];
+    int cnt = valid_out_pos(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data());
+    for (int i = 0; i < cnt; ++i) {
+      const int* p = vp.data() + i * 4;
+      int off = p[3];
+      int64_t idx = flat(p, b);
+      auto it = grid.find(idx);
+      if (it == grid.end()) {
+        out_ids[num_act * 4 + 0] = b;
+        for (int k = 0; k < 3; ++k) out_ids[num_act * 4 + 1 + k] = p[k];
+        it = grid.emplace(idx, num_act++).first;
+      }
+      pairs[((int64_t)off * 2 + 0) * V + num[off]] = (int32_t)j;
+      pairs[((int64_t)off * 2 + 1) * V + num[off]++] = it->second;
+    }
+  }
+  return num_act;
+}
+
+// indiceConv<float> (spconv_ops.h:260-361) with the CPU gather / scatter-add functors
+// (src/reordering.cc:20-49): subM centre = argmax(num) as a dense feat.W[centre], then per offset
+// gather -> GEMM (fresh dot product per row) -> scatter-add. fp32 throughout.
+void orc_indice_conv_f32(const float* feat, int64_t num_in, int cin, const float* W, int kv,
+                         int cout, const int32_t* pairs, int64_t pair_stride, const int32_t* num,
+                         int64_t num_out, int inverse, int subm, float* out) {
+  (void)num_in;
+  for (int64_t i = 0; i < num_out * cout; ++i) out[i] = 0.f;
+  int centre = -1;
+  if (subm) {
+    centre = (int)(std::max_element(num, num + kv) - num);
+    for (int64_t r = 0; r < num_out; ++r)
+      for (int co = 0; co < cout; ++co) {
+        float acc = 0.f;
+        for (int c = 0; c < cin; ++c) acc = acc + feat[r * cin + c] * W[((int64_t)centre * cin + c) * cout + co];
+        out[r * cout + co] = acc;
+      }
+  }
+  std::vector<float> buf(cout);
+  for (int k = 0; k < kv; ++k) {
+    int nhot = num[k];
+    if (nhot <= 0 || (subm && k == centre)) continue;
+    const int32_t* pin = pairs + ((int64_t)k * 2 + (inverse ? 1 : 0)) * pair_stride;
+    const int32_t* pout = pairs + ((int64_t)k * 2 + (inverse ? 0 : 1)) * pair_stride;
+    for (int p = 0; p < nhot; ++p) {
+      const float* f = feat + (int64_t)pin[p] * cin;
+      for (int co = 0; co < cout; ++co) {
+        float acc = 0.f;
+        for (int c = 0; c < cin; ++c) acc = acc + f[c] * W[((int64_t)k * cin + c) * cout + co];
+        buf[co] = acc;
+      }
+      float* o = out + (int64_t)pout[p] * cout;
+      for (int co = 0; co < cout; ++co) o[co] += buf[co];
+    }
+  }
+}
+
+}  // extern "C"

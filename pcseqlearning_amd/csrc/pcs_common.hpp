@@ -1,0 +1,109 @@
+// Shared device/host helpers for the gfx950 kernels behind the C-ABI in include/pcs.h.
+// Everything here is written for wave64 / CDNA4 only.
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <cstddef>
+#include <hip/hip_runtime.h>
+
+#define PCS_OK 0
+#define PCS_ERR_ARG (-1)       // bad argument (null pointer, negative size, unsupported shape)
+#define PCS_ERR_WORKSPACE (-2) // caller-provided workspace too small
+#define PCS_ERR_HIP (-3)       // a HIP runtime call failed (launch error, rocPRIM error)
+#define PCS_ERR_RANGE (-4)     // a size exceeds what the kernels index with (e.g. E >= 2^31)
+
+#define PCS_CHECK_HIP(expr)                      \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) return PCS_ERR_HIP;    \
+  } while (0)
+
+#define PCS_LAUNCH_CHECK()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return PCS_ERR_HIP; \
+  } while (0)
+
+namespace pcs {
+
+constexpr int kBlock = 256;
+
+// Memory-bound grid sizing: cap at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int grid_for(int64_t n, int block = kBlock) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace; never allocates device memory itself.
+struct Arena {
+  char* base;
+  size_t cap;
+  size_t off;
+  bool dry;  // size-query mode: only counts
+  Arena(void* ws, size_t bytes) : base((char*)ws), cap(bytes), off(0), dry(ws == nullptr) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T));
+    size_t at = off;
+    off += bytes;
+    if (dry) return nullptr;
+    if (off > cap) return nullptr;
+    return (T*)(base + at);
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+// ---- prims implemented in pcs_prims.hip (the only TU that includes rocPRIM) ----
+size_t sort_pairs_u64_temp_bytes(size_t n);
+int sort_pairs_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout,
+                   const int32_t* vin, int32_t* vout, size_t n, int begin_bit, int end_bit,
+                   hipStream_t s);
+size_t sort_pairs_u32_temp_bytes(size_t n);
+int sort_pairs_u32(void* tmp, size_t tmp_bytes, const uint32_t* kin, uint32_t* kout,
+                   const int32_t* vin, int32_t* vout, size_t n, int begin_bit, int end_bit,
+                   hipStream_t s);
+size_t scan_i32_temp_bytes(size_t n);
+int exclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n,
+                       hipStream_t s);
+int inclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n,
+                       hipStream_t s);
+size_t scan_i64_temp_bytes(size_t n);
+int exclusive_scan_i64(void* tmp, size_t tmp_bytes, const int64_t* in, int64_t* out, size_t n,
+                       hipStream_t s);
+
+// 64-lane butterfly reductions (all lanes end with the result).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// 64-bit mix used by the open-addressing coordinate tables (rulebook, cell lookup).
+__device__ __forceinline__ uint32_t mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+}  // namespace pcs

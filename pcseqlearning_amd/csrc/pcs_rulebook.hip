@@ -1,0 +1,348 @@
+// Sparse-conv rulebook (spconv "indice pairs") build for gfx950.
+//
+// Restates the semantics of the reference CPU builders
+//   pcdet/ops/spconv/include/spconv/geometry.h:25-85   (getValidOutPos: kernel-offset numbering)
+//   pcdet/ops/spconv/include/spconv/geometry.h:145-194 (getIndicePairsConv: first-encounter out ids)
+//   pcdet/ops/spconv/include/spconv/geometry.h:248-297 (getIndicePairsSubM)
+//   pcdet/ops/spconv/include/spconv/spconv_ops.h:27-141 (getIndicePair: shapes, subM forces s=1,p=k/2)
+// with a different data structure: instead of the dense `gridOut[batch*volume]` (371 MB memset at
+// the Waymo grid) an open-addressing coordinate table of 2x the active count lives in the caller's
+// workspace, and pairs are emitted by count -> scan -> fill so that, per kernel offset, pairs are in
+// ascending input index -- the reference CPU functor order -- by construction (no atomics on the
+// pair slots, so the rulebook is run-to-run deterministic, unlike indice.cu.h's atomicAdd slots).
+//
+// Pair (j, k): out position o_d = (in_d + pad_d - k_d*dil_d) / stride_d when divisible and in
+// range; kernel offset id k = (kz*KY + ky)*KX + kx. For a fixed input the reference enumerates
+// valid outputs in ascending k, so the first-encounter order of output voxels is the order of
+// min(j*KV + k) over the emissions that hit them.
+#include "pcs_common.hpp"
+
+namespace pcs {
+
+constexpr uint64_t kEmptyKey = ~0ULL;
+
+struct ConvGeom {
+  int ks[3], st[3], pd[3], dl[3];
+  int in_shape[3], out_shape[3];
+  int kv;
+};
+
+__device__ __forceinline__ uint32_t table_find(const uint64_t* __restrict__ keys, uint32_t hmask,
+                                               uint64_t key) {
+  uint32_t slot = mix64(key) & hmask;
+  while (true) {
+    uint64_t k = keys[slot];
+    if (k == key) return slot;
+    if (k == kEmptyKey) return 0xFFFFFFFFu;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+__device__ __forceinline__ uint32_t table_insert(uint64_t* __restrict__ keys, uint32_t hmask,
+                                                 uint64_t key) {
+  uint32_t slot = mix64(key) & hmask;
+  while (true) {
+    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
+                              (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return slot;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+// out position key of input voxel `c` (b,z,y,x) under kernel offset k, or kEmptyKey if invalid
+__device__ __forceinline__ uint64_t out_key(const ConvGeom& g, int4 c, int k) {
+  int kx = k % g.ks[2];
+  int t = k / g.ks[2];
+  int ky = t % g.ks[1];
+  int kz = t / g.ks[1];
+  int kk[3] = {kz, ky, kx};
+  int in[3] = {c.y, c.z, c.w};
+  int o[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int num = in[d] + g.pd[d] - kk[d] * g.dl[d];
+    if (num < 0) return kEmptyKey;
+    int q = num / g.st[d];
+    if (q * g.st[d] != num) return kEmptyKey;
+    if (q >= g.out_shape[d]) return kEmptyKey;
+    o[d] = q;
+  }
+  uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  return (uint64_t)c.x * vol + ((uint64_t)o[0] * g.out_shape[1] + o[1]) * g.out_shape[2] + o[2];
+}
+
+// ---- subM: table of the input voxels themselves, value = input index (last writer = max j)
+__global__ void __launch_bounds__(kBlock)
+insert_inputs_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t* __restrict__ keys,
+                     int32_t* __restrict__ vals, uint32_t hmask) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V) return;
+  int4 c = idx[j];
+  uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  uint64_t key = (uint64_t)c.x * vol + ((uint64_t)c.y * g.out_shape[1] + c.z) * g.out_shape[2] + c.w;
+  uint32_t slot = table_insert(keys, hmask, key);
+  atomicMax(&vals[slot], j);
+}
+
+// ---- strided conv P1: every emission claims its output cell with min(j*KV + k)
+__global__ void __launch_bounds__(kBlock)
+insert_outputs_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t* __restrict__ keys,
+                      uint32_t* __restrict__ minseq, uint32_t hmask) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V) return;
+  int4 c = idx[j];
+  for (int k = 0; k < g.kv; ++k) {
+    uint64_t key = out_key(g, c, k);
+    if (key == kEmptyKey) continue;
+    uint32_t slot = table_insert(keys, hmask, key);
+    atomicMin(&minseq[slot], (uint32_t)j * (uint32_t)g.kv + (uint32_t)k);
+  }
+}
+
+// ---- strided conv P2a: list occupied slots (order irrelevant: sorted by minseq afterwards)
+__global__ void __launch_bounds__(kBlock)
+list_outputs_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ minseq,
+                    uint32_t H, uint32_t* __restrict__ lseq, int32_t* __restrict__ lslot,
+                    int32_t* __restrict__ counter) {
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < H; s += gridDim.x * blockDim.x) {
+    if (keys[s] != kEmptyKey) {
+      int p = atomicAdd(counter, 1);
+      lseq[p] = minseq[s];
+      lslot[p] = (int32_t)s;
+    }
+  }
+}
+
+// ---- strided conv P2b: rank r (first-encounter order) -> out coords; slot value <- rank
+__global__ void __launch_bounds__(kBlock)
+assign_outputs_kernel(const int32_t* __restrict__ sslot, const int32_t* __restrict__ counter,
+                      const uint64_t* __restrict__ keys, ConvGeom g, int32_t* __restrict__ vals,
+                      int32_t* __restrict__ out_ids, int64_t* __restrict__ d_num_out) {
+  int U = *counter;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_num_out = U;
+  uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < U; r += gridDim.x * blockDim.x) {
+    int slot = sslot[r];
+    uint64_t key = keys[slot];
+    vals[slot] = r;
+    int b = (int)(key / vol);
+    uint64_t rem = key % vol;
+    int x = (int)(rem % g.out_shape[2]);
+    rem /= g.out_shape[2];
+    int y = (int)(rem % g.out_shape[1]);
+    int z = (int)(rem / g.out_shape[1]);
+    ((int4*)out_ids)[r] = make_int4(b, z, y, x);
+  }
+}
+
+// ---- count: one thread per input voxel, 27-bit hit mask, per-block per-offset counts
+__global__ void __launch_bounds__(kBlock)
+pair_count_kernel(const int4* __restrict__ idx, int V, ConvGeom g,
+                  const uint64_t* __restrict__ keys, uint32_t hmask, uint32_t* __restrict__ masks,
+                  int32_t* __restrict__ blockcnt, int nblocks) {
+  __shared__ int wcnt[kBlock / 64][32];
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t mask = 0;
+  if (j < V) {
+    int4 c = idx[j];
+    for (int k = 0; k < g.kv; ++k) {
+      uint64_t key = out_key(g, c, k);
+      if (key != kEmptyKey && table_find(keys, hmask, key) != 0xFFFFFFFFu) mask |= 1u << k;
+    }
+    masks[j] = mask;
+  }
+  for (int k = 0; k < g.kv; ++k) {
+    unsigned long long b = __ballot((mask >> k) & 1u);
+    if (lane == 0) wcnt[w][k] = __popcll(b);
+  }
+  __syncthreads();
+  if (threadIdx.x < g.kv) {
+    int k = threadIdx.x, sum = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) sum += wcnt[q][k];
+    blockcnt[(int64_t)k * nblocks + blockIdx.x] = sum;
+  }
+}
+
+// ---- fill: position = offset base of (k, block) + rank of this input among the block's hits
+__global__ void __launch_bounds__(kBlock)
+pair_fill_kernel(const int4* __restrict__ idx, int V, ConvGeom g,
+                 const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                 uint32_t hmask, const uint32_t* __restrict__ masks,
+                 const int32_t* __restrict__ blockoff, int nblocks, int32_t* __restrict__ pairs,
+                 int32_t* __restrict__ num) {
+  __shared__ int wcnt[kBlock / 64][32];
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t mask = (j < V) ? masks[j] : 0u;
+  for (int k = 0; k < g.kv; ++k) {
+    unsigned long long b = __ballot((mask >> k) & 1u);
+    if (lane == 0) wcnt[w][k] = __popcll(b);
+  }
+  __syncthreads();
+  int4 c = (j < V) ? idx[j] : make_int4(0, 0, 0, 0);
+  for (int k = 0; k < g.kv; ++k) {
+    unsigned long long b = __ballot((mask >> k) & 1u);
+    if ((mask >> k) & 1u) {
+      int pre = __popcll(b & ((1ULL << lane) - 1ULL));
+      for (int q = 0; q < w; ++q) pre += wcnt[q][k];
+      int64_t kb = (int64_t)k * nblocks;
+      int pos = blockoff[kb + blockIdx.x] - blockoff[kb] + pre;
+      uint32_t slot = table_find(keys, hmask, out_key(g, c, k));
+      pairs[((int64_t)k * 2 + 0) * V + pos] = j;
+      pairs[((int64_t)k * 2 + 1) * V + pos] = vals[slot];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < g.kv) {
+    int k = threadIdx.x;
+    num[k] = blockoff[(int64_t)(k + 1) * nblocks] - blockoff[(int64_t)k * nblocks];
+  }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+static inline uint32_t pow2_at_least(uint64_t x) {
+  uint32_t h = 64;
+  while (h < x) h <<= 1;
+  return h;
+}
+
+struct RulebookPlan {
+  uint32_t H;
+  int64_t cap;  // max distinct outputs (strided conv)
+  uint64_t* keys;
+  int32_t* vals;
+  uint32_t *minseq, *lseq, *lseq_s, *masks;
+  int32_t *lslot, *lslot_s, *counter, *blockcnt, *blockoff;
+  void* tmp;
+  size_t tmp_bytes;
+  int nblocks;
+};
+
+static int64_t emissions_per_input(const int* ks, const int* st) {
+  int64_t e = 1;
+  for (int d = 0; d < 3; ++d) e *= (ks[d] + st[d] - 1) / st[d];
+  return e;
+}
+
+static bool plan_rulebook(Arena& a, int64_t V, int kv, int subm, int64_t cap, RulebookPlan& p) {
+  if (V < 1) V = 1;
+  p.cap = subm ? V : cap;
+  p.H = pow2_at_least(2 * (uint64_t)p.cap);
+  p.nblocks = (int)((V + kBlock - 1) / kBlock);
+  p.keys = a.take<uint64_t>(p.H);
+  p.vals = a.take<int32_t>(p.H);
+  p.masks = a.take<uint32_t>(V);
+  size_t nb = (size_t)kv * p.nblocks + 1;
+  p.blockcnt = a.take<int32_t>(nb);
+  p.blockoff = a.take<int32_t>(nb);
+  size_t t = scan_i32_temp_bytes(nb);
+  if (!subm) {
+    p.minseq = a.take<uint32_t>(p.H);
+    p.lseq = a.take<uint32_t>(p.cap);
+    p.lseq_s = a.take<uint32_t>(p.cap);
+    p.lslot = a.take<int32_t>(p.cap);
+    p.lslot_s = a.take<int32_t>(p.cap);
+    p.counter = a.take<int32_t>(1);
+    size_t t2 = sort_pairs_u32_temp_bytes(p.cap);
+    if (t2 > t) t = t2;
+  }
+  p.tmp_bytes = t;
+  p.tmp = a.take<char>(t);
+  return a.ok();
+}
+
+}  // namespace pcs
+
+using namespace pcs;
+
+extern "C" {
+
+// upper bound on the number of output voxels of a strided conv over V inputs (rows to allocate
+// for out_ids); for subM the outputs are the inputs.
+int64_t pcs_indice_pairs_out_capacity(int64_t V, const int* ksize3, const int* stride3, int subm) {
+  if (subm) return V;
+  return V * emissions_per_input(ksize3, stride3);
+}
+
+size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const int* stride3,
+                                            int subm) {
+  Arena a(nullptr, 0);
+  RulebookPlan p;
+  int kv = ksize3[0] * ksize3[1] * ksize3[2];
+  plan_rulebook(a, V, kv, subm, pcs_indice_pairs_out_capacity(V > 0 ? V : 1, ksize3, stride3, subm), p);
+  return a.off;
+}
+
+int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
+                         const int* spatial_shape3, const int* ksize3, const int* stride3,
+                         const int* pad3, const int* dil3, int subm, int transpose,
+                         int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
+                         int64_t* d_num_out, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!indices || !out_shape3 || !spatial_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 ||
+      !pairs || !num || !d_num_out || !ws || V < 0 || batch < 1)
+    return PCS_ERR_ARG;
+  if (transpose) return PCS_ERR_ARG;  // deconv rulebooks: SURVEY 8(f) "next", not built yet
+  ConvGeom g;
+  g.kv = 1;
+  for (int d = 0; d < 3; ++d) {
+    g.ks[d] = ksize3[d];
+    g.dl[d] = dil3[d];
+    g.st[d] = subm ? 1 : stride3[d];
+    g.pd[d] = subm ? ksize3[d] / 2 : pad3[d];
+    g.in_shape[d] = spatial_shape3[d];
+    g.out_shape[d] = out_shape3[d];
+    if (g.ks[d] < 1 || g.st[d] < 1 || g.dl[d] < 1) return PCS_ERR_ARG;
+    if (g.st[d] != 1 && g.dl[d] != 1) return PCS_ERR_ARG;  // as ops.py:70-71
+    g.kv *= g.ks[d];
+  }
+  if (g.kv > 32) return PCS_ERR_ARG;  // hit masks are 32-bit; the path uses 3x3x3 and 3x1x1
+  if (V >= (1LL << 31) / g.kv) return PCS_ERR_RANGE;
+  uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  if (vol * (uint64_t)batch >= (1ULL << 62)) return PCS_ERR_RANGE;
+  PCS_CHECK_HIP(hipMemsetAsync(pairs, 0xFF, (size_t)g.kv * 2 * (V > 0 ? V : 0) * sizeof(int32_t), s));
+  PCS_CHECK_HIP(hipMemsetAsync(num, 0, g.kv * sizeof(int32_t), s));
+  if (V == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s)); return PCS_OK; }
+  int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, subm);
+  if (!subm && (!out_ids || out_cap < cap)) return PCS_ERR_ARG;
+  Arena a(ws, ws_bytes);
+  RulebookPlan p;
+  if (!plan_rulebook(a, V, g.kv, subm, cap, p)) return PCS_ERR_WORKSPACE;
+  uint32_t hmask = p.H - 1;
+  const int4* idx = (const int4*)indices;
+  int nb = p.nblocks;
+  PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
+  PCS_CHECK_HIP(hipMemsetAsync(p.vals, 0xFF, (size_t)p.H * sizeof(int32_t), s));
+  if (subm) {
+    insert_inputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask);
+    int64_t v64 = V;
+    PCS_CHECK_HIP(hipMemcpyAsync(d_num_out, &v64, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  } else {
+    PCS_CHECK_HIP(hipMemsetAsync(p.minseq, 0xFF, (size_t)p.H * sizeof(uint32_t), s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.counter, 0, sizeof(int32_t), s));
+    fill_u32_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lseq, p.cap, 0xFFFFFFFFu);
+    insert_outputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.minseq, hmask);
+    list_outputs_kernel<<<grid_for(p.H), kBlock, 0, s>>>(p.keys, p.minseq, p.H, p.lseq, p.lslot,
+                                                         p.counter);
+    int rc = sort_pairs_u32(p.tmp, p.tmp_bytes, p.lseq, p.lseq_s, p.lslot, p.lslot_s, p.cap, 0, 32, s);
+    if (rc) return rc;
+    assign_outputs_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lslot_s, p.counter, p.keys, g,
+                                                             p.vals, out_ids, d_num_out);
+  }
+  pair_count_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, hmask, p.masks, p.blockcnt, nb);
+  size_t nscan = (size_t)g.kv * nb + 1;
+  PCS_CHECK_HIP(hipMemsetAsync(p.blockcnt + (nscan - 1), 0, sizeof(int32_t), s));
+  int rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.blockcnt, p.blockoff, nscan, s);
+  if (rc) return rc;
+  pair_fill_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask, p.masks,
+                                         p.blockoff, nb, pairs, num);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI (include/pcs.h): torch owns the memory and the stream,
+every computation below runs in the hand-written HIP kernels of csrc/. No CPU fallback."""
+import torch
+
+from . import lib as L
+
+
+def _dev_scalar(device):
+    return torch.empty(1, dtype=torch.int64, device=device)
+
+
+# ---------------------------------------------------------------- grid sampling primitives
+def minmax4(points):
+    """[n,4] f32 -> [8] f32 (min0..3, max0..3), on device."""
+    L.require_gpu(points, "minmax4")
+    lib = L.load()
+    out = torch.empty(8, dtype=torch.float32, device=points.device)
+    L.check(lib.pcs_minmax4_f32(L.ptr(points), L.i64(points.shape[0]), L.ptr(out), L.stream()),
+            "pcs_minmax4_f32")
+    return out
+
+
+def grid_cluster_ids(points, size4, margin0=0.5, bounds8=None):
+    """torch_cluster.grid_cluster as GridSampling3D calls it (grid_sampling.py:32-37)."""
+    L.require_gpu(points, "grid_cluster_ids")
+    lib = L.load()
+    points = points.contiguous()
+    if bounds8 is None:
+        bounds8 = minmax4(points)
+    ids = torch.empty(points.shape[0], dtype=torch.int64, device=points.device)
+    L.check(lib.pcs_grid_cluster_ids(L.ptr(points), L.i64(points.shape[0]), L.ptr(bounds8),
+                                     L.host_floats(size4), L.f32(margin0), L.ptr(ids), L.stream()),
+            "pcs_grid_cluster_ids")
+    return ids
+
+
+class Segments:
+    """Result of a sorted unique: `order` (original indices sorted by (id, index)), `seg_start`
+    ([v+1] boundaries into order), `inv` ([n] id rank), `uniq` ([v]), `num` (v, host int)."""
+    __slots__ = ("order", "seg_start", "inv", "uniq", "num")
+
+
+def unique_i64(ids, key_bits=64, want_uniq=True, want_inv=True):
+    """torch.unique(ids, sorted=True, return_inverse=True) + segment structure. One host sync
+    (the unique count), as torch.unique has."""
+    L.require_gpu(ids, "unique_i64")
+    lib = L.load()
+    n = ids.shape[0]
+    dev = ids.device
+    seg = Segments()
+    uniq = torch.empty(n, dtype=torch.int64, device=dev) if want_uniq else None
+    inv = torch.empty(n, dtype=torch.int64, device=dev) if want_inv else None
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_unique_i64_workspace_bytes(L.i64(n)), dev)
+    L.check(lib.pcs_unique_i64(L.ptr(ids.contiguous()), L.i64(n), L.i32(key_bits), L.ptr(uniq),
+                               L.ptr(inv), L.ptr(order), L.ptr(seg_start), L.ptr(d_num), L.ptr(ws),
+                               L.i64(ws.numel()), L.stream()), "pcs_unique_i64")
+    v = int(d_num.item())
+    seg.num = v
+    seg.order = order
+    seg.seg_start = seg_start[:v + 1]
+    seg.inv = inv
+    seg.uniq = uniq[:v] if want_uniq else None
+    return seg
+
+
+def segment_reduce(data, seg, mean=True):
+    """scatter(data, inv, reduce='mean'/'sum') in ascending original index. data [n] or [n,d]."""
+    lib = L.load()
+    squeeze = data.dim() == 1
+    d2 = data.reshape(data.shape[0], -1).float().contiguous()
+    out = torch.empty(seg.num, d2.shape[1], dtype=torch.float32, device=data.device)
+    L.check(lib.pcs_segment_reduce_f32(L.ptr(d2), L.i32(d2.shape[1]), L.ptr(seg.order),
+                                       L.ptr(seg.seg_start), L.i64(seg.num), L.i32(int(mean)),
+                                       L.ptr(out), L.stream()), "pcs_segment_reduce_f32")
+    return out[:, 0] if squeeze else out
+
+
+def segment_pick(seg, last=True):
+    lib = L.load()
+    out = torch.empty(seg.num, dtype=torch.int64, device=seg.order.device)
+    L.check(lib.pcs_segment_pick(L.ptr(seg.order), L.ptr(seg.seg_start), L.i64(seg.num),
+                                 L.i32(int(last)), L.ptr(out), L.stream()), "pcs_segment_pick")
+    return out
+
+
+# ---------------------------------------------------------------- voxelizers
+def dynamic_voxelize(points, point_cloud_range, voxel_size, grid_size):
+    """DynamicMeanVFE (dynamic_mean_vfe.py:51-76). points [n, 1+3+C] (batch, x, y, z, feat).
+    Returns (voxel_features [V,3+C], voxel_coords [V,4] int32 (b,z,y,x), inv [n] int64)."""
+    L.require_gpu(points, "dynamic_voxelize")
+    lib = L.load()
+    points = points.float().contiguous()
+    n, ncol = points.shape
+    dev = points.device
+    feat = torch.empty(n, ncol - 1, dtype=torch.float32, device=dev)
+    coords = torch.empty(n, 4, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, dtype=torch.int64, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_dynamic_voxelize_workspace_bytes(L.i64(n)), dev)
+    L.check(lib.pcs_dynamic_voxelize(L.ptr(points), L.i64(n), L.i32(ncol),
+                                     L.host_floats(point_cloud_range), L.host_floats(voxel_size),
+                                     L.host_ints(grid_size), L.ptr(feat), L.ptr(coords),
+                                     L.ptr(inv), L.ptr(d_num), L.ptr(ws), L.i64(ws.numel()),
+                                     L.stream()), "pcs_dynamic_voxelize")
+    v = int(d_num.item())
+    return feat[:v], coords[:v], inv
+
+
+def hard_voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels):
+    """VoxelGeneratorV2 / points_to_voxel_3d_np (point2voxel.h:33-92). points [n, 3+C].
+    Returns (voxels [V,max_points,3+C], coords [V,3] int32 (z,y,x), num_points [V] int32)."""
+    L.require_gpu(points, "hard_voxelize")
+    lib = L.load()
+    points = points.float().contiguous()
+    n, ncol = points.shape
+    dev = points.device
+    voxels = torch.empty(max_voxels, max_points, ncol, dtype=torch.float32, device=dev)
+    coords = torch.empty(max_voxels, 3, dtype=torch.int32, device=dev)
+    num = torch.empty(max_voxels, dtype=torch.int32, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_hard_voxelize_workspace_bytes(L.i64(n)), dev)
+    L.check(lib.pcs_hard_voxelize(L.ptr(points), L.i64(n), L.i32(ncol),
+                                  L.host_floats(point_cloud_range), L.host_floats(voxel_size),
+                                  L.i32(max_points), L.i32(max_voxels), L.ptr(voxels),
+                                  L.ptr(coords), L.ptr(num), L.ptr(d_num), L.ptr(ws),
+                                  L.i64(ws.numel()), L.stream()), "pcs_hard_voxelize")
+    v = int(d_num.item())
+    return voxels[:v], coords[:v], num[:v]
+
+
+# ---------------------------------------------------------------- rulebook + conv
+def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding,
+                     dilation, subm, transpose=False):
+    """sparse_conv_ext.get_indice_pairs_3d. Returns (out_ids [V',4] int32, pairs [KV,2,V] int32,
+    num [KV] int32)."""
+    L.require_gpu(indices, "get_indice_pairs")
+    lib = L.load()
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    V = indices.shape[0]
+    dev = indices.device
+    kv = int(ksize[0] * ksize[1] * ksize[2])
+    ks, st = L.host_ints(ksize), L.host_ints(stride)
+    cap = int(lib.pcs_indice_pairs_out_capacity(L.i64(V), ks, st, L.i32(int(subm))))
+    pairs = torch.empty(kv, 2, V, dtype=torch.int32, device=dev)
+    num = torch.empty(kv, dtype=torch.int32, device=dev)
+    out_ids = None if subm else torch.empty(max(cap, 1), 4, dtype=torch.int32, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_get_indice_pairs_workspace_bytes(L.i64(V), ks, st, L.i32(int(subm))), dev)
+    L.check(lib.pcs_get_indice_pairs(L.ptr(indices), L.i64(V), L.i32(batch_size),
+                                     L.host_ints(out_shape), L.host_ints(spatial_shape), ks, st,
+                                     L.host_ints(padding), L.host_ints(dilation), L.i32(int(subm)),
+                                     L.i32(int(transpose)), L.ptr(out_ids), L.i64(cap),
+                                     L.ptr(pairs), L.ptr(num), L.ptr(d_num), L.ptr(ws),
+                                     L.i64(ws.numel()), L.stream()), "pcs_get_indice_pairs")
+    if subm:
+        return indices, pairs, num
+    return out_ids[:int(d_num.item())], pairs, num
+
+
+def build_neighbor_table(pairs, num, num_out, inverse=False):
+    lib = L.load()
+    kv = pairs.shape[0]
+    table = torch.empty(max(num_out, 1), kv, dtype=torch.int32, device=pairs.device)
+    L.check(lib.pcs_build_neighbor_table(L.ptr(pairs), L.i64(pairs.shape[2]), L.ptr(num),
+                                         L.i32(kv), L.i32(int(inverse)), L.i64(num_out),
+                                         L.ptr(table), L.stream()), "pcs_build_neighbor_table")
+    return table[:num_out]
+
+
+def indice_conv_table(features, filters, table, num_out, subm, bias=None, scale=None, shift=None,
+                      relu=False):
+    """out = epilogue(sum_k feat[table[:,k]] @ W[k]); filters [..., Cin, Cout]."""
+    L.require_gpu(features, "indice_conv")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = table.shape[1]
+    W = filters.reshape(kv, cin, cout).float().contiguous()
+    features = features.float().contiguous()
+    out = torch.empty(num_out, cout, dtype=torch.float32, device=features.device)
+    centre = kv // 2 if (subm and kv % 2 == 1) else -1
+    L.check(lib.pcs_indice_conv_table_f32(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv),
+                                          L.i32(cout), L.i32(centre), L.ptr(table.contiguous()),
+                                          L.i64(num_out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+                                          L.i32(int(relu)), L.ptr(out), L.stream()),
+            "pcs_indice_conv_table_f32")
+    return out
+
+
+def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=False):
+    """sparse_conv_ext.indice_conv_fp32 (spconv_ops.h:260-361)."""
+    L.require_gpu(features, "indice_conv")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = pairs.shape[0]
+    W = filters.reshape(kv, cin, cout).float().contiguous()
+    features = features.float().contiguous()
+    out = torch.empty(num_out, cout, dtype=torch.float32, device=features.device)
+    ws = L.workspace(lib.pcs_neighbor_table_bytes(L.i64(num_out), L.i32(kv)), features.device)
+    L.check(lib.pcs_indice_conv_f32(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                    L.ptr(pairs.contiguous()), L.i64(pairs.shape[2]), L.ptr(num),
+                                    L.i64(num_out), L.i32(int(inverse)), L.i32(int(subm)),
+                                    L.ptr(out), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_indice_conv_f32")
+    return out

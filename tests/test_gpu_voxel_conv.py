@@ -1,0 +1,171 @@
+"""Parity of the HIP voxelizers / rulebook / sparse conv (through the C ABI) against the CPU
+oracle and the golden vectors. Integer outputs bit-exact; conv within 1e-5 (fp32 accumulation
+order differs from a BLAS GEMM, the tolerance the reference itself would see)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pcseqlearning_amd import ops, synthetic  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _rulebook_gpu(idx, batch, out_shape, shape, ks, st, pd, dl, subm):
+    out_ids, pairs, num = ops.get_indice_pairs(dev(idx), batch, list(out_shape), list(shape),
+                                               list(ks), list(st), list(pd), list(dl), subm)
+    return out_ids.cpu().numpy(), pairs.cpu().numpy(), num.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "rulebook_*.npz"))))
+def test_rulebook_golden(path):
+    g = np.load(path)
+    out_ids, pairs, num = _rulebook_gpu(g["indices"], 2, g["out_shape"], g["spatial_shape"],
+                                        g["ksize"], g["stride"], g["padding"], g["dilation"],
+                                        bool(g["subm"]))
+    np.testing.assert_array_equal(num, g["num"])
+    np.testing.assert_array_equal(out_ids, g["out_ids"])
+    np.testing.assert_array_equal(pairs, g["pairs"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hardvox_*.npz"))))
+def test_hard_voxelizer_golden(path):
+    g = np.load(path)
+    voxels, coords, num = ops.hard_voxelize(dev(g["points"]), g["pc_range"], g["voxel_size"],
+                                            int(g["max_points"]), int(g["max_voxels"]))
+    np.testing.assert_array_equal(coords.cpu().numpy(), g["coords"])
+    np.testing.assert_array_equal(num.cpu().numpy(), g["num"])
+    np.testing.assert_array_equal(voxels.cpu().numpy(), g["voxels"])
+
+
+def test_hard_voxelizer_edge_cases(oracle):
+    rngs = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    vs = np.array([0.5, 0.5, 0.5], np.float32)
+    # every point out of range -> zero voxels; single point; duplicates
+    for pts in (np.full((10, 4), 5.0, np.float32), np.zeros((1, 4), np.float32),
+                np.zeros((9, 4), np.float32)):
+        v, c, n = ops.hard_voxelize(dev(pts), rngs, vs, 4, 10)
+        ov, oc, on = oracle.hard_voxelize(pts, rngs, vs, 4, 10)
+        np.testing.assert_array_equal(v.cpu().numpy(), ov)
+        np.testing.assert_array_equal(c.cpu().numpy(), oc)
+        np.testing.assert_array_equal(n.cpu().numpy(), on)
+
+
+def test_grid_sampling_vs_oracle(oracle):
+    rng = np.random.default_rng(5)
+    for n, gs in ((1, [0.4, 0.4, 0.6]), (777, [0.2, 0.2, 0.3]), (200000, [0.08, 0.08, 0.08])):
+        pts = np.concatenate([rng.integers(0, 4, (n, 1)).astype(np.float32),
+                              rng.uniform(-30, 30, (n, 3)).astype(np.float32)], axis=1)
+        o_means, o_inv, o_order, o_seg = oracle.grid_sample(pts, gs)
+        p = dev(pts)
+        ids = ops.grid_cluster_ids(p, [1.0] + gs, 0.5)
+        o_ids, _ = oracle.grid_cluster_ids(pts, [1.0] + gs, 0.5)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_ids)
+        seg = ops.unique_i64(ids)
+        assert seg.num == o_means.shape[0]
+        np.testing.assert_array_equal(seg.inv.cpu().numpy(), o_inv)
+        np.testing.assert_array_equal(seg.order.cpu().numpy(), o_order)
+        np.testing.assert_array_equal(seg.seg_start.cpu().numpy(), o_seg)
+        means = ops.segment_reduce(p, seg, mean=True)
+        np.testing.assert_array_equal(means.cpu().numpy(), o_means)  # same summation order
+        last = ops.segment_pick(seg, last=True).cpu().numpy()
+        np.testing.assert_array_equal(last, o_order[o_seg[1:] - 1])
+
+
+def test_dynamic_voxelize_vs_oracle(oracle):
+    pts = synthetic.gen_voxel_frame(1, 50000)
+    pts[:100, 1] = 1000.0  # out of range rows
+    feat, coords, inv = ops.dynamic_voxelize(dev(pts), synthetic.PC_RANGE, synthetic.VOXEL_SIZE,
+                                             synthetic.GRID_SIZE)
+    o_feat, o_coords, o_inv = oracle.dynamic_voxelize(pts, synthetic.PC_RANGE,
+                                                      synthetic.VOXEL_SIZE, synthetic.GRID_SIZE)
+    np.testing.assert_array_equal(coords.cpu().numpy(), o_coords)
+    np.testing.assert_array_equal(inv.cpu().numpy(), o_inv)
+    np.testing.assert_array_equal(feat.cpu().numpy(), o_feat)
+
+
+BACKBONE_LAYERS = [  # (ksize, stride, padding, subm) as spconv_backbone.py:55-95
+    ([3, 3, 3], [1, 1, 1], [1, 1, 1], True),
+    ([3, 3, 3], [2, 2, 2], [1, 1, 1], False),
+    ([3, 3, 3], [2, 2, 2], [0, 1, 1], False),
+    ([3, 1, 1], [2, 1, 1], [0, 0, 0], False),
+]
+
+
+def test_rulebook_and_conv_full_frame(oracle):
+    """BASELINE config 2: one 160k-pt frame -> dynamic voxelization -> rulebooks of every layer
+    geometry of VoxelBackBone8x -> conv, bit-exact indices vs the oracle, conv within 1e-5."""
+    pts = synthetic.gen_voxel_frame(0, 160000)
+    feat, coords, _ = ops.dynamic_voxelize(dev(pts), synthetic.PC_RANGE, synthetic.VOXEL_SIZE,
+                                           synthetic.GRID_SIZE)
+    shape = [41, 1504, 1504]
+    idx = coords.cpu().numpy()
+    rng = np.random.default_rng(7)
+    for ks, st, pd, subm in BACKBONE_LAYERS:
+        dl = [1, 1, 1]
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, dl)
+        got = _rulebook_gpu(idx, 1, out_shape, shape, ks, st, pd, dl, subm)
+        want = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, dl, subm)
+        np.testing.assert_array_equal(got[2], want[2])
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+        # conv on this rulebook
+        cin, cout = 5, 16
+        W = rng.normal(0, 0.05, (*ks, cin, cout)).astype(np.float32)
+        num_out = got[0].shape[0]
+        o = ops.indice_conv(feat, dev(W), dev(got[1]), dev(got[2]), num_out, False, subm)
+        ref = oracle.indice_conv(feat.cpu().numpy(), W, want[1], want[2], num_out, False, subm)
+        np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (7, 10)])
+def test_conv_channel_configs(oracle, cin, cout):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_subm3.npz"))
+    rng = np.random.default_rng(cin * 131 + cout)
+    V = g["indices"].shape[0]
+    feat = rng.normal(0, 1, (V, cin)).astype(np.float32)
+    W = rng.normal(0, 0.05, (3, 3, 3, cin, cout)).astype(np.float32)
+    o = ops.indice_conv(dev(feat), dev(W), dev(g["pairs"]), dev(g["num"]), V, False, True)
+    ref = oracle.indice_conv(feat, W, g["pairs"], g["num"], V, False, True)
+    np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    # bitwise reproducible run to run (no atomics on the data path)
+    o2 = ops.indice_conv(dev(feat), dev(W), dev(g["pairs"]), dev(g["num"]), V, False, True)
+    assert torch.equal(o, o2)
+
+
+def test_conv_epilogue_and_inverse(oracle):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_spconv_s2p1.npz"))
+    rng = np.random.default_rng(9)
+    V, Vo = g["indices"].shape[0], g["out_ids"].shape[0]
+    cin, cout = 16, 32
+    feat = rng.normal(0, 1, (V, cin)).astype(np.float32)
+    W = rng.normal(0, 0.05, (3, 3, 3, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 1, cout).astype(np.float32)
+    pairs, num = dev(g["pairs"]), dev(g["num"])
+    table = ops.build_neighbor_table(pairs, num, Vo)
+    o = ops.indice_conv_table(dev(feat), dev(W), table, Vo, False, dev(bias), dev(scale), dev(shift), True)
+    ref = oracle.indice_conv(feat, W, g["pairs"], g["num"], Vo, False, False)
+    ref = np.maximum((ref + bias) * scale + shift, 0)
+    np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    # inverse conv: gather from outputs, scatter to inputs (spconv_ops.h `inverse`)
+    fo = rng.normal(0, 1, (Vo, cin)).astype(np.float32)
+    oi = ops.indice_conv(dev(fo), dev(W), pairs, num, V, True, False)
+    refi = oracle.indice_conv(fo, W, g["pairs"], g["num"], V, True, False)
+    np.testing.assert_allclose(oi.cpu().numpy(), refi, rtol=1e-5, atol=2e-5)
+
+
+def test_empty_inputs():
+    idx = torch.zeros(0, 4, dtype=torch.int32, device=DEV)
+    out_ids, pairs, num = ops.get_indice_pairs(idx, 1, [5, 5, 5], [5, 5, 5], [3, 3, 3], [1, 1, 1],
+                                               [1, 1, 1], [1, 1, 1], True)
+    assert pairs.shape == (27, 2, 0) and int(num.sum()) == 0
