@@ -284,8 +284,8 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
                          const int* pad3, const int* dil3, int subm, int transpose,
                          int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
                          int64_t* d_num_out, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (!indices || !out_shape3 || !spatial_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 ||
-      !pairs || !num || !d_num_out || !ws || V < 0 || batch < 1)
+  if (!out_shape3 || !spatial_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 || !num ||
+      !d_num_out || !ws || V < 0 || batch < 1 || (V > 0 && (!indices || !pairs)))
     return PCS_ERR_ARG;
   if (transpose) return PCS_ERR_ARG;  // deconv rulebooks: SURVEY 8(f) "next", not built yet
   ConvGeom g;
@@ -305,7 +305,7 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
   if (V >= (1LL << 31) / g.kv) return PCS_ERR_RANGE;
   uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
   if (vol * (uint64_t)batch >= (1ULL << 62)) return PCS_ERR_RANGE;
-  PCS_CHECK_HIP(hipMemsetAsync(pairs, 0xFF, (size_t)g.kv * 2 * (V > 0 ? V : 0) * sizeof(int32_t), s));
+  if (V > 0) PCS_CHECK_HIP(hipMemsetAsync(pairs, 0xFF, (size_t)g.kv * 2 * V * sizeof(int32_t), s));
   PCS_CHECK_HIP(hipMemsetAsync(num, 0, g.kv * sizeof(int32_t), s));
   if (V == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s)); return PCS_OK; }
   int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, subm);
