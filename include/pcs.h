@@ -124,6 +124,88 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
                               const float* bias, const float* scale, const float* shift, int relu,
                               float* out, pcs_stream_t stream);
 
+/* ------------------------------------------------------------------ radius graph */
+
+/* RadiusGraph.build_graph, pcdet/models/model_utils/graph_utils.py:149-209 (hash_insert_gpu +
+ * radius_graph_gpu, pcdet/ops/torch_hash/src/torch_hash_kernel.cu:411-561) as ONE engine call
+ * pair: ref [N,4], query [M,4] f32 (frame, x, y, z); `radius` is the reference's fp32 radius
+ * (already including the frame offset term, registration_utils.py:111-112); frame cells follow
+ * the reference quantisation and the query looks at frame cells fq + dframe_min..dframe_max
+ * (qmin[0], qmax[0]); spatial qmin/qmax are the reference defaults (-1..1: the whole ball).
+ * Edges: grouped by ascending query, within a query ascending (dist2, ref index); at most
+ * max_nbr (1..32) per query. *d_num_edges = E, or -1 when extent/cell_size overflows the 17-bit
+ * cell coordinates. cell_size <= 0 -> radius/2. search and emit must see the same ws. */
+size_t pcs_radius_graph_workspace_bytes(int64_t N, int64_t M, int max_nbr);
+int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int64_t M,
+                            float radius, float cell_size, int dframe_min, int dframe_max,
+                            int max_nbr, int sort_by_dist, int64_t* d_num_edges, void* ws,
+                            size_t ws_bytes, pcs_stream_t stream);
+int pcs_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query,
+                          float* dists, const void* ws, size_t ws_bytes, pcs_stream_t stream);
+
+/* Literal drop-ins for torch_hash_cuda (pcdet/ops/torch_hash/src/torch_hash_api.cpp:9-15,
+ * torch_hash.h:16-32) on the reference's own table layout: keys[H] int64 (-1 empty),
+ * values[H,D] f32, reverse[H] int64, dims[D] int64; all caller-allocated, H chosen by the caller
+ * (graph_utils.py:179-183). hash_insert_gpu -> pcs_hash_insert; radius_graph_gpu ->
+ * pcs_radius_graph_table_count (degree kernel + cumsum) then pcs_radius_graph_table_fill.
+ * Unlike the reference kernels, query_keys is not mutated. max_nbr = -1 means unbounded. */
+int pcs_hash_insert(int64_t* keys, float* values, int64_t* reverse, int64_t H, const int64_t* dims,
+                    int D, const int64_t* insert_keys, const float* insert_values, int64_t n,
+                    pcs_stream_t stream);
+size_t pcs_radius_graph_table_workspace_bytes(int64_t M);
+int pcs_radius_graph_table_count(const int64_t* keys, const float* values, const int64_t* reverse,
+                                 int64_t H, const int64_t* dims, int D, const int64_t* query_keys,
+                                 const float* query_values, int64_t M, const int32_t* qmin,
+                                 const int32_t* qmax, const float* radius, int max_nbr,
+                                 int32_t* degree, int32_t* offset, int64_t* d_num_edges, void* ws,
+                                 size_t ws_bytes, pcs_stream_t stream);
+int pcs_radius_graph_table_fill(const int64_t* keys, const float* values, const int64_t* reverse,
+                                int64_t H, const int64_t* dims, int D, const int64_t* query_keys,
+                                const float* query_values, int64_t M, const int32_t* qmin,
+                                const int32_t* qmax, const float* radius, int sort_by_dist,
+                                const int32_t* degree, const int32_t* offset, int64_t* edges,
+                                float* dists, pcs_stream_t stream);
+
+/* ------------------------------------------------------------------ components, medians */
+
+/* connected_components, pcdet/models/model_utils/graph_utils.py:40-53 (scipy csgraph on the
+ * host in the reference): component[n] int64 = rank of the node's weakly connected component by
+ * its smallest node id; *d_num = number of components. */
+size_t pcs_connected_components_workspace_bytes(int64_t n);
+int pcs_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n,
+                             int64_t* component, int64_t* d_num, void* ws, size_t ws_bytes,
+                             pcs_stream_t stream);
+
+/* robust_median, pcdet/models/registration/preprocessors/registration_utils.py:60-81: per
+ * segment the element at sorted position deg//2. data[n] int64 -> out[v]. */
+int pcs_segment_median_i64(const int64_t* data, const int32_t* order, const int32_t* seg_start,
+                           int64_t v, int64_t* out, pcs_stream_t stream);
+
+/* torch_scatter.scatter(reduce='max'|'min') over segments (cluster_tracking.py:104,325-328). */
+int pcs_segment_minmax_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start,
+                           int64_t v, int is_max, float* out, pcs_stream_t stream);
+
+/* ------------------------------------------------------------------ registration */
+
+/* register_to_next_frame, pcdet/models/registration/preprocessors/registration_utils.py:83-206
+ * (the "TLS solve"): per-component regularised Kabsch ICP with the loss-delta / 3-strike stop
+ * rule evaluated on the device. BLOCKING: synchronises `stream` once per `chunk` iterations and
+ * at the end (the reference synchronises every iteration). mov_fxyz [Mn,4] (non-stationary
+ * moving points) is updated in place; mov_comp [Mn] int32 in [0,C); ref_fxyz [Rn,4]
+ * non-stationary reference points; ref_all [Ra,4] every reference point (coverage ratio);
+ * comp_deg [C] int64 moving points per component (stationary included). Outputs: T [C,16] f64
+ * row-major 4x4, l1_err [C] f64 (truncated mean of the last iteration), edge_ratio [C] f32.
+ * info: HOST int32[4] = {iterations, stopped by countdown, 0, 0}. `radius` is the graph's base
+ * radius; the frame-offset term is added inside as the reference does. */
+size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_t Ra, int64_t C);
+int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
+                               const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
+                               const int64_t* comp_deg, int64_t C, double radius, int frame_offset,
+                               double angle_regularizer, int max_iter, double stopping_delta,
+                               float cell_size, int chunk, double* T, double* l1_err,
+                               float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
+                               pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ def lib():
             build()
         _LIB = ctypes.CDLL(path)
         for name in ("orc_unique_i64", "orc_dynamic_voxelize", "orc_hard_voxelize",
-                     "orc_get_indice_pairs"):
+                     "orc_get_indice_pairs", "orc_radius_graph", "orc_connected_components"):
             getattr(_LIB, name).restype = ctypes.c_int64
     return _LIB
 
@@ -145,6 +145,52 @@ def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=Fals
                               ctypes.c_int64(pairs.shape[2]), _p(_c(num, np.int32)),
                               ctypes.c_int64(num_out), ctypes.c_int(int(inverse)),
                               ctypes.c_int(int(subm)), _p(out))
+    return out
+
+
+def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, qmin=(0, -1, -1, -1),
+                 qmax=(0, 1, 1, 1), want_dists=False):
+    """RadiusGraph.build_graph: returns (e_ref, e_query) int64 (and squared dists)."""
+    ref = _c(ref, np.float32)
+    query = _c(query, np.float32)
+    M = query.shape[0]
+    cap = max(M * max_nbr, 1)
+    e_ref = np.empty(cap, np.int64)
+    e_qry = np.empty(cap, np.int64)
+    d = np.empty(cap, np.float32)
+    E = lib().orc_radius_graph(_p(ref), ctypes.c_int64(ref.shape[0]), _p(query), ctypes.c_int64(M),
+                               ctypes.c_float(np.float32(radius)), _ints(qmin), _ints(qmax),
+                               ctypes.c_int(max_nbr), ctypes.c_int(int(sort_by_dist)), _p(e_ref),
+                               _p(e_qry), _p(d))
+    if want_dists:
+        return e_ref[:E].copy(), e_qry[:E].copy(), d[:E].copy()
+    return e_ref[:E].copy(), e_qry[:E].copy()
+
+
+def connected_components(e0, e1, n):
+    e0 = _c(e0, np.int64)
+    e1 = _c(e1, np.int64)
+    comp = np.empty(n, np.int64)
+    num = lib().orc_connected_components(_p(e0), _p(e1), ctypes.c_int64(e0.shape[0]),
+                                         ctypes.c_int64(n), _p(comp))
+    return int(num), comp
+
+
+def robust_median(data, index, num_segments):
+    """registration_utils.robust_median (:60-81): sort index*range + (data - min), pick the
+    element at exclusive_scan(deg) + deg // 2; empty segments -> int64(-1e10)."""
+    data = np.asarray(data, np.int64)
+    index = np.asarray(index, np.int64)
+    dmin, dmax = data.min(), data.max()
+    rng = dmax - dmin + 1
+    key = np.sort(index * rng + (data - dmin))
+    sidx = key // rng
+    sdata = key - rng * sidx + dmin
+    deg = np.bincount(index, minlength=num_segments)
+    off = np.cumsum(deg) - deg + deg // 2
+    out = np.full(num_segments, np.int64(-1e10), np.int64)
+    m = deg > 0
+    out[m] = sdata[off[m]]
     return out
 
 

@@ -311,4 +311,133 @@ void orc_indice_conv_f32(const float* feat, int64_t num_in, int cin, const float
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RadiusGraph.build_graph (pcdet/models/model_utils/graph_utils.py:149-209) + hash_insert_gpu /
+// radius_graph_gpu (pcdet/ops/torch_hash/src/torch_hash_kernel.cu:31-91, 224-409, 487-561),
+// followed literally: voxel coords by round-half-even, table of H = int(N/0.5) slots with linear
+// probing (inserted serially here, so deterministic), per query the cell combinations with dim 0
+// fastest, probe chain until an empty slot, fp32 dist2 over all 4 dims, `<=` radius^2, at most
+// max_nbr kept. Tie rule (the reference's depends on an atomicCAS race): (dist2, ref index)
+// ascending when sort_by_dist, ref index ascending otherwise.
+// Returns E; e_ref/e_qry/dists have capacity M*max_nbr.
+static inline int64_t orc_map2key(const int64_t* c, const int64_t* dims) {
+  int64_t ans = 0;
+  for (int i = 0; i < 4; ++i) {
+    int64_t k = c[i];
+    if (k >= dims[i]) k = dims[i];
+    if (k < 0) k = 0;
+    ans = ans * dims[i] + k;
+  }
+  return ans;
+}
+static inline int64_t orc_hashkey(int64_t key, int64_t H) { return ((key % H) * 999269 + 999437) % H; }
+
+int64_t orc_radius_graph(const float* ref, int64_t N, const float* qry, int64_t M, float radius,
+                         const int* qmin, const int* qmax, int max_nbr, int sort_by_dist,
+                         int64_t* e_ref, int64_t* e_qry, float* dists) {
+  if (N == 0 || M == 0) return 0;
+  float vs[4] = {(float)(1 - 1e-3), radius, radius, radius};
+  float lo[4], hi[4];
+  for (int d = 0; d < 4; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
+  for (int64_t i = 0; i < N; ++i)
+    for (int d = 0; d < 4; ++d) { lo[d] = std::fmin(lo[d], ref[i * 4 + d]); hi[d] = std::fmax(hi[d], ref[i * 4 + d]); }
+  for (int64_t i = 0; i < M; ++i)
+    for (int d = 0; d < 4; ++d) { lo[d] = std::fmin(lo[d], qry[i * 4 + d]); hi[d] = std::fmax(hi[d], qry[i * 4 + d]); }
+  int64_t dims[4];
+  for (int d = 0; d < 4; ++d) {
+    lo[d] = lo[d] - vs[d] * 2.f;
+    hi[d] = hi[d] + vs[d] * 2.f;
+    dims[d] = (int64_t)std::nearbyint((hi[d] - lo[d]) / vs[d]) + 3;
+  }
+  auto coord = [&](const float* p, int64_t* c) {
+    for (int d = 0; d < 4; ++d) c[d] = (int64_t)std::nearbyint((p[d] - lo[d]) / vs[d]) + 1;
+  };
+  int64_t H = (int64_t)((double)N / 0.5);
+  std::vector<int64_t> keys(H, -1), rev(H, 0);
+  std::vector<float> vals((size_t)H * 4);
+  for (int64_t i = 0; i < N; ++i) {
+    int64_t c[4];
+    coord(ref + i * 4, c);
+    int64_t key = orc_map2key(c, dims);
+    int64_t slot = orc_hashkey(key, H);
+    while (keys[slot] != -1) slot = (slot + 1) % H;
+    keys[slot] = key;
+    for (int d = 0; d < 4; ++d) vals[slot * 4 + d] = ref[i * 4 + d];
+    rev[slot] = i;
+  }
+  int w[4], ncomb = 1;
+  for (int d = 0; d < 4; ++d) { w[d] = qmax[d] - qmin[d] + 1; ncomb *= w[d]; }
+  float r2 = radius * radius;
+  int64_t E = 0;
+  std::vector<float> bd(max_nbr);
+  std::vector<int64_t> bi(max_nbr);
+  for (int64_t q = 0; q < M; ++q) {
+    int64_t qc[4];
+    coord(qry + q * 4, qc);
+    int cnt = 0;
+    for (int c = 0; c < ncomb; ++c) {
+      int64_t cc[4];
+      int tmp = c;
+      for (int d = 0; d < 4; ++d) { cc[d] = qc[d] + (tmp % w[d] + qmin[d]); tmp /= w[d]; }
+      int64_t key = orc_map2key(cc, dims);
+      int64_t slot = orc_hashkey(key, H);
+      while (keys[slot] != -1) {
+        if (keys[slot] == key) {
+          float dist2 = 0.f;
+          for (int d = 0; d < 4; ++d) {
+            float di = vals[slot * 4 + d] - qry[q * 4 + d];
+            dist2 = dist2 + di * di;
+          }
+          if (dist2 <= r2) {
+            float kk = sort_by_dist ? dist2 : 0.f;
+            int64_t idx = rev[slot];
+            int pos = cnt;
+            while (pos > 0) {
+              float kd = sort_by_dist ? bd[pos - 1] : 0.f;
+              bool less = (kk < kd) || (kk == kd && idx < bi[pos - 1]);
+              if (!less) break;
+              if (pos < max_nbr) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; }
+              --pos;
+            }
+            if (pos < max_nbr) { bd[pos] = dist2; bi[pos] = idx; if (cnt < max_nbr) ++cnt; }
+          }
+        }
+        slot = (slot + 1) % H;
+      }
+    }
+    for (int e = 0; e < cnt; ++e) {
+      e_ref[E] = bi[e];
+      e_qry[E] = q;
+      if (dists) dists[E] = bd[e];
+      ++E;
+    }
+  }
+  return E;
+}
+
+// connected_components (graph_utils.py:40-53): weakly connected components, label = order of
+// first appearance scanning nodes 0..n-1 (scipy.sparse.csgraph labelling). Returns the count.
+int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n,
+                                 int64_t* component) {
+  std::vector<int64_t> parent(n);
+  std::iota(parent.begin(), parent.end(), 0);
+  auto find = [&](int64_t x) {
+    while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+    return x;
+  };
+  for (int64_t e = 0; e < E; ++e) {
+    int64_t a = find(e0[e]), b = find(e1[e]);
+    if (a != b) parent[a > b ? a : b] = a > b ? b : a;
+  }
+  std::vector<int64_t> label(n, -1);
+  int64_t num = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t r = find(i);
+    if (label[r] < 0) label[r] = num++;
+    component[i] = label[r];
+  }
+  return num;
+}
+
 }  // extern "C"

@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # from fp32 (p - lo) / size and must match the CPU restatement bit for bit.
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
-    "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-Wno-unused-result",
 ]
 
 

@@ -96,6 +96,16 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// float atomics on ordered-int views: valid for non-NaN input.
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMin((int*)addr, __float_as_int(v));
+  else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
 // 64-bit mix used by the open-addressing coordinate tables (rulebook, cell lookup).
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   k ^= k >> 33;

@@ -1,0 +1,637 @@
+// Fused per-component ICP ("TLS solve") for gfx950.
+//
+// Reference: register_to_next_frame, pcdet/models/registration/preprocessors/
+// registration_utils.py:83-206. Per iteration the reference runs two radius-graph
+// builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
+// scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
+//
+// Here one call owns the whole loop. State stays in the caller's workspace; an iteration is
+//   memset x2 (moving grid) -> insert moving points (+ zero accumulators)
+//   -> 1-NN both directions (expanding-ring search on the fine-cell grids, pcs_grid.hpp) fused with
+//      pass 1 (edge count, sum of matched moving / reference coordinates per component)
+//   -> pass 2 (centred P,Q: 3x3 cross-covariance, sum |P-Q|^2, sum |P-Q| per component)
+//   -> solve (one thread per component: cov + reg*T_rot -> 3x3 one-sided Jacobi SVD in f64 ->
+//      R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T; then the loss-delta /
+//      3-strike countdown stop rule ON DEVICE)
+//   -> apply (all moving points, f64 -> fp32 as the reference stores them)
+// with every kernel skipping itself once the device-side `done` flag is set, so the host reads
+// one flag per chunk of iterations instead of one loss per iteration.
+// Per-component reductions use wave64 shuffle reductions over lanes that share a component and one
+// f64 hardware atomic per (wave, component, accumulator).
+#include "pcs_grid.hpp"
+
+namespace pcs {
+
+struct IcpState {
+  double last_error;
+  double loss;
+  int countdown;
+  int done;
+  int iters;
+  int err;
+};
+
+struct IcpBufs {
+  GridDesc* grid;
+  float *b_ref, *b_mov, *b_all;
+  IcpState* state;
+  // static reference grid (non-stationary reference points), moving grid, all-reference grid
+  uint64_t *keys_r, *keys_m, *keys_a;
+  int32_t *head_r, *head_m, *head_a, *next_r, *next_m, *next_a;
+  float *fr_r, *fr_m, *fr_a;
+  uint32_t Hr, Hm, Ha;
+  int32_t *nn_f, *nn_b;
+  float* prev;     // [Mn,4] positions before the last applied update
+  double* acc1;    // [C,8]: n, sum p (3), sum q (3), sum clamp(dist) (l1 pass)
+  double* acc2;    // [C,12]: sum P(x)Q (9), sum |P-Q|^2, sum |P-Q|, pad
+  double* Rt;      // [C,12]: R row-major, t
+  int32_t* cnt;    // [C] matched moving points in the final coverage query
+};
+
+static inline uint32_t p2(uint64_t x) { uint32_t h = 64; while (h < x) h <<= 1; return h; }
+
+static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
+  if (Mn < 1) Mn = 1;
+  if (Rn < 1) Rn = 1;
+  if (Ra < 1) Ra = 1;
+  if (C < 1) C = 1;
+  b.grid = a.take<GridDesc>(1);
+  b.b_ref = a.take<float>(8);
+  b.b_mov = a.take<float>(8);
+  b.b_all = a.take<float>(8);
+  b.state = a.take<IcpState>(1);
+  b.Hr = p2(2 * (uint64_t)Rn); b.Hm = p2(2 * (uint64_t)Mn); b.Ha = p2(2 * (uint64_t)Ra);
+  b.keys_r = a.take<uint64_t>(b.Hr); b.head_r = a.take<int32_t>(b.Hr); b.next_r = a.take<int32_t>(Rn);
+  b.keys_m = a.take<uint64_t>(b.Hm); b.head_m = a.take<int32_t>(b.Hm); b.next_m = a.take<int32_t>(Mn);
+  b.keys_a = a.take<uint64_t>(b.Ha); b.head_a = a.take<int32_t>(b.Ha); b.next_a = a.take<int32_t>(Ra);
+  b.fr_r = a.take<float>(2 * kFrameCells);
+  b.fr_m = a.take<float>(2 * kFrameCells);
+  b.fr_a = a.take<float>(2 * kFrameCells);
+  b.nn_f = a.take<int32_t>(Mn);
+  b.nn_b = a.take<int32_t>(Rn);
+  b.prev = a.take<float>(Mn * 4);
+  b.acc1 = a.take<double>(C * 8);
+  b.acc2 = a.take<double>(C * 12);
+  b.Rt = a.take<double>(C * 12);
+  b.cnt = a.take<int32_t>(C);
+  return a.ok();
+}
+
+// grid origin padded so that points moved by the registration stay inside the 17-bit cell range
+__global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* __restrict__ b_mov,
+                                 const float* __restrict__ b_all, float radius, float cell,
+                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st) {
+  if (threadIdx.x != 0) return;
+  float mn[4];
+  for (int d = 0; d < 4; ++d) mn[d] = fminf(fminf(b_ref[d], b_mov[d]), b_all[d]);
+  float vs0 = (float)(1 - 1e-3);
+  g->vs0 = vs0;
+  g->lo0 = mn[0] - vs0 * 2.f;
+  for (int d = 0; d < 3; ++d) g->lo[d] = mn[1 + d] - pad;
+  g->h = cell;
+  g->radius = radius;
+  g->radius2 = radius * radius;
+  g->rings = (int)ceilf(radius / cell);
+  st->last_error = 1e10;
+  st->loss = 0.0;
+  st->countdown = 3;
+  st->done = 0;
+  st->iters = 0;
+  st->err = 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+icp_init_T_kernel(double* __restrict__ T, int64_t C) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < C * 16;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int e = (int)(i & 15);
+    T[i] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
+  }
+}
+
+// moving-grid insert of one iteration (+ zero the accumulators); no-op once done
+__global__ void __launch_bounds__(kBlock)
+icp_insert_moving_kernel(const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
+                         uint64_t* __restrict__ keys, int32_t* __restrict__ head,
+                         int32_t* __restrict__ next, uint32_t hmask, float* __restrict__ fr,
+                         IcpState* __restrict__ st, double* __restrict__ acc1,
+                         double* __restrict__ acc2, int64_t C) {
+  if (st->done) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t k = i; k < C * 8; k += (int64_t)gridDim.x * blockDim.x) acc1[k] = 0.0;
+  for (int64_t k = i; k < C * 12; k += (int64_t)gridDim.x * blockDim.x) acc2[k] = 0.0;
+  if (i >= Mn) return;
+  GridDesc g = *gp;
+  float4 p = mov[i];
+  int fc = frame_cell(g, p.x);
+  int x = (int)floorf((p.y - g.lo[0]) / g.h);
+  int y = (int)floorf((p.z - g.lo[1]) / g.h);
+  int z = (int)floorf((p.w - g.lo[2]) / g.h);
+  if (x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax || fc < 0 ||
+      fc >= kFrameCells) {
+    atomicExch(&st->err, 1);
+    next[i] = -1;
+    return;
+  }
+  atomic_min_f32(&fr[fc], p.x);
+  atomic_max_f32(&fr[kFrameCells + fc], p.x);
+  uint64_t key = pack_cell(fc, x, y, z);
+  uint32_t slot = mix64(key) & hmask;
+  while (true) {
+    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmpty,
+                              (unsigned long long)key);
+    if (prev == kEmpty || prev == key) break;
+    slot = (slot + 1) & hmask;
+  }
+  next[i] = atomicExch(&head[slot], i);
+}
+
+// nearest reference point of the hashed cloud within radius (canonical ties: smaller index)
+__device__ __forceinline__ int nn_search(const GridDesc& g, float4 p, int df,
+                                         const float4* __restrict__ pts,
+                                         const uint64_t* __restrict__ keys,
+                                         const int32_t* __restrict__ head,
+                                         const int32_t* __restrict__ next, uint32_t hmask,
+                                         const float* __restrict__ fr) {
+  int fc = frame_cell(g, p.x) + df;
+  if (fc < 0 || fc >= kFrameCells) return -1;
+  float fa = fr[fc], fb = fr[kFrameCells + fc];
+  if (fa > fb) return -1;
+  float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+  float dfsq = dfl * dfl;
+  const float margin = 1e-5f * g.radius2 + 1e-6f;
+  int cx = (int)floorf((p.y - g.lo[0]) / g.h);
+  int cy = (int)floorf((p.z - g.lo[1]) / g.h);
+  int cz = (int)floorf((p.w - g.lo[2]) / g.h);
+  int best = -1;
+  float bestd = g.radius2;
+  for (int s = 0; s <= g.rings; ++s) {
+    if (s >= 1) {
+      float lb = (float)(s - 1) * g.h;
+      if (lb * lb > bestd - dfsq + margin) break;
+    }
+    for (int dz = -s; dz <= s; ++dz) {
+      int z = cz + dz;
+      if (z < 0 || z >= kCoordMax) continue;
+      for (int dy = -s; dy <= s; ++dy) {
+        int y = cy + dy;
+        if (y < 0 || y >= kCoordMax) continue;
+        bool shell = (dz == -s || dz == s || dy == -s || dy == s);
+        int step = shell ? 1 : (s > 0 ? 2 * s : 1);
+        for (int dx = -s; dx <= s; dx += step) {
+          int x = cx + dx;
+          if (x < 0 || x >= kCoordMax) continue;
+          int j = grid_head(keys, head, hmask, pack_cell(fc, x, y, z));
+          while (j >= 0) {
+            float4 c = pts[j];
+            float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+            float dist2 = 0.f;
+            dist2 = dist2 + d0 * d0;
+            dist2 = dist2 + d1 * d1;
+            dist2 = dist2 + d2 * d2;
+            dist2 = dist2 + d3 * d3;
+            if (dist2 <= g.radius2 && (best < 0 || dist2 < bestd || (dist2 == bestd && j < best))) {
+              best = j;
+              bestd = dist2;
+            }
+            j = next[j];
+          }
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
+// 64-lane butterflies first. All 64 lanes must call this.
+template <int NV>
+__device__ __forceinline__ void grouped_atomic_add(bool active, int key, const double (&v)[NV],
+                                                   double* __restrict__ base, int stride) {
+  int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    int leader = __ffsll((long long)todo) - 1;
+    int lkey = __shfl(key, leader, 64);
+    bool mine = active && key == lkey;
+    unsigned long long grp = __ballot(mine);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double x = wave_sum_f64(mine ? v[i] : 0.0);
+      if (lane == leader) atomicAdd(&base[(int64_t)lkey * stride + i], x);
+    }
+    todo &= ~grp;
+  }
+}
+
+// threads [0,Mn): forward (moving -> reference, df = +frame_offset);
+// threads [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
+__global__ void __launch_bounds__(kBlock)
+icp_nn_pass1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+                    const int32_t* __restrict__ comp, const GridDesc* __restrict__ gp, int df,
+                    const uint64_t* __restrict__ keys_r, const int32_t* __restrict__ head_r,
+                    const int32_t* __restrict__ next_r, uint32_t hmask_r,
+                    const float* __restrict__ fr_r, const uint64_t* __restrict__ keys_m,
+                    const int32_t* __restrict__ head_m, const int32_t* __restrict__ next_m,
+                    uint32_t hmask_m, const float* __restrict__ fr_m,
+                    const IcpState* __restrict__ st, int32_t* __restrict__ nn_f,
+                    int32_t* __restrict__ nn_b, double* __restrict__ acc1) {
+  if (st->done) return;
+  GridDesc g = *gp;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool active = false;
+  int c = 0;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (i < Mn) {
+    float4 p = mov[i];
+    int r = nn_search(g, p, df, ref, keys_r, head_r, next_r, hmask_r, fr_r);
+    nn_f[i] = r;
+    if (r >= 0) {
+      float4 q = ref[r];
+      active = true; c = comp[i];
+      v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
+    }
+  } else if (i < Mn + Rn) {
+    int r = i - Mn;
+    float4 q = ref[r];
+    int m = nn_search(g, q, -df, mov, keys_m, head_m, next_m, hmask_m, fr_m);
+    nn_b[r] = m;
+    if (m >= 0) {
+      float4 p = mov[m];
+      active = true; c = comp[m];
+      v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
+    }
+  }
+  grouped_atomic_add<7>(active, c, v, acc1, 8);
+}
+
+// centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151)
+__device__ __forceinline__ void centres(const double* __restrict__ a1, double* cm, double* cr) {
+  double n = a1[0];
+  if (n > 0.5) {
+    for (int d = 0; d < 3; ++d) {
+      cm[d] = (double)(float)(a1[1 + d] / n);
+      cr[d] = (double)(float)(a1[4 + d] / n);
+    }
+  } else {
+    for (int d = 0; d < 3; ++d) cm[d] = cr[d] = 0.0;
+  }
+}
+
+// MODE 0: pass 2 (cov, sum dist^2, sum dist) on the CURRENT positions.
+// MODE 1: l1 pass (sum of clamped dist) on the positions saved before the last update.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+icp_pass2_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+                 const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
+                 const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
+                 const double* __restrict__ acc1, double* __restrict__ acc2,
+                 double* __restrict__ acc_l1, double trunc) {
+  if (MODE == 0 && st->done) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool active = false;
+  int c = 0, m = -1, r = -1;
+  if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
+  else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
+  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double v1[1] = {0};
+  if (active) {
+    c = comp[m];
+    float4 p = mov[m], q = ref[r];
+    double cm[3], cr[3];
+    centres(acc1 + (int64_t)c * 8, cm, cr);
+    double P[3] = {(double)p.y - cm[0], (double)p.z - cm[1], (double)p.w - cm[2]};
+    double Q[3] = {(double)q.y - cr[0], (double)q.z - cr[1], (double)q.w - cr[2]};
+    double e0 = P[0] - Q[0], e1 = P[1] - Q[1], e2 = P[2] - Q[2];
+    double d2 = e0 * e0 + e1 * e1 + e2 * e2;
+    double dist = sqrt(d2);
+    if (MODE == 0) {
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) v[a * 3 + b] = P[a] * Q[b];
+      v[9] = d2;
+      v[10] = dist;
+    } else {
+      double n = acc1[(int64_t)c * 8];
+      double mean = acc2[(int64_t)c * 12 + 10] / n;
+      double lo = mean - trunc, hi = mean + trunc;
+      v1[0] = fmin(fmax(dist, lo), hi);
+    }
+  }
+  if (MODE == 0) grouped_atomic_add<11>(active, c, v, acc2, 12);
+  else grouped_atomic_add<1>(active, c, v1, acc_l1, 8);
+}
+
+// ---- 3x3 SVD by one-sided Jacobi (f64), singular values descending ----
+__device__ inline void svd3(const double M[9], double U[9], double S[3], double V[9]) {
+  double A[9];
+  for (int i = 0; i < 9; ++i) { A[i] = M[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) {
+          al += A[i * 3 + p] * A[i * 3 + p];
+          be += A[i * 3 + q] * A[i * 3 + q];
+          ga += A[i * 3 + p] * A[i * 3 + q];
+        }
+        double lim = 1e-15 * sqrt(al * be);
+        if (fabs(ga) <= lim || ga == 0.0) continue;
+        off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
+        double zeta = (be - al) / (2.0 * ga);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          double ap = A[i * 3 + p], aq = A[i * 3 + q];
+          A[i * 3 + p] = c * ap - s * aq;
+          A[i * 3 + q] = s * ap + c * aq;
+          double vp = V[i * 3 + p], vq = V[i * 3 + q];
+          V[i * 3 + p] = c * vp - s * vq;
+          V[i * 3 + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  for (int j = 0; j < 3; ++j)
+    S[j] = sqrt(A[0 * 3 + j] * A[0 * 3 + j] + A[1 * 3 + j] * A[1 * 3 + j] + A[2 * 3 + j] * A[2 * 3 + j]);
+  // sort columns by descending singular value
+  int ord[3] = {0, 1, 2};
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (S[ord[b]] > S[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+  double A2[9], V2[9], S2[3];
+  for (int j = 0; j < 3; ++j) {
+    S2[j] = S[ord[j]];
+    for (int i = 0; i < 3; ++i) { A2[i * 3 + j] = A[i * 3 + ord[j]]; V2[i * 3 + j] = V[i * 3 + ord[j]]; }
+  }
+  for (int j = 0; j < 3; ++j) {
+    S[j] = S2[j];
+    for (int i = 0; i < 3; ++i) {
+      V[i * 3 + j] = V2[i * 3 + j];
+      U[i * 3 + j] = S2[j] > 1e-300 ? A2[i * 3 + j] / S2[j] : 0.0;
+    }
+  }
+  // complete U when a singular value vanished (rank-deficient M): orthonormal completion
+  if (S[2] <= 1e-300) {
+    if (S[1] <= 1e-300) {
+      if (S[0] <= 1e-300) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+      // pick any unit vector orthogonal to u0
+      double u0[3] = {U[0], U[3], U[6]};
+      int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+      double e[3] = {0, 0, 0}; e[k] = 1.0;
+      double d = e[0] * u0[0] + e[1] * u0[1] + e[2] * u0[2];
+      double w[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+      double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      U[1] = w[0] / nw; U[4] = w[1] / nw; U[7] = w[2] / nw;
+    }
+    double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+    U[2] = a[1] * b[2] - a[2] * b[1];
+    U[5] = a[2] * b[0] - a[0] * b[2];
+    U[8] = a[0] * b[1] - a[1] * b[0];
+  }
+}
+
+__device__ inline double det3(const double A[9]) {
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
+         A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// one block; thread per component (grid-stride over C), then thread 0 runs the stop rule
+__global__ void __launch_bounds__(1024)
+icp_solve_kernel(int64_t C, double reg, double delta, const double* __restrict__ acc1,
+                 const double* __restrict__ acc2, double* __restrict__ T, double* __restrict__ Rt,
+                 IcpState* __restrict__ st) {
+  if (st->done) return;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+    const double* a1 = acc1 + c * 8;
+    const double* a2 = acc2 + c * 12;
+    double n = a1[0];
+    double cm[3], cr[3];
+    centres(a1, cm, cr);
+    double* Tc = T + c * 16;
+    double M[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double cov = a2[a * 3 + b];
+        if (n > 0.5) cov = cov / n;  // robust_mean: divide only where the count is positive
+        M[a * 3 + b] = cov + Tc[a * 4 + b] * reg;
+      }
+    double U[9], S[3], V[9];
+    svd3(M, U, S, V);
+    // R = V diag(1,1,det(V U^T)) U^T
+    double VUt[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        VUt[a * 3 + b] = V[a * 3 + 0] * U[b * 3 + 0] + V[a * 3 + 1] * U[b * 3 + 1] + V[a * 3 + 2] * U[b * 3 + 2];
+    double sg = det3(VUt);
+    double R[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        R[a * 3 + b] = V[a * 3 + 0] * U[b * 3 + 0] + V[a * 3 + 1] * U[b * 3 + 1] + sg * V[a * 3 + 2] * U[b * 3 + 2];
+    double t[3];
+    for (int a = 0; a < 3; ++a)
+      t[a] = cr[a] - (cm[0] * R[a * 3 + 0] + cm[1] * R[a * 3 + 1] + cm[2] * R[a * 3 + 2]);
+    double* rt = Rt + c * 12;
+    for (int i = 0; i < 9; ++i) rt[i] = R[i];
+    for (int i = 0; i < 3; ++i) rt[9 + i] = t[i];
+    // T <- T_i T with T_i = [[R, t], [0, 1]]
+    double Tn[16];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 4; ++b)
+        Tn[a * 4 + b] = R[a * 3 + 0] * Tc[0 * 4 + b] + R[a * 3 + 1] * Tc[1 * 4 + b] +
+                        R[a * 3 + 2] * Tc[2 * 4 + b] + t[a] * Tc[3 * 4 + b];
+    for (int b = 0; b < 4; ++b) Tn[12 + b] = Tc[12 + b];
+    for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double loss = 0.0;
+    for (int64_t c = 0; c < C; ++c) loss += acc2[c * 12 + 9];
+    st->loss = loss;
+    st->iters += 1;
+    if (st->last_error - loss < delta) st->countdown -= 1;
+    else st->countdown = 3;
+    if (st->countdown <= 0) st->done = 2;  // 2: this iteration's update still has to be applied
+    else st->last_error = loss;
+  }
+}
+
+// apply the iteration's (R, t) to every moving point; keeps the previous positions for the l1 pass
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
+                 const int32_t* __restrict__ comp, const double* __restrict__ Rt,
+                 const IcpState* __restrict__ st) {
+  if (st->done == 1) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mn) return;
+  float4 p = mov[i];
+  prev[i] = p;
+  const double* rt = Rt + (int64_t)comp[i] * 12;
+  double x = p.y, y = p.z, z = p.w;
+  float nx = (float)(x * rt[0] + y * rt[1] + z * rt[2] + rt[9]);
+  float ny = (float)(x * rt[3] + y * rt[4] + z * rt[5] + rt[10]);
+  float nz = (float)(x * rt[6] + y * rt[7] + z * rt[8] + rt[11]);
+  mov[i] = make_float4(p.x, nx, ny, nz);
+}
+
+__global__ void icp_latch_done_kernel(IcpState* st) {
+  if (threadIdx.x == 0 && st->done == 2) st->done = 1;
+}
+
+// coverage: moving points (final positions) with a reference point (stationary included) in range
+__global__ void __launch_bounds__(kBlock)
+icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref_all,
+                    const int32_t* __restrict__ comp, const GridDesc* __restrict__ gp, int df,
+                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ head,
+                    const int32_t* __restrict__ next, uint32_t hmask, const float* __restrict__ fr,
+                    int32_t* __restrict__ cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mn) return;
+  GridDesc g = *gp;
+  int r = nn_search(g, mov[i], df, ref_all, keys, head, next, hmask, fr);
+  if (r >= 0) atomicAdd(&cnt[comp[i]], 1);
+}
+
+__global__ void __launch_bounds__(kBlock)
+icp_finish_kernel(int64_t C, const double* __restrict__ acc1, const int32_t* __restrict__ cnt,
+                  const int64_t* __restrict__ comp_deg, double* __restrict__ l1,
+                  float* __restrict__ ratio) {
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    double n = acc1[c * 8];
+    l1[c] = n > 0.5 ? acc1[c * 8 + 7] / n : 0.0;
+    // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
+    ratio[c] = (float)cnt[c] / ((float)comp_deg[c] + 1e-6f);
+  }
+}
+
+}  // namespace pcs
+
+using namespace pcs;
+
+extern "C" {
+
+int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
+
+size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_t Ra, int64_t C) {
+  Arena a(nullptr, 0);
+  IcpBufs b;
+  plan_icp(a, Mn, Rn, Ra, C, b);
+  return a.off;
+}
+
+// BLOCKING (the one entry point that synchronises the stream: the reference reads the loss on the
+// host every iteration, this reads one flag per `chunk` iterations).
+//   mov_fxyz [Mn,4]  non-stationary moving points, updated in place
+//   mov_comp [Mn]    int32 component of each moving point, in [0, C)
+//   ref_fxyz [Rn,4]  non-stationary reference points; ref_all [Ra,4] all reference points
+//   comp_deg [C]     int64 number of moving points (stationary included) per component
+//   T [C,16] f64 out; l1_err [C] f64 out (last iteration); edge_ratio [C] f32 out
+//   info[4] host out: iterations run, stop reason (1 = countdown, 0 = max_iter), 0, 0
+int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
+                               const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
+                               const int64_t* comp_deg, int64_t C, double radius, int frame_offset,
+                               double angle_regularizer, int max_iter, double stopping_delta,
+                               float cell_size, int chunk, double* T, double* l1_err,
+                               float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
+                               hipStream_t s) {
+  if (!T || !l1_err || !edge_ratio || !ws || !info || C < 1 || Mn < 0 || Rn < 0 || Ra < 0 ||
+      !comp_deg || !(radius > 0) || max_iter < 0 || (Mn > 0 && (!mov_fxyz || !mov_comp)) ||
+      (Rn > 0 && !ref_fxyz) || (Ra > 0 && !ref_all))
+    return PCS_ERR_ARG;
+  if (Mn + Rn >= (1LL << 30)) return PCS_ERR_RANGE;
+  Arena a(ws, ws_bytes);
+  IcpBufs b;
+  if (!plan_icp(a, Mn, Rn, Ra, C, b)) return PCS_ERR_WORKSPACE;
+  // graph.radius = (radius^2 + frame_offset^2) ** 0.5, handed to the kernel as fp32
+  float rad = (float)sqrt(radius * radius + (double)frame_offset * (double)frame_offset);
+  float cell = cell_size > 0.f ? cell_size : (float)radius * 0.25f;
+  float pad = 4.f * (float)radius + 16.f;
+  if (chunk < 1) chunk = 8;
+
+  static const float inf8[8] = {1e30f, 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f, -1e30f};
+  auto bounds = [&](const float* p, int64_t n, float* out) -> int {
+    if (n > 0) return pcs_minmax4_f32(p, n, out, s);
+    return hipMemcpyAsync(out, inf8, sizeof(inf8), hipMemcpyHostToDevice, s) == hipSuccess ? PCS_OK : PCS_ERR_HIP;
+  };
+  int rc;
+  if ((rc = bounds(ref_fxyz, Rn, b.b_ref))) return rc;
+  if ((rc = bounds(mov_fxyz, Mn, b.b_mov))) return rc;
+  if ((rc = bounds(ref_all, Ra, b.b_all))) return rc;
+  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
+  icp_init_T_kernel<<<grid_for(C * 16), kBlock, 0, s>>>(T, C);
+  PCS_CHECK_HIP(hipMemsetAsync(b.acc1, 0, (size_t)C * 8 * sizeof(double), s));
+  PCS_CHECK_HIP(hipMemsetAsync(b.acc2, 0, (size_t)C * 12 * sizeof(double), s));
+  PCS_CHECK_HIP(hipMemsetAsync(b.cnt, 0, (size_t)C * sizeof(int32_t), s));
+  // static grids: non-stationary reference, all reference
+  auto build_static = [&](const float* pts, int64_t n, uint64_t* keys, int32_t* head, int32_t* next,
+                          uint32_t H, float* fr) -> int {
+    PCS_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)H * sizeof(uint64_t), s));
+    PCS_CHECK_HIP(hipMemsetAsync(head, 0xFF, (size_t)H * sizeof(int32_t), s));
+    frame_range_init_kernel<<<4, kBlock, 0, s>>>(fr);
+    if (n > 0)
+      grid_insert_kernel<<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+          (const float4*)pts, (int)n, b.grid, keys, head, next, H - 1, fr, &b.state->err);
+    return PCS_OK;
+  };
+  if ((rc = build_static(ref_fxyz, Rn, b.keys_r, b.head_r, b.next_r, b.Hr, b.fr_r))) return rc;
+  if ((rc = build_static(ref_all, Ra, b.keys_a, b.head_a, b.next_a, b.Ha, b.fr_a))) return rc;
+
+  int nb_m = (int)((Mn + kBlock - 1) / kBlock);
+  if (nb_m < 1) nb_m = 1;
+  int nb_e = (int)((Mn + Rn + kBlock - 1) / kBlock);
+  if (nb_e < 1) nb_e = 1;
+  IcpState host;
+  host.done = 0;
+  host.iters = 0;
+  host.err = 0;
+  int it = 0;
+  while (it < max_iter) {
+    int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
+    for (int k = 0; k < n_it; ++k) {
+      PCS_CHECK_HIP(hipMemsetAsync(b.keys_m, 0xFF, (size_t)b.Hm * sizeof(uint64_t), s));
+      PCS_CHECK_HIP(hipMemsetAsync(b.head_m, 0xFF, (size_t)b.Hm * sizeof(int32_t), s));
+      frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.fr_m);
+      icp_insert_moving_kernel<<<nb_m, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn, b.grid,
+                                                       b.keys_m, b.head_m, b.next_m, b.Hm - 1,
+                                                       b.fr_m, b.state, b.acc1, b.acc2, C);
+      icp_nn_pass1_kernel<<<nb_e, kBlock, 0, s>>>(
+          (const float4*)mov_fxyz, (int)Mn, (const float4*)ref_fxyz, (int)Rn, mov_comp, b.grid,
+          frame_offset, b.keys_r, b.head_r, b.next_r, b.Hr - 1, b.fr_r, b.keys_m, b.head_m,
+          b.next_m, b.Hm - 1, b.fr_m, b.state, b.nn_f, b.nn_b, b.acc1);
+      icp_pass2_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
+                                                  (const float4*)ref_fxyz, (int)Rn, mov_comp,
+                                                  b.nn_f, b.nn_b, b.state, b.acc1, b.acc2, nullptr, 0.0);
+      icp_solve_kernel<<<1, 1024, 0, s>>>(C, angle_regularizer, stopping_delta, b.acc1, b.acc2, T,
+                                          b.Rt, b.state);
+      icp_apply_kernel<<<nb_m, kBlock, 0, s>>>((float4*)mov_fxyz, (float4*)b.prev, (int)Mn, mov_comp,
+                                               b.Rt, b.state);
+      icp_latch_done_kernel<<<1, 64, 0, s>>>(b.state);
+    }
+    it += n_it;
+    PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+    if (host.err) return PCS_ERR_RANGE;
+    if (host.done) break;
+  }
+  info[0] = host.iters;
+  info[1] = host.done ? 1 : 0;
+  info[2] = info[3] = 0;
+  if (host.iters > 0) {
+    // l1 error of the last iteration: positions before its update are in `prev`
+    icp_pass2_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn,
+                                                (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
+                                                b.nn_b, b.state, b.acc1, b.acc2, b.acc1 + 7, 0.3);
+  }
+  if (Mn > 0 && Ra > 0)
+    icp_coverage_kernel<<<nb_m, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
+                                                (const float4*)ref_all, mov_comp, b.grid,
+                                                frame_offset, b.keys_a, b.head_a, b.next_a,
+                                                b.Ha - 1, b.fr_a, b.cnt);
+  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, b.acc1, b.cnt, comp_deg, l1_err, edge_ratio);
+  PCS_LAUNCH_CHECK();
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  return PCS_OK;
+}
+
+}  // extern "C"

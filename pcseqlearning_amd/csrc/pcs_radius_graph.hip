@@ -1,0 +1,429 @@
+// Radius graph (the pairwise point-correspondence primitive of the whole pipeline) for gfx950.
+//
+// Reference: pcdet/ops/torch_hash/src/torch_hash_kernel.cu (hash_insert_gpu_kernel :54-91,
+// count_radius_graph_degree_kernel :224-288, radius_graph_kernel :290-409, host wrappers :411-561)
+// driven by RadiusGraph.build_graph, pcdet/models/model_utils/graph_utils.py:149-209.
+//
+// What the reference computes (restated): with cell size = radius the 3x3x3
+// cell walk covers the whole ball, so for every query the candidate set is exactly
+//   { ref i : framecell(ref i) == framecell(query) + df, df in [qmin0, qmax0],
+//             dist2 = sum_{d=0..3} (ref_d - query_d)^2 (fp32, d ascending)  <=  radius^2 }
+// and the output keeps the max_nbr nearest (sort_by_dist) in ascending dist2. The reference's
+// tie order depends on an atomicCAS race; the canonical rule here is (dist2, ref index) ascending.
+//
+// Two implementations live in this file:
+//  1. pcs_radius_graph_*: the engine used by the host-side RadiusGraph module. It does NOT walk
+//     radius-sized cells: reference points are chained into an open-addressing table of FINER cells
+//     (cell size h <= radius) and every query runs an expanding-ring search that stops as soon as
+//     the ring's lower-bound distance exceeds its current k-th best. Same edges, a fraction of the
+//     distance evaluations (1-NN at radius 2.5 m over 0.4 m voxels examines tens of candidates
+//     instead of thousands). One search pass (no count pass + fill pass re-walk): per-query top-k
+//     lives in LDS, results are compacted by an exclusive scan of the degrees.
+//  2. pcs_hash_insert / pcs_radius_graph_table_*: literal drop-ins for the reference's
+//     torch_hash_cuda entry points on the reference's own table layout (keys/values/reverse,
+//     caller-allocated), for callers that bind at the pcdet/ops/torch_hash level.
+#include "pcs_grid.hpp"
+
+namespace pcs {
+
+constexpr int kMaxK = 32;
+
+// Per-query top-K (sorted ascending by (key, idx)) kept in LDS columns: element e of thread t at
+// [e * BLOCK + t] -> consecutive lanes hit consecutive banks.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ qry, int M,
+                     const GridDesc* __restrict__ gp, const uint64_t* __restrict__ keys,
+                     const int32_t* __restrict__ head, const int32_t* __restrict__ next,
+                     uint32_t hmask, const float* __restrict__ fr, int df_min, int df_max, int K,
+                     int sort_by_dist, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d,
+                     int32_t* __restrict__ deg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* sd = (float*)smem;
+  int* si = (int*)(smem + (size_t)K * BLOCK * sizeof(float));
+  int t = threadIdx.x;
+  int q = blockIdx.x * BLOCK + t;
+  if (q >= M) return;
+  GridDesc g = *gp;
+  float4 p = qry[q];
+  int fq = frame_cell(g, p.x);
+  int cx = (int)floorf((p.y - g.lo[0]) / g.h);
+  int cy = (int)floorf((p.z - g.lo[1]) / g.h);
+  int cz = (int)floorf((p.w - g.lo[2]) / g.h);
+  int cnt = 0;
+  const float margin = 1e-5f * g.radius2 + 1e-6f;
+  for (int df = df_min; df <= df_max; ++df) {
+    int fc = fq + df;
+    if (fc < 0 || fc >= kFrameCells) continue;
+    float fa = fr[fc], fb = fr[kFrameCells + fc];
+    if (fa > fb) continue;  // no reference point in this frame cell
+    // xyz budget: dist2 = dframe^2 + |dxyz|^2 and |dframe| >= distance from the query's frame
+    // value to the range of frame values present in the cell
+    float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+    float dfsq = dfl * dfl;
+    for (int s = 0; s <= g.rings; ++s) {
+      if (s >= 1) {
+        float lb = (float)(s - 1) * g.h;
+        float bound = (sort_by_dist && cnt == K) ? sd[(K - 1) * BLOCK + t] : g.radius2;
+        if (lb * lb > bound - dfsq + margin) break;
+      }
+      for (int dz = -s; dz <= s; ++dz) {
+        int z = cz + dz;
+        if (z < 0 || z >= kCoordMax) continue;
+        for (int dy = -s; dy <= s; ++dy) {
+          int y = cy + dy;
+          if (y < 0 || y >= kCoordMax) continue;
+          bool shell = (dz == -s || dz == s || dy == -s || dy == s);
+          int step = shell ? 1 : (s > 0 ? 2 * s : 1);
+          for (int dx = -s; dx <= s; dx += step) {
+            int x = cx + dx;
+            if (x < 0 || x >= kCoordMax) continue;
+            int j = grid_head(keys, head, hmask, pack_cell(fc, x, y, z));
+            while (j >= 0) {
+              float4 c = ref[j];
+              // torch_hash_kernel.cu:364-368: dims 0..3 in order, starting from 0
+              float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+              float dist2 = 0.f;
+              dist2 = dist2 + d0 * d0;
+              dist2 = dist2 + d1 * d1;
+              dist2 = dist2 + d2 * d2;
+              dist2 = dist2 + d3 * d3;
+              if (dist2 <= g.radius2) {
+                float key = sort_by_dist ? dist2 : 0.f;
+                // position among the kept ones: strict (key, idx) order
+                int pos = cnt;
+                while (pos > 0) {
+                  float kd = sd[(pos - 1) * BLOCK + t];
+                  int ki = si[(pos - 1) * BLOCK + t];
+                  bool less = (key < kd) || (key == kd && j < ki);
+                  if (!less) break;
+                  if (pos < K) {
+                    sd[pos * BLOCK + t] = kd;
+                    si[pos * BLOCK + t] = ki;
+                  }
+                  --pos;
+                }
+                if (pos < K) {
+                  sd[pos * BLOCK + t] = key;
+                  si[pos * BLOCK + t] = j;
+                  if (cnt < K) ++cnt;
+                }
+              }
+              j = next[j];
+            }
+          }
+        }
+      }
+    }
+  }
+  deg[q] = cnt;
+  for (int e = 0; e < cnt; ++e) {
+    nbr_idx[(int64_t)q * K + e] = si[e * BLOCK + t];
+    if (nbr_d) nbr_d[(int64_t)q * K + e] = sd[e * BLOCK + t];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+edge_total_kernel(const int32_t* __restrict__ deg, const int32_t* __restrict__ off, int M,
+                  const int32_t* __restrict__ err, int64_t* __restrict__ d_num) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t e = M > 0 ? (int64_t)off[M - 1] + deg[M - 1] : 0;
+    if (err && *err) e = -1;  // fine-cell coordinates overflowed: the caller must not use the result
+    *d_num = e;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+edge_emit_kernel(const int32_t* __restrict__ nbr_idx, const float* __restrict__ nbr_d,
+                 const int32_t* __restrict__ deg, const int32_t* __restrict__ off, int M, int K,
+                 int64_t* __restrict__ e_ref, int64_t* __restrict__ e_qry,
+                 float* __restrict__ dists) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < M; q += gridDim.x * blockDim.x) {
+    int n = deg[q], o = off[q];
+    for (int e = 0; e < n; ++e) {
+      e_ref[o + e] = nbr_idx[(int64_t)q * K + e];
+      e_qry[o + e] = q;
+      if (dists) dists[o + e] = nbr_d[(int64_t)q * K + e];
+    }
+  }
+}
+
+struct RadiusPlan {
+  GridDesc* grid;
+  float *b_ref, *b_qry;
+  uint64_t* keys;
+  int32_t *head, *next, *nbr_idx, *deg, *off, *err;
+  float *nbr_d, *fr;
+  void* tmp;
+  size_t tmp_bytes;
+  uint32_t H;
+};
+
+static inline uint32_t pow2_ge(uint64_t x) {
+  uint32_t h = 64;
+  while (h < x) h <<= 1;
+  return h;
+}
+
+static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
+  if (N < 1) N = 1;
+  if (M < 1) M = 1;
+  p.grid = a.take<GridDesc>(1);
+  p.b_ref = a.take<float>(8);
+  p.b_qry = a.take<float>(8);
+  p.err = a.take<int32_t>(1);
+  p.fr = a.take<float>(2 * kFrameCells);
+  p.H = pow2_ge(2 * (uint64_t)N);
+  p.keys = a.take<uint64_t>(p.H);
+  p.head = a.take<int32_t>(p.H);
+  p.next = a.take<int32_t>(N);
+  p.nbr_idx = a.take<int32_t>(M * K);
+  p.nbr_d = a.take<float>(M * K);
+  p.deg = a.take<int32_t>(M);
+  p.off = a.take<int32_t>(M);
+  p.tmp_bytes = scan_i32_temp_bytes(M);
+  p.tmp = a.take<char>(p.tmp_bytes);
+  return a.ok();
+}
+
+// ------------------------------------------------------------------------------------------
+// Literal torch_hash drop-ins on the reference table layout
+// (keys[H] i64 = -1 empty, values[H,D] f32, reverse[H] i64; H = int(N / 0.5) chosen by the caller).
+__device__ __forceinline__ int64_t ref_map2key(const int64_t* c, const int64_t* dims, int D) {
+  int64_t ans = 0;
+  for (int i = 0; i < D; ++i) {
+    int64_t k = c[i];
+    if (k >= dims[i]) k = dims[i];  // torch_hash_kernel.cu:36-38 clamps to dims[i], not dims[i]-1
+    if (k < 0) k = 0;
+    ans = ans * dims[i] + k;
+  }
+  return ans;
+}
+__device__ __forceinline__ int64_t ref_hashkey(int64_t key, int64_t H) {
+  return ((key % H) * 999269 + 999437) % H;  // torch_hash_kernel.cu:27-28,49-51
+}
+
+__global__ void __launch_bounds__(kBlock)
+table_insert_kernel(int64_t* __restrict__ keys, float* __restrict__ values,
+                    int64_t* __restrict__ reverse, int64_t H, const int64_t* __restrict__ dims,
+                    int D, const int64_t* __restrict__ ikeys, const float* __restrict__ ivals,
+                    int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t c[8];
+  for (int d = 0; d < D; ++d) c[d] = ikeys[i * D + d];
+  int64_t key = ref_map2key(c, dims, D);
+  int64_t slot = ref_hashkey(key, H);
+  // every point takes its own slot (duplicates are not merged), torch_hash_kernel.cu:72-80
+  while (atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)(-1LL),
+                   (unsigned long long)key) != (unsigned long long)(-1LL))
+    slot = (slot + 1) % H;
+  for (int d = 0; d < D; ++d) values[slot * D + d] = ivals[i * D + d];
+  reverse[slot] = i;
+}
+
+// One walk per query over the reference's cell combinations (dim 0 fastest), MODE 0 = count,
+// 1 = fill (sorted or first-come by ascending (walk order is racy in the reference -> canonical:
+// (dist2, ref index) when sorted, ref index when not)).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+table_walk_kernel(const int64_t* __restrict__ keys, const float* __restrict__ values,
+                  const int64_t* __restrict__ reverse, int64_t H, const int64_t* __restrict__ dims,
+                  int D, const int64_t* __restrict__ qkeys, const float* __restrict__ qvals,
+                  int64_t M, const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax,
+                  const float* __restrict__ radius, int max_nbr, int sort_by_dist,
+                  int32_t* __restrict__ degree, const int32_t* __restrict__ offset,
+                  int64_t* __restrict__ edges, float* __restrict__ dists) {
+  int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  int w[8], ncomb = 1;
+  for (int d = 0; d < D; ++d) { w[d] = qmax[d] - qmin[d] + 1; ncomb *= w[d]; }
+  float r = radius[q], r2 = r * r;
+  int cap = (MODE == 1) ? degree[q] : max_nbr;
+  int cnt = 0;
+  int64_t* eptr = (MODE == 1) ? edges + (int64_t)offset[q] * 2 : nullptr;
+  float* dptr = (MODE == 1) ? dists + offset[q] : nullptr;
+  for (int c = 0; c < ncomb; ++c) {
+    int64_t cc[8];
+    int tmp = c;
+    for (int d = 0; d < D; ++d) { cc[d] = qkeys[q * D + d] + (tmp % w[d] + qmin[d]); tmp /= w[d]; }
+    int64_t key = ref_map2key(cc, dims, D);
+    int64_t slot = ref_hashkey(key, H);
+    while (keys[slot] != -1) {
+      if (keys[slot] == key) {
+        float dist2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+          float di = values[slot * D + d] - qvals[q * D + d];
+          dist2 = dist2 + di * di;
+        }
+        if (dist2 <= r2) {
+          if (MODE == 0) {
+            if (max_nbr == -1 || cnt < max_nbr) ++cnt;
+          } else {
+            int64_t ridx = reverse[slot];
+            float kkey = sort_by_dist ? dist2 : 0.f;
+            int pos = cnt;
+            while (pos > 0) {
+              float kd = sort_by_dist ? dptr[pos - 1] : 0.f;
+              int64_t ki = eptr[(pos - 1) * 2];
+              bool less = (kkey < kd) || (kkey == kd && ridx < ki);
+              if (!less) break;
+              if (pos < cap) { dptr[pos] = dptr[pos - 1]; eptr[pos * 2] = ki; eptr[pos * 2 + 1] = q; }
+              --pos;
+            }
+            if (pos < cap) {
+              eptr[pos * 2] = ridx;
+              eptr[pos * 2 + 1] = q;
+              dptr[pos] = dist2;
+              if (cnt < cap) ++cnt;
+            }
+          }
+        }
+      }
+      slot = (slot + 1) % H;
+    }
+  }
+  if (MODE == 0) degree[q] = cnt;
+}
+
+}  // namespace pcs
+
+using namespace pcs;
+
+extern "C" {
+
+int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
+
+size_t pcs_radius_graph_workspace_bytes(int64_t N, int64_t M, int max_nbr) {
+  Arena a(nullptr, 0);
+  RadiusPlan p;
+  int K = max_nbr < 1 ? 1 : (max_nbr > kMaxK ? kMaxK : max_nbr);
+  plan_radius(a, N, M, K, p);
+  return a.off;
+}
+
+// Phase 1: grid build + search + degree scan. *d_num_edges = E (or -1 if the extent / cell_size
+// ratio overflowed the 17-bit fine-cell coordinates: discard and retry with a larger cell).
+// cell_size <= 0 picks radius/2.
+int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int64_t M,
+                            float radius, float cell_size, int dframe_min, int dframe_max,
+                            int max_nbr, int sort_by_dist, int64_t* d_num_edges, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
+  if (!d_num_edges || !ws || N < 0 || M < 0 || (N > 0 && !ref) || (M > 0 && !query) ||
+      !(radius > 0.f) || dframe_min > dframe_max)
+    return PCS_ERR_ARG;
+  if (max_nbr < 1 || max_nbr > kMaxK) return PCS_ERR_ARG;  // unbounded / >32: table_* entry points
+  if (N >= (1LL << 30) || M >= (1LL << 30) || M * (int64_t)max_nbr >= (1LL << 31)) return PCS_ERR_RANGE;
+  if (N == 0 || M == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num_edges, 0, sizeof(int64_t), s)); return PCS_OK; }
+  int K = max_nbr;
+  Arena a(ws, ws_bytes);
+  RadiusPlan p;
+  if (!plan_radius(a, N, M, K, p)) return PCS_ERR_WORKSPACE;
+  float cell = cell_size > 0.f ? cell_size : radius * 0.5f;
+  if (cell > radius) cell = radius;
+  int rc = pcs_minmax4_f32(ref, N, p.b_ref, s);
+  if (rc) return rc;
+  rc = pcs_minmax4_f32(query, M, p.b_qry, s);
+  if (rc) return rc;
+  grid_setup_kernel<<<1, 64, 0, s>>>(p.b_ref, p.b_qry, radius, cell, p.grid);
+  PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
+  PCS_CHECK_HIP(hipMemsetAsync(p.head, 0xFF, (size_t)p.H * sizeof(int32_t), s));
+  PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
+  uint32_t hmask = p.H - 1;
+  frame_range_init_kernel<<<4, kBlock, 0, s>>>(p.fr);
+  grid_insert_kernel<<<(int)((N + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      (const float4*)ref, (int)N, p.grid, p.keys, p.head, p.next, hmask, p.fr, p.err);
+  if (K <= 8) {
+    constexpr int B = 256;
+    size_t sh = (size_t)K * B * 8;
+    radius_search_kernel<B><<<(int)((M + B - 1) / B), B, sh, s>>>(
+        (const float4*)ref, (const float4*)query, (int)M, p.grid, p.keys, p.head, p.next, hmask,
+        p.fr, dframe_min, dframe_max, K, sort_by_dist, p.nbr_idx, p.nbr_d, p.deg);
+  } else {
+    constexpr int B = 128;
+    size_t sh = (size_t)K * B * 8;
+    radius_search_kernel<B><<<(int)((M + B - 1) / B), B, sh, s>>>(
+        (const float4*)ref, (const float4*)query, (int)M, p.grid, p.keys, p.head, p.next, hmask,
+        p.fr, dframe_min, dframe_max, K, sort_by_dist, p.nbr_idx, p.nbr_d, p.deg);
+  }
+  rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
+  if (rc) return rc;
+  edge_total_kernel<<<1, 64, 0, s>>>(p.deg, p.off, (int)M, p.err, d_num_edges);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// Phase 2: write the E edges found by the search still held in `ws` (same N, M, max_nbr).
+// e_ref[E], e_query[E] int64; dists[E] (squared, as the reference's dists buffer) may be NULL.
+int pcs_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query,
+                          float* dists, const void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!ws || M < 0 || max_nbr < 1 || max_nbr > kMaxK) return PCS_ERR_ARG;
+  if (M == 0 || N == 0) return PCS_OK;
+  if (!e_ref || !e_query) return PCS_ERR_ARG;
+  Arena a((void*)ws, ws_bytes);
+  RadiusPlan p;
+  if (!plan_radius(a, N, M, max_nbr, p)) return PCS_ERR_WORKSPACE;
+  edge_emit_kernel<<<grid_for(M), kBlock, 0, s>>>(p.nbr_idx, p.nbr_d, p.deg, p.off, (int)M, max_nbr,
+                                                  e_ref, e_query, dists);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// ---- torch_hash_cuda drop-ins (pcdet/ops/torch_hash/src/torch_hash_api.cpp:9-15) ----------
+int pcs_hash_insert(int64_t* keys, float* values, int64_t* reverse, int64_t H, const int64_t* dims,
+                    int D, const int64_t* insert_keys, const float* insert_values, int64_t n,
+                    hipStream_t s) {
+  if (!keys || !values || !reverse || !dims || H < 1 || D < 1 || D > 8 || n < 0) return PCS_ERR_ARG;
+  if (n == 0) return PCS_OK;
+  if (!insert_keys || !insert_values || n > H) return PCS_ERR_ARG;  // n > H would never terminate
+  table_insert_kernel<<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      keys, values, reverse, H, dims, D, insert_keys, insert_values, n);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+size_t pcs_radius_graph_table_workspace_bytes(int64_t M) { return scan_i32_temp_bytes(M > 0 ? M : 1); }
+
+// radius_graph_gpu phase 1 (count_radius_graph_degree_kernel + cumsum): degree[M], offset[M],
+// *d_num_edges.
+int pcs_radius_graph_table_count(const int64_t* keys, const float* values, const int64_t* reverse,
+                                 int64_t H, const int64_t* dims, int D, const int64_t* query_keys,
+                                 const float* query_values, int64_t M, const int32_t* qmin,
+                                 const int32_t* qmax, const float* radius, int max_nbr,
+                                 int32_t* degree, int32_t* offset, int64_t* d_num_edges, void* ws,
+                                 size_t ws_bytes, hipStream_t s) {
+  if (!keys || !values || !reverse || !dims || !qmin || !qmax || !radius || !degree || !offset ||
+      !d_num_edges || !ws || D < 1 || D > 8 || M < 0 || H < 1)
+    return PCS_ERR_ARG;
+  if (M == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num_edges, 0, sizeof(int64_t), s)); return PCS_OK; }
+  if (ws_bytes < scan_i32_temp_bytes(M)) return PCS_ERR_WORKSPACE;
+  table_walk_kernel<0><<<(int)((M + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      keys, values, reverse, H, dims, D, query_keys, query_values, M, qmin, qmax, radius, max_nbr,
+      0, degree, nullptr, nullptr, nullptr);
+  int rc = exclusive_scan_i32(ws, ws_bytes, degree, offset, M, s);
+  if (rc) return rc;
+  edge_total_kernel<<<1, 64, 0, s>>>(degree, offset, (int)M, nullptr, d_num_edges);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// radius_graph_gpu phase 2 (radius_graph_kernel): edges [E,2] int64 (ref, query), dists [E].
+int pcs_radius_graph_table_fill(const int64_t* keys, const float* values, const int64_t* reverse,
+                                int64_t H, const int64_t* dims, int D, const int64_t* query_keys,
+                                const float* query_values, int64_t M, const int32_t* qmin,
+                                const int32_t* qmax, const float* radius, int sort_by_dist,
+                                const int32_t* degree, const int32_t* offset, int64_t* edges,
+                                float* dists, hipStream_t s) {
+  if (!keys || !values || !reverse || !dims || !qmin || !qmax || !radius || !degree || !offset ||
+      D < 1 || D > 8 || M < 0 || H < 1)
+    return PCS_ERR_ARG;
+  if (M == 0) return PCS_OK;
+  if (!edges || !dists) return PCS_ERR_ARG;
+  table_walk_kernel<1><<<(int)((M + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      keys, values, reverse, H, dims, D, query_keys, query_values, M, qmin, qmax, radius, 0,
+      sort_by_dist, (int32_t*)degree, offset, edges, dists);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+}  // extern "C"

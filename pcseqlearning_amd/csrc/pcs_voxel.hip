@@ -21,16 +21,6 @@ __global__ void minmax4_init_kernel(float* out8) {
   else if (t < 8) out8[t] = -__builtin_inff();
 }
 
-// float atomics on ordered-int views: valid for non-NaN input.
-__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
-  if (v >= 0.f) atomicMin((int*)addr, __float_as_int(v));
-  else atomicMax((unsigned int*)addr, __float_as_uint(v));
-}
-__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
-  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
-  else atomicMin((unsigned int*)addr, __float_as_uint(v));
-}
-
 __global__ void __launch_bounds__(kBlock) minmax4_kernel(const float4* __restrict__ pts, int64_t n,
                                                          float* out8) {
   float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};

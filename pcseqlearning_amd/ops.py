@@ -207,3 +207,148 @@ def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=Fals
                                     L.ptr(out), L.ptr(ws), L.i64(ws.numel()), L.stream()),
             "pcs_indice_conv_f32")
     return out
+
+
+# ---------------------------------------------------------------- radius graph
+def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, dframe_min=0, dframe_max=0,
+                 cell_size=0.0, want_dists=False):
+    """Edges (e_ref, e_query) int64 of RadiusGraph.build_graph (graph_utils.py:149-209):
+    grouped by ascending query, within a query ascending (dist2, ref index). One host sync (E)."""
+    L.require_gpu(ref, "radius_graph")
+    lib = L.load()
+    ref = ref.float().contiguous()
+    query = query.float().contiguous()
+    N, M = ref.shape[0], query.shape[0]
+    dev = ref.device
+    d_num = _dev_scalar(dev)
+    nbytes = lib.pcs_radius_graph_workspace_bytes(L.i64(N), L.i64(M), L.i32(max_nbr))
+    ws = L.workspace(nbytes, dev)
+    L.check(lib.pcs_radius_graph_search(L.ptr(ref), L.i64(N), L.ptr(query), L.i64(M), L.f32(radius),
+                                        L.f32(cell_size), L.i32(dframe_min), L.i32(dframe_max),
+                                        L.i32(max_nbr), L.i32(int(sort_by_dist)), L.ptr(d_num),
+                                        L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_radius_graph_search")
+    E = int(d_num.item())
+    if E < 0:
+        raise L.PcsError("radius_graph: extent / cell_size exceeds the 17-bit cell range")
+    e_ref = torch.empty(E, dtype=torch.int64, device=dev)
+    e_query = torch.empty(E, dtype=torch.int64, device=dev)
+    dists = torch.empty(E, dtype=torch.float32, device=dev) if want_dists else None
+    if E > 0:
+        L.check(lib.pcs_radius_graph_emit(L.i64(N), L.i64(M), L.i32(max_nbr), L.ptr(e_ref),
+                                          L.ptr(e_query), L.ptr(dists), L.ptr(ws),
+                                          L.i64(ws.numel()), L.stream()), "pcs_radius_graph_emit")
+    if want_dists:
+        return e_ref, e_query, dists
+    return e_ref, e_query
+
+
+def hash_insert_gpu(keys, values, reverse_indices, dims, insert_keys, insert_values):
+    """torch_hash_cuda.hash_insert_gpu (torch_hash_kernel.cu:411-442), same argument order."""
+    L.require_gpu(keys, "hash_insert_gpu")
+    lib = L.load()
+    D = insert_values.shape[1]
+    L.check(lib.pcs_hash_insert(L.ptr(keys), L.ptr(values), L.ptr(reverse_indices),
+                                L.i64(keys.shape[0]), L.ptr(dims.contiguous()), L.i32(D),
+                                L.ptr(insert_keys.contiguous()), L.ptr(insert_values.contiguous()),
+                                L.i64(insert_keys.shape[0]), L.stream()), "pcs_hash_insert")
+
+
+def radius_graph_gpu(keys, values, reverse_indices, dims, query_keys, query_values, qmin, qmax,
+                     radius, max_num_neighbors, sort_by_dist):
+    """torch_hash_cuda.radius_graph_gpu (torch_hash_kernel.cu:487-561): returns edges [E,2]."""
+    L.require_gpu(keys, "radius_graph_gpu")
+    lib = L.load()
+    M, D = query_values.shape
+    dev = keys.device
+    degree = torch.empty(M, dtype=torch.int32, device=dev)
+    offset = torch.empty(M, dtype=torch.int32, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_radius_graph_table_workspace_bytes(L.i64(M)), dev)
+    args = (L.ptr(keys), L.ptr(values), L.ptr(reverse_indices), L.i64(keys.shape[0]),
+            L.ptr(dims.contiguous()), L.i32(D), L.ptr(query_keys.contiguous()),
+            L.ptr(query_values.contiguous()), L.i64(M), L.ptr(qmin.contiguous()),
+            L.ptr(qmax.contiguous()), L.ptr(radius.contiguous()))
+    L.check(lib.pcs_radius_graph_table_count(*args, L.i32(max_num_neighbors), L.ptr(degree),
+                                             L.ptr(offset), L.ptr(d_num), L.ptr(ws),
+                                             L.i64(ws.numel()), L.stream()),
+            "pcs_radius_graph_table_count")
+    E = int(d_num.item())
+    edges = torch.zeros(E, 2, dtype=torch.int64, device=dev)
+    dists = torch.zeros(E, dtype=torch.float32, device=dev)
+    if E == 0:
+        return edges
+    L.check(lib.pcs_radius_graph_table_fill(*args, L.i32(int(sort_by_dist)), L.ptr(degree),
+                                            L.ptr(offset), L.ptr(edges), L.ptr(dists), L.stream()),
+            "pcs_radius_graph_table_fill")
+    return edges
+
+
+# ---------------------------------------------------------------- components / medians
+def connected_components(e0, e1, num_nodes):
+    """graph_utils.connected_components: (num_components, component [N] int64)."""
+    L.require_gpu(e0, "connected_components")
+    lib = L.load()
+    dev = e0.device
+    comp = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_connected_components_workspace_bytes(L.i64(num_nodes)), dev)
+    L.check(lib.pcs_connected_components(L.ptr(e0.contiguous()), L.ptr(e1.contiguous()),
+                                         L.i64(e0.shape[0]), L.i64(num_nodes), L.ptr(comp),
+                                         L.ptr(d_num), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_connected_components")
+    return int(d_num.item()), comp
+
+
+def segment_median(data, seg):
+    lib = L.load()
+    data = data.long().contiguous()
+    out = torch.empty(seg.num, dtype=torch.int64, device=data.device)
+    L.check(lib.pcs_segment_median_i64(L.ptr(data), L.ptr(seg.order), L.ptr(seg.seg_start),
+                                       L.i64(seg.num), L.ptr(out), L.stream()),
+            "pcs_segment_median_i64")
+    return out
+
+
+def segment_minmax(data, seg, is_max=True):
+    lib = L.load()
+    squeeze = data.dim() == 1
+    d2 = data.reshape(data.shape[0], -1).float().contiguous()
+    out = torch.empty(seg.num, d2.shape[1], dtype=torch.float32, device=data.device)
+    L.check(lib.pcs_segment_minmax_f32(L.ptr(d2), L.i32(d2.shape[1]), L.ptr(seg.order),
+                                       L.ptr(seg.seg_start), L.i64(seg.num), L.i32(int(is_max)),
+                                       L.ptr(out), L.stream()), "pcs_segment_minmax_f32")
+    return out[:, 0] if squeeze else out
+
+
+# ---------------------------------------------------------------- registration
+def register_to_next_frame(mov_fxyz, mov_comp, ref_fxyz, ref_all, comp_deg, num_components, radius,
+                           frame_offset, angle_regularizer=10.0, max_iter=80, stopping_delta=5e-2,
+                           cell_size=0.0, chunk=8):
+    """Fused ICP of registration_utils.register_to_next_frame on the non-stationary subsets.
+    mov_fxyz is updated in place. Returns (T [C,4,4] f64, l1_err [C] f64, edge_ratio [C] f32,
+    iterations)."""
+    import ctypes
+    L.require_gpu(mov_fxyz, "register_to_next_frame")
+    lib = L.load()
+    dev = mov_fxyz.device
+    assert mov_fxyz.is_contiguous() and mov_fxyz.dtype == torch.float32
+    comp32 = mov_comp.int().contiguous()
+    ref_fxyz = ref_fxyz.float().contiguous()
+    ref_all = ref_all.float().contiguous()
+    C = int(num_components)
+    T = torch.empty(C, 4, 4, dtype=torch.float64, device=dev)
+    l1 = torch.empty(C, dtype=torch.float64, device=dev)
+    ratio = torch.empty(C, dtype=torch.float32, device=dev)
+    info = (ctypes.c_int32 * 4)()
+    Mn, Rn, Ra = mov_fxyz.shape[0], ref_fxyz.shape[0], ref_all.shape[0]
+    ws = L.workspace(lib.pcs_register_to_next_frame_workspace_bytes(L.i64(Mn), L.i64(Rn), L.i64(Ra),
+                                                                    L.i64(C)), dev)
+    L.check(lib.pcs_register_to_next_frame(
+        L.ptr(mov_fxyz), L.ptr(comp32), L.i64(Mn), L.ptr(ref_fxyz), L.i64(Rn), L.ptr(ref_all),
+        L.i64(Ra), L.ptr(comp_deg.long().contiguous()), L.i64(C), ctypes.c_double(radius),
+        L.i32(frame_offset), ctypes.c_double(angle_regularizer), L.i32(max_iter),
+        ctypes.c_double(stopping_delta), L.f32(cell_size), L.i32(chunk), L.ptr(T), L.ptr(l1),
+        L.ptr(ratio), info, L.ptr(ws), L.i64(ws.numel()), L.stream()),
+        "pcs_register_to_next_frame")
+    return T, l1, ratio, int(info[0])

@@ -1,0 +1,185 @@
+"""Parity of the HIP radius graph / connected components / medians / fused ICP against the CPU
+oracle and the reference-generated golden vectors. Edges, labels, medians bit-exact; transforms
+within 1e-5 (BASELINE.json north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pcseqlearning_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def cloud(rng, n, frames, extent):
+    return np.concatenate([rng.integers(0, frames, (n, 1)).astype(np.float32),
+                           rng.uniform(-extent, extent, (n, 3)).astype(np.float32)], axis=1)
+
+
+def test_radius_graph_hand_case():
+    pts = dev(np.array([[0, 0, 0, 0], [0, .1, .1, 0], [0, .2, .2, 0]], np.float32))
+    e_ref, e_q, d = ops.radius_graph(pts, pts, 0.15, 1, True, want_dists=True)
+    assert e_ref.tolist() == [0, 1, 2] and e_q.tolist() == [0, 1, 2] and d.tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("n,m,r,k,cell", [(3000, 1000, 0.8, 4, 0.0), (5000, 5000, 1.25, 32, 0.0),
+                                            (5000, 5000, 0.25, 32, 0.25), (4000, 2000, 2.5, 1, 0.4),
+                                            (1, 1, 1.0, 1, 0.0), (50, 3, 100.0, 32, 25.0)])
+def test_radius_graph_vs_oracle(oracle, n, m, r, k, cell):
+    rng = np.random.default_rng(n + m + k)
+    ref, qry = cloud(rng, n, 3, 6.0), cloud(rng, m, 3, 6.0)
+    for sort in (True, False):
+        o_ref, o_q, o_d = oracle.radius_graph(ref, qry, r, k, sort, want_dists=True)
+        e_ref, e_q, d = ops.radius_graph(dev(ref), dev(qry), r, k, sort, cell_size=cell, want_dists=True)
+        np.testing.assert_array_equal(e_q.cpu().numpy(), o_q)
+        np.testing.assert_array_equal(e_ref.cpu().numpy(), o_ref)
+        if sort:
+            np.testing.assert_array_equal(d.cpu().numpy(), o_d)
+
+
+def test_radius_graph_frame_offsets(oracle):
+    """register_to_next_frame's use: radius' = sqrt(r^2 + df^2), qmin[0] = qmax[0] = df."""
+    rng = np.random.default_rng(3)
+    for df in (1, -1, 5, -8):
+        a = cloud(rng, 3000, 1, 8.0); a[:, 0] = 8
+        b = cloud(rng, 2500, 1, 8.0); b[:, 0] = 8 + df
+        rad = np.float32((1.25 ** 2 + df ** 2) ** 0.5)
+        o_ref, o_q = oracle.radius_graph(b, a, rad, 1, True, qmin=(df, -1, -1, -1), qmax=(df, 1, 1, 1))
+        e_ref, e_q = ops.radius_graph(dev(b), dev(a), float(rad), 1, True, df, df, cell_size=0.3)
+        np.testing.assert_array_equal(e_q.cpu().numpy(), o_q)
+        np.testing.assert_array_equal(e_ref.cpu().numpy(), o_ref)
+        assert len(o_q) > 100
+
+
+def test_torch_hash_dropins_vs_oracle(oracle):
+    """hash_insert_gpu + radius_graph_gpu on the reference's table layout, driven exactly as
+    RadiusGraph.build_graph does (graph_utils.py:169-206)."""
+    rng = np.random.default_rng(4)
+    ref, qry = cloud(rng, 4000, 2, 5.0), cloud(rng, 1500, 2, 5.0)
+    r = 0.9
+    rt, qt = dev(ref), dev(qry)
+    radius = qt.new_zeros(qt.shape[0]) + r
+    vs = torch.tensor([1 - 1e-3, r, r, r], device=DEV)
+    allp = torch.cat([rt, qt], 0)
+    lo = allp.min(0)[0] - vs * 2
+    hi = allp.max(0)[0] + vs * 2
+    cr = torch.round((rt - lo) / vs).long() + 1
+    cq = torch.round((qt - lo) / vs).long() + 1
+    dims = torch.round((hi - lo) / vs).long() + 3
+    H = int(rt.shape[0] / 0.5)
+    keys = cr.new_zeros(H) - 1
+    values = rt.new_empty(H, 4)
+    rev = cr.new_zeros(H)
+    ops.hash_insert_gpu(keys, values, rev, dims, cr, rt)
+    qmin = torch.tensor([0, -1, -1, -1], dtype=torch.int32, device=DEV)
+    qmax = torch.tensor([0, 1, 1, 1], dtype=torch.int32, device=DEV)
+    for k, sort in ((32, True), (1, True), (3, False)):
+        edges = ops.radius_graph_gpu(keys, values, rev, dims, cq, qt, qmin, qmax, radius, k, sort)
+        o_ref, o_q = oracle.radius_graph(ref, qry, r, k, sort)
+        np.testing.assert_array_equal(edges[:, 0].cpu().numpy(), o_ref)
+        np.testing.assert_array_equal(edges[:, 1].cpu().numpy(), o_q)
+    assert int((keys >= 0).sum()) == rt.shape[0]  # every point owns a slot (duplicates not merged)
+
+
+def test_connected_components_vs_oracle(oracle):
+    rng = np.random.default_rng(5)
+    for n, E in ((1, 0), (10, 3), (20000, 15000), (50000, 200000)):
+        e0 = rng.integers(0, n, E)
+        e1 = rng.integers(0, n, E)
+        num, comp = ops.connected_components(dev(e0), dev(e1), n)
+        o_num, o_comp = oracle.connected_components(e0, e1, n)
+        assert num == o_num
+        np.testing.assert_array_equal(comp.cpu().numpy(), o_comp)
+
+
+def test_proposal_graph_components(oracle):
+    """ClusterProposal's unit of work: 32-NN radius graph of a cloud on itself -> components."""
+    rng = np.random.default_rng(6)
+    pts = cloud(rng, 20000, 2, 12.0)
+    pts[:, 3] *= 0.1
+    p = dev(pts)
+    e0, e1 = ops.radius_graph(p, p, 0.75, 32, True)
+    num, comp = ops.connected_components(e0, e1, pts.shape[0])
+    o0, o1 = oracle.radius_graph(pts, pts, 0.75, 32, True)
+    o_num, o_comp = oracle.connected_components(o0, o1, pts.shape[0])
+    np.testing.assert_array_equal(e0.cpu().numpy(), o0)
+    assert num == o_num
+    np.testing.assert_array_equal(comp.cpu().numpy(), o_comp)
+
+
+def test_segment_median_and_minmax(oracle):
+    rng = np.random.default_rng(7)
+    n = 30000
+    ids = rng.integers(0, 4000, n)
+    data = rng.integers(-3, 50, n)
+    seg = ops.unique_i64(dev(ids))
+    med = ops.segment_median(dev(data), seg).cpu().numpy()
+    uq = np.unique(ids)
+    want = oracle.robust_median(data, np.searchsorted(uq, ids), len(uq))
+    np.testing.assert_array_equal(med, want)
+    f = rng.normal(size=(n, 3)).astype(np.float32)
+    mx = ops.segment_minmax(dev(f), seg, True).cpu().numpy()
+    mn = ops.segment_minmax(dev(f), seg, False).cpu().numpy()
+    inv = np.searchsorted(uq, ids)
+    wmx = np.full((len(uq), 3), -np.inf, np.float32); np.maximum.at(wmx, inv, f)
+    wmn = np.full((len(uq), 3), np.inf, np.float32); np.minimum.at(wmn, inv, f)
+    np.testing.assert_array_equal(mx, wmx)
+    np.testing.assert_array_equal(mn, wmn)
+
+
+def _run_icp(g, radius, cell=0.0, chunk=8):
+    nsm = ~g["mov_stationary"]
+    nsr = ~g["ref_stationary"]
+    C = int(g["C"])
+    mov = dev(g["mov_fxyz"][nsm].copy())
+    comp = dev(g["mov_comp"][nsm])
+    deg = dev(np.bincount(g["mov_comp"], minlength=C))
+    fo = int(g["ref_frame"][0] - g["mov_frame"][0])
+    T, l1, ratio, iters = ops.register_to_next_frame(mov, comp, dev(g["ref_fxyz"][nsr]), dev(g["ref_fxyz"]),
+                                                     deg, C, radius, fo, 10.0, 80, 0.05, cell, chunk)
+    moved = g["mov_fxyz"].copy()
+    moved[nsm] = mov.cpu().numpy()
+    return T.cpu().numpy(), l1.cpu().numpy(), ratio.cpu().numpy(), moved, iters
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "reg_icp_*.npz"))))
+def test_icp_vs_reference_golden(path):
+    g = np.load(path)
+    T, l1, ratio, moved, iters = _run_icp(g, float(g["radius"]))
+    np.testing.assert_allclose(T, g["T"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(l1, g["l1"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ratio, g["ratio"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(moved, g["moved"], rtol=0, atol=2e-5)
+    # chunking of the device-side stop rule must not change the result
+    T2, _, _, _, iters2 = _run_icp(g, float(g["radius"]), cell=0.5, chunk=1)
+    assert iters2 == iters
+    np.testing.assert_allclose(T2, T, rtol=0, atol=1e-9)
+
+
+def test_icp_vs_oracle_larger(oracle):
+    """Bigger synthetic pair (stationary parts, empty component, negative frame offset)."""
+    from oracle import reg_oracle as R
+    from tests.golden.make_golden_reg import make_pair
+    rng = np.random.default_rng(99)
+    moving, ref = make_pair(rng, n_obj=40, pts_per_obj=300, frame_a=12, frame_b=9, shift=0.3)
+    C = int(moving["component"].max()) + 3  # two ids with no points at all
+    graph = R.Graph(1.25)
+    o_moved, o_T, o_l1, o_ratio, o_it = R.register_to_next_frame(graph, moving, ref, C, 10.0, 80, 0.05)
+    g = dict(mov_fxyz=moving["fxyz"], mov_comp=moving["component"], mov_frame=moving["frame"],
+             mov_stationary=moving["stationary"], ref_fxyz=ref["fxyz"], ref_frame=ref["frame"],
+             ref_stationary=ref["stationary"], C=np.array(C))
+    T, l1, ratio, moved, iters = _run_icp(g, 1.25, cell=0.4)
+    assert iters == o_it
+    np.testing.assert_allclose(T, o_T, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(l1, o_l1, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ratio, o_ratio, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(moved, o_moved, rtol=0, atol=2e-5)
