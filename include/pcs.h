@@ -57,8 +57,11 @@ int pcs_unique_i64(const int64_t* ids, int64_t n, int key_bits, int64_t* uniq, i
                    pcs_stream_t stream);
 
 /* torch_scatter.scatter(data, inv, reduce='mean'|'sum') (grid_sampling.py:42,
- * cluster_tracking.py:44) over the segments of pcs_unique_i64, summed in ascending original
- * index (deterministic). data [n,d] f32 -> out [v,d]. */
+ * cluster_tracking.py:44) over the segments of pcs_unique_i64. mean bit 0: 1 = mean, 0 = sum.
+ * mean bit 1 clear: summed serially in ascending original index (voxel-sized segments);
+ * set (d <= 16): one wave per segment, lane-strided partial sums + butterfly (pillar- and
+ * component-sized segments). Both orders are fixed, so results are reproducible run to run.
+ * data [n,d] f32 -> out [v,d]. */
 int pcs_segment_reduce_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start,
                            int64_t v, int mean, float* out, pcs_stream_t stream);
 
@@ -205,6 +208,32 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                float cell_size, int chunk, double* T, double* l1_err,
                                float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
                                pcs_stream_t stream);
+
+/* smooth_velo, pcdet/models/registration/preprocessors/cluster_tracking.py:162-199 (<=300 AdamW
+ * steps with MultiStepLR and a 3-strike stop, one persistent kernel). comp_velos [C,F,3] f32 is
+ * updated in place (the reference's Parameter aliases its input the same way);
+ * comp_center_diffs [C,F,3]; frame_lo <= frame_hi ordered ends of the range. */
+size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F);
+int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C, int F,
+                    int frame_lo, int frame_hi, float weight0, float weight, int num_itr,
+                    float stopping, void* ws, size_t ws_bytes, pcs_stream_t stream);
+
+/* points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168 (evaluation
+ * side-channel of ClusterProposal / ClusterTracking): points [N,3], boxes [B,7]
+ * (x,y,z,dx,dy,dz,heading) -> out [B,N] int32. */
+int pcs_points_in_boxes(const float* points, int64_t N, const float* boxes, int B, int32_t* out,
+                        pcs_stream_t stream);
+
+/* l1_minimization, pcdet/models/registration/preprocessors/preprocessor_utils.py:313-350 (ground
+ * height per 2 m pillar: L1 data term + 4-direction second-difference smoothness, AdamW with
+ * MultiStepLR, <= max_iters steps, 3-strike stop at 1e-4), one persistent kernel.
+ * pillar_min_z, weight, height_out: [X,Y] f32 (X*Y <= 12288); decay_steps: HOST int array;
+ * d_iters: optional device int32 receiving the number of steps taken. */
+size_t pcs_l1_minimization_workspace_bytes(int X, int Y);
+int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, int Y, double lr,
+                        const int* decay_steps, int n_decay, float rigid_weight, int max_iters,
+                        float* height_out, int32_t* d_iters, void* ws, size_t ws_bytes,
+                        pcs_stream_t stream);
 
 #ifdef __cplusplus
 }

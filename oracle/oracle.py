@@ -176,6 +176,14 @@ def connected_components(e0, e1, n):
     return int(num), comp
 
 
+def points_in_boxes(points, boxes):
+    pts = _c(points, np.float32)
+    bx = _c(boxes, np.float32)
+    out = np.zeros((bx.shape[0], pts.shape[0]), np.int32)
+    lib().orc_points_in_boxes(_p(pts), ctypes.c_int64(pts.shape[0]), _p(bx), ctypes.c_int(bx.shape[0]), _p(out))
+    return out
+
+
 def robust_median(data, index, num_segments):
     """registration_utils.robust_median (:60-81): sort index*range + (data - min), pick the
     element at exclusive_scan(deg) + deg // 2; empty segments -> int64(-1e10)."""

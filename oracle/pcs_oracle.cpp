@@ -440,4 +440,24 @@ int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E
   return num;
 }
 
+// points_in_boxes_cpu / check_pt_in_box3d_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168
+void orc_points_in_boxes(const float* pts, int64_t N, const float* boxes, int B, int32_t* out) {
+  for (int i = 0; i < B; ++i)
+    for (int64_t j = 0; j < N; ++j) {
+      const float* bx = boxes + i * 7;
+      float x = pts[j * 3], y = pts[j * 3 + 1], z = pts[j * 3 + 2];
+      float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
+      int flag = 0;
+      if (!(std::fabs(z - cz) > dz / 2.0)) {
+        const float MARGIN = 1e-2;
+        float cosa = std::cos((double)-rz), sina = std::sin((double)-rz);
+        float sx = x - cx, sy = y - cy;
+        float lx = sx * cosa + sy * (-sina);
+        float ly = sx * sina + sy * cosa;
+        flag = (std::fabs((double)lx) < dx / 2.0 + MARGIN) & (std::fabs((double)ly) < dy / 2.0 + MARGIN);
+      }
+      out[(int64_t)i * N + j] = flag;
+    }
+}
+
 }  // extern "C"

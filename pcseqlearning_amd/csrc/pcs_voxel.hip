@@ -148,6 +148,38 @@ segment_mean_kernel(const float* __restrict__ data, int d, const int32_t* __rest
   }
 }
 
+// Large segments (pillars, components): one wave per segment, lane l sums elements l, l+64, ...
+// in order, then a 64-lane butterfly. Deterministic (fixed order), d <= 16 columns.
+__global__ void __launch_bounds__(kBlock)
+segment_reduce_wave_kernel(const float* __restrict__ data, int d, const int32_t* __restrict__ order,
+                           const int32_t* __restrict__ seg_start, int64_t v,
+                           float* __restrict__ out, int mean) {
+  int lane = threadIdx.x & 63;
+  int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t seg = wave; seg < v; seg += nwaves) {
+    int b = seg_start[seg], e = seg_start[seg + 1];
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int p = b + lane; p < e; p += 64) {
+      const float* row = data + (int64_t)order[p] * d;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < d) acc[c] = acc[c] + row[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < d) {
+        float x = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = x + __shfl_xor(x, o, 64);
+        if (lane == 0) out[seg * d + c] = mean ? x / (float)(e - b) : x;
+      }
+    }
+  }
+}
+
 // last (= max original index) / first (= min original index) row of every segment
 __global__ void __launch_bounds__(kBlock)
 segment_pick_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ seg_start,
@@ -374,6 +406,14 @@ int pcs_segment_reduce_f32(const float* data, int d, const int32_t* order, const
                            int64_t v, int mean, float* out, hipStream_t s) {
   if (!data || !order || !seg_start || !out || d <= 0 || v < 0) return PCS_ERR_ARG;
   if (v == 0) return PCS_OK;
+  if ((mean & 2) && d <= 16) {
+    int64_t blocks = (v * 64 + kBlock - 1) / kBlock;
+    segment_reduce_wave_kernel<<<(int)(blocks > 2048 ? 2048 : blocks), kBlock, 0, s>>>(
+        data, d, order, seg_start, v, out, mean & 1);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
+  mean &= 1;
   segment_mean_kernel<<<grid_for(v * d), kBlock, 0, s>>>(data, d, order, seg_start, v, out, mean);
   PCS_LAUNCH_CHECK();
   return PCS_OK;

@@ -48,6 +48,13 @@ def unique_i64(ids, key_bits=64, want_uniq=True, want_inv=True):
     n = ids.shape[0]
     dev = ids.device
     seg = Segments()
+    if n == 0:
+        seg.num = 0
+        seg.order = torch.empty(0, dtype=torch.int32, device=dev)
+        seg.seg_start = torch.zeros(1, dtype=torch.int32, device=dev)
+        seg.inv = torch.empty(0, dtype=torch.int64, device=dev) if want_inv else None
+        seg.uniq = torch.empty(0, dtype=torch.int64, device=dev) if want_uniq else None
+        return seg
     uniq = torch.empty(n, dtype=torch.int64, device=dev) if want_uniq else None
     inv = torch.empty(n, dtype=torch.int64, device=dev) if want_inv else None
     order = torch.empty(n, dtype=torch.int32, device=dev)
@@ -66,14 +73,16 @@ def unique_i64(ids, key_bits=64, want_uniq=True, want_inv=True):
     return seg
 
 
-def segment_reduce(data, seg, mean=True):
-    """scatter(data, inv, reduce='mean'/'sum') in ascending original index. data [n] or [n,d]."""
+def segment_reduce(data, seg, mean=True, wave=False):
+    """scatter(data, inv, reduce='mean'/'sum'). data [n] or [n,d]. wave=False: serial ascending
+    original index per segment (small segments); wave=True: one wave per segment (large ones)."""
     lib = L.load()
     squeeze = data.dim() == 1
     d2 = data.reshape(data.shape[0], -1).float().contiguous()
     out = torch.empty(seg.num, d2.shape[1], dtype=torch.float32, device=data.device)
     L.check(lib.pcs_segment_reduce_f32(L.ptr(d2), L.i32(d2.shape[1]), L.ptr(seg.order),
-                                       L.ptr(seg.seg_start), L.i64(seg.num), L.i32(int(mean)),
+                                       L.ptr(seg.seg_start), L.i64(seg.num),
+                                       L.i32(int(mean) | (2 if (wave and d2.shape[1] <= 16) else 0)),
                                        L.ptr(out), L.stream()), "pcs_segment_reduce_f32")
     return out[:, 0] if squeeze else out
 
@@ -352,3 +361,53 @@ def register_to_next_frame(mov_fxyz, mov_comp, ref_fxyz, ref_all, comp_deg, num_
         L.ptr(ratio), info, L.ptr(ws), L.i64(ws.numel()), L.stream()),
         "pcs_register_to_next_frame")
     return T, l1, ratio, int(info[0])
+
+
+def smooth_velo(comp_velos, comp_center_diffs, frame_id, next_frame_id, weight0=1.0, weight=10.0,
+                num_itr=300, stopping=1e-3):
+    """cluster_tracking.smooth_velo: in place on comp_velos [C,F,3] f32 (and returns it)."""
+    if frame_id == next_frame_id:
+        return comp_velos
+    L.require_gpu(comp_velos, "smooth_velo")
+    lib = L.load()
+    lo, hi = (frame_id, next_frame_id) if frame_id < next_frame_id else (next_frame_id, frame_id)
+    assert comp_velos.is_contiguous() and comp_velos.dtype == torch.float32
+    C, F, _ = comp_velos.shape
+    ws = L.workspace(lib.pcs_smooth_velo_workspace_bytes(L.i64(C), L.i32(F)), comp_velos.device)
+    L.check(lib.pcs_smooth_velo(L.ptr(comp_velos), L.ptr(comp_center_diffs.float().contiguous()),
+                                L.i64(C), L.i32(F), L.i32(lo), L.i32(hi), L.f32(weight0),
+                                L.f32(weight), L.i32(num_itr), L.f32(stopping), L.ptr(ws),
+                                L.i64(ws.numel()), L.stream()), "pcs_smooth_velo")
+    return comp_velos
+
+
+def points_in_boxes(points, boxes):
+    """roiaware_pool3d_utils.points_in_boxes_cpu semantics on the device: [B, N] int32."""
+    L.require_gpu(points, "points_in_boxes")
+    lib = L.load()
+    points = points.float().contiguous()
+    boxes = boxes.float().contiguous()
+    assert boxes.shape[1] == 7 and points.shape[1] == 3
+    out = torch.zeros(boxes.shape[0], points.shape[0], dtype=torch.int32, device=points.device)
+    L.check(lib.pcs_points_in_boxes(L.ptr(points), L.i64(points.shape[0]), L.ptr(boxes),
+                                    L.i32(boxes.shape[0]), L.ptr(out), L.stream()),
+            "pcs_points_in_boxes")
+    return out
+
+
+def l1_minimization(pillar_min_z, weight, lr, decay_steps, rigid_weight, max_iters):
+    """preprocessor_utils.l1_minimization: returns pillar_height [X,Y] f32."""
+    L.require_gpu(pillar_min_z, "l1_minimization")
+    lib = L.load()
+    X, Y = pillar_min_z.shape
+    mz = pillar_min_z.float().contiguous()
+    w = weight.float().reshape(X, Y).contiguous()
+    out = torch.empty(X, Y, dtype=torch.float32, device=mz.device)
+    ws = L.workspace(lib.pcs_l1_minimization_workspace_bytes(L.i32(X), L.i32(Y)), mz.device)
+    import ctypes
+    L.check(lib.pcs_l1_minimization(L.ptr(mz), L.ptr(w), L.i32(X), L.i32(Y), ctypes.c_double(lr),
+                                    L.host_ints(list(decay_steps)), L.i32(len(decay_steps)),
+                                    L.f32(rigid_weight), L.i32(max_iters), L.ptr(out),
+                                    ctypes.c_void_p(0), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_l1_minimization")
+    return out

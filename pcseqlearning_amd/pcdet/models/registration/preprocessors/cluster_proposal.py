@@ -1,0 +1,155 @@
+"""ClusterProposal (pcdet/models/registration/preprocessors/cluster_proposal.py): per radius key
+and per 10-frame chunk, a 32-nearest radius graph of the chunk on itself and its connected
+components (ids offset by the running total), then the GT-box evaluation that tags every point
+with its box / trace. Graph + components run on the HIP engine with no host round trip of the
+edge list (the reference ships up to 32 N edges through scipy on the host)."""
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from ..... import ops
+from ....utils.common_utils import EasyDict, filter_dict
+from ....utils.timer import Timer
+from ...model_utils import graph_utils
+
+
+class ClusterProposal(nn.Module):
+    def __init__(self, model_cfg, runtime_cfg):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.forward_dict = EasyDict()
+        self.fake_params = nn.Parameter(torch.zeros(1, dtype=torch.float32), requires_grad=True)
+        self.component_keys = model_cfg["COMPONENT_KEYS"]
+        for i, key in enumerate(self.component_keys):
+            cfg = dict(model_cfg["GRAPH"])
+            cfg["RADIUS"] = cfg["RADIUS"][i]
+            self.add_module(f"graph_{key}", graph_utils.build_graph(cfg, runtime_cfg=runtime_cfg))
+        self.chunk = 10
+        self.verbose = bool((runtime_cfg or {}).get("verbose", False))
+
+    def propose_cluster(self, seq_dict):
+        pcseq = EasyDict(fxyz=seq_dict["point_fxyz"], frame=seq_dict["point_sweep"])
+        num_points = pcseq.fxyz.shape[0]
+        frames = pcseq.frame.reshape(-1)
+        num_frames = int(frames.max().long().item()) + 1
+        for comp_key in self.component_keys:
+            with Timer(f"Propose Cluster for {comp_key}"):
+                graph = getattr(self, f"graph_{comp_key}")
+                component = torch.zeros(num_points, dtype=torch.int64, device=pcseq.fxyz.device)
+                total = 0
+                for f0 in range(0, num_frames, self.chunk):
+                    mask = (frames >= f0) & (frames < f0 + self.chunk)
+                    if not bool(mask.any()):
+                        continue
+                    pcframe = EasyDict(filter_dict(pcseq, mask))
+                    e0, e1, _ = graph(pcframe, pcframe)
+                    num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0),
+                                                                 pcframe.fxyz.shape[0])
+                    component[mask] = comp.to(component) + total
+                    total += num
+                seq_dict[f"point_{comp_key}"] = component
+                if self.verbose:
+                    print(f"Cluster Proposal {comp_key}: num_components={total}")
+        return seq_dict
+
+    def assign_instances_to_boxes(self, point_instance_label, bp_mask):
+        """Majority box of every instance: (dict instance -> box id, per-point box id)."""
+        instance2box = defaultdict(lambda: -1)
+        point_box_id = torch.zeros_like(point_instance_label) - 1
+        for inst in point_instance_label.unique().tolist():
+            imask = (point_instance_label == inst).reshape(-1)
+            bi = bp_mask[:, imask]
+            if not bool(bi.any()):
+                continue
+            box_id = bi.long().sum(-1).argmax()
+            instance2box[inst] = box_id
+            point_box_id[imask] = box_id
+        return instance2box, point_box_id
+
+    def format_boxes(self, seq_dict, num_frames):
+        return EasyDict(dict(
+            attr=seq_dict["gt_box_attr"].reshape(-1, 7),
+            cls_label=seq_dict["gt_box_cls_label"].reshape(-1),
+            frame=seq_dict["gt_box_frame"].reshape(-1),
+            trace_id=seq_dict["gt_box_track_label"].reshape(-1),
+        ))
+
+    def evaluate_proposal(self, seq_dict):
+        """Point-wise IoU of the proposed components against the GT boxes / traces
+        (cluster_proposal.py:142-285); also emits point_gt_box_id etc. consumed downstream."""
+        num_frames = int(seq_dict["point_sweep"].max().long().item()) + 1
+        seq_boxes = self.format_boxes(seq_dict, num_frames)
+        if seq_boxes.attr.shape[0] == 0:
+            n = seq_dict[f"point_{self.component_keys[0]}"].numel()
+            for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):
+                seq_dict[f"point_{key}"] = seq_dict["segmentation_label"].new_zeros(n) - 1
+            return seq_dict
+        seq_boxes.best_iou = torch.zeros_like(seq_boxes.attr[:, 0])
+        num_traces = int(seq_boxes.trace_id.max().long().item()) + 1
+        traces = EasyDict(dict(
+            best_iou=seq_boxes.attr.new_zeros(num_traces),
+            min_frame=seq_boxes.trace_id.new_zeros(num_traces),
+            max_frame=seq_boxes.trace_id.new_zeros(num_traces),
+        ))
+        for t in range(num_traces):
+            tm = (seq_boxes.trace_id == t).reshape(-1)
+            if bool(tm.any()):
+                traces.min_frame[t] = seq_boxes.frame[tm].min().long()
+                traces.max_frame[t] = seq_boxes.frame[tm].max().long()
+
+        seq_points = None
+        for comp_key in self.component_keys:
+            seq_points = EasyDict(fxyz=seq_dict["point_fxyz"], frame=seq_dict["point_sweep"],
+                                  segmentation_label=seq_dict["segmentation_label"])
+            if "instance_label" in seq_dict:
+                seq_points["instance_label"] = seq_dict["instance_label"]
+            seq_points.component = seq_dict[f"point_{comp_key}"]
+            for key in ("gt_box_id", "pred_box_id", "gt_trace_id", "pred_trace_id"):
+                seq_points[key] = torch.zeros_like(seq_points.component) - 1
+            for frame_id in range(num_frames):
+                fmask = (seq_points.fxyz[:, 0] == frame_id).reshape(-1)
+                if not bool(fmask.any()):
+                    continue
+                fp = EasyDict(filter_dict(seq_points, fmask))
+                bmask = (seq_boxes.frame == frame_id).reshape(-1)
+                fb = EasyDict(filter_dict(seq_boxes, bmask))
+                if fb.attr.shape[0] == 0:
+                    continue
+                bp = ops.points_in_boxes(fp.fxyz[:, 1:], fb.attr).long()
+                in_box = (bp == 1).any(0)
+                fp.gt_box_id[in_box] = bp[:, in_box].argmax(0)
+                fp.gt_trace_id[in_box] = fb.trace_id[fp.gt_box_id[in_box]]
+                comp2box, fp.pred_box_id = self.assign_instances_to_boxes(fp.component, bp)
+                valid = (fp.pred_box_id >= 0).reshape(-1)
+                fp.pred_trace_id[valid] = fb.trace_id[fp.pred_box_id[valid]]
+                for c in fp.component.unique().tolist():
+                    box_id = comp2box[c]
+                    if box_id < 0:
+                        continue
+                    m1 = (fp.gt_box_id == box_id).reshape(-1)
+                    m2 = (fp.component == c).reshape(-1)
+                    iou = (m1 & m2).float().sum().item() / ((m1 | m2).float().sum().item() + 1e-6)
+                    if iou > fb.best_iou[box_id]:
+                        fb.best_iou[box_id] = iou
+                    t = fb.trace_id[box_id]
+                    if iou > traces.best_iou[t]:
+                        traces.best_iou[t] = iou
+                for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):
+                    seq_points[key][fmask] = fp[key]
+                seq_boxes["best_iou"][bmask] = fb["best_iou"]
+            seq_boxes[f"best_iou_after_{comp_key}"] = seq_boxes["best_iou"].clone()
+        seq_dict["gt_box_best_iou"] = seq_boxes.best_iou
+        seq_dict["gt_trace_best_iou"] = traces.best_iou
+        for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):
+            seq_dict[f"point_{key}"] = seq_points[key]
+        return seq_dict
+
+    def forward(self, seq_dict):
+        seq_dict = self.propose_cluster(seq_dict)
+        with Timer("Evaluate Proposal"):
+            seq_dict = self.evaluate_proposal(seq_dict)
+        return seq_dict
+
+    def get_output_feature_dim(self):
+        return 0

@@ -1,0 +1,440 @@
+"""ClusterTracking (pcdet/models/registration/preprocessors/cluster_tracking.py) on the HIP path.
+
+Same registry name, constructor `(model_cfg, runtime_cfg)`, `forward(seq_dict) -> seq_dict`, same
+on-disk outputs (`<DIR>/<seq>/<frame:03d>_<key>.pth`, `<DIR>/<seq>/all.pth`). The control flow
+restates SURVEY.md A.6 / cluster_tracking.py:430-787; every point-level computation goes through
+pcseqlearning_amd.ops (grid sampling, medians, fused ICP, radius graph, ordered segment reductions,
+smooth_velo, points_in_boxes). The polyscope visualiser hooks of the reference are not mirrored.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..... import ops
+from ....utils.common_utils import EasyDict, filter_dict
+from ....utils.timer import Timer
+from ...model_utils import graph_utils
+from ...model_utils.grid_sampling import GridSampling3D
+from .registration_utils import (IndexSegments, efficient_robust_sum, register_to_next_frame,
+                                 robust_mean, robust_median, segment_max, segment_min)
+
+
+def sample_frame(grid_sampler, frame):
+    """Voxel-subsample a frame: mean of fxyz / stationary, median of component / frame ids
+    (cluster_tracking.py:39-51)."""
+    seg = grid_sampler.segments(frame.fxyz)
+    new_frame = EasyDict()
+    new_frame["fxyz"] = ops.segment_reduce(frame.fxyz, seg, mean=True)
+    new_frame["stationary"] = ops.segment_reduce(frame.stationary.float(), seg, mean=True) > 0.5
+    for key in ("component", "frame"):
+        new_frame[key] = ops.segment_median(frame[key].long().reshape(-1), seg)
+    return new_frame
+
+
+def rotation_angle(R):
+    diag = R.reshape(*R.shape[:-2], 9)[..., [0, 4, 8]]
+    return ((diag.sum(-1) - 1) / 2).clamp(min=-1, max=1).arccos()
+
+
+def pose_inv(T):
+    R, t = T[..., :3, :3], T[..., :3, 3]
+    Tinv = T.clone()
+    Tinv[..., :3, :3] = R.transpose(-1, -2)
+    Tinv[..., :3, 3:] = -R.transpose(-1, -2) @ t.unsqueeze(-1)
+    return Tinv
+
+
+def dist_compensate(comp_deg):
+    """Size-dependent slack on the registration-error stop rule (cluster_tracking.py:80-87)."""
+    thresholds = [0, 10, 40, 100, 200, 400, 10000000]
+    slack = [1, 0.5, 0.3, 0.2, 0.1, 0.0]
+    out = torch.zeros_like(comp_deg).float()
+    for lo, hi, val in zip(thresholds[:-1], thresholds[1:], slack):
+        out[(comp_deg >= lo) & (comp_deg < hi)] = val
+    return out
+
+
+def _component_stats(frame_points, sg=None):
+    xyz = frame_points.fxyz[:, 1:]
+    num_components = int(frame_points.component.max().long().item()) + 1
+    if sg is None:
+        sg = IndexSegments(frame_points.component, num_components)
+    deg = efficient_robust_sum(torch.ones_like(xyz[:, 0]), sg, num_components)
+    valid = (deg > 0.5).reshape(-1)
+    center = efficient_robust_sum(xyz, sg, num_components)
+    center[valid] = center[valid] / deg[valid, None]
+    return num_components, sg, deg, valid, center
+
+
+def component_center(frame_points, sg=None):
+    return _component_stats(frame_points, sg)[4]
+
+
+def component_diameter(frame_points, sg=None):
+    """2 x the largest distance of a component's points to its centre (cluster_tracking.py:89-107)."""
+    num_components, sg, _, _, center = _component_stats(frame_points, sg)
+    dist = (frame_points.fxyz[:, 1:] - center[frame_points.component]).norm(p=2, dim=-1)
+    return segment_max(dist, sg, num_components) * 2
+
+
+def filter_components(frame_points, max_diameter=12.5, sg=None):
+    num_components = int(frame_points.component.max().long().item()) + 1
+    if sg is None:
+        sg = IndexSegments(frame_points.component, num_components)
+    deg = efficient_robust_sum(torch.ones_like(frame_points.fxyz[:, 0]), sg, num_components)
+    valid = (deg > 0.5).reshape(-1)
+    if max_diameter > 0:
+        valid = valid & (component_diameter(frame_points, sg) < max_diameter)
+    return valid
+
+
+def smooth_velo(comp_velos, comp_center_diffs, frame_id, next_frame_id, weight0=1, weight=10,
+                num_itr=300, stopping=1e-3):
+    """cluster_tracking.py:162-199 as one persistent HIP kernel; in place, like the reference's
+    Parameter (which aliases its input)."""
+    return ops.smooth_velo(comp_velos, comp_center_diffs, frame_id, next_frame_id, float(weight0),
+                           float(weight), num_itr, stopping)
+
+
+class ClusterTracking(nn.Module):
+    def __init__(self, model_cfg, runtime_cfg):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.forward_dict = EasyDict()
+        registration_cfg = model_cfg["REGISTRATION"]
+        self.stopping_delta = registration_cfg["STOPPING_DELTA"]
+        graph_cfg = registration_cfg["GRAPH"]
+        self.radius_list = graph_cfg["RADIUS"]
+        self.voxel_size_list = registration_cfg["VOXEL_SIZE"]
+        for i, (radius, voxel_size) in enumerate(zip(self.radius_list, self.voxel_size_list)):
+            cfg = dict(graph_cfg)
+            cfg["RADIUS"] = radius
+            graph = graph_utils.build_graph(cfg, {})
+            # fine-cell size of the fused ICP's neighbour search: a couple of sampling voxels
+            graph.icp_cell_size = 2.0 * float(max(voxel_size[:2]))
+            self.add_module(f"registration_graph_{i}", graph)
+            self.add_module(f"sampler_{i}", GridSampling3D(list(voxel_size)))
+        self.nn_graph = graph_utils.build_graph(model_cfg["NN_GRAPH"], runtime_cfg=runtime_cfg)
+        self.visualize = False  # the reference's polyscope hooks are out of scope
+        params = model_cfg.get("TRACKING_PARAMS", {})
+        self.reg_error_coeff = params.get("REGISTRATION_ERROR_COEFFICIENT", 0.13)
+        self.track_interval = params.get("TRACK_INTERVAL", 10)
+        self.angle_threshold = params.get("ANGLE_THRESHOLD", 45)
+        self.min_move_frame = params.get("MIN_MOVE_FRAME", 6)
+        self.component_keys = model_cfg["COMPONENT_KEYS"]
+        self.verbose = bool((runtime_cfg or {}).get("verbose", False))
+
+    # ------------------------------------------------------------------ boxes
+    def format_boxes(self, seq_dict, num_frames):
+        return EasyDict(dict(
+            attr=seq_dict["gt_box_attr"].reshape(-1, 7),
+            cls_label=seq_dict["gt_box_cls_label"].reshape(-1),
+            frame=seq_dict["gt_box_frame"].reshape(-1),
+            trace_id=seq_dict["gt_box_track_label"].reshape(-1),
+            velo=seq_dict["gt_box_velo"].reshape(-1),
+            moving=seq_dict["moving"].reshape(-1),
+        ))
+
+    # ------------------------------------------------------------------ full-resolution harvest
+    def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes):
+        """Map tracked voxels back to the full-resolution points of each frame and update the
+        per-box best IoU (cluster_tracking.py:287-428)."""
+        full = {k: [] for k in ("fxyz", "component", "segmentation_label", "instance_label",
+                                "original_indices", "frame_indices", "moving")}
+        transforms = extracted.pop("transforms")
+        device = all_points.fxyz.device
+        num_components = int(extracted.component.max().long().item()) + 1
+        comp_sg = IndexSegments(extracted.component, num_components)
+        component_hit = extracted.component.new_zeros(num_components)
+        size_min = segment_min(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
+        size_max = segment_max(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
+        component_size = size_max - size_min + 1
+        ext_frame = extracted.fxyz[:, 0].round().long()
+        for fid in ext_frame.unique().tolist():
+            frame_box_mask = (seq_boxes.frame == fid).reshape(-1)
+            frame_boxes = EasyDict(filter_dict(seq_boxes, frame_box_mask))
+            ref_mask = (all_points.frame == fid).reshape(-1)
+            ref_pts = EasyDict(filter_dict(all_points, ref_mask))
+            n_ref = ref_pts.fxyz.shape[0]
+            ref_pts.frame_indices = torch.arange(n_ref, device=device).to(extracted.component)
+            has_boxes = bool(frame_box_mask.any())
+            if has_boxes:
+                ref_bp = ops.points_in_boxes(ref_pts.fxyz[:, 1:], frame_boxes.attr).long()
+                ref_pts.gt_box_id = ref_bp.argmax(0)
+                ref_pts.gt_box_id[ref_bp.max(0)[0] == 0] = -1
+            else:
+                ref_pts.gt_box_id = torch.zeros(n_ref, device=device).to(ref_pts.frame) - 1
+            one = EasyDict(filter_dict(extracted, (ext_frame == fid).reshape(-1)))
+
+            self.nn_graph.radius *= 1.732
+            e_ext, e_ref, _ = self.nn_graph(one, ref_pts)
+            self.nn_graph.radius /= 1.732
+
+            center = robust_mean(one.fxyz[:, 1:3], one.component, num_components)
+            spread = (one.fxyz[:, 1:3] - center[one.component]).norm(p=2, dim=-1)
+            diameter = segment_max(spread, one.component, num_components)
+            dz = one.fxyz[e_ext, -1] - ref_pts.fxyz[e_ref, -1]
+            keep = dz < 0.5
+            dist = (ref_pts.fxyz[e_ref, 1:3] - center[one.component[e_ext]]).norm(p=2, dim=-1)
+            keep &= dist < diameter[one.component[e_ext]] + 0.05
+            keep &= dz > -0.05
+            e_ext, e_ref = e_ext[keep], e_ref[keep]
+            out = EasyDict(dict(
+                fxyz=ref_pts.fxyz[e_ref],
+                component=one.component[e_ext],
+                segmentation_label=ref_pts.full_segmentation_label[e_ref],
+                instance_label=ref_pts.full_instance_label[e_ref],
+                frame_indices=ref_pts.frame_indices[e_ref],
+                original_indices=ref_mask.nonzero()[e_ref],
+                moving=one.moving[e_ext],
+            ))
+            for key in full:
+                full[key].append(out[key])
+            if has_boxes:
+                bp = ops.points_in_boxes(out.fxyz[:, 1:], frame_boxes.attr).long()
+                for c in out.component.unique().tolist():
+                    cmask = (out.component == c).reshape(-1)
+                    if not bool(bp[:, cmask].any()):
+                        continue
+                    box_id = bp[:, cmask].float().sum(-1).argmax()
+                    m1 = ref_pts.gt_box_id == box_id
+                    mask = torch.zeros(n_ref, device=device, dtype=torch.bool)
+                    mask[out.frame_indices[cmask]] = True
+                    iou = (mask & m1).long().sum() / ((mask | m1).long().sum() + 1e-6)
+                    if iou > 0.7:
+                        component_hit[c] += 1
+                    if iou > frame_boxes.best_iou[box_id]:
+                        frame_boxes.best_iou[box_id] = iou
+            seq_boxes.best_iou[frame_box_mask] = frame_boxes.best_iou
+        full = EasyDict({k: torch.cat(v, dim=0) for k, v in full.items()})
+        full.component_hit = component_hit
+        full.component_size = component_size
+        full.transforms = transforms
+        return full, seq_boxes
+
+    # ------------------------------------------------------------------ tracking of one anchor
+    def track_frame(self, seq_points, frame, seq_boxes):
+        """Track the components of anchor frame `frame` through `seq_points` within
+        +-TRACK_INTERVAL frames (cluster_tracking.py:430-787)."""
+        num_components = int(frame.component.max().long().item()) + 1
+        frame_id = int(frame.frame[0].long().item())
+        frame_mask = (seq_points.frame == frame_id).reshape(-1)
+        min_frame_id = max(int(seq_points.frame.min().long().item()), frame_id - self.track_interval)
+        max_frame_id = min(int(seq_points.frame.max().long().item()), frame_id + self.track_interval)
+        comp_sg = IndexSegments(frame.component, num_components)
+        comp_deg = efficient_robust_sum(torch.ones_like(frame.component), comp_sg, num_components)
+        if self.verbose:
+            print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components")
+        comp_diameter = component_diameter(frame, comp_sg)
+
+        F = max_frame_id + 1
+        transforms = torch.diag_embed(
+            frame.fxyz.new_ones(num_components, max_frame_id - min_frame_id + 1, 4).double())
+        reg_errors = frame.fxyz.new_zeros(num_components, F)
+        comp_edge_ratios = frame.fxyz.new_zeros(num_components, F)
+        comp_min_frame_id = frame.component.new_zeros(num_components) + frame_id
+        comp_max_frame_id = frame.component.new_zeros(num_components) + frame_id
+        comp_velos = frame.fxyz.new_zeros(num_components, F, 3)
+        comp_centers = frame.fxyz.new_zeros(num_components, F, 3)
+        comp_centers[:, frame_id] = component_center(frame, comp_sg)
+        comp_center_diffs = frame.fxyz.new_zeros(num_components, F, 3)
+
+        valid_comp_mask = filter_components(frame, sg=comp_sg)
+        valid_point_mask = valid_comp_mask[frame.component]
+        ex_fxyz = [frame.fxyz[valid_point_mask]]
+        ex_component = [frame.component[valid_point_mask]]
+        ex_seg = [frame.segmentation_label[valid_point_mask]]
+        ex_indices = [valid_point_mask.nonzero().reshape(-1)]
+        ex_original = [frame_mask.nonzero()[valid_point_mask].reshape(-1)]
+
+        last_velo = None
+        moving = None
+        for track_dir in (-1, 1):  # backward, then forward
+            next_frame_id = frame_id + track_dir
+            stopped = ~valid_comp_mask
+            moving = valid_comp_mask.clone()
+            last_xyz = frame.fxyz[:, 1:].clone()
+            if track_dir == 1 and frame_id > 0:
+                last_velo = comp_velos[:, frame_id]
+            while min_frame_id <= next_frame_id <= max_frame_id and bool((~stopped).any()):
+                if self.verbose:
+                    print(f"Tracking {frame_id} --> {next_frame_id}")
+                next_mask = (seq_points.frame == next_frame_id).reshape(-1)
+                next_frame = EasyDict(filter_dict(seq_points, next_mask))
+                col = next_frame_id - min_frame_id
+                frame.require_corres = ((~stopped)[frame.component]).reshape(-1)
+                transforms[:, col] = transforms[:, col - track_dir]
+                if last_velo is not None:
+                    # constant-velocity prediction for the components still being tracked
+                    trans = last_velo.clone()
+                    trans[stopped] = 0
+                    frame.fxyz[:, 1:] += trans[frame.component] * track_dir
+                    transforms[:, col, :3, 3] += trans.double() * track_dir
+                for i in range(len(self.radius_list)):
+                    sampler = getattr(self, f"sampler_{i}")
+                    graph = getattr(self, f"registration_graph_{i}")
+                    sub_frame = sample_frame(sampler, frame)
+                    sub_next = sample_frame(sampler, next_frame)
+                    with Timer(f"REGISTRATION at Level {i}"):
+                        sub_frame, T, _l1, _ratio = register_to_next_frame(
+                            graph, sub_frame, sub_next, num_components,
+                            self.model_cfg["ANGLE_REGULARIZER"], max_iter=80,
+                            stopping_delta=self.stopping_delta[i])
+                    if i == 0:
+                        comp_edge_ratio = _ratio
+                    if i == len(self.radius_list) - 1:
+                        l1_reg_error = _l1
+                    Tc = T[frame.component]
+                    frame.fxyz[:, 1:] = (Tc[:, :3, :3] @ frame.fxyz[:, 1:, None].double()).squeeze(-1).float() \
+                        + Tc[:, :3, 3].float()
+                    transforms[:, col] = T @ transforms[:, col]
+
+                comp_centers[:, next_frame_id] = component_center(frame, comp_sg)
+                point_velo = (frame.fxyz[:, 1:] - last_xyz) * track_dir
+                comp_velo = robust_mean(point_velo, comp_sg, num_components)
+                comp_velo[:, 2] = 0
+                comp_velos[:, next_frame_id] = comp_velo
+                comp_center_diffs[:, next_frame_id] = \
+                    (comp_centers[:, next_frame_id] - comp_centers[:, next_frame_id - track_dir]) * track_dir
+                comp_velos = smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, next_frame_id)
+                delta_velo = comp_velos[:, next_frame_id] - comp_velo
+                comp_velo = comp_velos[:, next_frame_id]  # live view, like the reference's
+                frame.fxyz[:, 1:] += delta_velo[frame.component] * track_dir
+                transforms[:, col, :3, 3] += delta_velo * track_dir
+                last_xyz = frame.fxyz[:, 1:].clone()
+
+                # ---- stop rules (cluster_tracking.py:676-691)
+                stopped = stopped | (l1_reg_error > self.reg_error_coeff * comp_diameter *
+                                     (1 + dist_compensate(comp_deg)))
+                stopped = stopped | (comp_edge_ratio < 0.5)
+                if (next_frame_id - frame_id) * track_dir == self.min_move_frame:
+                    moved = (comp_centers[:, next_frame_id] - comp_centers[:, frame_id]).norm(p=2, dim=-1)
+                    moving = moving & (moved > 0.08 * comp_diameter)
+                if last_velo is not None:
+                    dev_velo_norm = (comp_velo - last_velo).norm(p=2, dim=-1)
+                    stopped = stopped | (dev_velo_norm > 0.24 * comp_diameter)
+                    prev_velo = comp_velos[:, next_frame_id - track_dir]
+                    norm = (comp_velo.norm(p=2, dim=-1) * prev_velo.norm(p=2, dim=-1)).clamp(min=1e-6)
+                    angle = ((comp_velo * prev_velo).sum(-1) / norm).clamp(min=-1, max=1).arccos() \
+                        / np.pi * 180.0
+                    stopped = stopped | (angle > self.angle_threshold) & \
+                        (comp_velos[:, next_frame_id, :2].norm(p=2, dim=-1) > 0.01)
+                last_velo = comp_velo
+                if next_frame_id == frame_id - 1:
+                    comp_velos[:, frame_id] = comp_velo
+                if track_dir == -1:
+                    comp_min_frame_id[~stopped] = next_frame_id
+                else:
+                    comp_max_frame_id[~stopped] = next_frame_id
+
+                # ---- harvest the target frame's points next to the moved anchor points
+                frame.fxyz[:, 0] = next_frame_id
+                f_this, f_next, _ = self.nn_graph(frame, next_frame)
+                ok = (~stopped)[frame.component[f_this]]
+                f_this, f_next = f_this[ok], f_next[ok]
+                ex_fxyz.append(next_frame.fxyz[f_next])
+                ex_component.append(frame.component[f_this])
+                ex_seg.append(next_frame.segmentation_label[f_next])
+                ex_indices.append(f_next.reshape(-1))
+                ex_original.append(next_mask.nonzero()[f_next].reshape(-1))
+                frame.fxyz[:, 0] = frame_id
+
+                reg_errors[:, next_frame_id] = l1_reg_error
+                comp_edge_ratios[:, next_frame_id] = comp_edge_ratio
+                next_frame_id += track_dir
+            frame.fxyz = seq_points.fxyz[frame_mask]
+
+        ex_component = torch.cat(ex_component, dim=0)
+        extracted = EasyDict(dict(
+            fxyz=torch.cat(ex_fxyz, dim=0),
+            component=ex_component,
+            segmentation_label=torch.cat(ex_seg, dim=0),
+            frame_indices=torch.cat(ex_indices, dim=0),
+            original_indices=torch.cat(ex_original, dim=0),
+            moving=moving[ex_component],
+            valid_comp_mask=moving[ex_component],
+            gt_box_label=torch.zeros_like(ex_component),
+        ))
+        valid_comp_mask = valid_comp_mask & ((comp_max_frame_id >= frame_id + self.min_move_frame) |
+                                             (comp_min_frame_id <= frame_id - self.min_move_frame))
+        extracted = EasyDict(filter_dict(extracted, valid_comp_mask[extracted.component]))
+        extracted.transforms = transforms
+        seq_points.extracted[extracted.original_indices] = True
+        self.last_track_debug = dict(reg_errors=reg_errors, comp_edge_ratios=comp_edge_ratios,
+                                     comp_velos=comp_velos, comp_min_frame_id=comp_min_frame_id,
+                                     comp_max_frame_id=comp_max_frame_id)
+        return extracted
+
+    # ------------------------------------------------------------------ whole sequence
+    def forward(self, seq_dict):
+        seq_points = EasyDict(
+            fxyz=seq_dict["point_fxyz"],
+            frame=seq_dict["point_sweep"],
+            gt_box_id=seq_dict["point_gt_box_id"],
+        )
+        for key in ("instance_label", "segmentation_label"):
+            if key in seq_dict:
+                seq_points[key] = seq_dict[key]
+        all_points = EasyDict(
+            fxyz=seq_dict["full_point_fxyz"],
+            frame=seq_dict["full_point_sweep"],
+            height=seq_dict["full_point_height"],
+        )
+        for key in ("full_instance_label", "full_segmentation_label"):
+            if key in seq_dict:
+                all_points[key] = seq_dict[key]
+        all_points = EasyDict(filter_dict(all_points, seq_dict["full_point_height"] > 0.0))
+
+        num_frames = int(seq_points.frame.max().long().item()) + 1
+        sequence_id = seq_dict["frame_id"][0][:-4]
+        outfolder = f"{self.model_cfg['DIR']}/{sequence_id}"
+        outpath = f"{outfolder}/all.pth"
+        save = self.model_cfg.get("SAVE", True)
+        if save and os.path.exists(outpath):
+            print(f"{outpath} already exists. skipping...")
+            return seq_dict
+        if save:
+            os.makedirs(outfolder, exist_ok=True)
+
+        seq_boxes = self.format_boxes(seq_dict, num_frames)
+        if seq_boxes.attr.shape[0] == 0:
+            return seq_dict
+        seq_boxes.best_iou = torch.zeros_like(seq_boxes.attr[:, 0])
+
+        results = {}
+        for comp_key in self.component_keys:
+            seq_points.component = seq_dict[f"point_{comp_key}"]
+            diam = component_diameter(seq_points)
+            seq_points.component_diameter = diam[seq_points.component]
+            seq_points.stationary = seq_points.component_diameter > 12.5
+            seq_points.extracted = torch.zeros_like(seq_points.fxyz[:, 0]).bool()
+            for frame_id in range(0, num_frames, self.track_interval):
+                frame_mask = (seq_points.fxyz[:, 0] == frame_id).reshape(-1)
+                if not bool(frame_mask.any()):
+                    continue
+                frame_points = EasyDict(filter_dict(seq_points, frame_mask))
+                frame_points.component = frame_points.component - frame_points.component.min()
+                with Timer(f"Tracking Frame {frame_id}"):
+                    extracted = self.track_frame(seq_points, frame_points, seq_boxes)
+                with Timer("Extract Traces from all points"):
+                    if extracted.fxyz.shape[0] > 0:
+                        extracted, seq_boxes = self.extract_traces_and_update_boxes(
+                            all_points, extracted, seq_boxes)
+                results[(frame_id, comp_key)] = extracted
+                if save:
+                    torch.save(dict(extracted), f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
+                extracted.pop("transforms")
+        if save:
+            torch.save(dict(seq_boxes), outpath)
+        seq_dict["cluster_tracking_results"] = results
+        seq_dict["gt_box_best_iou_tracking"] = seq_boxes.best_iou
+        return seq_dict
+
+    def get_output_feature_dim(self):
+        return 0
+
+    def extra_repr(self):
+        return (f"reg_error_coeff={self.reg_error_coeff}, min_move_frame={self.min_move_frame}, "
+                f"angle_threshold={self.angle_threshold}, track_interval={self.track_interval}")

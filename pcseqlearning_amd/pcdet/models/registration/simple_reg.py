@@ -1,0 +1,106 @@
+"""SimpleReg (pcdet/models/registration/simple_reg.py:13-157): per batch item build the
+`point_fxyz` sequence, subsample it on an 8 cm 4-D grid (keeping the largest original index of
+every occupied cell), format the GT boxes and run the preprocessors in order."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ...utils.common_utils import EasyDict, filter_dict
+from ..model_utils.grid_sampling import GridSampling3D
+from .registration_module_template import RegistrationTemplate
+
+
+def boxes_to_corners_3d(boxes):
+    """[N,7] (x,y,z,dx,dy,dz,heading) -> [N,8,3] (pcdet/utils/box_utils.py, same corner order)."""
+    template = boxes.new_tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
+                                 [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]]) / 2
+    corners = boxes[:, None, 3:6] * template[None]
+    c, s = torch.cos(boxes[:, 6]), torch.sin(boxes[:, 6])
+    rot = torch.stack([torch.stack([c, s, torch.zeros_like(c)], -1),
+                       torch.stack([-s, c, torch.zeros_like(c)], -1),
+                       torch.stack([torch.zeros_like(c), torch.zeros_like(c), torch.ones_like(c)], -1)], 1)
+    return corners @ rot + boxes[:, None, 0:3]
+
+
+class SimpleReg(RegistrationTemplate):
+    def __init__(self, model_cfg, runtime_cfg, dataset):
+        super().__init__(model_cfg, runtime_cfg, dataset)
+        self.module_list = self.build_networks()
+        self.fake_param = nn.Parameter(torch.zeros(1), requires_grad=True)
+        self.forward_dict = EasyDict()
+        self.subsample = model_cfg.get("SUBSAMPLE", False)
+        if self.subsample:
+            self.grid_sampler = GridSampling3D(grid_size=[0.08, 0.08, 0.08])
+
+    def process_sequence(self, seq_dict):
+        for module in self.preprocessors or []:
+            seq_dict = module(seq_dict)
+        return seq_dict
+
+    def format_boxes(self, seq_dict):
+        """Frame ids of the (frame-major, equally many per frame) GT boxes, track labels from the
+        object ids, per-trace velocity from consecutive corner displacement, `moving` flag."""
+        sweeps = seq_dict["point_sweep"]
+        num_frames = int(sweeps.max().long().item()) - int(sweeps.min().long().item()) + 1
+        attr = seq_dict["gt_box_attr"].reshape(-1, 7)
+        cls = seq_dict["gt_box_cls_label"].reshape(-1)
+        assert attr.shape[0] % num_frames == 0, "expects the same number of boxes in every frame"
+        frame = torch.repeat_interleave(torch.arange(0, num_frames), cls.numel() // num_frames).to(cls)
+        keep = attr[:, 3:6].norm(p=2, dim=-1) > 1e-5
+        attr, cls, frame = attr[keep], cls[keep], frame[keep]
+        obj_ids = np.asarray(seq_dict["obj_ids"]).astype(str).reshape(-1)[keep.cpu().numpy()]
+        track = torch.from_numpy(np.unique(obj_ids, return_inverse=True)[1]).to(cls).long()
+        velo = torch.zeros_like(attr[:, 0])
+        for t in track.unique().tolist():
+            tm = (track == t).reshape(-1)
+            order = torch.argsort(frame[tm])
+            corners = boxes_to_corners_3d(attr[tm][order])
+            tv = torch.zeros_like(velo[tm])
+            if tv.numel() > 1:
+                tv[1:] = (corners[1:] - corners[:-1]).norm(p=2, dim=-1).mean(dim=-1)
+                tv[0] = tv[1]
+            velo[tm.nonzero()[:, 0][order]] = tv
+        seq_dict.update(gt_box_attr=attr, gt_box_cls_label=cls, gt_box_frame=frame,
+                        gt_box_track_label=track, gt_box_velo=velo, moving=velo > 5e-2,
+                        obj_ids=obj_ids)
+        return seq_dict
+
+    def build_sequence(self, batch_dict, b):
+        seq_dict = EasyDict()
+        mask = (batch_dict["point_bxyz"][:, 0] == b).reshape(-1)
+        for key in ("point_bxyz", "point_feat", "segmentation_label", "instance_label",
+                    "is_foreground", "point_sweep"):
+            if key in batch_dict:
+                seq_dict[key] = batch_dict[key][mask]
+        seq_dict["point_fxyz"] = torch.cat([seq_dict["point_sweep"].reshape(-1, 1).to(seq_dict["point_bxyz"]),
+                                            seq_dict["point_bxyz"][:, 1:]], dim=-1)
+        seq_dict.pop("point_bxyz")
+        if self.subsample:
+            seg = self.grid_sampler.segments(seq_dict["point_fxyz"].contiguous())
+            pick = ops.segment_pick(seg, last=True)  # scatter(arange, inv, 'max')
+            for key in ("point_fxyz", "point_feat", "segmentation_label", "instance_label",
+                        "is_foreground", "point_sweep"):
+                if key in seq_dict:
+                    seq_dict[key] = seq_dict[key][pick]
+        for key in ("gt_box_cls_label", "gt_box_attr", "obj_ids", "frame_id"):
+            if key in batch_dict:
+                seq_dict[key] = batch_dict[key][b]
+        return self.format_boxes(seq_dict)
+
+    def forward(self, batch_dict):
+        outputs = []
+        for b in range(batch_dict["batch_size"]):
+            seq_dict = self.build_sequence(batch_dict, b)
+            sequence_id = seq_dict["frame_id"][0][:-4]
+            save_dir = self.model_cfg.get("SAVE_DIR", None)
+            if save_dir is None or not os.path.exists(f"{save_dir}/{sequence_id}/all.pth"):
+                seq_dict = self.process_sequence(seq_dict)
+            outputs.append(seq_dict)
+        self.last_outputs = outputs
+        if self.training:
+            device = batch_dict["point_bxyz"].device
+            return dict(loss=torch.zeros(1, device=device, requires_grad=True)), {}, {}
+        return {}, None

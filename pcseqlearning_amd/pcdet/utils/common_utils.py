@@ -1,0 +1,41 @@
+"""The two helpers of pcdet/utils/common_utils.py that the hot path uses."""
+import numpy as np
+import torch
+
+
+class EasyDict(dict):
+    """Attribute-style dict (the reference uses the `easydict` package, absent on the target)."""
+
+    def __init__(self, d=None, **kwargs):
+        super().__init__()
+        for k, v in dict(d or {}, **kwargs).items():
+            self[k] = v
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+
+def filter_dict(data_dict, mask, ignore_keys=()):
+    """Index every value of a dict with the same mask / index tensor
+    (pcdet/utils/common_utils.py:67-78), checking lengths for boolean masks."""
+    out = {}
+    for key, val in data_dict.items():
+        if key in ignore_keys:
+            out[key] = val
+            continue
+        if isinstance(mask, (torch.Tensor, np.ndarray)) and mask.dtype in (torch.bool, np.bool_):
+            assert mask.shape[0] == len(val), \
+                f"MisMatch for key={key}, mask.shape={mask.shape}, data.shape={len(val)}"
+        out[key] = val[mask]
+    return out
+
+
+def indexing_list_elements(data_dict, idx):
+    """Pick element idx of every list-valued entry (graph configs with per-level lists)."""
+    return {k: (v[idx] if isinstance(v, list) else v) for k, v in data_dict.items()}
