@@ -1,0 +1,6 @@
+from .spconv_backbone import VoxelBackBone8x
+from .vfe import DynamicMeanVFE, MeanVFE  # noqa: F401
+
+__all__ = {
+    "VoxelBackBone8x": VoxelBackBone8x,
+}

@@ -1,0 +1,117 @@
+"""SparseConvolution and its 3-D front-ends (pcdet/ops/spconv/conv.py:48-445): weight
+[k,k,k,Cin,Cout], rulebook cached under `indice_key` in the tensor's `indice_dict` as
+(outids, indices, indice_pairs, indice_pair_num, spatial_shape). The cached entry additionally
+keeps the output-major neighbour table the HIP conv kernel consumes."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from .... import ops as _ops
+from . import ops
+from .modules import SparseModule
+from .structure import SparseConvTensor
+
+
+def _fan_in_hwio(weight):
+    receptive = weight[..., 0, 0].numel() if weight.dim() > 2 else 1
+    return weight.size(-2) * receptive
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, fused_bn=False):
+        super().__init__()
+        assert groups == 1
+        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim  # noqa: E731
+        kernel_size, stride, padding = as_list(kernel_size), as_list(stride), as_list(padding)
+        dilation, output_padding = as_list(dilation), as_list(output_padding)
+        for d, s in zip(dilation, stride):
+            assert any([s == 1, d == 1]), "don't support this."
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.dilation, self.output_padding = dilation, output_padding
+        self.conv1x1 = np.prod(kernel_size) == 1
+        self.transposed, self.inverse = transposed, inverse
+        self.groups, self.subm, self.indice_key, self.fused_bn = groups, subm, indice_key, fused_bn
+        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(_fan_in_hwio(self.weight))
+            init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features, indices = input.features, input.indices
+        spatial_shape, batch_size = input.spatial_shape, input.batch_size
+        if self.subm:
+            out_spatial_shape = spatial_shape
+        elif self.transposed:
+            out_spatial_shape = ops.get_deconv_output_size(spatial_shape, self.kernel_size, self.stride,
+                                                           self.padding, self.dilation, self.output_padding)
+        else:
+            out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride,
+                                                         self.padding, self.dilation)
+        if self.conv1x1:
+            feats = torch.mm(features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                feats = feats + self.bias
+            out = SparseConvTensor(feats, indices, spatial_shape, batch_size)
+            out.indice_dict, out.grid = input.indice_dict, input.grid
+            return out
+        datas = input.find_indice_pair(self.indice_key)
+        table = None
+        if self.inverse:
+            assert datas is not None and self.indice_key is not None
+            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas[:5]
+            assert indice_pairs.shape[0] == np.prod(self.kernel_size), \
+                "inverse conv must have same kernel size as its couple conv"
+        elif self.indice_key is not None and datas is not None:
+            outids, _, indice_pairs, indice_pair_num, _ = datas[:5]
+            table = datas[5] if len(datas) > 5 else None
+        else:
+            outids, indice_pairs, indice_pair_num = ops.get_indice_pairs(
+                indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
+                self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid)
+            table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0])
+            input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num,
+                                                  spatial_shape, table)
+        if table is None:
+            table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0], self.inverse)
+        out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
+                                              self.subm and not self.inverse, bias=self.bias)
+        out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out.indice_dict, out.grid = input.indice_dict, input.grid
+        return out
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, True, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)

@@ -1,0 +1,48 @@
+"""pcdet/ops/spconv/ops.py: output-size helpers, get_indice_pairs, indice_conv on the HIP kernels."""
+from .... import ops as _ops
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    out = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+def _list(v, ndim):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None):
+    ndim = indices.shape[1] - 1
+    if ndim != 3:
+        raise NotImplementedError("only 3-D rulebooks are on the hot path")
+    ksize, stride, padding = _list(ksize, ndim), _list(stride, ndim), _list(padding, ndim)
+    dilation, out_padding = _list(dilation, ndim), _list(out_padding, ndim)
+    for d, s in zip(dilation, stride):
+        assert any([s == 1, d == 1]), "don't support this."
+    if subm:
+        out_shape = list(spatial_shape)
+    elif transpose:
+        out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, out_padding)
+    else:
+        out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    return _ops.get_indice_pairs(indices, batch_size, out_shape, list(spatial_shape), ksize, stride,
+                                 padding, dilation, subm, transpose)
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,
+                subm=False):
+    return _ops.indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
+                            inverse, subm)

@@ -1,0 +1,64 @@
+"""Pins the numpy tracking oracle (oracle/track_oracle.py) to golden vectors produced by the
+reference's own smooth_velo / component_diameter / track_frame (tests/golden/make_golden_track.py).
+
+track_frame is chaotic at its decision thresholds: the reference computes ICP centres with fp32
+scatter sums whose order is unspecified (its own results move by ~1e-5 run to run), and a single
+nearest-neighbour flip can push one component across a stop rule. The oracle is therefore pinned
+(a) exactly on everything upstream of such flips (smooth_velo, diameters, per-call ICP: see
+test_oracle_registration.py) and (b) statistically on the end-to-end extraction. CPU."""
+import os
+
+import numpy as np
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_smooth_velo_vs_reference():
+    from oracle import track_oracle as T
+    g = np.load(os.path.join(G, "smooth_velo.npz"))
+    for name in ("fwd", "bwd", "one", "same"):
+        a, b = g[f"range_{name}"]
+        out = T.smooth_velo(g["velos"].copy(), g["diffs"], int(a), int(b))
+        np.testing.assert_allclose(out, g[f"out_{name}"], rtol=0, atol=2e-5)
+
+
+def _seq(g):
+    from oracle import track_oracle as T
+    comp = g["component"]
+    C = int(comp.max()) + 1
+    diam = T.component_diameter(g["fxyz"], comp, C)
+    seq = dict(fxyz=g["fxyz"].copy(), frame=g["fxyz"][:, 0].astype(np.int64), component=comp,
+               stationary=diam[comp] > 12.5, extracted=np.zeros(len(comp), bool))
+    return seq, diam
+
+
+def test_component_diameter_vs_reference():
+    g = np.load(os.path.join(G, "track_small.npz"))
+    _, diam = _seq(g)
+    np.testing.assert_allclose(diam, g["comp_diameter"], rtol=1e-5, atol=1e-5)
+
+
+def test_track_frame_vs_reference():
+    from oracle import track_oracle as T
+    g = np.load(os.path.join(G, "track_small.npz"))
+    seq, _ = _seq(g)
+    tracker = T.Tracker()
+    for frame_id in (0, 8):
+        ex = tracker.track_frame(seq, frame_id)
+        want = set(g[f"a{frame_id}_original_indices"].tolist())
+        got = set(ex["original_indices"].tolist())
+        jacc = len(want & got) / len(want | got)
+        assert jacc > 0.9, (frame_id, jacc, len(want), len(got))
+        # components tracked by both: transforms agree to the reference's own fp32 noise for most
+        wc = set(g[f"a{frame_id}_component"].tolist())
+        gc = set(ex["component"].tolist())
+        both = sorted(wc & gc)
+        assert len(both) >= 0.8 * len(wc | gc)
+        # the first steps away from the anchor agree to fp32 noise; later frames inherit every
+        # earlier flip (the multi-frame chain amplifies 1e-6 perturbations to centimetres)
+        W, M = g[f"a{frame_id}_transforms"][both], ex["transforms"][both]
+        anchor_col = frame_id - max(0, frame_id - 8)
+        near = [c for c in (anchor_col - 1, anchor_col + 1) if 0 <= c < W.shape[1]]
+        d_near = np.abs(W[:, near] - M[:, near]).max(axis=(1, 2, 3))
+        assert np.median(d_near) < 1e-4, np.median(d_near)
+        assert np.median(np.abs(W - M).max(axis=(1, 2, 3))) < 0.5
