@@ -1,12 +1,23 @@
-"""bench.py -- throughput of the hot path on synthetic Waymo-shaped input, one process per GPU.
+"""bench.py -- end-to-end cluster-tracking throughput on synthetic Waymo-shaped sequences.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job throughput with inputs
-resident in HBM, plus `roofline` for the dominant kernel (HIP-event timed on the launch stream)
-and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload, rank 0, N=1).
+Workload = BASELINE.json configs[2]: a 20-frame x 160k-pt sequence through the reference's
+cluster_tracking_TLS_multiradius_every8 pipeline (8 cm subsample -> GroundPlaneRemover ->
+ClusterProposal at 3 radii -> ClusterTracking: 3 keys x anchors {0, 8, 16} x +-8 frames x 3 ICP
+levels), one sequence per GPU per step, inputs resident in HBM before the timed region, nothing
+written to disk. N GPUs process N different sequences (weak scaling); the only collective is the
+final all-reduce of {max wall time, sequences done} over RCCL.
+
+Rank 0 prints ONE JSON line: whole-job sequences/s plus
+  roofline      dominant kernel of the tracking stage (icp_nn_pass1_kernel: two-direction 1-NN
+                search + pass-1 reduction of the fused ICP), timed with HIP events on its launch
+                stream inside the timed steps; achieved = algorithmic bytes / kernel time.
+  cpu_baseline  the CPU oracle (serial numpy/C++ restatement, kind "port") timed on a bounded
+                sample of the same sequence and scaled to sequences/s (rank 0, N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -18,86 +29,81 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pcseqlearning_amd import ops, synthetic  # noqa: E402
+from pcseqlearning_amd import lib as L  # noqa: E402
+from pcseqlearning_amd import synthetic  # noqa: E402
+from pcseqlearning_amd.pcdet import models  # noqa: E402
+from pcseqlearning_amd.pcdet.utils import timer  # noqa: E402
+from tools.run_sequence import build_model  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-FRAMES_PER_SEQUENCE = 20
-SHAPE_ZYX = [41, 1504, 1504]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-class FrameWorkload:
-    """BASELINE config 2: one 160k-pt frame -> dynamic voxelization (voxel hash) -> subM 3x3x3
-    rulebook -> sparse conv C->16. A 'sequence' is 20 such frames (different seeds)."""
+def load_sequence(seed, frames, points):
+    """Synthetic sequence, cached under /tmp (generation is ~2 s of numpy ray casting per frame)."""
+    import pickle
+    path = f"/tmp/pcs_seq_s{seed}_f{frames}_p{points}.pkl"
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    batch = synthetic.gen_sequence(seed, frames, points)
+    try:
+        with open(path + f".{os.getpid()}", "wb") as f:
+            pickle.dump(batch, f)
+        os.replace(path + f".{os.getpid()}", path)
+    except OSError:
+        pass
+    return batch
 
-    name = "config2: 20 x (160k-pt frame: dynamic voxelize + subM 3x3x3 rulebook + sparse conv 5->16)"
 
-    def __init__(self, device, rank, n_points=160_000, frames=FRAMES_PER_SEQUENCE):
-        self.device = device
-        self.frames = []
-        # two distinct scenes per rank are enough to defeat caching; frames differ by seed
-        for f in range(frames):
-            pts = synthetic.gen_voxel_frame(seed=rank * 100 + (f % 4), n_target=n_points)
-            self.frames.append(torch.from_numpy(pts).to(device))
-        self.W = torch.from_numpy(np.random.default_rng(7).normal(0, 0.05, (3, 3, 3, 5, 16)).astype(np.float32)).to(device)
-        self.stats = {}
-
-    def frame(self, pts):
-        feat, coords, _ = ops.dynamic_voxelize(pts, synthetic.PC_RANGE, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE)
-        _, pairs, num = ops.get_indice_pairs(coords, 1, SHAPE_ZYX, SHAPE_ZYX, [3, 3, 3], [1, 1, 1],
-                                             [1, 1, 1], [1, 1, 1], True)
-        out = ops.indice_conv(feat, self.W, pairs, num, coords.shape[0], False, True)
-        return feat, coords, pairs, num, out
-
-    def step(self):
-        """One sequence = every frame once."""
-        for pts in self.frames:
-            self.frame(pts)
-
-    def roofline(self, reps=20):
-        """Dominant kernel group = the rulebook build (pcs_get_indice_pairs). Algorithmic bytes
-        (SURVEY 8d): 16*V read + 8*sum(P_k) write + 108."""
-        pts = self.frames[0]
-        feat, coords, pairs, num, _ = self.frame(pts)
-        V = coords.shape[0]
-        P = int(num.sum().item())
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        start.record()
-        for _ in range(reps):
-            ops.get_indice_pairs(coords, 1, SHAPE_ZYX, SHAPE_ZYX, [3, 3, 3], [1, 1, 1], [1, 1, 1],
-                                 [1, 1, 1], True)
-        end.record()
-        torch.cuda.synchronize()
-        ms = start.elapsed_time(end) / reps
-        alg_bytes = 16 * V + 8 * P + 108
-        achieved = alg_bytes / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "pcs_get_indice_pairs (subM rulebook: table build + count + scan + fill)",
-                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "V": V, "pairs": P}
-
-    def cpu_baseline(self):
-        """The CPU oracle (a serial restatement, kind 'port') on ONE frame of the same workload."""
-        from oracle import oracle as O
-        pts = self.frames[0].cpu().numpy()
-        W = self.W.cpu().numpy()
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < 10.0:
-            feat, coords, _ = O.dynamic_voxelize(pts, synthetic.PC_RANGE, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE)
-            _, pairs, num = O.get_indice_pairs(coords, SHAPE_ZYX, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], True)
-            O.indice_conv(feat, W, pairs, num, coords.shape[0], False, True)
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": round(reps / dt / FRAMES_PER_SEQUENCE, 4), "unit": "sequences/s", "cores": 1,
-                "kind": "port", "sample": f"{reps} frame passes of the same workload in {dt:.1f}s, single thread"}
+def cpu_baseline(batch, out, n_reg_calls):
+    """Oracle timed on: 8 cm subsample of the whole sequence, one 10-frame proposal chunk at
+    r = 0.25, and the 3 ICP levels of ONE anchor->next-frame pair; scaled by the number of such
+    units the GPU run executed. Ground removal has no CPU oracle (its third-party leaves are
+    unpinned) and is left out of the CPU estimate, which therefore flatters the CPU."""
+    from oracle import oracle as O
+    from oracle import reg_oracle as R
+    from oracle import track_oracle as T
+    t_all = time.perf_counter()
+    fxyz = np.concatenate([batch["point_sweep"].astype(np.float32), batch["point_bxyz"][:, 1:]], 1)
+    t0 = time.perf_counter()
+    O.grid_sample(fxyz, [0.08, 0.08, 0.08])
+    t_sub = time.perf_counter() - t0
+    pts = out["point_fxyz"].cpu().numpy()
+    frame = pts[:, 0].astype(np.int64)
+    comp = out["point_component_rad0x25"].cpu().numpy()
+    # one proposal chunk (10 frames) at the finest radius, 32-NN graph + components
+    m = frame < 10
+    t0 = time.perf_counter()
+    e0, e1 = O.radius_graph(pts[m][:60000], pts[m][:60000], 0.25, 32, True)
+    O.connected_components(e0, e1, min(int(m.sum()), 60000))
+    t_prop = (time.perf_counter() - t0) * (m.sum() / min(int(m.sum()), 60000))
+    # one frame pair, 3 levels
+    diam = T.component_diameter(pts, comp, int(comp.max()) + 1)
+    stat = diam[comp] > 12.5
+    f0 = dict(fxyz=pts[frame == 0].copy(), component=comp[frame == 0] - comp[frame == 0].min(),
+              stationary=stat[frame == 0], frame=frame[frame == 0])
+    f1 = dict(fxyz=pts[frame == 1], component=comp[frame == 1], stationary=stat[frame == 1], frame=frame[frame == 1])
+    C = int(f0["component"].max()) + 1
+    t0 = time.perf_counter()
+    for radius, vs in ((2.5, (0.4, 0.4, 0.6)), (1.25, (0.2, 0.2, 0.3)), (1.0, (0.1, 0.1, 0.15))):
+        a, b = T.sample_frame(vs, f0), T.sample_frame(vs, f1)
+        R.register_to_next_frame(R.Graph(radius), a, b, C, 10.0, 80, 0.05)
+    t_pair = time.perf_counter() - t0
+    n_pairs = n_reg_calls / 3.0
+    est = t_sub + t_prop * 2 * 3 + t_pair * n_pairs  # 2 chunks x 3 radii (coarser radii cost more)
+    return {"value": round(1.0 / est, 6), "unit": "sequences/s", "cores": 1, "kind": "port",
+            "sample": (f"oracle timed {time.perf_counter() - t_all:.1f}s on: 8cm subsample ({t_sub:.1f}s), one "
+                       f"10-frame r=0.25 proposal chunk ({t_prop:.1f}s, x6), one frame pair x 3 ICP levels "
+                       f"({t_pair:.1f}s, x{n_pairs:.0f} pairs); ground removal excluded; scaled to one sequence")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,56 +115,87 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group("nccl")  # RCCL over xGMI on ROCm
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    wl = FrameWorkload(device, rank)
+    host_batch = load_sequence(rank, args.frames, args.points)  # sequence s -> GPU s mod world
+    batch = models.load_data_to_gpu(host_batch, device)
+    model = build_model(save=False, device=device)
+    lib = L.load()
+
+    def step():
+        with torch.no_grad():
+            model(batch)
+
     for _ in range(args.warmup):
-        wl.step()
+        step()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib.pcs_profile_icp_nn(ctypes.c_int(1))
+    timer.RECORDS.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 3)()
+    lib.pcs_profile_icp_nn_read(prof)
+    lib.pcs_profile_icp_nn(ctypes.c_int(0))
+
+    total_sequences = float(args.steps)
     if dist is not None:
-        # the only collective of the path: MAX of the wall time, SUM of sequences processed
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         n = torch.tensor([float(args.steps)], dtype=torch.float64, device=device)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         total_sequences = float(n.item())
-    else:
-        total_sequences = float(args.steps)
 
     if rank == 0:
+        out = model.last_outputs[0]
+        ms, launches, nbytes = prof[0], prof[1], prof[2]
+        achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         line = {
-            "metric": "Waymo sequences/s (20-frame, 160k-pt)",
-            "value": round(total_sequences / dt, 4),
+            "metric": "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking",
+            "value": round(total_sequences / dt, 5),
             "unit": "sequences/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 points / f64 solve",
             "data": "synthetic",
-            "config": {"workload": wl.name, "points_per_frame": int(wl.frames[0].shape[0]),
-                       "frames_per_sequence": FRAMES_PER_SEQUENCE, "parallelism": f"one sequence per GPU x{world}"},
-            "roofline": wl.roofline(),
+            "config": {
+                "workload": ("configs[2]: 20-frame x 160k-pt synthetic sequence, "
+                             "cluster_tracking_TLS_multiradius_every8 end to end "
+                             "(subsample + ground removal + 3-radius proposal + tracking)"),
+                "frames": args.frames, "points_per_frame": args.points,
+                "points_after_subsample": int(out["full_point_fxyz"].shape[0]),
+                "points_after_ground_removal": int(out["point_fxyz"].shape[0]),
+                "parallelism": f"one sequence per GPU x{world}",
+                "stage_seconds_per_step": {k: round(v / args.steps, 3) for k, v in timer.RECORDS.items()},
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "icp_nn_pass1_kernel (fused ICP: 2-direction 1-NN search + pass-1 reduce)",
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = wl.cpu_baseline()
+            n_reg = model.preprocessors[2].num_registration_calls  # of the last step
+            line["config"]["icp_level_calls_per_sequence"] = n_reg
+            line["cpu_baseline"] = cpu_baseline(host_batch, out, n_reg)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -235,6 +235,13 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
                         float* height_out, int32_t* d_iters, void* ws, size_t ws_bytes,
                         pcs_stream_t stream);
 
+/* Measurement support for bench.py (not on the data path): HIP-event timing, on the launch
+ * stream, of the dominant kernel of the tracking stage (the fused ICP's two-direction 1-NN search +
+ * pass-1 reduction). enable=1 resets and starts accumulating; read returns HOST doubles
+ * {milliseconds, launches, algorithmic bytes}. */
+int pcs_profile_icp_nn(int enable);
+int pcs_profile_icp_nn_read(double* out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -505,6 +505,17 @@ icp_finish_kernel(int64_t C, const double* __restrict__ acc1, const int32_t* __r
   }
 }
 
+// ---- optional HIP-event timing of the dominant kernel (icp_nn_pass1_kernel), for bench.py ----
+struct NnProfile {
+  bool on = false;
+  double ms = 0.0;        // summed launch durations of the iterations that did work
+  int64_t launches = 0;
+  double bytes = 0.0;     // algorithmic bytes of those launches
+  hipEvent_t ev[2 * 96];
+  bool have = false;
+};
+static NnProfile g_prof;
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -512,6 +523,28 @@ using namespace pcs;
 extern "C" {
 
 int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
+
+// bench.py support: time icp_nn_pass1_kernel with HIP events on the launch stream.
+int pcs_profile_icp_nn(int enable) {
+  if (enable && !g_prof.have) {
+    for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
+    g_prof.have = true;
+  }
+  g_prof.on = enable != 0;
+  g_prof.ms = 0.0;
+  g_prof.launches = 0;
+  g_prof.bytes = 0.0;
+  return PCS_OK;
+}
+
+// out3 (host): {milliseconds, launches, algorithmic bytes} accumulated since the last enable.
+int pcs_profile_icp_nn_read(double* out3) {
+  if (!out3) return PCS_ERR_ARG;
+  out3[0] = g_prof.ms;
+  out3[1] = (double)g_prof.launches;
+  out3[2] = g_prof.bytes;
+  return PCS_OK;
+}
 
 size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_t Ra, int64_t C) {
   Arena a(nullptr, 0);
@@ -595,10 +628,13 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       icp_insert_moving_kernel<<<nb_m, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn, b.grid,
                                                        b.keys_m, b.head_m, b.next_m, b.Hm - 1,
                                                        b.fr_m, b.state, b.acc1, b.acc2, C);
+      bool prof = g_prof.on && (it + k) < 96;
+      if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k)], s));
       icp_nn_pass1_kernel<<<nb_e, kBlock, 0, s>>>(
           (const float4*)mov_fxyz, (int)Mn, (const float4*)ref_fxyz, (int)Rn, mov_comp, b.grid,
           frame_offset, b.keys_r, b.head_r, b.next_r, b.Hr - 1, b.fr_r, b.keys_m, b.head_m,
           b.next_m, b.Hm - 1, b.fr_m, b.state, b.nn_f, b.nn_b, b.acc1);
+      if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k) + 1], s));
       icp_pass2_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
                                                   (const float4*)ref_fxyz, (int)Rn, mov_comp,
                                                   b.nn_f, b.nn_b, b.state, b.acc1, b.acc2, nullptr, 0.0);
@@ -613,6 +649,18 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (host.err) return PCS_ERR_RANGE;
     if (host.done) break;
+  }
+  if (g_prof.on) {
+    // only the iterations that ran (later launches exit on the done flag)
+    int n_it = host.iters < 96 ? host.iters : 96;
+    for (int k = 0; k < n_it; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]) == hipSuccess) g_prof.ms += ms;
+    }
+    g_prof.launches += n_it;
+    // per launch: read every query point and every hashed point (16 B rows), write one int32
+    // neighbour per query (16 N + 16 M per graph, two graphs per iteration)
+    g_prof.bytes += (double)n_it * (2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn));
   }
   info[0] = host.iters;
   info[1] = host.done ? 1 : 0;

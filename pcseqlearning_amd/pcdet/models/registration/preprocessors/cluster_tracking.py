@@ -125,6 +125,7 @@ class ClusterTracking(nn.Module):
         self.min_move_frame = params.get("MIN_MOVE_FRAME", 6)
         self.component_keys = model_cfg["COMPONENT_KEYS"]
         self.verbose = bool((runtime_cfg or {}).get("verbose", False))
+        self.num_registration_calls = 0
 
     # ------------------------------------------------------------------ boxes
     def format_boxes(self, seq_dict, num_frames):
@@ -277,6 +278,7 @@ class ClusterTracking(nn.Module):
                     graph = getattr(self, f"registration_graph_{i}")
                     sub_frame = sample_frame(sampler, frame)
                     sub_next = sample_frame(sampler, next_frame)
+                    self.num_registration_calls += 1
                     with Timer(f"REGISTRATION at Level {i}"):
                         sub_frame, T, _l1, _ratio = register_to_next_frame(
                             graph, sub_frame, sub_next, num_components,
@@ -388,6 +390,7 @@ class ClusterTracking(nn.Module):
         all_points = EasyDict(filter_dict(all_points, seq_dict["full_point_height"] > 0.0))
 
         num_frames = int(seq_points.frame.max().long().item()) + 1
+        self.num_registration_calls = 0
         sequence_id = seq_dict["frame_id"][0][:-4]
         outfolder = f"{self.model_cfg['DIR']}/{sequence_id}"
         outpath = f"{outfolder}/all.pth"
