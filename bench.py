@@ -10,8 +10,8 @@ written to disk. N GPUs process N different sequences (weak scaling); the only c
 final all-reduce of {max wall time, sequences done} over RCCL.
 
 Rank 0 prints ONE JSON line: whole-job sequences/s plus
-  roofline      dominant kernel of the tracking stage (icp_nn_pass1_kernel: two-direction 1-NN
-                search + pass-1 reduction of the fused ICP), timed with HIP events on its launch
+  roofline      dominant kernel of the tracking stage (icp_nn_kernel: two-direction 1-NN
+                search of the fused ICP), timed with HIP events on its launch
                 stream inside the timed steps; achieved = algorithmic bytes / kernel time.
   cpu_baseline  the CPU oracle (serial numpy/C++ restatement, kind "port") timed on a bounded
                 sample of the same sequence and scaled to sequences/s (rank 0, N = 1 only).
@@ -185,7 +185,7 @@ def main():
                 "stage_seconds_per_step": {k: round(v / args.steps, 3) for k, v in timer.RECORDS.items()},
             },
             "roofline": {
-                "bound": "hbm", "kernel": "icp_nn_pass1_kernel (fused ICP: 2-direction 1-NN search + pass-1 reduce)",
+                "bound": "hbm", "kernel": "icp_nn_kernel (fused ICP: two-direction 1-NN search, 32 lanes per query)",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),

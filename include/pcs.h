@@ -60,7 +60,8 @@ int pcs_unique_i64(const int64_t* ids, int64_t n, int key_bits, int64_t* uniq, i
  * cluster_tracking.py:44) over the segments of pcs_unique_i64. mean bit 0: 1 = mean, 0 = sum.
  * mean bit 1 clear: summed serially in ascending original index (voxel-sized segments);
  * set (d <= 16): one wave per segment, lane-strided partial sums + butterfly (pillar- and
- * component-sized segments). Both orders are fixed, so results are reproducible run to run.
+ * component-sized segments); mean bit 2 set (d <= 16): one 256-thread workgroup per segment (few,
+ * very large segments: ground super-pillars). All orders are fixed: reproducible run to run.
  * data [n,d] f32 -> out [v,d]. */
 int pcs_segment_reduce_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start,
                            int64_t v, int mean, float* out, pcs_stream_t stream);

@@ -1,0 +1,352 @@
+// Two-level cell grid for the fused ICP's 1-NN searches (pcs_icp.hip).
+//
+// Points are counting-sorted into FINE cells of size h (contiguous storage: a candidate cell is one
+// coalescable run of float4 rows, loads are independent of each other -- no pointer chasing), and a
+// COARSE table of 4x4x4-fine-cell blocks keeps a 64-bit occupancy mask per block. With
+// h = (spatial radius)/4 a query's whole search ball lies inside its 3x3x3 coarse neighbourhood, so
+// the expanding-ring walk tests 27 masks held in registers and touches memory only for occupied
+// fine cells; a query with nothing around it leaves after the 27 mask loads.
+//
+// Build = memsets + count kernel (fine CAS + counter, coarse CAS + atomicOr) + single-block scan of
+// the fine-slot counters + fill kernel. Order inside a cell is arbitrary (atomic cursor); the search
+// result does not depend on it because ties resolve by (dist2, original index).
+#pragma once
+#include "pcs_grid.hpp"
+
+namespace pcs {
+
+struct Grid2 {
+  uint64_t* fkeys;   // [Hf] fine cell keys
+  int32_t* fcount;   // [Hf] points per fine slot
+  int32_t* fstart;   // [Hf] exclusive prefix of fcount
+  int32_t* fcursor;  // [Hf] fill cursor
+  uint64_t* ckeys;   // [Hc] coarse block keys
+  uint64_t* cmask;   // [Hc] occupancy of the 64 fine cells of the block
+  float4* spts;      // [N] points in cell order
+  int32_t* sidx;     // [N] original index of spts rows
+  int32_t* pslot;    // [N] fine slot of every original point
+  float* fr;         // [2*kFrameCells] frame-value range per frame cell
+  uint32_t Hf, Hc;
+  // reset spans: [ff_begin, ff_begin+ff_bytes) <- 0xFF (keys), [z_begin, z_begin+z_bytes) <- 0
+  void *ff_begin, *z_begin;
+  size_t ff_bytes, z_bytes;
+};
+
+static inline uint32_t g2_pow2(uint64_t x) { uint32_t h = 64; while (h < x) h <<= 1; return h; }
+
+static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
+  if (N < 1) N = 1;
+  g.Hf = g2_pow2(2 * (uint64_t)N);
+  g.Hc = g2_pow2(2 * (uint64_t)N);
+  size_t o0 = a.off;
+  g.fkeys = a.take<uint64_t>(g.Hf);
+  g.ckeys = a.take<uint64_t>(g.Hc);
+  size_t o1 = a.off;
+  g.fcount = a.take<int32_t>(g.Hf);
+  g.fcursor = a.take<int32_t>(g.Hf);
+  g.cmask = a.take<uint64_t>(g.Hc);
+  size_t o2 = a.off;
+  g.fstart = a.take<int32_t>(g.Hf);
+  g.ff_begin = a.dry ? nullptr : (void*)(a.base + o0);
+  g.ff_bytes = o1 - o0;
+  g.z_begin = a.dry ? nullptr : (void*)(a.base + o1);
+  g.z_bytes = o2 - o1;
+  g.spts = a.take<float4>(N);
+  g.sidx = a.take<int32_t>(N);
+  g.pslot = a.take<int32_t>(N);
+  g.fr = a.take<float>(2 * kFrameCells);
+}
+
+__device__ __forceinline__ uint32_t g2_claim(uint64_t* __restrict__ keys, uint32_t hmask, uint64_t key) {
+  uint32_t slot = mix64(key) & hmask;
+  while (true) {
+    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmpty,
+                              (unsigned long long)key);
+    if (prev == kEmpty || prev == key) return slot;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+__device__ __forceinline__ int g2_find(const uint64_t* __restrict__ keys, uint32_t hmask, uint64_t key) {
+  uint32_t slot = mix64(key) & hmask;
+  while (true) {
+    uint64_t k = keys[slot];
+    if (k == key) return (int)slot;
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & hmask;
+  }
+}
+
+// `skip` (device flag, may be null): when set the kernel does nothing (ICP already converged)
+static __global__ void __launch_bounds__(kBlock)
+g2_count_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restrict__ gp, Grid2 g,
+                const int* __restrict__ skip, int* __restrict__ err) {
+  if (skip && *skip) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  GridDesc d = *gp;
+  bool in = i < N;
+  float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int fc = frame_cell(d, p.x);
+  int x = (int)floorf((p.y - d.lo[0]) / d.h);
+  int y = (int)floorf((p.z - d.lo[1]) / d.h);
+  int z = (int)floorf((p.w - d.lo[2]) / d.h);
+  bool ok = in && !(x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax ||
+                    fc < 0 || fc >= kFrameCells);
+  if (in && !ok) { atomicExch(err, 1); g.pslot[i] = -1; }
+  // frame-value range per frame cell: a cloud is usually ONE frame, so every point would hit
+  // the same two words -- reduce across the wave first when the wave agrees on the frame cell
+  {
+    unsigned long long act = __ballot(ok);
+    if (act) {
+      int leader = __ffsll((long long)act) - 1;
+      int lfc = __shfl(fc, leader, 64);
+      bool uniform = __ballot(ok && fc != lfc) == 0;
+      if (uniform) {
+        float mn = wave_min(ok ? p.x : __builtin_inff());
+        float mx = wave_max(ok ? p.x : -__builtin_inff());
+        if ((threadIdx.x & 63) == leader) {
+          atomic_min_f32(&g.fr[lfc], mn);
+          atomic_max_f32(&g.fr[kFrameCells + lfc], mx);
+        }
+      } else if (ok) {
+        atomic_min_f32(&g.fr[fc], p.x);
+        atomic_max_f32(&g.fr[kFrameCells + fc], p.x);
+      }
+    }
+  }
+  if (!ok) return;
+  uint32_t fs = g2_claim(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
+  atomicAdd(&g.fcount[fs], 1);
+  g.pslot[i] = (int32_t)fs;
+  uint32_t cs = g2_claim(g.ckeys, g.Hc - 1, pack_cell(fc, x >> 2, y >> 2, z >> 2));
+  int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
+  atomicOr((unsigned long long*)&g.cmask[cs], 1ULL << bit);
+}
+
+// exclusive scan of fcount[Hf] -> fstart, one block
+static __global__ void __launch_bounds__(1024)
+g2_scan_kernel(Grid2 g, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ int part[1024];
+  int tid = threadIdx.x;
+  int per = (int)(g.Hf / 1024);  // Hf is a power of two >= 64; for Hf < 1024 per = 0
+  if (per == 0) {
+    if (tid == 0) {
+      int run = 0;
+      for (uint32_t s = 0; s < g.Hf; ++s) { g.fstart[s] = run; run += g.fcount[s]; }
+    }
+    return;
+  }
+  int base = tid * per, sum = 0;
+  for (int k = 0; k < per; ++k) sum += g.fcount[base + k];
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int k = 0; k < per; ++k) { g.fstart[base + k] = run; run += g.fcount[base + k]; }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+g2_fill_kernel(const float4* __restrict__ pts, int N, Grid2 g, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int fs = g.pslot[i];
+  if (fs < 0) return;
+  int pos = g.fstart[fs] + atomicAdd(&g.fcursor[fs], 1);
+  g.spts[pos] = pts[i];
+  g.sidx[pos] = i;
+}
+
+// nearest point of the grid within the radius (frame cell = query frame cell + df), canonical ties
+// (dist2, original index). Returns the ORIGINAL index or -1. *overflow is set when the spatial
+// search radius exceeds the 3x3x3 coarse neighbourhood (cell size chosen too small).
+__device__ __forceinline__ int g2_nearest(const GridDesc& d, const Grid2& g, float4 p, int df,
+                                          int* __restrict__ overflow) {
+  int fc = frame_cell(d, p.x) + df;
+  if (fc < 0 || fc >= kFrameCells) return -1;
+  float fa = g.fr[fc], fb = g.fr[kFrameCells + fc];
+  if (fa > fb) return -1;
+  float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+  float dfsq = dfl * dfl;
+  const float margin = 1e-5f * d.radius2 + 1e-6f;
+  float budget = d.radius2 - dfsq + margin;  // upper bound on |dxyz|^2 of any admissible candidate
+  if (budget < 0.f) return -1;
+  int rings = (int)ceilf(sqrtf(budget) / d.h);
+  if (rings > 4) { atomicExch(overflow, 1); rings = 4; }
+  int cx = (int)floorf((p.y - d.lo[0]) / d.h);
+  int cy = (int)floorf((p.z - d.lo[1]) / d.h);
+  int cz = (int)floorf((p.w - d.lo[2]) / d.h);
+  int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+  // occupancy masks of the 27 coarse blocks around the query
+  uint64_t m[27];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 27; ++q) {
+    int ox = q % 3 - 1, oy = (q / 3) % 3 - 1, oz = q / 9 - 1;
+    int X = bx + ox, Y = by + oy, Z = bz + oz;
+    uint64_t mk = 0;
+    if (X >= 0 && Y >= 0 && Z >= 0) {
+      int cs = g2_find(g.ckeys, g.Hc - 1, pack_cell(fc, X, Y, Z));
+      if (cs >= 0) mk = g.cmask[cs];
+    }
+    m[q] = mk;
+    any |= mk != 0;
+  }
+  if (!any) return -1;
+  int best = -1;
+  float bestd = d.radius2;
+  for (int s = 0; s <= rings; ++s) {
+    if (s >= 1) {
+      float lb = (float)(s - 1) * d.h;
+      if (lb * lb > bestd - dfsq + margin) break;
+    }
+    for (int dz = -s; dz <= s; ++dz) {
+      int z = cz + dz;
+      int qz = (z >> 2) - bz + 1;
+      for (int dy = -s; dy <= s; ++dy) {
+        int y = cy + dy;
+        int qy = (y >> 2) - by + 1;
+        bool shell = (dz == -s || dz == s || dy == -s || dy == s);
+        int step = shell ? 1 : (s > 0 ? 2 * s : 1);
+        for (int dx = -s; dx <= s; dx += step) {
+          int x = cx + dx;
+          int qx = (x >> 2) - bx + 1;
+          int q = qx + 3 * qy + 9 * qz;
+          // q is in [0,27) because |offset| <= 4 fine cells; select without dynamic indexing
+          uint64_t mk = 0;
+#pragma unroll
+          for (int t = 0; t < 27; ++t) mk = (t == q) ? m[t] : mk;
+          int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
+          if (!((mk >> bit) & 1ULL)) continue;
+          int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
+          if (fs < 0) continue;
+          int b = g.fstart[fs], e = b + g.fcount[fs];
+          for (int j = b; j < e; ++j) {
+            float4 c = g.spts[j];
+            float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+            float dist2 = 0.f;
+            dist2 = dist2 + d0 * d0;
+            dist2 = dist2 + d1 * d1;
+            dist2 = dist2 + d2 * d2;
+            dist2 = dist2 + d3 * d3;
+            if (dist2 <= d.radius2) {
+              int oi = g.sidx[j];
+              if (best < 0 || dist2 < bestd || (dist2 == bestd && oi < best)) { best = oi; bestd = dist2; }
+            }
+          }
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// Cooperative form: the 32 lanes of a half-wave serve ONE query (two queries per wave). The cells
+// of a ring are dealt to the lanes, so rings 0+1 (27 cells) cost one round of memory latency
+// instead of 27 serial ones, and a query without a partner walks its 9x9x9 cube in a few dozen
+// rounds. Every lane of the wave must call this (shuffles); the lanes of a half pass the same
+// p / df, `valid` = this half has a query. The result (original index or -1) is returned in
+// every lane of the half.
+__device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g, float4 p, int df,
+                                               bool valid, int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 31;
+  const int half_base = lane & 32;
+  int fc = frame_cell(d, p.x) + df;
+  float fa = 1.f, fb = 0.f;
+  if (valid && fc >= 0 && fc < kFrameCells) { fa = g.fr[fc]; fb = g.fr[kFrameCells + fc]; }
+  valid = valid && fa <= fb;
+  float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+  float dfsq = dfl * dfl;
+  const float margin = 1e-5f * d.radius2 + 1e-6f;
+  float budget = d.radius2 - dfsq + margin;
+  valid = valid && budget >= 0.f;
+  int rings = valid ? (int)ceilf(sqrtf(budget) / d.h) : 0;
+  if (rings > 4) { if (sub == 0) atomicExch(overflow, 1); rings = 4; }
+  int cx = (int)floorf((p.y - d.lo[0]) / d.h);
+  int cy = (int)floorf((p.z - d.lo[1]) / d.h);
+  int cz = (int)floorf((p.w - d.lo[2]) / d.h);
+  int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+  // lanes 0..26 of the half fetch one coarse occupancy mask each
+  uint64_t mymask = 0;
+  if (valid && sub < 27) {
+    int X = bx + sub % 3 - 1, Y = by + (sub / 3) % 3 - 1, Z = bz + sub / 9 - 1;
+    if (X >= 0 && Y >= 0 && Z >= 0) {
+      int cs = g2_find(g.ckeys, g.Hc - 1, pack_cell(fc, X, Y, Z));
+      if (cs >= 0) mymask = g.cmask[cs];
+    }
+  }
+  unsigned long long occ = __ballot(mymask != 0);
+  valid = valid && ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
+  int best = -1;
+  float bestd = d.radius2;
+  for (int s = 1; s <= 4; ++s) {
+    // stage s: cells at Chebyshev distance s (stage 1 also takes the centre cell)
+    bool on = valid && (s == 1 || s <= rings);
+    if (on && s >= 2) {
+      float lb = (float)(s - 1) * d.h;
+      on = !(lb * lb > bestd - dfsq + margin);
+    }
+    int side = 2 * s + 1, hs = s;
+    int total = on ? side * side * side : 0;
+    int tot_o = __shfl_xor(total, 32, 64);
+    int trips = ((total > tot_o ? total : tot_o) + 31) >> 5;  // same for both halves of the wave
+    for (int r = 0; r < trips; ++r) {
+      int idx = r * 32 + sub;
+      bool cell_on = idx < total;
+      int x = cx, y = cy, z = cz;
+      if (cell_on) {
+        int dx = idx % side - hs, dy = (idx / side) % side - hs, dz = idx / (side * side) - hs;
+        int cheb = max(max(abs(dx), abs(dy)), abs(dz));
+        cell_on = (cheb == s) || (s == 1);
+        x += dx; y += dy; z += dz;
+      }
+      int q = cell_on ? ((x >> 2) - bx + 1) + 3 * ((y >> 2) - by + 1) + 9 * ((z >> 2) - bz + 1) : 0;
+      unsigned lo32 = __shfl((unsigned)(mymask & 0xFFFFFFFFULL), half_base + q, 64);
+      unsigned hi32 = __shfl((unsigned)(mymask >> 32), half_base + q, 64);
+      uint64_t mk = ((uint64_t)hi32 << 32) | lo32;
+      int cand = -1;
+      float cd = 0.f;
+      if (cell_on) {
+        int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
+        if ((mk >> bit) & 1ULL) {
+          int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
+          if (fs >= 0) {
+            int b = g.fstart[fs], e = b + g.fcount[fs];
+            for (int j = b; j < e; ++j) {
+              float4 c = g.spts[j];
+              float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+              float dist2 = 0.f;
+              dist2 = dist2 + d0 * d0;
+              dist2 = dist2 + d1 * d1;
+              dist2 = dist2 + d2 * d2;
+              dist2 = dist2 + d3 * d3;
+              if (dist2 <= d.radius2) {
+                int oi = g.sidx[j];
+                if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
+              }
+            }
+          }
+        }
+      }
+      // best of the half's 32 lanes: (dist2, index) ascending, -1 = none
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        int oc = __shfl_xor(cand, o, 64);
+        float od = __shfl_xor(cd, o, 64);
+        bool take = oc >= 0 && (cand < 0 || od < cd || (od == cd && oc < cand));
+        if (take) { cand = oc; cd = od; }
+      }
+      if (cand >= 0 && (best < 0 || cd < bestd || (cd == bestd && cand < best))) { best = cand; bestd = cd; }
+    }
+  }
+  return best;
+}
+
+}  // namespace pcs

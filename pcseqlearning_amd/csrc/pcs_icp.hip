@@ -18,7 +18,7 @@
 // one flag per chunk of iterations instead of one loss per iteration.
 // Per-component reductions use wave64 shuffle reductions over lanes that share a component and one
 // f64 hardware atomic per (wave, component, accumulator).
-#include "pcs_grid.hpp"
+#include "pcs_grid2.hpp"
 
 namespace pcs {
 
@@ -36,10 +36,7 @@ struct IcpBufs {
   float *b_ref, *b_mov, *b_all;
   IcpState* state;
   // static reference grid (non-stationary reference points), moving grid, all-reference grid
-  uint64_t *keys_r, *keys_m, *keys_a;
-  int32_t *head_r, *head_m, *head_a, *next_r, *next_m, *next_a;
-  float *fr_r, *fr_m, *fr_a;
-  uint32_t Hr, Hm, Ha;
+  Grid2 gr, gm, ga;
   int32_t *nn_f, *nn_b;
   float* prev;     // [Mn,4] positions before the last applied update
   double* acc1;    // [C,8]: n, sum p (3), sum q (3), sum clamp(dist) (l1 pass)
@@ -60,13 +57,9 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.b_mov = a.take<float>(8);
   b.b_all = a.take<float>(8);
   b.state = a.take<IcpState>(1);
-  b.Hr = p2(2 * (uint64_t)Rn); b.Hm = p2(2 * (uint64_t)Mn); b.Ha = p2(2 * (uint64_t)Ra);
-  b.keys_r = a.take<uint64_t>(b.Hr); b.head_r = a.take<int32_t>(b.Hr); b.next_r = a.take<int32_t>(Rn);
-  b.keys_m = a.take<uint64_t>(b.Hm); b.head_m = a.take<int32_t>(b.Hm); b.next_m = a.take<int32_t>(Mn);
-  b.keys_a = a.take<uint64_t>(b.Ha); b.head_a = a.take<int32_t>(b.Ha); b.next_a = a.take<int32_t>(Ra);
-  b.fr_r = a.take<float>(2 * kFrameCells);
-  b.fr_m = a.take<float>(2 * kFrameCells);
-  b.fr_a = a.take<float>(2 * kFrameCells);
+  plan_grid2(a, Rn, b.gr);
+  plan_grid2(a, Mn, b.gm);
+  plan_grid2(a, Ra, b.ga);
   b.nn_f = a.take<int32_t>(Mn);
   b.nn_b = a.take<int32_t>(Rn);
   b.prev = a.take<float>(Mn * 4);
@@ -109,98 +102,16 @@ icp_init_T_kernel(double* __restrict__ T, int64_t C) {
   }
 }
 
-// moving-grid insert of one iteration (+ zero the accumulators); no-op once done
+// start of an iteration: reset the moving grid's frame-range table and the accumulators
 __global__ void __launch_bounds__(kBlock)
-icp_insert_moving_kernel(const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
-                         uint64_t* __restrict__ keys, int32_t* __restrict__ head,
-                         int32_t* __restrict__ next, uint32_t hmask, float* __restrict__ fr,
-                         IcpState* __restrict__ st, double* __restrict__ acc1,
-                         double* __restrict__ acc2, int64_t C) {
+icp_begin_iter_kernel(float* __restrict__ fr, const IcpState* __restrict__ st,
+                      double* __restrict__ acc1, double* __restrict__ acc2, int64_t C) {
   if (st->done) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t k = i; k < C * 8; k += (int64_t)gridDim.x * blockDim.x) acc1[k] = 0.0;
-  for (int64_t k = i; k < C * 12; k += (int64_t)gridDim.x * blockDim.x) acc2[k] = 0.0;
-  if (i >= Mn) return;
-  GridDesc g = *gp;
-  float4 p = mov[i];
-  int fc = frame_cell(g, p.x);
-  int x = (int)floorf((p.y - g.lo[0]) / g.h);
-  int y = (int)floorf((p.z - g.lo[1]) / g.h);
-  int z = (int)floorf((p.w - g.lo[2]) / g.h);
-  if (x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax || fc < 0 ||
-      fc >= kFrameCells) {
-    atomicExch(&st->err, 1);
-    next[i] = -1;
-    return;
-  }
-  atomic_min_f32(&fr[fc], p.x);
-  atomic_max_f32(&fr[kFrameCells + fc], p.x);
-  uint64_t key = pack_cell(fc, x, y, z);
-  uint32_t slot = mix64(key) & hmask;
-  while (true) {
-    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmpty,
-                              (unsigned long long)key);
-    if (prev == kEmpty || prev == key) break;
-    slot = (slot + 1) & hmask;
-  }
-  next[i] = atomicExch(&head[slot], i);
-}
-
-// nearest reference point of the hashed cloud within radius (canonical ties: smaller index)
-__device__ __forceinline__ int nn_search(const GridDesc& g, float4 p, int df,
-                                         const float4* __restrict__ pts,
-                                         const uint64_t* __restrict__ keys,
-                                         const int32_t* __restrict__ head,
-                                         const int32_t* __restrict__ next, uint32_t hmask,
-                                         const float* __restrict__ fr) {
-  int fc = frame_cell(g, p.x) + df;
-  if (fc < 0 || fc >= kFrameCells) return -1;
-  float fa = fr[fc], fb = fr[kFrameCells + fc];
-  if (fa > fb) return -1;
-  float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
-  float dfsq = dfl * dfl;
-  const float margin = 1e-5f * g.radius2 + 1e-6f;
-  int cx = (int)floorf((p.y - g.lo[0]) / g.h);
-  int cy = (int)floorf((p.z - g.lo[1]) / g.h);
-  int cz = (int)floorf((p.w - g.lo[2]) / g.h);
-  int best = -1;
-  float bestd = g.radius2;
-  for (int s = 0; s <= g.rings; ++s) {
-    if (s >= 1) {
-      float lb = (float)(s - 1) * g.h;
-      if (lb * lb > bestd - dfsq + margin) break;
-    }
-    for (int dz = -s; dz <= s; ++dz) {
-      int z = cz + dz;
-      if (z < 0 || z >= kCoordMax) continue;
-      for (int dy = -s; dy <= s; ++dy) {
-        int y = cy + dy;
-        if (y < 0 || y >= kCoordMax) continue;
-        bool shell = (dz == -s || dz == s || dy == -s || dy == s);
-        int step = shell ? 1 : (s > 0 ? 2 * s : 1);
-        for (int dx = -s; dx <= s; dx += step) {
-          int x = cx + dx;
-          if (x < 0 || x >= kCoordMax) continue;
-          int j = grid_head(keys, head, hmask, pack_cell(fc, x, y, z));
-          while (j >= 0) {
-            float4 c = pts[j];
-            float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
-            float dist2 = 0.f;
-            dist2 = dist2 + d0 * d0;
-            dist2 = dist2 + d1 * d1;
-            dist2 = dist2 + d2 * d2;
-            dist2 = dist2 + d3 * d3;
-            if (dist2 <= g.radius2 && (best < 0 || dist2 < bestd || (dist2 == bestd && j < best))) {
-              best = j;
-              bestd = dist2;
-            }
-            j = next[j];
-          }
-        }
-      }
-    }
-  }
-  return best;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = i; k < kFrameCells; k += stride) { fr[k] = __builtin_inff(); fr[kFrameCells + k] = -__builtin_inff(); }
+  for (int64_t k = i; k < C * 8; k += stride) acc1[k] = 0.0;
+  for (int64_t k = i; k < C * 12; k += stride) acc2[k] = 0.0;
 }
 
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
@@ -224,43 +135,51 @@ __device__ __forceinline__ void grouped_atomic_add(bool active, int key, const d
   }
 }
 
-// threads [0,Mn): forward (moving -> reference, df = +frame_offset);
-// threads [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
+// 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
+// queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
 __global__ void __launch_bounds__(kBlock)
-icp_nn_pass1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
-                    const int32_t* __restrict__ comp, const GridDesc* __restrict__ gp, int df,
-                    const uint64_t* __restrict__ keys_r, const int32_t* __restrict__ head_r,
-                    const int32_t* __restrict__ next_r, uint32_t hmask_r,
-                    const float* __restrict__ fr_r, const uint64_t* __restrict__ keys_m,
-                    const int32_t* __restrict__ head_m, const int32_t* __restrict__ next_m,
-                    uint32_t hmask_m, const float* __restrict__ fr_m,
-                    const IcpState* __restrict__ st, int32_t* __restrict__ nn_f,
-                    int32_t* __restrict__ nn_b, double* __restrict__ acc1) {
+icp_nn_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+              const GridDesc* __restrict__ gp, int df, Grid2 gr, Grid2 gm, IcpState* __restrict__ st,
+              int32_t* __restrict__ nn_f, int32_t* __restrict__ nn_b) {
   if (st->done) return;
   GridDesc g = *gp;
+  int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  int sub = threadIdx.x & 31;
+  bool fwd = qid < Mn;
+  bool valid = qid < Mn + Rn;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) p = fwd ? mov[qid] : ref[qid - Mn];
+  // a wave may straddle the forward/backward boundary: its two halves then search different grids
+  int res_f = g2_nearest_coop(g, gr, p, df, valid && fwd, &st->err);
+  bool any_bwd = __ballot(valid && !fwd) != 0;
+  int res = res_f;
+  if (any_bwd) {
+    int res_b = g2_nearest_coop(g, gm, p, -df, valid && !fwd, &st->err);
+    if (!fwd) res = res_b;
+  }
+  if (valid && sub == 0) {
+    if (fwd) nn_f[qid] = res;
+    else nn_b[qid - Mn] = res;
+  }
+}
+
+// pass 1: edge count and coordinate sums per component, one thread per potential edge
+__global__ void __launch_bounds__(kBlock)
+icp_pass1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+                 const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
+                 const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
+                 double* __restrict__ acc1) {
+  if (st->done) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool active = false;
-  int c = 0;
+  int c = 0, m = -1, r = -1;
+  if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
+  else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
   double v[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (i < Mn) {
-    float4 p = mov[i];
-    int r = nn_search(g, p, df, ref, keys_r, head_r, next_r, hmask_r, fr_r);
-    nn_f[i] = r;
-    if (r >= 0) {
-      float4 q = ref[r];
-      active = true; c = comp[i];
-      v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
-    }
-  } else if (i < Mn + Rn) {
-    int r = i - Mn;
-    float4 q = ref[r];
-    int m = nn_search(g, q, -df, mov, keys_m, head_m, next_m, hmask_m, fr_m);
-    nn_b[r] = m;
-    if (m >= 0) {
-      float4 p = mov[m];
-      active = true; c = comp[m];
-      v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
-    }
+  if (active) {
+    float4 p = mov[m], q = ref[r];
+    c = comp[m];
+    v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
   }
   grouped_atomic_add<7>(active, c, v, acc1, 8);
 }
@@ -443,10 +362,19 @@ icp_solve_kernel(int64_t C, double reg, double delta, const double* __restrict__
     for (int b = 0; b < 4; ++b) Tn[12 + b] = Tc[12 + b];
     for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
   }
+  // loss = sum over components of sum |P-Q|^2: strided partial sums + fixed LDS tree (a serial
+  // loop over C dependent global loads cost ~0.5 us per component)
+  __shared__ double red[1024];
+  double part = 0.0;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) part += acc2[c * 12 + 9];
+  red[threadIdx.x] = part;
   __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double loss = 0.0;
-    for (int64_t c = 0; c < C; ++c) loss += acc2[c * 12 + 9];
+    double loss = red[0];
     st->loss = loss;
     st->iters += 1;
     if (st->last_error - loss < delta) st->countdown -= 1;
@@ -480,16 +408,15 @@ __global__ void icp_latch_done_kernel(IcpState* st) {
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
 __global__ void __launch_bounds__(kBlock)
-icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref_all,
-                    const int32_t* __restrict__ comp, const GridDesc* __restrict__ gp, int df,
-                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ head,
-                    const int32_t* __restrict__ next, uint32_t hmask, const float* __restrict__ fr,
+icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __restrict__ comp,
+                    const GridDesc* __restrict__ gp, int df, Grid2 ga, IcpState* __restrict__ st,
                     int32_t* __restrict__ cnt) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mn) return;
   GridDesc g = *gp;
-  int r = nn_search(g, mov[i], df, ref_all, keys, head, next, hmask, fr);
-  if (r >= 0) atomicAdd(&cnt[comp[i]], 1);
+  int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  bool valid = qid < Mn;
+  float4 p = valid ? mov[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int r = g2_nearest_coop(g, ga, p, df, valid, &st->err);
+  if (valid && (threadIdx.x & 31) == 0 && r >= 0) atomicAdd(&cnt[comp[qid]], 1);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -505,7 +432,7 @@ icp_finish_kernel(int64_t C, const double* __restrict__ acc1, const int32_t* __r
   }
 }
 
-// ---- optional HIP-event timing of the dominant kernel (icp_nn_pass1_kernel), for bench.py ----
+// ---- optional HIP-event timing of the dominant kernel (icp_nn_kernel), for bench.py ----
 struct NnProfile {
   bool on = false;
   double ms = 0.0;        // summed launch durations of the iterations that did work
@@ -524,7 +451,7 @@ extern "C" {
 
 int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
 
-// bench.py support: time icp_nn_pass1_kernel with HIP events on the launch stream.
+// bench.py support: time icp_nn_kernel with HIP events on the launch stream.
 int pcs_profile_icp_nn(int enable) {
   if (enable && !g_prof.have) {
     for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
@@ -578,7 +505,14 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if (!plan_icp(a, Mn, Rn, Ra, C, b)) return PCS_ERR_WORKSPACE;
   // graph.radius = (radius^2 + frame_offset^2) ** 0.5, handed to the kernel as fp32
   float rad = (float)sqrt(radius * radius + (double)frame_offset * (double)frame_offset);
-  float cell = cell_size > 0.f ? cell_size : (float)radius * 0.25f;
+  // fine cell = (largest admissible spatial distance) / 4, so that the 3x3x3 coarse blocks cover
+  // the search ball: |dxyz|^2 <= rad^2 - df^2 + margin with df = frame_offset for integer frame
+  // values (the kernel flags PCS_ERR_RANGE if the data violate that). cell_size may enlarge it.
+  double rad2 = (double)rad * (double)rad;
+  double budget = rad2 - (double)frame_offset * (double)frame_offset + (2e-5 * rad2 + 2e-6);
+  if (budget < radius * radius) budget = radius * radius;
+  float cell = (float)(sqrt(budget) * 0.25 * 1.0005);
+  if (cell_size > cell) cell = cell_size;
   float pad = 4.f * (float)radius + 16.f;
   if (chunk < 1) chunk = 8;
 
@@ -597,23 +531,28 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   PCS_CHECK_HIP(hipMemsetAsync(b.acc2, 0, (size_t)C * 12 * sizeof(double), s));
   PCS_CHECK_HIP(hipMemsetAsync(b.cnt, 0, (size_t)C * sizeof(int32_t), s));
   // static grids: non-stationary reference, all reference
-  auto build_static = [&](const float* pts, int64_t n, uint64_t* keys, int32_t* head, int32_t* next,
-                          uint32_t H, float* fr) -> int {
-    PCS_CHECK_HIP(hipMemsetAsync(keys, 0xFF, (size_t)H * sizeof(uint64_t), s));
-    PCS_CHECK_HIP(hipMemsetAsync(head, 0xFF, (size_t)H * sizeof(int32_t), s));
-    frame_range_init_kernel<<<4, kBlock, 0, s>>>(fr);
-    if (n > 0)
-      grid_insert_kernel<<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-          (const float4*)pts, (int)n, b.grid, keys, head, next, H - 1, fr, &b.state->err);
+  auto build = [&](const float* pts, int64_t n, Grid2& g, const int* skip) -> int {
+    PCS_CHECK_HIP(hipMemsetAsync(g.ff_begin, 0xFF, g.ff_bytes, s));
+    PCS_CHECK_HIP(hipMemsetAsync(g.z_begin, 0, g.z_bytes, s));
+    if (n > 0) {
+      int nb = (int)((n + kBlock - 1) / kBlock);
+      g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, b.grid, g, skip, &b.state->err);
+      g2_scan_kernel<<<1, 1024, 0, s>>>(g, skip);
+      g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, g, skip);
+    }
     return PCS_OK;
   };
-  if ((rc = build_static(ref_fxyz, Rn, b.keys_r, b.head_r, b.next_r, b.Hr, b.fr_r))) return rc;
-  if ((rc = build_static(ref_all, Ra, b.keys_a, b.head_a, b.next_a, b.Ha, b.fr_a))) return rc;
+  frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.gr.fr);
+  frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.ga.fr);
+  if ((rc = build(ref_fxyz, Rn, b.gr, nullptr))) return rc;
+  if ((rc = build(ref_all, Ra, b.ga, nullptr))) return rc;
 
   int nb_m = (int)((Mn + kBlock - 1) / kBlock);
   if (nb_m < 1) nb_m = 1;
   int nb_e = (int)((Mn + Rn + kBlock - 1) / kBlock);
   if (nb_e < 1) nb_e = 1;
+  int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
+  if (nb_q < 1) nb_q = 1;
   IcpState host;
   host.done = 0;
   host.iters = 0;
@@ -622,19 +561,17 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   while (it < max_iter) {
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
     for (int k = 0; k < n_it; ++k) {
-      PCS_CHECK_HIP(hipMemsetAsync(b.keys_m, 0xFF, (size_t)b.Hm * sizeof(uint64_t), s));
-      PCS_CHECK_HIP(hipMemsetAsync(b.head_m, 0xFF, (size_t)b.Hm * sizeof(int32_t), s));
-      frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.fr_m);
-      icp_insert_moving_kernel<<<nb_m, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn, b.grid,
-                                                       b.keys_m, b.head_m, b.next_m, b.Hm - 1,
-                                                       b.fr_m, b.state, b.acc1, b.acc2, C);
+      icp_begin_iter_kernel<<<16, kBlock, 0, s>>>(b.gm.fr, b.state, b.acc1, b.acc2, C);
+      if ((rc = build(mov_fxyz, Mn, b.gm, &b.state->done))) return rc;
       bool prof = g_prof.on && (it + k) < 96;
       if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k)], s));
-      icp_nn_pass1_kernel<<<nb_e, kBlock, 0, s>>>(
-          (const float4*)mov_fxyz, (int)Mn, (const float4*)ref_fxyz, (int)Rn, mov_comp, b.grid,
-          frame_offset, b.keys_r, b.head_r, b.next_r, b.Hr - 1, b.fr_r, b.keys_m, b.head_m,
-          b.next_m, b.Hm - 1, b.fr_m, b.state, b.nn_f, b.nn_b, b.acc1);
+      icp_nn_kernel<<<nb_q, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn, (const float4*)ref_fxyz,
+                                            (int)Rn, b.grid, frame_offset, b.gr, b.gm, b.state,
+                                            b.nn_f, b.nn_b);
       if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k) + 1], s));
+      icp_pass1_kernel<<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
+                                               (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
+                                               b.nn_b, b.state, b.acc1);
       icp_pass2_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
                                                   (const float4*)ref_fxyz, (int)Rn, mov_comp,
                                                   b.nn_f, b.nn_b, b.state, b.acc1, b.acc2, nullptr, 0.0);
@@ -672,10 +609,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                                 b.nn_b, b.state, b.acc1, b.acc2, b.acc1 + 7, 0.3);
   }
   if (Mn > 0 && Ra > 0)
-    icp_coverage_kernel<<<nb_m, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
-                                                (const float4*)ref_all, mov_comp, b.grid,
-                                                frame_offset, b.keys_a, b.head_a, b.next_a,
-                                                b.Ha - 1, b.fr_a, b.cnt);
+    icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        (const float4*)mov_fxyz, (int)Mn, mov_comp, b.grid, frame_offset, b.ga, b.state, b.cnt);
   icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, b.acc1, b.cnt, comp_deg, l1_err, edge_ratio);
   PCS_LAUNCH_CHECK();
   PCS_CHECK_HIP(hipStreamSynchronize(s));

@@ -180,6 +180,45 @@ segment_reduce_wave_kernel(const float* __restrict__ data, int d, const int32_t*
   }
 }
 
+// Very large segments (8 m super-pillars of the ground fit: thousands of rows each, few hundred
+// segments): one 256-thread block per segment, thread-strided partial sums, wave butterflies, then
+// the 4 wave results added in wave order. Fixed order -> reproducible. d <= 16.
+__global__ void __launch_bounds__(kBlock)
+segment_reduce_block_kernel(const float* __restrict__ data, int d, const int32_t* __restrict__ order,
+                            const int32_t* __restrict__ seg_start, int64_t v,
+                            float* __restrict__ out, int mean) {
+  __shared__ float part[kBlock / 64][16];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t seg = blockIdx.x; seg < v; seg += gridDim.x) {
+    int b = seg_start[seg], e = seg_start[seg + 1];
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int p = b + (int)threadIdx.x; p < e; p += kBlock) {
+      const float* row = data + (int64_t)order[p] * d;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < d) acc[c] = acc[c] + row[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < d) {
+        float x = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = x + __shfl_xor(x, o, 64);
+        if (lane == 0) part[w][c] = x;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d) {
+      float x = part[0][threadIdx.x];
+      for (int q = 1; q < kBlock / 64; ++q) x = x + part[q][threadIdx.x];
+      out[seg * d + threadIdx.x] = mean ? x / (float)(e - b) : x;
+    }
+    __syncthreads();
+  }
+}
+
 // last (= max original index) / first (= min original index) row of every segment
 __global__ void __launch_bounds__(kBlock)
 segment_pick_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ seg_start,
@@ -406,6 +445,12 @@ int pcs_segment_reduce_f32(const float* data, int d, const int32_t* order, const
                            int64_t v, int mean, float* out, hipStream_t s) {
   if (!data || !order || !seg_start || !out || d <= 0 || v < 0) return PCS_ERR_ARG;
   if (v == 0) return PCS_OK;
+  if ((mean & 4) && d <= 16) {
+    segment_reduce_block_kernel<<<(int)(v > 4096 ? 4096 : v), kBlock, 0, s>>>(data, d, order,
+                                                                             seg_start, v, out, mean & 1);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   if ((mean & 2) && d <= 16) {
     int64_t blocks = (v * 64 + kBlock - 1) / kBlock;
     segment_reduce_wave_kernel<<<(int)(blocks > 2048 ? 2048 : blocks), kBlock, 0, s>>>(

@@ -73,7 +73,7 @@ def unique_i64(ids, key_bits=64, want_uniq=True, want_inv=True):
     return seg
 
 
-def segment_reduce(data, seg, mean=True, wave=False):
+def segment_reduce(data, seg, mean=True, wave=False, block=False):
     """scatter(data, inv, reduce='mean'/'sum'). data [n] or [n,d]. wave=False: serial ascending
     original index per segment (small segments); wave=True: one wave per segment (large ones)."""
     lib = L.load()
@@ -82,7 +82,8 @@ def segment_reduce(data, seg, mean=True, wave=False):
     out = torch.empty(seg.num, d2.shape[1], dtype=torch.float32, device=data.device)
     L.check(lib.pcs_segment_reduce_f32(L.ptr(d2), L.i32(d2.shape[1]), L.ptr(seg.order),
                                        L.ptr(seg.seg_start), L.i64(seg.num),
-                                       L.i32(int(mean) | (2 if (wave and d2.shape[1] <= 16) else 0)),
+                                       L.i32(int(mean) | (2 if (wave and d2.shape[1] <= 16) else 0)
+                                             | (4 if (block and d2.shape[1] <= 16) else 0)),
                                        L.ptr(out), L.stream()), "pcs_segment_reduce_f32")
     return out[:, 0] if squeeze else out
 

@@ -12,6 +12,7 @@ from ..... import ops
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
+from .eval_utils import component_box_iou, scatter_max_
 
 
 class ClusterProposal(nn.Module):
@@ -120,21 +121,15 @@ class ClusterProposal(nn.Module):
                 in_box = (bp == 1).any(0)
                 fp.gt_box_id[in_box] = bp[:, in_box].argmax(0)
                 fp.gt_trace_id[in_box] = fb.trace_id[fp.gt_box_id[in_box]]
-                comp2box, fp.pred_box_id = self.assign_instances_to_boxes(fp.component, bp)
+                gt_cnt = torch.bincount(fp.gt_box_id[in_box], minlength=fb.attr.shape[0])
+                _, inv, has_box, box, iou = component_box_iou(fp.component, bp, fp.gt_box_id, gt_cnt)
+                fp.pred_box_id = torch.where(has_box[inv], box[inv], torch.full_like(inv, -1))
                 valid = (fp.pred_box_id >= 0).reshape(-1)
                 fp.pred_trace_id[valid] = fb.trace_id[fp.pred_box_id[valid]]
-                for c in fp.component.unique().tolist():
-                    box_id = comp2box[c]
-                    if box_id < 0:
-                        continue
-                    m1 = (fp.gt_box_id == box_id).reshape(-1)
-                    m2 = (fp.component == c).reshape(-1)
-                    iou = (m1 & m2).float().sum().item() / ((m1 | m2).float().sum().item() + 1e-6)
-                    if iou > fb.best_iou[box_id]:
-                        fb.best_iou[box_id] = iou
-                    t = fb.trace_id[box_id]
-                    if iou > traces.best_iou[t]:
-                        traces.best_iou[t] = iou
+                # best IoU per box / per trace over the components assigned to it
+                scatter_max_(fb.best_iou, box[has_box], iou[has_box].to(fb.best_iou.dtype))
+                scatter_max_(traces.best_iou, fb.trace_id[box[has_box]].long(),
+                             iou[has_box].to(traces.best_iou.dtype))
                 for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):
                     seq_points[key][fmask] = fp[key]
                 seq_boxes["best_iou"][bmask] = fb["best_iou"]

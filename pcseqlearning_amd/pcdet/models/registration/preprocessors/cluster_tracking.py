@@ -17,6 +17,7 @@ from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
+from .eval_utils import component_box_iou, scatter_max_
 from .registration_utils import (IndexSegments, efficient_robust_sum, register_to_next_frame,
                                  robust_mean, robust_median, segment_max, segment_min)
 
@@ -195,19 +196,13 @@ class ClusterTracking(nn.Module):
                 full[key].append(out[key])
             if has_boxes:
                 bp = ops.points_in_boxes(out.fxyz[:, 1:], frame_boxes.attr).long()
-                for c in out.component.unique().tolist():
-                    cmask = (out.component == c).reshape(-1)
-                    if not bool(bp[:, cmask].any()):
-                        continue
-                    box_id = bp[:, cmask].float().sum(-1).argmax()
-                    m1 = ref_pts.gt_box_id == box_id
-                    mask = torch.zeros(n_ref, device=device, dtype=torch.bool)
-                    mask[out.frame_indices[cmask]] = True
-                    iou = (mask & m1).long().sum() / ((mask | m1).long().sum() + 1e-6)
-                    if iou > 0.7:
-                        component_hit[c] += 1
-                    if iou > frame_boxes.best_iou[box_id]:
-                        frame_boxes.best_iou[box_id] = iou
+                gt_cnt = torch.bincount(ref_pts.gt_box_id[ref_pts.gt_box_id >= 0],
+                                        minlength=frame_boxes.attr.shape[0])
+                uniq, _, has_box, box, iou = component_box_iou(
+                    out.component, bp, ref_pts.gt_box_id[out.frame_indices], gt_cnt)
+                iou32 = iou.to(frame_boxes.best_iou.dtype)
+                component_hit[uniq[has_box & (iou32 > 0.7)]] += 1
+                scatter_max_(frame_boxes.best_iou, box[has_box], iou32[has_box])
             seq_boxes.best_iou[frame_box_mask] = frame_boxes.best_iou
         full = EasyDict({k: torch.cat(v, dim=0) for k, v in full.items()})
         full.component_hit = component_hit

@@ -1,0 +1,33 @@
+"""GT-box bookkeeping shared by ClusterProposal.evaluate_proposal (cluster_proposal.py:238-255) and
+ClusterTracking.extract_traces_and_update_boxes (cluster_tracking.py:388-411): the reference loops
+over components in Python (a mask, two reductions and two `.item()` syncs per component); the same
+quantities are histograms, computed here in a handful of device ops."""
+import torch
+
+
+def component_box_iou(component, bp_mask, point_gt_box_id, gt_count_per_box):
+    """For every distinct component of `component` [n]:
+      box  = argmax_b #points of the component inside box b   (bp_mask [B,n], 0/1)
+      iou  = |comp & gt(box)| / (|comp| + |gt(box)| - |comp & gt(box)| + 1e-6)
+    with gt(box) = points whose (single) gt box id is `box`; |gt(box)| given by gt_count_per_box [B].
+    Returns (uniq [U], inv [n], has_box [U] bool, box [U] long, iou [U] float64)."""
+    uniq, inv = component.unique(return_inverse=True)
+    U, B = uniq.numel(), bp_mask.shape[0]
+    counts = torch.zeros(U, B, dtype=torch.int64, device=component.device)
+    counts.index_add_(0, inv, bp_mask.t().long())
+    has_box = counts.sum(1) > 0
+    box = counts.argmax(1)
+    size = torch.bincount(inv, minlength=U)
+    in_gt = point_gt_box_id >= 0
+    hist = torch.bincount(inv[in_gt] * B + point_gt_box_id[in_gt].long(), minlength=U * B).reshape(U, B)
+    inter = hist.gather(1, box[:, None])[:, 0]
+    union = size + gt_count_per_box.long()[box] - inter
+    iou = inter.double() / (union.double() + 1e-6)
+    return uniq, inv, has_box, box, iou
+
+
+def scatter_max_(dst, index, values):
+    """dst[index] = max(dst[index], values) (values already in dst's dtype)."""
+    if index.numel():
+        dst.scatter_reduce_(0, index, values, reduce="amax", include_self=True)
+    return dst

@@ -27,7 +27,7 @@ def grid_sample(point_bxyz, grid_size):
 
 
 def _seg_sum(data, sg, n):
-    return efficient_robust_sum(data, sg, n)
+    return efficient_robust_sum(data, sg, n, block=True)
 
 
 def iterative_reweighted_ransac(points, pillars, w0, num_pillars, sigma2, stopping_delta=1e-2, sg=None):

@@ -51,10 +51,11 @@ def efficient_robust_mean(data, index, max_index, sort_index=None):
     return robust_mean(data, index, max_index)
 
 
-def efficient_robust_sum(data, index, max_index, sort_index=None):
+def efficient_robust_sum(data, index, max_index, sort_index=None, block=False):
+    """block=True: one workgroup per segment (few, very large segments)."""
     sg = _segments(index, max_index)
     flat = data.reshape(data.shape[0], -1)
-    vals = ops.segment_reduce(flat, sg.seg, mean=False, wave=True).to(data.dtype)
+    vals = ops.segment_reduce(flat, sg.seg, mean=False, wave=True, block=block).to(data.dtype)
     return sg.scatter_dense(vals, max_index).reshape((max_index,) + tuple(data.shape[1:]))
 
 
@@ -100,7 +101,7 @@ def register_to_next_frame(graph, moving, ref, num_components, angle_regularizer
     mov_fxyz = moving.fxyz[ns_mask].contiguous()
     mov_comp = moving.component[ns_mask]
     ref_ns = ref.fxyz[~ref.stationary]
-    cell = getattr(graph, "icp_cell_size", None) or 0.0
+    cell = 0.0  # fused ICP picks radius / 4 (two-level grid, pcs_grid2.hpp)
     T, l1_component_error, comp_edge_ratio, _ = ops.register_to_next_frame(
         mov_fxyz, mov_comp, ref_ns, ref.fxyz, component_deg, num_components, float(temp_radius),
         frame_offset, float(angle_regularizer), int(max_iter), float(stopping_delta), float(cell))
