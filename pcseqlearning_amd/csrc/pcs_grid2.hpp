@@ -7,8 +7,8 @@
 // the expanding-ring walk tests 27 masks held in registers and touches memory only for occupied
 // fine cells; a query with nothing around it leaves after the 27 mask loads.
 //
-// Build = memsets + count kernel (fine CAS + counter, coarse CAS + atomicOr) + single-block scan of
-// the fine-slot counters + fill kernel. Order inside a cell is arbitrary (atomic cursor); the search
+// Build = clear + count kernel (fine CAS + counter, coarse CAS + atomicOr) + alloc kernel (one
+// cursor atomic per occupied fine slot) + fill kernel. Order inside a cell is arbitrary (atomic cursor); the search
 // result does not depend on it because ties resolve by (dist2, original index).
 #pragma once
 #include "pcs_grid.hpp"
@@ -77,11 +77,11 @@ __device__ __forceinline__ int g2_find(const uint64_t* __restrict__ keys, uint32
   }
 }
 
-// `skip` (device flag, may be null): when set the kernel does nothing (ICP already converged)
+// Gating: the kernels of ICP iteration k do nothing once k > *stop (the stop rule has fired).
 static __global__ void __launch_bounds__(kBlock)
 g2_count_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restrict__ gp, Grid2 g,
-                const int* __restrict__ skip, int* __restrict__ err) {
-  if (skip && *skip) return;
+                int k, const int* __restrict__ stop, int* __restrict__ err) {
+  if (k > *stop) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   GridDesc d = *gp;
   bool in = i < N;
@@ -123,37 +123,20 @@ g2_count_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restric
   atomicOr((unsigned long long*)&g.cmask[cs], 1ULL << bit);
 }
 
-// exclusive scan of fcount[Hf] -> fstart, one block
-static __global__ void __launch_bounds__(1024)
-g2_scan_kernel(Grid2 g, const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  __shared__ int part[1024];
-  int tid = threadIdx.x;
-  int per = (int)(g.Hf / 1024);  // Hf is a power of two >= 64; for Hf < 1024 per = 0
-  if (per == 0) {
-    if (tid == 0) {
-      int run = 0;
-      for (uint32_t s = 0; s < g.Hf; ++s) { g.fstart[s] = run; run += g.fcount[s]; }
-    }
-    return;
-  }
-  int base = tid * per, sum = 0;
-  for (int k = 0; k < per; ++k) sum += g.fcount[base + k];
-  part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = tid >= o ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = part[tid] - sum;
-  for (int k = 0; k < per; ++k) { g.fstart[base + k] = run; run += g.fcount[base + k]; }
+// every occupied fine slot reserves its run of the sorted array with one atomic on a cursor
+// (a scan would give a canonical layout, which nothing needs: results are layout-independent)
+static __global__ void __launch_bounds__(kBlock)
+g2_alloc_kernel(Grid2 g, int k, const int* __restrict__ stop, int* __restrict__ cursor) {
+  if (k > *stop) return;
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= g.Hf) return;
+  int c = g.fcount[s];
+  if (c > 0) g.fstart[s] = atomicAdd(cursor, c);
 }
 
 static __global__ void __launch_bounds__(kBlock)
-g2_fill_kernel(const float4* __restrict__ pts, int N, Grid2 g, const int* __restrict__ skip) {
-  if (skip && *skip) return;
+g2_fill_kernel(const float4* __restrict__ pts, int N, Grid2 g, int k, const int* __restrict__ stop) {
+  if (k > *stop) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int fs = g.pslot[i];

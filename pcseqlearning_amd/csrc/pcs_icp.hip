@@ -5,20 +5,25 @@
 // builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
 // scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
 //
-// Here one call owns the whole loop. State stays in the caller's workspace; an iteration is
-//   memset x2 (moving grid) -> insert moving points (+ zero accumulators)
-//   -> 1-NN both directions (expanding-ring search on the fine-cell grids, pcs_grid.hpp) fused with
-//      pass 1 (edge count, sum of matched moving / reference coordinates per component)
-//   -> pass 2 (centred P,Q: 3x3 cross-covariance, sum |P-Q|^2, sum |P-Q| per component)
-//   -> solve (one thread per component: cov + reg*T_rot -> 3x3 one-sided Jacobi SVD in f64 ->
-//      R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T; then the loss-delta /
-//      3-strike countdown stop rule ON DEVICE)
-//   -> apply (all moving points, f64 -> fp32 as the reference stores them)
-// with every kernel skipping itself once the device-side `done` flag is set, so the host reads
-// one flag per chunk of iterations instead of one loss per iteration.
-// Per-component reductions use wave64 shuffle reductions over lanes that share a component and one
-// f64 hardware atomic per (wave, component, accumulator).
+// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is
+//   begin      clear the moving grid, the frame-range table and the accumulators
+//   count/alloc/fill   counting-sort the moved points into the two-level grid (pcs_grid2.hpp)
+//   nn         1-NN both directions, 32 lanes per query
+//   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
+//              component (raw moments in f64; the centred covariance and the loss follow
+//              algebraically, so the reference's second pass over the edges is not needed)
+//   solve      one thread per component: cov + reg*T_rot -> 3x3 one-sided Jacobi SVD (f64) ->
+//              R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T; block 0 also
+//              reduces the loss and applies the loss-delta / 3-strike stop rule ON THE DEVICE
+//   apply      all moving points, f64 -> fp32 as the reference stores them
+// Every kernel of iteration k returns immediately when k > state.stop_iter, so the host enqueues
+// iterations in chunks and reads one word per chunk instead of one loss per iteration.
+// Per-component sums: lanes of a wave that share a component are combined by 64-lane butterflies,
+// then one f64 hardware atomic per (wave, component, accumulator).
 #include "pcs_grid2.hpp"
+
+#include <climits>
+#include <mutex>
 
 namespace pcs {
 
@@ -26,26 +31,27 @@ struct IcpState {
   double last_error;
   double loss;
   int countdown;
-  int done;
-  int iters;
+  int stop_iter;  // iterations > stop_iter do not run (INT_MAX until the stop rule fires)
+  int iters;      // iterations solved so far
   int err;
+  int cursor;     // allocation cursor of the moving grid's cell runs
+  int pad;
 };
+
+constexpr int kAcc = 20;  // n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2, sum dist, sum clamp, pad
 
 struct IcpBufs {
   GridDesc* grid;
   float *b_ref, *b_mov, *b_all;
   IcpState* state;
-  // static reference grid (non-stationary reference points), moving grid, all-reference grid
-  Grid2 gr, gm, ga;
+  Grid2 gr, gm, ga;  // non-stationary reference (static), moving (per iteration), all reference
   int32_t *nn_f, *nn_b;
-  float* prev;     // [Mn,4] positions before the last applied update
-  double* acc1;    // [C,8]: n, sum p (3), sum q (3), sum clamp(dist) (l1 pass)
-  double* acc2;    // [C,12]: sum P(x)Q (9), sum |P-Q|^2, sum |P-Q|, pad
-  double* Rt;      // [C,12]: R row-major, t
-  int32_t* cnt;    // [C] matched moving points in the final coverage query
+  float* prev;   // [Mn,4] positions before the last applied update
+  double* acc;   // [C, kAcc]
+  double* Rt;    // [C,12]: R row-major, t
+  int32_t* cnt;  // [C] matched moving points in the final coverage query
+  int32_t* cur_static;  // [2] allocation cursors of the two static grids
 };
-
-static inline uint32_t p2(uint64_t x) { uint32_t h = 64; while (h < x) h <<= 1; return h; }
 
 static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
   if (Mn < 1) Mn = 1;
@@ -57,14 +63,14 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.b_mov = a.take<float>(8);
   b.b_all = a.take<float>(8);
   b.state = a.take<IcpState>(1);
+  b.cur_static = a.take<int32_t>(2);
   plan_grid2(a, Rn, b.gr);
   plan_grid2(a, Mn, b.gm);
   plan_grid2(a, Ra, b.ga);
   b.nn_f = a.take<int32_t>(Mn);
   b.nn_b = a.take<int32_t>(Rn);
   b.prev = a.take<float>(Mn * 4);
-  b.acc1 = a.take<double>(C * 8);
-  b.acc2 = a.take<double>(C * 12);
+  b.acc = a.take<double>(C * kAcc);
   b.Rt = a.take<double>(C * 12);
   b.cnt = a.take<int32_t>(C);
   return a.ok();
@@ -88,9 +94,10 @@ __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* _
   st->last_error = 1e10;
   st->loss = 0.0;
   st->countdown = 3;
-  st->done = 0;
+  st->stop_iter = INT_MAX;
   st->iters = 0;
   st->err = 0;
+  st->cursor = 0;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -102,16 +109,21 @@ icp_init_T_kernel(double* __restrict__ T, int64_t C) {
   }
 }
 
-// start of an iteration: reset the moving grid's frame-range table and the accumulators
+// start of iteration k: clear the moving grid (keys <- empty, counters/masks <- 0), its
+// frame-range table, the accumulators and the allocation cursor
 __global__ void __launch_bounds__(kBlock)
-icp_begin_iter_kernel(float* __restrict__ fr, const IcpState* __restrict__ st,
-                      double* __restrict__ acc1, double* __restrict__ acc2, int64_t C) {
-  if (st->done) return;
+icp_begin_kernel(int k, Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc, int64_t C) {
+  if (k > st->stop_iter) return;
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = i; k < kFrameCells; k += stride) { fr[k] = __builtin_inff(); fr[kFrameCells + k] = -__builtin_inff(); }
-  for (int64_t k = i; k < C * 8; k += stride) acc1[k] = 0.0;
-  for (int64_t k = i; k < C * 12; k += stride) acc2[k] = 0.0;
+  uint4* ff = (uint4*)gm.ff_begin;
+  uint4* zz = (uint4*)gm.z_begin;
+  const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zero = make_uint4(0, 0, 0, 0);
+  for (int64_t q = i; q < (int64_t)(gm.ff_bytes / 16); q += stride) ff[q] = ones;
+  for (int64_t q = i; q < (int64_t)(gm.z_bytes / 16); q += stride) zz[q] = zero;
+  for (int64_t q = i; q < kFrameCells; q += stride) { gm.fr[q] = __builtin_inff(); gm.fr[kFrameCells + q] = -__builtin_inff(); }
+  for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
+  if (i == 0) st->cursor = 0;
 }
 
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
@@ -138,10 +150,10 @@ __device__ __forceinline__ void grouped_atomic_add(bool active, int key, const d
 // 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
 // queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
 __global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+icp_nn_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
               const GridDesc* __restrict__ gp, int df, Grid2 gr, Grid2 gm, IcpState* __restrict__ st,
               int32_t* __restrict__ nn_f, int32_t* __restrict__ nn_b) {
-  if (st->done) return;
+  if (k > st->stop_iter) return;
   GridDesc g = *gp;
   int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   int sub = threadIdx.x & 31;
@@ -150,12 +162,16 @@ icp_nn_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid) p = fwd ? mov[qid] : ref[qid - Mn];
   // a wave may straddle the forward/backward boundary: its two halves then search different grids
-  int res_f = g2_nearest_coop(g, gr, p, df, valid && fwd, &st->err);
+  bool any_fwd = __ballot(valid && fwd) != 0;
   bool any_bwd = __ballot(valid && !fwd) != 0;
-  int res = res_f;
+  int res = -1;
+  if (any_fwd) {
+    int r = g2_nearest_coop(g, gr, p, df, valid && fwd, &st->err);
+    if (fwd) res = r;
+  }
   if (any_bwd) {
-    int res_b = g2_nearest_coop(g, gm, p, -df, valid && !fwd, &st->err);
-    if (!fwd) res = res_b;
+    int r = g2_nearest_coop(g, gm, p, -df, valid && !fwd, &st->err);
+    if (!fwd) res = r;
   }
   if (valid && sub == 0) {
     if (fwd) nn_f[qid] = res;
@@ -163,81 +179,100 @@ icp_nn_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__
   }
 }
 
-// pass 1: edge count and coordinate sums per component, one thread per potential edge
+// raw moments of the matched pairs per component, one thread per potential edge
 __global__ void __launch_bounds__(kBlock)
-icp_pass1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
-                 const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
-                 const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
-                 double* __restrict__ acc1) {
-  if (st->done) return;
+icp_moments_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref,
+                   int Rn, const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
+                   const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
+                   double* __restrict__ acc) {
+  if (k > st->stop_iter) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool active = false;
   int c = 0, m = -1, r = -1;
   if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
   else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  double v[17];
+#pragma unroll
+  for (int q = 0; q < 17; ++q) v[q] = 0.0;
   if (active) {
-    float4 p = mov[m], q = ref[r];
+    float4 pf = mov[m], qf = ref[r];
     c = comp[m];
-    v[0] = 1.0; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.y; v[5] = q.z; v[6] = q.w;
+    double p[3] = {pf.y, pf.z, pf.w}, q[3] = {qf.y, qf.z, qf.w};
+    v[0] = 1.0;
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v[1 + a] = p[a];
+      v[4 + a] = q[a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = p[a] * q[b];
+      double e = p[a] - q[a];
+      d2 += e * e;
+    }
+    v[16] = d2;
   }
-  grouped_atomic_add<7>(active, c, v, acc1, 8);
+  grouped_atomic_add<17>(active, c, v, acc, kAcc);
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151)
-__device__ __forceinline__ void centres(const double* __restrict__ a1, double* cm, double* cr) {
-  double n = a1[0];
+__device__ __forceinline__ void centres(const double* __restrict__ a, double* cm, double* cr) {
+  double n = a[0];
   if (n > 0.5) {
     for (int d = 0; d < 3; ++d) {
-      cm[d] = (double)(float)(a1[1 + d] / n);
-      cr[d] = (double)(float)(a1[4 + d] / n);
+      cm[d] = (double)(float)(a[1 + d] / n);
+      cr[d] = (double)(float)(a[4 + d] / n);
     }
   } else {
     for (int d = 0; d < 3; ++d) cm[d] = cr[d] = 0.0;
   }
 }
 
-// MODE 0: pass 2 (cov, sum dist^2, sum dist) on the CURRENT positions.
-// MODE 1: l1 pass (sum of clamped dist) on the positions saved before the last update.
+// sum over the component's pairs of |P - Q|^2 with P = p - cm, Q = q - cr:
+//   sum |p-q|^2 - 2 d . sum(p-q) + n |d|^2,  d = cm - cr
+__device__ __forceinline__ double comp_loss(const double* __restrict__ a) {
+  double n = a[0];
+  if (!(n > 0.5)) return 0.0;
+  double cm[3], cr[3];
+  centres(a, cm, cr);
+  double s = a[16];
+  for (int k = 0; k < 3; ++k) {
+    double d = cm[k] - cr[k];
+    s += -2.0 * d * (a[1 + k] - a[4 + k]) + n * d * d;
+  }
+  return s;
+}
+
+// l1 passes on the positions saved before the last update. MODE 0: sum of dist; MODE 1: sum of
+// dist clamped to mean +- trunc (truncated_robust_mean, registration_utils.py:44-58).
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
-icp_pass2_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
-                 const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
-                 const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
-                 const double* __restrict__ acc1, double* __restrict__ acc2,
-                 double* __restrict__ acc_l1, double trunc) {
-  if (MODE == 0 && st->done) return;
+icp_l1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
+              const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
+              const int32_t* __restrict__ nn_b, double* __restrict__ acc, double trunc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool active = false;
   int c = 0, m = -1, r = -1;
   if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
   else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
-  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  double v1[1] = {0};
+  double v[1] = {0.0};
   if (active) {
     c = comp[m];
     float4 p = mov[m], q = ref[r];
+    const double* a = acc + (int64_t)c * kAcc;
     double cm[3], cr[3];
-    centres(acc1 + (int64_t)c * 8, cm, cr);
-    double P[3] = {(double)p.y - cm[0], (double)p.z - cm[1], (double)p.w - cm[2]};
-    double Q[3] = {(double)q.y - cr[0], (double)q.z - cr[1], (double)q.w - cr[2]};
-    double e0 = P[0] - Q[0], e1 = P[1] - Q[1], e2 = P[2] - Q[2];
-    double d2 = e0 * e0 + e1 * e1 + e2 * e2;
-    double dist = sqrt(d2);
+    centres(a, cm, cr);
+    double e0 = ((double)p.y - cm[0]) - ((double)q.y - cr[0]);
+    double e1 = ((double)p.z - cm[1]) - ((double)q.z - cr[1]);
+    double e2 = ((double)p.w - cm[2]) - ((double)q.w - cr[2]);
+    double dist = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
     if (MODE == 0) {
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) v[a * 3 + b] = P[a] * Q[b];
-      v[9] = d2;
-      v[10] = dist;
+      v[0] = dist;
     } else {
-      double n = acc1[(int64_t)c * 8];
-      double mean = acc2[(int64_t)c * 12 + 10] / n;
-      double lo = mean - trunc, hi = mean + trunc;
-      v1[0] = fmin(fmax(dist, lo), hi);
+      double mean = a[17] / a[0];
+      v[0] = fmin(fmax(dist, mean - trunc), mean + trunc);
     }
   }
-  if (MODE == 0) grouped_atomic_add<11>(active, c, v, acc2, 12);
-  else grouped_atomic_add<1>(active, c, v1, acc_l1, 8);
+  grouped_atomic_add<1>(active, c, v, acc + (MODE == 0 ? 17 : 18), kAcc);
 }
 
 // ---- 3x3 SVD by one-sided Jacobi (f64), singular values descending ----
@@ -273,7 +308,6 @@ __device__ inline void svd3(const double M[9], double U[9], double S[3], double 
   }
   for (int j = 0; j < 3; ++j)
     S[j] = sqrt(A[0 * 3 + j] * A[0 * 3 + j] + A[1 * 3 + j] * A[1 * 3 + j] + A[2 * 3 + j] * A[2 * 3 + j]);
-  // sort columns by descending singular value
   int ord[3] = {0, 1, 2};
   for (int a = 0; a < 2; ++a)
     for (int b = a + 1; b < 3; ++b)
@@ -294,7 +328,6 @@ __device__ inline void svd3(const double M[9], double U[9], double S[3], double 
   if (S[2] <= 1e-300) {
     if (S[1] <= 1e-300) {
       if (S[0] <= 1e-300) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
-      // pick any unit vector orthogonal to u0
       double u0[3] = {U[0], U[3], U[6]};
       int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
       double e[3] = {0, 0, 0}; e[k] = 1.0;
@@ -315,81 +348,74 @@ __device__ inline double det3(const double A[9]) {
          A[2] * (A[3] * A[7] - A[4] * A[6]);
 }
 
-// one block; thread per component (grid-stride over C), then thread 0 runs the stop rule
-__global__ void __launch_bounds__(1024)
-icp_solve_kernel(int64_t C, double reg, double delta, const double* __restrict__ acc1,
-                 const double* __restrict__ acc2, double* __restrict__ T, double* __restrict__ Rt,
-                 IcpState* __restrict__ st) {
-  if (st->done) return;
-  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
-    const double* a1 = acc1 + c * 8;
-    const double* a2 = acc2 + c * 12;
-    double n = a1[0];
+// one thread per component over many 64-thread blocks; block 0 additionally reduces the loss and
+// runs the stop rule. Gating on k vs stop_iter is safe against block 0 finishing early: stop_iter
+// can only drop to k, which still admits iteration k.
+__global__ void __launch_bounds__(64)
+icp_solve_kernel(int k, int64_t C, double reg, double delta, const double* __restrict__ acc,
+                 double* __restrict__ T, double* __restrict__ Rt, IcpState* __restrict__ st) {
+  if (k > st->stop_iter) return;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c < C) {
+    const double* a = acc + c * kAcc;
+    double n = a[0];
     double cm[3], cr[3];
-    centres(a1, cm, cr);
+    centres(a, cm, cr);
     double* Tc = T + c * 16;
     double M[9];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) {
-        double cov = a2[a * 3 + b];
-        if (n > 0.5) cov = cov / n;  // robust_mean: divide only where the count is positive
-        M[a * 3 + b] = cov + Tc[a * 4 + b] * reg;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        // sum P(x)Q = sum p q^T - cm sum q^T - sum p cr^T + n cm cr^T;  robust_mean divides by n
+        double cov = a[7 + i * 3 + j] - cm[i] * a[4 + j] - a[1 + i] * cr[j] + n * cm[i] * cr[j];
+        if (n > 0.5) cov = cov / n; else cov = 0.0;
+        M[i * 3 + j] = cov + Tc[i * 4 + j] * reg;
       }
     double U[9], S[3], V[9];
     svd3(M, U, S, V);
-    // R = V diag(1,1,det(V U^T)) U^T
     double VUt[9];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b)
-        VUt[a * 3 + b] = V[a * 3 + 0] * U[b * 3 + 0] + V[a * 3 + 1] * U[b * 3 + 1] + V[a * 3 + 2] * U[b * 3 + 2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
     double sg = det3(VUt);
     double R[9];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b)
-        R[a * 3 + b] = V[a * 3 + 0] * U[b * 3 + 0] + V[a * 3 + 1] * U[b * 3 + 1] + sg * V[a * 3 + 2] * U[b * 3 + 2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
     double t[3];
-    for (int a = 0; a < 3; ++a)
-      t[a] = cr[a] - (cm[0] * R[a * 3 + 0] + cm[1] * R[a * 3 + 1] + cm[2] * R[a * 3 + 2]);
+    for (int i = 0; i < 3; ++i)
+      t[i] = cr[i] - (cm[0] * R[i * 3 + 0] + cm[1] * R[i * 3 + 1] + cm[2] * R[i * 3 + 2]);
     double* rt = Rt + c * 12;
     for (int i = 0; i < 9; ++i) rt[i] = R[i];
     for (int i = 0; i < 3; ++i) rt[9 + i] = t[i];
-    // T <- T_i T with T_i = [[R, t], [0, 1]]
     double Tn[16];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 4; ++b)
-        Tn[a * 4 + b] = R[a * 3 + 0] * Tc[0 * 4 + b] + R[a * 3 + 1] * Tc[1 * 4 + b] +
-                        R[a * 3 + 2] * Tc[2 * 4 + b] + t[a] * Tc[3 * 4 + b];
-    for (int b = 0; b < 4; ++b) Tn[12 + b] = Tc[12 + b];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j)
+        Tn[i * 4 + j] = R[i * 3 + 0] * Tc[0 * 4 + j] + R[i * 3 + 1] * Tc[1 * 4 + j] +
+                        R[i * 3 + 2] * Tc[2 * 4 + j] + t[i] * Tc[3 * 4 + j];
+    for (int j = 0; j < 4; ++j) Tn[12 + j] = Tc[12 + j];
     for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
   }
-  // loss = sum over components of sum |P-Q|^2: strided partial sums + fixed LDS tree (a serial
-  // loop over C dependent global loads cost ~0.5 us per component)
-  __shared__ double red[1024];
-  double part = 0.0;
-  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) part += acc2[c * 12 + 9];
-  red[threadIdx.x] = part;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double loss = red[0];
-    st->loss = loss;
-    st->iters += 1;
-    if (st->last_error - loss < delta) st->countdown -= 1;
-    else st->countdown = 3;
-    if (st->countdown <= 0) st->done = 2;  // 2: this iteration's update still has to be applied
-    else st->last_error = loss;
+  if (blockIdx.x == 0) {
+    double part = 0.0;
+    for (int64_t q = threadIdx.x; q < C; q += 64) part += comp_loss(acc + q * kAcc);
+    double loss = wave_sum_f64(part);
+    if (threadIdx.x == 0) {
+      st->loss = loss;
+      st->iters = k;
+      if (st->last_error - loss < delta) st->countdown -= 1;
+      else st->countdown = 3;
+      if (st->countdown <= 0) st->stop_iter = k;  // this iteration's update is still applied
+      else st->last_error = loss;
+    }
   }
 }
 
-// apply the iteration's (R, t) to every moving point; keeps the previous positions for the l1 pass
+// apply iteration k's (R, t) to every moving point; keeps the previous positions for the l1 passes
 __global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
+icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
                  const int32_t* __restrict__ comp, const double* __restrict__ Rt,
                  const IcpState* __restrict__ st) {
-  if (st->done == 1) return;
+  if (k > st->stop_iter) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Mn) return;
   float4 p = mov[i];
@@ -400,10 +426,6 @@ icp_apply_kernel(float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
   float ny = (float)(x * rt[3] + y * rt[4] + z * rt[5] + rt[10]);
   float nz = (float)(x * rt[6] + y * rt[7] + z * rt[8] + rt[11]);
   mov[i] = make_float4(p.x, nx, ny, nz);
-}
-
-__global__ void icp_latch_done_kernel(IcpState* st) {
-  if (threadIdx.x == 0 && st->done == 2) st->done = 1;
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
@@ -420,13 +442,13 @@ icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __res
 }
 
 __global__ void __launch_bounds__(kBlock)
-icp_finish_kernel(int64_t C, const double* __restrict__ acc1, const int32_t* __restrict__ cnt,
-                  const int64_t* __restrict__ comp_deg, double* __restrict__ l1,
+icp_finish_kernel(int64_t C, const double* __restrict__ acc, const int32_t* __restrict__ cnt,
+                  const int64_t* __restrict__ comp_deg, int have_l1, double* __restrict__ l1,
                   float* __restrict__ ratio) {
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
-    double n = acc1[c * 8];
-    l1[c] = n > 0.5 ? acc1[c * 8 + 7] / n : 0.0;
+    double n = acc[c * kAcc];
+    l1[c] = (have_l1 && n > 0.5) ? acc[c * kAcc + 18] / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
     ratio[c] = (float)cnt[c] / ((float)comp_deg[c] + 1e-6f);
   }
@@ -434,14 +456,18 @@ icp_finish_kernel(int64_t C, const double* __restrict__ acc1, const int32_t* __r
 
 // ---- optional HIP-event timing of the dominant kernel (icp_nn_kernel), for bench.py ----
 struct NnProfile {
-  bool on = false;
-  double ms = 0.0;        // summed launch durations of the iterations that did work
+  double ms = 0.0;
   int64_t launches = 0;
-  double bytes = 0.0;     // algorithmic bytes of those launches
+  double bytes = 0.0;
+};
+static bool g_prof_on = false;
+static NnProfile g_prof_total;
+static std::mutex g_prof_mu;
+struct NnEvents {
   hipEvent_t ev[2 * 96];
   bool have = false;
 };
-static NnProfile g_prof;
+static thread_local NnEvents t_ev;
 
 }  // namespace pcs
 
@@ -451,25 +477,22 @@ extern "C" {
 
 int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
 
-// bench.py support: time icp_nn_kernel with HIP events on the launch stream.
+// bench.py support: time icp_nn_kernel with HIP events on the launch stream (any number of host
+// threads / streams; totals are accumulated under a mutex).
 int pcs_profile_icp_nn(int enable) {
-  if (enable && !g_prof.have) {
-    for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
-    g_prof.have = true;
-  }
-  g_prof.on = enable != 0;
-  g_prof.ms = 0.0;
-  g_prof.launches = 0;
-  g_prof.bytes = 0.0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = enable != 0;
+  g_prof_total = NnProfile();
   return PCS_OK;
 }
 
 // out3 (host): {milliseconds, launches, algorithmic bytes} accumulated since the last enable.
 int pcs_profile_icp_nn_read(double* out3) {
   if (!out3) return PCS_ERR_ARG;
-  out3[0] = g_prof.ms;
-  out3[1] = (double)g_prof.launches;
-  out3[2] = g_prof.bytes;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  out3[0] = g_prof_total.ms;
+  out3[1] = (double)g_prof_total.launches;
+  out3[2] = g_prof_total.bytes;
   return PCS_OK;
 }
 
@@ -481,7 +504,7 @@ size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_
 }
 
 // BLOCKING (the one entry point that synchronises the stream: the reference reads the loss on the
-// host every iteration, this reads one flag per `chunk` iterations).
+// host every iteration, this reads one word per `chunk` iterations).
 //   mov_fxyz [Mn,4]  non-stationary moving points, updated in place
 //   mov_comp [Mn]    int32 component of each moving point, in [0, C)
 //   ref_fxyz [Rn,4]  non-stationary reference points; ref_all [Ra,4] all reference points
@@ -499,7 +522,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       !comp_deg || !(radius > 0) || max_iter < 0 || (Mn > 0 && (!mov_fxyz || !mov_comp)) ||
       (Rn > 0 && !ref_fxyz) || (Ra > 0 && !ref_all))
     return PCS_ERR_ARG;
-  if (Mn + Rn >= (1LL << 30)) return PCS_ERR_RANGE;
+  if (Mn + Rn >= (1LL << 26)) return PCS_ERR_RANGE;
   Arena a(ws, ws_bytes);
   IcpBufs b;
   if (!plan_icp(a, Mn, Rn, Ra, C, b)) return PCS_ERR_WORKSPACE;
@@ -527,25 +550,26 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if ((rc = bounds(ref_all, Ra, b.b_all))) return rc;
   icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
   icp_init_T_kernel<<<grid_for(C * 16), kBlock, 0, s>>>(T, C);
-  PCS_CHECK_HIP(hipMemsetAsync(b.acc1, 0, (size_t)C * 8 * sizeof(double), s));
-  PCS_CHECK_HIP(hipMemsetAsync(b.acc2, 0, (size_t)C * 12 * sizeof(double), s));
+  PCS_CHECK_HIP(hipMemsetAsync(b.acc, 0, (size_t)C * kAcc * sizeof(double), s));
   PCS_CHECK_HIP(hipMemsetAsync(b.cnt, 0, (size_t)C * sizeof(int32_t), s));
-  // static grids: non-stationary reference, all reference
-  auto build = [&](const float* pts, int64_t n, Grid2& g, const int* skip) -> int {
-    PCS_CHECK_HIP(hipMemsetAsync(g.ff_begin, 0xFF, g.ff_bytes, s));
-    PCS_CHECK_HIP(hipMemsetAsync(g.z_begin, 0, g.z_bytes, s));
-    if (n > 0) {
-      int nb = (int)((n + kBlock - 1) / kBlock);
-      g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, b.grid, g, skip, &b.state->err);
-      g2_scan_kernel<<<1, 1024, 0, s>>>(g, skip);
-      g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, g, skip);
-    }
-    return PCS_OK;
+  PCS_CHECK_HIP(hipMemsetAsync(b.cur_static, 0, 2 * sizeof(int32_t), s));
+
+  auto sort_into = [&](const float* pts, int64_t n, Grid2& g, int k, int* cursor) {
+    if (n <= 0) return;
+    int nb = (int)((n + kBlock - 1) / kBlock);
+    const int* stop = &b.state->stop_iter;
+    g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, b.grid, g, k, stop, &b.state->err);
+    g2_alloc_kernel<<<(int)((g.Hf + kBlock - 1) / kBlock), kBlock, 0, s>>>(g, k, stop, cursor);
+    g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, g, k, stop);
   };
-  frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.gr.fr);
-  frame_range_init_kernel<<<4, kBlock, 0, s>>>(b.ga.fr);
-  if ((rc = build(ref_fxyz, Rn, b.gr, nullptr))) return rc;
-  if ((rc = build(ref_all, Ra, b.ga, nullptr))) return rc;
+  // static grids: non-stationary reference, all reference
+  for (Grid2* g : {&b.gr, &b.ga}) {
+    PCS_CHECK_HIP(hipMemsetAsync(g->ff_begin, 0xFF, g->ff_bytes, s));
+    PCS_CHECK_HIP(hipMemsetAsync(g->z_begin, 0, g->z_bytes, s));
+    frame_range_init_kernel<<<4, kBlock, 0, s>>>(g->fr);
+  }
+  sort_into(ref_fxyz, Rn, b.gr, 0, &b.cur_static[0]);
+  sort_into(ref_all, Ra, b.ga, 0, &b.cur_static[1]);
 
   int nb_m = (int)((Mn + kBlock - 1) / kBlock);
   if (nb_m < 1) nb_m = 1;
@@ -553,67 +577,80 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if (nb_e < 1) nb_e = 1;
   int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
   if (nb_q < 1) nb_q = 1;
+  int nb_c = (int)((C + 63) / 64);
+  int nb_clear = (int)((b.gm.ff_bytes / 16 + kBlock - 1) / kBlock);
+  if (nb_clear > 1024) nb_clear = 1024;
+  if (nb_clear < 1) nb_clear = 1;
+
+  bool prof = g_prof_on;
+  if (prof && !t_ev.have) {
+    for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
+    t_ev.have = true;
+  }
   IcpState host;
-  host.done = 0;
+  host.stop_iter = INT_MAX;
   host.iters = 0;
   host.err = 0;
   int it = 0;
   while (it < max_iter) {
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
-    for (int k = 0; k < n_it; ++k) {
-      icp_begin_iter_kernel<<<16, kBlock, 0, s>>>(b.gm.fr, b.state, b.acc1, b.acc2, C);
-      if ((rc = build(mov_fxyz, Mn, b.gm, &b.state->done))) return rc;
-      bool prof = g_prof.on && (it + k) < 96;
-      if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k)], s));
-      icp_nn_kernel<<<nb_q, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn, (const float4*)ref_fxyz,
-                                            (int)Rn, b.grid, frame_offset, b.gr, b.gm, b.state,
-                                            b.nn_f, b.nn_b);
-      if (prof) PCS_CHECK_HIP(hipEventRecord(g_prof.ev[2 * (it + k) + 1], s));
-      icp_pass1_kernel<<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
-                                               (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
-                                               b.nn_b, b.state, b.acc1);
-      icp_pass2_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)mov_fxyz, (int)Mn,
-                                                  (const float4*)ref_fxyz, (int)Rn, mov_comp,
-                                                  b.nn_f, b.nn_b, b.state, b.acc1, b.acc2, nullptr, 0.0);
-      icp_solve_kernel<<<1, 1024, 0, s>>>(C, angle_regularizer, stopping_delta, b.acc1, b.acc2, T,
-                                          b.Rt, b.state);
-      icp_apply_kernel<<<nb_m, kBlock, 0, s>>>((float4*)mov_fxyz, (float4*)b.prev, (int)Mn, mov_comp,
-                                               b.Rt, b.state);
-      icp_latch_done_kernel<<<1, 64, 0, s>>>(b.state);
+    for (int j = 0; j < n_it; ++j) {
+      int k = it + j + 1;  // 1-based iteration number
+      icp_begin_kernel<<<nb_clear, kBlock, 0, s>>>(k, b.gm, b.state, b.acc, C);
+      sort_into(mov_fxyz, Mn, b.gm, k, &b.state->cursor);
+      bool pk = prof && k <= 96;
+      if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1)], s));
+      icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
+                                            (const float4*)ref_fxyz, (int)Rn, b.grid, frame_offset,
+                                            b.gr, b.gm, b.state, b.nn_f, b.nn_b);
+      if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1) + 1], s));
+      icp_moments_kernel<<<nb_e, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
+                                                 (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
+                                                 b.nn_b, b.state, b.acc);
+      icp_solve_kernel<<<nb_c, 64, 0, s>>>(k, C, angle_regularizer, stopping_delta, b.acc, T, b.Rt,
+                                           b.state);
+      icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
+                                               mov_comp, b.Rt, b.state);
     }
     it += n_it;
     PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (host.err) return PCS_ERR_RANGE;
-    if (host.done) break;
+    if (host.stop_iter != INT_MAX) break;
   }
-  if (g_prof.on) {
-    // only the iterations that ran (later launches exit on the done flag)
-    int n_it = host.iters < 96 ? host.iters : 96;
-    for (int k = 0; k < n_it; ++k) {
+  if (prof) {
+    int n_done = host.iters < 96 ? host.iters : 96;
+    double ms_sum = 0.0;
+    for (int k = 0; k < n_done; ++k) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]) == hipSuccess) g_prof.ms += ms;
+      if (hipEventElapsedTime(&ms, t_ev.ev[2 * k], t_ev.ev[2 * k + 1]) == hipSuccess) ms_sum += ms;
     }
-    g_prof.launches += n_it;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_total.ms += ms_sum;
+    g_prof_total.launches += n_done;
     // per launch: read every query point and every hashed point (16 B rows), write one int32
     // neighbour per query (16 N + 16 M per graph, two graphs per iteration)
-    g_prof.bytes += (double)n_it * (2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn));
+    g_prof_total.bytes += (double)n_done * (2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn));
   }
   info[0] = host.iters;
-  info[1] = host.done ? 1 : 0;
+  info[1] = host.stop_iter != INT_MAX ? 1 : 0;
   info[2] = info[3] = 0;
   if (host.iters > 0) {
     // l1 error of the last iteration: positions before its update are in `prev`
-    icp_pass2_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn,
-                                                (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
-                                                b.nn_b, b.state, b.acc1, b.acc2, b.acc1 + 7, 0.3);
+    icp_l1_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
+                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, b.acc, 0.3);
+    icp_l1_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
+                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, b.acc, 0.3);
   }
   if (Mn > 0 && Ra > 0)
     icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
         (const float4*)mov_fxyz, (int)Mn, mov_comp, b.grid, frame_offset, b.ga, b.state, b.cnt);
-  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, b.acc1, b.cnt, comp_deg, l1_err, edge_ratio);
+  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, b.acc, b.cnt, comp_deg, host.iters > 0, l1_err,
+                                                   edge_ratio);
   PCS_LAUNCH_CHECK();
+  PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
   PCS_CHECK_HIP(hipStreamSynchronize(s));
+  if (host.err) return PCS_ERR_RANGE;
   return PCS_OK;
 }
 

@@ -401,29 +401,92 @@ class ClusterTracking(nn.Module):
             return seq_dict
         seq_boxes.best_iou = torch.zeros_like(seq_boxes.attr[:, 0])
 
-        results = {}
+        # The 3 keys x anchors {0, 8, 16, ...} are independent units (the reference runs them one
+        # after the other). Each unit is a chain of small, latency-bound launches, so units run
+        # concurrently: one host thread + one HIP stream per unit, every thread on its own clone of
+        # the graph / sampler modules (their radius / qmin / qmax are mutated during registration).
+        # best_iou is a running maximum, so per-unit copies merged by max equal the serial result.
+        key_points = {}
         for comp_key in self.component_keys:
-            seq_points.component = seq_dict[f"point_{comp_key}"]
-            diam = component_diameter(seq_points)
-            seq_points.component_diameter = diam[seq_points.component]
-            seq_points.stationary = seq_points.component_diameter > 12.5
-            seq_points.extracted = torch.zeros_like(seq_points.fxyz[:, 0]).bool()
+            sp = EasyDict(dict(seq_points))
+            sp.component = seq_dict[f"point_{comp_key}"]
+            diam = component_diameter(sp)
+            sp.component_diameter = diam[sp.component]
+            sp.stationary = sp.component_diameter > 12.5
+            key_points[comp_key] = sp
+        units = []
+        for comp_key in self.component_keys:
+            sp = key_points[comp_key]
+            present = torch.unique(sp.fxyz[:, 0]).long().tolist()
             for frame_id in range(0, num_frames, self.track_interval):
-                frame_mask = (seq_points.fxyz[:, 0] == frame_id).reshape(-1)
-                if not bool(frame_mask.any()):
-                    continue
-                frame_points = EasyDict(filter_dict(seq_points, frame_mask))
-                frame_points.component = frame_points.component - frame_points.component.min()
-                with Timer(f"Tracking Frame {frame_id}"):
-                    extracted = self.track_frame(seq_points, frame_points, seq_boxes)
-                with Timer("Extract Traces from all points"):
-                    if extracted.fxyz.shape[0] > 0:
-                        extracted, seq_boxes = self.extract_traces_and_update_boxes(
-                            all_points, extracted, seq_boxes)
-                results[(frame_id, comp_key)] = extracted
-                if save:
-                    torch.save(dict(extracted), f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
-                extracted.pop("transforms")
+                if frame_id in present:
+                    units.append((comp_key, frame_id))
+
+        def run_unit(worker, comp_key, frame_id):
+            sp = EasyDict(dict(key_points[comp_key]))
+            sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
+            frame_mask = (sp.fxyz[:, 0] == frame_id).reshape(-1)
+            frame_points = EasyDict(filter_dict(sp, frame_mask))
+            frame_points.component = frame_points.component - frame_points.component.min()
+            boxes = EasyDict(dict(seq_boxes))
+            boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)
+            with Timer(f"Tracking Frame {frame_id}"):
+                extracted = worker.track_frame(sp, frame_points, boxes)
+            with Timer("Extract Traces from all points"):
+                if extracted.fxyz.shape[0] > 0:
+                    extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes)
+            return extracted, boxes.best_iou
+
+        n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 9)), len(units)))
+        results, best = {}, []
+        if n_workers == 1 or not seq_points.fxyz.is_cuda:
+            for comp_key, frame_id in units:
+                ex, biou = run_unit(self, comp_key, frame_id)
+                results[(frame_id, comp_key)] = ex
+                best.append(biou)
+        else:
+            import copy
+            import queue
+            from concurrent.futures import ThreadPoolExecutor
+            device = seq_points.fxyz.device
+            if len(getattr(self, "_workers", [])) < n_workers:
+                self._workers = []
+                for _ in range(n_workers):
+                    w = copy.copy(self)
+                    w._modules = {k: copy.deepcopy(m) for k, m in self._modules.items()}
+                    w.num_registration_calls = 0
+                    w._stream = torch.cuda.Stream(device=device)
+                    self._workers.append(w)
+            main_stream = torch.cuda.current_stream(device)
+            free = queue.Queue()
+            for w in self._workers[:n_workers]:
+                w.num_registration_calls = 0
+                w._stream.wait_stream(main_stream)
+                free.put(w)
+
+            def job(comp_key, frame_id):
+                w = free.get()
+                try:
+                    with torch.cuda.device(device), torch.cuda.stream(w._stream):
+                        out = run_unit(w, comp_key, frame_id)
+                        w._stream.synchronize()
+                    return out
+                finally:
+                    free.put(w)
+
+            with ThreadPoolExecutor(max_workers=n_workers) as pool:
+                futs = {u: pool.submit(job, *u) for u in units}
+                for (comp_key, frame_id), fut in futs.items():
+                    ex, biou = fut.result()
+                    results[(frame_id, comp_key)] = ex
+                    best.append(biou)
+            self.num_registration_calls = sum(w.num_registration_calls for w in self._workers[:n_workers])
+        for biou in best:
+            seq_boxes.best_iou = torch.maximum(seq_boxes.best_iou, biou)
+        for (frame_id, comp_key), extracted in results.items():
+            if save:
+                torch.save(dict(extracted), f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
+            extracted.pop("transforms", None)
         if save:
             torch.save(dict(seq_boxes), outpath)
         seq_dict["cluster_tracking_results"] = results
