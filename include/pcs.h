@@ -243,6 +243,17 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
 int pcs_profile_icp_nn(int enable);
 int pcs_profile_icp_nn_read(double* out3);
 
+/* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
+ * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per
+ * round instead of ~25 + eigh + a host sync). xyz [n,3] f32; pillar_idx [n] int64 in [0,P);
+ * w0 [n] f32; origin [P,3] f32 (a point near each pillar, conditions the raw moments). Outputs:
+ * plane [P,6] f32 (centre, unit normal with n_z >= 0), plane_err [n] f32, optional *d_rounds. */
+size_t pcs_irls_plane_fit_workspace_bytes(int64_t n, int64_t P);
+int pcs_irls_plane_fit(const float* xyz, const int64_t* pillar_idx, int64_t n, const float* w0,
+                       const float* origin, int64_t P, float sigma2, float stopping_delta,
+                       int max_rounds, float* plane, float* plane_err, int32_t* d_rounds, void* ws,
+                       size_t ws_bytes, pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,6 +252,194 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
   if (tid == 0) { st->iters = it; st->last_loss = last_loss; }
 }
 
+
+// iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80:
+// per pillar, <= 50 rounds of {weighted centre, weighted covariance / count, normal = eigenvector of
+// the smallest eigenvalue, Cauchy weights on the point-plane error times a 0.5 m distance falloff},
+// stopped when no weight moves by more than `delta`. The reference issues ~25 torch kernels, a
+// batched eigh and a host sync per round (x 50 rounds x 30 height ratios per sequence).
+// Here a round is two kernels: `irls_accumulate` (one pass over the voxels: new weight from the
+// previous plane, raw weighted moments about the pillar's reference point via wave-aggregated f64
+// atomics, max weight change) and `irls_solve` (one thread per pillar: centre, covariance, 3x3
+// symmetric Jacobi eigen-solve). The convergence test runs on the device (rounds after it are
+// skipped), so the host never synchronises inside the loop.
+struct IrlsState {
+  int stop_round;   // rounds > stop_round do not run
+  int rounds;
+  unsigned max_dw_bits;  // max |new_w - w| of the current round (float bits, >= 0)
+  int pad;
+};
+
+constexpr int kIrlsAcc = 12;  // sum w, sum w x (3), sum w x x^T (6: xx xy xz yy yz zz), count, pad
+
+__global__ void irls_init_kernel(IrlsState* st, double* acc, int64_t P) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i == 0) { st->stop_round = 0x7fffffff; st->rounds = 0; st->max_dw_bits = 0; }
+  for (int64_t q = i; q < P * kIrlsAcc; q += (int64_t)gridDim.x * blockDim.x) acc[q] = 0.0;
+}
+
+// round r (1-based). r == 1 uses the given weights w0; later rounds derive the weight from the
+// plane of round r-1 (centre / normal in `plane`), exactly the reference's update order.
+__global__ void __launch_bounds__(kBlock)
+irls_accumulate_kernel(int r, const float* __restrict__ xyz, const int64_t* __restrict__ pidx,
+                       int64_t n, const float* __restrict__ origin, float sigma2, float delta,
+                       float* __restrict__ w, const float* __restrict__ plane,
+                       float* __restrict__ perr, double* __restrict__ acc,
+                       IrlsState* __restrict__ st) {
+  if (r > st->stop_round) return;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool active = i < n;
+  int c = 0;
+  double v[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) v[q] = 0.0;
+  float dw = 0.f;
+  if (active) {
+    c = (int)pidx[i];
+    float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    float wi = w[i];
+    if (r > 1) {
+      const float* pl = plane + (int64_t)c * 6;  // centre (3), normal (3) of the previous round
+      float dx = x - pl[0], dy = y - pl[1], dz = z - pl[2];
+      float e = fabsf(dx * pl[3] + dy * pl[4] + dz * pl[5]);
+      perr[i] = e;
+      float nw = sigma2 / (e * e + sigma2);
+      float dist_w = 0.25f / (dx * dx + dy * dy + dz * dz + 0.25f);
+      nw = nw * dist_w;
+      dw = fabsf(nw - wi);
+      // the reference tests max|new_w - w| < delta BEFORE adopting new_w: if the test passes the
+      // loop ends with the old weights, so the accumulation below must then be discarded. The
+      // solve kernel handles that (it ignores this round's sums when the test passed).
+      wi = nw;
+      w[i] = nw;
+    }
+    float ox = x - origin[c * 3], oy = y - origin[c * 3 + 1], oz = z - origin[c * 3 + 2];
+    double W = wi;
+    v[0] = W; v[1] = W * ox; v[2] = W * oy; v[3] = W * oz;
+    v[4] = W * ox * ox; v[5] = W * ox * oy; v[6] = W * ox * oz;
+    v[7] = W * oy * oy; v[8] = W * oy * oz; v[9] = W * oz * oz;
+    v[10] = 1.0;
+  }
+  float mx = wave_max(dw);
+  if ((threadIdx.x & 63) == 0 && r > 1) atomicMax(&st->max_dw_bits, __float_as_uint(mx));
+  // same machinery as the ICP: lanes sharing a pillar are combined before the atomics
+  {
+    int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+      int leader = __ffsll((long long)todo) - 1;
+      int lkey = __shfl(c, leader, 64);
+      bool mine = active && c == lkey;
+      unsigned long long grp = __ballot(mine);
+#pragma unroll
+      for (int q = 0; q < 11; ++q) {
+        double xsum = wave_sum_f64(mine ? v[q] : 0.0);
+        if (lane == leader) atomicAdd(&acc[(int64_t)lkey * kIrlsAcc + q], xsum);
+      }
+      todo &= ~grp;
+    }
+  }
+}
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, f32 like the reference's eigh)
+__device__ inline void eig3_smallest(const float A_in[6], float nrm[3]) {
+  // A = [[a0 a1 a2],[a1 a3 a4],[a2 a4 a5]]
+  double A[3][3] = {{A_in[0], A_in[1], A_in[2]}, {A_in[1], A_in[3], A_in[4]}, {A_in[2], A_in[4], A_in[5]}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    if (off <= 1e-14 * dia || off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int m = 0;
+  if (A[1][1] < A[m][m]) m = 1;
+  if (A[2][2] < A[m][m]) m = 2;
+  double sgn = V[2][m] < 0 ? -1.0 : 1.0;  // canonical sign: normal points up
+  for (int k = 0; k < 3; ++k) nrm[k] = (float)(sgn * V[k][m]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+irls_solve_kernel(int r, int64_t P, const float* __restrict__ origin, float delta,
+                  double* __restrict__ acc, float* __restrict__ plane, IrlsState* __restrict__ st) {
+  if (r > st->stop_round) return;
+  // convergence of the reference: round r computed new weights from plane r-1; if none moved by
+  // delta or more the loop ends and plane r-1 is the result
+  bool converged = r > 1 && __uint_as_float(st->max_dw_bits) < delta;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c < P) {
+    double* a = acc + c * kIrlsAcc;
+    if (!converged) {
+      double ws = a[0] + 1e-6;
+      double cnt = a[10] > 0.5 ? a[10] : 1.0;
+      // centre = sum(w x) / (sum w + 1e-6) with x = o + origin; m = centre - origin
+      double m[3];
+      for (int q = 0; q < 3; ++q) m[q] = (a[1 + q] + (double)origin[c * 3 + q] * a[0]) / ws - (double)origin[c * 3 + q];
+      // sum w d d^T with d = x - centre = o - m:  S_oo - m S_o^T - S_o m^T + W m m^T
+      double So[3] = {a[1], a[2], a[3]};
+      double Soo[6] = {a[4], a[5], a[6], a[7], a[8], a[9]};
+      int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+      float cov[6];
+      for (int q = 0; q < 6; ++q) {
+        int i = ia[q], j = ib[q];
+        double sdd = Soo[q] - m[i] * So[j] - So[i] * m[j] + a[0] * m[i] * m[j];
+        cov[q] = (float)(sdd / cnt);
+      }
+      float nrm[3];
+      eig3_smallest(cov, nrm);
+      float* pl = plane + c * 6;
+      pl[0] = (float)(m[0] + origin[c * 3]);
+      pl[1] = (float)(m[1] + origin[c * 3 + 1]);
+      pl[2] = (float)(m[2] + origin[c * 3 + 2]);
+      pl[3] = nrm[0]; pl[4] = nrm[1]; pl[5] = nrm[2];
+    }
+    for (int q = 0; q < kIrlsAcc; ++q) a[q] = 0.0;  // ready for the next round
+  }
+  __threadfence();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (converged) st->stop_round = r;
+    else st->rounds = r;
+  }
+}
+
+__global__ void irls_reset_dw_kernel(int r, IrlsState* st) {
+  if (r > st->stop_round) return;
+  if (threadIdx.x == 0) st->max_dw_bits = 0;
+}
+
+// final point-plane error against the last plane (the reference's `plane_fitting_error`)
+__global__ void __launch_bounds__(kBlock)
+irls_error_kernel(const float* __restrict__ xyz, const int64_t* __restrict__ pidx, int64_t n,
+                  const float* __restrict__ plane, float* __restrict__ perr) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float* pl = plane + pidx[i] * 6;
+    float dx = xyz[i * 3] - pl[0], dy = xyz[i * 3 + 1] - pl[1], dz = xyz[i * 3 + 2] - pl[2];
+    perr[i] = fabsf(dx * pl[3] + dy * pl[4] + dz * pl[5]);
+  }
+}
+
 // points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168: serial
 // boxes x points double loop on the host in the reference; one thread per (box, point) here.
 // Same arithmetic: |z - cz| <= dz/2 in double, rotation by cos/sin of the double angle rounded to
@@ -358,6 +546,49 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
                                        rigid_weight, max_iters, height_out, m, v, st);
   if (d_iters)
     PCS_CHECK_HIP(hipMemcpyAsync(d_iters, &st->iters, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+size_t pcs_irls_plane_fit_workspace_bytes(int64_t n, int64_t P) {
+  Arena a(nullptr, 0);
+  a.take<IrlsState>(1);
+  a.take<double>((size_t)(P > 0 ? P : 1) * kIrlsAcc);
+  a.take<float>((size_t)(n > 0 ? n : 1));
+  return a.off;
+}
+
+// xyz [n,3] f32, pillar_idx [n] int64 in [0,P), w0 [n] f32 initial weights, origin [P,3] f32 (any
+// point near each pillar; only conditions the raw moments). Outputs: plane [P,6] (centre, normal),
+// plane_err [n] f32 (error of every point against the returned plane), *d_rounds (optional device
+// int32) = rounds whose plane was adopted. Never synchronises.
+int pcs_irls_plane_fit(const float* xyz, const int64_t* pillar_idx, int64_t n, const float* w0,
+                       const float* origin, int64_t P, float sigma2, float stopping_delta,
+                       int max_rounds, float* plane, float* plane_err, int32_t* d_rounds, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
+  if (!xyz || !pillar_idx || !w0 || !origin || !plane || !plane_err || !ws || n < 1 || P < 1 ||
+      max_rounds < 1)
+    return PCS_ERR_ARG;
+  Arena a(ws, ws_bytes);
+  IrlsState* st = a.take<IrlsState>(1);
+  double* acc = a.take<double>((size_t)P * kIrlsAcc);
+  float* w = a.take<float>((size_t)n);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemcpyAsync(w, w0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  irls_init_kernel<<<grid_for(P * kIrlsAcc), kBlock, 0, s>>>(st, acc, P);
+  int nb = (int)((n + kBlock - 1) / kBlock);
+  int nbp = (int)((P + kBlock - 1) / kBlock);
+  // the reference runs `for itr in range(50)`: round r fits plane r from weights r; the weights of
+  // round r+1 come from plane r; it breaks (keeping plane r) when they moved by less than delta
+  for (int r = 1; r <= max_rounds; ++r) {
+    irls_reset_dw_kernel<<<1, 64, 0, s>>>(r, st);
+    irls_accumulate_kernel<<<nb, kBlock, 0, s>>>(r, xyz, pillar_idx, n, origin, sigma2,
+                                                 stopping_delta, w, plane, plane_err, acc, st);
+    irls_solve_kernel<<<nbp, kBlock, 0, s>>>(r, P, origin, stopping_delta, acc, plane, st);
+  }
+  irls_error_kernel<<<grid_for(n), kBlock, 0, s>>>(xyz, pillar_idx, n, plane, plane_err);
+  if (d_rounds)
+    PCS_CHECK_HIP(hipMemcpyAsync(d_rounds, &st->rounds, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

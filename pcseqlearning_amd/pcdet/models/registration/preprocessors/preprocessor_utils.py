@@ -30,31 +30,19 @@ def _seg_sum(data, sg, n):
     return efficient_robust_sum(data, sg, n, block=True)
 
 
-def iterative_reweighted_ransac(points, pillars, w0, num_pillars, sigma2, stopping_delta=1e-2, sg=None):
+def iterative_reweighted_ransac(points, pillars, w0, num_pillars, sigma2, stopping_delta=1e-2, sg=None,
+                                origin=None):
     """<= 50 IRLS plane fits per pillar: weighted centre, weighted covariance, smallest
     eigenvector as the normal, Cauchy weights on the point-plane error times a 0.5 m distance
-    falloff; stops when no weight moves by more than stopping_delta (preprocessor_utils.py:32-80)."""
-    if sg is None:
-        sg = IndexSegments(points.pillar_idx, num_pillars)
-    w = w0
+    falloff; stops when no weight moves by more than stopping_delta (preprocessor_utils.py:32-80).
+    Runs as ops.irls_plane_fit: two HIP kernels per round, convergence tested on the device."""
     xyz = points.bxyz[:, 1:4]
-    cnt = _seg_sum(torch.ones_like(w), sg, num_pillars).clamp(min=1)
-    for _ in range(50):
-        center = _seg_sum(xyz * w, sg, num_pillars)
-        wsum = _seg_sum(w, sg, num_pillars) + 1e-6
-        pillars.center = center / wsum
-        d = xyz - pillars.center[points.pillar_idx]
-        ddT = (w[:, :, None] * d[:, :, None]) * d[:, None, :]
-        cov = _seg_sum(ddT.reshape(-1, 9), sg, num_pillars).reshape(-1, 3, 3) / cnt[:, :, None]
-        _, Q = torch.linalg.eigh(cov)
-        pillars.normal = Q[:, :, 0]
-        points.plane_fitting_error = (d * pillars.normal[points.pillar_idx]).sum(-1).abs()
-        new_w = (sigma2 / (points.plane_fitting_error.square() + sigma2)).reshape(-1)
-        dist_w = (0.5 ** 2) / (d.square().sum(dim=-1) + 0.5 ** 2)
-        new_w = (new_w * dist_w).reshape(-1, 1)
-        if (new_w - w).abs().max() < stopping_delta:
-            break
-        w = new_w
+    if origin is None:
+        if sg is None:
+            sg = IndexSegments(points.pillar_idx, num_pillars)
+        origin = robust_mean(xyz, sg, num_pillars)
+    pillars.center, pillars.normal, points.plane_fitting_error = ops.irls_plane_fit(
+        xyz, points.pillar_idx, w0, origin, num_pillars, sigma2, stopping_delta, 50)
     return points, pillars
 
 
@@ -99,11 +87,13 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     npil.best_center = npil.min_z.new_zeros(num_new, 3)
 
     sigma = cfg["SIGMA2"] ** 0.5
+    origin = robust_mean(nv.bxyz[:, 1:4], sg, num_new)
     for ratio in torch.linspace(0.3, 1, 30).tolist():
         cur_z = npil.min_z * ratio + npil.max_z * (1 - ratio)
         z_diff = cur_z[nv.pillar_idx] - z
         w0 = (cfg["SIGMA2"] / (z_diff.square() + cfg["SIGMA2"])).reshape(-1, 1)
-        nv, npil = iterative_reweighted_ransac(nv, npil, w0, num_new, sigma2=cfg["SIGMA2"], sg=sg)
+        nv, npil = iterative_reweighted_ransac(nv, npil, w0, num_new, sigma2=cfg["SIGMA2"], sg=sg,
+                                               origin=origin)
         hit = (nv.plane_fitting_error < sigma).float()
         num_hit = _seg_sum(hit, sg, num_new)
         better = npil.best_confidence < num_hit
