@@ -179,25 +179,31 @@ icp_nn_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __res
   }
 }
 
-// raw moments of the matched pairs per component, one thread per potential edge
+// raw moments of the matched pairs per component, one thread per potential edge. Each workgroup
+// first accumulates into a small LDS table keyed by component (ds_add_f64; neighbouring edges
+// mostly share a component), then flushes one global f64 atomic per (component, accumulator).
+constexpr int kMomSlots = 64;
 __global__ void __launch_bounds__(kBlock)
 icp_moments_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref,
                    int Rn, const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
                    const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
                    double* __restrict__ acc) {
   if (k > st->stop_iter) return;
+  __shared__ int skey[kMomSlots];
+  __shared__ double sacc[kMomSlots][17];
+  for (int q = threadIdx.x; q < kMomSlots; q += kBlock) skey[q] = -1;
+  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) (&sacc[0][0])[q] = 0.0;
+  __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool active = false;
   int c = 0, m = -1, r = -1;
   if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
   else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
-  double v[17];
-#pragma unroll
-  for (int q = 0; q < 17; ++q) v[q] = 0.0;
   if (active) {
     float4 pf = mov[m], qf = ref[r];
     c = comp[m];
     double p[3] = {pf.y, pf.z, pf.w}, q[3] = {qf.y, qf.z, qf.w};
+    double v[17];
     v[0] = 1.0;
     double d2 = 0.0;
 #pragma unroll
@@ -210,8 +216,28 @@ icp_moments_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* 
       d2 += e * e;
     }
     v[16] = d2;
+    // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
+    int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
+    int found = -1;
+    for (int t = 0; t < kMomSlots; ++t) {
+      int old = atomicCAS(&skey[slot], -1, c);
+      if (old == -1 || old == c) { found = slot; break; }
+      slot = (slot + 1) & (kMomSlots - 1);
+    }
+    if (found >= 0) {
+#pragma unroll
+      for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&sacc[found][q2], v[q2]);
+    } else {
+#pragma unroll
+      for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&acc[(int64_t)c * kAcc + q2], v[q2]);
+    }
   }
-  grouped_atomic_add<17>(active, c, v, acc, kAcc);
+  __syncthreads();
+  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
+    int sl = q / 17, a = q - sl * 17;
+    int key = skey[sl];
+    if (key >= 0) atomicAdd(&acc[(int64_t)key * kAcc + a], sacc[sl][a]);
+  }
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151)

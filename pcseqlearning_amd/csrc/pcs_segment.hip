@@ -102,22 +102,26 @@ segment_median_kernel(const int64_t* __restrict__ data, const int32_t* __restric
 }
 
 // ------------------------------------------------------------------ per-segment max / min (f32)
+// one wave per (segment, column): lane-strided scan + butterfly (min / max are order-free)
 __global__ void __launch_bounds__(kBlock)
 segment_minmax_kernel(const float* __restrict__ data, int d, const int32_t* __restrict__ order,
                       const int32_t* __restrict__ seg_start, int64_t v, int is_max,
                       float* __restrict__ out) {
+  int lane = threadIdx.x & 63;
+  int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int64_t total = v * d;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = wave; t < total; t += nwaves) {
     int64_t seg = t / d;
     int c = (int)(t - seg * d);
     int b = seg_start[seg], e = seg_start[seg + 1];
-    float acc = data[(int64_t)order[b] * d + c];
-    for (int p = b + 1; p < e; ++p) {
+    float acc = is_max ? -__builtin_inff() : __builtin_inff();
+    for (int p = b + lane; p < e; p += 64) {
       float x = data[(int64_t)order[p] * d + c];
       acc = is_max ? fmaxf(acc, x) : fminf(acc, x);
     }
-    out[t] = acc;
+    acc = is_max ? wave_max(acc) : wave_min(acc);
+    if (lane == 0) out[t] = acc;
   }
 }
 
@@ -175,7 +179,11 @@ int pcs_segment_minmax_f32(const float* data, int d, const int32_t* order, const
                            int64_t v, int is_max, float* out, hipStream_t s) {
   if (v < 0 || d < 1 || (v > 0 && (!data || !order || !seg_start || !out))) return PCS_ERR_ARG;
   if (v == 0) return PCS_OK;
-  segment_minmax_kernel<<<grid_for(v * d), kBlock, 0, s>>>(data, d, order, seg_start, v, is_max, out);
+  {
+    int64_t blocks = (v * d * 64 + kBlock - 1) / kBlock;
+    segment_minmax_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), kBlock, 0, s>>>(data, d, order, seg_start, v,
+                                                                                is_max, out);
+  }
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
