@@ -123,6 +123,7 @@ int pcs_indice_conv_f32(const float* features, int cin, const float* filters, in
  * BatchNorm / ReLU (fused_spconv_ops.h:29-132, modules.py:125-187) fold into the epilogue. */
 int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
                              int inverse, int64_t num_out, int32_t* table, pcs_stream_t stream);
+int pcs_conv_use_mfma(int enable); /* 1 (default): MFMA tiles for Cin >= 16; 0: FMA tiles only */
 int pcs_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv,
                               int cout, int centre, const int32_t* table, int64_t num_out,
                               const float* bias, const float* scale, const float* shift, int relu,

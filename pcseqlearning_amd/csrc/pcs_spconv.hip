@@ -103,6 +103,79 @@ indice_conv_tile_kernel(const float* __restrict__ feat, int cin, const float* __
   }
 }
 
+
+// MFMA variant (Cin % 4 == 0, Cout in {16,32,64,128}): same 64-row output tile and LDS staging,
+// the inner product runs on the matrix cores with v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate:
+// bit-for-bit a k-ordered fmaf chain, so results equal the FMA kernel's). Wave w owns rows
+// 16w..16w+15 of the tile and all Cout columns (NC accumulators of 4 VGPRs).
+// Fragment maps (cdna_hip_programming.md 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D: col = l&15, row = (l>>4)*4 + reg.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int A_LD = CIN_MAX + 4;  // row stride 68: 4*row + k spreads the 16x4 fragment over banks
+
+template <int NC>
+__global__ void __launch_bounds__(kBlock)
+indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
+                        int kv, int centre, const int32_t* __restrict__ table, int64_t num_out,
+                        const float* __restrict__ bias, const float* __restrict__ scale,
+                        const float* __restrict__ shift, int relu, float* __restrict__ out) {
+  constexpr int COUT = NC * 16;
+  constexpr int W_LD = COUT + 16;  // k and k+1 land 16 banks apart: conflict-free 32-lane groups
+  __shared__ float As[TM][A_LD];
+  __shared__ float Ws[CIN_MAX][W_LD];
+  __shared__ int Tk[TM];
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int fi = lane & 15, fk = lane >> 4;
+  int64_t row0 = (int64_t)blockIdx.x * TM;
+  f32x4 acc[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int step = 0; step < kv; ++step) {
+    int k = step;
+    if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+    int any = 0;
+    if (tid < TM) {
+      int64_t r = row0 + tid;
+      int t = (r < num_out) ? table[r * kv + k] : -1;
+      Tk[tid] = t;
+      any = t >= 0;
+    }
+    any = __syncthreads_or(any);
+    if (!any) continue;
+    for (int e = tid; e < TM * cin; e += kBlock) {
+      int r = e / cin, c = e - r * cin;
+      int in = Tk[r];
+      As[r][c] = in >= 0 ? feat[(int64_t)in * cin + c] : 0.f;
+    }
+    const float* Wk = W + (int64_t)k * cin * COUT;
+    for (int e = tid; e < cin * COUT; e += kBlock) Ws[e / COUT][e % COUT] = Wk[e];
+    __syncthreads();
+    for (int c0 = 0; c0 < cin; c0 += 4) {
+      float a = As[wv * 16 + fi][c0 + fk];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        float b = Ws[c0 + fk][n * 16 + fi];
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    int col = n * 16 + fi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t r = row0 + wv * 16 + fk * 4 + j;
+      if (r >= num_out) continue;
+      float v = acc[n][j];
+      if (bias) v = v + bias[col];
+      if (scale) v = fmaf(v, scale[col], shift[col]);
+      if (relu) v = fmaxf(v, 0.f);
+      out[r * COUT + col] = v;
+    }
+  }
+}
+
 // any (Cin, Cout): one thread per output element, same accumulation order
 __global__ void __launch_bounds__(kBlock)
 indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
@@ -132,11 +205,20 @@ indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float*
   }
 }
 
+static int g_use_mfma = 1;
+
 }  // namespace pcs
 
 using namespace pcs;
 
 extern "C" {
+
+// 1 (default): layers with Cin >= 16, Cin % 4 == 0 run on v_mfma_f32_16x16x4_f32; 0: FMA tiles
+// everywhere (for A/B measurements; both give bit-identical results).
+int pcs_conv_use_mfma(int enable) {
+  g_use_mfma = enable != 0;
+  return PCS_OK;
+}
 
 size_t pcs_neighbor_table_bytes(int64_t num_out, int kv) {
   return align_up((size_t)(num_out > 0 ? num_out : 1) * kv * sizeof(int32_t));
@@ -169,6 +251,26 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
   int64_t nb = (num_out + TM - 1) / TM;
   if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
   bool tiled = cin <= CIN_MAX && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
+  // matrix cores where the tile is dense enough to feed them: 4-aligned input channels (the
+  // first layer, Cin = 3..5, stays on the FMA path: it is bandwidth-bound)
+  if (tiled && g_use_mfma && (cin % 4 == 0) && cin >= 16) {
+    switch (cout) {
+      case 16:
+        indice_conv_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        break;
+      case 32:
+        indice_conv_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        break;
+      case 64:
+        indice_conv_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        break;
+      default:
+        indice_conv_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        break;
+    }
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   if (tiled) {
     switch (cout) {
       case 16:

@@ -1,0 +1,87 @@
+"""BASELINE config 5: full VoxelBackBone8x forward on one 160k-pt synthetic frame (dynamic VFE ->
+12 sparse convs over 8 rulebooks), eval-mode BN. Times the forward with the MFMA tiles and with
+the FMA tiles (bit-identical outputs are asserted) and prints one JSON line.
+
+  python tools/bench_backbone.py [--points 160000] [--reps 20] [--mfma 0|1|both]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pcseqlearning_amd import lib as L  # noqa: E402
+from pcseqlearning_amd import synthetic  # noqa: E402
+from pcseqlearning_amd.pcdet.models.backbones_3d import VoxelBackBone8x  # noqa: E402
+from pcseqlearning_amd.pcdet.models.backbones_3d.vfe import DynamicMeanVFE  # noqa: E402
+
+
+def conv_flops(out):
+    """2 * sum(P_k) * Cin * Cout over the 12 convs, from the cached rulebooks."""
+    t = out["encoded_spconv_tensor"]
+    return t.indice_dict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=160000)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--mfma", default="both")
+    args = ap.parse_args()
+    dev = "cuda:0"
+    lib = L.load()
+    torch.manual_seed(0)
+    pts = torch.from_numpy(synthetic.gen_voxel_frame(0, args.points)).to(dev)
+    vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
+    net = VoxelBackBone8x({}, 5, synthetic.GRID_SIZE.tolist()).to(dev).eval()
+
+    def forward():
+        batch = vfe({"points": pts, "batch_size": 1})
+        with torch.no_grad():
+            return net(batch)
+
+    modes = {"both": (1, 0), "1": (1,), "0": (0,)}[args.mfma]
+    results, outs = {}, {}
+    for mode in modes:
+        lib.pcs_conv_use_mfma(ctypes.c_int(mode))
+        out = forward()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+            out = forward()
+        e.record()
+        torch.cuda.synchronize()
+        results["mfma" if mode else "fma"] = s.elapsed_time(e) / args.reps
+        outs[mode] = out["encoded_spconv_tensor"].features.clone()
+    lib.pcs_conv_use_mfma(ctypes.c_int(1))
+    if len(modes) == 2:
+        assert torch.equal(outs[1], outs[0]), "MFMA and FMA tiles must agree bit for bit"
+    # flops of the conv layers from the rulebooks of the last forward
+    d = out["encoded_spconv_tensor"].indice_dict
+    chans = {"subm1": [(5, 16), (16, 16)], "spconv2": [(16, 32)], "subm2": [(32, 32)] * 2,
+             "spconv3": [(32, 64)], "subm3": [(64, 64)] * 2, "spconv4": [(64, 64)],
+             "subm4": [(64, 64)] * 2, "spconv_down2": [(64, 128)]}
+    flops = 0
+    voxels = {}
+    for key, layers in chans.items():
+        num = int(d[key][3].sum())
+        voxels[key] = int(d[key][0].shape[0])
+        for cin, cout in layers:
+            flops += 2 * num * cin * cout
+    line = {"workload": "config5: VoxelBackBone8x forward, one synthetic frame", "points": args.points,
+            "voxels": int(out["multi_scale_3d_features"]["x_conv1"].indices.shape[0]),
+            "ms_per_forward": {k: round(v, 3) for k, v in results.items()},
+            "conv_gflop": round(flops / 1e9, 3),
+            "conv_tflops_mfma_path": round(flops / (results.get("mfma", results.get("fma")) * 1e-3) / 1e12, 3),
+            "output_voxels_per_rulebook": voxels, "bit_identical_mfma_vs_fma": len(modes) == 2}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
