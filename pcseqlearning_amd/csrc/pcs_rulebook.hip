@@ -39,12 +39,15 @@ __device__ __forceinline__ uint32_t table_find(const uint64_t* __restrict__ keys
 }
 
 __device__ __forceinline__ uint32_t table_insert(uint64_t* __restrict__ keys, uint32_t hmask,
-                                                 uint64_t key) {
+                                                 uint64_t key, bool* claimed = nullptr) {
   uint32_t slot = mix64(key) & hmask;
   while (true) {
     uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
                               (unsigned long long)key);
-    if (prev == kEmptyKey || prev == key) return slot;
+    if (prev == kEmptyKey || prev == key) {
+      if (claimed) *claimed = prev == kEmptyKey;
+      return slot;
+    }
     slot = (slot + 1) & hmask;
   }
 }
@@ -87,30 +90,30 @@ insert_inputs_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t* 
 // ---- strided conv P1: every emission claims its output cell with min(j*KV + k)
 __global__ void __launch_bounds__(kBlock)
 insert_outputs_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t* __restrict__ keys,
-                      uint32_t* __restrict__ minseq, uint32_t hmask) {
+                      uint32_t* __restrict__ minseq, uint32_t hmask, int32_t* __restrict__ lslot,
+                      int32_t* __restrict__ counter) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= V) return;
   int4 c = idx[j];
   for (int k = 0; k < g.kv; ++k) {
     uint64_t key = out_key(g, c, k);
     if (key == kEmptyKey) continue;
-    uint32_t slot = table_insert(keys, hmask, key);
+    bool claimed = false;
+    uint32_t slot = table_insert(keys, hmask, key, &claimed);
     atomicMin(&minseq[slot], (uint32_t)j * (uint32_t)g.kv + (uint32_t)k);
+    // the claimer lists the slot (order irrelevant: sorted by minseq afterwards), so the 16 V-slot
+    // table never has to be scanned for its occupied entries
+    if (claimed) lslot[atomicAdd(counter, 1)] = (int32_t)slot;
   }
 }
 
-// ---- strided conv P2a: list occupied slots (order irrelevant: sorted by minseq afterwards)
+// ---- strided conv P2a: final first-encounter key of every listed output slot
 __global__ void __launch_bounds__(kBlock)
-list_outputs_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ minseq,
-                    uint32_t H, uint32_t* __restrict__ lseq, int32_t* __restrict__ lslot,
-                    int32_t* __restrict__ counter) {
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < H; s += gridDim.x * blockDim.x) {
-    if (keys[s] != kEmptyKey) {
-      int p = atomicAdd(counter, 1);
-      lseq[p] = minseq[s];
-      lslot[p] = (int32_t)s;
-    }
-  }
+list_outputs_kernel(const uint32_t* __restrict__ minseq, const int32_t* __restrict__ lslot,
+                    const int32_t* __restrict__ counter, uint32_t* __restrict__ lseq) {
+  int U = *counter;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < U; p += gridDim.x * blockDim.x)
+    lseq[p] = minseq[lslot[p]];
 }
 
 // ---- strided conv P2b: rank r (first-encounter order) -> out coords; slot value <- rank
@@ -326,9 +329,9 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
     PCS_CHECK_HIP(hipMemsetAsync(p.minseq, 0xFF, (size_t)p.H * sizeof(uint32_t), s));
     PCS_CHECK_HIP(hipMemsetAsync(p.counter, 0, sizeof(int32_t), s));
     fill_u32_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lseq, p.cap, 0xFFFFFFFFu);
-    insert_outputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.minseq, hmask);
-    list_outputs_kernel<<<grid_for(p.H), kBlock, 0, s>>>(p.keys, p.minseq, p.H, p.lseq, p.lslot,
-                                                         p.counter);
+    insert_outputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.minseq, hmask, p.lslot,
+                                                p.counter);
+    list_outputs_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.minseq, p.lslot, p.counter, p.lseq);
     int rc = sort_pairs_u32(p.tmp, p.tmp_bytes, p.lseq, p.lseq_s, p.lslot, p.lslot_s, p.cap, 0, 32, s);
     if (rc) return rc;
     assign_outputs_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lslot_s, p.counter, p.keys, g,

@@ -121,35 +121,75 @@ indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __
                         const float* __restrict__ shift, int relu, float* __restrict__ out) {
   constexpr int COUT = NC * 16;
   constexpr int W_LD = COUT + 16;  // k and k+1 land 16 banks apart: conflict-free 32-lane groups
-  __shared__ float As[TM][A_LD];
-  __shared__ float Ws[CIN_MAX][W_LD];
-  __shared__ int Tk[TM];
+  constexpr int NA = TM * CIN_MAX / 4 / kBlock;     // float4 A loads per thread at Cin = 64
+  constexpr int NW = CIN_MAX * COUT / 4 / kBlock;   // float4 W loads per thread at Cin = 64
+  __shared__ __align__(16) float As[TM][A_LD];
+  __shared__ __align__(16) float Ws[CIN_MAX][W_LD];
+  __shared__ int Tt[TM][32];   // the tile's rows of the neighbour table (kv <= 32)
+  __shared__ int steps[32];    // active offsets, accumulation order (centre first for subM)
+  __shared__ int nsteps;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int fi = lane & 15, fk = lane >> 4;
   int64_t row0 = (int64_t)blockIdx.x * TM;
+  for (int e = tid; e < TM * kv; e += kBlock) {
+    int r = e / kv, k = e - r * kv;
+    int64_t gr = row0 + r;
+    Tt[r][k] = gr < num_out ? table[gr * kv + k] : -1;
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wave: which offsets have a partner in this tile, in accumulation order
+    int n = 0;
+    for (int step = 0; step < kv; ++step) {
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      bool any = __ballot(Tt[tid][k] >= 0) != 0;
+      if (any) { if (tid == 0) steps[n] = k; ++n; }
+    }
+    if (tid == 0) nsteps = n;
+  }
+  __syncthreads();
+  int ns = nsteps;
+  int cin4 = cin >> 2;
+  int a_cnt = TM * cin4;        // float4 elements of the A tile
+  int w_cnt = cin * COUT / 4;   // float4 elements of W[k]
+  float4 ra[NA], rw[NW];
+  auto prefetch = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int e = tid + i * kBlock;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < a_cnt) {
+        int r = e / cin4, c4 = e - r * cin4;
+        int in = Tt[r][k];
+        if (in >= 0) v = *(const float4*)(feat + (int64_t)in * cin + c4 * 4);
+      }
+      ra[i] = v;
+    }
+    const float4* Wk = (const float4*)(W + (int64_t)k * cin * COUT);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      int e = tid + i * kBlock;
+      rw[i] = e < w_cnt ? Wk[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
   f32x4 acc[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int step = 0; step < kv; ++step) {
-    int k = step;
-    if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
-    int any = 0;
-    if (tid < TM) {
-      int64_t r = row0 + tid;
-      int t = (r < num_out) ? table[r * kv + k] : -1;
-      Tk[tid] = t;
-      any = t >= 0;
+  if (ns > 0) prefetch(steps[0]);
+  for (int si = 0; si < ns; ++si) {
+    // stage the prefetched tiles, then put the next offset's loads in flight under the MFMAs
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int e = tid + i * kBlock;
+      if (e < a_cnt) { int r = e / cin4, c4 = e - r * cin4; *(float4*)&As[r][c4 * 4] = ra[i]; }
     }
-    any = __syncthreads_or(any);
-    if (!any) continue;
-    for (int e = tid; e < TM * cin; e += kBlock) {
-      int r = e / cin, c = e - r * cin;
-      int in = Tk[r];
-      As[r][c] = in >= 0 ? feat[(int64_t)in * cin + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      int e = tid + i * kBlock;
+      if (e < w_cnt) { int r = (e * 4) / COUT, c = (e * 4) - r * COUT; *(float4*)&Ws[r][c] = rw[i]; }
     }
-    const float* Wk = W + (int64_t)k * cin * COUT;
-    for (int e = tid; e < cin * COUT; e += kBlock) Ws[e / COUT][e % COUT] = Wk[e];
     __syncthreads();
+    if (si + 1 < ns) prefetch(steps[si + 1]);
     for (int c0 = 0; c0 < cin; c0 += 4) {
       float a = As[wv * 16 + fi][c0 + fk];
 #pragma unroll
