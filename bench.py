@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units per GPU (default 9)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +122,7 @@ def main():
 
     host_batch = load_sequence(rank, args.frames, args.points)  # sequence s -> GPU s mod world
     batch = models.load_data_to_gpu(host_batch, device)
-    model = build_model(save=False, device=device)
+    model = build_model(save=False, device=device, streams=args.streams)
     lib = L.load()
 
     def step():

@@ -237,7 +237,8 @@ __device__ __forceinline__ int g2_nearest(const GridDesc& d, const Grid2& g, flo
 // p / df, `valid` = this half has a query. The result (original index or -1) is returned in
 // every lane of the half.
 __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g, float4 p, int df,
-                                               bool valid, int* __restrict__ overflow) {
+                                               bool valid, int* __restrict__ overflow,
+                                               float* __restrict__ best_dist2 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 31;
   const int half_base = lane & 32;
@@ -329,6 +330,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       if (cand >= 0 && (best < 0 || cd < bestd || (cd == bestd && cand < best))) { best = cand; bestd = cd; }
     }
   }
+  if (best_dist2) *best_dist2 = bestd;
   return best;
 }
 

@@ -49,6 +49,7 @@ struct IcpBufs {
   float* prev;   // [Mn,4] positions before the last applied update
   double* acc;   // [C, kAcc]
   double* Rt;    // [C,12]: R row-major, t
+  double* lossc; // [C] per-component sum |P-Q|^2 of the current iteration
   int32_t* cnt;  // [C] matched moving points in the final coverage query
   int32_t* cur_static;  // [2] allocation cursors of the two static grids
 };
@@ -72,6 +73,7 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<double>(C * kAcc);
   b.Rt = a.take<double>(C * 12);
+  b.lossc = a.take<double>(C);
   b.cnt = a.take<int32_t>(C);
   return a.ok();
 }
@@ -253,21 +255,6 @@ __device__ __forceinline__ void centres(const double* __restrict__ a, double* cm
   }
 }
 
-// sum over the component's pairs of |P - Q|^2 with P = p - cm, Q = q - cr:
-//   sum |p-q|^2 - 2 d . sum(p-q) + n |d|^2,  d = cm - cr
-__device__ __forceinline__ double comp_loss(const double* __restrict__ a) {
-  double n = a[0];
-  if (!(n > 0.5)) return 0.0;
-  double cm[3], cr[3];
-  centres(a, cm, cr);
-  double s = a[16];
-  for (int k = 0; k < 3; ++k) {
-    double d = cm[k] - cr[k];
-    s += -2.0 * d * (a[1 + k] - a[4 + k]) + n * d * d;
-  }
-  return s;
-}
-
 // l1 passes on the positions saved before the last update. MODE 0: sum of dist; MODE 1: sum of
 // dist clamped to mean +- trunc (truncated_robust_mean, registration_utils.py:44-58).
 template <int MODE>
@@ -374,84 +361,102 @@ __device__ inline double det3(const double A[9]) {
          A[2] * (A[3] * A[7] - A[4] * A[6]);
 }
 
-// one thread per component over many 64-thread blocks; block 0 additionally reduces the loss and
-// runs the stop rule. Gating on k vs stop_iter is safe against block 0 finishing early: stop_iter
-// can only drop to k, which still admits iteration k.
+// one thread per component over many 64-thread blocks: rotation, translation, T update and the
+// component's loss term
 __global__ void __launch_bounds__(64)
-icp_solve_kernel(int k, int64_t C, double reg, double delta, const double* __restrict__ acc,
-                 double* __restrict__ T, double* __restrict__ Rt, IcpState* __restrict__ st) {
+icp_solve_kernel(int k, int64_t C, double reg, const double* __restrict__ acc,
+                 double* __restrict__ T, double* __restrict__ Rt, double* __restrict__ lossc,
+                 const IcpState* __restrict__ st) {
   if (k > st->stop_iter) return;
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c < C) {
-    const double* a = acc + c * kAcc;
-    double n = a[0];
-    double cm[3], cr[3];
-    centres(a, cm, cr);
-    double* Tc = T + c * 16;
-    double M[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        // sum P(x)Q = sum p q^T - cm sum q^T - sum p cr^T + n cm cr^T;  robust_mean divides by n
-        double cov = a[7 + i * 3 + j] - cm[i] * a[4 + j] - a[1 + i] * cr[j] + n * cm[i] * cr[j];
-        if (n > 0.5) cov = cov / n; else cov = 0.0;
-        M[i * 3 + j] = cov + Tc[i * 4 + j] * reg;
-      }
-    double U[9], S[3], V[9];
-    svd3(M, U, S, V);
-    double VUt[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
-    double sg = det3(VUt);
-    double R[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
-    double t[3];
-    for (int i = 0; i < 3; ++i)
-      t[i] = cr[i] - (cm[0] * R[i * 3 + 0] + cm[1] * R[i * 3 + 1] + cm[2] * R[i * 3 + 2]);
-    double* rt = Rt + c * 12;
-    for (int i = 0; i < 9; ++i) rt[i] = R[i];
-    for (int i = 0; i < 3; ++i) rt[9 + i] = t[i];
-    double Tn[16];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 4; ++j)
-        Tn[i * 4 + j] = R[i * 3 + 0] * Tc[0 * 4 + j] + R[i * 3 + 1] * Tc[1 * 4 + j] +
-                        R[i * 3 + 2] * Tc[2 * 4 + j] + t[i] * Tc[3 * 4 + j];
-    for (int j = 0; j < 4; ++j) Tn[12 + j] = Tc[12 + j];
-    for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
+  if (c >= C) return;
+  const double* a = acc + c * kAcc;
+  double n = a[0];
+  double cm[3], cr[3];
+  centres(a, cm, cr);
+  double* Tc = T + c * 16;
+  double M[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      // sum P(x)Q = sum p q^T - cm sum q^T - sum p cr^T + n cm cr^T;  robust_mean divides by n
+      double cov = a[7 + i * 3 + j] - cm[i] * a[4 + j] - a[1 + i] * cr[j] + n * cm[i] * cr[j];
+      if (n > 0.5) cov = cov / n; else cov = 0.0;
+      M[i * 3 + j] = cov + Tc[i * 4 + j] * reg;
+    }
+  double U[9], S[3], V[9];
+  svd3(M, U, S, V);
+  double VUt[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
+  double sg = det3(VUt);
+  double R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
+  double t[3];
+  for (int i = 0; i < 3; ++i)
+    t[i] = cr[i] - (cm[0] * R[i * 3 + 0] + cm[1] * R[i * 3 + 1] + cm[2] * R[i * 3 + 2]);
+  double* rt = Rt + c * 12;
+  for (int i = 0; i < 9; ++i) rt[i] = R[i];
+  for (int i = 0; i < 3; ++i) rt[9 + i] = t[i];
+  double Tn[16];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j)
+      Tn[i * 4 + j] = R[i * 3 + 0] * Tc[0 * 4 + j] + R[i * 3 + 1] * Tc[1 * 4 + j] +
+                      R[i * 3 + 2] * Tc[2 * 4 + j] + t[i] * Tc[3 * 4 + j];
+  for (int j = 0; j < 4; ++j) Tn[12 + j] = Tc[12 + j];
+  for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
+  // sum |P - Q|^2 = sum |p-q|^2 - 2 d . sum(p-q) + n |d|^2,  d = cm - cr
+  double ls = 0.0;
+  if (n > 0.5) {
+    ls = a[16];
+    for (int q = 0; q < 3; ++q) {
+      double d = cm[q] - cr[q];
+      ls += -2.0 * d * (a[1 + q] - a[4 + q]) + n * d * d;
+    }
+  }
+  lossc[c] = ls;
+}
+
+// apply iteration k's (R, t) to every moving point (the previous positions are kept for the l1
+// passes). Block 0 also reduces the per-component losses (fixed tree) and runs the loss-delta /
+// 3-strike stop rule: it may lower stop_iter to k, which still admits every kernel of iteration k.
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
+                 const int32_t* __restrict__ comp, const double* __restrict__ Rt,
+                 const double* __restrict__ lossc, int64_t C, double delta,
+                 IcpState* __restrict__ st) {
+  if (k > st->stop_iter) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Mn) {
+    float4 p = mov[i];
+    prev[i] = p;
+    const double* rt = Rt + (int64_t)comp[i] * 12;
+    double x = p.y, y = p.z, z = p.w;
+    float nx = (float)(x * rt[0] + y * rt[1] + z * rt[2] + rt[9]);
+    float ny = (float)(x * rt[3] + y * rt[4] + z * rt[5] + rt[10]);
+    float nz = (float)(x * rt[6] + y * rt[7] + z * rt[8] + rt[11]);
+    mov[i] = make_float4(p.x, nx, ny, nz);
   }
   if (blockIdx.x == 0) {
+    __shared__ double red[kBlock / 64];
     double part = 0.0;
-    for (int64_t q = threadIdx.x; q < C; q += 64) part += comp_loss(acc + q * kAcc);
-    double loss = wave_sum_f64(part);
+    for (int64_t q = threadIdx.x; q < C; q += kBlock) part += lossc[q];
+    part = wave_sum_f64(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
     if (threadIdx.x == 0) {
+      double loss = 0.0;
+      for (int q = 0; q < kBlock / 64; ++q) loss += red[q];
       st->loss = loss;
       st->iters = k;
       if (st->last_error - loss < delta) st->countdown -= 1;
       else st->countdown = 3;
-      if (st->countdown <= 0) st->stop_iter = k;  // this iteration's update is still applied
+      if (st->countdown <= 0) st->stop_iter = k;
       else st->last_error = loss;
     }
   }
-}
-
-// apply iteration k's (R, t) to every moving point; keeps the previous positions for the l1 passes
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
-                 const int32_t* __restrict__ comp, const double* __restrict__ Rt,
-                 const IcpState* __restrict__ st) {
-  if (k > st->stop_iter) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Mn) return;
-  float4 p = mov[i];
-  prev[i] = p;
-  const double* rt = Rt + (int64_t)comp[i] * 12;
-  double x = p.y, y = p.z, z = p.w;
-  float nx = (float)(x * rt[0] + y * rt[1] + z * rt[2] + rt[9]);
-  float ny = (float)(x * rt[3] + y * rt[4] + z * rt[5] + rt[10]);
-  float nz = (float)(x * rt[6] + y * rt[7] + z * rt[8] + rt[11]);
-  mov[i] = make_float4(p.x, nx, ny, nz);
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
@@ -633,10 +638,9 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       icp_moments_kernel<<<nb_e, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
                                                  (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
                                                  b.nn_b, b.state, b.acc);
-      icp_solve_kernel<<<nb_c, 64, 0, s>>>(k, C, angle_regularizer, stopping_delta, b.acc, T, b.Rt,
-                                           b.state);
+      icp_solve_kernel<<<nb_c, 64, 0, s>>>(k, C, angle_regularizer, b.acc, T, b.Rt, b.lossc, b.state);
       icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
-                                               mov_comp, b.Rt, b.state);
+                                               mov_comp, b.Rt, b.lossc, C, stopping_delta, b.state);
     }
     it += n_it;
     PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));

@@ -22,7 +22,7 @@
 //  2. pcs_hash_insert / pcs_radius_graph_table_*: literal drop-ins for the reference's
 //     torch_hash_cuda entry points on the reference's own table layout (keys/values/reverse,
 //     caller-allocated), for callers that bind at the pcdet/ops/torch_hash level.
-#include "pcs_grid.hpp"
+#include "pcs_grid2.hpp"
 
 namespace pcs {
 
@@ -123,6 +123,24 @@ radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ 
   }
 }
 
+// max_nbr == 1, sorted: the two-level grid + 32-lanes-per-query search of the fused ICP
+__global__ void __launch_bounds__(kBlock)
+nn1_search_kernel(const float4* __restrict__ qry, int M, const GridDesc* __restrict__ gp, Grid2 g,
+                  int df, int32_t* __restrict__ err, int32_t* __restrict__ nbr_idx,
+                  float* __restrict__ nbr_d, int32_t* __restrict__ deg) {
+  GridDesc d = *gp;
+  int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  bool valid = qid < M;
+  float4 p = valid ? qry[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float bd = 0.f;
+  int r = g2_nearest_coop(d, g, p, df, valid, err, &bd);
+  if (valid && (threadIdx.x & 31) == 0) {
+    deg[qid] = r >= 0;
+    nbr_idx[qid] = r;
+    nbr_d[qid] = bd;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 edge_total_kernel(const int32_t* __restrict__ deg, const int32_t* __restrict__ off, int M,
                   const int32_t* __restrict__ err, int64_t* __restrict__ d_num) {
@@ -154,6 +172,8 @@ struct RadiusPlan {
   uint64_t* keys;
   int32_t *head, *next, *nbr_idx, *deg, *off, *err;
   float *nbr_d, *fr;
+  Grid2 g2;          // max_nbr == 1 path
+  int32_t* g2_words; // [0] cursor, [1] "stop" word (INT_MAX: the gated grid kernels always run)
   void* tmp;
   size_t tmp_bytes;
   uint32_t H;
@@ -183,6 +203,10 @@ static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
   p.off = a.take<int32_t>(M);
   p.tmp_bytes = scan_i32_temp_bytes(M);
   p.tmp = a.take<char>(p.tmp_bytes);
+  if (K == 1) {
+    plan_grid2(a, N, p.g2);
+    p.g2_words = a.take<int32_t>(2);
+  }
   return a.ok();
 }
 
@@ -319,7 +343,10 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
   Arena a(ws, ws_bytes);
   RadiusPlan p;
   if (!plan_radius(a, N, M, K, p)) return PCS_ERR_WORKSPACE;
-  float cell = cell_size > 0.f ? cell_size : radius * 0.5f;
+  // cell_size > 0: fine cell; for max_nbr == 1 (sorted, one frame offset) it selects the two-level
+  // grid, which needs cell_size >= (spatial radius) / 4. cell_size < 0: |cell_size| on the general
+  // engine whatever max_nbr is. 0: radius / 2 on the general engine.
+  float cell = cell_size != 0.f ? fabsf(cell_size) : radius * 0.5f;
   if (cell > radius) cell = radius;
   int rc = pcs_minmax4_f32(ref, N, p.b_ref, s);
   if (rc) return rc;
@@ -329,6 +356,27 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
   PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
   PCS_CHECK_HIP(hipMemsetAsync(p.head, 0xFF, (size_t)p.H * sizeof(int32_t), s));
   PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
+  if (K == 1 && sort_by_dist && dframe_min == dframe_max && cell_size > 0.f) {
+    // cell_size must be (spatial radius) / 4 or more so that the 3x3x3 coarse blocks cover the ball;
+    // if the data say otherwise the search raises the overflow flag and *d_num_edges becomes -1
+    static const int32_t words[2] = {0, 0x7fffffff};
+    PCS_CHECK_HIP(hipMemcpyAsync(p.g2_words, words, sizeof(words), hipMemcpyHostToDevice, s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.g2.ff_begin, 0xFF, p.g2.ff_bytes, s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.g2.z_begin, 0, p.g2.z_bytes, s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
+    frame_range_init_kernel<<<4, kBlock, 0, s>>>(p.g2.fr);
+    int nb = (int)((N + kBlock - 1) / kBlock);
+    g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, p.g2_words + 1, p.err);
+    g2_alloc_kernel<<<(int)((p.g2.Hf + kBlock - 1) / kBlock), kBlock, 0, s>>>(p.g2, 0, p.g2_words + 1, p.g2_words);
+    g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.g2, 0, p.g2_words + 1);
+    nn1_search_kernel<<<(int)((M * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        (const float4*)query, (int)M, p.grid, p.g2, dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg);
+    rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
+    if (rc) return rc;
+    edge_total_kernel<<<1, 64, 0, s>>>(p.deg, p.off, (int)M, p.err, d_num_edges);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   uint32_t hmask = p.H - 1;
   frame_range_init_kernel<<<4, kBlock, 0, s>>>(p.fr);
   grid_insert_kernel<<<(int)((N + kBlock - 1) / kBlock), kBlock, 0, s>>>(

@@ -270,7 +270,8 @@ struct IrlsState {
   int pad;
 };
 
-constexpr int kIrlsAcc = 12;  // sum w, sum w x (3), sum w x x^T (6: xx xy xz yy yz zz), count, pad
+constexpr int kIrlsAcc = 12;
+constexpr int kIrlsSlots = 16;  // sum w, sum w x (3), sum w x x^T (6: xx xy xz yy yz zz), count, pad
 
 __global__ void irls_init_kernel(IrlsState* st, double* acc, int64_t P) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -287,6 +288,11 @@ irls_accumulate_kernel(int r, const float* __restrict__ xyz, const int64_t* __re
                        float* __restrict__ perr, double* __restrict__ acc,
                        IrlsState* __restrict__ st) {
   if (r > st->stop_round) return;
+  __shared__ int skey[kIrlsSlots];
+  __shared__ double sacc[kIrlsSlots][11];
+  for (int q = threadIdx.x; q < kIrlsSlots; q += kBlock) skey[q] = -1;
+  for (int q = threadIdx.x; q < kIrlsSlots * 11; q += kBlock) (&sacc[0][0])[q] = 0.0;
+  __syncthreads();
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool active = i < n;
   int c = 0;
@@ -322,22 +328,29 @@ irls_accumulate_kernel(int r, const float* __restrict__ xyz, const int64_t* __re
   }
   float mx = wave_max(dw);
   if ((threadIdx.x & 63) == 0 && r > 1) atomicMax(&st->max_dw_bits, __float_as_uint(mx));
-  // same machinery as the ICP: lanes sharing a pillar are combined before the atomics
-  {
-    int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-      int leader = __ffsll((long long)todo) - 1;
-      int lkey = __shfl(c, leader, 64);
-      bool mine = active && c == lkey;
-      unsigned long long grp = __ballot(mine);
-#pragma unroll
-      for (int q = 0; q < 11; ++q) {
-        double xsum = wave_sum_f64(mine ? v[q] : 0.0);
-        if (lane == leader) atomicAdd(&acc[(int64_t)lkey * kIrlsAcc + q], xsum);
-      }
-      todo &= ~grp;
+  // per-workgroup LDS table keyed by pillar (voxels are sorted by pillar: a workgroup sees one or
+  // two pillars), flushed with one global f64 atomic per (pillar, accumulator)
+  int found = -1;
+  if (active) {
+    int slot = (int)(((unsigned)c * 2654435761u) >> 28) & (kIrlsSlots - 1);
+    for (int t = 0; t < kIrlsSlots; ++t) {
+      int old = atomicCAS(&skey[slot], -1, c);
+      if (old == -1 || old == c) { found = slot; break; }
+      slot = (slot + 1) & (kIrlsSlots - 1);
     }
+    if (found >= 0) {
+#pragma unroll
+      for (int q = 0; q < 11; ++q) atomicAdd(&sacc[found][q], v[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 11; ++q) atomicAdd(&acc[(int64_t)c * kIrlsAcc + q], v[q]);
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < kIrlsSlots * 11; q += kBlock) {
+    int sl = q / 11, a = q - sl * 11;
+    int key = skey[sl];
+    if (key >= 0) atomicAdd(&acc[(int64_t)key * kIrlsAcc + a], sacc[sl][a]);
   }
 }
 

@@ -239,6 +239,15 @@ def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, dframe_min=0, d
                                         L.ptr(ws), L.i64(ws.numel()), L.stream()),
             "pcs_radius_graph_search")
     E = int(d_num.item())
+    if E < 0 and max_nbr == 1 and cell_size > 0:
+        # the two-level 1-NN grid did not cover the search ball with this cell size: general engine
+        cell_size = -float(cell_size)
+        L.check(lib.pcs_radius_graph_search(L.ptr(ref), L.i64(N), L.ptr(query), L.i64(M), L.f32(radius),
+                                            L.f32(cell_size), L.i32(dframe_min), L.i32(dframe_max),
+                                            L.i32(max_nbr), L.i32(int(sort_by_dist)), L.ptr(d_num),
+                                            L.ptr(ws), L.i64(ws.numel()), L.stream()),
+                "pcs_radius_graph_search")
+        E = int(d_num.item())
     if E < 0:
         raise L.PcsError("radius_graph: extent / cell_size exceeds the 17-bit cell range")
     e_ref = torch.empty(E, dtype=torch.int64, device=dev)

@@ -52,7 +52,8 @@ class RadiusGraph(nn.Module):
             # spatial radius without the frame-offset term
             df = max(abs(qmin[0]), abs(qmax[0]))
             r_xyz = max(radius * radius - df * df, 1e-6) ** 0.5
-            cell = r_xyz / 2 if self.max_num_neighbors > 1 else r_xyz / 4
+            # 1-NN: the two-level grid wants (largest admissible spatial distance) / 4
+            cell = r_xyz / 2 if self.max_num_neighbors > 1 else (r_xyz * r_xyz + 3e-5 * radius * radius + 3e-6) ** 0.5 / 4 * 1.0005
         e_ref, e_query = ops.radius_graph(ref_bxyz, query_bxyz, radius, self.max_num_neighbors,
                                           self.sort_by_dist, qmin[0], qmax[0], cell_size=cell)
         return e_ref, e_query, None
