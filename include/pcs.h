@@ -220,6 +220,52 @@ int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C
                     int frame_lo, int frame_hi, float weight0, float weight, int num_itr,
                     float stopping, void* ws, size_t ws_bytes, pcs_stream_t stream);
 
+/* ClusterTracking.track_frame, pcdet/models/registration/preprocessors/cluster_tracking.py:430-787
+ * (with sample_frame :39-51, component_center / component_diameter / filter_components :89-160,
+ * dist_compensate :80-87, smooth_velo :162-199 and the harvest through NN_GRAPH :702-741): tracks
+ * the components of one anchor frame backward and forward through the sequence. The whole loop
+ * runs inside this call on `stream` (BLOCKING: it reads a few words per step), so independent
+ * anchors / component keys can be driven from independent host threads.
+ *   seq_fxyz [N,4] f32, seq_component [N] int64, seq_stationary [N] uint8: the sub-sampled
+ *     sequence, rows grouped by ascending frame; frame_offsets: HOST [num_frames+1] row ranges.
+ *   anchor_frame, [min_frame_id, max_frame_id]: the anchor and the window to track through.
+ *   comp_base: subtracted from the anchor rows' component ids (the caller's `component.min()`);
+ *   C: number of (re-based) components.
+ *   outputs: ex_index / ex_local / ex_component [ex_cap] int64 = extracted rows as (row in the
+ *     sequence, row within its frame, component), anchor rows first, then per visited frame in
+ *     visiting order; transforms [C, W, 4, 4] f64 with W = max_frame_id - min_frame_id + 1;
+ *     reg_errors, comp_edge_ratios [C, F] f32 and comp_velos [C, F, 3] f32 with F = max_frame_id + 1;
+ *     comp_min_frame_id / comp_max_frame_id [C] int64; moving, valid_comp [C] uint8 (valid_comp =
+ *     filter_components of the anchor). info: HOST int64[4] = {rows extracted, registration calls,
+ *     frame steps, 0}. Returns PCS_ERR_RANGE when a search grid overflowed (caller falls back to
+ *     the op-by-op host path). */
+#define PCS_TRACK_MAX_LEVELS 4
+typedef struct PcsTrackParams {
+  int32_t num_levels;      /* REGISTRATION.GRAPH.RADIUS / VOXEL_SIZE / STOPPING_DELTA entries */
+  int32_t max_iter;        /* register_to_next_frame max_iter (80 in track_frame) */
+  int32_t min_move_frame;  /* TRACKING_PARAMS.MIN_MOVE_FRAME */
+  int32_t smooth_num_itr;  /* smooth_velo num_itr (300) */
+  double radius[PCS_TRACK_MAX_LEVELS];
+  double stopping_delta[PCS_TRACK_MAX_LEVELS];
+  double angle_regularizer;
+  float voxel_size[PCS_TRACK_MAX_LEVELS][3];
+  float nn_radius;         /* NN_GRAPH.RADIUS */
+  float reg_error_coeff;   /* TRACKING_PARAMS.REGISTRATION_ERROR_COEFFICIENT */
+  float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
+  float max_diameter;      /* filter_components max_diameter (12.5) */
+  float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
+} PcsTrackParams;
+size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
+                                       int num_frames);
+int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* seq_component,
+                    const uint8_t* seq_stationary, const int64_t* frame_offsets, int num_frames,
+                    int anchor_frame, int min_frame_id, int max_frame_id, int64_t comp_base,
+                    int64_t C, int64_t* ex_index, int64_t* ex_local, int64_t* ex_component,
+                    int64_t ex_cap, double* transforms, float* reg_errors, float* comp_edge_ratios,
+                    float* comp_velos, int64_t* comp_min_frame_id, int64_t* comp_max_frame_id,
+                    uint8_t* moving, uint8_t* valid_comp, int64_t* info, void* ws, size_t ws_bytes,
+                    pcs_stream_t stream);
+
 /* points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168 (evaluation
  * side-channel of ClusterProposal / ClusterTracking): points [N,3], boxes [B,7]
  * (x,y,z,dx,dy,dz,heading) -> out [B,N] int32. */
@@ -243,6 +289,10 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
  * {milliseconds, launches, algorithmic bytes}. */
 int pcs_profile_icp_nn(int enable);
 int pcs_profile_icp_nn_read(double* out3);
+
+/* Diagnostic: enqueue `n` one-wave no-op kernels on `stream` (host launch-rate probe used by
+ * tools/launch_scaling.py; no reference counterpart). */
+int pcs_profile_launch_loop(int64_t n, pcs_stream_t stream);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per

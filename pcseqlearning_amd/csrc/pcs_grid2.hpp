@@ -230,12 +230,33 @@ __device__ __forceinline__ int g2_nearest(const GridDesc& d, const Grid2& g, flo
   return best;
 }
 
-// Cooperative form: the 32 lanes of a half-wave serve ONE query (two queries per wave). The cells
-// of a ring are dealt to the lanes, so rings 0+1 (27 cells) cost one round of memory latency
-// instead of 27 serial ones, and a query without a partner walks its 9x9x9 cube in a few dozen
-// rounds. Every lane of the wave must call this (shuffles); the lanes of a half pass the same
-// p / df, `valid` = this half has a query. The result (original index or -1) is returned in
-// every lane of the half.
+// bits of coarse block (X,Y,Z) whose fine cells lie within Chebyshev distance s of cell (cx,cy,cz)
+__device__ __forceinline__ uint64_t g2_box_mask(int X, int Y, int Z, int cx, int cy, int cz, int s) {
+  int x0 = max(cx - s - 4 * X, 0), x1 = min(cx + s - 4 * X, 3);
+  int y0 = max(cy - s - 4 * Y, 0), y1 = min(cy + s - 4 * Y, 3);
+  int z0 = max(cz - s - 4 * Z, 0), z1 = min(cz + s - 4 * Z, 3);
+  if (x0 > x1 || y0 > y1 || z0 > z1) return 0;
+  unsigned xb = ((1u << (x1 - x0 + 1)) - 1u) << x0;
+  unsigned yb = ((1u << (y1 - y0 + 1)) - 1u) << y0;
+  unsigned zb = ((1u << (z1 - z0 + 1)) - 1u) << z0;
+  unsigned ys = (yb & 1u) | ((yb & 2u) << 3) | ((yb & 4u) << 6) | ((yb & 8u) << 9);  // bits 0,4,8,12
+  unsigned row16 = xb * ys;
+  uint64_t zs = (uint64_t)(zb & 1u) | ((uint64_t)(zb & 2u) << 15) | ((uint64_t)(zb & 4u) << 30) |
+                ((uint64_t)(zb & 8u) << 45);                                         // bits 0,16,32,48
+  return (uint64_t)row16 * zs;
+}
+
+// Cooperative form: the 32 lanes of a half-wave serve ONE query (two queries per wave).
+//   1. lanes 0..26 fetch the occupancy masks of the 3x3x3 coarse blocks around the query;
+//   2. the 27 fine cells at Chebyshev distance <= 1 are dealt to 27 lanes (one round of memory
+//      latency); most queries have their partner there and stop: everything else is >= h away;
+//   3. otherwise every lane walks the OCCUPIED cells of its own block (set bits of its mask), each
+//      pruned by its per-axis distance bound against the best found so far -- empty space costs
+//      nothing, cells outside the ball cost a few ALU ops and no memory access.
+// Pruning is conservative only: the result is the exact nearest point within the radius under the
+// canonical order (dist2, original index), whatever the traversal order. Every lane of the wave
+// must call this (shuffles); the lanes of a half pass the same p / df, `valid` = this half has a
+// query. The result (original index or -1) is returned in every lane of the half.
 __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g, float4 p, int df,
                                                bool valid, int* __restrict__ overflow,
                                                float* __restrict__ best_dist2 = nullptr) {
@@ -259,8 +280,8 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
   // lanes 0..26 of the half fetch one coarse occupancy mask each
   uint64_t mymask = 0;
+  int X = bx + sub % 3 - 1, Y = by + (sub / 3) % 3 - 1, Z = bz + sub / 9 - 1;
   if (valid && sub < 27) {
-    int X = bx + sub % 3 - 1, Y = by + (sub / 3) % 3 - 1, Z = bz + sub / 9 - 1;
     if (X >= 0 && Y >= 0 && Z >= 0) {
       int cs = g2_find(g.ckeys, g.Hc - 1, pack_cell(fc, X, Y, Z));
       if (cs >= 0) mymask = g.cmask[cs];
@@ -268,70 +289,74 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   }
   unsigned long long occ = __ballot(mymask != 0);
   valid = valid && ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
-  int best = -1;
-  float bestd = d.radius2;
-  for (int s = 1; s <= 4; ++s) {
-    // stage s: cells at Chebyshev distance s (stage 1 also takes the centre cell)
-    bool on = valid && (s == 1 || s <= rings);
-    if (on && s >= 2) {
-      float lb = (float)(s - 1) * d.h;
-      on = !(lb * lb > bestd - dfsq + margin);
+  int cand = -1;
+  float cd = 0.f;
+  auto scan_cell = [&](int x, int y, int z) {
+    int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
+    if (fs < 0) return;
+    int b = g.fstart[fs], e = b + g.fcount[fs];
+    for (int j = b; j < e; ++j) {
+      float4 c = g.spts[j];
+      float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+      float dist2 = 0.f;
+      dist2 = dist2 + d0 * d0;
+      dist2 = dist2 + d1 * d1;
+      dist2 = dist2 + d2 * d2;
+      dist2 = dist2 + d3 * d3;
+      if (dist2 <= d.radius2) {
+        int oi = g.sidx[j];
+        if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
+      }
     }
-    int side = 2 * s + 1, hs = s;
-    int total = on ? side * side * side : 0;
-    int tot_o = __shfl_xor(total, 32, 64);
-    int trips = ((total > tot_o ? total : tot_o) + 31) >> 5;  // same for both halves of the wave
-    for (int r = 0; r < trips; ++r) {
-      int idx = r * 32 + sub;
-      bool cell_on = idx < total;
-      int x = cx, y = cy, z = cz;
-      if (cell_on) {
-        int dx = idx % side - hs, dy = (idx / side) % side - hs, dz = idx / (side * side) - hs;
-        int cheb = max(max(abs(dx), abs(dy)), abs(dz));
-        cell_on = (cheb == s) || (s == 1);
-        x += dx; y += dy; z += dz;
-      }
-      int q = cell_on ? ((x >> 2) - bx + 1) + 3 * ((y >> 2) - by + 1) + 9 * ((z >> 2) - bz + 1) : 0;
-      unsigned lo32 = __shfl((unsigned)(mymask & 0xFFFFFFFFULL), half_base + q, 64);
-      unsigned hi32 = __shfl((unsigned)(mymask >> 32), half_base + q, 64);
-      uint64_t mk = ((uint64_t)hi32 << 32) | lo32;
-      int cand = -1;
-      float cd = 0.f;
-      if (cell_on) {
-        int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
-        if ((mk >> bit) & 1ULL) {
-          int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
-          if (fs >= 0) {
-            int b = g.fstart[fs], e = b + g.fcount[fs];
-            for (int j = b; j < e; ++j) {
-              float4 c = g.spts[j];
-              float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
-              float dist2 = 0.f;
-              dist2 = dist2 + d0 * d0;
-              dist2 = dist2 + d1 * d1;
-              dist2 = dist2 + d2 * d2;
-              dist2 = dist2 + d3 * d3;
-              if (dist2 <= d.radius2) {
-                int oi = g.sidx[j];
-                if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
-              }
-            }
-          }
-        }
-      }
-      // best of the half's 32 lanes: (dist2, index) ascending, -1 = none
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        int oc = __shfl_xor(cand, o, 64);
-        float od = __shfl_xor(cd, o, 64);
-        bool take = oc >= 0 && (cand < 0 || od < cd || (od == cd && oc < cand));
-        if (take) { cand = oc; cd = od; }
-      }
-      if (cand >= 0 && (best < 0 || cd < bestd || (cd == bestd && cand < best))) { best = cand; bestd = cd; }
+  };
+  // ---- near cells: Chebyshev distance <= 1, one cell per lane
+  {
+    bool cell_on = valid && sub < 27;
+    int x = cx + sub % 3 - 1, y = cy + (sub / 3) % 3 - 1, z = cz + sub / 9 - 1;
+    int q = cell_on ? ((x >> 2) - bx + 1) + 3 * ((y >> 2) - by + 1) + 9 * ((z >> 2) - bz + 1) : 0;
+    unsigned lo32 = __shfl((unsigned)(mymask & 0xFFFFFFFFULL), half_base + q, 64);
+    unsigned hi32 = __shfl((unsigned)(mymask >> 32), half_base + q, 64);
+    uint64_t mk = ((uint64_t)hi32 << 32) | lo32;
+    if (cell_on) {
+      int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
+      if ((mk >> bit) & 1ULL) scan_cell(x, y, z);
     }
   }
-  if (best_dist2) *best_dist2 = bestd;
-  return best;
+  // best of the half so far (needed to decide whether the far cells can matter)
+  auto reduce_half = [&]() {
+    if (__ballot(cand >= 0) == 0) return;  // nothing found anywhere in the wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      int oc = __shfl_xor(cand, o, 64);
+      float od = __shfl_xor(cd, o, 64);
+      bool take = oc >= 0 && (cand < 0 || od < cd || (od == cd && oc < cand));
+      if (take) { cand = oc; cd = od; }
+    }
+  };
+  reduce_half();
+  // ---- far cells: everything at Chebyshev distance >= 2 is at least h away
+  float bound = (cand >= 0 ? cd : d.radius2) - dfsq + margin;  // admissible |dxyz|^2 of a better point
+  bool more = valid && rings >= 2 && !(d.h * d.h > bound);
+  uint64_t rem = 0;
+  if (more && sub < 27) rem = mymask & ~g2_box_mask(X, Y, Z, cx, cy, cz, 1);
+  if (__ballot(rem != 0)) {
+    const float h2 = d.h * d.h;
+    while (__ballot(rem != 0)) {
+      if (rem) {
+        int bit = __ffsll((long long)rem) - 1;
+        rem &= rem - 1;
+        int x = 4 * X + (bit & 3), y = 4 * Y + ((bit >> 2) & 3), z = 4 * Z + (bit >> 4);
+        float ax = (float)max(abs(x - cx) - 1, 0), ay = (float)max(abs(y - cy) - 1, 0),
+              az = (float)max(abs(z - cz) - 1, 0);
+        float lb2 = ((ax * ax + ay * ay) + az * az) * h2;
+        float bnd = (cand >= 0 ? cd : d.radius2) - dfsq + margin;
+        if (!(lb2 > bnd)) scan_cell(x, y, z);
+      }
+    }
+    reduce_half();
+  }
+  if (best_dist2) *best_dist2 = cand >= 0 ? cd : d.radius2;
+  return cand;
 }
 
 }  // namespace pcs

@@ -27,6 +27,9 @@
 
 namespace pcs {
 
+__global__ void noop_kernel() {}
+
+
 struct IcpState {
   double last_error;
   double loss;
@@ -510,6 +513,12 @@ int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
 
 // bench.py support: time icp_nn_kernel with HIP events on the launch stream (any number of host
 // threads / streams; totals are accumulated under a mutex).
+int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
+  for (int64_t i = 0; i < n; ++i) pcs::noop_kernel<<<1, 64, 0, s>>>();
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 int pcs_profile_icp_nn(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;

@@ -210,6 +210,20 @@ static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
   return a.ok();
 }
 
+// view of the 1-NN search result left in `ws` by pcs_radius_graph_search(max_nbr = 1): per query
+// the neighbour index (nbr_idx, valid where deg == 1) -- used by the native tracker
+// (pcs_tracker.hip), which filters the edges on the device instead of emitting them
+int radius_nn1_view(int64_t N, int64_t M, void* ws, size_t ws_bytes, const int32_t** nbr_idx,
+                    const int32_t** deg, const int32_t** err) {
+  Arena a(ws, ws_bytes);
+  RadiusPlan p;
+  if (!plan_radius(a, N, M, 1, p)) return PCS_ERR_WORKSPACE;
+  *nbr_idx = p.nbr_idx;
+  *deg = p.deg;
+  *err = p.err;
+  return PCS_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Literal torch_hash drop-ins on the reference table layout
 // (keys[H] i64 = -1 empty, values[H,D] f32, reverse[H] i64; H = int(N / 0.5) chosen by the caller).

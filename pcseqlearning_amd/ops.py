@@ -442,3 +442,97 @@ def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_de
                                    L.ptr(perr), ctypes.c_void_p(0), L.ptr(ws), L.i64(ws.numel()),
                                    L.stream()), "pcs_irls_plane_fit")
     return plane[:, :3], plane[:, 3:], perr
+
+
+# ---------------------------------------------------------------- native tracker
+class TrackParams(__import__("ctypes").Structure):
+    """Mirror of PcsTrackParams (include/pcs.h)."""
+    import ctypes as _c
+    _fields_ = [
+        ("num_levels", _c.c_int32), ("max_iter", _c.c_int32), ("min_move_frame", _c.c_int32),
+        ("smooth_num_itr", _c.c_int32),
+        ("radius", _c.c_double * 4), ("stopping_delta", _c.c_double * 4),
+        ("angle_regularizer", _c.c_double),
+        ("voxel_size", (_c.c_float * 3) * 4),
+        ("nn_radius", _c.c_float), ("reg_error_coeff", _c.c_float), ("angle_threshold", _c.c_float),
+        ("max_diameter", _c.c_float), ("smooth_weight0", _c.c_float), ("smooth_weight", _c.c_float),
+        ("smooth_stopping", _c.c_float),
+    ]
+
+
+def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
+                 reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
+                 smooth=(1.0, 10.0, 300, 1e-3)):
+    prm = TrackParams()
+    L_ = len(radius_list)
+    if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
+        raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")
+    prm.num_levels = L_
+    prm.max_iter = int(max_iter)
+    prm.min_move_frame = int(min_move_frame)
+    prm.smooth_num_itr = int(smooth[2])
+    for i in range(L_):
+        prm.radius[i] = float(radius_list[i])
+        prm.stopping_delta[i] = float(stopping_delta[i])
+        for k in range(3):
+            prm.voxel_size[i][k] = float(voxel_size_list[i][k])
+    prm.angle_regularizer = float(angle_regularizer)
+    prm.nn_radius = float(nn_radius)
+    prm.reg_error_coeff = float(reg_error_coeff)
+    prm.angle_threshold = float(angle_threshold)
+    prm.max_diameter = float(max_diameter)
+    prm.smooth_weight0, prm.smooth_weight, prm.smooth_stopping = float(smooth[0]), float(smooth[1]), float(smooth[3])
+    return prm
+
+
+def track_frame(prm, seq_fxyz, seq_component, seq_stationary, frame_offsets, anchor_frame,
+                min_frame_id, max_frame_id, comp_base, num_components):
+    """ClusterTracking.track_frame in one native call (pcs_track_frame). `frame_offsets`: host list
+    [num_frames + 1] of row ranges of the frame-grouped sequence. Returns a dict of tensors
+    (ex_index / ex_local / ex_component already cut to the extracted count) and the info triple."""
+    import ctypes
+    L.require_gpu(seq_fxyz, "track_frame")
+    lib = L.load()
+    dev = seq_fxyz.device
+    assert seq_fxyz.is_contiguous() and seq_fxyz.dtype == torch.float32 and seq_fxyz.shape[1] == 4
+    comp = seq_component.long().contiguous()
+    stat = seq_stationary.to(torch.uint8).contiguous()
+    nf = len(frame_offsets) - 1
+    offs = (ctypes.c_int64 * (nf + 1))(*[int(v) for v in frame_offsets])
+    C = int(num_components)
+    F = max_frame_id + 1
+    W = max_frame_id - min_frame_id + 1
+    sizes = [frame_offsets[f + 1] - frame_offsets[f] for f in range(min_frame_id, max_frame_id + 1)]
+    na = frame_offsets[anchor_frame + 1] - frame_offsets[anchor_frame]
+    nmax = max([1] + [frame_offsets[f + 1] - frame_offsets[f]
+                      for f in range(min_frame_id, max_frame_id + 1) if f != anchor_frame])
+    cap = int(sum(sizes))
+    out = dict(
+        ex_index=torch.empty(cap, dtype=torch.int64, device=dev),
+        ex_local=torch.empty(cap, dtype=torch.int64, device=dev),
+        ex_component=torch.empty(cap, dtype=torch.int64, device=dev),
+        transforms=torch.empty(C, W, 4, 4, dtype=torch.float64, device=dev),
+        reg_errors=torch.empty(C, F, dtype=torch.float32, device=dev),
+        comp_edge_ratios=torch.empty(C, F, dtype=torch.float32, device=dev),
+        comp_velos=torch.empty(C, F, 3, dtype=torch.float32, device=dev),
+        comp_min_frame_id=torch.empty(C, dtype=torch.int64, device=dev),
+        comp_max_frame_id=torch.empty(C, dtype=torch.int64, device=dev),
+        moving=torch.empty(C, dtype=torch.uint8, device=dev),
+        valid_comp=torch.empty(C, dtype=torch.uint8, device=dev),
+    )
+    info = (ctypes.c_int64 * 4)()
+    ws = L.workspace(lib.pcs_track_frame_workspace_bytes(L.i64(na), L.i64(nmax), L.i64(C), L.i32(F)), dev)
+    L.check(lib.pcs_track_frame(
+        ctypes.byref(prm), L.ptr(seq_fxyz), L.ptr(comp), L.ptr(stat), offs, L.i32(nf),
+        L.i32(anchor_frame), L.i32(min_frame_id), L.i32(max_frame_id), L.i64(comp_base), L.i64(C),
+        L.ptr(out["ex_index"]), L.ptr(out["ex_local"]), L.ptr(out["ex_component"]), L.i64(cap),
+        L.ptr(out["transforms"]), L.ptr(out["reg_errors"]), L.ptr(out["comp_edge_ratios"]),
+        L.ptr(out["comp_velos"]), L.ptr(out["comp_min_frame_id"]), L.ptr(out["comp_max_frame_id"]),
+        L.ptr(out["moving"]), L.ptr(out["valid_comp"]), info, L.ptr(ws), L.i64(ws.numel()),
+        L.stream()), "pcs_track_frame")
+    n_ex = int(info[0])
+    for k in ("ex_index", "ex_local", "ex_component"):
+        out[k] = out[k][:n_ex]
+    out["moving"] = out["moving"].bool()
+    out["valid_comp"] = out["valid_comp"].bool()
+    return out, (n_ex, int(info[1]), int(info[2]))

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
+from .....lib import PcsError
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
@@ -127,6 +128,9 @@ class ClusterTracking(nn.Module):
         self.component_keys = model_cfg["COMPONENT_KEYS"]
         self.verbose = bool((runtime_cfg or {}).get("verbose", False))
         self.num_registration_calls = 0
+        # NATIVE_TRACKER: run track_frame's loop in pcs_track_frame (default) or op by op
+        self.native = bool(model_cfg.get("NATIVE_TRACKER", True))
+        self._track_params = None
 
     # ------------------------------------------------------------------ boxes
     def format_boxes(self, seq_dict, num_frames):
@@ -213,7 +217,86 @@ class ClusterTracking(nn.Module):
     # ------------------------------------------------------------------ tracking of one anchor
     def track_frame(self, seq_points, frame, seq_boxes):
         """Track the components of anchor frame `frame` through `seq_points` within
-        +-TRACK_INTERVAL frames (cluster_tracking.py:430-787)."""
+        +-TRACK_INTERVAL frames (cluster_tracking.py:430-787).
+
+        When the sequence rows are grouped by frame (`seq_points.frame_offsets`, set by forward)
+        the whole loop runs in one native call (pcs_track_frame, GIL released, one HIP stream);
+        `track_frame_host` is the same loop op by op on the same kernels (bit-identical ids) and
+        is the fallback when the rows are not grouped or a search grid overflows."""
+        offsets = seq_points.get("frame_offsets", None) if self.native else None
+        if offsets is not None and seq_points.fxyz.is_cuda:
+            try:
+                return self._track_frame_native(seq_points, frame, offsets)
+            except PcsError as err:
+                if "PCS_ERR_RANGE" not in str(err):
+                    raise
+        return self.track_frame_host(seq_points, frame, seq_boxes)
+
+    @staticmethod
+    def frame_offsets_of(frame_ids):
+        """(offsets, perm): host list [num_frames + 1] of row ranges of the rows grouped by
+        ascending frame id, and the stable permutation that groups them (None if they already are)."""
+        fr = frame_ids.reshape(-1).long()
+        if fr.numel() == 0:
+            return None, None
+        perm = None
+        if bool((fr[1:] < fr[:-1]).any()):
+            perm = torch.argsort(fr, stable=True)
+            fr = fr[perm]
+        num_frames = int(fr[-1].item()) + 1
+        bounds = torch.searchsorted(fr, torch.arange(num_frames + 1, device=fr.device))
+        return bounds.tolist(), perm
+
+    def _track_frame_native(self, seq_points, frame, offsets):
+        frame_id = int(frame.frame[0].long().item())
+        n_a = offsets[frame_id + 1] - offsets[frame_id]
+        assert frame.fxyz.shape[0] == n_a, "anchor rows must be the frame's rows of seq_points"
+        perm = seq_points.get("frame_perm", None)
+        s_fxyz, s_comp, s_stat = seq_points.fxyz, seq_points.component, seq_points.stationary
+        if perm is not None:  # rows not grouped by frame: track on the grouped copy, map rows back
+            s_fxyz, s_comp, s_stat = s_fxyz[perm].contiguous(), s_comp[perm], s_stat[perm]
+        num_components = int(frame.component.max().long().item()) + 1
+        comp_base = int((s_comp[offsets[frame_id]] - frame.component[0]).long().item())
+        present = [f for f in range(len(offsets) - 1) if offsets[f + 1] > offsets[f]]
+        min_frame_id = max(present[0], frame_id - self.track_interval)
+        max_frame_id = min(present[-1], frame_id + self.track_interval)
+        if self.verbose:
+            print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components (native)")
+        if self._track_params is None:
+            self._track_params = ops.track_params(
+                self.radius_list, self.voxel_size_list, self.stopping_delta,
+                self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
+                self.angle_threshold, self.min_move_frame, max_iter=80)
+        out, (_, reg_calls, _) = ops.track_frame(
+            self._track_params, s_fxyz, s_comp, s_stat, offsets,
+            frame_id, min_frame_id, max_frame_id, comp_base, num_components)
+        self.num_registration_calls += reg_calls
+        idx, comp, moving = out["ex_index"], out["ex_component"].to(frame.component.dtype), out["moving"]
+        if perm is not None:
+            idx = perm[idx]
+        extracted = EasyDict(dict(
+            fxyz=seq_points.fxyz[idx],
+            component=comp,
+            segmentation_label=seq_points.segmentation_label[idx],
+            frame_indices=out["ex_local"],
+            original_indices=idx,
+            moving=moving[comp],
+            valid_comp_mask=moving[comp],
+            gt_box_label=torch.zeros_like(comp),
+        ))
+        valid = out["valid_comp"] & ((out["comp_max_frame_id"] >= frame_id + self.min_move_frame) |
+                                     (out["comp_min_frame_id"] <= frame_id - self.min_move_frame))
+        extracted = EasyDict(filter_dict(extracted, valid[extracted.component]))
+        extracted.transforms = out["transforms"]
+        seq_points.extracted[extracted.original_indices] = True
+        self.last_track_debug = dict(reg_errors=out["reg_errors"], comp_edge_ratios=out["comp_edge_ratios"],
+                                     comp_velos=out["comp_velos"],
+                                     comp_min_frame_id=out["comp_min_frame_id"],
+                                     comp_max_frame_id=out["comp_max_frame_id"])
+        return extracted
+
+    def track_frame_host(self, seq_points, frame, seq_boxes):
+        """track_frame op by op (one framework call per step of cluster_tracking.py:430-787)."""
         num_components = int(frame.component.max().long().item()) + 1
         frame_id = int(frame.frame[0].long().item())
         frame_mask = (seq_points.frame == frame_id).reshape(-1)
@@ -258,7 +341,7 @@ class ClusterTracking(nn.Module):
                 if self.verbose:
                     print(f"Tracking {frame_id} --> {next_frame_id}")
                 next_mask = (seq_points.frame == next_frame_id).reshape(-1)
-                next_frame = EasyDict(filter_dict(seq_points, next_mask))
+                next_frame = EasyDict(filter_dict(seq_points, next_mask, ignore_keys=("frame_offsets", "frame_perm")))
                 col = next_frame_id - min_frame_id
                 frame.require_corres = ((~stopped)[frame.component]).reshape(-1)
                 transforms[:, col] = transforms[:, col - track_dir]
@@ -406,9 +489,11 @@ class ClusterTracking(nn.Module):
         # concurrently: one host thread + one HIP stream per unit, every thread on its own clone of
         # the graph / sampler modules (their radius / qmin / qmax are mutated during registration).
         # best_iou is a running maximum, so per-unit copies merged by max equal the serial result.
+        frame_offsets, frame_perm = self.frame_offsets_of(seq_points.frame) if self.native else (None, None)
         key_points = {}
         for comp_key in self.component_keys:
             sp = EasyDict(dict(seq_points))
+            sp.frame_offsets, sp.frame_perm = frame_offsets, frame_perm
             sp.component = seq_dict[f"point_{comp_key}"]
             diam = component_diameter(sp)
             sp.component_diameter = diam[sp.component]
@@ -426,7 +511,7 @@ class ClusterTracking(nn.Module):
             sp = EasyDict(dict(key_points[comp_key]))
             sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
             frame_mask = (sp.fxyz[:, 0] == frame_id).reshape(-1)
-            frame_points = EasyDict(filter_dict(sp, frame_mask))
+            frame_points = EasyDict(filter_dict(sp, frame_mask, ignore_keys=("frame_offsets", "frame_perm")))
             frame_points.component = frame_points.component - frame_points.component.min()
             boxes = EasyDict(dict(seq_boxes))
             boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)

@@ -51,26 +51,31 @@ def _tracker():
     return CT.ClusterTracking(cfg, {}).to(DEV)
 
 
-def _prepare(g):
+def _prepare(g, native=False):
     sp = _seq_points(g)
     diam = CT.component_diameter(sp)
     sp.component_diameter = diam[sp.component]
     sp.stationary = sp.component_diameter > 12.5
     sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
+    if native:
+        sp.frame_offsets, sp.frame_perm = CT.ClusterTracking.frame_offsets_of(sp.frame)
+        assert sp.frame_offsets is not None
     return sp
 
 
 def _track(tracker, sp, frame_id):
     from pcseqlearning_amd.pcdet.utils.common_utils import filter_dict
     mask = (sp.fxyz[:, 0] == frame_id).reshape(-1)
-    fp = EasyDict(filter_dict(sp, mask))
+    fp = EasyDict(filter_dict(sp, mask, ignore_keys=("frame_offsets", "frame_perm")))
     fp.component = fp.component - fp.component.min()
     return tracker.track_frame(sp, fp, None)
 
 
-def test_track_frame_vs_oracle():
+@pytest.mark.parametrize("native", [False, True])
+def test_track_frame_vs_oracle(native):
     """Cluster / track ids bit-exact against the CPU oracle, transforms within 1e-5, on the small
-    sequence of the golden file (inputs only are taken from it)."""
+    sequence of the golden file (inputs only are taken from it); for the op-by-op host loop and
+    for the native loop (pcs_track_frame)."""
     from oracle import track_oracle as T
     g = np.load(os.path.join(G, "track_small.npz"))
     comp = g["component"]
@@ -79,7 +84,7 @@ def test_track_frame_vs_oracle():
     seq = dict(fxyz=g["fxyz"].copy(), frame=g["fxyz"][:, 0].astype(np.int64), component=comp,
                stationary=o_diam[comp] > 12.5, extracted=np.zeros(len(comp), bool))
     oracle_tracker = T.Tracker()
-    tracker, sp = _tracker(), _prepare(g)
+    tracker, sp = _tracker(), _prepare(g, native)
     np.testing.assert_array_equal(sp.stationary.cpu().numpy(), seq["stationary"])
     for frame_id in (0, 8):
         want = oracle_tracker.track_frame(seq, frame_id)
@@ -109,3 +114,30 @@ def test_track_frame_vs_reference():
         anchor_col = frame_id - max(0, frame_id - 8)
         near = [c for c in (anchor_col - 1, anchor_col + 1) if 0 <= c < W.shape[1]]
         assert np.median(np.abs(W[:, near] - M[:, near]).max(axis=(1, 2, 3))) < 1e-4
+
+
+def test_track_frame_native_vs_host():
+    """pcs_track_frame (the whole loop in one native call) against the op-by-op host loop on the
+    same kernels: identical extraction, masks, frame ranges and debug records; transforms equal to
+    f64 round-off."""
+    g = np.load(os.path.join(G, "track_small.npz"))
+    for frame_id in (0, 8, 16):
+        if not (g["fxyz"][:, 0] == frame_id).any():
+            continue
+        host, sp_h = _tracker(), _prepare(g)
+        nat, sp_n = _tracker(), _prepare(g, native=True)
+        a = _track(host, sp_h, frame_id)
+        b = _track(nat, sp_n, frame_id)
+        assert nat.num_registration_calls == host.num_registration_calls > 0
+        for key in ("original_indices", "frame_indices", "component", "moving", "valid_comp_mask",
+                    "segmentation_label", "fxyz"):
+            np.testing.assert_array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), err_msg=key)
+        np.testing.assert_allclose(a.transforms.cpu().numpy(), b.transforms.cpu().numpy(), rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(sp_h.extracted.cpu().numpy(), sp_n.extracted.cpu().numpy())
+        for key in ("comp_min_frame_id", "comp_max_frame_id"):
+            np.testing.assert_array_equal(host.last_track_debug[key].cpu().numpy(),
+                                          nat.last_track_debug[key].cpu().numpy(), err_msg=key)
+        for key in ("reg_errors", "comp_edge_ratios", "comp_velos"):
+            np.testing.assert_allclose(host.last_track_debug[key].cpu().numpy(),
+                                       nat.last_track_debug[key].cpu().numpy(), rtol=0, atol=1e-6,
+                                       err_msg=key)

@@ -1,0 +1,62 @@
+"""Host launch-rate probe: how do kernel launches from T host threads (one HIP stream each) scale?
+
+  torch : each thread issues small in-place torch ops (interpreter + ATen dispatch per launch)
+  native: each thread calls pcs_profile_launch_loop once (a C loop of launches, GIL released)
+
+Prints launches/s per mode and thread count. Used to decide where the tracking control flow has
+to live.
+"""
+import argparse
+import ctypes
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pcseqlearning_amd import lib as L  # noqa: E402
+
+
+def run(mode, T, n):
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(dev) for _ in range(T)]
+    xs = [torch.zeros(64, device=dev) for _ in range(T)]
+    barrier = threading.Barrier(T + 1)
+
+    def work(i):
+        with torch.cuda.stream(streams[i]):
+            barrier.wait()
+            if mode == "torch":
+                x = xs[i]
+                for _ in range(n):
+                    x.add_(1.0)
+            else:
+                rc = lib.pcs_profile_launch_loop(ctypes.c_int64(n), ctypes.c_void_p(streams[i].cuda_stream))
+                assert rc == 0
+            streams[i].synchronize()
+            barrier.wait()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    for t in th:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    return T * n / dt
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=20000)
+    args = ap.parse_args()
+    run("native", 1, 1000)
+    for mode in ("torch", "native"):
+        for T in (1, 2, 3, 5, 9):
+            r = run(mode, T, args.n)
+            print(f"{mode:7s} threads={T}  {r / 1e3:8.1f} k launches/s  ({1e6 / r * T:6.2f} us per launch per thread)", flush=True)
