@@ -293,6 +293,9 @@ int pcs_profile_icp_nn_read(double* out3);
 /* Diagnostic: enqueue `n` one-wave no-op kernels on `stream` (host launch-rate probe used by
  * tools/launch_scaling.py; no reference counterpart). */
 int pcs_profile_launch_loop(int64_t n, pcs_stream_t stream);
+/* Diagnostic: n x {8 no-op launches, one small device->host read, stream sync}; mode 0 pageable
+ * destination, 1 pinned destination, 2 pinned word written by a kernel. Allocates its own scratch. */
+int pcs_profile_sync_loop(int64_t n, int mode, pcs_stream_t stream);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per
@@ -304,6 +307,15 @@ int pcs_irls_plane_fit(const float* xyz, const int64_t* pillar_idx, int64_t n, c
                        const float* origin, int64_t P, float sigma2, float stopping_delta,
                        int max_rounds, float* plane, float* plane_err, int32_t* d_rounds, void* ws,
                        size_t ws_bytes, pcs_stream_t stream);
+
+/* The same fit when the rows are grouped by pillar, as the reference has them after its
+ * sort-by-pillar (preprocessor_utils.py:112-118): seg_start [P+1] int32 row ranges replace
+ * pillar_idx. One launch per round (a workgroup per pillar, fixed-order sums: bit-reproducible). */
+size_t pcs_irls_plane_fit_sorted_workspace_bytes(int64_t n, int64_t P);
+int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_t n, const float* w0,
+                              const float* origin, int64_t P, float sigma2, float stopping_delta,
+                              int max_rounds, float* plane, float* plane_err, int32_t* d_rounds,
+                              void* ws, size_t ws_bytes, pcs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -519,6 +519,31 @@ int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
   return PCS_OK;
 }
 
+// n x {8 no-op launches, one small device->host read, stream sync}; mode 0: pageable destination
+// (hipMemcpyAsync), mode 1: pinned destination, mode 2: pinned word written by the kernel itself
+__global__ void probe_write_kernel(int* dst, int v) { *dst = v; }
+int pcs_profile_sync_loop(int64_t n, int mode, hipStream_t s) {
+  int* dev = nullptr;
+  int* pinned = nullptr;
+  PCS_CHECK_HIP(hipMalloc(&dev, 64));
+  PCS_CHECK_HIP(hipHostMalloc(&pinned, 64));
+  int host[16];
+  for (int64_t i = 0; i < n; ++i) {
+    for (int j = 0; j < 8; ++j) pcs::noop_kernel<<<1, 64, 0, s>>>();
+    if (mode == 0) {
+      PCS_CHECK_HIP(hipMemcpyAsync(host, dev, 56, hipMemcpyDeviceToHost, s));
+    } else if (mode == 1) {
+      PCS_CHECK_HIP(hipMemcpyAsync(pinned, dev, 56, hipMemcpyDeviceToHost, s));
+    } else {
+      probe_write_kernel<<<1, 1, 0, s>>>(pinned, (int)i);
+    }
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+  }
+  hipFree(dev);
+  hipHostFree(pinned);
+  return PCS_OK;
+}
+
 int pcs_profile_icp_nn(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;

@@ -127,6 +127,262 @@ smooth_velo_kernel(float* __restrict__ v, const float* __restrict__ d, int C, in
   if (tid == 0) { st->iters = it; st->last_loss = last_loss; }
 }
 
+// The same loop with the state on chip: v in LDS, d and the Adam moments in registers (<= SV_ELEMS
+// elements per thread), the per-step scalars tabulated once. Identical arithmetic and the same
+// element -> thread map / reduction tree as smooth_velo_kernel; used when the in-range elements fit.
+constexpr int SV_ELEMS = 8;
+constexpr int SV_MAX_ITR = 512;
+
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_lds_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                       float weight0, float weight, int num_itr, float stopping,
+                       SmoothState* __restrict__ st) {
+  extern __shared__ float sv[];               // [n_in] current iterate
+  __shared__ double red[SV_BLOCK / 64];
+  __shared__ float t_step[SV_MAX_ITR], t_bc2[SV_MAX_ITR], t_decay[SV_MAX_ITR];
+  __shared__ int stop_flag;
+  const int nf = b - a + 1;
+  const int n_in = C * nf * 2;
+  const float inv_fit = 1.0f / (float)(C * nf * 2);
+  const float inv_sm = 1.0f / (float)(C * (nf - 1) * 2);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float last_loss = 1e10f;
+  int countdown = 3;
+  float de[SV_ELEMS], me[SV_ELEMS], se[SV_ELEMS];
+  int tpos[SV_ELEMS];  // 0: interior, bit0: first frame of the range, bit1: last frame
+#pragma unroll
+  for (int j = 0; j < SV_ELEMS; ++j) {
+    int e = tid + j * SV_BLOCK;
+    de[j] = 0.f; me[j] = 0.f; se[j] = 0.f; tpos[j] = 0;
+    if (e < n_in) {
+      int k = e & 1;
+      int t = (e >> 1) % nf;
+      int c = (e >> 1) / nf;
+      int64_t at = ((int64_t)c * F + (a + t)) * 3 + k;
+      sv[e] = v[at];
+      de[j] = d[at];
+      tpos[j] = (t == 0 ? 1 : 0) | (t == nf - 1 ? 2 : 0);
+    }
+  }
+  for (int it = tid; it < num_itr; it += SV_BLOCK) {
+    double lr = lr_at(it);
+    double bc1 = 1.0 - pow(0.9, (double)(it + 1));
+    double bc2 = 1.0 - pow(0.999, (double)(it + 1));
+    t_step[it] = (float)(lr / bc1);
+    t_bc2[it] = (float)sqrt(bc2);
+    t_decay[it] = (float)(1.0 - lr * 1e-2);
+  }
+  if (tid == 0) stop_flag = 0;
+  __syncthreads();
+  int it = 0;
+  for (; it < num_itr; ++it) {
+    double part = 0.0;
+    float g[SV_ELEMS];
+#pragma unroll
+    for (int j = 0; j < SV_ELEMS; ++j) {
+      int e = tid + j * SV_BLOCK;
+      g[j] = 0.f;
+      if (e < n_in) {
+        float x = sv[e];
+        float r = x - de[j];
+        part += (double)(r * r) * inv_fit * weight0;
+        float gj = r * 2.f * (inv_fit * weight0);
+        if (!(tpos[j] & 2)) {
+          float y = x - sv[e + 2];
+          part += (double)fabsf(y) * inv_sm * weight;
+          gj += (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
+        }
+        if (!(tpos[j] & 1)) {
+          float y = sv[e - 2] - x;
+          gj -= (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
+        }
+        g[j] = gj;
+      }
+    }
+    part = wave_sum_f64(part);
+    if (lane == 0) red[w] = part;
+    __syncthreads();  // partial sums visible; every read of the old iterate is done
+    const float step_size = t_step[it], bc2_sqrt = t_bc2[it], decay = t_decay[it];
+#pragma unroll
+    for (int j = 0; j < SV_ELEMS; ++j) {
+      int e = tid + j * SV_BLOCK;
+      if (e < n_in) {
+        me[j] = me[j] + 0.1f * (g[j] - me[j]);
+        se[j] = se[j] * 0.999f + 0.001f * g[j] * g[j];
+        float x = sv[e] * decay;
+        float denom = sqrtf(se[j]) / bc2_sqrt + 1e-8f;
+        sv[e] = x - step_size * (me[j] / denom);
+      }
+    }
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int q = 0; q < SV_BLOCK / 64; ++q) tot += red[q];
+      float loss = (float)tot;
+      if (last_loss - loss < stopping) countdown -= 1;
+      else countdown = 3;
+      if (countdown <= 0) stop_flag = 1;
+      else last_loss = loss;
+    }
+    __syncthreads();
+    if (stop_flag) { ++it; break; }
+  }
+#pragma unroll
+  for (int j = 0; j < SV_ELEMS; ++j) {
+    int e = tid + j * SV_BLOCK;
+    if (e < n_in) {
+      int k = e & 1;
+      int t = (e >> 1) % nf;
+      int c = (e >> 1) / nf;
+      v[((int64_t)c * F + (a + t)) * 3 + k] = sv[e];
+    }
+  }
+  if (tid == 0) { st->iters = it; st->last_loss = last_loss; }
+}
+
+// Many components (thousands of small clusters): the same loop spread over up to SV_MAX_BLOCKS
+// workgroups, each owning a contiguous range of components (so the t +- 1 neighbours stay local) with
+// its slice of v in LDS. The only coupling is the scalar loss of the 3-strike stop rule: one f64
+// partial per workgroup and ONE grid barrier per step (arrival counter that only grows; partials
+// double-buffered by step parity). All workgroups evaluate the same stop rule on the same sum, so
+// they leave together. The grid is at most 64 x 1024 threads, far below what the device keeps
+// resident, and the barrier wait is bounded: on time-out the error word is set and every wave exits.
+constexpr int SV_MAX_BLOCKS = 64;
+struct SmoothGrid {
+  unsigned int arrive;
+  int timeout;
+  double partial[2][SV_MAX_BLOCKS];
+};
+
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                        float weight0, float weight, int num_itr, float stopping, int cpb,
+                        SmoothGrid* __restrict__ g, SmoothState* __restrict__ st,
+                        int* __restrict__ err) {
+  extern __shared__ float sv[];               // this workgroup's slice of the iterate
+  __shared__ double red[SV_BLOCK / 64];
+  __shared__ float t_step[SV_MAX_ITR], t_bc2[SV_MAX_ITR], t_decay[SV_MAX_ITR];
+  __shared__ int stop_flag;
+  const int nf = b - a + 1;
+  const int c0 = blockIdx.x * cpb;
+  const int c1 = min(C, c0 + cpb);
+  const int n_loc = (c1 - c0) * nf * 2;
+  const int B = gridDim.x;
+  const float inv_fit = 1.0f / (float)(C * nf * 2);
+  const float inv_sm = 1.0f / (float)(C * (nf - 1) * 2);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float last_loss = 1e10f;
+  int countdown = 3;
+  float de[SV_ELEMS], me[SV_ELEMS], se[SV_ELEMS];
+  int tpos[SV_ELEMS];
+#pragma unroll
+  for (int j = 0; j < SV_ELEMS; ++j) {
+    int e = tid + j * SV_BLOCK;
+    de[j] = 0.f; me[j] = 0.f; se[j] = 0.f; tpos[j] = 0;
+    if (e < n_loc) {
+      int k = e & 1;
+      int t = (e >> 1) % nf;
+      int c = c0 + (e >> 1) / nf;
+      int64_t at = ((int64_t)c * F + (a + t)) * 3 + k;
+      sv[e] = v[at];
+      de[j] = d[at];
+      tpos[j] = (t == 0 ? 1 : 0) | (t == nf - 1 ? 2 : 0);
+    }
+  }
+  for (int it = tid; it < num_itr; it += SV_BLOCK) {
+    double lr = lr_at(it);
+    double bc1 = 1.0 - pow(0.9, (double)(it + 1));
+    double bc2 = 1.0 - pow(0.999, (double)(it + 1));
+    t_step[it] = (float)(lr / bc1);
+    t_bc2[it] = (float)sqrt(bc2);
+    t_decay[it] = (float)(1.0 - lr * 1e-2);
+  }
+  if (tid == 0) stop_flag = 0;
+  __syncthreads();
+  int it = 0;
+  for (; it < num_itr; ++it) {
+    double part = 0.0;
+    float gr[SV_ELEMS];
+#pragma unroll
+    for (int j = 0; j < SV_ELEMS; ++j) {
+      int e = tid + j * SV_BLOCK;
+      gr[j] = 0.f;
+      if (e < n_loc) {
+        float x = sv[e];
+        float r = x - de[j];
+        part += (double)(r * r) * inv_fit * weight0;
+        float gj = r * 2.f * (inv_fit * weight0);
+        if (!(tpos[j] & 2)) {
+          float y = x - sv[e + 2];
+          part += (double)fabsf(y) * inv_sm * weight;
+          gj += (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
+        }
+        if (!(tpos[j] & 1)) {
+          float y = sv[e - 2] - x;
+          gj -= (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
+        }
+        gr[j] = gj;
+      }
+    }
+    part = wave_sum_f64(part);
+    if (lane == 0) red[w] = part;
+    __syncthreads();  // partial sums visible; every read of the old iterate is done
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int q = 0; q < SV_BLOCK / 64; ++q) tot += red[q];
+      __hip_atomic_store(&g->partial[it & 1][blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&g->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float step_size = t_step[it], bc2_sqrt = t_bc2[it], decay = t_decay[it];
+#pragma unroll
+    for (int j = 0; j < SV_ELEMS; ++j) {
+      int e = tid + j * SV_BLOCK;
+      if (e < n_loc) {
+        me[j] = me[j] + 0.1f * (gr[j] - me[j]);
+        se[j] = se[j] * 0.999f + 0.001f * gr[j] * gr[j];
+        float x = sv[e] * decay;
+        float denom = sqrtf(se[j]) / bc2_sqrt + 1e-8f;
+        sv[e] = x - step_size * (me[j] / denom);
+      }
+    }
+    if (tid == 0) {
+      const unsigned target = (unsigned)(it + 1) * (unsigned)B;
+      bool ok = false;
+      for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (__hip_atomic_load(&g->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
+        if (__hip_atomic_load(&g->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        __hip_atomic_store(&g->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err) atomicExch(err, 3);
+        stop_flag = 2;
+      } else {
+        double tot = 0.0;
+        for (int q = 0; q < B; ++q)
+          tot += __hip_atomic_load(&g->partial[it & 1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float loss = (float)tot;
+        if (last_loss - loss < stopping) countdown -= 1;
+        else countdown = 3;
+        if (countdown <= 0) stop_flag = 1;
+        else last_loss = loss;
+      }
+    }
+    __syncthreads();
+    if (stop_flag) { ++it; break; }
+  }
+#pragma unroll
+  for (int j = 0; j < SV_ELEMS; ++j) {
+    int e = tid + j * SV_BLOCK;
+    if (e < n_loc) {
+      int k = e & 1;
+      int t = (e >> 1) % nf;
+      int c = c0 + (e >> 1) / nf;
+      v[((int64_t)c * F + (a + t)) * 3 + k] = sv[e];
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) { st->iters = it; st->last_loss = last_loss; }
+}
+
 // elements outside (c, [a,b], {0,1}) only see the decoupled weight decay of every executed step
 __global__ void __launch_bounds__(kBlock)
 smooth_velo_decay_kernel(float* __restrict__ v, int64_t total, int F, int a, int b,
@@ -453,6 +709,141 @@ irls_error_kernel(const float* __restrict__ xyz, const int64_t* __restrict__ pid
   }
 }
 
+// ---- segmented form: the reference sorts the voxels by pillar before the fits
+// (preprocessor_utils.py:112-118), so a pillar is one contiguous run of rows. One workgroup per
+// pillar does a whole round (new weights from the previous plane, weighted raw moments in a fixed
+// order -- no atomics, bit-reproducible --, 3x3 eigen-solve) in ONE launch. The global
+// convergence test of round r (max weight change over ALL rows < delta) is evaluated by every
+// workgroup of launch r+1 from one word per round, so nothing synchronises inside a launch:
+// planes are double-buffered and the plane of round r-1 survives until the test of round r is known.
+constexpr int kIrlsMaxRounds = 62;
+struct IrlsSegState {
+  int stop_round;   // launches with r > stop_round return immediately
+  int rounds;       // rounds whose plane was adopted
+  int final_buf;    // plane buffer holding the result
+  int pad;
+  unsigned dw[kIrlsMaxRounds + 2];  // max |new_w - w| per round (float bits)
+};
+
+__global__ void irls_seg_init_kernel(IrlsSegState* st) {
+  int i = threadIdx.x;
+  if (i == 0) { st->stop_round = 0x7fffffff; st->rounds = 0; st->final_buf = 0; st->pad = 0; }
+  if (i < kIrlsMaxRounds + 2) st->dw[i] = 0;
+}
+
+// round r (1-based); r == max_rounds + 1 with check_only: only the convergence test of the last round
+__global__ void __launch_bounds__(kBlock)
+irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
+                      const int32_t* __restrict__ seg_start, const float* __restrict__ origin,
+                      float sigma2, float delta, float* __restrict__ w, float* __restrict__ planes,
+                      int64_t P, IrlsSegState* __restrict__ st) {
+  if (r > st->stop_round) return;
+  float* plane_prev = planes + (size_t)((r - 1) & 1) * P * 6;  // plane of round r-1
+  float* plane_cur = planes + (size_t)(r & 1) * P * 6;         // plane of round r (and of r-2)
+  if (r > 2 && __uint_as_float(st->dw[r - 1]) < delta) {
+    // round r-1's new weights moved by less than delta: the loop ended with the plane of round r-2
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->stop_round = r - 1; st->rounds = r - 2; st->final_buf = r & 1; }
+    return;
+  }
+  if (check_only) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->rounds = r - 1; st->final_buf = (r - 1) & 1; }
+    return;
+  }
+  const int c = blockIdx.x;
+  const int b = seg_start[c], e = seg_start[c + 1];
+  const float o0 = origin[c * 3], o1 = origin[c * 3 + 1], o2 = origin[c * 3 + 2];
+  float pl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r > 1) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pl[q] = plane_prev[(int64_t)c * 6 + q];
+  }
+  double v[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) v[q] = 0.0;
+  float dw = 0.f;
+  for (int i = b + (int)threadIdx.x; i < e; i += kBlock) {
+    float x = xyz[(int64_t)i * 3], y = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
+    float wi = w[i];
+    if (r > 1) {
+      float dx = x - pl[0], dy = y - pl[1], dz = z - pl[2];
+      float er = fabsf(dx * pl[3] + dy * pl[4] + dz * pl[5]);
+      float nw = sigma2 / (er * er + sigma2);
+      float dist_w = 0.25f / (dx * dx + dy * dy + dz * dz + 0.25f);
+      nw = nw * dist_w;
+      dw = fmaxf(dw, fabsf(nw - wi));
+      wi = nw;
+      w[i] = nw;
+    }
+    float ox = x - o0, oy = y - o1, oz = z - o2;
+    double W = wi;
+    v[0] += W; v[1] += W * ox; v[2] += W * oy; v[3] += W * oz;
+    v[4] += W * ox * ox; v[5] += W * ox * oy; v[6] += W * ox * oz;
+    v[7] += W * oy * oy; v[8] += W * oy * oz; v[9] += W * oz * oz;
+    v[10] += 1.0;
+  }
+  __shared__ double part[kBlock / 64][11];
+  __shared__ float sdw[kBlock / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 11; ++q) {
+    double x = wave_sum_f64(v[q]);
+    if (lane == 0) part[wv][q] = x;
+  }
+  float mx = wave_max(dw);
+  if (lane == 0) sdw[wv] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a[11];
+    for (int q = 0; q < 11; ++q) {
+      double x = part[0][q];
+      for (int k = 1; k < kBlock / 64; ++k) x += part[k][q];
+      a[q] = x;
+    }
+    float m4 = sdw[0];
+    for (int k = 1; k < kBlock / 64; ++k) m4 = fmaxf(m4, sdw[k]);
+    if (r > 1) atomicMax(&st->dw[r], __float_as_uint(m4));
+    double ws = a[0] + 1e-6;
+    double cnt = a[10] > 0.5 ? a[10] : 1.0;
+    double og[3] = {(double)o0, (double)o1, (double)o2};
+    double m[3];
+    for (int q = 0; q < 3; ++q) m[q] = (a[1 + q] + og[q] * a[0]) / ws - og[q];
+    double So[3] = {a[1], a[2], a[3]};
+    double Soo[6] = {a[4], a[5], a[6], a[7], a[8], a[9]};
+    const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+    float cov[6];
+    for (int q = 0; q < 6; ++q) {
+      int i = ia[q], j = ib[q];
+      double sdd = Soo[q] - m[i] * So[j] - So[i] * m[j] + a[0] * m[i] * m[j];
+      cov[q] = (float)(sdd / cnt);
+    }
+    float nrm[3];
+    eig3_smallest(cov, nrm);
+    float* out = plane_cur + (int64_t)c * 6;
+    out[0] = (float)(m[0] + og[0]);
+    out[1] = (float)(m[1] + og[1]);
+    out[2] = (float)(m[2] + og[2]);
+    out[3] = nrm[0]; out[4] = nrm[1]; out[5] = nrm[2];
+  }
+}
+
+// result plane -> caller's buffer, point-plane error of every row against it
+__global__ void __launch_bounds__(kBlock)
+irls_seg_finish_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ seg_start, int64_t P,
+                       const float* __restrict__ planes, const IrlsSegState* __restrict__ st,
+                       float* __restrict__ plane_out, float* __restrict__ perr) {
+  const int c = blockIdx.x;
+  const float* pl = planes + (size_t)st->final_buf * P * 6 + (int64_t)c * 6;
+  float q[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) q[k] = pl[k];
+  if (threadIdx.x < 6) plane_out[(int64_t)c * 6 + threadIdx.x] = q[threadIdx.x];
+  const int b = seg_start[c], e = seg_start[c + 1];
+  for (int i = b + (int)threadIdx.x; i < e; i += kBlock) {
+    float dx = xyz[(int64_t)i * 3] - q[0], dy = xyz[(int64_t)i * 3 + 1] - q[1], dz = xyz[(int64_t)i * 3 + 2] - q[2];
+    perr[i] = fabsf(dx * q[3] + dy * q[4] + dz * q[5]);
+  }
+}
+
 // points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168: serial
 // boxes x points double loop on the host in the reference; one thread per (box, point) here.
 // Same arithmetic: |z - cz| <= dz/2 in double, rotation by cos/sin of the double angle rounded to
@@ -482,6 +873,46 @@ points_in_boxes_kernel(const float* __restrict__ pts, int64_t N, const float* __
   }
 }
 
+// comp_velos [C,F,3] f32 updated in place; comp_center_diffs [C,F,3]. frame_lo <= frame_hi are the
+// ordered ends of the optimised range (the reference swaps them itself when tracking backwards).
+// `err` (optional device word) is set to 3 if the multi-workgroup form timed out at its barrier.
+int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo,
+                    int frame_hi, float weight0, float weight, int num_itr, float stopping, void* ws,
+                    size_t ws_bytes, int* err, hipStream_t s) {
+  if (!comp_velos || !comp_center_diffs || !ws || C < 1 || F < 1 || frame_lo < 0 ||
+      frame_hi >= F || frame_lo > frame_hi || num_itr < 0)
+    return PCS_ERR_ARG;
+  if (frame_lo == frame_hi) return PCS_OK;  // cluster_tracking.py:166-167
+  if (C * (int64_t)F * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
+  Arena a(ws, ws_bytes);
+  SmoothState* st = a.take<SmoothState>(1);
+  SmoothGrid* grid = a.take<SmoothGrid>(1);
+  float* m = a.take<float>((size_t)C * F * 2);
+  float* sq = a.take<float>((size_t)C * F * 2);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  const int nf = frame_hi - frame_lo + 1;
+  int64_t n_in = C * (int64_t)nf * 2;
+  const int cpb = (SV_BLOCK * SV_ELEMS) / (nf * 2);  // components per workgroup
+  const int64_t blocks = cpb > 0 ? (C + cpb - 1) / cpb : (int64_t)SV_MAX_BLOCKS + 1;
+  if (n_in <= (int64_t)SV_BLOCK * SV_ELEMS && num_itr <= SV_MAX_ITR) {
+    smooth_velo_lds_kernel<<<1, SV_BLOCK, (size_t)n_in * sizeof(float), s>>>(
+        comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
+        stopping, st);
+  } else if (blocks <= SV_MAX_BLOCKS && num_itr <= SV_MAX_ITR) {
+    PCS_CHECK_HIP(hipMemsetAsync(grid, 0, sizeof(SmoothGrid), s));
+    smooth_velo_grid_kernel<<<(int)blocks, SV_BLOCK, (size_t)cpb * nf * 2 * sizeof(float), s>>>(
+        comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
+        stopping, cpb, grid, st, err);
+  } else {
+    smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
+                                              frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
+  }
+  smooth_velo_decay_kernel<<<grid_for(C * (int64_t)F * 3), kBlock, 0, s>>>(
+      comp_velos, C * (int64_t)F * 3, F, frame_lo, frame_hi, st);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -491,6 +922,7 @@ extern "C" {
 size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F) {
   Arena a(nullptr, 0);
   a.take<SmoothState>(1);
+  a.take<SmoothGrid>(1);
   a.take<float>((size_t)C * F * 2);
   a.take<float>((size_t)C * F * 2);
   return a.off;
@@ -501,22 +933,8 @@ size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F) {
 int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C, int F,
                     int frame_lo, int frame_hi, float weight0, float weight, int num_itr,
                     float stopping, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (!comp_velos || !comp_center_diffs || !ws || C < 1 || F < 1 || frame_lo < 0 ||
-      frame_hi >= F || frame_lo > frame_hi || num_itr < 0)
-    return PCS_ERR_ARG;
-  if (frame_lo == frame_hi) return PCS_OK;  // cluster_tracking.py:166-167
-  if (C * (int64_t)F * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
-  Arena a(ws, ws_bytes);
-  SmoothState* st = a.take<SmoothState>(1);
-  float* m = a.take<float>((size_t)C * F * 2);
-  float* sq = a.take<float>((size_t)C * F * 2);
-  if (!a.ok()) return PCS_ERR_WORKSPACE;
-  smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
-                                            frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
-  smooth_velo_decay_kernel<<<grid_for(C * (int64_t)F * 3), kBlock, 0, s>>>(
-      comp_velos, C * (int64_t)F * 3, F, frame_lo, frame_hi, st);
-  PCS_LAUNCH_CHECK();
-  return PCS_OK;
+  return pcs::smooth_velo_run(comp_velos, comp_center_diffs, C, F, frame_lo, frame_hi, weight0, weight,
+                              num_itr, stopping, ws, ws_bytes, nullptr, s);
 }
 
 // out [B, N] int32 (1 = point inside box)
@@ -559,6 +977,43 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
                                        rigid_weight, max_iters, height_out, m, v, st);
   if (d_iters)
     PCS_CHECK_HIP(hipMemcpyAsync(d_iters, &st->iters, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+size_t pcs_irls_plane_fit_sorted_workspace_bytes(int64_t n, int64_t P) {
+  Arena a(nullptr, 0);
+  a.take<IrlsSegState>(1);
+  a.take<float>((size_t)(P > 0 ? P : 1) * 12);
+  a.take<float>((size_t)(n > 0 ? n : 1));
+  return a.off;
+}
+
+// Rows grouped by pillar: seg_start [P+1] int32 row ranges (empty pillars allowed). Same outputs as
+// pcs_irls_plane_fit. One launch per round, bit-reproducible (fixed-order sums). Never synchronises.
+int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_t n, const float* w0,
+                              const float* origin, int64_t P, float sigma2, float stopping_delta,
+                              int max_rounds, float* plane, float* plane_err, int32_t* d_rounds,
+                              void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!xyz || !seg_start || !w0 || !origin || !plane || !plane_err || !ws || n < 1 || P < 1 ||
+      max_rounds < 1 || max_rounds > kIrlsMaxRounds)
+    return PCS_ERR_ARG;
+  if (P >= (1LL << 24) || n >= (1LL << 31)) return PCS_ERR_RANGE;
+  Arena a(ws, ws_bytes);
+  IrlsSegState* st = a.take<IrlsSegState>(1);
+  float* planes = a.take<float>((size_t)P * 12);
+  float* w = a.take<float>((size_t)n);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemcpyAsync(w, w0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  irls_seg_init_kernel<<<1, 64, 0, s>>>(st);
+  for (int r = 1; r <= max_rounds; ++r)
+    irls_seg_round_kernel<<<(int)P, kBlock, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta,
+                                                    w, planes, P, st);
+  irls_seg_round_kernel<<<1, 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin, sigma2,
+                                         stopping_delta, w, planes, P, st);
+  irls_seg_finish_kernel<<<(int)P, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, plane, plane_err);
+  if (d_rounds)
+    PCS_CHECK_HIP(hipMemcpyAsync(d_rounds, &st->rounds, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

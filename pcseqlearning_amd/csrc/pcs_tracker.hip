@@ -444,6 +444,9 @@ __global__ void trk_copy_count_kernel(const int64_t* src, int64_t* dst) { *dst =
 
 int radius_nn1_view(int64_t N, int64_t M, void* ws, size_t ws_bytes, const int32_t** nbr_idx,
                     const int32_t** deg, const int32_t** err);
+int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo,
+                    int frame_hi, float weight0, float weight, int num_itr, float stopping, void* ws,
+                    size_t ws_bytes, int* err, hipStream_t s);
 
 struct TrkPlan {
   TrkState* st;
@@ -716,9 +719,9 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
         int a0 = anchor_frame + dir, b0 = next;
         if (a0 != b0) {
           int lo = a0 < b0 ? a0 : b0, hi = a0 < b0 ? b0 : a0;
-          TRK_RC(pcs_smooth_velo(comp_velos, p.diffs, C, F, lo, hi, prm->smooth_weight0,
+          TRK_RC(smooth_velo_run(comp_velos, p.diffs, C, F, lo, hi, prm->smooth_weight0,
                                  prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping,
-                                 p.ws_sv, p.sv_bytes, s));
+                                 p.ws_sv, p.sv_bytes, &p.st->err, s));
         }
       }
       trk_after_smooth_kernel<<<gAC, kBlock, 0, s>>>(

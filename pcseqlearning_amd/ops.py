@@ -423,19 +423,31 @@ def l1_minimization(pillar_min_z, weight, lr, decay_steps, rigid_weight, max_ite
     return out
 
 
-def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_delta=1e-2, max_rounds=50):
-    """preprocessor_utils.iterative_reweighted_ransac as two kernels per round, no host sync.
+def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_delta=1e-2, max_rounds=50,
+                   seg_start=None):
+    """preprocessor_utils.iterative_reweighted_ransac with the convergence test on the device (no
+    host sync). `seg_start` ([P+1] int32 row ranges) says the rows are grouped by pillar: one launch
+    per round with fixed-order sums; without it, two launches per round and f64 atomics.
     Returns (center [P,3], normal [P,3], plane_fitting_error [n])."""
     import ctypes
     L.require_gpu(xyz, "irls_plane_fit")
     lib = L.load()
     xyz = xyz.float().contiguous()
-    pidx = pillar_idx.long().contiguous()
     w0 = w0.float().reshape(-1).contiguous()
     origin = origin.float().contiguous()
     n, P = xyz.shape[0], int(num_pillars)
     plane = torch.zeros(P, 6, dtype=torch.float32, device=xyz.device)
     perr = torch.empty(n, dtype=torch.float32, device=xyz.device)
+    if seg_start is not None:
+        assert seg_start.dtype == torch.int32 and seg_start.shape[0] == P + 1
+        ws = L.workspace(lib.pcs_irls_plane_fit_sorted_workspace_bytes(L.i64(n), L.i64(P)), xyz.device)
+        L.check(lib.pcs_irls_plane_fit_sorted(L.ptr(xyz), L.ptr(seg_start.contiguous()), L.i64(n), L.ptr(w0),
+                                              L.ptr(origin), L.i64(P), L.f32(sigma2), L.f32(stopping_delta),
+                                              L.i32(max_rounds), L.ptr(plane), L.ptr(perr),
+                                              ctypes.c_void_p(0), L.ptr(ws), L.i64(ws.numel()),
+                                              L.stream()), "pcs_irls_plane_fit_sorted")
+        return plane[:, :3], plane[:, 3:], perr
+    pidx = pillar_idx.long().contiguous()
     ws = L.workspace(lib.pcs_irls_plane_fit_workspace_bytes(L.i64(n), L.i64(P)), xyz.device)
     L.check(lib.pcs_irls_plane_fit(L.ptr(xyz), L.ptr(pidx), L.i64(n), L.ptr(w0), L.ptr(origin), L.i64(P),
                                    L.f32(sigma2), L.f32(stopping_delta), L.i32(max_rounds), L.ptr(plane),

@@ -515,9 +515,9 @@ class ClusterTracking(nn.Module):
             frame_points.component = frame_points.component - frame_points.component.min()
             boxes = EasyDict(dict(seq_boxes))
             boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)
-            with Timer(f"Tracking Frame {frame_id}"):
+            with Timer(f"Tracking Frame {frame_id}"), Timer(f"unit {comp_key}@{frame_id} track"):
                 extracted = worker.track_frame(sp, frame_points, boxes)
-            with Timer("Extract Traces from all points"):
+            with Timer("Extract Traces from all points"), Timer(f"unit {comp_key}@{frame_id} extract"):
                 if extracted.fxyz.shape[0] > 0:
                     extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes)
             return extracted, boxes.best_iou

@@ -31,7 +31,7 @@ def _seg_sum(data, sg, n):
 
 
 def iterative_reweighted_ransac(points, pillars, w0, num_pillars, sigma2, stopping_delta=1e-2, sg=None,
-                                origin=None):
+                                origin=None, seg_start=None):
     """<= 50 IRLS plane fits per pillar: weighted centre, weighted covariance, smallest
     eigenvector as the normal, Cauchy weights on the point-plane error times a 0.5 m distance
     falloff; stops when no weight moves by more than stopping_delta (preprocessor_utils.py:32-80).
@@ -42,7 +42,7 @@ def iterative_reweighted_ransac(points, pillars, w0, num_pillars, sigma2, stoppi
             sg = IndexSegments(points.pillar_idx, num_pillars)
         origin = robust_mean(xyz, sg, num_pillars)
     pillars.center, pillars.normal, points.plane_fitting_error = ops.irls_plane_fit(
-        xyz, points.pillar_idx, w0, origin, num_pillars, sigma2, stopping_delta, 50)
+        xyz, points.pillar_idx, w0, origin, num_pillars, sigma2, stopping_delta, 50, seg_start=seg_start)
     return points, pillars
 
 
@@ -88,12 +88,15 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
 
     sigma = cfg["SIGMA2"] ** 0.5
     origin = robust_mean(nv.bxyz[:, 1:4], sg, num_new)
+    # rows are sorted by super-pillar: dense row ranges for the one-launch-per-round plane fit
+    seg_start = torch.searchsorted(nv.pillar_idx.contiguous(),
+                                   torch.arange(num_new + 1, device=dev)).int()
     for ratio in torch.linspace(0.3, 1, 30).tolist():
         cur_z = npil.min_z * ratio + npil.max_z * (1 - ratio)
         z_diff = cur_z[nv.pillar_idx] - z
         w0 = (cfg["SIGMA2"] / (z_diff.square() + cfg["SIGMA2"])).reshape(-1, 1)
         nv, npil = iterative_reweighted_ransac(nv, npil, w0, num_new, sigma2=cfg["SIGMA2"], sg=sg,
-                                               origin=origin)
+                                               origin=origin, seg_start=seg_start)
         hit = (nv.plane_fitting_error < sigma).float()
         num_hit = _seg_sum(hit, sg, num_new)
         better = npil.best_confidence < num_hit

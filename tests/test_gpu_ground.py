@@ -50,12 +50,17 @@ def test_irls_plane_fit_vs_torch():
     pidx = torch.cat(idx).long().to(DEV)
     w0 = (0.0025 / ((xyz[:, 2] - 0.0).square() + 0.0025)).reshape(-1, 1)
     origin = torch.zeros(P, 3, device=DEV).index_add_(0, pidx, xyz) / per
-    c, n, e = ops.irls_plane_fit(xyz, pidx, w0, origin, P, 0.0025)
     rc, rn, re = _irls_torch(xyz, pidx, w0.reshape(-1), P, 0.0025)
-    assert torch.allclose(c, rc, atol=2e-4), (c - rc).abs().max()
-    assert torch.allclose(n, rn, atol=2e-4), (n - rn).abs().max()
-    assert torch.allclose(e, re, atol=3e-4), (e - re).abs().max()
-    assert (n[:, 2] > 0.9).all()
+    seg_start = torch.searchsorted(pidx, torch.arange(P + 1, device=DEV)).int()
+    for seg in (None, seg_start):  # atomics path, one-launch-per-round path on grouped rows
+        c, n, e = ops.irls_plane_fit(xyz, pidx, w0, origin, P, 0.0025, seg_start=seg)
+        assert torch.allclose(c, rc, atol=2e-4), (c - rc).abs().max()
+        assert torch.allclose(n, rn, atol=2e-4), (n - rn).abs().max()
+        assert torch.allclose(e, re, atol=3e-4), (e - re).abs().max()
+        assert (n[:, 2] > 0.9).all()
+    # fixed-order sums: the grouped path is bit-reproducible
+    c2, n2, e2 = ops.irls_plane_fit(xyz, pidx, w0, origin, P, 0.0025, seg_start=seg_start)
+    assert torch.equal(c, c2) and torch.equal(n, n2) and torch.equal(e, e2)
 
 
 def test_l1_minimization_vs_torch_adamw():

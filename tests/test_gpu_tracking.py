@@ -32,6 +32,19 @@ def test_smooth_velo_vs_reference():
         np.testing.assert_allclose(out.cpu().numpy(), g[f"out_{name}"], rtol=0, atol=2e-5)
 
 
+def test_smooth_velo_many_components_vs_oracle():
+    """The multi-workgroup form (thousands of components: one grid barrier per AdamW step) and the
+    single-workgroup forms against the CPU oracle."""
+    from oracle import track_oracle as T
+    rng = np.random.default_rng(3)
+    for C, F, a, b in ((3000, 12, 3, 11), (700, 9, 8, 2), (40000, 6, 1, 4)):
+        diffs = (rng.standard_normal((C, F, 3)) * 0.3).astype(np.float32)
+        velos = (diffs + rng.standard_normal((C, F, 3)) * 0.05).astype(np.float32)
+        want = T.smooth_velo(velos.copy(), diffs, a, b)
+        got = ops.smooth_velo(dev(velos.copy()), dev(diffs), a, b)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-5)
+
+
 def _seq_points(g):
     sp = EasyDict(fxyz=dev(g["fxyz"].copy()), frame=dev(g["fxyz"][:, :1].astype(np.int64)),
                   gt_box_id=dev(np.full(len(g["fxyz"]), -1, np.int64)),

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--units", action="store_true", help="print the per-unit track / extract spans")
     args = ap.parse_args()
     batch = bench.load_sequence(0, 20, 160000)
     model = build_model(streams=args.streams)
@@ -56,6 +57,10 @@ def main():
         trk = sum(v for k, v in timer.RECORDS.items() if k.startswith("Tracking Frame"))
         ext = timer.RECORDS.get("Extract Traces from all points", 0.0)
         print(f"   sum over units: track_frame {trk * 1e3:.1f} ms, extract traces {ext * 1e3:.1f} ms")
+        if args.units:
+            for k in sorted(timer.RECORDS):
+                if k.startswith("unit "):
+                    print(f"      {k:44s} {timer.RECORDS[k] * 1e3:8.1f} ms")
 
 
 if __name__ == "__main__":
