@@ -99,41 +99,54 @@ class ClusterProposal(nn.Module):
                 traces.min_frame[t] = seq_boxes.frame[tm].min().long()
                 traces.max_frame[t] = seq_boxes.frame[tm].max().long()
 
-        seq_points = None
-        for comp_key in self.component_keys:
-            seq_points = EasyDict(fxyz=seq_dict["point_fxyz"], frame=seq_dict["point_sweep"],
-                                  segmentation_label=seq_dict["segmentation_label"])
-            if "instance_label" in seq_dict:
-                seq_points["instance_label"] = seq_dict["instance_label"]
-            seq_points.component = seq_dict[f"point_{comp_key}"]
-            for key in ("gt_box_id", "pred_box_id", "gt_trace_id", "pred_trace_id"):
-                seq_points[key] = torch.zeros_like(seq_points.component) - 1
-            for frame_id in range(num_frames):
-                fmask = (seq_points.fxyz[:, 0] == frame_id).reshape(-1)
-                if not bool(fmask.any()):
-                    continue
-                fp = EasyDict(filter_dict(seq_points, fmask))
-                bmask = (seq_boxes.frame == frame_id).reshape(-1)
-                fb = EasyDict(filter_dict(seq_boxes, bmask))
-                if fb.attr.shape[0] == 0:
-                    continue
-                bp = ops.points_in_boxes(fp.fxyz[:, 1:], fb.attr).long()
-                in_box = (bp == 1).any(0)
-                fp.gt_box_id[in_box] = bp[:, in_box].argmax(0)
-                fp.gt_trace_id[in_box] = fb.trace_id[fp.gt_box_id[in_box]]
-                gt_cnt = torch.bincount(fp.gt_box_id[in_box], minlength=fb.attr.shape[0])
-                _, inv, has_box, box, iou = component_box_iou(fp.component, bp, fp.gt_box_id, gt_cnt)
-                fp.pred_box_id = torch.where(has_box[inv], box[inv], torch.full_like(inv, -1))
-                valid = (fp.pred_box_id >= 0).reshape(-1)
-                fp.pred_trace_id[valid] = fb.trace_id[fp.pred_box_id[valid]]
-                # best IoU per box / per trace over the components assigned to it
-                scatter_max_(fb.best_iou, box[has_box], iou[has_box].to(fb.best_iou.dtype))
+        # The box membership of the points does not depend on the component key: frames outermost,
+        # points_in_boxes / GT ids once per frame, then the per-key component statistics. best_iou is a
+        # running maximum, so the per-key snapshots are cumulative maxima in key order.
+        n_pts = seq_dict["point_fxyz"].shape[0]
+        fxyz = seq_dict["point_fxyz"]
+        proto = seq_dict[f"point_{self.component_keys[0]}"]
+        gt_box_id = torch.zeros_like(proto) - 1
+        gt_trace_id = torch.zeros_like(proto) - 1
+        pred = {k: (torch.zeros_like(proto) - 1, torch.zeros_like(proto) - 1) for k in self.component_keys}
+        key_best = {k: torch.zeros_like(seq_boxes.best_iou) for k in self.component_keys}
+        for frame_id in range(num_frames):
+            fmask = (fxyz[:, 0] == frame_id).reshape(-1)
+            if not bool(fmask.any()):
+                continue
+            bmask = (seq_boxes.frame == frame_id).reshape(-1)
+            fb = EasyDict(filter_dict(seq_boxes, bmask))
+            if fb.attr.shape[0] == 0:
+                continue
+            f_fxyz = fxyz[fmask]
+            bp = ops.points_in_boxes(f_fxyz[:, 1:], fb.attr).long()
+            in_box = (bp == 1).any(0)
+            f_gt_box = torch.zeros(f_fxyz.shape[0], dtype=proto.dtype, device=proto.device) - 1
+            f_gt_trace = f_gt_box.clone()
+            f_gt_box[in_box] = bp[:, in_box].argmax(0).to(proto.dtype)
+            f_gt_trace[in_box] = fb.trace_id[f_gt_box[in_box]].to(proto.dtype)
+            gt_cnt = torch.bincount(f_gt_box[in_box], minlength=fb.attr.shape[0])
+            gt_box_id[fmask] = f_gt_box
+            gt_trace_id[fmask] = f_gt_trace
+            for comp_key in self.component_keys:
+                comp = seq_dict[f"point_{comp_key}"][fmask]
+                _, inv, has_box, box, iou = component_box_iou(comp, bp, f_gt_box, gt_cnt)
+                p_box = torch.where(has_box[inv], box[inv], torch.full_like(inv, -1))
+                p_trace = torch.zeros_like(p_box) - 1
+                valid = (p_box >= 0).reshape(-1)
+                p_trace[valid] = fb.trace_id[p_box[valid]].to(p_trace.dtype)
+                pred[comp_key][0][fmask] = p_box.to(proto.dtype)
+                pred[comp_key][1][fmask] = p_trace.to(proto.dtype)
+                f_best = key_best[comp_key][bmask]
+                scatter_max_(f_best, box[has_box], iou[has_box].to(f_best.dtype))
+                key_best[comp_key][bmask] = f_best
                 scatter_max_(traces.best_iou, fb.trace_id[box[has_box]].long(),
                              iou[has_box].to(traces.best_iou.dtype))
-                for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):
-                    seq_points[key][fmask] = fp[key]
-                seq_boxes["best_iou"][bmask] = fb["best_iou"]
-            seq_boxes[f"best_iou_after_{comp_key}"] = seq_boxes["best_iou"].clone()
+        for comp_key in self.component_keys:
+            seq_boxes.best_iou = torch.maximum(seq_boxes.best_iou, key_best[comp_key])
+            seq_boxes[f"best_iou_after_{comp_key}"] = seq_boxes.best_iou.clone()
+        last = self.component_keys[-1]
+        seq_points = EasyDict(gt_box_id=gt_box_id, gt_trace_id=gt_trace_id,
+                              pred_box_id=pred[last][0], pred_trace_id=pred[last][1])
         seq_dict["gt_box_best_iou"] = seq_boxes.best_iou
         seq_dict["gt_trace_best_iou"] = traces.best_iou
         for key in ("gt_box_id", "gt_trace_id", "pred_trace_id", "pred_box_id"):

@@ -144,13 +144,41 @@ class ClusterTracking(nn.Module):
         ))
 
     # ------------------------------------------------------------------ full-resolution harvest
-    def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes):
+    def frame_views(self, all_points, seq_boxes, frame_ids):
+        """Per-frame views shared by every tracking unit of a sequence: the frame's full-resolution
+        points, its GT boxes, and the box membership of the points (independent of the component
+        key and the anchor, so built once per sequence instead of once per unit and frame)."""
+        device = all_points.fxyz.device
+        views = {}
+        for fid in frame_ids:
+            v = EasyDict()
+            v.frame_box_mask = (seq_boxes.frame == fid).reshape(-1)
+            v.frame_boxes = EasyDict(filter_dict(seq_boxes, v.frame_box_mask, ignore_keys=("best_iou",)))
+            v.frame_boxes.pop("best_iou", None)
+            v.ref_mask = (all_points.frame == fid).reshape(-1)
+            v.ref_index = v.ref_mask.nonzero()
+            ref_pts = EasyDict(filter_dict(all_points, v.ref_mask))
+            n_ref = ref_pts.fxyz.shape[0]
+            ref_pts.frame_indices = torch.arange(n_ref, device=device)
+            v.has_boxes = v.frame_boxes.attr.shape[0] > 0
+            if v.has_boxes:
+                ref_bp = ops.points_in_boxes(ref_pts.fxyz[:, 1:], v.frame_boxes.attr).long()
+                ref_pts.gt_box_id = ref_bp.argmax(0)
+                ref_pts.gt_box_id[ref_bp.max(0)[0] == 0] = -1
+                v.gt_cnt = torch.bincount(ref_pts.gt_box_id[ref_pts.gt_box_id >= 0],
+                                          minlength=v.frame_boxes.attr.shape[0])
+            else:
+                ref_pts.gt_box_id = torch.zeros(n_ref, device=device).to(ref_pts.frame) - 1
+            v.ref_pts = ref_pts
+            views[fid] = v
+        return views
+
+    def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes, views=None):
         """Map tracked voxels back to the full-resolution points of each frame and update the
         per-box best IoU (cluster_tracking.py:287-428)."""
         full = {k: [] for k in ("fxyz", "component", "segmentation_label", "instance_label",
                                 "original_indices", "frame_indices", "moving")}
         transforms = extracted.pop("transforms")
-        device = all_points.fxyz.device
         num_components = int(extracted.component.max().long().item()) + 1
         comp_sg = IndexSegments(extracted.component, num_components)
         component_hit = extracted.component.new_zeros(num_components)
@@ -158,20 +186,12 @@ class ClusterTracking(nn.Module):
         size_max = segment_max(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
         component_size = size_max - size_min + 1
         ext_frame = extracted.fxyz[:, 0].round().long()
-        for fid in ext_frame.unique().tolist():
-            frame_box_mask = (seq_boxes.frame == fid).reshape(-1)
-            frame_boxes = EasyDict(filter_dict(seq_boxes, frame_box_mask))
-            ref_mask = (all_points.frame == fid).reshape(-1)
-            ref_pts = EasyDict(filter_dict(all_points, ref_mask))
-            n_ref = ref_pts.fxyz.shape[0]
-            ref_pts.frame_indices = torch.arange(n_ref, device=device).to(extracted.component)
-            has_boxes = bool(frame_box_mask.any())
-            if has_boxes:
-                ref_bp = ops.points_in_boxes(ref_pts.fxyz[:, 1:], frame_boxes.attr).long()
-                ref_pts.gt_box_id = ref_bp.argmax(0)
-                ref_pts.gt_box_id[ref_bp.max(0)[0] == 0] = -1
-            else:
-                ref_pts.gt_box_id = torch.zeros(n_ref, device=device).to(ref_pts.frame) - 1
+        frame_ids = ext_frame.unique().tolist()
+        if views is None:
+            views = self.frame_views(all_points, seq_boxes, frame_ids)
+        for fid in frame_ids:
+            v = views[fid]
+            ref_pts, frame_boxes, has_boxes = v.ref_pts, v.frame_boxes, v.has_boxes
             one = EasyDict(filter_dict(extracted, (ext_frame == fid).reshape(-1)))
 
             self.nn_graph.radius *= 1.732
@@ -192,22 +212,21 @@ class ClusterTracking(nn.Module):
                 component=one.component[e_ext],
                 segmentation_label=ref_pts.full_segmentation_label[e_ref],
                 instance_label=ref_pts.full_instance_label[e_ref],
-                frame_indices=ref_pts.frame_indices[e_ref],
-                original_indices=ref_mask.nonzero()[e_ref],
+                frame_indices=ref_pts.frame_indices[e_ref].to(extracted.component),
+                original_indices=v.ref_index[e_ref],
                 moving=one.moving[e_ext],
             ))
             for key in full:
                 full[key].append(out[key])
             if has_boxes:
                 bp = ops.points_in_boxes(out.fxyz[:, 1:], frame_boxes.attr).long()
-                gt_cnt = torch.bincount(ref_pts.gt_box_id[ref_pts.gt_box_id >= 0],
-                                        minlength=frame_boxes.attr.shape[0])
                 uniq, _, has_box, box, iou = component_box_iou(
-                    out.component, bp, ref_pts.gt_box_id[out.frame_indices], gt_cnt)
-                iou32 = iou.to(frame_boxes.best_iou.dtype)
+                    out.component, bp, ref_pts.gt_box_id[e_ref], v.gt_cnt)
+                best_iou = seq_boxes.best_iou[v.frame_box_mask]
+                iou32 = iou.to(best_iou.dtype)
                 component_hit[uniq[has_box & (iou32 > 0.7)]] += 1
-                scatter_max_(frame_boxes.best_iou, box[has_box], iou32[has_box])
-            seq_boxes.best_iou[frame_box_mask] = frame_boxes.best_iou
+                scatter_max_(best_iou, box[has_box], iou32[has_box])
+                seq_boxes.best_iou[v.frame_box_mask] = best_iou
         full = EasyDict({k: torch.cat(v, dim=0) for k, v in full.items()})
         full.component_hit = component_hit
         full.component_size = component_size
@@ -507,6 +526,8 @@ class ClusterTracking(nn.Module):
                 if frame_id in present:
                     units.append((comp_key, frame_id))
 
+        views = self.frame_views(all_points, seq_boxes, sorted(set(seq_points.frame.reshape(-1).long().unique().tolist())))
+
         def run_unit(worker, comp_key, frame_id):
             sp = EasyDict(dict(key_points[comp_key]))
             sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
@@ -519,7 +540,7 @@ class ClusterTracking(nn.Module):
                 extracted = worker.track_frame(sp, frame_points, boxes)
             with Timer("Extract Traces from all points"), Timer(f"unit {comp_key}@{frame_id} extract"):
                 if extracted.fxyz.shape[0] > 0:
-                    extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes)
+                    extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes, views)
             return extracted, boxes.best_iou
 
         n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 9)), len(units)))
@@ -548,6 +569,12 @@ class ClusterTracking(nn.Module):
                 w.num_registration_calls = 0
                 w._stream.wait_stream(main_stream)
                 free.put(w)
+            # The stage ends with its longest unit (an anchor in mid-sequence is tracked through
+            # twice as many frames as one at either end): longest first. (High-priority HIP streams
+            # for the long units were measured and made every unit slower.)
+            span = {u: min(num_frames - 1, u[1] + self.track_interval) - max(0, u[1] - self.track_interval)
+                    for u in units}
+            order = sorted(units, key=lambda u: -span[u])
 
             def job(comp_key, frame_id):
                 w = free.get()
@@ -560,7 +587,7 @@ class ClusterTracking(nn.Module):
                     free.put(w)
 
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
-                futs = {u: pool.submit(job, *u) for u in units}
+                futs = {u: pool.submit(job, *u) for u in order}
                 for (comp_key, frame_id), fut in futs.items():
                     ex, biou = fut.result()
                     results[(frame_id, comp_key)] = ex

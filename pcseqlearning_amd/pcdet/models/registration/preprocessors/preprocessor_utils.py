@@ -13,6 +13,7 @@ import torch
 
 from ..... import ops
 from ....utils.common_utils import EasyDict, filter_dict
+from ....utils.timer import Timer
 from ...model_utils.grid_sampling import GridSampling3D
 from .registration_utils import IndexSegments, efficient_robust_sum, robust_mean, segment_max, segment_min
 
@@ -86,6 +87,8 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     npil.best_normal[:, -1] = 1.0
     npil.best_center = npil.min_z.new_zeros(num_new, 3)
 
+    t_fit = Timer("ground: plane hypotheses (IRLS x 30 ratios)")
+    t_fit.__enter__()
     sigma = cfg["SIGMA2"] ** 0.5
     origin = robust_mean(nv.bxyz[:, 1:4], sg, num_new)
     # rows are sorted by super-pillar: dense row ranges for the one-launch-per-round plane fit
@@ -105,6 +108,9 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
             npil.best_center[better] = npil.center[better]
             npil.best_confidence[better] = num_hit[better]
 
+    t_fit.__exit__(None, None, None)
+    t_tls = Timer("ground: hypothesis pruning (100 thresholds)")
+    t_tls.__enter__()
     # "truncated least squares": drop hypotheses whose 8-NN mean curvature exceeds a shrinking bound
     xyz, normal, conf = npil.best_center, npil.best_normal, npil.best_confidence
     for threshold in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100):
@@ -118,6 +124,9 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
         keep = mean_curv < threshold
         xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
     conf[:] = 1
+    t_tls.__exit__(None, None, None)
+    t_prop = Timer("ground: propagation to pillars")
+    t_prop.__enter__()
 
     # every pillar takes the hypothesis with the best confidence / (distance + 1), in list order
     for idx in range(conf.shape[0]):
@@ -128,6 +137,7 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
         pillars.best_normal[mask] = normal[idx]
         pillars.best_confidence[mask] = ind[mask]
 
+    t_prop.__exit__(None, None, None)
     vn = pillars.best_normal[voxels.pillar_idx]
     vc = pillars.best_center[voxels.pillar_idx]
     vd = voxels.bxyz[:, 1:] - vc
@@ -169,8 +179,9 @@ def ground_plane_removal(point_bxyz, cfg, warmup=None):
     points = EasyDict(bxyz=point_bxyz)
     pillar_size = torch.tensor(cfg["PILLAR_SIZE"]).to(points.bxyz)
     pc_range_min = points.bxyz[:, 1:3].min(0)[0] - 0.05
-    voxels, point_voxel_index = grid_sample(points.bxyz, [0.10, 0.10, 0.03])
-    pillar_dims, num_pillars, voxels, pillars = format_pillars(voxels, pillar_size, pc_range_min)
+    with Timer("ground: grid sample + pillars"):
+        voxels, point_voxel_index = grid_sample(points.bxyz, [0.10, 0.10, 0.03])
+        pillar_dims, num_pillars, voxels, pillars = format_pillars(voxels, pillar_size, pc_range_min)
     if warmup is not None:
         pillars.height = warmup["pillar_height"]
         pillars.min_z = warmup["pillar_min_z"]
@@ -178,7 +189,8 @@ def ground_plane_removal(point_bxyz, cfg, warmup=None):
         if cfg.get("RANSAC", False):
             voxels, pillars = compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cfg)
         if cfg.get("JointOpt", False):
-            pillars = l1_minimization(voxels, pillars, pillar_dims, cfg)
+            with Timer("ground: l1 minimization"):
+                pillars = l1_minimization(voxels, pillars, pillar_dims, cfg)
     ij = (voxels.pillar_coords[:, 0], voxels.pillar_coords[:, 1])
     voxel_height = pillars.height[ij]
     voxel_min_z = pillars.min_z[ij]

@@ -6,13 +6,14 @@ import time
 import torch
 
 VERBOSE = False
+SYNC = False  # synchronise the device around every span (stage-time tooling)
 RECORDS = {}
 
 
 class Timer:
     def __init__(self, name, sync=False):
         self.name = name
-        self.sync = sync or VERBOSE
+        self.sync = sync or VERBOSE or SYNC
 
     def __enter__(self):
         if self.sync and torch.cuda.is_available():

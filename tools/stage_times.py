@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--units", action="store_true", help="print the per-unit track / extract spans")
+    ap.add_argument("--detail", action="store_true", help="device-synchronised spans inside the stages")
     args = ap.parse_args()
+    timer.SYNC = args.detail
     batch = bench.load_sequence(0, 20, 160000)
     model = build_model(streams=args.streams)
     batch = models.load_data_to_gpu(batch)
@@ -57,6 +59,10 @@ def main():
         trk = sum(v for k, v in timer.RECORDS.items() if k.startswith("Tracking Frame"))
         ext = timer.RECORDS.get("Extract Traces from all points", 0.0)
         print(f"   sum over units: track_frame {trk * 1e3:.1f} ms, extract traces {ext * 1e3:.1f} ms")
+        if args.detail:
+            for k in sorted(timer.RECORDS):
+                if not k.startswith(("unit ", "Tracking Frame", "REGISTRATION")):
+                    print(f"      {k:44s} {timer.RECORDS[k] * 1e3:8.1f} ms")
         if args.units:
             for k in sorted(timer.RECORDS):
                 if k.startswith("unit "):
