@@ -93,16 +93,19 @@ class ClusterProposal(nn.Module):
             min_frame=seq_boxes.trace_id.new_zeros(num_traces),
             max_frame=seq_boxes.trace_id.new_zeros(num_traces),
         ))
-        for t in range(num_traces):
-            tm = (seq_boxes.trace_id == t).reshape(-1)
-            if bool(tm.any()):
-                traces.min_frame[t] = seq_boxes.frame[tm].min().long()
-                traces.max_frame[t] = seq_boxes.frame[tm].max().long()
+        tid = seq_boxes.trace_id.long()
+        fr = seq_boxes.frame.to(traces.min_frame.dtype)
+        present = torch.zeros(num_traces, dtype=torch.bool, device=tid.device)
+        present[tid] = True
+        lo = torch.full_like(traces.min_frame, torch.iinfo(traces.min_frame.dtype).max)
+        traces.min_frame = torch.where(present, lo.scatter_reduce(0, tid, fr, reduce="amin"), traces.min_frame)
+        traces.max_frame = torch.where(present, torch.zeros_like(lo).scatter_reduce(0, tid, fr, reduce="amax",
+                                                                                  include_self=False),
+                                       traces.max_frame)
 
         # The box membership of the points does not depend on the component key: frames outermost,
         # points_in_boxes / GT ids once per frame, then the per-key component statistics. best_iou is a
         # running maximum, so the per-key snapshots are cumulative maxima in key order.
-        n_pts = seq_dict["point_fxyz"].shape[0]
         fxyz = seq_dict["point_fxyz"]
         proto = seq_dict[f"point_{self.component_keys[0]}"]
         gt_box_id = torch.zeros_like(proto) - 1

@@ -113,30 +113,42 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     t_tls.__enter__()
     # "truncated least squares": drop hypotheses whose 8-NN mean curvature exceeds a shrinking bound
     xyz, normal, conf = npil.best_center, npil.best_normal, npil.best_confidence
-    for threshold in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100):
+
+    def mean_curvature(xyz, normal):
+        if xyz.shape[0] == 0:
+            return xyz.new_zeros(0), float("-inf")
         e0, e1, k = _knn_self(xyz, cfg["K"])
         diff = xyz[e1] - xyz[e0]
         p2p = (diff * normal[e0]).sum(dim=-1).abs()
         curvature = p2p / (diff.norm(p=2, dim=-1) + 1e-4)
         mean_curv = curvature.reshape(-1, k).mean(-1)
-        if threshold > mean_curv.max():
+        return mean_curv, float(mean_curv.max().item())
+
+    # the k-NN curvature only changes when a hypothesis is dropped: evaluated once per pruning
+    # event, not once per threshold (the reference recomputes it for each of the 100 thresholds)
+    mean_curv, max_curv = mean_curvature(xyz, normal)
+    for threshold in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100):
+        if np.float32(threshold) > np.float32(max_curv):  # fp32, like the tensor comparison it replaces
             continue
         keep = mean_curv < threshold
         xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+        mean_curv, max_curv = mean_curvature(xyz, normal)
     conf[:] = 1
     t_tls.__exit__(None, None, None)
     t_prop = Timer("ground: propagation to pillars")
     t_prop.__enter__()
 
-    # every pillar takes the hypothesis with the best confidence / (distance + 1), in list order
-    for idx in range(conf.shape[0]):
-        dist = (pillars.xyz[:, :2] - xyz[idx, :2]).norm(p=2, dim=-1)
-        ind = conf[idx] / (dist + 1)
-        mask = ind > pillars.best_confidence
-        pillars.best_center[mask] = xyz[idx]
-        pillars.best_normal[mask] = normal[idx]
-        pillars.best_confidence[mask] = ind[mask]
-
+    # every pillar takes the hypothesis with the best confidence / (distance + 1); the reference
+    # scans the hypotheses in list order with a strict '>' update, i.e. the FIRST maximum wins:
+    # one [pillars, hypotheses] table and a first-occurrence max
+    if conf.shape[0] > 0:
+        dist = (pillars.xyz[:, None, :2] - xyz[None, :, :2]).norm(p=2, dim=-1)
+        ind = conf[None, :] / (dist + 1)
+        best_val, best_idx = ind.max(dim=1)
+        mask = best_val > pillars.best_confidence
+        pillars.best_center[mask] = xyz[best_idx[mask]]
+        pillars.best_normal[mask] = normal[best_idx[mask]]
+        pillars.best_confidence[mask] = best_val[mask]
     t_prop.__exit__(None, None, None)
     vn = pillars.best_normal[voxels.pillar_idx]
     vc = pillars.best_center[voxels.pillar_idx]
