@@ -317,6 +317,20 @@ int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_
                               int max_rounds, float* plane, float* plane_err, int32_t* d_rounds,
                               void* ws, size_t ws_bytes, pcs_stream_t stream);
 
+/* The hypothesis loop of compute_min_height_from_ransac, preprocessor_utils.py:120-135: for each of
+ * R height ratios (HOST float array, R <= 64) the plane fit above from the initial weights
+ * sigma2 / ((min_z*ratio + max_z*(1-ratio) - z)^2 + sigma2), its hit count per pillar (rows with
+ * point-plane error < hit_below) and, per pillar, the first ratio with the most hits. The R fits run
+ * side by side (grid = pillars x ratios, one launch per round). min_z / max_z [P]; outputs
+ * best_center / best_normal [P,3] (defaults 0 / (0,0,1) when nothing hits), best_conf [P]. */
+size_t pcs_ransac_plane_hypotheses_workspace_bytes(int64_t n, int64_t P, int R);
+int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n,
+                                const float* min_z, const float* max_z, const float* ratios, int R,
+                                const float* origin, int64_t P, float sigma2, float stopping_delta,
+                                int max_rounds, float hit_below, float* best_center,
+                                float* best_normal, float* best_conf, void* ws, size_t ws_bytes,
+                                pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

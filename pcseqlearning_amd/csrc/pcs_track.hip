@@ -726,17 +726,27 @@ struct IrlsSegState {
 };
 
 __global__ void irls_seg_init_kernel(IrlsSegState* st) {
+  st += blockIdx.x;
   int i = threadIdx.x;
   if (i == 0) { st->stop_round = 0x7fffffff; st->rounds = 0; st->final_buf = 0; st->pad = 0; }
   if (i < kIrlsMaxRounds + 2) st->dw[i] = 0;
 }
 
 // round r (1-based); r == max_rounds + 1 with check_only: only the convergence test of the last round
+// gridDim.y independent fits share xyz / seg_start / origin (the 30 height ratios of
+// compute_min_height_from_ransac, preprocessor_utils.py:120-135): fit y has its own weights
+// w[y*n..], planes, state; with `ratios` != nullptr its initial weights are formed here from
+// cur_z = min_z * ratio + max_z * (1 - ratio) instead of being read from w.
 __global__ void __launch_bounds__(kBlock)
 irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
                       const int32_t* __restrict__ seg_start, const float* __restrict__ origin,
                       float sigma2, float delta, float* __restrict__ w, float* __restrict__ planes,
-                      int64_t P, IrlsSegState* __restrict__ st) {
+                      int64_t P, IrlsSegState* __restrict__ st, int64_t n,
+                      const float* __restrict__ ratios, const float* __restrict__ min_z,
+                      const float* __restrict__ max_z) {
+  st += blockIdx.y;
+  w += (size_t)blockIdx.y * n;
+  planes += (size_t)blockIdx.y * P * 12;
   if (r > st->stop_round) return;
   float* plane_prev = planes + (size_t)((r - 1) & 1) * P * 6;  // plane of round r-1
   float* plane_cur = planes + (size_t)(r & 1) * P * 6;         // plane of round r (and of r-2)
@@ -761,9 +771,23 @@ irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
 #pragma unroll
   for (int q = 0; q < 11; ++q) v[q] = 0.0;
   float dw = 0.f;
+  float cur_z = 0.f;
+  const bool from_ratio = ratios != nullptr && r == 1;
+  if (from_ratio) {
+    float ratio = ratios[blockIdx.y];
+    float omr = (float)(1.0 - (double)ratio);  // Python forms 1 - ratio in double
+    cur_z = min_z[c] * ratio + max_z[c] * omr;
+  }
   for (int i = b + (int)threadIdx.x; i < e; i += kBlock) {
     float x = xyz[(int64_t)i * 3], y = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
-    float wi = w[i];
+    float wi;
+    if (from_ratio) {
+      float zd = cur_z - z;
+      wi = (1.f / (zd * zd + sigma2)) * sigma2;  // scalar / tensor is reciprocal() * scalar in torch
+      w[i] = wi;
+    } else {
+      wi = w[i];
+    }
     if (r > 1) {
       float dx = x - pl[0], dy = y - pl[1], dz = z - pl[2];
       float er = fabsf(dx * pl[3] + dy * pl[4] + dz * pl[5]);
@@ -826,11 +850,16 @@ irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
   }
 }
 
-// result plane -> caller's buffer, point-plane error of every row against it
+// result plane -> caller's buffer, point-plane error of every row against it; with `num_hit`
+// also the rows of the pillar whose error is below `hit_below` (the hypothesis' confidence)
 __global__ void __launch_bounds__(kBlock)
 irls_seg_finish_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ seg_start, int64_t P,
                        const float* __restrict__ planes, const IrlsSegState* __restrict__ st,
-                       float* __restrict__ plane_out, float* __restrict__ perr) {
+                       float* __restrict__ plane_out, float* __restrict__ perr, float hit_below,
+                       float* __restrict__ num_hit) {
+  st += blockIdx.y;
+  planes += (size_t)blockIdx.y * P * 12;
+  plane_out += (size_t)blockIdx.y * P * 6;
   const int c = blockIdx.x;
   const float* pl = planes + (size_t)st->final_buf * P * 6 + (int64_t)c * 6;
   float q[6];
@@ -838,10 +867,47 @@ irls_seg_finish_kernel(const float* __restrict__ xyz, const int32_t* __restrict_
   for (int k = 0; k < 6; ++k) q[k] = pl[k];
   if (threadIdx.x < 6) plane_out[(int64_t)c * 6 + threadIdx.x] = q[threadIdx.x];
   const int b = seg_start[c], e = seg_start[c + 1];
+  int hits = 0;
   for (int i = b + (int)threadIdx.x; i < e; i += kBlock) {
     float dx = xyz[(int64_t)i * 3] - q[0], dy = xyz[(int64_t)i * 3 + 1] - q[1], dz = xyz[(int64_t)i * 3 + 2] - q[2];
-    perr[i] = fabsf(dx * q[3] + dy * q[4] + dz * q[5]);
+    float er = fabsf(dx * q[3] + dy * q[4] + dz * q[5]);
+    if (perr) perr[i] = er;
+    hits += er < hit_below;
   }
+  if (num_hit) {
+    __shared__ int sh[kBlock / 64];
+    hits = wave_sum_i32(hits);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < kBlock / 64; ++k) t += sh[k];
+      num_hit[(size_t)blockIdx.y * P + c] = (float)t;
+    }
+  }
+}
+
+// sequential choice over the fits in order: a later fit replaces the best only with strictly
+// more hits (preprocessor_utils.py:131-135)
+__global__ void __launch_bounds__(kBlock)
+irls_select_kernel(int R, int64_t P, const float* __restrict__ planes_out,
+                   const float* __restrict__ num_hit, float* __restrict__ best_center,
+                   float* __restrict__ best_normal, float* __restrict__ best_conf) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= P) return;
+  float conf = 0.f;
+  float ctr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 1.f};
+  for (int y = 0; y < R; ++y) {
+    float h = num_hit[(size_t)y * P + c];
+    if (conf < h) {
+      conf = h;
+      const float* pl = planes_out + ((size_t)y * P + c) * 6;
+      ctr[0] = pl[0]; ctr[1] = pl[1]; ctr[2] = pl[2];
+      nrm[0] = pl[3]; nrm[1] = pl[4]; nrm[2] = pl[5];
+    }
+  }
+  best_conf[c] = conf;
+  for (int k = 0; k < 3; ++k) { best_center[c * 3 + k] = ctr[k]; best_normal[c * 3 + k] = nrm[k]; }
 }
 
 // points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168: serial
@@ -1008,12 +1074,66 @@ int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_
   irls_seg_init_kernel<<<1, 64, 0, s>>>(st);
   for (int r = 1; r <= max_rounds; ++r)
     irls_seg_round_kernel<<<(int)P, kBlock, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta,
-                                                    w, planes, P, st);
+                                                    w, planes, P, st, n, nullptr, nullptr, nullptr);
   irls_seg_round_kernel<<<1, 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin, sigma2,
-                                         stopping_delta, w, planes, P, st);
-  irls_seg_finish_kernel<<<(int)P, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, plane, plane_err);
+                                         stopping_delta, w, planes, P, st, n, nullptr, nullptr, nullptr);
+  irls_seg_finish_kernel<<<(int)P, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, plane, plane_err, 0.f,
+                                                   nullptr);
   if (d_rounds)
     PCS_CHECK_HIP(hipMemcpyAsync(d_rounds, &st->rounds, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+size_t pcs_ransac_plane_hypotheses_workspace_bytes(int64_t n, int64_t P, int R) {
+  Arena a(nullptr, 0);
+  if (R < 1) R = 1;
+  a.take<IrlsSegState>(R);
+  a.take<float>((size_t)R * (P > 0 ? P : 1) * 12);
+  a.take<float>((size_t)R * (n > 0 ? n : 1));
+  a.take<float>((size_t)R * (P > 0 ? P : 1) * 6);
+  a.take<float>((size_t)R * (P > 0 ? P : 1));
+  a.take<float>(R);
+  return a.off;
+}
+
+// The hypothesis loop of compute_min_height_from_ransac (preprocessor_utils.py:120-135): for every
+// height ratio (HOST array, R <= 64) the IRLS plane fit of every pillar from the initial weights
+// sigma2 / ((min_z*ratio + max_z*(1-ratio) - z)^2 + sigma2), its hit count (rows with point-plane
+// error < hit_below), and per pillar the first fit with the most hits. The R fits are independent
+// and run side by side: one launch per round for all of them (grid = pillars x ratios).
+int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n,
+                                const float* min_z, const float* max_z, const float* ratios, int R,
+                                const float* origin, int64_t P, float sigma2, float stopping_delta,
+                                int max_rounds, float hit_below, float* best_center,
+                                float* best_normal, float* best_conf, void* ws, size_t ws_bytes,
+                                hipStream_t s) {
+  if (!xyz || !seg_start || !min_z || !max_z || !ratios || !origin || !best_center || !best_normal ||
+      !best_conf || !ws || n < 1 || P < 1 || R < 1 || R > 64 || max_rounds < 1 ||
+      max_rounds > kIrlsMaxRounds)
+    return PCS_ERR_ARG;
+  if (P >= 65536 * 16 || n >= (1LL << 31)) return PCS_ERR_RANGE;
+  Arena a(ws, ws_bytes);
+  IrlsSegState* st = a.take<IrlsSegState>(R);
+  float* planes = a.take<float>((size_t)R * P * 12);
+  float* w = a.take<float>((size_t)R * n);
+  float* planes_out = a.take<float>((size_t)R * P * 6);
+  float* num_hit = a.take<float>((size_t)R * P);
+  float* d_ratios = a.take<float>(R);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemcpyAsync(d_ratios, ratios, (size_t)R * sizeof(float), hipMemcpyHostToDevice, s));
+  irls_seg_init_kernel<<<R, 64, 0, s>>>(st);
+  dim3 grid((unsigned)P, (unsigned)R);
+  for (int r = 1; r <= max_rounds; ++r)
+    irls_seg_round_kernel<<<grid, kBlock, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta, w,
+                                                  planes, P, st, n, d_ratios, min_z, max_z);
+  irls_seg_round_kernel<<<dim3(1, (unsigned)R), 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin,
+                                                            sigma2, stopping_delta, w, planes, P, st, n,
+                                                            d_ratios, min_z, max_z);
+  irls_seg_finish_kernel<<<grid, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, planes_out, nullptr,
+                                                 hit_below, num_hit);
+  irls_select_kernel<<<grid_for(P), kBlock, 0, s>>>(R, P, planes_out, num_hit, best_center, best_normal,
+                                                    best_conf);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

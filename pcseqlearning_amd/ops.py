@@ -456,6 +456,31 @@ def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_de
     return plane[:, :3], plane[:, 3:], perr
 
 
+def ransac_plane_hypotheses(xyz, seg_start, min_z, max_z, ratios, origin, sigma2, stopping_delta=1e-2,
+                            max_rounds=50, hit_below=None):
+    """All height-ratio hypotheses of compute_min_height_from_ransac in one call (the R IRLS fits run
+    side by side). Returns (best_center [P,3], best_normal [P,3], best_confidence [P])."""
+    L.require_gpu(xyz, "ransac_plane_hypotheses")
+    lib = L.load()
+    xyz = xyz.float().contiguous()
+    n, P, R = xyz.shape[0], min_z.shape[0], len(ratios)
+    assert seg_start.dtype == torch.int32 and seg_start.shape[0] == P + 1
+    dev = xyz.device
+    center = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    normal = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    conf = torch.empty(P, dtype=torch.float32, device=dev)
+    if hit_below is None:
+        hit_below = float(sigma2) ** 0.5
+    ws = L.workspace(lib.pcs_ransac_plane_hypotheses_workspace_bytes(L.i64(n), L.i64(P), L.i32(R)), dev)
+    L.check(lib.pcs_ransac_plane_hypotheses(
+        L.ptr(xyz), L.ptr(seg_start.contiguous()), L.i64(n), L.ptr(min_z.float().contiguous()),
+        L.ptr(max_z.float().contiguous()), L.host_floats(ratios), L.i32(R), L.ptr(origin.float().contiguous()),
+        L.i64(P), L.f32(sigma2), L.f32(stopping_delta), L.i32(max_rounds), L.f32(hit_below),
+        L.ptr(center), L.ptr(normal), L.ptr(conf), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+        "pcs_ransac_plane_hypotheses")
+    return center, normal, conf
+
+
 # ---------------------------------------------------------------- native tracker
 class TrackParams(__import__("ctypes").Structure):
     """Mirror of PcsTrackParams (include/pcs.h)."""

@@ -156,10 +156,24 @@ class ClusterProposal(nn.Module):
             seq_dict[f"point_{key}"] = seq_points[key]
         return seq_dict
 
+    EVAL_KEYS = ("point_gt_box_id", "point_gt_trace_id", "point_pred_trace_id", "point_pred_box_id",
+                 "gt_box_best_iou", "gt_trace_best_iou")
+
     def forward(self, seq_dict):
         seq_dict = self.propose_cluster(seq_dict)
-        with Timer("Evaluate Proposal"):
-            seq_dict = self.evaluate_proposal(seq_dict)
+        if not self.model_cfg.get("DEFER_EVALUATION", True):
+            with Timer("Evaluate Proposal"):
+                return self.evaluate_proposal(seq_dict)
+        # No later stage reads the evaluation's outputs: parked for run_deferred (ClusterTracking runs
+        # it on the main thread while its units track in native code; SimpleReg runs what is left).
+        snapshot = EasyDict(dict(seq_dict))
+
+        def evaluate():
+            with Timer("Evaluate Proposal"):
+                out = self.evaluate_proposal(snapshot)
+            return {k: out[k] for k in self.EVAL_KEYS if k in out}
+
+        seq_dict.setdefault("_deferred", []).append(evaluate)
         return seq_dict
 
     def get_output_feature_dim(self):

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ..... import ops
 from .....lib import PcsError
-from ....utils.common_utils import EasyDict, filter_dict
+from ....utils.common_utils import EasyDict, filter_dict, run_deferred
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
@@ -471,8 +471,9 @@ class ClusterTracking(nn.Module):
         seq_points = EasyDict(
             fxyz=seq_dict["point_fxyz"],
             frame=seq_dict["point_sweep"],
-            gt_box_id=seq_dict["point_gt_box_id"],
         )
+        if "point_gt_box_id" in seq_dict:  # absent while ClusterProposal's evaluation is deferred
+            seq_points.gt_box_id = seq_dict["point_gt_box_id"]
         for key in ("instance_label", "segmentation_label"):
             if key in seq_dict:
                 seq_points[key] = seq_dict[key]
@@ -588,6 +589,9 @@ class ClusterTracking(nn.Module):
 
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
                 futs = {u: pool.submit(job, *u) for u in order}
+                # the units are now in native code on their own threads: the main thread does the
+                # parked host-side work (ClusterProposal's evaluation) meanwhile
+                run_deferred(seq_dict)
                 for (comp_key, frame_id), fut in futs.items():
                     ex, biou = fut.result()
                     results[(frame_id, comp_key)] = ex

@@ -94,20 +94,26 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     # rows are sorted by super-pillar: dense row ranges for the one-launch-per-round plane fit
     seg_start = torch.searchsorted(nv.pillar_idx.contiguous(),
                                    torch.arange(num_new + 1, device=dev)).int()
-    for ratio in torch.linspace(0.3, 1, 30).tolist():
-        cur_z = npil.min_z * ratio + npil.max_z * (1 - ratio)
-        z_diff = cur_z[nv.pillar_idx] - z
-        w0 = (cfg["SIGMA2"] / (z_diff.square() + cfg["SIGMA2"])).reshape(-1, 1)
-        nv, npil = iterative_reweighted_ransac(nv, npil, w0, num_new, sigma2=cfg["SIGMA2"], sg=sg,
-                                               origin=origin, seg_start=seg_start)
-        hit = (nv.plane_fitting_error < sigma).float()
-        num_hit = _seg_sum(hit, sg, num_new)
-        better = npil.best_confidence < num_hit
-        if bool(better.any()):
-            npil.best_normal[better] = npil.normal[better]
-            npil.best_center[better] = npil.center[better]
-            npil.best_confidence[better] = num_hit[better]
-
+    ratios = torch.linspace(0.3, 1, 30).tolist()
+    if cfg.get("BATCHED_HYPOTHESES", True):
+        # the 30 fits are independent: side by side in one call (pcs_ransac_plane_hypotheses)
+        npil.best_center, npil.best_normal, npil.best_confidence = ops.ransac_plane_hypotheses(
+            nv.bxyz[:, 1:4], seg_start, npil.min_z, npil.max_z, ratios, origin, cfg["SIGMA2"],
+            hit_below=sigma)
+    else:
+        for ratio in ratios:
+            cur_z = npil.min_z * ratio + npil.max_z * (1 - ratio)
+            z_diff = cur_z[nv.pillar_idx] - z
+            w0 = (cfg["SIGMA2"] / (z_diff.square() + cfg["SIGMA2"])).reshape(-1, 1)
+            nv, npil = iterative_reweighted_ransac(nv, npil, w0, num_new, sigma2=cfg["SIGMA2"], sg=sg,
+                                                   origin=origin, seg_start=seg_start)
+            hit = (nv.plane_fitting_error < sigma).float()
+            num_hit = _seg_sum(hit, sg, num_new)
+            better = npil.best_confidence < num_hit
+            if bool(better.any()):
+                npil.best_normal[better] = npil.normal[better]
+                npil.best_center[better] = npil.center[better]
+                npil.best_confidence[better] = num_hit[better]
     t_fit.__exit__(None, None, None)
     t_tls = Timer("ground: hypothesis pruning (100 thresholds)")
     t_tls.__enter__()

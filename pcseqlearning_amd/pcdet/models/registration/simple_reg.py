@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
-from ...utils.common_utils import EasyDict, filter_dict
+from ...utils.common_utils import EasyDict, filter_dict, run_deferred
 from ..model_utils.grid_sampling import GridSampling3D
 from .registration_module_template import RegistrationTemplate
 
@@ -38,7 +38,7 @@ class SimpleReg(RegistrationTemplate):
     def process_sequence(self, seq_dict):
         for module in self.preprocessors or []:
             seq_dict = module(seq_dict)
-        return seq_dict
+        return run_deferred(seq_dict)
 
     def format_boxes(self, seq_dict):
         """Frame ids of the (frame-major, equally many per frame) GT boxes, track labels from the

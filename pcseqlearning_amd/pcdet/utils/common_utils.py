@@ -39,3 +39,13 @@ def filter_dict(data_dict, mask, ignore_keys=()):
 def indexing_list_elements(data_dict, idx):
     """Pick element idx of every list-valued entry (graph configs with per-level lists)."""
     return {k: (v[idx] if isinstance(v, list) else v) for k, v in data_dict.items()}
+
+
+def run_deferred(data_dict):
+    """Run the side computations a module parked under `_deferred` (callables returning a dict of
+    new entries) and merge their results. A module defers work whose results no later stage
+    consumes (the GT-evaluation side channel of ClusterProposal), so that the main thread can do it
+    while the tracking units run in native code on their own threads and streams."""
+    for fn in data_dict.pop("_deferred", []):
+        data_dict.update(fn())
+    return data_dict

@@ -95,3 +95,47 @@ def test_l1_minimization_vs_torch_adamw():
     # sign() kinks make individual trajectories diverge slightly; the optimum they reach agrees
     assert (got - h.data).abs().mean() < 5e-3, (got - h.data).abs().mean()
     assert (got - h.data).abs().max() < 5e-2, (got - h.data).abs().max()
+
+
+def test_ransac_plane_hypotheses_batched_vs_loop():
+    """pcs_ransac_plane_hypotheses (30 fits side by side + hit counts + first-best selection) against
+    the reference-shaped loop over ratios on the one-fit-at-a-time kernels: identical."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    P, pts, idx = 50, [], []
+    for p in range(P):
+        per = int(torch.randint(0, 900, (1,), generator=g)) if p % 7 else 0   # some empty pillars
+        xy = torch.rand(per, 2, generator=g) * 8 + torch.tensor([8.0 * (p % 8), 8.0 * (p // 8)])
+        z = 0.02 * xy[:, 0] + torch.randn(per, generator=g) * 0.02
+        z[: per // 4] += torch.rand(per // 4, generator=g) * 3.0
+        pts.append(torch.cat([xy, z[:, None]], 1)); idx.append(torch.full((per,), p))
+    xyz = torch.cat(pts).float().to(DEV)
+    pidx = torch.cat(idx).long().to(DEV)
+    n = xyz.shape[0]
+    seg_start = torch.searchsorted(pidx, torch.arange(P + 1, device=DEV)).int()
+    cnt = (seg_start[1:] - seg_start[:-1]).clamp(min=1).float()
+    origin = torch.zeros(P, 3, device=DEV).index_add_(0, pidx, xyz) / cnt[:, None]
+    z = xyz[:, 2]
+    min_z = torch.full((P,), float("inf"), device=DEV).scatter_reduce(0, pidx, z, reduce="amin")
+    max_z = torch.full((P,), float("-inf"), device=DEV).scatter_reduce(0, pidx, z, reduce="amax")
+    min_z[min_z == float("inf")] = 0
+    max_z[max_z == float("-inf")] = 0
+    sigma2 = 0.0025
+    sigma = sigma2 ** 0.5
+    ratios = torch.linspace(0.3, 1, 30).tolist()
+    bc = torch.zeros(P, 3, device=DEV); bn = torch.zeros(P, 3, device=DEV); bn[:, 2] = 1.0
+    bconf = torch.zeros(P, device=DEV)
+    for ratio in ratios:
+        cur_z = min_z * ratio + max_z * (1 - ratio)
+        zd = cur_z[pidx] - z
+        w0 = sigma2 / (zd.square() + sigma2)
+        c, nrm, err = ops.irls_plane_fit(xyz, pidx, w0, origin, P, sigma2, seg_start=seg_start)
+        num_hit = torch.zeros(P, device=DEV).index_add_(0, pidx, (err < sigma).float())
+        better = bconf < num_hit
+        bn[better] = nrm[better]; bc[better] = c[better]; bconf[better] = num_hit[better]
+    gc, gn, gconf = ops.ransac_plane_hypotheses(xyz, seg_start, min_z, max_z, ratios, origin, sigma2,
+                                                hit_below=sigma)
+    # same kernels, but the initial weights are formed in the kernel instead of by torch ops
+    # (1-ulp differences): float tolerance, and the hit counts may differ for a rare borderline row
+    assert (gconf - bconf).abs().max() <= 2 and (gconf != bconf).float().mean() < 0.1
+    assert torch.allclose(gc, bc, atol=2e-4) and torch.allclose(gn, bn, atol=2e-4)
+    assert n > 0 and (bconf > 0).sum() > P // 2
