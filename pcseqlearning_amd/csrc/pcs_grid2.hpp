@@ -1,30 +1,33 @@
-// Two-level cell grid for the fused ICP's 1-NN searches (pcs_icp.hip).
+// Two-level cell grid for the 1-NN searches of the fused ICP (pcs_icp.hip), the sorted 1-NN radius
+// graph (pcs_radius_graph.hip) and the tracker's harvest.
 //
-// Points are counting-sorted into FINE cells of size h (contiguous storage: a candidate cell is one
-// coalescable run of float4 rows, loads are independent of each other -- no pointer chasing), and a
-// COARSE table of 4x4x4-fine-cell blocks keeps a 64-bit occupancy mask per block. With
+// FINE cells of size h live in an open-addressing table; every fine slot owns a fixed run of
+// kCellCap rows of the point array (a candidate cell is one coalescable run of float4 rows, no
+// pointer chasing), so the whole build is ONE kernel: claim the slot, take a position with an
+// atomic counter, store the point. Cells that fill up spill into a small overflow list that every
+// query scans (voxel-subsampled clouds put a handful of points in a cell: the list is normally
+// empty). A COARSE table of 4x4x4-fine-cell blocks keeps a 64-bit occupancy mask per block. With
 // h = (spatial radius)/4 a query's whole search ball lies inside its 3x3x3 coarse neighbourhood, so
-// the expanding-ring walk tests 27 masks held in registers and touches memory only for occupied
-// fine cells; a query with nothing around it leaves after the 27 mask loads.
-//
-// Build = clear + count kernel (fine CAS + counter, coarse CAS + atomicOr) + alloc kernel (one
-// cursor atomic per occupied fine slot) + fill kernel. Order inside a cell is arbitrary (atomic cursor); the search
-// result does not depend on it because ties resolve by (dist2, original index).
+// a query tests 27 masks held in registers and touches memory only for occupied fine cells.
+// Order inside a cell is arbitrary (atomic counter); the search result does not depend on it
+// because ties resolve by (dist2, original index).
 #pragma once
 #include "pcs_grid.hpp"
 
 namespace pcs {
 
+constexpr int kCellCap = 16;
+
 struct Grid2 {
   uint64_t* fkeys;   // [Hf] fine cell keys
-  int32_t* fcount;   // [Hf] points per fine slot
-  int32_t* fstart;   // [Hf] exclusive prefix of fcount
-  int32_t* fcursor;  // [Hf] fill cursor
+  int32_t* fcount;   // [Hf] points inserted into the fine slot (may exceed kCellCap: the rest spilled)
   uint64_t* ckeys;   // [Hc] coarse block keys
   uint64_t* cmask;   // [Hc] occupancy of the 64 fine cells of the block
-  float4* spts;      // [N] points in cell order
-  int32_t* sidx;     // [N] original index of spts rows
-  int32_t* pslot;    // [N] fine slot of every original point
+  float4* spts;      // [Hf * kCellCap] points, slot-major
+  int32_t* sidx;     // [Hf * kCellCap] original index of spts rows
+  int32_t* ovf;      // [1] number of spilled points
+  float4* ovf_pts;   // [N]
+  int32_t* ovf_idx;  // [N]
   float* fr;         // [2*kFrameCells] frame-value range per frame cell
   uint32_t Hf, Hc;
   // reset spans: [ff_begin, ff_begin+ff_bytes) <- 0xFF (keys), [z_begin, z_begin+z_bytes) <- 0
@@ -43,17 +46,17 @@ static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   g.ckeys = a.take<uint64_t>(g.Hc);
   size_t o1 = a.off;
   g.fcount = a.take<int32_t>(g.Hf);
-  g.fcursor = a.take<int32_t>(g.Hf);
   g.cmask = a.take<uint64_t>(g.Hc);
+  g.ovf = a.take<int32_t>(4);
   size_t o2 = a.off;
-  g.fstart = a.take<int32_t>(g.Hf);
   g.ff_begin = a.dry ? nullptr : (void*)(a.base + o0);
   g.ff_bytes = o1 - o0;
   g.z_begin = a.dry ? nullptr : (void*)(a.base + o1);
   g.z_bytes = o2 - o1;
-  g.spts = a.take<float4>(N);
-  g.sidx = a.take<int32_t>(N);
-  g.pslot = a.take<int32_t>(N);
+  g.spts = a.take<float4>((size_t)g.Hf * kCellCap);
+  g.sidx = a.take<int32_t>((size_t)g.Hf * kCellCap);
+  g.ovf_pts = a.take<float4>(N);
+  g.ovf_idx = a.take<int32_t>(N);
   g.fr = a.take<float>(2 * kFrameCells);
 }
 
@@ -77,22 +80,35 @@ __device__ __forceinline__ int g2_find(const uint64_t* __restrict__ keys, uint32
   }
 }
 
-// Gating: the kernels of ICP iteration k do nothing once k > *stop (the stop rule has fired).
-static __global__ void __launch_bounds__(kBlock)
-g2_count_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restrict__ gp, Grid2 g,
-                int k, const int* __restrict__ stop, int* __restrict__ err) {
-  if (k > *stop) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  GridDesc d = *gp;
-  bool in = i < N;
-  float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+// grid-stride reset of one grid (keys <- empty, counters / masks / spill count <- 0, frame ranges):
+// callable from any kernel whose grid is done with the table
+__device__ __forceinline__ void g2_clear(const Grid2& g, int64_t tid, int64_t nthreads) {
+  uint4* ff = (uint4*)g.ff_begin;
+  uint4* zz = (uint4*)g.z_begin;
+  const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zero = make_uint4(0, 0, 0, 0);
+  for (int64_t q = tid; q < (int64_t)(g.ff_bytes / 16); q += nthreads) ff[q] = ones;
+  for (int64_t q = tid; q < (int64_t)(g.z_bytes / 16); q += nthreads) zz[q] = zero;
+  for (int64_t q = tid; q < kFrameCells; q += nthreads) {
+    g.fr[q] = __builtin_inff();
+    g.fr[kFrameCells + q] = -__builtin_inff();
+  }
+}
+
+static __global__ void __launch_bounds__(kBlock) g2_clear_kernel(Grid2 g) {
+  g2_clear(g, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// Build: one thread per point. Gating: the kernels of ICP iteration k do nothing once k > *stop
+// (the stop rule has fired).
+__device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& g, bool in, int i,
+                                                float4 p, int* __restrict__ err) {
   int fc = frame_cell(d, p.x);
   int x = (int)floorf((p.y - d.lo[0]) / d.h);
   int y = (int)floorf((p.z - d.lo[1]) / d.h);
   int z = (int)floorf((p.w - d.lo[2]) / d.h);
   bool ok = in && !(x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax ||
                     fc < 0 || fc >= kFrameCells);
-  if (in && !ok) { atomicExch(err, 1); g.pslot[i] = -1; }
+  if (in && !ok) atomicExch(err, 1);
   // frame-value range per frame cell: a cloud is usually ONE frame, so every point would hit
   // the same two words -- reduce across the wave first when the wave agrees on the frame cell
   {
@@ -116,118 +132,29 @@ g2_count_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restric
   }
   if (!ok) return;
   uint32_t fs = g2_claim(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
-  atomicAdd(&g.fcount[fs], 1);
-  g.pslot[i] = (int32_t)fs;
+  int pos = atomicAdd(&g.fcount[fs], 1);
+  if (pos < kCellCap) {
+    g.spts[(size_t)fs * kCellCap + pos] = p;
+    g.sidx[(size_t)fs * kCellCap + pos] = i;
+  } else {
+    int o = atomicAdd(g.ovf, 1);
+    g.ovf_pts[o] = p;
+    g.ovf_idx[o] = i;
+  }
   uint32_t cs = g2_claim(g.ckeys, g.Hc - 1, pack_cell(fc, x >> 2, y >> 2, z >> 2));
   int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
   atomicOr((unsigned long long*)&g.cmask[cs], 1ULL << bit);
 }
 
-// every occupied fine slot reserves its run of the sorted array with one atomic on a cursor
-// (a scan would give a canonical layout, which nothing needs: results are layout-independent)
 static __global__ void __launch_bounds__(kBlock)
-g2_alloc_kernel(Grid2 g, int k, const int* __restrict__ stop, int* __restrict__ cursor) {
-  if (k > *stop) return;
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= g.Hf) return;
-  int c = g.fcount[s];
-  if (c > 0) g.fstart[s] = atomicAdd(cursor, c);
-}
-
-static __global__ void __launch_bounds__(kBlock)
-g2_fill_kernel(const float4* __restrict__ pts, int N, Grid2 g, int k, const int* __restrict__ stop) {
-  if (k > *stop) return;
+g2_insert_kernel(const float4* __restrict__ pts, int N, const GridDesc* __restrict__ gp, Grid2 g,
+                 int k, const int* __restrict__ stop, int* __restrict__ err) {
+  if (stop && k > *stop) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int fs = g.pslot[i];
-  if (fs < 0) return;
-  int pos = g.fstart[fs] + atomicAdd(&g.fcursor[fs], 1);
-  g.spts[pos] = pts[i];
-  g.sidx[pos] = i;
-}
-
-// nearest point of the grid within the radius (frame cell = query frame cell + df), canonical ties
-// (dist2, original index). Returns the ORIGINAL index or -1. *overflow is set when the spatial
-// search radius exceeds the 3x3x3 coarse neighbourhood (cell size chosen too small).
-__device__ __forceinline__ int g2_nearest(const GridDesc& d, const Grid2& g, float4 p, int df,
-                                          int* __restrict__ overflow) {
-  int fc = frame_cell(d, p.x) + df;
-  if (fc < 0 || fc >= kFrameCells) return -1;
-  float fa = g.fr[fc], fb = g.fr[kFrameCells + fc];
-  if (fa > fb) return -1;
-  float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
-  float dfsq = dfl * dfl;
-  const float margin = 1e-5f * d.radius2 + 1e-6f;
-  float budget = d.radius2 - dfsq + margin;  // upper bound on |dxyz|^2 of any admissible candidate
-  if (budget < 0.f) return -1;
-  int rings = (int)ceilf(sqrtf(budget) / d.h);
-  if (rings > 4) { atomicExch(overflow, 1); rings = 4; }
-  int cx = (int)floorf((p.y - d.lo[0]) / d.h);
-  int cy = (int)floorf((p.z - d.lo[1]) / d.h);
-  int cz = (int)floorf((p.w - d.lo[2]) / d.h);
-  int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
-  // occupancy masks of the 27 coarse blocks around the query
-  uint64_t m[27];
-  bool any = false;
-#pragma unroll
-  for (int q = 0; q < 27; ++q) {
-    int ox = q % 3 - 1, oy = (q / 3) % 3 - 1, oz = q / 9 - 1;
-    int X = bx + ox, Y = by + oy, Z = bz + oz;
-    uint64_t mk = 0;
-    if (X >= 0 && Y >= 0 && Z >= 0) {
-      int cs = g2_find(g.ckeys, g.Hc - 1, pack_cell(fc, X, Y, Z));
-      if (cs >= 0) mk = g.cmask[cs];
-    }
-    m[q] = mk;
-    any |= mk != 0;
-  }
-  if (!any) return -1;
-  int best = -1;
-  float bestd = d.radius2;
-  for (int s = 0; s <= rings; ++s) {
-    if (s >= 1) {
-      float lb = (float)(s - 1) * d.h;
-      if (lb * lb > bestd - dfsq + margin) break;
-    }
-    for (int dz = -s; dz <= s; ++dz) {
-      int z = cz + dz;
-      int qz = (z >> 2) - bz + 1;
-      for (int dy = -s; dy <= s; ++dy) {
-        int y = cy + dy;
-        int qy = (y >> 2) - by + 1;
-        bool shell = (dz == -s || dz == s || dy == -s || dy == s);
-        int step = shell ? 1 : (s > 0 ? 2 * s : 1);
-        for (int dx = -s; dx <= s; dx += step) {
-          int x = cx + dx;
-          int qx = (x >> 2) - bx + 1;
-          int q = qx + 3 * qy + 9 * qz;
-          // q is in [0,27) because |offset| <= 4 fine cells; select without dynamic indexing
-          uint64_t mk = 0;
-#pragma unroll
-          for (int t = 0; t < 27; ++t) mk = (t == q) ? m[t] : mk;
-          int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
-          if (!((mk >> bit) & 1ULL)) continue;
-          int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
-          if (fs < 0) continue;
-          int b = g.fstart[fs], e = b + g.fcount[fs];
-          for (int j = b; j < e; ++j) {
-            float4 c = g.spts[j];
-            float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
-            float dist2 = 0.f;
-            dist2 = dist2 + d0 * d0;
-            dist2 = dist2 + d1 * d1;
-            dist2 = dist2 + d2 * d2;
-            dist2 = dist2 + d3 * d3;
-            if (dist2 <= d.radius2) {
-              int oi = g.sidx[j];
-              if (best < 0 || dist2 < bestd || (dist2 == bestd && oi < best)) { best = oi; bestd = dist2; }
-            }
-          }
-        }
-      }
-    }
-  }
-  return best;
+  GridDesc d = *gp;
+  bool in = i < N;
+  float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  g2_insert_point(d, g, in, i, p, err);
 }
 
 // bits of coarse block (X,Y,Z) whose fine cells lie within Chebyshev distance s of cell (cx,cy,cz)
@@ -294,7 +221,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   auto scan_cell = [&](int x, int y, int z) {
     int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
     if (fs < 0) return;
-    int b = g.fstart[fs], e = b + g.fcount[fs];
+    int b = fs * kCellCap, e = b + min(g.fcount[fs], kCellCap);
     for (int j = b; j < e; ++j) {
       float4 c = g.spts[j];
       float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
@@ -309,6 +236,25 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       }
     }
   };
+  // ---- spilled points (cells with more than kCellCap points; normally none): every lane of the
+  //      half takes a stride of the list; same frame cell and radius test as the cell walk
+  {
+    int no = valid ? *g.ovf : 0;
+    for (int j = sub; j < no; j += 32) {
+      float4 c = g.ovf_pts[j];
+      if (frame_cell(d, c.x) != fc) continue;
+      float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+      float dist2 = 0.f;
+      dist2 = dist2 + d0 * d0;
+      dist2 = dist2 + d1 * d1;
+      dist2 = dist2 + d2 * d2;
+      dist2 = dist2 + d3 * d3;
+      if (dist2 <= d.radius2) {
+        int oi = g.ovf_idx[j];
+        if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
+      }
+    }
+  }
   // ---- near cells: Chebyshev distance <= 1, one cell per lane
   {
     bool cell_on = valid && sub < 27;

@@ -5,9 +5,11 @@
 // builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
 // scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
 //
-// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is
-//   begin      clear the moving grid, the frame-range table and the accumulators
-//   count/alloc/fill   counting-sort the moved points into the two-level grid (pcs_grid2.hpp)
+// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is five
+// launches (the concurrent tracking units share a dispatch rate of a few hundred thousand kernels
+// per second, so launches are the currency):
+//   insert     the moved points into the two-level grid (pcs_grid2.hpp; one kernel: claim the fine
+//              slot, take a row of its run); also zeroes the accumulators
 //   nn         1-NN both directions, 32 lanes per query
 //   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
 //              component (raw moments in f64; the centred covariance and the loss follow
@@ -15,7 +17,8 @@
 //   solve      one thread per component: cov + reg*T_rot -> 3x3 one-sided Jacobi SVD (f64) ->
 //              R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T; block 0 also
 //              reduces the loss and applies the loss-delta / 3-strike stop rule ON THE DEVICE
-//   apply      all moving points, f64 -> fp32 as the reference stores them
+//   apply      all moving points, f64 -> fp32 as the reference stores them; then resets the moving
+//              grid for the next iteration
 // Every kernel of iteration k returns immediately when k > state.stop_iter, so the host enqueues
 // iterations in chunks and reads one word per chunk instead of one loss per iteration.
 // Per-component sums: lanes of a wave that share a component are combined by 64-lane butterflies,
@@ -54,7 +57,6 @@ struct IcpBufs {
   double* Rt;    // [C,12]: R row-major, t
   double* lossc; // [C] per-component sum |P-Q|^2 of the current iteration
   int32_t* cnt;  // [C] matched moving points in the final coverage query
-  int32_t* cur_static;  // [2] allocation cursors of the two static grids
 };
 
 static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
@@ -63,11 +65,10 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   if (Ra < 1) Ra = 1;
   if (C < 1) C = 1;
   b.grid = a.take<GridDesc>(1);
-  b.b_ref = a.take<float>(8);
-  b.b_mov = a.take<float>(8);
-  b.b_all = a.take<float>(8);
+  b.b_ref = a.take<float>(24);  // ref, mov, all: 8 floats each, contiguous
+  b.b_mov = b.b_ref ? b.b_ref + 8 : nullptr;
+  b.b_all = b.b_ref ? b.b_ref + 16 : nullptr;
   b.state = a.take<IcpState>(1);
-  b.cur_static = a.take<int32_t>(2);
   plan_grid2(a, Rn, b.gr);
   plan_grid2(a, Mn, b.gm);
   plan_grid2(a, Ra, b.ga);
@@ -105,30 +106,72 @@ __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* _
   st->cursor = 0;
 }
 
+// start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, the three grids
+// <- empty (one launch instead of a dozen memsets)
 __global__ void __launch_bounds__(kBlock)
-icp_init_T_kernel(double* __restrict__ T, int64_t C) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < C * 16;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int e = (int)(i & 15);
-    T[i] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
+icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ T, double* __restrict__ acc,
+                 int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm, Grid2 ga) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (i < 24) bounds24[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
+  for (int64_t q = i; q < C * 16; q += stride) {
+    int e = (int)(q & 15);
+    T[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
+  }
+  for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
+  for (int64_t q = i; q < C; q += stride) cnt[q] = 0;
+  g2_clear(gr, i, stride);
+  g2_clear(gm, i, stride);
+  g2_clear(ga, i, stride);
+}
+
+// min / max of the three clouds in one launch: blockIdx.y selects the cloud
+__global__ void __launch_bounds__(kBlock)
+icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restrict__ mov, int Mn,
+                  const float4* __restrict__ all, int Ra, float* __restrict__ bounds24) {
+  const float4* pts = blockIdx.y == 0 ? ref : (blockIdx.y == 1 ? mov : all);
+  int n = blockIdx.y == 0 ? Rn : (blockIdx.y == 1 ? Mn : Ra);
+  float* out8 = bounds24 + 8 * blockIdx.y;
+  float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
+  }
+  __shared__ float smn[kBlock / 64][4], smx[kBlock / 64][4];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float a = wave_min(mn[d]), b = wave_max(mx[d]);
+    if (lane == 0) { smn[w][d] = a; smx[w][d] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && n > 0) {
+    int d = threadIdx.x;
+    float a = smn[0][d], b = smx[0][d];
+    for (int k = 1; k < kBlock / 64; ++k) { a = fminf(a, smn[k][d]); b = fmaxf(b, smx[k][d]); }
+    atomic_min_f32(&out8[d], a);
+    atomic_max_f32(&out8[4 + d], b);
   }
 }
 
-// start of iteration k: clear the moving grid (keys <- empty, counters/masks <- 0), its
-// frame-range table, the accumulators and the allocation cursor
+// iteration k, first launch: the moved points into the (already reset) moving grid; the
+// accumulators of the previous iteration are zeroed here (they must survive the last iteration for
+// the l1 passes, so the kernel that decides the stop cannot do it)
 __global__ void __launch_bounds__(kBlock)
-icp_begin_kernel(int k, Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc, int64_t C) {
+icp_insert_kernel(int k, const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
+                  Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc, int64_t C) {
   if (k > st->stop_iter) return;
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  uint4* ff = (uint4*)gm.ff_begin;
-  uint4* zz = (uint4*)gm.z_begin;
-  const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zero = make_uint4(0, 0, 0, 0);
-  for (int64_t q = i; q < (int64_t)(gm.ff_bytes / 16); q += stride) ff[q] = ones;
-  for (int64_t q = i; q < (int64_t)(gm.z_bytes / 16); q += stride) zz[q] = zero;
-  for (int64_t q = i; q < kFrameCells; q += stride) { gm.fr[q] = __builtin_inff(); gm.fr[kFrameCells + q] = -__builtin_inff(); }
   for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
-  if (i == 0) st->cursor = 0;
+  GridDesc d = *gp;
+  bool in = i < Mn;
+  float4 p = in ? mov[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  g2_insert_point(d, gm, in, i, p, &st->err);
 }
 
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
@@ -429,9 +472,11 @@ __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
                  const int32_t* __restrict__ comp, const double* __restrict__ Rt,
                  const double* __restrict__ lossc, int64_t C, double delta,
-                 IcpState* __restrict__ st) {
+                 IcpState* __restrict__ st, Grid2 gm) {
   if (k > st->stop_iter) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the searches of this iteration are done with the moving grid: reset it for the next insert
+  g2_clear(gm, i, (int64_t)gridDim.x * blockDim.x);
   if (i < Mn) {
     float4 p = mov[i];
     prev[i] = p;
@@ -513,6 +558,16 @@ int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
 
 // bench.py support: time icp_nn_kernel with HIP events on the launch stream (any number of host
 // threads / streams; totals are accumulated under a mutex).
+__global__ void busy_kernel(int ticks) {  // ~ticks x 10 ns on the 100 MHz wall clock
+  long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+int pcs_profile_busy_loop(int64_t n, int ticks, int blocks, hipStream_t s) {
+  for (int64_t i = 0; i < n; ++i) busy_kernel<<<blocks, 64, 0, s>>>(ticks);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
   for (int64_t i = 0; i < n; ++i) pcs::noop_kernel<<<1, 64, 0, s>>>();
   PCS_LAUNCH_CHECK();
@@ -604,37 +659,27 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   float pad = 4.f * (float)radius + 16.f;
   if (chunk < 1) chunk = 8;
 
-  static const float inf8[8] = {1e30f, 1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f, -1e30f};
-  auto bounds = [&](const float* p, int64_t n, float* out) -> int {
-    if (n > 0) return pcs_minmax4_f32(p, n, out, s);
-    return hipMemcpyAsync(out, inf8, sizeof(inf8), hipMemcpyHostToDevice, s) == hipSuccess ? PCS_OK : PCS_ERR_HIP;
-  };
-  int rc;
-  if ((rc = bounds(ref_fxyz, Rn, b.b_ref))) return rc;
-  if ((rc = bounds(mov_fxyz, Mn, b.b_mov))) return rc;
-  if ((rc = bounds(ref_all, Ra, b.b_all))) return rc;
-  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
-  icp_init_T_kernel<<<grid_for(C * 16), kBlock, 0, s>>>(T, C);
-  PCS_CHECK_HIP(hipMemsetAsync(b.acc, 0, (size_t)C * kAcc * sizeof(double), s));
-  PCS_CHECK_HIP(hipMemsetAsync(b.cnt, 0, (size_t)C * sizeof(int32_t), s));
-  PCS_CHECK_HIP(hipMemsetAsync(b.cur_static, 0, 2 * sizeof(int32_t), s));
-
-  auto sort_into = [&](const float* pts, int64_t n, Grid2& g, int k, int* cursor) {
-    if (n <= 0) return;
-    int nb = (int)((n + kBlock - 1) / kBlock);
-    const int* stop = &b.state->stop_iter;
-    g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, b.grid, g, k, stop, &b.state->err);
-    g2_alloc_kernel<<<(int)((g.Hf + kBlock - 1) / kBlock), kBlock, 0, s>>>(g, k, stop, cursor);
-    g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)pts, (int)n, g, k, stop);
-  };
-  // static grids: non-stationary reference, all reference
-  for (Grid2* g : {&b.gr, &b.ga}) {
-    PCS_CHECK_HIP(hipMemsetAsync(g->ff_begin, 0xFF, g->ff_bytes, s));
-    PCS_CHECK_HIP(hipMemsetAsync(g->z_begin, 0, g->z_bytes, s));
-    frame_range_init_kernel<<<4, kBlock, 0, s>>>(g->fr);
+  // one launch resets everything the call owns, one finds the three bounding boxes
+  {
+    int64_t words = (int64_t)(b.gr.ff_bytes + b.ga.ff_bytes + b.gm.ff_bytes) / 16 + C * kAcc;
+    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, T, b.acc, b.cnt, C, b.gr, b.gm, b.ga);
+    int64_t nmax = Mn > Rn ? Mn : Rn;
+    if (Ra > nmax) nmax = Ra;
+    int gb = (int)((nmax + kBlock - 1) / kBlock);
+    if (gb < 1) gb = 1;
+    if (gb > 256) gb = 256;
+    icp_bounds_kernel<<<dim3(gb, 3), kBlock, 0, s>>>((const float4*)ref_fxyz, (int)Rn,
+                                                     (const float4*)mov_fxyz, (int)Mn,
+                                                     (const float4*)ref_all, (int)Ra, b.b_ref);
   }
-  sort_into(ref_fxyz, Rn, b.gr, 0, &b.cur_static[0]);
-  sort_into(ref_all, Ra, b.ga, 0, &b.cur_static[1]);
+  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
+  // static grids: non-stationary reference, all reference
+  if (Rn > 0)
+    g2_insert_kernel<<<(int)((Rn + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        (const float4*)ref_fxyz, (int)Rn, b.grid, b.gr, 0, &b.state->stop_iter, &b.state->err);
+  if (Ra > 0)
+    g2_insert_kernel<<<(int)((Ra + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        (const float4*)ref_all, (int)Ra, b.grid, b.ga, 0, &b.state->stop_iter, &b.state->err);
 
   int nb_m = (int)((Mn + kBlock - 1) / kBlock);
   if (nb_m < 1) nb_m = 1;
@@ -643,9 +688,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
   if (nb_q < 1) nb_q = 1;
   int nb_c = (int)((C + 63) / 64);
-  int nb_clear = (int)((b.gm.ff_bytes / 16 + kBlock - 1) / kBlock);
-  if (nb_clear > 1024) nb_clear = 1024;
-  if (nb_clear < 1) nb_clear = 1;
 
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -661,8 +703,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
     for (int j = 0; j < n_it; ++j) {
       int k = it + j + 1;  // 1-based iteration number
-      icp_begin_kernel<<<nb_clear, kBlock, 0, s>>>(k, b.gm, b.state, b.acc, C);
-      sort_into(mov_fxyz, Mn, b.gm, k, &b.state->cursor);
+      icp_insert_kernel<<<nb_m, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm,
+                                                b.state, b.acc, C);
       bool pk = prof && k <= 96;
       if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1)], s));
       icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
@@ -674,7 +716,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                                  b.nn_b, b.state, b.acc);
       icp_solve_kernel<<<nb_c, 64, 0, s>>>(k, C, angle_regularizer, b.acc, T, b.Rt, b.lossc, b.state);
       icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
-                                               mov_comp, b.Rt, b.lossc, C, stopping_delta, b.state);
+                                               mov_comp, b.Rt, b.lossc, C, stopping_delta, b.state,
+                                               b.gm);
     }
     it += n_it;
     PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));

@@ -367,22 +367,13 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
   rc = pcs_minmax4_f32(query, M, p.b_qry, s);
   if (rc) return rc;
   grid_setup_kernel<<<1, 64, 0, s>>>(p.b_ref, p.b_qry, radius, cell, p.grid);
-  PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
-  PCS_CHECK_HIP(hipMemsetAsync(p.head, 0xFF, (size_t)p.H * sizeof(int32_t), s));
   PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
   if (K == 1 && sort_by_dist && dframe_min == dframe_max && cell_size > 0.f) {
     // cell_size must be (spatial radius) / 4 or more so that the 3x3x3 coarse blocks cover the ball;
     // if the data say otherwise the search raises the overflow flag and *d_num_edges becomes -1
-    static const int32_t words[2] = {0, 0x7fffffff};
-    PCS_CHECK_HIP(hipMemcpyAsync(p.g2_words, words, sizeof(words), hipMemcpyHostToDevice, s));
-    PCS_CHECK_HIP(hipMemsetAsync(p.g2.ff_begin, 0xFF, p.g2.ff_bytes, s));
-    PCS_CHECK_HIP(hipMemsetAsync(p.g2.z_begin, 0, p.g2.z_bytes, s));
-    PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
-    frame_range_init_kernel<<<4, kBlock, 0, s>>>(p.g2.fr);
+    g2_clear_kernel<<<grid_for((int64_t)(p.g2.ff_bytes / 16)), kBlock, 0, s>>>(p.g2);
     int nb = (int)((N + kBlock - 1) / kBlock);
-    g2_count_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, p.g2_words + 1, p.err);
-    g2_alloc_kernel<<<(int)((p.g2.Hf + kBlock - 1) / kBlock), kBlock, 0, s>>>(p.g2, 0, p.g2_words + 1, p.g2_words);
-    g2_fill_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.g2, 0, p.g2_words + 1);
+    g2_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, nullptr, p.err);
     nn1_search_kernel<<<(int)((M * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
         (const float4*)query, (int)M, p.grid, p.g2, dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg);
     rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
@@ -391,6 +382,8 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
     PCS_LAUNCH_CHECK();
     return PCS_OK;
   }
+  PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
+  PCS_CHECK_HIP(hipMemsetAsync(p.head, 0xFF, (size_t)p.H * sizeof(int32_t), s));
   uint32_t hmask = p.H - 1;
   frame_range_init_kernel<<<4, kBlock, 0, s>>>(p.fr);
   grid_insert_kernel<<<(int)((N + kBlock - 1) / kBlock), kBlock, 0, s>>>(

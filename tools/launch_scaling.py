@@ -33,6 +33,11 @@ def run(mode, T, n):
                 x = xs[i]
                 for _ in range(n):
                     x.add_(1.0)
+            elif mode.startswith("busy"):
+                ticks, blocks = (int(x) for x in mode[4:].split("x"))
+                rc = lib.pcs_profile_busy_loop(ctypes.c_int64(n), ctypes.c_int(ticks), ctypes.c_int(blocks),
+                                               ctypes.c_void_p(streams[i].cuda_stream))
+                assert rc == 0
             elif mode.startswith("sync"):
                 rc = lib.pcs_profile_sync_loop(ctypes.c_int64(n), ctypes.c_int(int(mode[4:])),
                                                ctypes.c_void_p(streams[i].cuda_stream))
@@ -64,6 +69,10 @@ if __name__ == "__main__":
         for T in (1, 2, 3, 5, 9):
             r = run(mode, T, args.n)
             print(f"{mode:7s} threads={T}  {r / 1e3:8.1f} k launches/s  ({1e6 / r * T:6.2f} us per launch per thread)", flush=True)
+    for mode in ("busy500x1", "busy500x64", "busy1000x512"):
+        for T in (1, 2, 3, 4, 6, 9):
+            r = run(mode, T, args.n // 4)
+            print(f"{mode:12s} threads={T}  {1e6 / r * T:7.2f} us per kernel per chain  (aggregate {r / 1e3:7.1f} k kernels/s)", flush=True)
     for mode in ("sync0", "sync1", "sync2"):
         for T in (1, 3, 9):
             r = run(mode, T, args.n // 10)
