@@ -40,7 +40,7 @@ struct IcpState {
   int stop_iter;  // iterations > stop_iter do not run (INT_MAX until the stop rule fires)
   int iters;      // iterations solved so far
   int err;
-  int cursor;     // allocation cursor of the moving grid's cell runs
+  int decided;    // last iteration whose stop rule has been evaluated
   int pad;
 };
 
@@ -53,9 +53,10 @@ struct IcpBufs {
   Grid2 gr, gm, ga;  // non-stationary reference (static), moving (per iteration), all reference
   int32_t *nn_f, *nn_b;
   float* prev;   // [Mn,4] positions before the last applied update
-  double* acc;   // [C, kAcc]
-  double* Rt;    // [C,12]: R row-major, t
-  double* lossc; // [C] per-component sum |P-Q|^2 of the current iteration
+  double* acc;   // [2, C, kAcc] raw moments, buffer k & 1 for iteration k
+  double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
+  double* lossc; // [C] per-component sum |P-Q|^2 of the last applied iteration
+  int32_t* first; // [C] smallest moving-point index of the component (INT_MAX: none)
   int32_t* cnt;  // [C] matched moving points in the final coverage query
 };
 
@@ -75,9 +76,10 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.nn_f = a.take<int32_t>(Mn);
   b.nn_b = a.take<int32_t>(Rn);
   b.prev = a.take<float>(Mn * 4);
-  b.acc = a.take<double>(C * kAcc);
-  b.Rt = a.take<double>(C * 12);
+  b.acc = a.take<double>(2 * C * kAcc);
+  b.Tb = a.take<double>(2 * C * 16);
   b.lossc = a.take<double>(C);
+  b.first = a.take<int32_t>(C);
   b.cnt = a.take<int32_t>(C);
   return a.ok();
 }
@@ -103,23 +105,24 @@ __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* _
   st->stop_iter = INT_MAX;
   st->iters = 0;
   st->err = 0;
-  st->cursor = 0;
+  st->decided = 0;
 }
 
 // start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, the three grids
 // <- empty (one launch instead of a dozen memsets)
 __global__ void __launch_bounds__(kBlock)
-icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ T, double* __restrict__ acc,
-                 int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm, Grid2 ga) {
+icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* __restrict__ acc,
+                 double* __restrict__ lossc, int32_t* __restrict__ first, int32_t* __restrict__ cnt,
+                 int64_t C, Grid2 gr, Grid2 gm, Grid2 ga) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (i < 24) bounds24[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
-  for (int64_t q = i; q < C * 16; q += stride) {
+  for (int64_t q = i; q < 2 * C * 16; q += stride) {
     int e = (int)(q & 15);
-    T[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
+    Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
   }
-  for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
-  for (int64_t q = i; q < C; q += stride) cnt[q] = 0;
+  for (int64_t q = i; q < 2 * C * kAcc; q += stride) acc[q] = 0.0;
+  for (int64_t q = i; q < C; q += stride) { cnt[q] = 0; lossc[q] = 0.0; first[q] = INT_MAX; }
   g2_clear(gr, i, stride);
   g2_clear(gm, i, stride);
   g2_clear(ga, i, stride);
@@ -128,7 +131,8 @@ icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ T, double* _
 // min / max of the three clouds in one launch: blockIdx.y selects the cloud
 __global__ void __launch_bounds__(kBlock)
 icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restrict__ mov, int Mn,
-                  const float4* __restrict__ all, int Ra, float* __restrict__ bounds24) {
+                  const float4* __restrict__ all, int Ra, float* __restrict__ bounds24,
+                  const int32_t* __restrict__ comp, int32_t* __restrict__ first) {
   const float4* pts = blockIdx.y == 0 ? ref : (blockIdx.y == 1 ? mov : all);
   int n = blockIdx.y == 0 ? Rn : (blockIdx.y == 1 ? Mn : Ra);
   float* out8 = bounds24 + 8 * blockIdx.y;
@@ -136,6 +140,7 @@ icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restri
   float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pts[i];
+    if (blockIdx.y == 1) atomicMin(&first[comp[i]], i);  // the thread that will own the component's T
     mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
     mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
     mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
@@ -158,13 +163,47 @@ icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restri
   }
 }
 
-// iteration k, first launch: the moved points into the (already reset) moving grid; the
-// accumulators of the previous iteration are zeroed here (they must survive the last iteration for
-// the l1 passes, so the kernel that decides the stop cannot do it)
+// loss-delta / 3-strike stop rule of iteration k_done (registration_utils.py:186-193), evaluated by
+// ONE workgroup from the per-component losses with a fixed reduction tree. It may lower stop_iter to
+// k_done, which still admits every kernel of iteration k_done.
+__device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const double* __restrict__ lossc,
+                                           int64_t C, int k_done, double delta) {
+  __shared__ double red[kBlock / 64];
+  if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
+  double part = 0.0;
+  for (int64_t q = threadIdx.x; q < C; q += kBlock) part += lossc[q];
+  part = wave_sum_f64(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double loss = 0.0;
+    for (int q = 0; q < kBlock / 64; ++q) loss += red[q];
+    st->loss = loss;
+    if (st->last_error - loss < delta) st->countdown -= 1;
+    else st->countdown = 3;
+    if (st->countdown <= 0) st->stop_iter = k_done;
+    else st->last_error = loss;
+    st->decided = k_done;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+icp_decide_kernel(int k_done, IcpState* __restrict__ st, const double* __restrict__ lossc, int64_t C,
+                  double delta) {
+  icp_decide(st, lossc, C, k_done, delta);
+}
+
+// iteration k, first launch: workgroup 0 first settles the stop rule of iteration k-1 (its losses
+// were written by the previous launch); the moved points go into the (already reset) moving grid
+// and this iteration's accumulator buffer is zeroed. The other workgroups may run before the stop
+// is known: what they touch (moving grid, buffer k & 1) is not read again after a stop.
 __global__ void __launch_bounds__(kBlock)
 icp_insert_kernel(int k, const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
-                  Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc, int64_t C) {
+                  Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc2,
+                  const double* __restrict__ lossc, int64_t C, double delta) {
   if (k > st->stop_iter) return;
+  if (blockIdx.x == 0) icp_decide(st, lossc, C, k - 1, delta);
+  double* acc = acc2 + (size_t)(k & 1) * C * kAcc;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
@@ -407,20 +446,14 @@ __device__ inline double det3(const double A[9]) {
          A[2] * (A[3] * A[7] - A[4] * A[6]);
 }
 
-// one thread per component over many 64-thread blocks: rotation, translation, T update and the
-// component's loss term
-__global__ void __launch_bounds__(64)
-icp_solve_kernel(int k, int64_t C, double reg, const double* __restrict__ acc,
-                 double* __restrict__ T, double* __restrict__ Rt, double* __restrict__ lossc,
-                 const IcpState* __restrict__ st) {
-  if (k > st->stop_iter) return;
-  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double* a = acc + c * kAcc;
+// regularised Kabsch step of one component from its raw moments `a` and accumulated transform Tc:
+// rotation R, translation t, updated transform Tn = [R t] Tc and the component's loss term
+__device__ inline void icp_solve_component(const double* __restrict__ a, const double* __restrict__ Tc,
+                                           double reg, double R[9], double t[3], double Tn[16],
+                                           double* ls_out) {
   double n = a[0];
   double cm[3], cr[3];
   centres(a, cm, cr);
-  double* Tc = T + c * 16;
   double M[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -436,23 +469,16 @@ icp_solve_kernel(int k, int64_t C, double reg, const double* __restrict__ acc,
     for (int j = 0; j < 3; ++j)
       VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
   double sg = det3(VUt);
-  double R[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)
       R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
-  double t[3];
   for (int i = 0; i < 3; ++i)
     t[i] = cr[i] - (cm[0] * R[i * 3 + 0] + cm[1] * R[i * 3 + 1] + cm[2] * R[i * 3 + 2]);
-  double* rt = Rt + c * 12;
-  for (int i = 0; i < 9; ++i) rt[i] = R[i];
-  for (int i = 0; i < 3; ++i) rt[9 + i] = t[i];
-  double Tn[16];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 4; ++j)
       Tn[i * 4 + j] = R[i * 3 + 0] * Tc[0 * 4 + j] + R[i * 3 + 1] * Tc[1 * 4 + j] +
                       R[i * 3 + 2] * Tc[2 * 4 + j] + t[i] * Tc[3 * 4 + j];
   for (int j = 0; j < 4; ++j) Tn[12 + j] = Tc[12 + j];
-  for (int i = 0; i < 16; ++i) Tc[i] = Tn[i];
   // sum |P - Q|^2 = sum |p-q|^2 - 2 d . sum(p-q) + n |d|^2,  d = cm - cr
   double ls = 0.0;
   if (n > 0.5) {
@@ -462,48 +488,40 @@ icp_solve_kernel(int k, int64_t C, double reg, const double* __restrict__ acc,
       ls += -2.0 * d * (a[1 + q] - a[4 + q]) + n * d * d;
     }
   }
-  lossc[c] = ls;
+  *ls_out = ls;
 }
 
-// apply iteration k's (R, t) to every moving point (the previous positions are kept for the l1
-// passes). Block 0 also reduces the per-component losses (fixed tree) and runs the loss-delta /
-// 3-strike stop rule: it may lower stop_iter to k, which still admits every kernel of iteration k.
+// iteration k, last launch: every moving point solves its own component's step from the completed
+// moments (redundantly across the points of a component: a 3x3 SVD is cheaper than another launch)
+// and moves; the component's first point also stores the updated transform (read buffer k-1, write
+// buffer k) and the loss term. The previous positions are kept for the l1 passes. Then the moving
+// grid, which the searches of this iteration are done with, is reset for the next insert.
 __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
-                 const int32_t* __restrict__ comp, const double* __restrict__ Rt,
-                 const double* __restrict__ lossc, int64_t C, double delta,
-                 IcpState* __restrict__ st, Grid2 gm) {
+                 const int32_t* __restrict__ comp, const int32_t* __restrict__ first,
+                 const double* __restrict__ acc2, double* __restrict__ Tb, double* __restrict__ lossc,
+                 int64_t C, double reg, IcpState* __restrict__ st, Grid2 gm) {
   if (k > st->stop_iter) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // the searches of this iteration are done with the moving grid: reset it for the next insert
   g2_clear(gm, i, (int64_t)gridDim.x * blockDim.x);
-  if (i < Mn) {
-    float4 p = mov[i];
-    prev[i] = p;
-    const double* rt = Rt + (int64_t)comp[i] * 12;
-    double x = p.y, y = p.z, z = p.w;
-    float nx = (float)(x * rt[0] + y * rt[1] + z * rt[2] + rt[9]);
-    float ny = (float)(x * rt[3] + y * rt[4] + z * rt[5] + rt[10]);
-    float nz = (float)(x * rt[6] + y * rt[7] + z * rt[8] + rt[11]);
-    mov[i] = make_float4(p.x, nx, ny, nz);
-  }
-  if (blockIdx.x == 0) {
-    __shared__ double red[kBlock / 64];
-    double part = 0.0;
-    for (int64_t q = threadIdx.x; q < C; q += kBlock) part += lossc[q];
-    part = wave_sum_f64(part);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double loss = 0.0;
-      for (int q = 0; q < kBlock / 64; ++q) loss += red[q];
-      st->loss = loss;
-      st->iters = k;
-      if (st->last_error - loss < delta) st->countdown -= 1;
-      else st->countdown = 3;
-      if (st->countdown <= 0) st->stop_iter = k;
-      else st->last_error = loss;
-    }
+  if (i == 0) st->iters = k;
+  if (i >= Mn) return;
+  int c = comp[i];
+  const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
+  const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
+  double R[9], t[3], Tn[16], ls;
+  icp_solve_component(a, Tc, reg, R, t, Tn, &ls);
+  float4 p = mov[i];
+  prev[i] = p;
+  double x = p.y, y = p.z, z = p.w;
+  float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
+  float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
+  float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
+  mov[i] = make_float4(p.x, nx, ny, nz);
+  if (first[c] == i) {
+    double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
+    for (int q = 0; q < 16; ++q) To[q] = Tn[q];
+    lossc[c] = ls;
   }
 }
 
@@ -522,14 +540,15 @@ icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __res
 
 __global__ void __launch_bounds__(kBlock)
 icp_finish_kernel(int64_t C, const double* __restrict__ acc, const int32_t* __restrict__ cnt,
-                  const int64_t* __restrict__ comp_deg, int have_l1, double* __restrict__ l1,
-                  float* __restrict__ ratio) {
+                  const int64_t* __restrict__ comp_deg, int have_l1, const double* __restrict__ Tfin,
+                  double* __restrict__ T, double* __restrict__ l1, float* __restrict__ ratio) {
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
     double n = acc[c * kAcc];
     l1[c] = (have_l1 && n > 0.5) ? acc[c * kAcc + 18] / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
     ratio[c] = (float)cnt[c] / ((float)comp_deg[c] + 1e-6f);
+    for (int q = 0; q < 16; ++q) T[c * 16 + q] = Tfin[c * 16 + q];
   }
 }
 
@@ -662,7 +681,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   // one launch resets everything the call owns, one finds the three bounding boxes
   {
     int64_t words = (int64_t)(b.gr.ff_bytes + b.ga.ff_bytes + b.gm.ff_bytes) / 16 + C * kAcc;
-    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, T, b.acc, b.cnt, C, b.gr, b.gm, b.ga);
+    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, b.Tb, b.acc, b.lossc, b.first, b.cnt, C,
+                                                        b.gr, b.gm, b.ga);
     int64_t nmax = Mn > Rn ? Mn : Rn;
     if (Ra > nmax) nmax = Ra;
     int gb = (int)((nmax + kBlock - 1) / kBlock);
@@ -670,7 +690,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     if (gb > 256) gb = 256;
     icp_bounds_kernel<<<dim3(gb, 3), kBlock, 0, s>>>((const float4*)ref_fxyz, (int)Rn,
                                                      (const float4*)mov_fxyz, (int)Mn,
-                                                     (const float4*)ref_all, (int)Ra, b.b_ref);
+                                                     (const float4*)ref_all, (int)Ra, b.b_ref, mov_comp,
+                                                     b.first);
   }
   icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
   // static grids: non-stationary reference, all reference
@@ -687,7 +708,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if (nb_e < 1) nb_e = 1;
   int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
   if (nb_q < 1) nb_q = 1;
-  int nb_c = (int)((C + 63) / 64);
 
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -704,7 +724,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     for (int j = 0; j < n_it; ++j) {
       int k = it + j + 1;  // 1-based iteration number
       icp_insert_kernel<<<nb_m, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm,
-                                                b.state, b.acc, C);
+                                                b.state, b.acc, b.lossc, C, stopping_delta);
       bool pk = prof && k <= 96;
       if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1)], s));
       icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
@@ -713,13 +733,14 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1) + 1], s));
       icp_moments_kernel<<<nb_e, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
                                                  (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
-                                                 b.nn_b, b.state, b.acc);
-      icp_solve_kernel<<<nb_c, 64, 0, s>>>(k, C, angle_regularizer, b.acc, T, b.Rt, b.lossc, b.state);
+                                                 b.nn_b, b.state, b.acc + (size_t)(k & 1) * C * kAcc);
       icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
-                                               mov_comp, b.Rt, b.lossc, C, stopping_delta, b.state,
-                                               b.gm);
+                                               mov_comp, b.first, b.acc, b.Tb, b.lossc, C,
+                                               angle_regularizer, b.state, b.gm);
     }
     it += n_it;
+    // the stop rule of the chunk's last iteration (the others were settled by the next insert)
+    icp_decide_kernel<<<1, kBlock, 0, s>>>(it, b.state, b.lossc, C, stopping_delta);
     PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (host.err) return PCS_ERR_RANGE;
@@ -742,18 +763,20 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   info[0] = host.iters;
   info[1] = host.stop_iter != INT_MAX ? 1 : 0;
   info[2] = info[3] = 0;
+  double* acc_fin = b.acc + (size_t)(host.iters & 1) * C * kAcc;  // moments of the last iteration
+  const double* T_fin = b.Tb + (size_t)(host.iters & 1) * C * 16;
   if (host.iters > 0) {
     // l1 error of the last iteration: positions before its update are in `prev`
     icp_l1_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, b.acc, 0.3);
+                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, acc_fin, 0.3);
     icp_l1_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, b.acc, 0.3);
+                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, acc_fin, 0.3);
   }
   if (Mn > 0 && Ra > 0)
     icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
         (const float4*)mov_fxyz, (int)Mn, mov_comp, b.grid, frame_offset, b.ga, b.state, b.cnt);
-  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, b.acc, b.cnt, comp_deg, host.iters > 0, l1_err,
-                                                   edge_ratio);
+  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, acc_fin, b.cnt, comp_deg, host.iters > 0, T_fin, T,
+                                                   l1_err, edge_ratio);
   PCS_LAUNCH_CHECK();
   PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
   PCS_CHECK_HIP(hipStreamSynchronize(s));

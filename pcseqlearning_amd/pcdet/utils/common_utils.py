@@ -25,14 +25,19 @@ def filter_dict(data_dict, mask, ignore_keys=()):
     """Index every value of a dict with the same mask / index tensor
     (pcdet/utils/common_utils.py:67-78), checking lengths for boolean masks."""
     out = {}
+    index = mask
+    is_bool = isinstance(mask, (torch.Tensor, np.ndarray)) and mask.dtype in (torch.bool, np.bool_)
+    if is_bool and isinstance(mask, torch.Tensor) and mask.dim() == 1 and mask.is_cuda:
+        # one compaction of the mask shared by every entry (a boolean index would redo it per entry)
+        index = mask.nonzero(as_tuple=True)[0]
     for key, val in data_dict.items():
         if key in ignore_keys:
             out[key] = val
             continue
-        if isinstance(mask, (torch.Tensor, np.ndarray)) and mask.dtype in (torch.bool, np.bool_):
+        if is_bool:
             assert mask.shape[0] == len(val), \
                 f"MisMatch for key={key}, mask.shape={mask.shape}, data.shape={len(val)}"
-        out[key] = val[mask]
+        out[key] = val[index] if isinstance(val, torch.Tensor) else val[mask]
     return out
 
 
