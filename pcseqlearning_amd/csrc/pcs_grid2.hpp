@@ -18,21 +18,29 @@ namespace pcs {
 
 constexpr int kCellCap = 16;
 
+// A table slot is one 16-byte word so that a probe fetches the key and its payload together (one
+// dependent load instead of two): fine = {key, point count}, coarse = {key, 64-bit occupancy mask}.
+struct FineSlot {
+  uint64_t key;
+  int32_t count;  // points inserted (may exceed kCellCap: the rest spilled)
+  int32_t pad;
+};
+struct CoarseSlot {
+  uint64_t key;
+  uint64_t mask;  // occupancy of the 64 fine cells of the block
+};
+
 struct Grid2 {
-  uint64_t* fkeys;   // [Hf] fine cell keys
-  int32_t* fcount;   // [Hf] points inserted into the fine slot (may exceed kCellCap: the rest spilled)
-  uint64_t* ckeys;   // [Hc] coarse block keys
-  uint64_t* cmask;   // [Hc] occupancy of the 64 fine cells of the block
-  float4* spts;      // [Hf * kCellCap] points, slot-major
-  int32_t* sidx;     // [Hf * kCellCap] original index of spts rows
-  int32_t* ovf;      // [1] number of spilled points
-  float4* ovf_pts;   // [N]
-  int32_t* ovf_idx;  // [N]
-  float* fr;         // [2*kFrameCells] frame-value range per frame cell
+  FineSlot* fslot;    // [Hf]
+  CoarseSlot* cslot;  // [Hc]
+  float4* spts;       // [Hf * kCellCap] points, slot-major
+  int32_t* sidx;      // [Hf * kCellCap] original index of spts rows
+  int32_t* ovf;       // [1] number of spilled points
+  float4* ovf_pts;    // [N]
+  int32_t* ovf_idx;   // [N]
+  float* fr;          // [2*kFrameCells] frame-value range per frame cell
   uint32_t Hf, Hc;
-  // reset spans: [ff_begin, ff_begin+ff_bytes) <- 0xFF (keys), [z_begin, z_begin+z_bytes) <- 0
-  void *ff_begin, *z_begin;
-  size_t ff_bytes, z_bytes;
+  size_t slot_words;  // 16-byte words of fslot + cslot (contiguous), for the reset loop
 };
 
 static inline uint32_t g2_pow2(uint64_t x) { uint32_t h = 64; while (h < x) h <<= 1; return h; }
@@ -41,18 +49,10 @@ static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   if (N < 1) N = 1;
   g.Hf = g2_pow2(2 * (uint64_t)N);
   g.Hc = g2_pow2(2 * (uint64_t)N);
-  size_t o0 = a.off;
-  g.fkeys = a.take<uint64_t>(g.Hf);
-  g.ckeys = a.take<uint64_t>(g.Hc);
-  size_t o1 = a.off;
-  g.fcount = a.take<int32_t>(g.Hf);
-  g.cmask = a.take<uint64_t>(g.Hc);
+  g.fslot = a.take<FineSlot>(g.Hf);    // Hf * 16 bytes is a multiple of the arena alignment, so the
+  g.cslot = a.take<CoarseSlot>(g.Hc);  // two tables are contiguous
+  g.slot_words = (size_t)g.Hf + g.Hc;
   g.ovf = a.take<int32_t>(4);
-  size_t o2 = a.off;
-  g.ff_begin = a.dry ? nullptr : (void*)(a.base + o0);
-  g.ff_bytes = o1 - o0;
-  g.z_begin = a.dry ? nullptr : (void*)(a.base + o1);
-  g.z_bytes = o2 - o1;
   g.spts = a.take<float4>((size_t)g.Hf * kCellCap);
   g.sidx = a.take<int32_t>((size_t)g.Hf * kCellCap);
   g.ovf_pts = a.take<float4>(N);
@@ -60,21 +60,27 @@ static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   g.fr = a.take<float>(2 * kFrameCells);
 }
 
-__device__ __forceinline__ uint32_t g2_claim(uint64_t* __restrict__ keys, uint32_t hmask, uint64_t key) {
+// claim / find: `base` is an array of 16-byte slots whose first 8 bytes are the key
+template <typename Slot>
+__device__ __forceinline__ uint32_t g2_claim(Slot* __restrict__ base, uint32_t hmask, uint64_t key) {
   uint32_t slot = mix64(key) & hmask;
   while (true) {
-    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmpty,
+    uint64_t prev = atomicCAS((unsigned long long*)&base[slot].key, (unsigned long long)kEmpty,
                               (unsigned long long)key);
     if (prev == kEmpty || prev == key) return slot;
     slot = (slot + 1) & hmask;
   }
 }
 
-__device__ __forceinline__ int g2_find(const uint64_t* __restrict__ keys, uint32_t hmask, uint64_t key) {
+// one 16-byte load per probe: returns the slot index (or -1) and the payload words in *lo / *hi
+template <typename Slot>
+__device__ __forceinline__ int g2_find(const Slot* __restrict__ base, uint32_t hmask, uint64_t key,
+                                       uint32_t* lo, uint32_t* hi) {
   uint32_t slot = mix64(key) & hmask;
   while (true) {
-    uint64_t k = keys[slot];
-    if (k == key) return (int)slot;
+    uint4 w = ((const uint4*)base)[slot];
+    uint64_t k = ((uint64_t)w.y << 32) | w.x;
+    if (k == key) { *lo = w.z; *hi = w.w; return (int)slot; }
     if (k == kEmpty) return -1;
     slot = (slot + 1) & hmask;
   }
@@ -83,15 +89,14 @@ __device__ __forceinline__ int g2_find(const uint64_t* __restrict__ keys, uint32
 // grid-stride reset of one grid (keys <- empty, counters / masks / spill count <- 0, frame ranges):
 // callable from any kernel whose grid is done with the table
 __device__ __forceinline__ void g2_clear(const Grid2& g, int64_t tid, int64_t nthreads) {
-  uint4* ff = (uint4*)g.ff_begin;
-  uint4* zz = (uint4*)g.z_begin;
-  const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zero = make_uint4(0, 0, 0, 0);
-  for (int64_t q = tid; q < (int64_t)(g.ff_bytes / 16); q += nthreads) ff[q] = ones;
-  for (int64_t q = tid; q < (int64_t)(g.z_bytes / 16); q += nthreads) zz[q] = zero;
+  uint4* w = (uint4*)g.fslot;
+  const uint4 empty = make_uint4(~0u, ~0u, 0u, 0u);
+  for (int64_t q = tid; q < (int64_t)g.slot_words; q += nthreads) w[q] = empty;
   for (int64_t q = tid; q < kFrameCells; q += nthreads) {
     g.fr[q] = __builtin_inff();
     g.fr[kFrameCells + q] = -__builtin_inff();
   }
+  if (tid == 0) g.ovf[0] = 0;
 }
 
 static __global__ void __launch_bounds__(kBlock) g2_clear_kernel(Grid2 g) {
@@ -131,8 +136,8 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
     }
   }
   if (!ok) return;
-  uint32_t fs = g2_claim(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
-  int pos = atomicAdd(&g.fcount[fs], 1);
+  uint32_t fs = g2_claim(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z));
+  int pos = atomicAdd(&g.fslot[fs].count, 1);
   if (pos < kCellCap) {
     g.spts[(size_t)fs * kCellCap + pos] = p;
     g.sidx[(size_t)fs * kCellCap + pos] = i;
@@ -141,9 +146,9 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
     g.ovf_pts[o] = p;
     g.ovf_idx[o] = i;
   }
-  uint32_t cs = g2_claim(g.ckeys, g.Hc - 1, pack_cell(fc, x >> 2, y >> 2, z >> 2));
+  uint32_t cs = g2_claim(g.cslot, g.Hc - 1, pack_cell(fc, x >> 2, y >> 2, z >> 2));
   int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
-  atomicOr((unsigned long long*)&g.cmask[cs], 1ULL << bit);
+  atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << bit);
 }
 
 static __global__ void __launch_bounds__(kBlock)
@@ -210,30 +215,40 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   int X = bx + sub % 3 - 1, Y = by + (sub / 3) % 3 - 1, Z = bz + sub / 9 - 1;
   if (valid && sub < 27) {
     if (X >= 0 && Y >= 0 && Z >= 0) {
-      int cs = g2_find(g.ckeys, g.Hc - 1, pack_cell(fc, X, Y, Z));
-      if (cs >= 0) mymask = g.cmask[cs];
+      uint32_t lo = 0, hi = 0;
+      int cs = g2_find(g.cslot, g.Hc - 1, pack_cell(fc, X, Y, Z), &lo, &hi);
+      if (cs >= 0) mymask = ((uint64_t)hi << 32) | lo;
     }
   }
   unsigned long long occ = __ballot(mymask != 0);
   valid = valid && ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
   int cand = -1;
   float cd = 0.f;
+  auto consider = [&](float4 c, int oi) {
+    float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+    float dist2 = 0.f;
+    dist2 = dist2 + d0 * d0;
+    dist2 = dist2 + d1 * d1;
+    dist2 = dist2 + d2 * d2;
+    dist2 = dist2 + d3 * d3;
+    if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) { cand = oi; cd = dist2; }
+  };
+  // a cell's run is kCellCap contiguous rows: four rows and their indices are requested together
+  // (one round of memory latency per four points instead of one per point)
   auto scan_cell = [&](int x, int y, int z) {
-    int fs = g2_find(g.fkeys, g.Hf - 1, pack_cell(fc, x, y, z));
+    uint32_t cnt_w = 0, pad_w = 0;
+    int fs = g2_find(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z), &cnt_w, &pad_w);
     if (fs < 0) return;
-    int b = fs * kCellCap, e = b + min(g.fcount[fs], kCellCap);
-    for (int j = b; j < e; ++j) {
-      float4 c = g.spts[j];
-      float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
-      float dist2 = 0.f;
-      dist2 = dist2 + d0 * d0;
-      dist2 = dist2 + d1 * d1;
-      dist2 = dist2 + d2 * d2;
-      dist2 = dist2 + d3 * d3;
-      if (dist2 <= d.radius2) {
-        int oi = g.sidx[j];
-        if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
-      }
+    int cnt = min((int)cnt_w, kCellCap);
+    const float4* run = g.spts + (size_t)fs * kCellCap;
+    const int4* idx = (const int4*)(g.sidx + (size_t)fs * kCellCap);
+    for (int j = 0; j < cnt; j += 4) {
+      float4 c0 = run[j], c1 = run[j + 1], c2 = run[j + 2], c3 = run[j + 3];
+      int4 oi = idx[j >> 2];
+      consider(c0, oi.x);
+      if (j + 1 < cnt) consider(c1, oi.y);
+      if (j + 2 < cnt) consider(c2, oi.z);
+      if (j + 3 < cnt) consider(c3, oi.w);
     }
   };
   // ---- spilled points (cells with more than kCellCap points; normally none): every lane of the
@@ -243,16 +258,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     for (int j = sub; j < no; j += 32) {
       float4 c = g.ovf_pts[j];
       if (frame_cell(d, c.x) != fc) continue;
-      float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
-      float dist2 = 0.f;
-      dist2 = dist2 + d0 * d0;
-      dist2 = dist2 + d1 * d1;
-      dist2 = dist2 + d2 * d2;
-      dist2 = dist2 + d3 * d3;
-      if (dist2 <= d.radius2) {
-        int oi = g.ovf_idx[j];
-        if (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand)) { cand = oi; cd = dist2; }
-      }
+      consider(c, g.ovf_idx[j]);
     }
   }
   // ---- near cells: Chebyshev distance <= 1, one cell per lane

@@ -55,7 +55,7 @@ struct IcpBufs {
   float* prev;   // [Mn,4] positions before the last applied update
   double* acc;   // [2, C, kAcc] raw moments, buffer k & 1 for iteration k
   double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
-  double* lossc; // [C] per-component sum |P-Q|^2 of the last applied iteration
+  double* lossp; // [ceil(Mn / kBlock)] per-workgroup sums of the component losses, last applied iteration
   int32_t* first; // [C] smallest moving-point index of the component (INT_MAX: none)
   int32_t* cnt;  // [C] matched moving points in the final coverage query
 };
@@ -78,7 +78,7 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<double>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
-  b.lossc = a.take<double>(C);
+  b.lossp = a.take<double>((Mn + kBlock - 1) / kBlock + 1);
   b.first = a.take<int32_t>(C);
   b.cnt = a.take<int32_t>(C);
   return a.ok();
@@ -112,8 +112,8 @@ __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* _
 // <- empty (one launch instead of a dozen memsets)
 __global__ void __launch_bounds__(kBlock)
 icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* __restrict__ acc,
-                 double* __restrict__ lossc, int32_t* __restrict__ first, int32_t* __restrict__ cnt,
-                 int64_t C, Grid2 gr, Grid2 gm, Grid2 ga) {
+                 int32_t* __restrict__ first, int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm,
+                 Grid2 ga) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (i < 24) bounds24[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
@@ -122,7 +122,7 @@ icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* 
     Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
   }
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) acc[q] = 0.0;
-  for (int64_t q = i; q < C; q += stride) { cnt[q] = 0; lossc[q] = 0.0; first[q] = INT_MAX; }
+  for (int64_t q = i; q < C; q += stride) { cnt[q] = 0; first[q] = INT_MAX; }
   g2_clear(gr, i, stride);
   g2_clear(gm, i, stride);
   g2_clear(ga, i, stride);
@@ -164,14 +164,14 @@ icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restri
 }
 
 // loss-delta / 3-strike stop rule of iteration k_done (registration_utils.py:186-193), evaluated by
-// ONE workgroup from the per-component losses with a fixed reduction tree. It may lower stop_iter to
+// ONE workgroup from the per-workgroup loss partials of the apply launch (fixed reduction tree). It may lower stop_iter to
 // k_done, which still admits every kernel of iteration k_done.
-__device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const double* __restrict__ lossc,
-                                           int64_t C, int k_done, double delta) {
+__device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const double* __restrict__ lossp,
+                                           int nparts, int k_done, double delta) {
   __shared__ double red[kBlock / 64];
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
   double part = 0.0;
-  for (int64_t q = threadIdx.x; q < C; q += kBlock) part += lossc[q];
+  for (int q = threadIdx.x; q < nparts; q += kBlock) part += lossp[q];
   part = wave_sum_f64(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
@@ -188,25 +188,22 @@ __device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const doub
 }
 
 __global__ void __launch_bounds__(kBlock)
-icp_decide_kernel(int k_done, IcpState* __restrict__ st, const double* __restrict__ lossc, int64_t C,
+icp_decide_kernel(int k_done, IcpState* __restrict__ st, const double* __restrict__ lossp, int nparts,
                   double delta) {
-  icp_decide(st, lossc, C, k_done, delta);
+  icp_decide(st, lossp, nparts, k_done, delta);
 }
 
 // iteration k, first launch: workgroup 0 first settles the stop rule of iteration k-1 (its losses
-// were written by the previous launch); the moved points go into the (already reset) moving grid
-// and this iteration's accumulator buffer is zeroed. The other workgroups may run before the stop
-// is known: what they touch (moving grid, buffer k & 1) is not read again after a stop.
+// were written by the previous launch); the moved points go into the (already reset) moving grid.
+// The other workgroups may run before the stop is known: the moving grid is not read again after
+// a stop.
 __global__ void __launch_bounds__(kBlock)
 icp_insert_kernel(int k, const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
-                  Grid2 gm, IcpState* __restrict__ st, double* __restrict__ acc2,
-                  const double* __restrict__ lossc, int64_t C, double delta) {
+                  Grid2 gm, IcpState* __restrict__ st, const double* __restrict__ lossp, int nparts,
+                  double delta) {
   if (k > st->stop_iter) return;
-  if (blockIdx.x == 0) icp_decide(st, lossc, C, k - 1, delta);
-  double* acc = acc2 + (size_t)(k & 1) * C * kAcc;
+  if (blockIdx.x == 0) icp_decide(st, lossp, nparts, k - 1, delta);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t q = i; q < C * kAcc; q += stride) acc[q] = 0.0;
   GridDesc d = *gp;
   bool in = i < Mn;
   float4 p = in ? mov[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -499,29 +496,45 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
 __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
                  const int32_t* __restrict__ comp, const int32_t* __restrict__ first,
-                 const double* __restrict__ acc2, double* __restrict__ Tb, double* __restrict__ lossc,
+                 double* __restrict__ acc2, double* __restrict__ Tb, double* __restrict__ lossp,
                  int64_t C, double reg, IcpState* __restrict__ st, Grid2 gm) {
   if (k > st->stop_iter) return;
+  __shared__ double red[kBlock / 64];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   g2_clear(gm, i, (int64_t)gridDim.x * blockDim.x);
   if (i == 0) st->iters = k;
-  if (i >= Mn) return;
-  int c = comp[i];
-  const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
-  const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
-  double R[9], t[3], Tn[16], ls;
-  icp_solve_component(a, Tc, reg, R, t, Tn, &ls);
-  float4 p = mov[i];
-  prev[i] = p;
-  double x = p.y, y = p.z, z = p.w;
-  float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
-  float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
-  float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
-  mov[i] = make_float4(p.x, nx, ny, nz);
-  if (first[c] == i) {
-    double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
-    for (int q = 0; q < 16; ++q) To[q] = Tn[q];
-    lossc[c] = ls;
+  double ls_mine = 0.0;
+  if (i < Mn) {
+    int c = comp[i];
+    const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
+    const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
+    double R[9], t[3], Tn[16], ls;
+    icp_solve_component(a, Tc, reg, R, t, Tn, &ls);
+    float4 p = mov[i];
+    prev[i] = p;
+    double x = p.y, y = p.z, z = p.w;
+    float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
+    float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
+    float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
+    mov[i] = make_float4(p.x, nx, ny, nz);
+    if (first[c] == i) {
+      // the component's owner: transform, loss term, and the other moment buffer zeroed for the
+      // next iteration (nothing reads it during this launch)
+      double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
+      for (int q = 0; q < 16; ++q) To[q] = Tn[q];
+      double* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
+      for (int q = 0; q < kAcc; ++q) an[q] = 0.0;
+      ls_mine = ls;
+    }
+  }
+  // loss partial of this workgroup (fixed order: lanes, then waves)
+  ls_mine = wave_sum_f64(ls_mine);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls_mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int q = 0; q < kBlock / 64; ++q) tot += red[q];
+    lossp[blockIdx.x] = tot;
   }
 }
 
@@ -680,9 +693,9 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
 
   // one launch resets everything the call owns, one finds the three bounding boxes
   {
-    int64_t words = (int64_t)(b.gr.ff_bytes + b.ga.ff_bytes + b.gm.ff_bytes) / 16 + C * kAcc;
-    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, b.Tb, b.acc, b.lossc, b.first, b.cnt, C,
-                                                        b.gr, b.gm, b.ga);
+    int64_t words = (int64_t)(b.gr.slot_words + b.ga.slot_words + b.gm.slot_words) + C * kAcc;
+    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, b.Tb, b.acc, b.first, b.cnt, C, b.gr,
+                                                        b.gm, b.ga);
     int64_t nmax = Mn > Rn ? Mn : Rn;
     if (Ra > nmax) nmax = Ra;
     int gb = (int)((nmax + kBlock - 1) / kBlock);
@@ -724,7 +737,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     for (int j = 0; j < n_it; ++j) {
       int k = it + j + 1;  // 1-based iteration number
       icp_insert_kernel<<<nb_m, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm,
-                                                b.state, b.acc, b.lossc, C, stopping_delta);
+                                                b.state, b.lossp, nb_m, stopping_delta);
       bool pk = prof && k <= 96;
       if (pk) PCS_CHECK_HIP(hipEventRecord(t_ev.ev[2 * (k - 1)], s));
       icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
@@ -735,12 +748,12 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                                  (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
                                                  b.nn_b, b.state, b.acc + (size_t)(k & 1) * C * kAcc);
       icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
-                                               mov_comp, b.first, b.acc, b.Tb, b.lossc, C,
+                                               mov_comp, b.first, b.acc, b.Tb, b.lossp, C,
                                                angle_regularizer, b.state, b.gm);
     }
     it += n_it;
     // the stop rule of the chunk's last iteration (the others were settled by the next insert)
-    icp_decide_kernel<<<1, kBlock, 0, s>>>(it, b.state, b.lossc, C, stopping_delta);
+    icp_decide_kernel<<<1, kBlock, 0, s>>>(it, b.state, b.lossp, nb_m, stopping_delta);
     PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (host.err) return PCS_ERR_RANGE;

@@ -371,7 +371,7 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
   if (K == 1 && sort_by_dist && dframe_min == dframe_max && cell_size > 0.f) {
     // cell_size must be (spatial radius) / 4 or more so that the 3x3x3 coarse blocks cover the ball;
     // if the data say otherwise the search raises the overflow flag and *d_num_edges becomes -1
-    g2_clear_kernel<<<grid_for((int64_t)(p.g2.ff_bytes / 16)), kBlock, 0, s>>>(p.g2);
+    g2_clear_kernel<<<grid_for((int64_t)p.g2.slot_words), kBlock, 0, s>>>(p.g2);
     int nb = (int)((N + kBlock - 1) / kBlock);
     g2_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, nullptr, p.err);
     nn1_search_kernel<<<(int)((M * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
