@@ -272,6 +272,16 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
 int pcs_points_in_boxes(const float* points, int64_t N, const float* boxes, int B, int32_t* out,
                         pcs_stream_t stream);
 
+/* The per-frame points_in_boxes_cpu calls of the evaluation loops (cluster_proposal.py:200-215,
+ * cluster_tracking.py:388-400) for all frames at once. boxes [B,7] grouped by ascending frame,
+ * box_offsets: DEVICE int32 [F+1]; point_frame [N] int64. A point is tested against the boxes of
+ * its own frame only. member [N,Bmax] int32 (column = box index within the frame; 0 beyond the
+ * frame's count) and / or first [N] int32 (lowest containing box index within the frame, -1 none);
+ * either may be NULL. */
+int pcs_points_in_frame_boxes(const float* points, const int64_t* point_frame, int64_t N,
+                              const float* boxes, const int32_t* box_offsets, int F, int Bmax,
+                              int32_t* member, int32_t* first, pcs_stream_t stream);
+
 /* l1_minimization, pcdet/models/registration/preprocessors/preprocessor_utils.py:313-350 (ground
  * height per 2 m pillar: L1 data term + 4-direction second-difference smoothness, AdamW with
  * MultiStepLR, <= max_iters steps, 3-strike stop at 1e-4), one persistent kernel.

@@ -939,6 +939,45 @@ points_in_boxes_kernel(const float* __restrict__ pts, int64_t N, const float* __
   }
 }
 
+__device__ __forceinline__ int point_in_box(float x, float y, float z, const float* __restrict__ bx) {
+  float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
+  if ((double)fabsf(z - cz) > (double)dz / 2.0) return 0;
+  const float MARGIN = 1e-2;
+  float cosa = (float)cos((double)(-rz)), sina = (float)sin((double)(-rz));
+  float sx = x - cx, sy = y - cy;
+  float lx = sx * cosa + sy * (-sina);
+  float ly = sx * sina + sy * cosa;
+  return ((double)fabsf(lx) < (double)dx / 2.0 + (double)MARGIN) &
+         ((double)fabsf(ly) < (double)dy / 2.0 + (double)MARGIN);
+}
+
+// The per-frame points_in_boxes calls of the evaluation loops (cluster_proposal.py:200-215,
+// cluster_tracking.py:388-400) for all frames at once: boxes are grouped by frame
+// (box_offsets [F+1]); a point is tested against the boxes of its own frame only. member [N,Bmax]
+// (column = box index within the frame, 0 beyond the frame's box count) and / or first [N]
+// (lowest box index within the frame that contains the point, -1 = none).
+__global__ void __launch_bounds__(kBlock)
+points_in_frame_boxes_kernel(const float* __restrict__ pts, const int64_t* __restrict__ frame,
+                             int64_t N, const float* __restrict__ boxes,
+                             const int32_t* __restrict__ box_offsets, int F, int Bmax,
+                             int32_t* __restrict__ member, int32_t* __restrict__ first) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < N;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f = frame[j];
+    int b0 = 0, nb = 0;
+    if (f >= 0 && f < F) { b0 = box_offsets[f]; nb = box_offsets[f + 1] - b0; }
+    float x = pts[j * 3], y = pts[j * 3 + 1], z = pts[j * 3 + 2];
+    int fst = -1;
+    for (int bl = 0; bl < Bmax; ++bl) {
+      int in = 0;
+      if (bl < nb) in = point_in_box(x, y, z, boxes + (int64_t)(b0 + bl) * 7);
+      if (member) member[j * Bmax + bl] = in;
+      if (in && fst < 0) fst = bl;
+    }
+    if (first) first[j] = fst;
+  }
+}
+
 // comp_velos [C,F,3] f32 updated in place; comp_center_diffs [C,F,3]. frame_lo <= frame_hi are the
 // ordered ends of the optimised range (the reference swaps them itself when tracking backwards).
 // `err` (optional device word) is set to 3 if the multi-workgroup form timed out at its barrier.
@@ -1009,6 +1048,20 @@ int pcs_points_in_boxes(const float* points, int64_t N, const float* boxes, int 
   if (N < 0 || B < 0 || ((N > 0 && B > 0) && (!points || !boxes || !out))) return PCS_ERR_ARG;
   if (N == 0 || B == 0) return PCS_OK;
   points_in_boxes_kernel<<<grid_for((int64_t)B * N), kBlock, 0, s>>>(points, N, boxes, B, out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+int pcs_points_in_frame_boxes(const float* points, const int64_t* point_frame, int64_t N,
+                              const float* boxes, const int32_t* box_offsets, int F, int Bmax,
+                              int32_t* member, int32_t* first, hipStream_t s) {
+  if (N < 0 || F < 0 || Bmax < 0 || (N > 0 && (!points || !point_frame || !box_offsets)) ||
+      (!member && !first))
+    return PCS_ERR_ARG;
+  if (N == 0) return PCS_OK;
+  if (Bmax > 0 && !boxes) return PCS_ERR_ARG;
+  points_in_frame_boxes_kernel<<<grid_for(N), kBlock, 0, s>>>(points, point_frame, N, boxes, box_offsets,
+                                                              F, Bmax, member, first);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

@@ -405,6 +405,26 @@ def points_in_boxes(points, boxes):
     return out
 
 
+def points_in_frame_boxes(points, point_frame, boxes, box_offsets, bmax, want_member=True, want_first=True):
+    """points_in_boxes of every point against the boxes of its own frame (boxes grouped by frame,
+    `box_offsets` device int32 [F+1]). Returns (member [N,bmax] int32 or None, first [N] int32 or None)."""
+    L.require_gpu(points, "points_in_frame_boxes")
+    lib = L.load()
+    points = points.float().contiguous()
+    frame = point_frame.long().contiguous()
+    boxes = boxes.float().contiguous()
+    assert points.shape[1] == 3 and (boxes.numel() == 0 or boxes.shape[1] == 7)
+    assert box_offsets.dtype == torch.int32 and box_offsets.is_cuda
+    n, F = points.shape[0], box_offsets.shape[0] - 1
+    member = torch.empty(n, bmax, dtype=torch.int32, device=points.device) if want_member else None
+    first = torch.empty(n, dtype=torch.int32, device=points.device) if want_first else None
+    L.check(lib.pcs_points_in_frame_boxes(L.ptr(points), L.ptr(frame), L.i64(n), L.ptr(boxes),
+                                          L.ptr(box_offsets.contiguous()), L.i32(F), L.i32(bmax),
+                                          L.ptr(member), L.ptr(first), L.stream()),
+            "pcs_points_in_frame_boxes")
+    return member, first
+
+
 def l1_minimization(pillar_min_z, weight, lr, decay_steps, rigid_weight, max_iters):
     """preprocessor_utils.l1_minimization: returns pillar_height [X,Y] f32."""
     L.require_gpu(pillar_min_z, "l1_minimization")

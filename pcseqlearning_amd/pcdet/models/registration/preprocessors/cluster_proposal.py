@@ -12,7 +12,7 @@ from ..... import ops
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
-from .eval_utils import component_box_iou, scatter_max_
+from .eval_utils import component_box_iou, component_box_iou_frames, scatter_max_
 
 
 class ClusterProposal(nn.Module):
@@ -103,47 +103,48 @@ class ClusterProposal(nn.Module):
                                                                                   include_self=False),
                                        traces.max_frame)
 
-        # The box membership of the points does not depend on the component key: frames outermost,
-        # points_in_boxes / GT ids once per frame, then the per-key component statistics. best_iou is a
-        # running maximum, so the per-key snapshots are cumulative maxima in key order.
+        # All frames at once (the reference loops over frames and, inside, over components): boxes are
+        # grouped by frame, a point is tested against the boxes of its own frame
+        # (ops.points_in_frame_boxes), and the per-(frame, component) statistics are histograms
+        # (eval_utils.component_box_iou_frames). Box ids are indices within the frame, as in the
+        # reference. best_iou is a running maximum, so the per-key snapshots are cumulative maxima.
         fxyz = seq_dict["point_fxyz"]
         proto = seq_dict[f"point_{self.component_keys[0]}"]
+        dev = fxyz.device
+        assert bool((seq_boxes.frame[1:] >= seq_boxes.frame[:-1]).all()), "boxes must be grouped by frame"
+        box_cnt = torch.bincount(seq_boxes.frame.long(), minlength=num_frames)
+        box_off = torch.zeros(num_frames + 1, dtype=torch.int64, device=dev)
+        box_off[1:] = box_cnt.cumsum(0)
+        bmax = int(box_cnt.max().item())
         gt_box_id = torch.zeros_like(proto) - 1
         gt_trace_id = torch.zeros_like(proto) - 1
         pred = {k: (torch.zeros_like(proto) - 1, torch.zeros_like(proto) - 1) for k in self.component_keys}
         key_best = {k: torch.zeros_like(seq_boxes.best_iou) for k in self.component_keys}
-        for frame_id in range(num_frames):
-            fmask = (fxyz[:, 0] == frame_id).reshape(-1)
-            if not bool(fmask.any()):
-                continue
-            bmask = (seq_boxes.frame == frame_id).reshape(-1)
-            fb = EasyDict(filter_dict(seq_boxes, bmask))
-            if fb.attr.shape[0] == 0:
-                continue
-            f_fxyz = fxyz[fmask]
-            bp = ops.points_in_boxes(f_fxyz[:, 1:], fb.attr).long()
-            in_box = (bp == 1).any(0)
-            f_gt_box = torch.zeros(f_fxyz.shape[0], dtype=proto.dtype, device=proto.device) - 1
-            f_gt_trace = f_gt_box.clone()
-            f_gt_box[in_box] = bp[:, in_box].argmax(0).to(proto.dtype)
-            f_gt_trace[in_box] = fb.trace_id[f_gt_box[in_box]].to(proto.dtype)
-            gt_cnt = torch.bincount(f_gt_box[in_box], minlength=fb.attr.shape[0])
-            gt_box_id[fmask] = f_gt_box
-            gt_trace_id[fmask] = f_gt_trace
-            for comp_key in self.component_keys:
-                comp = seq_dict[f"point_{comp_key}"][fmask]
-                _, inv, has_box, box, iou = component_box_iou(comp, bp, f_gt_box, gt_cnt)
-                p_box = torch.where(has_box[inv], box[inv], torch.full_like(inv, -1))
-                p_trace = torch.zeros_like(p_box) - 1
-                valid = (p_box >= 0).reshape(-1)
-                p_trace[valid] = fb.trace_id[p_box[valid]].to(p_trace.dtype)
-                pred[comp_key][0][fmask] = p_box.to(proto.dtype)
-                pred[comp_key][1][fmask] = p_trace.to(proto.dtype)
-                f_best = key_best[comp_key][bmask]
-                scatter_max_(f_best, box[has_box], iou[has_box].to(f_best.dtype))
-                key_best[comp_key][bmask] = f_best
-                scatter_max_(traces.best_iou, fb.trace_id[box[has_box]].long(),
-                             iou[has_box].to(traces.best_iou.dtype))
+        fr = fxyz[:, 0].round().long()
+        sel = (box_cnt[fr.clamp(0, num_frames - 1)] > 0) & (fr >= 0) & (fr < num_frames)
+        idx = sel.nonzero(as_tuple=True)[0]            # points of frames that have boxes
+        s_fr = fr[idx]
+        member, first = ops.points_in_frame_boxes(fxyz[idx, 1:].contiguous(), s_fr, seq_boxes.attr,
+                                                  box_off.int(), bmax)
+        gt_local = first.to(proto.dtype)
+        in_box = gt_local >= 0
+        g_global = box_off[s_fr] + gt_local.clamp(min=0)
+        gt_box_id[idx] = gt_local
+        gt_trace_id[idx] = torch.where(in_box, seq_boxes.trace_id[g_global].to(proto.dtype), gt_local)
+        gt_cnt_all = torch.bincount(g_global[in_box], minlength=seq_boxes.attr.shape[0])
+        for comp_key in self.component_keys:
+            comp = seq_dict[f"point_{comp_key}"][idx]
+            gframe, _, inv, has_box, box, iou = component_box_iou_frames(comp, s_fr, member, gt_local,
+                                                                        box_off, gt_cnt_all)
+            p_box = torch.where(has_box[inv], box[inv], torch.full_like(inv, -1))
+            gbox_pt = box_off[s_fr] + p_box.clamp(min=0)
+            p_trace = torch.where(p_box >= 0, seq_boxes.trace_id[gbox_pt].to(p_box.dtype), p_box)
+            pred[comp_key][0][idx] = p_box.to(proto.dtype)
+            pred[comp_key][1][idx] = p_trace.to(proto.dtype)
+            gbox = (box_off[gframe] + box)[has_box]
+            scatter_max_(key_best[comp_key], gbox, iou[has_box].to(key_best[comp_key].dtype))
+            scatter_max_(traces.best_iou, seq_boxes.trace_id[gbox].long(),
+                         iou[has_box].to(traces.best_iou.dtype))
         for comp_key in self.component_keys:
             seq_boxes.best_iou = torch.maximum(seq_boxes.best_iou, key_best[comp_key])
             seq_boxes[f"best_iou_after_{comp_key}"] = seq_boxes.best_iou.clone()

@@ -18,7 +18,7 @@ from ....utils.common_utils import EasyDict, filter_dict, run_deferred
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
-from .eval_utils import component_box_iou, scatter_max_
+from .eval_utils import component_box_iou_frames, scatter_max_
 from .registration_utils import (IndexSegments, efficient_robust_sum, register_to_next_frame,
                                  robust_mean, robust_median, segment_max, segment_min)
 
@@ -144,40 +144,48 @@ class ClusterTracking(nn.Module):
         ))
 
     # ------------------------------------------------------------------ full-resolution harvest
-    def frame_views(self, all_points, seq_boxes, frame_ids):
-        """Per-frame views shared by every tracking unit of a sequence: the frame's full-resolution
-        points, its GT boxes, and the box membership of the points (independent of the component
-        key and the anchor, so built once per sequence instead of once per unit and frame)."""
-        device = all_points.fxyz.device
-        views = {}
-        for fid in frame_ids:
-            v = EasyDict()
-            v.frame_box_mask = (seq_boxes.frame == fid).reshape(-1)
-            v.frame_boxes = EasyDict(filter_dict(seq_boxes, v.frame_box_mask, ignore_keys=("best_iou",)))
-            v.frame_boxes.pop("best_iou", None)
-            v.ref_mask = (all_points.frame == fid).reshape(-1)
-            v.ref_index = v.ref_mask.nonzero()
-            ref_pts = EasyDict(filter_dict(all_points, v.ref_mask))
-            n_ref = ref_pts.fxyz.shape[0]
-            ref_pts.frame_indices = torch.arange(n_ref, device=device)
-            v.has_boxes = v.frame_boxes.attr.shape[0] > 0
-            if v.has_boxes:
-                ref_bp = ops.points_in_boxes(ref_pts.fxyz[:, 1:], v.frame_boxes.attr).long()
-                ref_pts.gt_box_id = ref_bp.argmax(0)
-                ref_pts.gt_box_id[ref_bp.max(0)[0] == 0] = -1
-                v.gt_cnt = torch.bincount(ref_pts.gt_box_id[ref_pts.gt_box_id >= 0],
-                                          minlength=v.frame_boxes.attr.shape[0])
-            else:
-                ref_pts.gt_box_id = torch.zeros(n_ref, device=device).to(ref_pts.frame) - 1
-            v.ref_pts = ref_pts
-            views[fid] = v
-        return views
+    def sequence_views(self, all_points, seq_boxes):
+        """What every tracking unit of a sequence needs of the full-resolution points and the GT boxes,
+        built once per sequence: the points grouped by frame (stable, so the order within a frame is
+        the reference's masked order), the row range of every frame, the boxes' row ranges per frame,
+        and for every point the first box of its frame that contains it (its GT box)."""
+        dev = all_points.fxyz.device
+        v = EasyDict()
+        fr = all_points.frame.reshape(-1).long()
+        num_frames = int(fr.max().item()) + 1
+        perm = torch.argsort(fr, stable=True)
+        v.perm = perm
+        v.frame = fr[perm]
+        v.fxyz = all_points.fxyz[perm].contiguous()
+        for key in ("full_segmentation_label", "full_instance_label"):
+            v[key] = all_points[key][perm]
+        v.frame_start = torch.searchsorted(v.frame, torch.arange(num_frames + 1, device=dev))
+        v.frame_start_host = v.frame_start.tolist()
+        assert bool((seq_boxes.frame[1:] >= seq_boxes.frame[:-1]).all()), "boxes must be grouped by frame"
+        box_cnt = torch.bincount(seq_boxes.frame.long(), minlength=num_frames)
+        v.box_cnt = box_cnt
+        v.box_off = torch.zeros(box_cnt.numel() + 1, dtype=torch.int64, device=dev)
+        v.box_off[1:] = box_cnt.cumsum(0)
+        v.box_off32 = v.box_off.int()
+        v.bmax = int(box_cnt.max().item()) if box_cnt.numel() else 0
+        v.num_frames = num_frames
+        _, first = ops.points_in_frame_boxes(v.fxyz[:, 1:].contiguous(), v.frame, seq_boxes.attr,
+                                             v.box_off32, v.bmax, want_member=False)
+        v.gt_local = first.long()
+        inb = v.gt_local >= 0
+        v.gt_cnt_all = torch.bincount((v.box_off[v.frame.clamp(max=box_cnt.numel() - 1)] + v.gt_local)[inb],
+                                      minlength=seq_boxes.attr.shape[0])
+        return v
 
     def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes, views=None):
         """Map tracked voxels back to the full-resolution points of each frame and update the
-        per-box best IoU (cluster_tracking.py:287-428)."""
-        full = {k: [] for k in ("fxyz", "component", "segmentation_label", "instance_label",
-                                "original_indices", "frame_indices", "moving")}
+        per-box best IoU (cluster_tracking.py:287-428). The reference loops over the frames; here
+        all frames go through one radius-graph call (edges never cross frames), the per-(frame,
+        component) centres / diameters are segment reductions on a combined key, and the GT
+        bookkeeping is the histogram form of eval_utils."""
+        if views is None:
+            views = self.sequence_views(all_points, seq_boxes)
+        v = views
         transforms = extracted.pop("transforms")
         num_components = int(extracted.component.max().long().item()) + 1
         comp_sg = IndexSegments(extracted.component, num_components)
@@ -186,48 +194,54 @@ class ClusterTracking(nn.Module):
         size_max = segment_max(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
         component_size = size_max - size_min + 1
         ext_frame = extracted.fxyz[:, 0].round().long()
-        frame_ids = ext_frame.unique().tolist()
-        if views is None:
-            views = self.frame_views(all_points, seq_boxes, frame_ids)
-        for fid in frame_ids:
-            v = views[fid]
-            ref_pts, frame_boxes, has_boxes = v.ref_pts, v.frame_boxes, v.has_boxes
-            one = EasyDict(filter_dict(extracted, (ext_frame == fid).reshape(-1)))
+        f_lo, f_hi = int(ext_frame.min().item()), int(ext_frame.max().item())
+        lo, hi = v.frame_start_host[f_lo], v.frame_start_host[f_hi + 1]
+        ref_fxyz = v.fxyz[lo:hi]
 
-            self.nn_graph.radius *= 1.732
-            e_ext, e_ref, _ = self.nn_graph(one, ref_pts)
-            self.nn_graph.radius /= 1.732
+        self.nn_graph.radius *= 1.732
+        e_ext, e_ref, _ = self.nn_graph(extracted, EasyDict(fxyz=ref_fxyz))
+        self.nn_graph.radius /= 1.732
 
-            center = robust_mean(one.fxyz[:, 1:3], one.component, num_components)
-            spread = (one.fxyz[:, 1:3] - center[one.component]).norm(p=2, dim=-1)
-            diameter = segment_max(spread, one.component, num_components)
-            dz = one.fxyz[e_ext, -1] - ref_pts.fxyz[e_ref, -1]
-            keep = dz < 0.5
-            dist = (ref_pts.fxyz[e_ref, 1:3] - center[one.component[e_ext]]).norm(p=2, dim=-1)
-            keep &= dist < diameter[one.component[e_ext]] + 0.05
-            keep &= dz > -0.05
-            e_ext, e_ref = e_ext[keep], e_ref[keep]
-            out = EasyDict(dict(
-                fxyz=ref_pts.fxyz[e_ref],
-                component=one.component[e_ext],
-                segmentation_label=ref_pts.full_segmentation_label[e_ref],
-                instance_label=ref_pts.full_instance_label[e_ref],
-                frame_indices=ref_pts.frame_indices[e_ref].to(extracted.component),
-                original_indices=v.ref_index[e_ref],
-                moving=one.moving[e_ext],
-            ))
-            for key in full:
-                full[key].append(out[key])
-            if has_boxes:
-                bp = ops.points_in_boxes(out.fxyz[:, 1:], frame_boxes.attr).long()
-                uniq, _, has_box, box, iou = component_box_iou(
-                    out.component, bp, ref_pts.gt_box_id[e_ref], v.gt_cnt)
-                best_iou = seq_boxes.best_iou[v.frame_box_mask]
-                iou32 = iou.to(best_iou.dtype)
-                component_hit[uniq[has_box & (iou32 > 0.7)]] += 1
-                scatter_max_(best_iou, box[has_box], iou32[has_box])
-                seq_boxes.best_iou[v.frame_box_mask] = best_iou
-        full = EasyDict({k: torch.cat(v, dim=0) for k, v in full.items()})
+        # centre and xy-diameter of every (frame, component) of the tracked voxels
+        comp = extracted.component.long()
+        gkey = (ext_frame - f_lo) * num_components + comp
+        num_groups = (f_hi - f_lo + 1) * num_components
+        gsg = IndexSegments(gkey, num_groups)
+        center = robust_mean(extracted.fxyz[:, 1:3], gsg, num_groups)
+        spread = (extracted.fxyz[:, 1:3] - center[gkey]).norm(p=2, dim=-1)
+        diameter = segment_max(spread, gsg, num_groups)
+        ekey = gkey[e_ext]
+        dz = extracted.fxyz[e_ext, -1] - ref_fxyz[e_ref, -1]
+        keep = dz < 0.5
+        dist = (ref_fxyz[e_ref, 1:3] - center[ekey]).norm(p=2, dim=-1)
+        keep &= dist < diameter[ekey] + 0.05
+        keep &= dz > -0.05
+        kidx = keep.nonzero(as_tuple=True)[0]
+        e_ext, e_ref = e_ext[kidx], e_ref[kidx]
+        g_ref = e_ref + lo                       # row in the frame-grouped full-resolution arrays
+        out_frame = v.frame[g_ref]
+        full = EasyDict(dict(
+            fxyz=v.fxyz[g_ref],
+            component=extracted.component[e_ext],
+            segmentation_label=v.full_segmentation_label[g_ref],
+            instance_label=v.full_instance_label[g_ref],
+            original_indices=v.perm[g_ref].reshape(-1, 1),
+            frame_indices=(g_ref - v.frame_start[out_frame]).to(extracted.component),
+            moving=extracted.moving[e_ext],
+        ))
+        # GT bookkeeping on the frames that have boxes
+        if v.bmax > 0 and full.fxyz.shape[0] > 0:
+            sel = (v.box_cnt[out_frame] > 0).nonzero(as_tuple=True)[0]
+            if sel.numel():
+                s_fr = out_frame[sel]
+                member, _ = ops.points_in_frame_boxes(full.fxyz[sel, 1:].contiguous(), s_fr, seq_boxes.attr,
+                                                      v.box_off32, v.bmax, want_first=False)
+                gframe, gcomp, _, has_box, box, iou = component_box_iou_frames(
+                    full.component[sel], s_fr, member, v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all)
+                iou32 = iou.to(seq_boxes.best_iou.dtype)
+                hit = has_box & (iou32 > 0.7)
+                component_hit.index_add_(0, gcomp[hit], torch.ones_like(gcomp[hit]).to(component_hit))
+                scatter_max_(seq_boxes.best_iou, (v.box_off[gframe] + box)[has_box], iou32[has_box])
         full.component_hit = component_hit
         full.component_size = component_size
         full.transforms = transforms
@@ -527,7 +541,7 @@ class ClusterTracking(nn.Module):
                 if frame_id in present:
                     units.append((comp_key, frame_id))
 
-        views = self.frame_views(all_points, seq_boxes, sorted(set(seq_points.frame.reshape(-1).long().unique().tolist())))
+        views = self.sequence_views(all_points, seq_boxes)
 
         def run_unit(worker, comp_key, frame_id):
             sp = EasyDict(dict(key_points[comp_key]))

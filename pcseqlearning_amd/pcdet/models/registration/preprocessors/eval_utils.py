@@ -31,3 +31,31 @@ def scatter_max_(dst, index, values):
     if index.numel():
         dst.scatter_reduce_(0, index, values, reduce="amax", include_self=True)
     return dst
+
+
+def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt_count_all):
+    """component_box_iou for many frames at once: a group is a (frame, component) pair, boxes are
+    indexed within their frame (`member` [n,Bmax] from ops.points_in_frame_boxes, `gt_local` [n] the
+    point's gt box within its frame or -1, `box_offsets` [F+1] long, `gt_count_all` [B] per global box).
+    Every point's frame must have boxes. Returns (group_frame [G], group_comp [G], inv [n],
+    has_box [G], box_local [G], iou [G] float64), groups ordered by (frame, component) as the
+    per-frame loop visits them."""
+    n, bmax = member.shape
+    comp = component.long()
+    span = int(comp.max().item()) + 1 if n else 1
+    key = frame.long() * span + comp
+    uniq, inv = key.unique(return_inverse=True)
+    G = uniq.numel()
+    gframe, gcomp = uniq // span, uniq % span
+    counts = torch.zeros(G, bmax, dtype=torch.int64, device=comp.device)
+    counts.index_add_(0, inv, member.long())
+    has_box = counts.sum(1) > 0
+    box = counts.argmax(1)
+    size = torch.bincount(inv, minlength=G)
+    in_gt = gt_local >= 0
+    hist = torch.bincount(inv[in_gt] * bmax + gt_local[in_gt].long(), minlength=G * bmax).reshape(G, bmax)
+    inter = hist.gather(1, box[:, None])[:, 0]
+    gbox = (box_offsets[gframe] + box).clamp(max=max(gt_count_all.numel() - 1, 0))
+    union = size + gt_count_all.long()[gbox] - inter
+    iou = inter.double() / (union.double() + 1e-6)
+    return gframe, gcomp, inv, has_box, box, iou
