@@ -160,6 +160,8 @@ def main():
 
     if rank == 0:
         out = model.last_outputs[0]
+        # HIP events attached to the dispatch itself (hipExtLaunchKernelGGL): begin-to-end time of the
+        # launch, the quantity rocprofv3 reports as the kernel duration
         ms, launches, nbytes = prof[0], prof[1], prof[2]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         line = {

@@ -296,7 +296,9 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
 /* Measurement support for bench.py (not on the data path): HIP-event timing, on the launch
  * stream, of the dominant kernel of the tracking stage (the fused ICP's two-direction 1-NN search +
  * pass-1 reduction). enable=1 resets and starts accumulating; read returns HOST doubles
- * {milliseconds, launches, algorithmic bytes}. */
+ * {milliseconds, launches, algorithmic bytes}. The milliseconds are begin-to-end times of the
+ * launches themselves: the HIP events ride on the dispatch (hipExtLaunchKernelGGL), which is what
+ * rocprofv3 reports as the kernel duration. */
 int pcs_profile_icp_nn(int enable);
 int pcs_profile_icp_nn_read(double* out3);
 
