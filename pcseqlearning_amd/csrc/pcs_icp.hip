@@ -5,12 +5,11 @@
 // builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
 // scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
 //
-// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is five
+// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is THREE
 // launches (the concurrent tracking units share a dispatch rate of a few hundred thousand kernels
 // per second, so launches are the currency):
-//   insert     the moved points into the two-level grid (pcs_grid2.hpp; one kernel: claim the fine
-//              slot, take a row of its run); also zeroes the accumulators
-//   nn         1-NN both directions, 32 lanes per query
+//   nn         1-NN both directions, 32 lanes per query (two-level grid, pcs_grid2.hpp); workgroup
+//              0 first settles the stop rule of iteration k-1
 //   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
 //              component (raw moments in f64; the centred covariance and the loss follow
 //              algebraically, so the reference's second pass over the edges is not needed)
@@ -53,8 +52,9 @@ struct IcpBufs {
   GridDesc* grid;
   float *b_ref, *b_mov, *b_all;
   IcpState* state;
-  Grid2 gr, gm, ga;  // non-stationary reference (static), moving (per iteration), all reference
-  int32_t *nn_f, *nn_b;
+  Grid2 gr, ga;      // non-stationary reference, all reference (static)
+  Grid2 gm[2];       // moving points: iteration k searches gm[k & 1], its apply fills gm[(k+1) & 1]
+  int32_t *nn_f, *nn_b;  // [2, Mn] / [2, Rn]: buffer k & 1 holds iteration k's neighbours
   float* prev;   // [Mn,4] positions before the last applied update
   double* acc;   // [2, C, kAcc] raw moments, buffer k & 1 for iteration k
   double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
@@ -75,10 +75,11 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.b_all = b.b_ref ? b.b_ref + 16 : nullptr;
   b.state = a.take<IcpState>(1);
   plan_grid2(a, Rn, b.gr);
-  plan_grid2(a, Mn, b.gm);
+  plan_grid2(a, Mn, b.gm[0]);
+  plan_grid2(a, Mn, b.gm[1]);
   plan_grid2(a, Ra, b.ga);
-  b.nn_f = a.take<int32_t>(Mn);
-  b.nn_b = a.take<int32_t>(Rn);
+  b.nn_f = a.take<int32_t>(2 * Mn);
+  b.nn_b = a.take<int32_t>(2 * Rn);
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<double>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
@@ -117,8 +118,8 @@ __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* _
 // <- empty (one launch instead of a dozen memsets)
 __global__ void __launch_bounds__(kBlock)
 icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* __restrict__ acc,
-                 int32_t* __restrict__ first, int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm,
-                 Grid2 ga) {
+                 int32_t* __restrict__ first, int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm0,
+                 Grid2 gm1, Grid2 ga) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (i < 24) bounds24[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
@@ -129,7 +130,8 @@ icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* 
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) acc[q] = 0.0;
   for (int64_t q = i; q < C; q += stride) { cnt[q] = 0; first[q] = INT_MAX; }
   g2_clear(gr, i, stride);
-  g2_clear(gm, i, stride);
+  g2_clear(gm0, i, stride);
+  g2_clear(gm1, i, stride);
   g2_clear(ga, i, stride);
 }
 
@@ -198,23 +200,6 @@ icp_decide_kernel(int k_done, IcpState* __restrict__ st, const double* __restric
   icp_decide(st, lossp, nparts, k_done, delta);
 }
 
-// iteration k, first launch: workgroup 0 first settles the stop rule of iteration k-1 (its losses
-// were written by the previous launch); the moved points go into the (already reset) moving grid.
-// The other workgroups may run before the stop is known: the moving grid is not read again after
-// a stop.
-__global__ void __launch_bounds__(kBlock)
-icp_insert_kernel(int k, const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp,
-                  Grid2 gm, IcpState* __restrict__ st, const double* __restrict__ lossp, int nparts,
-                  double delta) {
-  if (k > st->stop_iter) return;
-  if (blockIdx.x == 0) icp_decide(st, lossp, nparts, k - 1, delta);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  GridDesc d = *gp;
-  bool in = i < Mn;
-  float4 p = in ? mov[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  g2_insert_point(d, gm, in, i, p, &st->err);
-}
-
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
 // 64-lane butterflies first. All 64 lanes must call this.
 template <int NV>
@@ -241,8 +226,13 @@ __device__ __forceinline__ void grouped_atomic_add(bool active, int key, const d
 __global__ void __launch_bounds__(kBlock)
 icp_nn_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
               const GridDesc* __restrict__ gp, int df, Grid2 gr, Grid2 gm, IcpState* __restrict__ st,
-              int32_t* __restrict__ nn_f, int32_t* __restrict__ nn_b) {
+              int32_t* __restrict__ nn_f, int32_t* __restrict__ nn_b,
+              const double* __restrict__ lossp, int nparts, double delta) {
   if (k > st->stop_iter) return;
+  // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss partials
+  // were written by the previous launch). The other workgroups may run before the stop is known:
+  // they only write this iteration's neighbour buffers, which nothing reads after a stop.
+  if (blockIdx.x == 0) icp_decide(st, lossp, nparts, k - 1, delta);
   GridDesc g = *gp;
   int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   int sub = threadIdx.x & 31;
@@ -496,19 +486,24 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
 // iteration k, last launch: every moving point solves its own component's step from the completed
 // moments (redundantly across the points of a component: a 3x3 SVD is cheaper than another launch)
 // and moves; the component's first point also stores the updated transform (read buffer k-1, write
-// buffer k) and the loss term. The previous positions are kept for the l1 passes. Then the moving
-// grid, which the searches of this iteration are done with, is reset for the next insert.
+// buffer k) and the loss term. The previous positions are kept for the l1 passes. The moved points go
+// straight into the grid of the next iteration (the moving grid is double-buffered: no separate
+// build launch), and the grid this iteration searched is reset.
 __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
                  const int32_t* __restrict__ comp, const int32_t* __restrict__ first,
                  double* __restrict__ acc2, double* __restrict__ Tb, double* __restrict__ lossp,
-                 int64_t C, double reg, IcpState* __restrict__ st, Grid2 gm) {
+                 int64_t C, double reg, IcpState* __restrict__ st, const GridDesc* __restrict__ gp,
+                 Grid2 gm_done, Grid2 gm_next) {
   if (k > st->stop_iter) return;
   __shared__ double red[kBlock / 64];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  g2_clear(gm, i, (int64_t)gridDim.x * blockDim.x);
+  // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
+  // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
+  g2_clear(gm_done, i, (int64_t)gridDim.x * blockDim.x);
   if (i == 0) st->iters = k;
   double ls_mine = 0.0;
+  float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < Mn) {
     int c = comp[i];
     const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
@@ -521,7 +516,8 @@ icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int
     float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
     float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
     float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
-    mov[i] = make_float4(p.x, nx, ny, nz);
+    moved = make_float4(p.x, nx, ny, nz);
+    mov[i] = moved;
     if (first[c] == i) {
       // the component's owner: transform, loss term, and the other moment buffer zeroed for the
       // next iteration (nothing reads it during this launch)
@@ -531,6 +527,10 @@ icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int
       for (int q = 0; q < kAcc; ++q) an[q] = 0.0;
       ls_mine = ls;
     }
+  }
+  {
+    GridDesc d = *gp;
+    g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
   // loss partial of this workgroup (fixed order: lanes, then waves)
   ls_mine = wave_sum_f64(ls_mine);
@@ -698,9 +698,9 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
 
   // one launch resets everything the call owns, one finds the three bounding boxes
   {
-    int64_t words = (int64_t)(b.gr.slot_words + b.ga.slot_words + b.gm.slot_words) + C * kAcc;
+    int64_t words = (int64_t)(b.gr.slot_words + b.ga.slot_words + 2 * b.gm[0].slot_words) + C * kAcc;
     icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, b.Tb, b.acc, b.first, b.cnt, C, b.gr,
-                                                        b.gm, b.ga);
+                                                        b.gm[0], b.gm[1], b.ga);
     int64_t nmax = Mn > Rn ? Mn : Rn;
     if (Ra > nmax) nmax = Ra;
     int gb = (int)((nmax + kBlock - 1) / kBlock);
@@ -719,6 +719,10 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if (Ra > 0)
     g2_insert_kernel<<<(int)((Ra + kBlock - 1) / kBlock), kBlock, 0, s>>>(
         (const float4*)ref_all, (int)Ra, b.grid, b.ga, 0, &b.state->stop_iter, &b.state->err);
+  // the moving points as they arrive: the grid of iteration 1
+  if (Mn > 0)
+    g2_insert_kernel<<<(int)((Mn + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm[1], 0, &b.state->stop_iter, &b.state->err);
 
   int nb_m = (int)((Mn + kBlock - 1) / kBlock);
   if (nb_m < 1) nb_m = 1;
@@ -741,8 +745,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
     for (int j = 0; j < n_it; ++j) {
       int k = it + j + 1;  // 1-based iteration number
-      icp_insert_kernel<<<nb_m, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm,
-                                                b.state, b.lossp, nb_m, stopping_delta);
+      int32_t* nnf = b.nn_f + (size_t)(k & 1) * (Mn > 0 ? Mn : 1);
+      int32_t* nnb = b.nn_b + (size_t)(k & 1) * (Rn > 0 ? Rn : 1);
       bool pk = prof && k <= kProfIters;
       if (pk) {
         // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
@@ -750,18 +754,21 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
         hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q), dim3(kBlock), 0, s, t_ev.ev[2 * (k - 1)],
                               t_ev.ev[2 * (k - 1) + 1], 0, k, (const float4*)mov_fxyz, (int)Mn,
                               (const float4*)ref_fxyz, (int)Rn, (const GridDesc*)b.grid, frame_offset,
-                              b.gr, b.gm, b.state, b.nn_f, b.nn_b);
+                              b.gr, b.gm[k & 1], b.state, nnf, nnb, (const double*)b.lossp, nb_m,
+                              stopping_delta);
       } else {
         icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
                                               (const float4*)ref_fxyz, (int)Rn, b.grid, frame_offset,
-                                              b.gr, b.gm, b.state, b.nn_f, b.nn_b);
+                                              b.gr, b.gm[k & 1], b.state, nnf, nnb, b.lossp, nb_m,
+                                              stopping_delta);
       }
       icp_moments_kernel<<<nb_e, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
-                                                 (const float4*)ref_fxyz, (int)Rn, mov_comp, b.nn_f,
-                                                 b.nn_b, b.state, b.acc + (size_t)(k & 1) * C * kAcc);
+                                                 (const float4*)ref_fxyz, (int)Rn, mov_comp, nnf, nnb,
+                                                 b.state, b.acc + (size_t)(k & 1) * C * kAcc);
       icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
                                                mov_comp, b.first, b.acc, b.Tb, b.lossp, C,
-                                               angle_regularizer, b.state, b.gm);
+                                               angle_regularizer, b.state, b.grid, b.gm[k & 1],
+                                               b.gm[(k + 1) & 1]);
     }
     it += n_it;
     // the stop rule of the chunk's last iteration (the others were settled by the next insert)
@@ -789,13 +796,15 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   info[1] = host.stop_iter != INT_MAX ? 1 : 0;
   info[2] = info[3] = 0;
   double* acc_fin = b.acc + (size_t)(host.iters & 1) * C * kAcc;  // moments of the last iteration
+  const int32_t* nnf_fin = b.nn_f + (size_t)(host.iters & 1) * (Mn > 0 ? Mn : 1);
+  const int32_t* nnb_fin = b.nn_b + (size_t)(host.iters & 1) * (Rn > 0 ? Rn : 1);
   const double* T_fin = b.Tb + (size_t)(host.iters & 1) * C * 16;
   if (host.iters > 0) {
     // l1 error of the last iteration: positions before its update are in `prev`
     icp_l1_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, acc_fin, 0.3);
+                                             (int)Rn, mov_comp, nnf_fin, nnb_fin, acc_fin, 0.3);
     icp_l1_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, b.nn_f, b.nn_b, acc_fin, 0.3);
+                                             (int)Rn, mov_comp, nnf_fin, nnb_fin, acc_fin, 0.3);
   }
   if (Mn > 0 && Ra > 0)
     icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
