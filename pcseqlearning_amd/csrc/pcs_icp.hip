@@ -26,8 +26,12 @@
 
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 namespace pcs {
 
@@ -48,6 +52,8 @@ struct IcpState {
 constexpr int kProfIters = 96;  // iterations per call whose icp_nn_kernel is timed when profiling
 constexpr int kAcc = 20;  // n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2, sum dist, sum clamp, pad
 
+struct IcpProblem;
+
 struct IcpBufs {
   GridDesc* grid;
   float *b_ref, *b_mov, *b_all;
@@ -60,8 +66,30 @@ struct IcpBufs {
   double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
   double* lossp; // [ceil(Mn / kBlock)] per-workgroup sums of the component losses, last applied iteration
   int32_t* first; // [C] smallest moving-point index of the component (INT_MAX: none)
+  IcpProblem* desc; // device copy of this call's problem descriptor
 
   int32_t* cnt;  // [C] matched moving points in the final coverage query
+};
+
+// One ICP problem as the iteration kernels see it. The kernels take an ARRAY of these and
+// blockIdx.y selects the problem, so the iterations of several calls (the concurrent tracking units)
+// can share launches; a stand-alone call is an array of one.
+struct IcpProblem {
+  float4* mov;
+  float4* prev;
+  const float4* ref;
+  const int32_t* comp;
+  const int32_t* first;
+  int32_t *nn_f, *nn_b;
+  double *acc, *Tb, *lossp;
+  IcpState* st;
+  const GridDesc* grid;
+  Grid2 gr, gm[2];
+  int64_t C;
+  double reg, delta;
+  int Mn, Rn, df, nparts;
+  int k0;    // iteration number of chunk position 0
+  int n_it;  // chunk positions this problem takes part in
 };
 
 static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
@@ -85,6 +113,7 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.Tb = a.take<double>(2 * C * 16);
   b.lossp = a.take<double>((Mn + kBlock - 1) / kBlock + 1);
   b.first = a.take<int32_t>(C);
+  b.desc = a.take<IcpProblem>(1);
 
   b.cnt = a.take<int32_t>(C);
   return a.ok();
@@ -194,10 +223,15 @@ __device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const doub
   }
 }
 
+// end of a chunk: the stop rule of every problem's last iteration (the others were settled by the
+// next search launch), and the state mirrored where the host reads it (`out` may be pinned host
+// memory: the host then needs no copy, only the stream synchronisation)
 __global__ void __launch_bounds__(kBlock)
-icp_decide_kernel(int k_done, IcpState* __restrict__ st, const double* __restrict__ lossp, int nparts,
-                  double delta) {
-  icp_decide(st, lossp, nparts, k_done, delta);
+icp_decide_kernel(const IcpProblem* __restrict__ P, int kbase, IcpState* __restrict__ out) {
+  const IcpProblem& pr = P[blockIdx.y];
+  icp_decide(pr.st, pr.lossp, pr.nparts, pr.k0 + kbase + pr.n_it - 1, pr.delta);
+  __syncthreads();
+  if (out && threadIdx.x == 0) out[blockIdx.y] = *pr.st;
 }
 
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
@@ -224,37 +258,40 @@ __device__ __forceinline__ void grouped_atomic_add(bool active, int key, const d
 // 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
 // queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
 __global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
-              const GridDesc* __restrict__ gp, int df, Grid2 gr, Grid2 gm, IcpState* __restrict__ st,
-              int32_t* __restrict__ nn_f, int32_t* __restrict__ nn_b,
-              const double* __restrict__ lossp, int nparts, double delta) {
+icp_nn_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  const IcpProblem& pr = P[blockIdx.y];
+  if (j >= pr.n_it) return;
+  const int k = pr.k0 + kbase + j;
+  IcpState* st = pr.st;
   if (k > st->stop_iter) return;
+  const int Mn = pr.Mn, Rn = pr.Rn;
+  if (blockIdx.x != 0 && (int64_t)blockIdx.x * (kBlock / 32) >= (int64_t)Mn + Rn) return;
   // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss partials
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (blockIdx.x == 0) icp_decide(st, lossp, nparts, k - 1, delta);
-  GridDesc g = *gp;
+  if (blockIdx.x == 0) icp_decide(st, pr.lossp, pr.nparts, k - 1, pr.delta);
+  GridDesc g = *pr.grid;
   int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   int sub = threadIdx.x & 31;
   bool fwd = qid < Mn;
   bool valid = qid < Mn + Rn;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) p = fwd ? mov[qid] : ref[qid - Mn];
+  if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
   // a wave may straddle the forward/backward boundary: its two halves then search different grids
   bool any_fwd = __ballot(valid && fwd) != 0;
   bool any_bwd = __ballot(valid && !fwd) != 0;
   int res = -1;
   if (any_fwd) {
-    int r = g2_nearest_coop(g, gr, p, df, valid && fwd, &st->err);
+    int r = g2_nearest_coop(g, pr.gr, p, pr.df, valid && fwd, &st->err);
     if (fwd) res = r;
   }
   if (any_bwd) {
-    int r = g2_nearest_coop(g, gm, p, -df, valid && !fwd, &st->err);
+    int r = g2_nearest_coop(g, pr.gm[k & 1], p, -pr.df, valid && !fwd, &st->err);
     if (!fwd) res = r;
   }
   if (valid && sub == 0) {
-    if (fwd) nn_f[qid] = res;
-    else nn_b[qid - Mn] = res;
+    if (fwd) pr.nn_f[(size_t)(k & 1) * (Mn > 0 ? Mn : 1) + qid] = res;
+    else pr.nn_b[(size_t)(k & 1) * (Rn > 0 ? Rn : 1) + (qid - Mn)] = res;
   }
 }
 
@@ -263,11 +300,19 @@ icp_nn_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __res
 // mostly share a component), then flushes one global f64 atomic per (component, accumulator).
 constexpr int kMomSlots = 64;
 __global__ void __launch_bounds__(kBlock)
-icp_moments_kernel(int k, const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref,
-                   int Rn, const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
-                   const int32_t* __restrict__ nn_b, const IcpState* __restrict__ st,
-                   double* __restrict__ acc) {
-  if (k > st->stop_iter) return;
+icp_moments_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  const IcpProblem& pr = P[blockIdx.y];
+  if (j >= pr.n_it) return;
+  const int k = pr.k0 + kbase + j;
+  if (k > pr.st->stop_iter) return;
+  const int Mn = pr.Mn, Rn = pr.Rn;
+  if ((int64_t)blockIdx.x * kBlock >= (int64_t)Mn + Rn) return;
+  const float4* __restrict__ mov = pr.mov;
+  const float4* __restrict__ ref = pr.ref;
+  const int32_t* __restrict__ comp = pr.comp;
+  const int32_t* __restrict__ nn_f = pr.nn_f + (size_t)(k & 1) * (Mn > 0 ? Mn : 1);
+  const int32_t* __restrict__ nn_b = pr.nn_b + (size_t)(k & 1) * (Rn > 0 ? Rn : 1);
+  double* __restrict__ acc = pr.acc + (size_t)(k & 1) * pr.C * kAcc;
   __shared__ int skey[kMomSlots];
   __shared__ double sacc[kMomSlots][17];
   for (int q = threadIdx.x; q < kMomSlots; q += kBlock) skey[q] = -1;
@@ -490,17 +535,31 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
 // straight into the grid of the next iteration (the moving grid is double-buffered: no separate
 // build launch), and the grid this iteration searched is reset.
 __global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(int k, float4* __restrict__ mov, float4* __restrict__ prev, int Mn,
-                 const int32_t* __restrict__ comp, const int32_t* __restrict__ first,
-                 double* __restrict__ acc2, double* __restrict__ Tb, double* __restrict__ lossp,
-                 int64_t C, double reg, IcpState* __restrict__ st, const GridDesc* __restrict__ gp,
-                 Grid2 gm_done, Grid2 gm_next) {
+icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  const IcpProblem& pr = P[blockIdx.y];
+  if (j >= pr.n_it) return;
+  const int k = pr.k0 + kbase + j;
+  IcpState* st = pr.st;
   if (k > st->stop_iter) return;
+  if ((int)blockIdx.x >= pr.nparts) return;
+  const int Mn = pr.Mn;
+  const int64_t C = pr.C;
+  const double reg = pr.reg;
+  float4* __restrict__ mov = pr.mov;
+  float4* __restrict__ prev = pr.prev;
+  const int32_t* __restrict__ comp = pr.comp;
+  const int32_t* __restrict__ first = pr.first;
+  double* __restrict__ acc2 = pr.acc;
+  double* __restrict__ Tb = pr.Tb;
+  double* __restrict__ lossp = pr.lossp;
+  const GridDesc* __restrict__ gp = pr.grid;
+  const Grid2& gm_done = pr.gm[k & 1];
+  const Grid2& gm_next = pr.gm[(k + 1) & 1];
   __shared__ double red[kBlock / 64];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
-  g2_clear(gm_done, i, (int64_t)gridDim.x * blockDim.x);
+  g2_clear(gm_done, i, (int64_t)pr.nparts * blockDim.x);
   if (i == 0) st->iters = k;
   double ls_mine = 0.0;
   float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -585,6 +644,186 @@ struct NnEvents {
 };
 static thread_local NnEvents t_ev;
 
+// launches of one chunk (n_max iteration positions) for an array of problems already on the device
+static int icp_launch_chunk(const IcpProblem* d_probs, int nprob, int n_max, int kbase, int max_nb_q,
+                            int max_nb_e, int max_nb_m, IcpState* out, hipStream_t s, hipEvent_t* ev) {
+  for (int j = 0; j < n_max; ++j) {
+    if (ev) {
+      // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
+      // difference is the kernel's own begin-to-end time, as rocprofv3 reports it
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(max_nb_q, nprob), dim3(kBlock), 0, s, ev[2 * j],
+                            ev[2 * j + 1], 0, d_probs, j, kbase);
+    } else {
+      icp_nn_kernel<<<dim3(max_nb_q, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+    }
+    icp_moments_kernel<<<dim3(max_nb_e, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+    icp_apply_kernel<<<dim3(max_nb_m, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+  }
+  // the stop rule of the chunk's last iteration (the others were settled by the next search)
+  icp_decide_kernel<<<dim3(1, nprob), kBlock, 0, s>>>(d_probs, kbase, out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// ---- shared launches for concurrent calls ---------------------------------------------------
+// Kernels of different streams overlap only 2-3 deep on this hardware, while the iteration kernels
+// of one problem leave most of the device idle. Threads that registered as participants (the
+// tracking units, pcs_tracker.hip) therefore hand their chunks to ONE launcher thread: whatever is
+// pending when the launcher is free goes out as one array of problems (blockIdx.y = problem), so
+// nine chains of ~50 us iterations become one chain of wider kernels. A caller synchronises its own
+// stream before submitting and continues on it after the launcher has synchronised the shared
+// stream, so no cross-stream ordering is needed. While a batch runs (~0.4 ms) later requests queue
+// up, which is what keeps the batches full without any waiting window.
+constexpr int kMaxBatch = 64;
+static double g_batch_stats[4] = {0, 0, 0, 0};  // batches, problems, busy seconds, idle seconds
+struct IcpRequest {
+  IcpProblem prob;
+  int nb_q, nb_e, nb_m;
+  double bytes_per_launch;
+  IcpState result;
+  int rc = 0;
+  bool done = false;
+};
+
+class IcpBatcher {
+ public:
+  static IcpBatcher& get() {
+    static IcpBatcher* inst = new IcpBatcher();  // never destroyed: the launcher thread outlives main
+    return *inst;
+  }
+  void add_participant() {
+    std::lock_guard<std::mutex> lk(mu_);
+    ++participants_;
+  }
+  void remove_participant() {
+    std::lock_guard<std::mutex> lk(mu_);
+    --participants_;
+  }
+  // a participant is between the start of an ICP call and the end of its iteration loop: it WILL
+  // submit a chunk shortly, so the launcher holds the next batch until all of these have
+  void enter_icp() {
+    std::lock_guard<std::mutex> lk(mu_);
+    ++in_icp_;
+  }
+  void leave_icp() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      --in_icp_;
+    }
+    cv_work_.notify_one();
+  }
+  int run(IcpRequest* req) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!started_) {
+      if (hipGetDevice(&device_) != hipSuccess) return PCS_ERR_HIP;
+      started_ = true;
+      std::thread(&IcpBatcher::loop, this).detach();
+    }
+    req->done = false;
+    pending_.push_back(req);
+    cv_work_.notify_one();
+    cv_done_.wait(lk, [&] { return req->done; });
+    return req->rc;
+  }
+
+ private:
+  void loop() {
+    bool ok = hipSetDevice(device_) == hipSuccess &&
+              hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&d_probs_, kMaxBatch * sizeof(IcpProblem)) == hipSuccess &&
+              hipHostMalloc(&h_probs_, kMaxBatch * sizeof(IcpProblem)) == hipSuccess &&
+              hipHostMalloc(&h_state_, kMaxBatch * sizeof(IcpState)) == hipSuccess;
+    hipEvent_t ev[2 * 16];
+    bool have_ev = false;
+    std::vector<IcpRequest*> batch;
+    auto t_free = std::chrono::steady_clock::now();
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        // go when every participant that is inside an ICP call has submitted its chunk (those that
+        // were in the previous batch need a few microseconds to come back); 2 ms safety net
+        for (;;) {
+          bool ready = cv_work_.wait_for(lk, std::chrono::milliseconds(2), [&] {
+            return !pending_.empty() && (int)pending_.size() >= in_icp_;
+          });
+          if (ready || !pending_.empty()) break;
+        }
+        batch.clear();
+        while (!pending_.empty() && (int)batch.size() < kMaxBatch) {
+          batch.push_back(pending_.front());
+          pending_.erase(pending_.begin());
+        }
+      }
+      auto t_start = std::chrono::steady_clock::now();
+      int rc = ok ? PCS_OK : PCS_ERR_HIP;
+      int n = (int)batch.size(), n_max = 0, q = 1, e = 1, m = 1;
+      double bytes = 0.0;
+      if (rc == PCS_OK) {
+        for (int i = 0; i < n; ++i) {
+          h_probs_[i] = batch[i]->prob;
+          if (batch[i]->prob.n_it > n_max) n_max = batch[i]->prob.n_it;
+          if (batch[i]->nb_q > q) q = batch[i]->nb_q;
+          if (batch[i]->nb_e > e) e = batch[i]->nb_e;
+          if (batch[i]->nb_m > m) m = batch[i]->nb_m;
+          bytes += batch[i]->bytes_per_launch;
+        }
+        bool prof = g_prof_on && n_max <= 16;
+        if (prof && !have_ev) {
+          for (int i = 0; i < 32; ++i) prof = prof && hipEventCreate(&ev[i]) == hipSuccess;
+          have_ev = prof;
+        }
+        if (hipMemcpyAsync(d_probs_, h_probs_, (size_t)n * sizeof(IcpProblem), hipMemcpyHostToDevice,
+                           stream_) != hipSuccess)
+          rc = PCS_ERR_HIP;
+        if (rc == PCS_OK) rc = icp_launch_chunk(d_probs_, n, n_max, 0, q, e, m, h_state_, stream_, prof ? ev : nullptr);
+        if (rc == PCS_OK && hipStreamSynchronize(stream_) != hipSuccess) rc = PCS_ERR_HIP;
+        if (rc == PCS_OK && prof) {
+          double ms_sum = 0.0;
+          for (int j = 0; j < n_max; ++j) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]) == hipSuccess) ms_sum += ms;
+          }
+          std::lock_guard<std::mutex> lk(g_prof_mu);
+          g_prof_total.ms += ms_sum;
+          g_prof_total.launches += n_max;
+          g_prof_total.bytes += bytes * n_max;
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto t_end = std::chrono::steady_clock::now();
+        g_batch_stats[0] += 1;
+        g_batch_stats[1] += n;
+        g_batch_stats[2] += std::chrono::duration<double>(t_end - t_start).count();
+        g_batch_stats[3] += std::chrono::duration<double>(t_start - t_free).count();
+        t_free = t_end;
+        for (int i = 0; i < n; ++i) {
+          if (rc == PCS_OK) batch[i]->result = h_state_[i];
+          batch[i]->rc = rc;
+          batch[i]->done = true;
+        }
+      }
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::vector<IcpRequest*> pending_;
+  int participants_ = 0;
+  int in_icp_ = 0;
+  bool started_ = false;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  IcpProblem* d_probs_ = nullptr;
+  IcpProblem* h_probs_ = nullptr;
+  IcpState* h_state_ = nullptr;
+};
+
+// set by pcs_icp_share_launches(): the calling thread's ICP calls go through the shared launcher
+static thread_local bool t_share_launches = false;
+static thread_local double t_share_wait_s = 0.0;  // time this thread spent inside IcpBatcher::run
+static thread_local double t_icp_s = 0.0;         // time this thread spent inside the ICP entry point
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -636,6 +875,33 @@ int pcs_profile_sync_loop(int64_t n, int mode, hipStream_t s) {
   return PCS_OK;
 }
 
+// the calling thread's pcs_register_to_next_frame calls use (1) / stop using (0) the shared launcher
+int pcs_icp_share_launches(int enable) {
+  if (enable && !t_share_launches) IcpBatcher::get().add_participant();
+  if (!enable && t_share_launches) IcpBatcher::get().remove_participant();
+  t_share_launches = enable != 0;
+  return PCS_OK;
+}
+
+// diagnostic: {batches, problems, seconds launching + waiting for batches, seconds idle} of the
+// shared launcher since the last call (reset on read)
+// diagnostic: seconds the calling thread has spent waiting in the shared launcher / inside
+// pcs_register_to_next_frame since the last call (reset on read)
+int pcs_profile_thread_icp_read(double* out2) {
+  if (!out2) return PCS_ERR_ARG;
+  out2[0] = t_share_wait_s;
+  out2[1] = t_icp_s;
+  t_share_wait_s = 0.0;
+  t_icp_s = 0.0;
+  return PCS_OK;
+}
+
+int pcs_profile_batcher_read(double* out4) {
+  if (!out4) return PCS_ERR_ARG;
+  for (int i = 0; i < 4; ++i) { out4[i] = g_batch_stats[i]; g_batch_stats[i] = 0; }
+  return PCS_OK;
+}
+
 int pcs_profile_icp_nn(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
@@ -680,6 +946,10 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       (Rn > 0 && !ref_fxyz) || (Ra > 0 && !ref_all))
     return PCS_ERR_ARG;
   if (Mn + Rn >= (1LL << 26)) return PCS_ERR_RANGE;
+  struct CallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~CallTimer() { t_icp_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  } call_timer;
   Arena a(ws, ws_bytes);
   IcpBufs b;
   if (!plan_icp(a, Mn, Rn, Ra, C, b)) return PCS_ERR_WORKSPACE;
@@ -731,11 +1001,55 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
   if (nb_q < 1) nb_q = 1;
 
-  bool prof = g_prof_on;
+  // this call's problem descriptor
+  IcpRequest req;
+  {
+    IcpProblem& pr = req.prob;
+    pr.mov = (float4*)mov_fxyz;
+    pr.prev = (float4*)b.prev;
+    pr.ref = (const float4*)ref_fxyz;
+    pr.comp = mov_comp;
+    pr.first = b.first;
+    pr.nn_f = b.nn_f;
+    pr.nn_b = b.nn_b;
+    pr.acc = b.acc;
+    pr.Tb = b.Tb;
+    pr.lossp = b.lossp;
+    pr.st = b.state;
+    pr.grid = b.grid;
+    pr.gr = b.gr;
+    pr.gm[0] = b.gm[0];
+    pr.gm[1] = b.gm[1];
+    pr.C = C;
+    pr.reg = angle_regularizer;
+    pr.delta = stopping_delta;
+    pr.Mn = (int)Mn;
+    pr.Rn = (int)Rn;
+    pr.df = frame_offset;
+    pr.nparts = nb_m;
+    pr.k0 = 1;
+    pr.n_it = 0;
+    req.nb_q = nb_q;
+    req.nb_e = nb_e;
+    req.nb_m = nb_m;
+    // per launch: read every query point and every hashed point (16 B rows), write one int32
+    // neighbour per query (SURVEY.md 8d: 16 N + 16 M per graph, two graphs per iteration)
+    req.bytes_per_launch = 2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn);
+  }
+  const bool shared = t_share_launches;
+  struct IcpPhase {  // tells the shared launcher that this thread is about to submit chunks
+    bool on;
+    explicit IcpPhase(bool o) : on(o) { if (on) IcpBatcher::get().enter_icp(); }
+    void end() { if (on) { IcpBatcher::get().leave_icp(); on = false; } }
+    ~IcpPhase() { end(); }
+  } phase(shared);
+  bool prof = g_prof_on && !shared;
   if (prof && !t_ev.have) {
     for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
     t_ev.have = true;
   }
+  if (!shared)
+    PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
   IcpState host;
   host.stop_iter = INT_MAX;
   host.iters = 0;
@@ -743,41 +1057,39 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   int it = 0;
   while (it < max_iter) {
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
-    for (int j = 0; j < n_it; ++j) {
-      int k = it + j + 1;  // 1-based iteration number
-      int32_t* nnf = b.nn_f + (size_t)(k & 1) * (Mn > 0 ? Mn : 1);
-      int32_t* nnb = b.nn_b + (size_t)(k & 1) * (Rn > 0 ? Rn : 1);
-      bool pk = prof && k <= kProfIters;
-      if (pk) {
-        // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
-        // difference is the kernel's own begin-to-end time, as rocprofv3 reports it
-        hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q), dim3(kBlock), 0, s, t_ev.ev[2 * (k - 1)],
-                              t_ev.ev[2 * (k - 1) + 1], 0, k, (const float4*)mov_fxyz, (int)Mn,
-                              (const float4*)ref_fxyz, (int)Rn, (const GridDesc*)b.grid, frame_offset,
-                              b.gr, b.gm[k & 1], b.state, nnf, nnb, (const double*)b.lossp, nb_m,
-                              stopping_delta);
-      } else {
-        icp_nn_kernel<<<nb_q, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
-                                              (const float4*)ref_fxyz, (int)Rn, b.grid, frame_offset,
-                                              b.gr, b.gm[k & 1], b.state, nnf, nnb, b.lossp, nb_m,
-                                              stopping_delta);
+    if (shared) {
+      // everything this call enqueued so far must be complete before the shared stream touches it
+      PCS_CHECK_HIP(hipStreamSynchronize(s));
+      req.prob.k0 = it + 1;
+      req.prob.n_it = n_it;
+      auto tw = std::chrono::steady_clock::now();
+      int rc2 = IcpBatcher::get().run(&req);
+      t_share_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      if (rc2) return rc2;
+      host = req.result;
+    } else {
+      // the device copy of the descriptor keeps k0 = 1 / n_it = 0: the chunk position is passed
+      // as kbase and every position is enabled through n_it below
+      if (it == 0) {
+        req.prob.n_it = chunk;
+        PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
       }
-      icp_moments_kernel<<<nb_e, kBlock, 0, s>>>(k, (const float4*)mov_fxyz, (int)Mn,
-                                                 (const float4*)ref_fxyz, (int)Rn, mov_comp, nnf, nnb,
-                                                 b.state, b.acc + (size_t)(k & 1) * C * kAcc);
-      icp_apply_kernel<<<nb_m, kBlock, 0, s>>>(k, (float4*)mov_fxyz, (float4*)b.prev, (int)Mn,
-                                               mov_comp, b.first, b.acc, b.Tb, b.lossp, C,
-                                               angle_regularizer, b.state, b.grid, b.gm[k & 1],
-                                               b.gm[(k + 1) & 1]);
+      if (n_it != chunk) {
+        req.prob.n_it = n_it;
+        PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
+      }
+      bool pk = prof && it + n_it <= kProfIters;
+      int rc2 = icp_launch_chunk(b.desc, 1, n_it, it, nb_q, nb_e, nb_m, nullptr, s,
+                                 pk ? &t_ev.ev[2 * it] : nullptr);
+      if (rc2) return rc2;
+      PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+      PCS_CHECK_HIP(hipStreamSynchronize(s));
     }
     it += n_it;
-    // the stop rule of the chunk's last iteration (the others were settled by the next insert)
-    icp_decide_kernel<<<1, kBlock, 0, s>>>(it, b.state, b.lossp, nb_m, stopping_delta);
-    PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (host.err) return PCS_ERR_RANGE;
     if (host.stop_iter != INT_MAX) break;
   }
+  phase.end();
   if (prof) {
     int n_done = host.iters < kProfIters ? host.iters : kProfIters;
     double ms_sum = 0.0;
@@ -788,9 +1100,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_total.ms += ms_sum;
     g_prof_total.launches += n_done;
-    // per launch: read every query point and every hashed point (16 B rows), write one int32
-    // neighbour per query (SURVEY.md 8d: 16 N + 16 M per graph, two graphs per iteration)
-    g_prof_total.bytes += (double)n_done * (2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn));
+    g_prof_total.bytes += (double)n_done * req.bytes_per_launch;
   }
   info[0] = host.iters;
   info[1] = host.stop_iter != INT_MAX ? 1 : 0;

@@ -594,6 +594,13 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   Arena a(ws, ws_bytes);
   TrkPlan p;
   if (!plan_track(a, na, nm, C, F, p)) return PCS_ERR_WORKSPACE;
+  // optional: the ICP iterations of the concurrent tracking units share launches for the duration
+  // of the call (prm->share_launches; see IcpBatcher in pcs_icp.hip for when that pays)
+  struct ShareGuard {
+    bool on;
+    explicit ShareGuard(bool o) : on(o) { if (on) pcs_icp_share_launches(1); }
+    ~ShareGuard() { if (on) pcs_icp_share_launches(0); }
+  } share_guard(prm->share_launches != 0);
 
   const float4* anchor = (const float4*)seq_fxyz + off_a;
   const int gA = nblk(na), gC = nblk(C);
@@ -759,6 +766,11 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   info[0] = host.ex_count;
   info[1] = reg_calls;
   info[2] = steps;
+  {
+    double t2[2] = {0, 0};
+    pcs_profile_thread_icp_read(t2);
+    info[3] = (int64_t)(t2[0] * 1e6) * 1000000LL + (int64_t)(t2[1] * 1e6);  // us in launcher | us in ICP
+  }
   return PCS_OK;
 }
 

@@ -513,14 +513,15 @@ class TrackParams(__import__("ctypes").Structure):
         ("voxel_size", (_c.c_float * 3) * 4),
         ("nn_radius", _c.c_float), ("reg_error_coeff", _c.c_float), ("angle_threshold", _c.c_float),
         ("max_diameter", _c.c_float), ("smooth_weight0", _c.c_float), ("smooth_weight", _c.c_float),
-        ("smooth_stopping", _c.c_float),
+        ("smooth_stopping", _c.c_float), ("share_launches", _c.c_int32),
     ]
 
 
 def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
-                 smooth=(1.0, 10.0, 300, 1e-3)):
+                 smooth=(1.0, 10.0, 300, 1e-3), share_launches=False):
     prm = TrackParams()
+    prm.share_launches = int(bool(share_launches))
     L_ = len(radius_list)
     if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
         raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")
@@ -592,4 +593,5 @@ def track_frame(prm, seq_fxyz, seq_component, seq_stationary, frame_offsets, anc
         out[k] = out[k][:n_ex]
     out["moving"] = out["moving"].bool()
     out["valid_comp"] = out["valid_comp"].bool()
+    out["_icp_us"] = (int(info[3]) // 1000000, int(info[3]) % 1000000)  # diagnostic: in launcher, in ICP
     return out, (n_ex, int(info[1]), int(info[2]))

@@ -299,11 +299,13 @@ class ClusterTracking(nn.Module):
             self._track_params = ops.track_params(
                 self.radius_list, self.voxel_size_list, self.stopping_delta,
                 self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
-                self.angle_threshold, self.min_move_frame, max_iter=80)
+                self.angle_threshold, self.min_move_frame, max_iter=80,
+                share_launches=bool(self.model_cfg.get("SHARE_ICP_LAUNCHES", False)))
         out, (_, reg_calls, _) = ops.track_frame(
             self._track_params, s_fxyz, s_comp, s_stat, offsets,
             frame_id, min_frame_id, max_frame_id, comp_base, num_components)
         self.num_registration_calls += reg_calls
+        icp_us = out.pop("_icp_us")  # diagnostic: microseconds (in the shared launcher, in ICP calls)
         idx, comp, moving = out["ex_index"], out["ex_component"].to(frame.component.dtype), out["moving"]
         if perm is not None:
             idx = perm[idx]
@@ -322,7 +324,8 @@ class ClusterTracking(nn.Module):
         extracted = EasyDict(filter_dict(extracted, valid[extracted.component]))
         extracted.transforms = out["transforms"]
         seq_points.extracted[extracted.original_indices] = True
-        self.last_track_debug = dict(reg_errors=out["reg_errors"], comp_edge_ratios=out["comp_edge_ratios"],
+        self.last_track_debug = dict(icp_us=icp_us, reg_errors=out["reg_errors"],
+                                     comp_edge_ratios=out["comp_edge_ratios"],
                                      comp_velos=out["comp_velos"],
                                      comp_min_frame_id=out["comp_min_frame_id"],
                                      comp_max_frame_id=out["comp_max_frame_id"])

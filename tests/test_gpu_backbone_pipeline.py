@@ -112,15 +112,21 @@ def test_points_in_boxes_vs_oracle(oracle):
 
 def test_full_pipeline_streams_vs_serial():
     """SimpleReg end to end on a small sequence: the concurrent (one stream per tracking unit)
-    schedule must give bit-identical results to the serial one, run to run."""
+    schedule, the shared-launch schedule and the op-by-op host loop must all give bit-identical
+    results to the serial native schedule, run to run."""
     from pcseqlearning_amd.pcdet import models
     from tools.run_sequence import build_model
     batch = synthetic.gen_sequence(5, 10, 12000, n_static=14, n_vehicle=8, n_ped=4)
     batch = models.load_data_to_gpu(batch, DEV)
     outs = []
-    for streams in (1, 9, 9):
+    # serial, concurrent, concurrent again, concurrent with the ICP iterations of the units sharing
+    # launches (pcs_icp_share_launches), and the op-by-op host loop instead of the native tracker
+    for streams, share, native in ((1, False, True), (9, False, True), (9, False, True), (9, True, True),
+                                   (9, False, False)):
         model = build_model(save=False, device=DEV)
         model.preprocessors[2].model_cfg["NUM_STREAMS"] = streams
+        model.preprocessors[2].model_cfg["SHARE_ICP_LAUNCHES"] = share
+        model.preprocessors[2].native = native
         with torch.no_grad():
             model(batch)
         outs.append(model.last_outputs[0])

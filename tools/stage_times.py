@@ -59,6 +59,13 @@ def main():
         trk = sum(v for k, v in timer.RECORDS.items() if k.startswith("Tracking Frame"))
         ext = timer.RECORDS.get("Extract Traces from all points", 0.0)
         print(f"   sum over units: track_frame {trk * 1e3:.1f} ms, extract traces {ext * 1e3:.1f} ms")
+        import ctypes
+        from pcseqlearning_amd import lib as L
+        st = (ctypes.c_double * 4)()
+        L.load().pcs_profile_batcher_read(st)
+        if st[0] > 0:
+            print(f"   shared launcher: {int(st[0])} batches, {st[1] / st[0]:.2f} problems per batch, "
+                  f"{st[2] / st[0] * 1e6:.0f} us per batch, busy {st[2] * 1e3:.1f} ms, idle {st[3] * 1e3:.1f} ms")
         if args.detail:
             for k in sorted(timer.RECORDS):
                 if not k.startswith(("unit ", "Tracking Frame", "REGISTRATION")):
