@@ -56,6 +56,11 @@ struct Arena {
   bool ok() const { return dry || off <= cap; }
 };
 
+// Per-thread page of pinned, device-visible host memory for the few status words a blocking entry
+// point reads back (implemented in pcs_prims.hip): the last kernel of a phase writes them there, so
+// the host needs only the stream synchronisation, not a device-to-host copy. nullptr if pinning fails.
+void* thread_pinned_page();
+
 // ---- prims implemented in pcs_prims.hip (the only TU that includes rocPRIM) ----
 size_t sort_pairs_u64_temp_bytes(size_t n);
 int sort_pairs_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout,

@@ -618,7 +618,9 @@ icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __res
 __global__ void __launch_bounds__(kBlock)
 icp_finish_kernel(int64_t C, const double* __restrict__ acc, const int32_t* __restrict__ cnt,
                   const int64_t* __restrict__ comp_deg, int have_l1, const double* __restrict__ Tfin,
-                  double* __restrict__ T, double* __restrict__ l1, float* __restrict__ ratio) {
+                  double* __restrict__ T, double* __restrict__ l1, float* __restrict__ ratio,
+                  const IcpState* __restrict__ st, IcpState* __restrict__ out) {
+  if (out && blockIdx.x == 0 && threadIdx.x == 0) *out = *st;  // err word for the host (pinned)
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
     double n = acc[c * kAcc];
@@ -1037,6 +1039,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     req.bytes_per_launch = 2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn);
   }
   const bool shared = t_share_launches;
+  // status words come back through pinned memory written by the kernels (no device-to-host copy)
+  IcpState* pin = (IcpState*)thread_pinned_page();
   struct IcpPhase {  // tells the shared launcher that this thread is about to submit chunks
     bool on;
     explicit IcpPhase(bool o) : on(o) { if (on) IcpBatcher::get().enter_icp(); }
@@ -1079,11 +1083,12 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
         PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
       }
       bool pk = prof && it + n_it <= kProfIters;
-      int rc2 = icp_launch_chunk(b.desc, 1, n_it, it, nb_q, nb_e, nb_m, nullptr, s,
+      int rc2 = icp_launch_chunk(b.desc, 1, n_it, it, nb_q, nb_e, nb_m, pin, s,
                                  pk ? &t_ev.ev[2 * it] : nullptr);
       if (rc2) return rc2;
-      PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+      if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
       PCS_CHECK_HIP(hipStreamSynchronize(s));
+      if (pin) host = *pin;
     }
     it += n_it;
     if (host.err) return PCS_ERR_RANGE;
@@ -1119,11 +1124,13 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   if (Mn > 0 && Ra > 0)
     icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
         (const float4*)mov_fxyz, (int)Mn, mov_comp, b.grid, frame_offset, b.ga, b.state, b.cnt);
+  // NB: the coverage kernel may still raise st->err; it runs before this launch on the same stream
   icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, acc_fin, b.cnt, comp_deg, host.iters > 0, T_fin, T,
-                                                   l1_err, edge_ratio);
+                                                   l1_err, edge_ratio, b.state, pin);
   PCS_LAUNCH_CHECK();
-  PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+  if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
   PCS_CHECK_HIP(hipStreamSynchronize(s));
+  if (pin) host = *pin;
   if (host.err) return PCS_ERR_RANGE;
   return PCS_OK;
 }

@@ -79,3 +79,15 @@ int exclusive_scan_i64(void* tmp, size_t tmp_bytes, const int64_t* in, int64_t* 
 }
 
 }  // namespace pcs
+
+namespace pcs {
+void* thread_pinned_page() {
+  static thread_local void* page = nullptr;
+  static thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (hipHostMalloc(&page, 4096, hipHostMallocDefault) != hipSuccess) page = nullptr;
+  }
+  return page;
+}
+}  // namespace pcs

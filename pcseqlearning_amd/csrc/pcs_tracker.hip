@@ -442,6 +442,10 @@ trk_harvest_emit_kernel(const int32_t* __restrict__ flag, const int32_t* __restr
 
 __global__ void trk_copy_count_kernel(const int64_t* src, int64_t* dst) { *dst = *src; }
 
+// the state words the host is about to read, mirrored into pinned host memory (the host then needs
+// the stream synchronisation only)
+__global__ void trk_publish_kernel(const TrkState* __restrict__ st, TrkState* __restrict__ out) { *out = *st; }
+
 int radius_nn1_view(int64_t N, int64_t M, void* ws, size_t ws_bytes, const int32_t** nbr_idx,
                     const int32_t** deg, const int32_t** err);
 int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo,
@@ -648,6 +652,19 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   const float nn_cell = (float)(sqrt(nn_r * nn_r + 3e-5 * nn_r * nn_r + 3e-6) / 4 * 1.0005);
   int64_t steps = 0, reg_calls = 0;
   TrkState host;
+  // pinned page: bytes [0, 256) are the ICP's, the tracker's mirror sits behind them
+  char* page = (char*)thread_pinned_page();
+  TrkState* pin = page ? (TrkState*)(page + 1024) : nullptr;
+  auto read_state = [&]() -> int {
+    if (pin) {
+      trk_publish_kernel<<<1, 1, 0, s>>>(p.st, pin);
+    } else if (hipMemcpyAsync(&host, p.st, sizeof(TrkState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+      return PCS_ERR_HIP;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return PCS_ERR_HIP;
+    if (pin) host = *pin;
+    return PCS_OK;
+  };
 
   for (int dir = -1; dir <= 1; dir += 2) {
     int next = anchor_frame + dir;
@@ -656,8 +673,7 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
     trk_dir_init_kernel<<<gAC, kBlock, 0, s>>>((int)C, (int)na, valid_comp, p.stopped, moving, anchor,
                                                p.xyzf, p.last, p.st);
     while (next >= min_frame_id && next <= max_frame_id) {
-      PCS_CHECK_HIP(hipMemcpyAsync(&host, p.st, sizeof(TrkState), hipMemcpyDeviceToHost, s));
-      PCS_CHECK_HIP(hipStreamSynchronize(s));
+      TRK_RC(read_state());
       if (host.err || host.counts[0] < 0) return PCS_ERR_RANGE;
       if (!host.active) break;
       PCS_CHECK_HIP(hipMemsetAsync(&p.st->active, 0, sizeof(int32_t), s));
@@ -700,8 +716,7 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
         } else {
           PCS_CHECK_HIP(hipMemsetAsync(&p.st->counts[2], 0, 2 * sizeof(int64_t), s));
         }
-        PCS_CHECK_HIP(hipMemcpyAsync(&host, p.st, sizeof(TrkState), hipMemcpyDeviceToHost, s));
-        PCS_CHECK_HIP(hipStreamSynchronize(s));
+        TRK_RC(read_state());
         const int64_t Mn = host.counts[1], Ra = host.counts[2], Rn = host.counts[3];
         // ---- register_to_next_frame
         int32_t icp_info[4];
@@ -760,8 +775,7 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   }
   trk_copy_count_kernel<<<1, 1, 0, s>>>(p.exc + ex_par, &p.st->ex_count);
   PCS_LAUNCH_CHECK();
-  PCS_CHECK_HIP(hipMemcpyAsync(&host, p.st, sizeof(TrkState), hipMemcpyDeviceToHost, s));
-  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  TRK_RC(read_state());
   if (host.err || host.counts[0] < 0) return PCS_ERR_RANGE;
   info[0] = host.ex_count;
   info[1] = reg_calls;

@@ -53,16 +53,26 @@ class SimpleReg(RegistrationTemplate):
         attr, cls, frame = attr[keep], cls[keep], frame[keep]
         obj_ids = np.asarray(seq_dict["obj_ids"]).astype(str).reshape(-1)[keep.cpu().numpy()]
         track = torch.from_numpy(np.unique(obj_ids, return_inverse=True)[1]).to(cls).long()
+        # per trace, boxes in frame order: velocity = mean corner displacement to the previous box of
+        # the trace, the first box takes the second's (the reference loops over the traces; here all
+        # traces at once on the (trace, frame)-sorted list)
         velo = torch.zeros_like(attr[:, 0])
-        for t in track.unique().tolist():
-            tm = (track == t).reshape(-1)
-            order = torch.argsort(frame[tm])
-            corners = boxes_to_corners_3d(attr[tm][order])
-            tv = torch.zeros_like(velo[tm])
-            if tv.numel() > 1:
-                tv[1:] = (corners[1:] - corners[:-1]).norm(p=2, dim=-1).mean(dim=-1)
-                tv[0] = tv[1]
-            velo[tm.nonzero()[:, 0][order]] = tv
+        if attr.shape[0] > 1:
+            order = torch.argsort(track * (int(frame.max().item()) + 1) + frame.long(), stable=True)
+            tr_s = track[order]
+            corners = boxes_to_corners_3d(attr[order])
+            same = tr_s[1:] == tr_s[:-1]
+            step = (corners[1:] - corners[:-1]).norm(p=2, dim=-1).mean(dim=-1)
+            tv = torch.zeros_like(velo)
+            tv[1:] = torch.where(same, step, torch.zeros_like(step))
+            first = torch.ones_like(tr_s, dtype=torch.bool)
+            first[1:] = ~same
+            nxt = torch.zeros_like(tv)
+            nxt[:-1] = tv[1:]                       # value of the following row ...
+            has_next = torch.zeros_like(first)
+            has_next[:-1] = same                    # ... if it belongs to the same trace
+            tv = torch.where(first, torch.where(has_next, nxt, torch.zeros_like(tv)), tv)
+            velo[order] = tv
         seq_dict.update(gt_box_attr=attr, gt_box_cls_label=cls, gt_box_frame=frame,
                         gt_box_track_label=track, gt_box_velo=velo, moving=velo > 5e-2,
                         obj_ids=obj_ids)
