@@ -136,8 +136,20 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
     }
   }
   if (!ok) return;
-  uint32_t fs = g2_claim(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z));
+  // the fine and the coarse claim do not depend on each other: their first probes go out together
+  // (two atomic round trips for the whole insert instead of four), collisions take the slow loops
+  const uint64_t fkey = pack_cell(fc, x, y, z), ckey = pack_cell(fc, x >> 2, y >> 2, z >> 2);
+  const uint32_t fmask = g.Hf - 1, cmask = g.Hc - 1;
+  uint32_t fs = mix64(fkey) & fmask, cs = mix64(ckey) & cmask;
+  uint64_t pf = atomicCAS((unsigned long long*)&g.fslot[fs].key, (unsigned long long)kEmpty,
+                          (unsigned long long)fkey);
+  uint64_t pc = atomicCAS((unsigned long long*)&g.cslot[cs].key, (unsigned long long)kEmpty,
+                          (unsigned long long)ckey);
+  if (!(pf == kEmpty || pf == fkey)) fs = g2_claim(g.fslot, fmask, fkey);
+  if (!(pc == kEmpty || pc == ckey)) cs = g2_claim(g.cslot, cmask, ckey);
+  int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
   int pos = atomicAdd(&g.fslot[fs].count, 1);
+  atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << bit);
   if (pos < kCellCap) {
     g.spts[(size_t)fs * kCellCap + pos] = p;
     g.sidx[(size_t)fs * kCellCap + pos] = i;
@@ -146,9 +158,6 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
     g.ovf_pts[o] = p;
     g.ovf_idx[o] = i;
   }
-  uint32_t cs = g2_claim(g.cslot, g.Hc - 1, pack_cell(fc, x >> 2, y >> 2, z >> 2));
-  int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
-  atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << bit);
 }
 
 static __global__ void __launch_bounds__(kBlock)

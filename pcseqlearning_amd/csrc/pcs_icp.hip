@@ -561,6 +561,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
   g2_clear(gm_done, i, (int64_t)pr.nparts * blockDim.x);
   if (i == 0) st->iters = k;
+
   double ls_mine = 0.0;
   float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < Mn) {
@@ -591,6 +592,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
     GridDesc d = *gp;
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
+
   // loss partial of this workgroup (fixed order: lanes, then waves)
   ls_mine = wave_sum_f64(ls_mine);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls_mine;
