@@ -499,16 +499,61 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
       if (n > 0.5) cov = cov / n; else cov = 0.0;
       M[i * 3 + j] = cov + Tc[i * 4 + j] * reg;
     }
-  double U[9], S[3], V[9];
-  svd3(M, U, S, V);
-  double VUt[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
-  double sg = det3(VUt);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
+  // R = V diag(1, 1, det(V U^T)) U^T for M = U S V^T. With det M > 0 (always, unless the matches
+  // outweigh the regulariser reg * T_rot) that is the transpose of the orthogonal polar factor of M,
+  // which Newton's iteration X <- (X + X^-T) / 2 reaches in a handful of steps with one division
+  // each; the Jacobi SVD (dozens of dependent f64 sqrt / div) is kept for the rest.
+  bool have_R = false;
+  {
+    double fro = 0.0;
+    for (int i = 0; i < 9; ++i) fro += M[i] * M[i];
+    double dM = det3(M);
+    if (dM > 0.0 && fro > 0.0) {
+      double sc = 1.7320508075688772 / sqrt(fro);  // singular values to ~1
+      double X[9];
+      for (int i = 0; i < 9; ++i) X[i] = M[i] * sc;
+      bool conv = false;
+      for (int itn = 0; itn < 12 && !conv; ++itn) {
+        double Cf[9];  // cofactor matrix: X^-T = Cf / det X
+        Cf[0] = X[4] * X[8] - X[5] * X[7];
+        Cf[1] = X[5] * X[6] - X[3] * X[8];
+        Cf[2] = X[3] * X[7] - X[4] * X[6];
+        Cf[3] = X[2] * X[7] - X[1] * X[8];
+        Cf[4] = X[0] * X[8] - X[2] * X[6];
+        Cf[5] = X[1] * X[6] - X[0] * X[7];
+        Cf[6] = X[1] * X[5] - X[2] * X[4];
+        Cf[7] = X[2] * X[3] - X[0] * X[5];
+        Cf[8] = X[0] * X[4] - X[1] * X[3];
+        double dx = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
+        if (!(dx > 1e-300)) break;
+        double inv = 1.0 / dx, delta = 0.0;
+        for (int i = 0; i < 9; ++i) {
+          double xn = 0.5 * (X[i] + Cf[i] * inv);
+          delta = fmax(delta, fabs(xn - X[i]));
+          X[i] = xn;
+        }
+        conv = delta < 1e-15;
+      }
+      if (conv) {
+        // one more step from a converged iterate changes nothing above 1e-30: X is orthogonal
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) R[i * 3 + j] = X[j * 3 + i];
+        have_R = true;
+      }
+    }
+  }
+  if (!have_R) {
+    double U[9], S[3], V[9];
+    svd3(M, U, S, V);
+    double VUt[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        VUt[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
+    double sg = det3(VUt);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + sg * V[i * 3 + 2] * U[j * 3 + 2];
+  }
   for (int i = 0; i < 3; ++i)
     t[i] = cr[i] - (cm[0] * R[i * 3 + 0] + cm[1] * R[i * 3 + 1] + cm[2] * R[i * 3 + 2]);
   for (int i = 0; i < 3; ++i)
