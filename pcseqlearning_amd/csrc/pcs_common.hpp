@@ -61,6 +61,11 @@ struct Arena {
 // the host needs only the stream synchronisation, not a device-to-host copy. nullptr if pinning fails.
 void* thread_pinned_page();
 
+// sorted unique on keys written by the caller into the workspace (pcs_voxel.hip)
+int unique_prepared_ptrs(void* ws, size_t ws_bytes, int64_t n, uint64_t** keys, int32_t** vals);
+int unique_prepared_run(void* ws, size_t ws_bytes, int64_t n, int key_bits, int32_t* seg_start,
+                        int64_t* d_num, const int32_t** sorted_vals, hipStream_t s);
+
 // ---- prims implemented in pcs_prims.hip (the only TU that includes rocPRIM) ----
 size_t sort_pairs_u64_temp_bytes(size_t n);
 int sort_pairs_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout,

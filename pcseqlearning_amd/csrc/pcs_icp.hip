@@ -122,8 +122,10 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
 // grid origin padded so that points moved by the registration stay inside the 17-bit cell range
 __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* __restrict__ b_mov,
                                  const float* __restrict__ b_all, float radius, float cell,
-                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st) {
+                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st,
+                                 IcpProblem prob, IcpProblem* __restrict__ desc) {
   if (threadIdx.x != 0) return;
+  if (desc) *desc = prob;  // the call's problem descriptor, for the iteration kernels
   float mn[4];
   for (int d = 0; d < 4; ++d) mn[d] = fminf(fminf(b_ref[d], b_mov[d]), b_all[d]);
   float vs0 = (float)(1 - 1e-3);
@@ -162,6 +164,23 @@ icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* 
   g2_clear(gm0, i, stride);
   g2_clear(gm1, i, stride);
   g2_clear(ga, i, stride);
+}
+
+// the three grids of a call in one launch: blockIdx.y = 0 non-stationary reference, 1 all reference,
+// 2 the moving points as they arrive (the grid of iteration 1)
+__global__ void __launch_bounds__(kBlock)
+icp_insert3_kernel(const float4* __restrict__ ref, int Rn, const float4* __restrict__ all, int Ra,
+                   const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp, Grid2 gr,
+                   Grid2 ga, Grid2 gm1, IcpState* __restrict__ st) {
+  const float4* pts = blockIdx.y == 0 ? ref : (blockIdx.y == 1 ? all : mov);
+  const int n = blockIdx.y == 0 ? Rn : (blockIdx.y == 1 ? Ra : Mn);
+  if ((int64_t)blockIdx.x * kBlock >= n) return;
+  const Grid2& g = blockIdx.y == 0 ? gr : (blockIdx.y == 1 ? ga : gm1);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  GridDesc d = *gp;
+  bool in = i < n;
+  float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  g2_insert_point(d, g, in, i, p, &st->err);
 }
 
 // min / max of the three clouds in one launch: blockIdx.y selects the cloud
@@ -1030,19 +1049,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                                      (const float4*)ref_all, (int)Ra, b.b_ref, mov_comp,
                                                      b.first);
   }
-  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
-  // static grids: non-stationary reference, all reference
-  if (Rn > 0)
-    g2_insert_kernel<<<(int)((Rn + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-        (const float4*)ref_fxyz, (int)Rn, b.grid, b.gr, 0, &b.state->stop_iter, &b.state->err);
-  if (Ra > 0)
-    g2_insert_kernel<<<(int)((Ra + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-        (const float4*)ref_all, (int)Ra, b.grid, b.ga, 0, &b.state->stop_iter, &b.state->err);
-  // the moving points as they arrive: the grid of iteration 1
-  if (Mn > 0)
-    g2_insert_kernel<<<(int)((Mn + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-        (const float4*)mov_fxyz, (int)Mn, b.grid, b.gm[1], 0, &b.state->stop_iter, &b.state->err);
-
   int nb_m = (int)((Mn + kBlock - 1) / kBlock);
   if (nb_m < 1) nb_m = 1;
   int nb_e = (int)((Mn + Rn + kBlock - 1) / kBlock);
@@ -1086,6 +1092,19 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     req.bytes_per_launch = 2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn);
   }
   const bool shared = t_share_launches;
+  // grid description + the descriptor's device copy (chunk positions 0..chunk-1 enabled, k0 = 1: the
+  // stand-alone path passes the chunk's first iteration as kbase), then the three grids in one launch
+  req.prob.n_it = chunk;
+  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state, req.prob,
+                                    shared ? nullptr : b.desc);
+  {
+    int64_t nmax = Mn > Rn ? Mn : Rn;
+    if (Ra > nmax) nmax = Ra;
+    if (nmax > 0)
+      icp_insert3_kernel<<<dim3((unsigned)((nmax + kBlock - 1) / kBlock), 3), kBlock, 0, s>>>(
+          (const float4*)ref_fxyz, (int)Rn, (const float4*)ref_all, (int)Ra, (const float4*)mov_fxyz,
+          (int)Mn, b.grid, b.gr, b.ga, b.gm[1], b.state);
+  }
   // status words come back through pinned memory written by the kernels (no device-to-host copy)
   IcpState* pin = (IcpState*)thread_pinned_page();
   struct IcpPhase {  // tells the shared launcher that this thread is about to submit chunks
@@ -1099,8 +1118,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
     t_ev.have = true;
   }
-  if (!shared)
-    PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
   IcpState host;
   host.stop_iter = INT_MAX;
   host.iters = 0;
@@ -1121,10 +1138,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     } else {
       // the device copy of the descriptor keeps k0 = 1 / n_it = 0: the chunk position is passed
       // as kbase and every position is enabled through n_it below
-      if (it == 0) {
-        req.prob.n_it = chunk;
-        PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
-      }
       if (n_it != chunk) {
         req.prob.n_it = n_it;
         PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));

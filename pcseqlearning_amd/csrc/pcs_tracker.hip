@@ -163,40 +163,112 @@ trk_step_begin_kernel(int C, int n, int F, int W, int col, int dir, int last_col
   }
 }
 
-// sample_frame on the sorted-unique voxel structure: per voxel the serial mean of fxyz (ascending
-// original index, as pcs_segment_reduce_f32's serial mode), the stationary vote and the upper
-// median of the component ids; counts the sampled voxels per component (bincount).
+// ---- anchor + target frame sampled by ONE key / sort / segment pipeline -------------------------
+// Both clouds get their grid_cluster ids (same arithmetic as grid_ids_kernel, each with its own
+// bounds) under a set bit on top of the key, so one sort yields the anchor's voxels first, then the
+// target's, every voxel's rows in ascending original index: exactly the two separate pipelines,
+// half the launches.
 __global__ void __launch_bounds__(kBlock)
-trk_sample_emit_kernel(const float4* __restrict__ pts, const float* __restrict__ stat_f,
-                       const int64_t* __restrict__ comp64, const int32_t* __restrict__ order,
-                       const int32_t* __restrict__ seg, const int64_t* __restrict__ d_num, int n,
-                       float4* __restrict__ sub, int32_t* __restrict__ sub_comp,
-                       int32_t* __restrict__ flag_ns, unsigned long long* __restrict__ sub_deg) {
+trk_bounds2_kernel(const float4* __restrict__ a, int na, const float4* __restrict__ b, int nb,
+                   float* __restrict__ out16) {
+  const float4* pts = blockIdx.y == 0 ? a : b;
+  int n = blockIdx.y == 0 ? na : nb;
+  float* out8 = out16 + 8 * blockIdx.y;
+  float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
+  }
+  __shared__ float smn[kBlock / 64][4], smx[kBlock / 64][4];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float x = wave_min(mn[d]), y = wave_max(mx[d]);
+    if (lane == 0) { smn[w][d] = x; smx[w][d] = y; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && n > 0) {
+    int d = threadIdx.x;
+    float x = smn[0][d], y = smx[0][d];
+    for (int k = 1; k < kBlock / 64; ++k) { x = fminf(x, smn[k][d]); y = fmaxf(y, smx[k][d]); }
+    atomic_min_f32(&out8[d], x);
+    atomic_max_f32(&out8[4 + d], y);
+  }
+}
+
+__global__ void trk_bounds_reset_kernel(float* out16) {
+  int t = threadIdx.x;
+  if (t < 16) out16[t] = ((t & 7) < 4) ? __builtin_inff() : -__builtin_inff();
+}
+
+__global__ void __launch_bounds__(kBlock)
+trk_keys2_kernel(const float4* __restrict__ a, int na, const float4* __restrict__ b, int nb,
+                 const float* __restrict__ bounds16, float4 size, float margin0,
+                 uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= na + nb) return;
+  int set = i >= na;
+  const float* b8 = bounds16 + 8 * set;
+  float st[4], en[4], sz[4] = {size.x, size.y, size.z, size.w};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { st[d] = b8[d]; en[d] = b8[4 + d]; }
+  st[0] = st[0] - margin0;
+  en[0] = en[0] + margin0;
+  int64_t stride[4];
+  stride[0] = 1;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / sz[d]) + 1);
+  float4 p = set ? b[i - na] : a[i];
+  int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
+               (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
+  keys[i] = ((uint64_t)set << 62) | (uint64_t)id;
+  vals[i] = i;
+}
+
+// per voxel of the combined structure: serial mean of fxyz, stationary vote, (anchor only) median
+// component and the per-component voxel count; also finds where the target's voxels begin
+__global__ void __launch_bounds__(kBlock)
+trk_sample2_emit_kernel(const float4* __restrict__ a, const float* __restrict__ stat_a,
+                        const int64_t* __restrict__ comp64, int na, const float4* __restrict__ b,
+                        const float* __restrict__ stat_b, const int32_t* __restrict__ order,
+                        const int32_t* __restrict__ seg, const int64_t* __restrict__ d_num, int n,
+                        float4* __restrict__ sub, int32_t* __restrict__ sub_comp,
+                        int32_t* __restrict__ flag_ns, unsigned long long* __restrict__ sub_deg,
+                        int64_t* __restrict__ d_va) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  if (s >= *d_num) { flag_ns[s] = 0; return; }
-  int b = seg[s], e = seg[s + 1];
+  int64_t v = *d_num;
+  if (s >= v) { flag_ns[s] = 0; return; }
+  int bb = seg[s], e = seg[s + 1];
+  bool tgt = order[bb] >= na;
+  // first target voxel (or v if there is none)
+  if (tgt && (s == 0 || order[seg[s - 1]] < na)) *d_va = s;
+  if (!tgt && s == v - 1) *d_va = v;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, st = 0.f;
-  for (int p = b; p < e; ++p) {
+  for (int p = bb; p < e; ++p) {
     int o = order[p];
-    float4 q = pts[o];
+    float4 q = tgt ? b[o - na] : a[o];
     a0 = a0 + q.x; a1 = a1 + q.y; a2 = a2 + q.z; a3 = a3 + q.w;
-    st = st + stat_f[o];
+    st = st + (tgt ? stat_b[o - na] : stat_a[o]);
   }
-  float cnt = (float)(e - b);
+  float cnt = (float)(e - bb);
   sub[s] = make_float4(a0 / cnt, a1 / cnt, a2 / cnt, a3 / cnt);
   flag_ns[s] = !((st / cnt) > 0.5f);
-  if (comp64) {
-    int k = (e - b) / 2;
-    int64_t first = comp64[order[b]];
+  if (!tgt) {
+    int k = (e - bb) / 2;
+    int64_t first = comp64[order[bb]];
     bool same = true;
-    for (int p = b + 1; p < e; ++p) if (comp64[order[p]] != first) { same = false; break; }
+    for (int p = bb + 1; p < e; ++p) if (comp64[order[p]] != first) { same = false; break; }
     int64_t res = first;
     if (!same) {
-      for (int p = b; p < e; ++p) {
+      for (int p = bb; p < e; ++p) {
         int64_t x = comp64[order[p]];
         int lt = 0, eq = 0;
-        for (int q = b; q < e; ++q) {
+        for (int q = bb; q < e; ++q) {
           int64_t y = comp64[order[q]];
           lt += (y < x);
           eq += (y == x);
@@ -209,22 +281,34 @@ trk_sample_emit_kernel(const float4* __restrict__ pts, const float* __restrict__
   }
 }
 
-// stable compaction of the flagged rows; *d_count = number kept, *d_total = *d_num
+// split + compact: anchor voxels -> sub_a (all) / mov (non-stationary), target -> sub_n / ref_ns;
+// counts = {anchor voxels, anchor non-stationary, target voxels, target non-stationary}
 __global__ void __launch_bounds__(kBlock)
-trk_compact_kernel(const float4* __restrict__ sub, const int32_t* __restrict__ sub_comp,
-                   const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int n,
-                   const int64_t* __restrict__ d_num, float4* __restrict__ out,
-                   int32_t* __restrict__ out_comp, int64_t* __restrict__ d_total,
-                   int64_t* __restrict__ d_count) {
+trk_compact2_kernel(const float4* __restrict__ sub, const int32_t* __restrict__ sub_comp,
+                    const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int n,
+                    const int64_t* __restrict__ d_num, const int64_t* __restrict__ d_va,
+                    float4* __restrict__ mov, int32_t* __restrict__ mov_comp,
+                    float4* __restrict__ sub_n, float4* __restrict__ ref_ns,
+                    int64_t* __restrict__ counts) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  if (flag[s]) {
-    out[pos[s]] = sub[s];
-    if (out_comp) out_comp[pos[s]] = sub_comp[s];
+  int64_t v = *d_num, va = *d_va;
+  int total_ns = pos[n - 1] + flag[n - 1];
+  int ns_a = va < n ? pos[va] : total_ns;  // non-stationary anchor voxels = rank of the first target voxel
+  if (s < v) {
+    float4 q = sub[s];
+    if (s < va) {
+      if (flag[s]) { mov[pos[s]] = q; mov_comp[pos[s]] = sub_comp[s]; }
+    } else {
+      sub_n[s - va] = q;
+      if (flag[s]) ref_ns[pos[s] - ns_a] = q;
+    }
   }
-  if (s == n - 1) {
-    *d_count = (int64_t)pos[s] + flag[s];
-    *d_total = *d_num;
+  if (s == 0) {
+    counts[0] = va;
+    counts[1] = ns_a;
+    counts[2] = v - va;
+    counts[3] = total_ns - ns_a;
   }
 }
 
@@ -473,7 +557,7 @@ struct TrkPlan {
   int64_t* ids;
   int32_t *order_s, *seg_s;
   int64_t* d_nums;
-  float4 *sub_a, *mov, *sub_n, *ref_ns;
+  float4 *sub_a, *mov, *sub_n, *ref_ns, *sub2;
   int32_t *sub_comp, *mov_comp, *flag, *pos;
   float* stat_n;
   void *ws_unique, *ws_icp, *ws_rg, *ws_sv, *tmp_scan;
@@ -517,23 +601,24 @@ static bool plan_track(Arena& a, int64_t na, int64_t nm, int64_t C, int F, TrkPl
   p.red4a = a.take<float>(na * 4);
   p.red4b = a.take<float>(na * 4);
   p.red1 = a.take<float>(na);
-  p.b8 = a.take<float>(8);
+  p.b8 = a.take<float>(16);
   p.ids = a.take<int64_t>(nx);
   p.order_s = a.take<int32_t>(nx);
-  p.seg_s = a.take<int32_t>(nx + 1);
-  p.d_nums = a.take<int64_t>(1);
+  p.seg_s = a.take<int32_t>(na + nm + 1);
+  p.d_nums = a.take<int64_t>(2);
+  p.sub2 = a.take<float4>(na + nm);
   p.sub_a = a.take<float4>(na);
   p.mov = a.take<float4>(na);
   p.sub_n = a.take<float4>(nm);
   p.ref_ns = a.take<float4>(nm);
-  p.sub_comp = a.take<int32_t>(na);
+  p.sub_comp = a.take<int32_t>(na + nm);
   p.mov_comp = a.take<int32_t>(na);
-  p.flag = a.take<int32_t>(nx);
-  p.pos = a.take<int32_t>(nx);
+  p.flag = a.take<int32_t>(na + nm);
+  p.pos = a.take<int32_t>(na + nm);
   p.stat_n = a.take<float>(nm);
-  p.scan_bytes = scan_i32_temp_bytes(nx);
+  p.scan_bytes = scan_i32_temp_bytes(na + nm);
   p.tmp_scan = a.take<char>(p.scan_bytes);
-  p.unique_bytes = pcs_unique_i64_workspace_bytes(nx);
+  p.unique_bytes = pcs_unique_i64_workspace_bytes(na + nm);
   p.ws_unique = a.take<char>(p.unique_bytes);
   p.icp_bytes = pcs_register_to_next_frame_workspace_bytes(na, nm, nm, C);
   p.ws_icp = a.take<char>(p.icp_bytes);
@@ -689,32 +774,34 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
         trk_stat_to_float_kernel<<<gN, kBlock, 0, s>>>(seq_stationary + off_n, (int)nn, p.stat_n);
       for (int lv = 0; lv < L; ++lv) {
         float size4[4] = {1.f, prm->voxel_size[lv][0], prm->voxel_size[lv][1], prm->voxel_size[lv][2]};
-        // ---- sample_frame(anchor), non-stationary subset, sampled-voxel count per component
-        TRK_RC(pcs_minmax4_f32((const float*)p.xyzf, na, p.b8, s));
-        TRK_RC(pcs_grid_cluster_ids((const float*)p.xyzf, na, p.b8, size4, 0.5f, p.ids, s));
-        TRK_RC(pcs_unique_i64(p.ids, na, 64, nullptr, nullptr, p.order_s, p.seg_s, p.d_nums,
-                              p.ws_unique, p.unique_bytes, s));
-        PCS_CHECK_HIP(hipMemsetAsync(p.sub_deg, 0, (size_t)C * sizeof(unsigned long long), s));
-        trk_sample_emit_kernel<<<gA, kBlock, 0, s>>>(p.xyzf, p.stat_a, p.comp64, p.order_s, p.seg_s,
-                                                     p.d_nums, (int)na, p.sub_a, p.sub_comp, p.flag,
-                                                     p.sub_deg);
-        TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, na, s));
-        trk_compact_kernel<<<gA, kBlock, 0, s>>>(p.sub_a, p.sub_comp, p.flag, p.pos, (int)na, p.d_nums,
-                                                 p.mov, p.mov_comp, &p.st->counts[0], &p.st->counts[1]);
-        // ---- sample_frame(target frame)
-        if (nn > 0) {
-          TRK_RC(pcs_minmax4_f32((const float*)nxt, nn, p.b8, s));
-          TRK_RC(pcs_grid_cluster_ids((const float*)nxt, nn, p.b8, size4, 0.5f, p.ids, s));
-          TRK_RC(pcs_unique_i64(p.ids, nn, 64, nullptr, nullptr, p.order_s, p.seg_s, p.d_nums,
-                                p.ws_unique, p.unique_bytes, s));
-          trk_sample_emit_kernel<<<gN, kBlock, 0, s>>>(nxt, p.stat_n, nullptr, p.order_s, p.seg_s,
-                                                       p.d_nums, (int)nn, p.sub_n, nullptr, p.flag,
-                                                       nullptr);
-          TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, nn, s));
-          trk_compact_kernel<<<gN, kBlock, 0, s>>>(p.sub_n, nullptr, p.flag, p.pos, (int)nn, p.d_nums,
-                                                   p.ref_ns, nullptr, &p.st->counts[2], &p.st->counts[3]);
-        } else {
-          PCS_CHECK_HIP(hipMemsetAsync(&p.st->counts[2], 0, 2 * sizeof(int64_t), s));
+        // ---- sample_frame(anchor) and sample_frame(target) in one pipeline: combined keys, one
+        //      sort, one segment pass; then the non-stationary subsets and the per-component counts
+        {
+          const int64_t n2 = na + nn;
+          const int g2 = nblk(n2);
+          uint64_t* keys = nullptr;
+          int32_t* vals = nullptr;
+          TRK_RC(unique_prepared_ptrs(p.ws_unique, p.unique_bytes, n2, &keys, &vals));
+          trk_bounds_reset_kernel<<<1, 64, 0, s>>>(p.b8);
+          {
+            int64_t nmax2 = na > nn ? na : nn;
+            int gb = nblk(nmax2);
+            if (gb > 128) gb = 128;
+            trk_bounds2_kernel<<<dim3(gb, 2), kBlock, 0, s>>>(p.xyzf, (int)na, nxt, (int)nn, p.b8);
+          }
+          trk_keys2_kernel<<<g2, kBlock, 0, s>>>(p.xyzf, (int)na, nxt, (int)nn, p.b8,
+                                                 make_float4(size4[0], size4[1], size4[2], size4[3]), 0.5f,
+                                                 keys, vals);
+          const int32_t* order2 = nullptr;
+          TRK_RC(unique_prepared_run(p.ws_unique, p.unique_bytes, n2, 64, p.seg_s, p.d_nums, &order2, s));
+          PCS_CHECK_HIP(hipMemsetAsync(p.sub_deg, 0, (size_t)C * sizeof(unsigned long long), s));
+          trk_sample2_emit_kernel<<<g2, kBlock, 0, s>>>(p.xyzf, p.stat_a, p.comp64, (int)na, nxt, p.stat_n,
+                                                        order2, p.seg_s, p.d_nums, (int)n2, p.sub2,
+                                                        p.sub_comp, p.flag, p.sub_deg, p.d_nums + 1);
+          TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, n2, s));
+          trk_compact2_kernel<<<g2, kBlock, 0, s>>>(p.sub2, p.sub_comp, p.flag, p.pos, (int)n2, p.d_nums,
+                                                    p.d_nums + 1, p.mov, p.mov_comp, p.sub_n, p.ref_ns,
+                                                    &p.st->counts[0]);
         }
         TRK_RC(read_state());
         const int64_t Mn = host.counts[1], Ra = host.counts[2], Rn = host.counts[3];

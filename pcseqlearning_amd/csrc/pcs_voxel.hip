@@ -395,6 +395,28 @@ static int run_unique(UniquePlan& p, int64_t n, int key_bits, uint64_t sentinel,
   return PCS_OK;
 }
 
+// ---- sorted unique on keys the caller writes straight into the workspace (saves the key copy and
+// the copy of the sorted order): used by the native tracker's combined anchor + target sampling
+int unique_prepared_ptrs(void* ws, size_t ws_bytes, int64_t n, uint64_t** keys, int32_t** vals) {
+  Arena a(ws, ws_bytes);
+  UniquePlan p;
+  if (!plan_unique(a, n > 0 ? n : 1, p)) return PCS_ERR_WORKSPACE;
+  *keys = p.k0;
+  *vals = p.v0;
+  return PCS_OK;
+}
+
+// seg_start [v+1] boundaries into *sorted_vals (original indices ordered by (key, index)), *d_num = v
+int unique_prepared_run(void* ws, size_t ws_bytes, int64_t n, int key_bits, int32_t* seg_start,
+                        int64_t* d_num, const int32_t** sorted_vals, hipStream_t s) {
+  if (n < 1) return PCS_ERR_ARG;
+  Arena a(ws, ws_bytes);
+  UniquePlan p;
+  if (!plan_unique(a, n, p)) return PCS_ERR_WORKSPACE;
+  *sorted_vals = p.v1;
+  return run_unique(p, n, key_bits, ~0ULL, nullptr, nullptr, nullptr, seg_start, d_num, s);
+}
+
 }  // namespace pcs
 
 using namespace pcs;
