@@ -164,6 +164,15 @@ def main():
         # launch, the quantity rocprofv3 reports as the kernel duration
         ms, launches, nbytes = prof[0], prof[1], prof[2]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        # fabric-side bytes per launch from the committed PMC passes of this workload (counters cannot
+        # be read live; see the note in the file for what FETCH_SIZE counts on gfx950)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_icp_nn_hbm_pmc_v10.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic = round((pmc["FETCH_SIZE_KB_per_dispatch"] + pmc["WRITE_SIZE_KB_per_dispatch"]) * 1024.0, 1)
+            traffic_src = "profiles/r01_icp_nn_hbm_pmc_v10.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, serial schedule)"
         line = {
             "metric": "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking",
             "value": round(total_sequences / dt, 5),
@@ -192,7 +201,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "icp_nn_kernel (fused ICP: two-direction 1-NN search, 32 lanes per query)",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
             },
