@@ -136,6 +136,55 @@ def test_segment_median_and_minmax(oracle):
     np.testing.assert_array_equal(mn, wmn)
 
 
+def test_nn1_dense_cells_spill(oracle):
+    """Cells holding far more points than their fixed run (kCellCap = 16): the spill list of the
+    two-level grid must give the same exact nearest neighbours (ties by index) as the oracle, for
+    the sorted 1-NN radius graph and through the fused ICP."""
+    rng = np.random.default_rng(11)
+    blobs = rng.uniform(-5, 5, (12, 3)).astype(np.float32)
+    dense = (blobs[rng.integers(0, 12, 1500)] + rng.normal(0, 0.004, (1500, 3))).astype(np.float32)
+    ref = np.concatenate([np.zeros((1500, 1), np.float32), dense], 1)
+    ref = np.concatenate([ref, cloud(rng, 2000, 1, 6.0)], 0)
+    ref[:, 0] = 0
+    dup = ref[rng.integers(0, len(ref), 200)].copy()          # exact duplicates: index ties
+    ref = np.concatenate([ref, dup], 0)
+    qry = np.concatenate([ref[rng.integers(0, len(ref), 800)] + rng.normal(0, 0.02, (800, 4)).astype(np.float32),
+                          cloud(rng, 800, 1, 6.0)], 0).astype(np.float32)
+    qry[:, 0] = 0
+    o_ref, o_q, o_d = oracle.radius_graph(ref, qry, 0.5, 1, True, want_dists=True)
+    e_ref, e_q, d = ops.radius_graph(dev(ref), dev(qry), 0.5, 1, True, cell_size=0.13, want_dists=True)
+    np.testing.assert_array_equal(e_q.cpu().numpy(), o_q)
+    np.testing.assert_array_equal(e_ref.cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), o_d)
+    assert len(o_q) > 900
+
+    # the same clouds through the ICP (static grids AND the per-iteration moving grid spill)
+    from oracle import reg_oracle as R
+    comp = (np.arange(len(qry)) % 7).astype(np.int64)
+    moving = dict(fxyz=qry.copy(), component=comp, frame=np.zeros(len(qry), np.int64),
+                  stationary=np.zeros(len(qry), bool))
+    moving["fxyz"][:, 1:] += np.float32(0.05)
+    dense_q = (blobs[rng.integers(0, 12, 600)] + rng.normal(0, 0.004, (600, 3))).astype(np.float32)
+    extra = np.concatenate([np.zeros((600, 1), np.float32), dense_q], 1)
+    moving = dict(fxyz=np.concatenate([moving["fxyz"], extra]), component=np.concatenate([comp, np.full(600, 3)]),
+                  frame=np.zeros(len(qry) + 600, np.int64), stationary=np.zeros(len(qry) + 600, bool))
+    refd = dict(fxyz=ref.copy(), frame=np.ones(len(ref), np.int64), stationary=np.zeros(len(ref), bool))
+    refd["fxyz"][:, 0] = 1
+    graph = R.Graph(0.5)
+    o_moved, o_T, o_l1, o_ratio, o_it = R.register_to_next_frame(graph, moving, refd, 7, 10.0, 40, 0.05)
+    g = dict(mov_fxyz=moving["fxyz"], mov_comp=moving["component"], mov_frame=moving["frame"],
+             mov_stationary=moving["stationary"], ref_fxyz=refd["fxyz"], ref_frame=refd["frame"],
+             ref_stationary=refd["stationary"], C=np.array(7))
+    nsm = ~g["mov_stationary"]
+    mov = dev(g["mov_fxyz"][nsm].copy())
+    T, l1, ratio, iters = ops.register_to_next_frame(mov, dev(g["mov_comp"]), dev(g["ref_fxyz"]), dev(g["ref_fxyz"]),
+                                                     dev(np.bincount(g["mov_comp"], minlength=7)), 7, 0.5, 1,
+                                                     10.0, 40, 0.05, 0.0, 8)
+    assert iters == o_it
+    np.testing.assert_allclose(T.cpu().numpy(), o_T, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(mov.cpu().numpy(), o_moved, rtol=0, atol=2e-5)
+
+
 def _run_icp(g, radius, cell=0.0, chunk=8):
     nsm = ~g["mov_stationary"]
     nsr = ~g["ref_stationary"]
