@@ -34,24 +34,46 @@ class ClusterProposal(nn.Module):
         num_points = pcseq.fxyz.shape[0]
         frames = pcseq.frame.reshape(-1)
         num_frames = int(frames.max().long().item()) + 1
-        for comp_key in self.component_keys:
-            with Timer(f"Propose Cluster for {comp_key}"):
-                graph = getattr(self, f"graph_{comp_key}")
-                component = torch.zeros(num_points, dtype=torch.int64, device=pcseq.fxyz.device)
-                total = 0
-                for f0 in range(0, num_frames, self.chunk):
-                    mask = (frames >= f0) & (frames < f0 + self.chunk)
-                    if not bool(mask.any()):
-                        continue
-                    pcframe = EasyDict(filter_dict(pcseq, mask))
-                    e0, e1, _ = graph(pcframe, pcframe)
-                    num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0),
-                                                                 pcframe.fxyz.shape[0])
-                    component[mask] = comp.to(component) + total
-                    total += num
-                seq_dict[f"point_{comp_key}"] = component
-                if self.verbose:
-                    print(f"Cluster Proposal {comp_key}: num_components={total}")
+        graphs = [getattr(self, f"graph_{k}") for k in self.component_keys]
+        radii = [float(torch.tensor(float(g.radius), dtype=torch.float32)) for g in graphs]
+        shared = (len({(g.max_num_neighbors, g.sort_by_dist, g.relative_key) for g in graphs}) == 1
+                  and graphs[0].sort_by_dist and not self.model_cfg.get("SEPARATE_GRAPHS", False))
+        components = {k: torch.zeros(num_points, dtype=torch.int64, device=pcseq.fxyz.device)
+                      for k in self.component_keys}
+        totals = {k: 0 for k in self.component_keys}
+        for f0 in range(0, num_frames, self.chunk):
+            mask = (frames >= f0) & (frames < f0 + self.chunk)
+            if not bool(mask.any()):
+                continue
+            idx = mask.nonzero(as_tuple=True)[0]
+            pcframe = EasyDict(filter_dict(pcseq, idx))
+            n_chunk = pcframe.fxyz.shape[0]
+            if shared:
+                # The k nearest within r, listed nearest first, are the k nearest within R >= r cut at
+                # r: ONE graph at the largest radius serves every key (the reference builds one per
+                # key). The cut uses the engine's own test, dist2 <= fl32(r) * fl32(r) in fp32.
+                big = max(range(len(graphs)), key=lambda i: radii[i])
+                with Timer(f"Propose Cluster: graph r={radii[big]:g}"):
+                    g = graphs[big]
+                    pts = pcframe[g.relative_key]
+                    e0_all, e1_all, d2_all = ops.radius_graph(
+                        pts, pts, radii[big], g.max_num_neighbors, True, 0, 0,
+                        cell_size=-(radii[big] / 2), want_dists=True)
+            for key, graph, radius in zip(self.component_keys, graphs, radii):
+                with Timer(f"Propose Cluster for {key}"):
+                    if shared:
+                        r32 = torch.tensor(radius, dtype=torch.float32)
+                        keep = (d2_all <= float(r32 * r32)).nonzero(as_tuple=True)[0]
+                        e0, e1 = e0_all[keep], e1_all[keep]
+                    else:
+                        e0, e1, _ = graph(pcframe, pcframe)
+                    num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0), n_chunk)
+                    components[key][idx] = comp.to(torch.int64) + totals[key]
+                    totals[key] += num
+        for key in self.component_keys:
+            seq_dict[f"point_{key}"] = components[key]
+            if self.verbose:
+                print(f"Cluster Proposal {key}: num_components={totals[key]}")
         return seq_dict
 
     def assign_instances_to_boxes(self, point_instance_label, bp_mask):
