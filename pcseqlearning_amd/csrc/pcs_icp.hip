@@ -13,15 +13,19 @@
 //   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
 //              component (raw moments in f64; the centred covariance and the loss follow
 //              algebraically, so the reference's second pass over the edges is not needed)
-//   solve      one thread per component: cov + reg*T_rot -> 3x3 one-sided Jacobi SVD (f64) ->
-//              R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T; block 0 also
-//              reduces the loss and applies the loss-delta / 3-strike stop rule ON THE DEVICE
-//   apply      all moving points, f64 -> fp32 as the reference stores them; then resets the moving
-//              grid for the next iteration
-// Every kernel of iteration k returns immediately when k > state.stop_iter, so the host enqueues
-// iterations in chunks and reads one word per chunk instead of one loss per iteration.
-// Per-component sums: lanes of a wave that share a component are combined by 64-lane butterflies,
-// then one f64 hardware atomic per (wave, component, accumulator).
+//   apply      every moving point solves its own component's regularised Kabsch step from the
+//              completed moments (cov + reg*T_rot -> rotation by Newton's polar iteration, Jacobi SVD
+//              when det <= 0; R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T) -- a
+//              3x3 solve per point is cheaper than another launch --, moves (f64 -> fp32 as the
+//              reference stores them), the component's first point stores T and the loss term; the
+//              moved points go straight into the grid of iteration k+1 (double-buffered) and the grid
+//              just searched is reset
+// The three kernels take an ARRAY of problem descriptors (blockIdx.y = problem): a stand-alone call is
+// an array of one, concurrent calls can share launches (IcpBatcher below). Every kernel of iteration
+// k returns immediately when k > state.stop_iter, so the host enqueues iterations in chunks and
+// reads one word per chunk (through pinned memory) instead of one loss per iteration.
+// Per-component sums: a small LDS table keyed by component per workgroup, then one f64 hardware
+// atomic per (workgroup, component, accumulator).
 #include "pcs_grid2.hpp"
 
 #include <hip/hip_ext.h>

@@ -281,7 +281,7 @@ trk_sample2_emit_kernel(const float4* __restrict__ a, const float* __restrict__ 
   }
 }
 
-// split + compact: anchor voxels -> sub_a (all) / mov (non-stationary), target -> sub_n / ref_ns;
+// split + compact: anchor voxels -> mov (the non-stationary ones), target -> sub_n (all) / ref_ns;
 // counts = {anchor voxels, anchor non-stationary, target voxels, target non-stationary}
 __global__ void __launch_bounds__(kBlock)
 trk_compact2_kernel(const float4* __restrict__ sub, const int32_t* __restrict__ sub_comp,
@@ -554,10 +554,9 @@ struct TrkPlan {
   double *Tl, *l1, *l1_tmp;
   // sampling (a = anchor, n = target frame)
   float *b8;
-  int64_t* ids;
-  int32_t *order_s, *seg_s;
+  int32_t* seg_s;
   int64_t* d_nums;
-  float4 *sub_a, *mov, *sub_n, *ref_ns, *sub2;
+  float4 *mov, *sub_n, *ref_ns, *sub2;
   int32_t *sub_comp, *mov_comp, *flag, *pos;
   float* stat_n;
   void *ws_unique, *ws_icp, *ws_rg, *ws_sv, *tmp_scan;
@@ -568,7 +567,6 @@ struct TrkPlan {
 static bool plan_track(Arena& a, int64_t na, int64_t nm, int64_t C, int F, TrkPlan& p) {
   if (na < 1) na = 1;
   if (nm < 1) nm = 1;
-  int64_t nx = na > nm ? na : nm;
   p.st = a.take<TrkState>(1);
   p.exc = a.take<int64_t>(2);
   p.xyzf = a.take<float4>(na + 1);  // + 1: the d = 4 reductions read one float past the last row
@@ -602,12 +600,9 @@ static bool plan_track(Arena& a, int64_t na, int64_t nm, int64_t C, int F, TrkPl
   p.red4b = a.take<float>(na * 4);
   p.red1 = a.take<float>(na);
   p.b8 = a.take<float>(16);
-  p.ids = a.take<int64_t>(nx);
-  p.order_s = a.take<int32_t>(nx);
   p.seg_s = a.take<int32_t>(na + nm + 1);
   p.d_nums = a.take<int64_t>(2);
   p.sub2 = a.take<float4>(na + nm);
-  p.sub_a = a.take<float4>(na);
   p.mov = a.take<float4>(na);
   p.sub_n = a.take<float4>(nm);
   p.ref_ns = a.take<float4>(nm);
