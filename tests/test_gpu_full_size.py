@@ -1,0 +1,120 @@
+"""BASELINE configs[2] at full size (20 frames x 160 k points): the oracle cannot walk this in
+seconds, so parity is checked through size-independent properties of the outputs and through the
+schedule equivalence (serial native tracker == 9 concurrent units, bit for bit)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def full_runs():
+    import bench
+    from pcseqlearning_amd.pcdet import models
+    from tools.run_sequence import build_model
+    batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
+    outs = []
+    for streams in (9, 1):
+        model = build_model(save=False, device=DEV, streams=streams)
+        with torch.no_grad():
+            model(batch)
+        outs.append(model.last_outputs[0])
+    return outs
+
+
+def test_full_size_schedules_agree(full_runs):
+    a, b = full_runs
+    assert a["cluster_tracking_results"].keys() == b["cluster_tracking_results"].keys()
+    assert len(a["cluster_tracking_results"]) == 9
+    for key, ra in a["cluster_tracking_results"].items():
+        rb = b["cluster_tracking_results"][key]
+        for field in ("fxyz", "component", "original_indices", "frame_indices", "moving", "component_hit"):
+            assert torch.equal(ra[field], rb[field]), (key, field)
+    for k in ("point_component_rad1x25", "point_component_rad0x75", "point_component_rad0x25",
+              "point_gt_box_id", "gt_box_best_iou_tracking", "point_height"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_full_size_properties(full_runs):
+    out = full_runs[0]
+    n_sub, n_pts = out["full_point_fxyz"].shape[0], out["point_fxyz"].shape[0]
+    assert 1_000_000 < n_sub < 3_200_000 and 100_000 < n_pts < n_sub
+    # subsample: one point per occupied 8 cm cell -> no two kept points share a cell of their frame
+    f = out["full_point_fxyz"]
+    cell = torch.cat([f[:, :1].round().long(), torch.floor(f[:, 1:] / 0.08).long()], 1)
+    # (cells are anchored at the data minimum in the pipeline; a lattice anchored at 0 can only
+    # split cells further, so duplicates here would be duplicates there too)
+    key = ((cell[:, 0] * 4096 + (cell[:, 1] + 2048)) * 4096 + (cell[:, 2] + 2048)) * 512 + (cell[:, 3] + 256)
+    assert key.unique().numel() > 0.55 * n_sub
+    # ground removal: finite heights, the kept points are exactly those at least 0.5 m above ground
+    h = out["full_point_height"]
+    assert bool(torch.isfinite(h).all()) and int((h >= 0.5).sum()) == n_pts
+    # proposals: dense labels 0..C-1, a component never spans two 10-frame chunks, and the finer
+    # radius refines the coarser one (every fine component lies inside one coarse component)
+    fr = out["point_fxyz"][:, 0].round().long()
+    comps = {}
+    for key_name in ("rad1x25", "rad0x75", "rad0x25"):
+        c = out[f"point_component_{key_name}"]
+        C = int(c.max()) + 1
+        assert c.unique().numel() == C and int(c.min()) == 0
+        chunk = fr // 10
+        lo = torch.full((C,), 99, device=c.device).scatter_reduce(0, c, chunk, reduce="amin")
+        hi = torch.zeros(C, dtype=torch.long, device=c.device).scatter_reduce(0, c, chunk, reduce="amax")
+        assert torch.equal(lo, hi)
+        comps[key_name] = c
+    for fine, coarse in (("rad0x25", "rad0x75"), ("rad0x75", "rad1x25")):
+        cf, cc = comps[fine], comps[coarse]
+        Cf = int(cf.max()) + 1
+        lo = torch.full((Cf,), 1 << 40, device=cf.device).scatter_reduce(0, cf, cc, reduce="amin")
+        hi = torch.zeros(Cf, dtype=torch.long, device=cf.device).scatter_reduce(0, cf, cc, reduce="amax")
+        assert torch.equal(lo, hi), (fine, coarse)
+    # tracking units: extracted rows are real full-resolution rows of the right frame, indices
+    # consistent, transforms are rigid (rotation orthonormal, det +1, bottom row 0 0 0 1)
+    all_fxyz = out["full_point_fxyz"][out["full_point_height"] > 0.0]
+    n_tracked = 0
+    for (anchor, key_name), res in out["cluster_tracking_results"].items():
+        oi = res["original_indices"].reshape(-1)
+        assert int(oi.min()) >= 0 and int(oi.max()) < all_fxyz.shape[0]
+        assert torch.equal(all_fxyz[oi], res["fxyz"])
+        frames = res["fxyz"][:, 0].round().long()
+        assert int(frames.min()) >= max(0, anchor - 8) and int(frames.max()) <= min(19, anchor + 8)
+        # (row of the sequence, component) pairs are unique: a point is harvested once per component
+        pair = oi * (int(res["component"].max()) + 1) + res["component"].long()
+        assert pair.unique().numel() == pair.numel()
+        n_tracked += int(res["component"].unique().numel())
+    assert n_tracked > 100
+    # GT bookkeeping: IoUs are in [0, 1]
+    iou = out["gt_box_best_iou_tracking"]
+    assert float(iou.min()) >= 0.0 and float(iou.max()) <= 1.0 + 1e-6 and float(iou.max()) > 0.5
+
+
+def test_full_size_transforms_are_rigid():
+    """One anchor of the full-size sequence through the native tracker: every per-component,
+    per-frame transform is a rigid motion."""
+    import bench
+    from pcseqlearning_amd.pcdet import models
+    from tools.run_sequence import build_model
+    batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
+    model = build_model(save=True, device=DEV, streams=9)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for p in model.model_cfg.PREPROCESSORS:
+            p["DIR"] = tmp + "/" + p["NAME"]
+            p["LOG_DIR"] = tmp + "/log"
+        model.model_cfg.SAVE_DIR = None
+        with torch.no_grad():
+            model(batch)
+        import glob
+        files = sorted(glob.glob(f"{tmp}/ClusterTracking/*/0*_component_*.pth"))
+        assert len(files) == 9
+        for path in files[:3]:
+            T = torch.load(path, map_location="cpu")["transforms"].reshape(-1, 4, 4)
+            R = T[:, :3, :3]
+            eye = torch.eye(3, dtype=T.dtype).expand_as(R)
+            assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-9
+            assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-9
+            assert torch.equal(T[:, 3], torch.tensor([0, 0, 0, 1], dtype=T.dtype).expand(T.shape[0], 4))
+        assert len(glob.glob(f"{tmp}/ClusterTracking/*/all.pth")) == 1
