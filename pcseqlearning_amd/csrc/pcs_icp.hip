@@ -70,7 +70,6 @@ struct IcpBufs {
   double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
   double* lossp; // [ceil(Mn / kBlock)] per-workgroup sums of the component losses, last applied iteration
   int32_t* first; // [C] smallest moving-point index of the component (INT_MAX: none)
-  IcpProblem* desc; // device copy of this call's problem descriptor
 
   int32_t* cnt;  // [C] matched moving points in the final coverage query
 };
@@ -117,7 +116,6 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.Tb = a.take<double>(2 * C * 16);
   b.lossp = a.take<double>((Mn + kBlock - 1) / kBlock + 1);
   b.first = a.take<int32_t>(C);
-  b.desc = a.take<IcpProblem>(1);
 
   b.cnt = a.take<int32_t>(C);
   return a.ok();
@@ -126,10 +124,8 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
 // grid origin padded so that points moved by the registration stay inside the 17-bit cell range
 __global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* __restrict__ b_mov,
                                  const float* __restrict__ b_all, float radius, float cell,
-                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st,
-                                 IcpProblem prob, IcpProblem* __restrict__ desc) {
+                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st) {
   if (threadIdx.x != 0) return;
-  if (desc) *desc = prob;  // the call's problem descriptor, for the iteration kernels
   float mn[4];
   for (int d = 0; d < 4; ++d) mn[d] = fminf(fminf(b_ref[d], b_mov[d]), b_all[d]);
   float vs0 = (float)(1 - 1e-3);
@@ -256,6 +252,12 @@ icp_decide_kernel(const IcpProblem* __restrict__ P, int kbase, IcpState* __restr
   __syncthreads();
   if (out && threadIdx.x == 0) out[blockIdx.y] = *pr.st;
 }
+__global__ void __launch_bounds__(kBlock)
+icp_decide_kernel_v(const IcpProblem pr, int kbase, IcpState* __restrict__ out) {
+  icp_decide(pr.st, pr.lossp, pr.nparts, pr.k0 + kbase + pr.n_it - 1, pr.delta);
+  __syncthreads();
+  if (out && threadIdx.x == 0) out[0] = *pr.st;
+}
 
 // one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
 // 64-lane butterflies first. All 64 lanes must call this.
@@ -280,9 +282,7 @@ __device__ __forceinline__ void grouped_atomic_add(bool active, int key, const d
 
 // 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
 // queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
-__global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  const IcpProblem& pr = P[blockIdx.y];
+__device__ __forceinline__ void icp_nn_kernel_body(const IcpProblem& pr, int j, int kbase) {
   if (j >= pr.n_it) return;
   const int k = pr.k0 + kbase + j;
   IcpState* st = pr.st;
@@ -318,13 +318,22 @@ icp_nn_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
   }
 }
 
+// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
+// sits in the kernel-argument segment, one dependent global load less at the head of the launch
+__global__ void __launch_bounds__(kBlock)
+icp_nn_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  icp_nn_kernel_body(P[blockIdx.y], j, kbase);
+}
+__global__ void __launch_bounds__(kBlock)
+icp_nn_kernel_v(const IcpProblem pr, int j, int kbase) {
+  icp_nn_kernel_body(pr, j, kbase);
+}
+
 // raw moments of the matched pairs per component, one thread per potential edge. Each workgroup
 // first accumulates into a small LDS table keyed by component (ds_add_f64; neighbouring edges
 // mostly share a component), then flushes one global f64 atomic per (component, accumulator).
 constexpr int kMomSlots = 64;
-__global__ void __launch_bounds__(kBlock)
-icp_moments_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  const IcpProblem& pr = P[blockIdx.y];
+__device__ __forceinline__ void icp_moments_kernel_body(const IcpProblem& pr, int j, int kbase) {
   if (j >= pr.n_it) return;
   const int k = pr.k0 + kbase + j;
   if (k > pr.st->stop_iter) return;
@@ -385,6 +394,17 @@ icp_moments_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
     int key = skey[sl];
     if (key >= 0) atomicAdd(&acc[(int64_t)key * kAcc + a], sacc[sl][a]);
   }
+}
+
+// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
+// sits in the kernel-argument segment, one dependent global load less at the head of the launch
+__global__ void __launch_bounds__(kBlock)
+icp_moments_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  icp_moments_kernel_body(P[blockIdx.y], j, kbase);
+}
+__global__ void __launch_bounds__(kBlock)
+icp_moments_kernel_v(const IcpProblem pr, int j, int kbase) {
+  icp_moments_kernel_body(pr, j, kbase);
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151)
@@ -602,9 +622,7 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
 // buffer k) and the loss term. The previous positions are kept for the l1 passes. The moved points go
 // straight into the grid of the next iteration (the moving grid is double-buffered: no separate
 // build launch), and the grid this iteration searched is reset.
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  const IcpProblem& pr = P[blockIdx.y];
+__device__ __forceinline__ void icp_apply_kernel_body(const IcpProblem& pr, int j, int kbase) {
   if (j >= pr.n_it) return;
   const int k = pr.k0 + kbase + j;
   IcpState* st = pr.st;
@@ -672,6 +690,17 @@ icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
   }
 }
 
+// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
+// sits in the kernel-argument segment, one dependent global load less at the head of the launch
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
+  icp_apply_kernel_body(P[blockIdx.y], j, kbase);
+}
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel_v(const IcpProblem pr, int j, int kbase) {
+  icp_apply_kernel_body(pr, j, kbase);
+}
+
 // coverage: moving points (final positions) with a reference point (stationary included) in range
 __global__ void __launch_bounds__(kBlock)
 icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __restrict__ comp,
@@ -716,23 +745,37 @@ struct NnEvents {
 };
 static thread_local NnEvents t_ev;
 
-// launches of one chunk (n_max iteration positions) for an array of problems already on the device
-static int icp_launch_chunk(const IcpProblem* d_probs, int nprob, int n_max, int kbase, int max_nb_q,
-                            int max_nb_e, int max_nb_m, IcpState* out, hipStream_t s, hipEvent_t* ev) {
+// launches of one chunk (n_max iteration positions): an array of problems already on the device, or
+// (host_prob != nullptr) ONE problem passed by value
+static int icp_launch_chunk(const IcpProblem* d_probs, const IcpProblem* host_prob, int nprob, int n_max,
+                            int kbase, int max_nb_q, int max_nb_e, int max_nb_m, IcpState* out,
+                            hipStream_t s, hipEvent_t* ev) {
   for (int j = 0; j < n_max; ++j) {
-    if (ev) {
-      // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
-      // difference is the kernel's own begin-to-end time, as rocprofv3 reports it
-      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(max_nb_q, nprob), dim3(kBlock), 0, s, ev[2 * j],
-                            ev[2 * j + 1], 0, d_probs, j, kbase);
+    if (host_prob) {
+      if (ev) {
+        // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
+        // difference is the kernel's own begin-to-end time, as rocprofv3 reports it
+        hipExtLaunchKernelGGL(icp_nn_kernel_v, dim3(max_nb_q), dim3(kBlock), 0, s, ev[2 * j], ev[2 * j + 1],
+                              0, *host_prob, j, kbase);
+      } else {
+        icp_nn_kernel_v<<<max_nb_q, kBlock, 0, s>>>(*host_prob, j, kbase);
+      }
+      icp_moments_kernel_v<<<max_nb_e, kBlock, 0, s>>>(*host_prob, j, kbase);
+      icp_apply_kernel_v<<<max_nb_m, kBlock, 0, s>>>(*host_prob, j, kbase);
     } else {
-      icp_nn_kernel<<<dim3(max_nb_q, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+      if (ev) {
+        hipExtLaunchKernelGGL(icp_nn_kernel, dim3(max_nb_q, nprob), dim3(kBlock), 0, s, ev[2 * j],
+                              ev[2 * j + 1], 0, d_probs, j, kbase);
+      } else {
+        icp_nn_kernel<<<dim3(max_nb_q, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+      }
+      icp_moments_kernel<<<dim3(max_nb_e, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
+      icp_apply_kernel<<<dim3(max_nb_m, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
     }
-    icp_moments_kernel<<<dim3(max_nb_e, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
-    icp_apply_kernel<<<dim3(max_nb_m, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
   }
   // the stop rule of the chunk's last iteration (the others were settled by the next search)
-  icp_decide_kernel<<<dim3(1, nprob), kBlock, 0, s>>>(d_probs, kbase, out);
+  if (host_prob) icp_decide_kernel_v<<<1, kBlock, 0, s>>>(*host_prob, kbase, out);
+  else icp_decide_kernel<<<dim3(1, nprob), kBlock, 0, s>>>(d_probs, kbase, out);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
@@ -847,7 +890,8 @@ class IcpBatcher {
         if (hipMemcpyAsync(d_probs_, h_probs_, (size_t)n * sizeof(IcpProblem), hipMemcpyHostToDevice,
                            stream_) != hipSuccess)
           rc = PCS_ERR_HIP;
-        if (rc == PCS_OK) rc = icp_launch_chunk(d_probs_, n, n_max, 0, q, e, m, h_state_, stream_, prof ? ev : nullptr);
+        if (rc == PCS_OK)
+          rc = icp_launch_chunk(d_probs_, nullptr, n, n_max, 0, q, e, m, h_state_, stream_, prof ? ev : nullptr);
         if (rc == PCS_OK && hipStreamSynchronize(stream_) != hipSuccess) rc = PCS_ERR_HIP;
         if (rc == PCS_OK && prof) {
           double ms_sum = 0.0;
@@ -1096,11 +1140,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     req.bytes_per_launch = 2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn);
   }
   const bool shared = t_share_launches;
-  // grid description + the descriptor's device copy (chunk positions 0..chunk-1 enabled, k0 = 1: the
-  // stand-alone path passes the chunk's first iteration as kbase), then the three grids in one launch
-  req.prob.n_it = chunk;
-  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state, req.prob,
-                                    shared ? nullptr : b.desc);
+  // grid description, then the three grids in one launch
+  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
   {
     int64_t nmax = Mn > Rn ? Mn : Rn;
     if (Ra > nmax) nmax = Ra;
@@ -1140,14 +1181,10 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       if (rc2) return rc2;
       host = req.result;
     } else {
-      // the device copy of the descriptor keeps k0 = 1 / n_it = 0: the chunk position is passed
-      // as kbase and every position is enabled through n_it below
-      if (n_it != chunk) {
-        req.prob.n_it = n_it;
-        PCS_CHECK_HIP(hipMemcpyAsync(b.desc, &req.prob, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
-      }
+      // the descriptor travels by value (k0 = 1; the chunk's first iteration is passed as kbase)
+      req.prob.n_it = n_it;
       bool pk = prof && it + n_it <= kProfIters;
-      int rc2 = icp_launch_chunk(b.desc, 1, n_it, it, nb_q, nb_e, nb_m, pin, s,
+      int rc2 = icp_launch_chunk(nullptr, &req.prob, 1, n_it, it, nb_q, nb_e, nb_m, pin, s,
                                  pk ? &t_ev.ev[2 * it] : nullptr);
       if (rc2) return rc2;
       if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
