@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units per GPU (default 9)")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units per GPU (default 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -561,7 +561,9 @@ class ClusterTracking(nn.Module):
                     extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes, views)
             return extracted, boxes.best_iou
 
-        n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 9)), len(units)))
+        # 4 concurrent units: beyond that the kernels of different streams no longer overlap on this
+        # hardware and every unit only gets slower (see pcseqlearning_amd/__init__.py)
+        n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 4)), len(units)))
         results, best = {}, []
         if n_workers == 1 or not seq_points.fxyz.is_cuda:
             for comp_key, frame_id in units:

@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--save", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--repeat", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units (default 9)")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units (default 4)")
     args = ap.parse_args()
     t0 = time.time()
     batch = synthetic.gen_sequence(args.seed, args.frames, args.points)
