@@ -7,6 +7,7 @@ pcseqlearning_amd.ops (grid sampling, medians, fused ICP, radius graph, ordered 
 smooth_velo, points_in_boxes). The polyscope visualiser hooks of the reference are not mirrored.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -483,6 +484,43 @@ class ClusterTracking(nn.Module):
                                      comp_max_frame_id=comp_max_frame_id)
         return extracted
 
+    @staticmethod
+    def plan_units(units, cost, n_workers):
+        """Units -> per-worker lists (each longest first) with a small makespan: LPT, then moves and
+        swaps away from the fullest worker while they help."""
+        plan = [[] for _ in range(n_workers)]
+        load = [0.0] * n_workers
+        for u in sorted(units, key=lambda u: -cost[u]):
+            w = min(range(n_workers), key=lambda i: load[i])
+            plan[w].append(u)
+            load[w] += cost[u]
+        improved = True
+        while improved:
+            improved = False
+            a = max(range(n_workers), key=lambda i: load[i])
+            for b in range(n_workers):
+                if b == a:
+                    continue
+                for ua in list(plan[a]):
+                    if max(load[a] - cost[ua], load[b] + cost[ua]) < load[a] - 1e-9:      # move
+                        plan[a].remove(ua); plan[b].append(ua)
+                        load[a] -= cost[ua]; load[b] += cost[ua]
+                        improved = True
+                        break
+                    for ub in list(plan[b]):
+                        d = cost[ua] - cost[ub]
+                        if d > 0 and max(load[a] - d, load[b] + d) < load[a] - 1e-9:      # swap
+                            plan[a].remove(ua); plan[b].remove(ub)
+                            plan[a].append(ub); plan[b].append(ua)
+                            load[a] -= d; load[b] += d
+                            improved = True
+                            break
+                    if improved:
+                        break
+                if improved:
+                    break
+        return [sorted(p, key=lambda u: -cost[u]) for p in plan]
+
     # ------------------------------------------------------------------ whole sequence
     def forward(self, seq_dict):
         seq_points = EasyDict(
@@ -589,30 +627,44 @@ class ClusterTracking(nn.Module):
                 w.num_registration_calls = 0
                 w._stream.wait_stream(main_stream)
                 free.put(w)
-            # The stage ends with its longest unit (an anchor in mid-sequence is tracked through
-            # twice as many frames as one at either end): longest first. (High-priority HIP streams
-            # for the long units were measured and made every unit slower.)
-            span = {u: min(num_frames - 1, u[1] + self.track_interval) - max(0, u[1] - self.track_interval)
+            # A unit costs about as much as the frames it tracks through (an anchor in mid-sequence:
+            # twice as many as one at either end). The units are planned onto the workers up front
+            # (longest-processing-time first, then moves / swaps off the fullest worker): taking
+            # them from a common queue leaves one worker with three medium units at the end.
+            # (High-priority HIP streams for the long units were measured and made every unit slower.)
+            span = {u: 1 + min(num_frames - 1, u[1] + self.track_interval) - max(0, u[1] - self.track_interval)
                     for u in units}
-            order = sorted(units, key=lambda u: -span[u])
+            # ... scaled by what a unit of the same (key, window length) took in the previous sequence
+            # (keys with thousands of small components are dearer per frame), when there is one
+            seen = getattr(self, "_unit_seconds", {})
+            per_frame = [seen[(u[0], span[u])] / span[u] for u in units if (u[0], span[u]) in seen]
+            default = sum(per_frame) / len(per_frame) if per_frame else 1.0
+            cost = {u: seen.get((u[0], span[u]), default * span[u]) for u in units}
+            plan = self.plan_units(units, cost, n_workers)
+            took = {}
 
-            def job(comp_key, frame_id):
-                w = free.get()
-                try:
-                    with torch.cuda.device(device), torch.cuda.stream(w._stream):
-                        out = run_unit(w, comp_key, frame_id)
-                        w._stream.synchronize()
-                    return out
-                finally:
-                    free.put(w)
+            def worker_job(w, my_units):
+                outs = []
+                with torch.cuda.device(device), torch.cuda.stream(w._stream):
+                    for comp_key, frame_id in my_units:
+                        t0 = time.perf_counter()
+                        outs.append(((comp_key, frame_id), run_unit(w, comp_key, frame_id)))
+                        took[(comp_key, span[(comp_key, frame_id)])] = time.perf_counter() - t0
+                    w._stream.synchronize()
+                return outs
 
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
-                futs = {u: pool.submit(job, *u) for u in order}
+                futs = [pool.submit(worker_job, free.get(), my_units) for my_units in plan if my_units]
                 # the units are now in native code on their own threads: the main thread does the
                 # parked host-side work (ClusterProposal's evaluation) meanwhile
                 run_deferred(seq_dict)
-                for (comp_key, frame_id), fut in futs.items():
-                    ex, biou = fut.result()
+                done = {}
+                for fut in futs:
+                    for unit, out in fut.result():
+                        done[unit] = out
+                self._unit_seconds = took
+                for comp_key, frame_id in units:      # results in the reference's unit order
+                    ex, biou = done[(comp_key, frame_id)]
                     results[(frame_id, comp_key)] = ex
                     best.append(biou)
             self.num_registration_calls = sum(w.num_registration_calls for w in self._workers[:n_workers])
