@@ -643,18 +643,40 @@ class ClusterTracking(nn.Module):
             plan = self.plan_units(units, cost, n_workers)
             took = {}
 
-            def worker_job(w, my_units):
-                outs = []
+            import threading
+            plan_lock = threading.Lock()
+
+            def next_unit(i):
+                """Own list first (longest first); an idle worker takes the shortest unit still
+                waiting on the fullest list, so a slow stream does not hold the stage up."""
+                with plan_lock:
+                    if plan[i]:
+                        return plan[i].pop(0)
+                    rest = [(sum(cost[u] for u in plan[j]), j) for j in range(len(plan)) if plan[j]]
+                    if not rest:
+                        return None
+                    return plan[max(rest)[1]].pop()
+
+            def worker_job(w, i):
+                outs, work = [], 0.0
+                t_start = time.perf_counter()
                 with torch.cuda.device(device), torch.cuda.stream(w._stream):
-                    for comp_key, frame_id in my_units:
+                    while True:
+                        unit = next_unit(i)
+                        if unit is None:
+                            break
                         t0 = time.perf_counter()
-                        outs.append(((comp_key, frame_id), run_unit(w, comp_key, frame_id)))
-                        took[(comp_key, span[(comp_key, frame_id)])] = time.perf_counter() - t0
+                        outs.append((unit, run_unit(w, *unit)))
+                        took[(unit[0], span[unit])] = time.perf_counter() - t0
+                        work += cost[unit]
                     w._stream.synchronize()
+                # planned work per second: a stream that landed on a hardware queue it has to share
+                # runs its units about twice as slowly as the others
+                w._rate = work / max(time.perf_counter() - t_start, 1e-6) if work else None
                 return outs
 
             with ThreadPoolExecutor(max_workers=n_workers) as pool:
-                futs = [pool.submit(worker_job, free.get(), my_units) for my_units in plan if my_units]
+                futs = [pool.submit(worker_job, free.get(), i) for i in range(len(plan)) if plan[i]]
                 # the units are now in native code on their own threads: the main thread does the
                 # parked host-side work (ClusterProposal's evaluation) meanwhile
                 run_deferred(seq_dict)
@@ -663,6 +685,15 @@ class ClusterTracking(nn.Module):
                     for unit, out in fut.result():
                         done[unit] = out
                 self._unit_seconds = took
+                # re-roll the stream of a worker that was markedly slower than the median one (streams
+                # map onto hardware queues round-robin; a fresh stream takes another queue)
+                active = [w for w in self._workers[:n_workers] if getattr(w, "_rate", None)]
+                if len(active) >= 3 and seen:
+                    rates = sorted(w._rate for w in active)
+                    median = rates[len(rates) // 2]
+                    for w in active:
+                        if w._rate < 0.6 * median:
+                            w._stream = torch.cuda.Stream(device=device)
                 for comp_key, frame_id in units:      # results in the reference's unit order
                     ex, biou = done[(comp_key, frame_id)]
                     results[(frame_id, comp_key)] = ex
