@@ -32,3 +32,43 @@ def test_component_box_iou_matches_loop():
             want_best[b] = w
     scatter_max_(best, box[has_box], iou[has_box].float())
     assert torch.allclose(best, want_best)
+
+
+def test_component_box_iou_frames_matches_per_frame():
+    """The all-frames form (groups = (frame, component), boxes indexed within their frame) against the
+    per-frame component_box_iou it replaces in the evaluation / extraction loops."""
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors.eval_utils import component_box_iou_frames
+    g = torch.Generator().manual_seed(1)
+    F, n = 6, 4000
+    nbox = torch.tensor([5, 0, 9, 3, 0, 7])            # frames 1 and 4 have no boxes
+    box_off = torch.zeros(F + 1, dtype=torch.long)
+    box_off[1:] = nbox.cumsum(0)
+    bmax = int(nbox.max())
+    frame = torch.randint(0, F, (n,), generator=g)
+    frame = frame[(nbox[frame] > 0)]                    # the callers drop frames without boxes
+    n = frame.numel()
+    comp = torch.randint(0, 40, (n,), generator=g) * 2
+    member = torch.zeros(n, bmax, dtype=torch.int32)
+    hit = torch.rand(n, bmax, generator=g) < 0.08
+    member[hit & (torch.arange(bmax)[None, :] < nbox[frame][:, None])] = 1
+    in_box = member.any(1)
+    gt_local = torch.where(in_box, member.argmax(1), torch.full((n,), -1))
+    gt_cnt_all = torch.bincount((box_off[frame] + gt_local)[in_box], minlength=int(box_off[-1]))
+    gframe, gcomp, inv, has_box, box, iou = component_box_iou_frames(comp, frame, member, gt_local, box_off, gt_cnt_all)
+    pos = 0
+    for f in range(F):
+        sel = (frame == f).nonzero(as_tuple=True)[0]
+        if sel.numel() == 0:
+            continue
+        B = int(nbox[f])
+        bp = member[sel, :B].t().long()
+        uniq, inv_f, hb, bx, io = component_box_iou(comp[sel], bp, gt_local[sel],
+                                                  gt_cnt_all[box_off[f]:box_off[f + 1]])
+        k = uniq.numel()
+        assert torch.equal(gframe[pos:pos + k], torch.full((k,), f)) and torch.equal(gcomp[pos:pos + k], uniq)
+        assert torch.equal(has_box[pos:pos + k], hb)
+        assert torch.equal(box[pos:pos + k][hb], bx[hb])
+        assert torch.equal(iou[pos:pos + k][hb], io[hb])
+        assert torch.equal(inv[sel] - pos, inv_f)
+        pos += k
+    assert pos == gframe.numel()

@@ -185,6 +185,34 @@ def test_nn1_dense_cells_spill(oracle):
     np.testing.assert_allclose(mov.cpu().numpy(), o_moved, rtol=0, atol=2e-5)
 
 
+def test_points_in_frame_boxes_vs_oracle(oracle):
+    """All frames at once against the oracle's points_in_boxes (roiaware_pool3d.cpp:121-168) frame by
+    frame: membership matrix in within-frame box order, first containing box."""
+    rng = np.random.default_rng(4)
+    F = 5
+    nbox = np.array([4, 0, 7, 2, 5])
+    off = np.concatenate([[0], np.cumsum(nbox)]).astype(np.int32)
+    boxes = np.concatenate([rng.uniform(-20, 20, (off[-1], 3)) * [1, 1, 0.05],
+                            rng.uniform([2, 1, 1], [8, 4, 3], (off[-1], 3)),
+                            rng.uniform(-3.2, 3.2, (off[-1], 1))], 1).astype(np.float32)
+    n = 6000
+    frame = rng.integers(0, F, n)
+    centre = boxes[rng.integers(0, off[-1], n), :3]
+    pts = (centre + rng.normal(0, 2.5, (n, 3)) * [1, 1, 0.4]).astype(np.float32)
+    bmax = int(nbox.max())
+    member, first = ops.points_in_frame_boxes(dev(pts), dev(frame.astype(np.int64)), dev(boxes),
+                                              dev(off), bmax)
+    member, first = member.cpu().numpy(), first.cpu().numpy()
+    for f in range(F):
+        sel = np.nonzero(frame == f)[0]
+        want = oracle.points_in_boxes(pts[sel], boxes[off[f]:off[f + 1]]) if nbox[f] else np.zeros((0, len(sel)), np.int32)
+        np.testing.assert_array_equal(member[sel, :nbox[f]].T, want)
+        assert not member[sel, nbox[f]:].any()
+        want_first = np.where(want.any(0), want.argmax(0), -1) if nbox[f] else np.full(len(sel), -1)
+        np.testing.assert_array_equal(first[sel], want_first)
+    assert member.sum() > 200
+
+
 def _run_icp(g, radius, cell=0.0, chunk=8):
     nsm = ~g["mov_stationary"]
     nsr = ~g["ref_stationary"]
