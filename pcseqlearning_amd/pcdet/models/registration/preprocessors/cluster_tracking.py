@@ -675,7 +675,15 @@ class ClusterTracking(nn.Module):
                 w._rate = work / max(time.perf_counter() - t_start, 1e-6) if work else None
                 return outs
 
-            with ThreadPoolExecutor(max_workers=n_workers) as pool:
+            # one pool for the life of the module: its threads keep their pinned status page and
+            # profiling events (thread-local in the native library) from sequence to sequence
+            if getattr(self, "_pool_size", 0) != n_workers:
+                if getattr(self, "_pool", None) is not None:
+                    self._pool.shutdown(wait=True)
+                self._pool = ThreadPoolExecutor(max_workers=n_workers, thread_name_prefix="pcs-track")
+                self._pool_size = n_workers
+            pool = self._pool
+            if True:
                 futs = [pool.submit(worker_job, free.get(), i) for i in range(len(plan)) if plan[i]]
                 # the units are now in native code on their own threads: the main thread does the
                 # parked host-side work (ClusterProposal's evaluation) meanwhile
