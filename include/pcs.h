@@ -211,8 +211,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
                                pcs_stream_t stream);
 
-/* Opt the CALLING THREAD's pcs_register_to_next_frame calls into (1) / out of (0) the shared
- * launcher: concurrent calls from several host threads then hand their iteration chunks to one
+/* Opt the CALLING THREAD's pcs_register_to_next_frame calls into (group id g >= 1) / out of (0) a
+ * shared launcher (one per group; threads that move in lock-step should share a group): concurrent calls from several host threads then hand their iteration chunks to one
  * launcher thread, which issues them as one array of problems per launch (kernels of different
  * streams overlap only 2-3 deep, the iteration kernels of one problem leave the device mostly
  * idle). Results are identical; pcs_track_frame switches it on for its own duration. The launcher
@@ -268,7 +268,7 @@ typedef struct PcsTrackParams {
   float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
   float max_diameter;      /* filter_components max_diameter (12.5) */
   float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
-  int32_t share_launches;  /* 1: this call's ICP iterations go through pcs_icp_share_launches */
+  int32_t share_launches;  /* g >= 1: this call's ICP iterations go through pcs_icp_share_launches(g) */
 } PcsTrackParams;
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames);

@@ -790,6 +790,7 @@ static int icp_launch_chunk(const IcpProblem* d_probs, const IcpProblem* host_pr
 // stream, so no cross-stream ordering is needed. While a batch runs (~0.4 ms) later requests queue
 // up, which is what keeps the batches full without any waiting window.
 constexpr int kMaxBatch = 64;
+constexpr int kMaxGroups = 16;
 static double g_batch_stats[4] = {0, 0, 0, 0};  // batches, problems, busy seconds, idle seconds
 struct IcpRequest {
   IcpProblem prob;
@@ -802,9 +803,15 @@ struct IcpRequest {
 
 class IcpBatcher {
  public:
-  static IcpBatcher& get() {
-    static IcpBatcher* inst = new IcpBatcher();  // never destroyed: the launcher thread outlives main
-    return *inst;
+  // one launcher (thread + stream) per group id: callers that move in lock-step -- the component
+  // keys of one anchor frame -- share a group, independent groups run side by side
+  static IcpBatcher& get(int group) {
+    static std::mutex gmu;
+    static IcpBatcher* inst[kMaxGroups] = {};  // never destroyed: the launcher threads outlive main
+    std::lock_guard<std::mutex> lk(gmu);
+    int g = group < 0 ? 0 : group % kMaxGroups;
+    if (!inst[g]) inst[g] = new IcpBatcher();
+    return *inst[g];
   }
   void add_participant() {
     std::lock_guard<std::mutex> lk(mu_);
@@ -937,6 +944,7 @@ class IcpBatcher {
 
 // set by pcs_icp_share_launches(): the calling thread's ICP calls go through the shared launcher
 static thread_local bool t_share_launches = false;
+static thread_local int t_share_group = 0;
 static thread_local double t_share_wait_s = 0.0;  // time this thread spent inside IcpBatcher::run
 static thread_local double t_icp_s = 0.0;         // time this thread spent inside the ICP entry point
 
@@ -993,9 +1001,11 @@ int pcs_profile_sync_loop(int64_t n, int mode, hipStream_t s) {
 
 // the calling thread's pcs_register_to_next_frame calls use (1) / stop using (0) the shared launcher
 int pcs_icp_share_launches(int enable) {
-  if (enable && !t_share_launches) IcpBatcher::get().add_participant();
-  if (!enable && t_share_launches) IcpBatcher::get().remove_participant();
+  // enable = 0: off; enable = g >= 1: share launches with the other threads of group g
+  if (t_share_launches) IcpBatcher::get(t_share_group).remove_participant();
   t_share_launches = enable != 0;
+  t_share_group = enable;
+  if (t_share_launches) IcpBatcher::get(t_share_group).add_participant();
   return PCS_OK;
 }
 
@@ -1154,8 +1164,8 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   IcpState* pin = (IcpState*)thread_pinned_page();
   struct IcpPhase {  // tells the shared launcher that this thread is about to submit chunks
     bool on;
-    explicit IcpPhase(bool o) : on(o) { if (on) IcpBatcher::get().enter_icp(); }
-    void end() { if (on) { IcpBatcher::get().leave_icp(); on = false; } }
+    explicit IcpPhase(bool o) : on(o) { if (on) IcpBatcher::get(t_share_group).enter_icp(); }
+    void end() { if (on) { IcpBatcher::get(t_share_group).leave_icp(); on = false; } }
     ~IcpPhase() { end(); }
   } phase(shared);
   bool prof = g_prof_on && !shared;
@@ -1176,7 +1186,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       req.prob.k0 = it + 1;
       req.prob.n_it = n_it;
       auto tw = std::chrono::steady_clock::now();
-      int rc2 = IcpBatcher::get().run(&req);
+      int rc2 = IcpBatcher::get(t_share_group).run(&req);
       t_share_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
       if (rc2) return rc2;
       host = req.result;

@@ -682,9 +682,9 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   // of the call (prm->share_launches; see IcpBatcher in pcs_icp.hip for when that pays)
   struct ShareGuard {
     bool on;
-    explicit ShareGuard(bool o) : on(o) { if (on) pcs_icp_share_launches(1); }
+    explicit ShareGuard(int group) : on(group != 0) { if (on) pcs_icp_share_launches(group); }
     ~ShareGuard() { if (on) pcs_icp_share_launches(0); }
-  } share_guard(prm->share_launches != 0);
+  } share_guard(prm->share_launches);
 
   const float4* anchor = (const float4*)seq_fxyz + off_a;
   const int gA = nblk(na), gC = nblk(C);

@@ -521,7 +521,7 @@ def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
                  smooth=(1.0, 10.0, 300, 1e-3), share_launches=False):
     prm = TrackParams()
-    prm.share_launches = int(bool(share_launches))
+    prm.share_launches = int(share_launches)  # 0 off, g >= 1: launcher group
     L_ = len(radius_list)
     if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
         raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")

@@ -296,12 +296,13 @@ class ClusterTracking(nn.Module):
         max_frame_id = min(present[-1], frame_id + self.track_interval)
         if self.verbose:
             print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components (native)")
-        if self._track_params is None:
+        share = self.model_cfg.get("SHARE_ICP_LAUNCHES", False)
+        group = 0 if not share else (1 if share is True else 1 + frame_id // max(self.track_interval, 1))
+        if self._track_params is None or self._track_params.share_launches != group:
             self._track_params = ops.track_params(
                 self.radius_list, self.voxel_size_list, self.stopping_delta,
                 self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
-                self.angle_threshold, self.min_move_frame, max_iter=80,
-                share_launches=bool(self.model_cfg.get("SHARE_ICP_LAUNCHES", False)))
+                self.angle_threshold, self.min_move_frame, max_iter=80, share_launches=group)
         out, (_, reg_calls, _) = ops.track_frame(
             self._track_params, s_fxyz, s_comp, s_stat, offsets,
             frame_id, min_frame_id, max_frame_id, comp_base, num_components)

@@ -21,12 +21,15 @@ def main():
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--units", action="store_true", help="print the per-unit track / extract spans")
+    ap.add_argument("--share", default=None, help="SHARE_ICP_LAUNCHES: 'all' (one launcher) or 'anchor' (one per anchor)")
     ap.add_argument("--detail", action="store_true", help="device-synchronised spans inside the stages")
     args = ap.parse_args()
     timer.SYNC = args.detail
     batch = bench.load_sequence(0, 20, 160000)
     model = build_model(streams=args.streams)
     batch = models.load_data_to_gpu(batch)
+    if args.share:
+        model.preprocessors[2].model_cfg["SHARE_ICP_LAUNCHES"] = True if args.share == "all" else args.share
     spans = {}
 
     def wrap(mod, name):
