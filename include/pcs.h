@@ -297,6 +297,21 @@ int pcs_points_in_frame_boxes(const float* points, const int64_t* point_frame, i
                               const float* boxes, const int32_t* box_offsets, int F, int Bmax,
                               int32_t* member, int32_t* first, pcs_stream_t stream);
 
+/* Sequence loader, device side: WaymoDataset.get_lidar / load_data / __getitem__
+ * (pcdet/datasets/waymo/waymo_dataset.py:334-343, 383-391, 584-630) + the point_xyz branch of
+ * collate_batch (pcdet/datasets/dataset.py:222-232) for all sweeps of one sample in one pass.
+ * raw [N,8] f32 rows [x,y,z,intensity,elongation,range,rimage_w,rimage_h] of the kept lidars, sweeps
+ * concatenated in output order; seg [N,2] int32 [instance, segmentation] or NULL; sweep_offsets
+ * DEVICE int64 [F+1] (rows of sweep s are [off[s], off[s+1])); sweep_T DEVICE f64 [F,3,4] = rows of
+ * T0^-1 T1; sweep_ids DEVICE int32 [F] (sample index of the sweep, int(frame_id[-3:])).
+ * Out: point_bxyz [N,4] f32 (batch index, aligned xyz), point_feat [N,3] f32 (tanh intensity,
+ * elongation, range/75), point_sweep [N] int32, segmentation_label / instance_label [N] int32
+ * (untouched when seg is NULL). num_sweeps <= 1024. */
+int pcs_assemble_sweeps(const float* raw, const int32_t* seg, const int64_t* sweep_offsets,
+                        const double* sweep_T, const int32_t* sweep_ids, int num_sweeps, int64_t N,
+                        int batch_index, float* point_bxyz, float* point_feat, int32_t* point_sweep,
+                        int32_t* segmentation_label, int32_t* instance_label, pcs_stream_t stream);
+
 /* l1_minimization, pcdet/models/registration/preprocessors/preprocessor_utils.py:313-350 (ground
  * height per 2 m pillar: L1 data term + 4-direction second-difference smoothness, AdamW with
  * MultiStepLR, <= max_iters steps, 3-strike stop at 1e-4), one persistent kernel.

@@ -425,6 +425,35 @@ def points_in_frame_boxes(points, point_frame, boxes, box_offsets, bmax, want_me
     return member, first
 
 
+def assemble_sweeps(raw, seg, sweep_offsets, sweep_T, sweep_ids, batch_index=0):
+    """Device side of the sequence loader (WaymoDataset.get_lidar / __getitem__ + the point_xyz
+    branch of collate_batch): raw [N,8] f32 rows of all sweeps -> (point_bxyz [N,4] f32, point_feat
+    [N,3] f32, point_sweep [N,1] int32, segmentation_label [N] int32, instance_label [N] int32);
+    the two label arrays are None when `seg` is None. sweep_offsets int64 [F+1], sweep_T f64
+    [F,3,4], sweep_ids int32 [F], all on the device."""
+    L.require_gpu(raw, "assemble_sweeps")
+    lib = L.load()
+    dev = raw.device
+    assert raw.dtype == torch.float32 and raw.dim() == 2 and raw.shape[1] == 8 and raw.is_contiguous()
+    N, F = raw.shape[0], sweep_ids.shape[0]
+    assert sweep_offsets.dtype == torch.int64 and sweep_offsets.shape[0] == F + 1 and sweep_offsets.is_cuda
+    assert sweep_T.dtype == torch.float64 and tuple(sweep_T.shape) == (F, 3, 4) and sweep_T.is_cuda
+    assert sweep_ids.dtype == torch.int32 and sweep_ids.is_cuda
+    if seg is not None:
+        assert seg.dtype == torch.int32 and tuple(seg.shape) == (N, 2) and seg.is_contiguous() and seg.is_cuda
+    bxyz = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    feat = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    sweep = torch.empty(N, 1, dtype=torch.int32, device=dev)
+    seg_label = torch.empty(N, dtype=torch.int32, device=dev) if seg is not None else None
+    inst_label = torch.empty(N, dtype=torch.int32, device=dev) if seg is not None else None
+    L.check(lib.pcs_assemble_sweeps(L.ptr(raw), L.ptr(seg), L.ptr(sweep_offsets.contiguous()),
+                                    L.ptr(sweep_T.contiguous()), L.ptr(sweep_ids.contiguous()), L.i32(F),
+                                    L.i64(N), L.i32(batch_index), L.ptr(bxyz), L.ptr(feat), L.ptr(sweep),
+                                    L.ptr(seg_label), L.ptr(inst_label), L.stream()),
+            "pcs_assemble_sweeps")
+    return bxyz, feat, sweep, seg_label, inst_label
+
+
 def l1_minimization(pillar_min_z, weight, lr, decay_steps, rigid_weight, max_iters):
     """preprocessor_utils.l1_minimization: returns pillar_height [X,Y] f32."""
     L.require_gpu(pillar_min_z, "l1_minimization")

@@ -1,0 +1,67 @@
+"""Writes the inputs stored in a loader golden file back to disk in the reference's layout
+(`<tag>/<sequence>/%04d.npy`, `%04d_seg.npy`, `<sequence>.pkl`, `ImageSets/val.txt`) and builds the
+dataset config of tools/cfgs/dataset_configs/waymo/PCsequence/registration/all_sequence.yaml."""
+import pickle
+from pathlib import Path
+
+import numpy as np
+
+TAG = "waymo_processed_data_v0_5_0"
+SEQ = "segment-1005081002024129653_5313_150_5333_150_with_camera_labels"
+BOX_CLASSES = ["Vehicle", "Pedestrian", "Cyclist"]
+
+
+def infos_of(g):
+    infos = []
+    for f in range(int(g["num_frames"])):
+        infos.append({
+            "point_cloud": {"num_features": 5, "lidar_sequence": SEQ, "sample_idx": f},
+            "frame_id": f"{SEQ}_{f:03d}", "metadata": {"context_name": SEQ}, "pose": np.array(g[f"pose_{f}"]),
+            "num_points_of_each_lidar": [int(c) for c in g[f"counts_{f}"]],
+            "annos": {"name": np.array(g[f"names_{f}"]), "gt_boxes_lidar": np.array(g[f"boxes_{f}"]),
+                      "obj_ids": np.array(g[f"ids_{f}"]), "num_points_in_gt": np.array(g[f"npts_{f}"])},
+        })
+    return infos
+
+
+def write_sequence(root, g):
+    root = Path(root)
+    seq_dir = root / TAG / SEQ
+    seq_dir.mkdir(parents=True)
+    (root / "ImageSets").mkdir()
+    (root / "ImageSets" / "val.txt").write_text(SEQ + ".tfrecord\n")
+    for f in range(int(g["num_frames"])):
+        np.save(seq_dir / ("%04d.npy" % f), g[f"raw_{f}"])
+        np.save(seq_dir / ("%04d_seg.npy" % f), g[f"seg_{f}"])
+    with open(seq_dir / f"{SEQ}.pkl", "wb") as fh:
+        pickle.dump(infos_of(g), fh)
+    return root
+
+
+def dataset_cfg(root, num_sweeps, sweep_dir, sample_range):
+    from pcseqlearning_amd.pcdet.utils.common_utils import EasyDict
+    return EasyDict({
+        "DATASET": "WaymoDataset", "DATA_PATH": str(root), "PROCESSED_DATA_TAG": TAG,
+        "BOX_CLASSES": list(BOX_CLASSES), "POINT_CLOUD_RANGE": [-75.2, -75.2, -2, 75.2, 75.2, 4],
+        "DATA_SPLIT": {"train": "train", "test": "val"}, "NUM_SWEEPS": int(num_sweeps), "SWEEP_DIR": int(sweep_dir),
+        "SAMPLED_INTERVAL": {"train": 1, "test": 1}, "SAMPLED_SEQUENCE_INTERVAL": {"train": 1, "test": 1},
+        "SAMPLE_IDX_RANGE": {"train": list(sample_range), "test": list(sample_range)},
+        "GT_VELOCITY": True, "SYNC_MOVING_POINTS": False, "EVALUATION_LIST": ["seg"],
+        "SEGMENTATION_CFG": {"NUM_SEG_CLASSES": 23, "USE_ONLY_SAMPLES_WITH_SEG_LABELS": False, "LOAD_SEG": True},
+        "FILTER_EMPTY_BOXES_FOR_TRAIN": True, "DISABLE_NLZ_FLAG_ON_POINTS": True, "USE_SHARED_MEMORY": False,
+        "DROP_POINTS_BY_LIDAR_INDEX": [1, 2, 3, 4],
+        "POINT_FEATURE_ENCODING": {"encoding_type": "absolute_coordinates_encoding",
+                                   "used_feature_list": ["intensity", "elongation", "range"],
+                                   "src_feature_list": ["intensity", "elongation", "range", "rimage_w", "rimage_h"]},
+        "MAX_NUM_POINTS": 40000000,
+        "DATA_PROCESSOR": [{"NAME": "transform_points_to_voxels", "VOXEL_SIZE": [0.1, 0.1, 0.15],
+                            "POINT_CLOUD_RANGE": [-75.2, -75.2, -2, 75.2, 75.2, 4], "MAX_POINTS_PER_VOXEL": 5,
+                            "MAX_NUMBER_OF_VOXELS": {"train": 150000, "test": 150000}, "DRY": True}],
+    })
+
+
+def build_dataset(root, g):
+    from pcseqlearning_amd.pcdet.datasets import WaymoDataset
+    s = int(g["start_index"])
+    return WaymoDataset(dataset_cfg(root, int(g["num_sweeps"]), int(g["sweep_dir"]), [s, s + 1]), training=False,
+                        root_path=Path(root), logger=None)
