@@ -2,6 +2,8 @@
 ClusterTracking) on one synthetic Waymo-shaped sequence and print per-stage timings.
 
   python tools/run_sequence.py --frames 20 --points 160000 [--seed 0] [--save]
+  python tools/run_sequence.py --data-root /tmp/waymo_synth --frames 20     (sequence on disk, through
+      the WaymoDataset loader; tools/make_waymo_sequence.py writes one)
 """
 import argparse
 import os
@@ -33,8 +35,36 @@ def build_model(save=False, verbose=False, device="cuda", streams=None):
     return model.to(device).eval()
 
 
+def loader_cfg(root, num_sweeps):
+    """tools/cfgs/dataset_configs/waymo/PCsequence/registration/all_sequence.yaml of the reference."""
+    from pcseqlearning_amd.pcdet.utils.common_utils import EasyDict
+    return EasyDict({
+        "DATASET": "WaymoDataset", "DATA_PATH": str(root), "PROCESSED_DATA_TAG": "waymo_processed_data_v0_5_0",
+        "BOX_CLASSES": ["Vehicle", "Pedestrian", "Cyclist"], "POINT_CLOUD_RANGE": [-75.2, -75.2, -2, 75.2, 75.2, 4],
+        "DATA_SPLIT": {"train": "train", "test": "val"}, "NUM_SWEEPS": int(num_sweeps), "SWEEP_DIR": 1,
+        "SAMPLED_INTERVAL": {"train": 1, "test": 1}, "SAMPLED_SEQUENCE_INTERVAL": {"train": 1, "test": 1},
+        "SAMPLE_IDX_RANGE": {"train": [0, 1], "test": [0, 1]}, "SYNC_MOVING_POINTS": False,
+        "SEGMENTATION_CFG": {"NUM_SEG_CLASSES": 23, "USE_ONLY_SAMPLES_WITH_SEG_LABELS": False, "LOAD_SEG": True},
+        "DROP_POINTS_BY_LIDAR_INDEX": [1, 2, 3, 4],
+        "POINT_FEATURE_ENCODING": {"encoding_type": "absolute_coordinates_encoding",
+                                   "used_feature_list": ["intensity", "elongation", "range"],
+                                   "src_feature_list": ["intensity", "elongation", "range", "rimage_w", "rimage_h"]},
+        "MAX_NUM_POINTS": 40000000,
+        "DATA_PROCESSOR": [{"NAME": "transform_points_to_voxels", "VOXEL_SIZE": [0.1, 0.1, 0.15],
+                            "POINT_CLOUD_RANGE": [-75.2, -75.2, -2, 75.2, 75.2, 4], "MAX_POINTS_PER_VOXEL": 5,
+                            "MAX_NUMBER_OF_VOXELS": {"train": 150000, "test": 150000}, "DRY": True}],
+    })
+
+
+def load_from_disk(root, num_sweeps, device="cuda"):
+    from pcseqlearning_amd.pcdet.datasets import WaymoDataset
+    ds = WaymoDataset(loader_cfg(root, num_sweeps), training=False, root_path=root)
+    return ds.load_batch_to_gpu([0], device)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--data-root", default=None, help="sequence on disk in the reference's layout")
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--seed", type=int, default=0)
@@ -44,8 +74,12 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units (default 4)")
     args = ap.parse_args()
     t0 = time.time()
-    batch = synthetic.gen_sequence(args.seed, args.frames, args.points)
-    print(f"generated {batch['point_bxyz'].shape[0]} points in {time.time() - t0:.1f}s", flush=True)
+    if args.data_root:
+        batch = load_from_disk(args.data_root, args.frames)
+        print(f"loaded {batch['point_bxyz'].shape[0]} points from {args.data_root} in {time.time() - t0:.2f}s", flush=True)
+    else:
+        batch = synthetic.gen_sequence(args.seed, args.frames, args.points)
+        print(f"generated {batch['point_bxyz'].shape[0]} points in {time.time() - t0:.1f}s", flush=True)
     model = build_model(args.save, args.verbose, streams=args.streams)
     batch = models.load_data_to_gpu(batch)
     for r in range(args.repeat):
