@@ -129,6 +129,14 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
                               const float* bias, const float* scale, const float* shift, int relu,
                               float* out, pcs_stream_t stream);
 
+/* SparseConvTensor.dense() (pcdet/ops/spconv/structure.py:5-18,55-64) in its channels-first form, as
+ * HeightCompression consumes it (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27;
+ * SURVEY 8f row f3): features [V,C] at indices [V,4] (b,z,y,x) -> out [B,C,D,H,W] f32, zeros
+ * elsewhere ([B, C*D, H, W] when viewed). status: optional device int, set to 1 if an index lies
+ * outside the shape (that row is skipped). */
+int pcs_sparse_to_dense(const float* features, const int32_t* indices, int64_t V, int C, int B, int D,
+                        int H, int W, float* out, int* status, pcs_stream_t stream);
+
 /* ------------------------------------------------------------------ radius graph */
 
 /* RadiusGraph.build_graph, pcdet/models/model_utils/graph_utils.py:149-209 (hash_insert_gpu +

@@ -349,3 +349,39 @@ int pcs_indice_conv_f32(const float* features, int cin, const float* filters, in
 }
 
 }  // extern "C"
+
+// ---- SparseConvTensor.dense() + HeightCompression (pcdet/ops/spconv/structure.py:5-18,55-64;
+// pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27): features [V,C] at
+// indices [V,4] (b,z,y,x) -> channels-first dense [B,C,D,H,W] (== [B, C*D, H, W] viewed), zeros
+// elsewhere. The reference builds [B,D,H,W,C], permutes and copies; here one fill + one scatter.
+namespace pcs {
+__global__ void __launch_bounds__(kBlock)
+sparse_to_dense_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int64_t V, int C,
+                       int B, int D, int H, int W, float* __restrict__ out, int* __restrict__ status) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= V * C) return;
+  int64_t v = t / C;
+  int c = (int)(t - v * C);
+  int4 q = ((const int4*)idx)[v];
+  if (q.x < 0 || q.x >= B || q.y < 0 || q.y >= D || q.z < 0 || q.z >= H || q.w < 0 || q.w >= W) {
+    if (status) atomicExch(status, 1);
+    return;
+  }
+  out[((((int64_t)q.x * C + c) * D + q.y) * H + q.z) * W + q.w] = feat[t];
+}
+}  // namespace pcs
+
+extern "C" int pcs_sparse_to_dense(const float* features, const int32_t* indices, int64_t V, int C, int B,
+                                   int D, int H, int W, float* out, int* status, hipStream_t s) {
+  if (V < 0 || C < 1 || B < 1 || D < 1 || H < 1 || W < 1 || !out) return PCS_ERR_ARG;
+  if (V > 0 && (!features || !indices)) return PCS_ERR_ARG;
+  size_t bytes = (size_t)B * C * D * H * W * sizeof(float);
+  PCS_CHECK_HIP(hipMemsetAsync(out, 0, bytes, s));
+  if (status) PCS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
+  if (V == 0) return PCS_OK;
+  int64_t n = V * C;
+  pcs::sparse_to_dense_kernel<<<(unsigned)((n + pcs::kBlock - 1) / pcs::kBlock), pcs::kBlock, 0, s>>>(
+      features, indices, V, C, B, D, H, W, out, status);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}

@@ -172,6 +172,22 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
     return out_ids[:int(d_num.item())], pairs, num
 
 
+def sparse_to_dense(features, indices, batch_size, spatial_shape):
+    """SparseConvTensor.dense(channels_first=True): features [V,C] f32 at indices [V,4] int32
+    (b,z,y,x) -> [B,C,D,H,W] f32."""
+    L.require_gpu(features, "sparse_to_dense")
+    lib = L.load()
+    features = features.float().contiguous()
+    indices = indices.int().contiguous()
+    V, C = features.shape
+    D, H, W = (int(x) for x in spatial_shape)
+    out = torch.empty(int(batch_size), C, D, H, W, dtype=torch.float32, device=features.device)
+    L.check(lib.pcs_sparse_to_dense(L.ptr(features), L.ptr(indices), L.i64(V), L.i32(C), L.i32(int(batch_size)),
+                                    L.i32(D), L.i32(H), L.i32(W), L.ptr(out), L.ptr(None), L.stream()),
+            "pcs_sparse_to_dense")
+    return out
+
+
 def build_neighbor_table(pairs, num, num_out, inverse=False):
     lib = L.load()
     kv = pairs.shape[0]

@@ -1,6 +1,8 @@
 """post_act_block / SparseBasicBlock (pcdet/models/blocks/spconv_blocks.py:8-64)."""
+import torch
 import torch.nn as nn
 
+from ...ops.spconv.modules import fold_batchnorm
 from ...utils.spconv_utils import replace_feature, spconv
 
 
@@ -36,10 +38,16 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         identity = x.features
-        out = self.conv1(x)
-        out = replace_feature(out, self.relu(self.bn1(out.features)))
-        out = self.conv2(out)
-        out = replace_feature(out, self.bn2(out.features))
+        if (not self.training and x.features.is_cuda and not torch.is_grad_enabled()
+                and self.bn1.track_running_stats and self.bn2.track_running_stats):
+            # eval mode: both normalisations (and the first ReLU) ride in the conv epilogues
+            out = self.conv1(x, *fold_batchnorm(self.bn1), relu=True)
+            out = self.conv2(out, *fold_batchnorm(self.bn2), relu=False)
+        else:
+            out = self.conv1(x)
+            out = replace_feature(out, self.relu(self.bn1(out.features)))
+            out = self.conv2(out)
+            out = replace_feature(out, self.bn2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
         return replace_feature(out, self.relu(out.features + identity))

@@ -52,7 +52,9 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(_fan_in_hwio(self.weight))
             init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, input):
+    def forward(self, input, scale=None, shift=None, relu=False):
+        """`scale` / `shift` [Cout] and `relu`: an eval-mode BatchNorm (+ ReLU) folded into the conv
+        kernel's epilogue (out = relu((conv + bias) * scale + shift)), see SparseSequential."""
         assert isinstance(input, SparseConvTensor)
         features, indices = input.features, input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
@@ -68,6 +70,10 @@ class SparseConvolution(SparseModule):
             feats = torch.mm(features, self.weight.view(self.in_channels, self.out_channels))
             if self.bias is not None:
                 feats = feats + self.bias
+            if scale is not None:
+                feats = feats * scale + shift
+            if relu:
+                feats = torch.relu(feats)
             out = SparseConvTensor(feats, indices, spatial_shape, batch_size)
             out.indice_dict, out.grid = input.indice_dict, input.grid
             return out
@@ -91,7 +97,8 @@ class SparseConvolution(SparseModule):
         if table is None:
             table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0], self.inverse)
         out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
-                                              self.subm and not self.inverse, bias=self.bias)
+                                              self.subm and not self.inverse, bias=self.bias, scale=scale,
+                                              shift=shift, relu=relu)
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

@@ -47,13 +47,46 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
+                # eval mode: conv -> BatchNorm1d [-> ReLU] runs as ONE kernel, the normalisation folded
+                # into the conv epilogue (fused_spconv_ops.h:29-132 is the reference's own fused form)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if (not self.training and hasattr(module, "weight") and hasattr(module, "inverse")
+                        and isinstance(nxt, nn.BatchNorm1d) and nxt.track_running_stats
+                        and input.features.is_cuda and not torch.is_grad_enabled()):
+                    scale, shift = fold_batchnorm(nxt)
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    input = module(input, scale=scale, shift=shift, relu=relu)
+                    i += 3 if relu else 2
+                    continue
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     input.features = module(input.features)
             else:
                 input = module(input)
+            i += 1
         return input
+
+
+def fold_batchnorm(bn):
+    """Eval-mode BatchNorm1d as y = x * scale + shift, cached on the module until a parameter or
+    running statistic changes."""
+    key = tuple(t._version if t is not None else -1 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cached = getattr(bn, "_pcs_folded", None)
+    if cached is not None and cached[0] == key and cached[1].device == bn.running_mean.device:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+        scale = inv * bn.weight.float() if bn.weight is not None else inv
+        shift = -bn.running_mean.float() * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias.float()
+        scale, shift = scale.contiguous(), shift.contiguous()
+    bn._pcs_folded = (key, scale, shift)
+    return scale, shift

@@ -27,6 +27,11 @@ class SparseConvTensor(object):
         return self
 
     def dense(self, channels_first=True):
+        if (channels_first and self.features.is_cuda and len(self.spatial_shape) == 3
+                and self.features.dtype == torch.float32 and not self.features.requires_grad):
+            # one fill + one scatter straight into [B,C,D,H,W] (pcs_sparse_to_dense)
+            from .... import ops as _ops
+            return _ops.sparse_to_dense(self.features, self.indices, self.batch_size, self.spatial_shape)
         shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
         out = torch.zeros(*shape, dtype=self.features.dtype, device=self.features.device)
         idx = self.indices.long()

@@ -1,0 +1,139 @@
+"""VoxelResBackBone8x (residual blocks on the HIP sparse conv, eval-mode
+BatchNorm / ReLU folded into the conv epilogues) against a layer-by-layer oracle chain, and
+HeightCompression / SparseConvTensor.dense() (pcs_sparse_to_dense) against the reference's
+scatter_nd + permute."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pcseqlearning_amd import ops, synthetic  # noqa: E402
+from pcseqlearning_amd.pcdet.models.backbones_2d import HeightCompression  # noqa: E402
+from pcseqlearning_amd.pcdet.models.backbones_3d import VoxelBackBone8x, VoxelResBackBone8x  # noqa: E402
+from pcseqlearning_amd.pcdet.models.backbones_3d.vfe import DynamicMeanVFE  # noqa: E402
+from pcseqlearning_amd.pcdet.ops.spconv.structure import SparseConvTensor  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bn_np(x, bn):
+    w, b = bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()
+    m, v = bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy()
+    return ((x - m) / np.sqrt(v + bn.eps) * w + b).astype(np.float32)
+
+
+def randomise_bn(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+
+
+def test_voxel_res_backbone_8x_vs_oracle(oracle):
+    torch.manual_seed(1)
+    pts = synthetic.gen_voxel_frame(3, 30000)
+    vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
+    net = VoxelResBackBone8x({}, 5, synthetic.GRID_SIZE.tolist()).to(DEV).eval()
+    randomise_bn(net)
+    batch = vfe({"points": dev(pts), "batch_size": 1})
+    with torch.no_grad():
+        out = net(batch)
+    feat, coords, _ = oracle.dynamic_voxelize(pts, synthetic.PC_RANGE, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE)
+    cache = {}
+    k3, s1, s2, p1 = [3, 3, 3], [1, 1, 1], [2, 2, 2], [1, 1, 1]
+
+    def conv(convm, x, idx, shape, ks, st, pd, subm, key):
+        if key in cache:
+            out_idx, pairs, num, oshape = cache[key]
+        else:
+            oshape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+            out_idx, pairs, num = oracle.get_indice_pairs(idx, oshape, ks, st, pd, [1, 1, 1], subm)
+            cache[key] = (out_idx, pairs, num, oshape)
+        y = oracle.indice_conv(x, convm.weight.detach().cpu().numpy(), pairs, num, out_idx.shape[0], False, subm)
+        return y, out_idx, oshape
+
+    def basic_block(blk, x, idx, shape, key):
+        y, _, _ = conv(blk.conv1, x, idx, shape, k3, s1, p1, True, key)
+        y = np.maximum(bn_np(y, blk.bn1), 0)
+        y, _, _ = conv(blk.conv2, y, idx, shape, k3, s1, p1, True, key)
+        y = bn_np(y, blk.bn2)
+        return np.maximum(y + x, 0).astype(np.float32)
+
+    x, idx, shape = feat, coords, [41, 1504, 1504]
+    y, idx, shape = conv(net.conv_input[0], x, idx, shape, k3, s1, p1, True, "res1")
+    x = np.maximum(bn_np(y, net.conv_input[1]), 0)
+    x = basic_block(net.conv1[0], x, idx, shape, "res1")
+    x = basic_block(net.conv1[1], x, idx, shape, "res1")
+    stages = {"x_conv1": (x, idx)}
+    for name, stage, pad, key in (("x_conv2", net.conv2, p1, "res2"), ("x_conv3", net.conv3, p1, "res3"),
+                                  ("x_conv4", net.conv4, [0, 1, 1], "res4")):
+        y, idx, shape = conv(stage[0][0], x, idx, shape, k3, s2, pad, False, name + "_down")
+        x = np.maximum(bn_np(y, stage[0][1]), 0)
+        x = basic_block(stage[1], x, idx, shape, key)
+        x = basic_block(stage[2], x, idx, shape, key)
+        stages[name] = (x, idx)
+    y, idx, shape = conv(net.conv_out[0], x, idx, shape, [3, 1, 1], [2, 1, 1], [0, 0, 0], False, "down2")
+    x = np.maximum(bn_np(y, net.conv_out[1]), 0)
+    for name, (ox, oidx) in stages.items():
+        t = out["multi_scale_3d_features"][name]
+        np.testing.assert_array_equal(t.indices.cpu().numpy(), oidx)
+        np.testing.assert_allclose(t.features.cpu().numpy(), ox, rtol=2e-4, atol=2e-4)
+    enc = out["encoded_spconv_tensor"]
+    assert enc.spatial_shape == [2, 188, 188] and shape == [2, 188, 188]
+    np.testing.assert_array_equal(enc.indices.cpu().numpy(), idx)
+    np.testing.assert_allclose(enc.features.cpu().numpy(), x, rtol=2e-4, atol=2e-4)
+    assert out["multi_scale_3d_strides"] == {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
+
+    # ---- HeightCompression on the encoded tensor: scatter_nd + permute + view of the reference
+    hc = HeightCompression({"NUM_BEV_FEATURES": 256})
+    with torch.no_grad():
+        bev = hc(dict(out))["spatial_features"]
+    assert tuple(bev.shape) == (1, 128 * 2, 188, 188) and hc.num_bev_features == 256
+    want = np.zeros((1, 2, 188, 188, 128), dtype=np.float32)
+    ii = enc.indices.cpu().numpy()
+    want[ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]] = enc.features.cpu().numpy()
+    want = want.transpose(0, 4, 1, 2, 3).reshape(1, 256, 188, 188)
+    np.testing.assert_array_equal(bev.cpu().numpy(), want)
+
+
+def test_folded_batchnorm_matches_module_by_module():
+    """The conv epilogue form (eval mode, no_grad) against the same network run module by module
+    (train-mode graph walk with frozen statistics is not the same thing: use grad-enabled eval)."""
+    torch.manual_seed(2)
+    pts = synthetic.gen_voxel_frame(4, 20000)
+    vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
+    for cls in (VoxelBackBone8x, VoxelResBackBone8x):
+        net = cls({}, 5, synthetic.GRID_SIZE.tolist()).to(DEV).eval()
+        randomise_bn(net)
+        batch = vfe({"points": dev(pts), "batch_size": 1})
+        with torch.no_grad():
+            fused = net(dict(batch))["encoded_spconv_tensor"]
+        with torch.enable_grad():  # the fusion is gated on no_grad: this walks conv, bn, relu separately
+            plain = net(dict(batch))["encoded_spconv_tensor"]
+        assert torch.equal(fused.indices, plain.indices)
+        np.testing.assert_allclose(fused.features.cpu().numpy(), plain.features.detach().cpu().numpy(),
+                                   rtol=1e-4, atol=1e-4)
+
+
+def test_sparse_to_dense_vs_scatter():
+    rng = np.random.default_rng(0)
+    B, D, H, W, C = 2, 3, 17, 23, 20
+    lin = rng.choice(B * D * H * W, 900, replace=False)
+    idx = np.stack(np.unravel_index(lin, (B, D, H, W)), axis=1).astype(np.int32)
+    feat = rng.normal(size=(900, C)).astype(np.float32)
+    got = ops.sparse_to_dense(dev(feat), dev(idx), B, [D, H, W]).cpu().numpy()
+    want = np.zeros((B, D, H, W, C), dtype=np.float32)
+    want[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = feat
+    np.testing.assert_array_equal(got, want.transpose(0, 4, 1, 2, 3))
+    t = SparseConvTensor(dev(feat), dev(idx), [D, H, W], B)
+    np.testing.assert_array_equal(t.dense().cpu().numpy(), want.transpose(0, 4, 1, 2, 3))
+    np.testing.assert_array_equal(t.dense(channels_first=False).cpu().numpy(), want)
+    empty = ops.sparse_to_dense(torch.empty(0, C, device=DEV), torch.empty(0, 4, dtype=torch.int32, device=DEV), 1, [D, H, W])
+    assert tuple(empty.shape) == (1, C, D, H, W) and float(empty.abs().sum()) == 0.0
