@@ -137,3 +137,59 @@ def test_sparse_to_dense_vs_scatter():
     np.testing.assert_array_equal(t.dense(channels_first=False).cpu().numpy(), want)
     empty = ops.sparse_to_dense(torch.empty(0, C, device=DEV), torch.empty(0, 4, dtype=torch.int32, device=DEV), 1, [D, H, W])
     assert tuple(empty.shape) == (1, C, D, H, W) and float(empty.abs().sum()) == 0.0
+
+
+def test_unet_up_block_modules_vs_oracle(oracle):
+    """The decoder step of the reference's sparse UNet (spconv_unet.py:164-189: lateral
+    SparseBasicBlock, concat with the bottom features, subM conv, channel reduction, inverse conv on
+    the strided conv's rulebook) built from the mirrored modules, against an oracle chain. (UNetV2
+    itself cannot be imported in the reference: its `post_processors` package is not in the tree.)"""
+    from functools import partial
+    from pcseqlearning_amd.pcdet.models.blocks import SparseBasicBlock, post_act_block
+    from pcseqlearning_amd.pcdet.utils.spconv_utils import replace_feature, spconv
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    shape = [9, 40, 40]
+    lin = rng.choice(int(np.prod(shape)), 1500, replace=False)
+    idx = np.concatenate([np.zeros((1500, 1), np.int64), np.stack(np.unravel_index(lin, shape), 1)], 1).astype(np.int32)
+    idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    feat = rng.normal(size=(1500, 8)).astype(np.float32)
+    norm_fn = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    down = post_act_block(8, 16, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv2", conv_type="spconv").to(DEV).eval()
+    conv_t = SparseBasicBlock(16, 16, indice_key="subm2", norm_fn=norm_fn).to(DEV).eval()
+    conv_m = post_act_block(32, 16, 3, norm_fn=norm_fn, padding=1, indice_key="subm2").to(DEV).eval()
+    conv_inv = post_act_block(16, 8, 3, norm_fn=norm_fn, indice_key="spconv2", conv_type="inverseconv").to(DEV).eval()
+    for m in (down, conv_t, conv_m, conv_inv):
+        randomise_bn(m)
+    with torch.no_grad():
+        x0 = spconv.SparseConvTensor(dev(feat), dev(idx), shape, 1)
+        x_lat = down(x0)
+        x_trans = conv_t(x_lat)
+        x = replace_feature(x_trans, torch.cat((x_lat.features, x_trans.features), dim=1))
+        x_m = conv_m(x)
+        red = x.features.view(x.features.shape[0], x_m.features.shape[1], -1).sum(dim=2)
+        x = replace_feature(x, x_m.features + red)
+        up = conv_inv(x)
+    # oracle chain
+    k3, p1 = [3, 3, 3], [1, 1, 1]
+    oshape = oracle.conv_out_shape(shape, k3, [2, 2, 2], p1, [1, 1, 1])
+    d_idx, d_pairs, d_num = oracle.get_indice_pairs(idx, oshape, k3, [2, 2, 2], p1, [1, 1, 1], False)
+    lat = np.maximum(bn_np(oracle.indice_conv(feat, down[0].weight.detach().cpu().numpy(), d_pairs, d_num,
+                                              d_idx.shape[0], False, False), down[1]), 0)
+    _, s_pairs, s_num = oracle.get_indice_pairs(d_idx, oshape, k3, [1, 1, 1], p1, [1, 1, 1], True)
+    n2 = d_idx.shape[0]
+
+    def subm(convm, v):
+        return oracle.indice_conv(v, convm.weight.detach().cpu().numpy(), s_pairs, s_num, n2, False, True)
+
+    t = np.maximum(bn_np(subm(conv_t.conv1, lat), conv_t.bn1), 0)
+    t = np.maximum(bn_np(subm(conv_t.conv2, t), conv_t.bn2) + lat, 0)
+    cat = np.concatenate([lat, t], axis=1)
+    m = np.maximum(bn_np(subm(conv_m[0], cat), conv_m[1]), 0)
+    mixed = (m + cat.reshape(n2, 16, -1).sum(axis=2)).astype(np.float32)
+    inv = oracle.indice_conv(mixed, conv_inv[0].weight.detach().cpu().numpy(), d_pairs, d_num, idx.shape[0], True, False)
+    want = np.maximum(bn_np(inv, conv_inv[1]), 0)
+    np.testing.assert_array_equal(x_lat.indices.cpu().numpy(), d_idx)
+    np.testing.assert_array_equal(up.indices.cpu().numpy(), idx)   # back on the input's voxels
+    assert up.spatial_shape == shape
+    np.testing.assert_allclose(up.features.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
