@@ -129,6 +129,19 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
                               const float* bias, const float* scale, const float* shift, int relu,
                               float* out, pcs_stream_t stream);
 
+/* sparse_conv_ext.indice_conv_backward_fp32 (src/all.cc:34-37; indiceConvBackward,
+ * include/spconv/spconv_ops.h:363-449): features [num_in,cin], filters [kv,cin,cout],
+ * out_grad [num_out,cout], the forward call's rulebook (pairs [kv,2,pair_stride], num [kv]) and its
+ * inverse / subm flags -> in_grad [num_in,cin], filters_grad [kv,cin,cout]. Deterministic (no atomics:
+ * the input gradient is a conv over the transposed rulebook, the filter gradient a two-stage sum). */
+size_t pcs_indice_conv_backward_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin,
+                                                int cout);
+int pcs_indice_conv_backward_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                                 const float* out_grad, const int32_t* pairs, int64_t pair_stride,
+                                 const int32_t* num, int64_t num_in, int64_t num_out, int inverse,
+                                 int subm, float* in_grad, float* filters_grad, void* ws,
+                                 size_t ws_bytes, pcs_stream_t stream);
+
 /* SparseConvTensor.dense() (pcdet/ops/spconv/structure.py:5-18,55-64) in its channels-first form, as
  * HeightCompression consumes it (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27;
  * SURVEY 8f row f3): features [V,C] at indices [V,4] (b,z,y,x) -> out [B,C,D,H,W] f32, zeros

@@ -148,6 +148,36 @@ def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=Fals
     return out
 
 
+def indice_conv_backward(features, filters, out_grad, pairs, num, inverse=False, subm=False):
+    """indiceConvBackward (pcdet/ops/spconv/include/spconv/spconv_ops.h:363-449): per kernel offset,
+    filters_grad[k] = gathered_in^T @ gathered_out_grad and in_grad[i] += out_grad[o] @ W[k]^T over
+    the rulebook pairs; for subM the centre offset (the one with the most pairs) is the plain
+    product over all rows. Returns (input_grad [Nin,Cin], filters_grad like filters). Pinned by
+    torch's dense conv3d autograd (tests/test_oracle_pinning.py)."""
+    feat = _c(features, np.float32)
+    og = _c(out_grad, np.float32)
+    kv = pairs.shape[0]
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    W = _c(filters, np.float32).reshape(kv, cin, cout)
+    in_grad = np.zeros_like(feat)
+    w_grad = np.zeros_like(W)
+    num = np.asarray(num)
+    centre = int(np.argmax(num)) if subm else -1
+    if subm:
+        w_grad[centre] = feat.T @ og
+        in_grad += og @ W[centre].T
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(kv):
+        n = int(num[k])
+        if n <= 0 or k == centre:
+            continue
+        i_in, i_out = pairs[k, a, :n], pairs[k, b, :n]
+        gi, go = feat[i_in], og[i_out]
+        w_grad[k] = gi.T @ go
+        np.add.at(in_grad, i_in, go @ W[k].T)
+    return in_grad, w_grad.reshape(filters.shape)
+
+
 def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, qmin=(0, -1, -1, -1),
                  qmax=(0, 1, 1, 1), want_dists=False):
     """RadiusGraph.build_graph: returns (e_ref, e_query) int64 (and squared dists)."""

@@ -350,6 +350,150 @@ int pcs_indice_conv_f32(const float* features, int cin, const float* filters, in
 
 }  // extern "C"
 
+// ---- indiceConvBackward (spconv_ops.h:363-449) --------------------------------
+// input gradient: the same output-stationary conv, run over the TRANSPOSED rulebook (feature-row
+// major table of out_grad rows) with W[k]^T -- no scatter-add, no atomics. filter gradient: per
+// offset k, dW[k] = sum over pairs of in[i]^T (x) out_grad[o]; the pairs of an offset are cut into
+// chunks of kGradChunk, one workgroup per (chunk, k, 32x32 tile) accumulates its outer products in
+// registers and stores a partial; a second kernel adds the partials in ascending chunk order, so
+// the result does not depend on scheduling (the reference: one cuBLAS GEMM per offset).
+namespace pcs {
+constexpr int kGradChunk = 1024;
+constexpr int kGT = 32;  // tile edge (input channels x output channels)
+
+__global__ void __launch_bounds__(kBlock)
+transpose_filters_kernel(const float* __restrict__ W, int kv, int cin, int cout, float* __restrict__ Wt) {
+  int64_t total = (int64_t)kv * cin * cout;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = t / ((int64_t)cin * cout);
+    int r = (int)(t - k * cin * cout);
+    int ci = r / cout, co = r - ci * cout;
+    Wt[(k * cout + co) * cin + ci] = W[t];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+filter_grad_partial_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ og, int cout,
+                           const int32_t* __restrict__ pairs, int64_t pair_stride,
+                           const int32_t* __restrict__ num, int side_in, int tiles_j,
+                           float* __restrict__ partial, int kv) {
+  const int chunk = blockIdx.x, k = blockIdx.y;
+  const int ti0 = (blockIdx.z / tiles_j) * kGT, tj0 = (blockIdx.z % tiles_j) * kGT;
+  const int n = num[k];
+  const int p0 = chunk * kGradChunk;
+  if (p0 >= n) return;
+  const int p1 = min(n, p0 + kGradChunk);
+  const int32_t* pin = pairs + ((int64_t)k * 2 + side_in) * pair_stride;
+  const int32_t* pout = pairs + ((int64_t)k * 2 + (1 - side_in)) * pair_stride;
+  __shared__ float s_in[kGT][kGT + 1];
+  __shared__ float s_og[kGT][kGT + 1];
+  // thread (ty, tx) owns dW[ti0 + 2 ty + {0,1}][tj0 + 2 tx + {0,1}]
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+  for (int pb = p0; pb < p1; pb += kGT) {
+    // stage 32 pairs x 32 channels of both sides (zero beyond the ranges)
+    for (int q = threadIdx.x; q < kGT * kGT; q += kBlock) {
+      int pr = q >> 5, c = q & 31;
+      int p = pb + pr;
+      float vi = 0.f, vo = 0.f;
+      if (p < p1) {
+        int i = pin[p], o = pout[p];
+        if (ti0 + c < cin) vi = feat[(int64_t)i * cin + ti0 + c];
+        if (tj0 + c < cout) vo = og[(int64_t)o * cout + tj0 + c];
+      }
+      s_in[pr][c] = vi;
+      s_og[pr][c] = vo;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int pr = 0; pr < kGT; ++pr) {
+      float i0 = s_in[pr][2 * ty], i1 = s_in[pr][2 * ty + 1];
+      float o0 = s_og[pr][2 * tx], o1 = s_og[pr][2 * tx + 1];
+      a00 = fmaf(i0, o0, a00); a01 = fmaf(i0, o1, a01);
+      a10 = fmaf(i1, o0, a10); a11 = fmaf(i1, o1, a11);
+    }
+    __syncthreads();
+  }
+  float* dst = partial + ((int64_t)chunk * kv + k) * cin * cout;
+  int ci = ti0 + 2 * ty, cj = tj0 + 2 * tx;
+  if (ci < cin && cj < cout) dst[(int64_t)ci * cout + cj] = a00;
+  if (ci < cin && cj + 1 < cout) dst[(int64_t)ci * cout + cj + 1] = a01;
+  if (ci + 1 < cin && cj < cout) dst[(int64_t)(ci + 1) * cout + cj] = a10;
+  if (ci + 1 < cin && cj + 1 < cout) dst[(int64_t)(ci + 1) * cout + cj + 1] = a11;
+}
+
+__global__ void __launch_bounds__(kBlock)
+filter_grad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ num, int kv,
+                          int cin, int cout, float* __restrict__ dW) {
+  int64_t per = (int64_t)cin * cout;
+  int64_t total = (int64_t)kv * per;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int k = (int)(t / per);
+    int64_t r = t - (int64_t)k * per;
+    int chunks = (num[k] + kGradChunk - 1) / kGradChunk;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc = acc + partial[((int64_t)c * kv + k) * per + r];
+    dW[t] = acc;
+  }
+}
+}  // namespace pcs
+
+extern "C" size_t pcs_indice_conv_backward_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv,
+                                                           int cin, int cout) {
+  if (num_in < 1) num_in = 1;
+  if (pair_stride < 1) pair_stride = 1;
+  int64_t chunks = (pair_stride + pcs::kGradChunk - 1) / pcs::kGradChunk;
+  size_t b = pcs::align_up((size_t)num_in * kv * sizeof(int32_t));
+  b += pcs::align_up((size_t)kv * cin * cout * sizeof(float));
+  b += pcs::align_up((size_t)chunks * kv * cin * cout * sizeof(float));
+  return b;
+}
+
+extern "C" int pcs_indice_conv_backward_f32(const float* features, int cin, const float* filters, int kv,
+                                            int cout, const float* out_grad, const int32_t* pairs,
+                                            int64_t pair_stride, const int32_t* num, int64_t num_in,
+                                            int64_t num_out, int inverse, int subm, float* in_grad,
+                                            float* filters_grad, void* ws, size_t ws_bytes, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !filters || !out_grad || !pairs || !num || !in_grad || !filters_grad || cin < 1 ||
+      cout < 1 || kv < 1 || num_in < 0 || num_out < 0 || pair_stride < 0)
+    return PCS_ERR_ARG;
+  if (!ws || ws_bytes < pcs_indice_conv_backward_workspace_bytes(num_in, pair_stride, kv, cin, cout))
+    return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemsetAsync(filters_grad, 0, (size_t)kv * cin * cout * sizeof(float), s));
+  if (num_in == 0) return PCS_OK;
+  if (num_out == 0 || pair_stride == 0) {
+    PCS_CHECK_HIP(hipMemsetAsync(in_grad, 0, (size_t)num_in * cin * sizeof(float), s));
+    return PCS_OK;
+  }
+  char* w = (char*)ws;
+  int32_t* table_t = (int32_t*)w;
+  w += align_up((size_t)num_in * kv * sizeof(int32_t));
+  float* Wt = (float*)w;
+  w += align_up((size_t)kv * cin * cout * sizeof(float));
+  float* partial = (float*)w;
+  // ---- input gradient: in_grad[i] = sum_k out_grad[T'[i][k]] . W[k]^T
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, inverse ? 0 : 1, num_in, table_t, s);
+  if (rc) return rc;
+  transpose_filters_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>(filters, kv, cin, cout, Wt);
+  int centre = (subm && (kv & 1)) ? kv / 2 : -1;
+  rc = pcs_indice_conv_table_f32(out_grad, cout, Wt, kv, cin, centre, table_t, num_in, nullptr, nullptr,
+                                 nullptr, 0, in_grad, s);
+  if (rc) return rc;
+  // ---- filter gradient
+  int64_t chunks = (pair_stride + kGradChunk - 1) / kGradChunk;
+  int tiles_i = (cin + kGT - 1) / kGT, tiles_j = (cout + kGT - 1) / kGT;
+  if (chunks >= 65536 || kv >= 65536) return PCS_ERR_RANGE;
+  filter_grad_partial_kernel<<<dim3((unsigned)chunks, kv, tiles_i * tiles_j), kBlock, 0, s>>>(
+      features, cin, out_grad, cout, pairs, pair_stride, num, inverse ? 1 : 0, tiles_j, partial, kv);
+  filter_grad_reduce_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>(partial, num, kv, cin,
+                                                                                 cout, filters_grad);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 // ---- SparseConvTensor.dense() + HeightCompression (pcdet/ops/spconv/structure.py:5-18,55-64;
 // pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27): features [V,C] at
 // indices [V,4] (b,z,y,x) -> channels-first dense [B,C,D,H,W] (== [B, C*D, H, W] viewed), zeros

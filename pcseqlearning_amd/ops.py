@@ -172,6 +172,31 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
     return out_ids[:int(d_num.item())], pairs, num
 
 
+def indice_conv_backward(features, filters, out_bp, pairs, num, inverse=False, subm=False):
+    """sparse_conv_ext.indice_conv_backward_fp32 (spconv_ops.h:363-449): returns (input_bp like
+    features, filters_bp like filters)."""
+    L.require_gpu(features, "indice_conv_backward")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = pairs.shape[0]
+    W = filters.detach().reshape(kv, cin, cout).float().contiguous()
+    features = features.detach().float().contiguous()
+    out_bp = out_bp.detach().float().contiguous()
+    pairs = pairs.contiguous()
+    num_in, num_out, stride = features.shape[0], out_bp.shape[0], pairs.shape[2]
+    in_bp = torch.empty_like(features)
+    w_bp = torch.empty(kv, cin, cout, dtype=torch.float32, device=features.device)
+    ws = L.workspace(lib.pcs_indice_conv_backward_workspace_bytes(L.i64(num_in), L.i64(stride), L.i32(kv),
+                                                                  L.i32(cin), L.i32(cout)), features.device)
+    L.check(lib.pcs_indice_conv_backward_f32(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                             L.ptr(out_bp), L.ptr(pairs), L.i64(stride), L.ptr(num),
+                                             L.i64(num_in), L.i64(num_out), L.i32(int(inverse)),
+                                             L.i32(int(subm)), L.ptr(in_bp), L.ptr(w_bp), L.ptr(ws),
+                                             L.i64(ws.numel()), L.stream()),
+            "pcs_indice_conv_backward_f32")
+    return in_bp, w_bp.reshape(filters.shape)
+
+
 def sparse_to_dense(features, indices, batch_size, spatial_shape):
     """SparseConvTensor.dense(channels_first=True): features [V,C] f32 at indices [V,4] int32
     (b,z,y,x) -> [B,C,D,H,W] f32."""

@@ -11,6 +11,7 @@ from torch.nn import init
 from torch.nn.parameter import Parameter
 
 from .... import ops as _ops
+from . import functional as Fsp
 from . import ops
 from .modules import SparseModule
 from .structure import SparseConvTensor
@@ -96,9 +97,22 @@ class SparseConvolution(SparseModule):
                                                   spatial_shape, table)
         if table is None:
             table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0], self.inverse)
-        out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
-                                              self.subm and not self.inverse, bias=self.bias, scale=scale,
-                                              shift=shift, relu=relu)
+        if torch.is_grad_enabled() and (features.requires_grad or self.weight.requires_grad):
+            # differentiable path (functional.py): the conv through its autograd function, bias and
+            # any epilogue as ordinary tensor ops
+            fn = (Fsp.indice_inverse_conv if self.inverse else
+                  Fsp.indice_subm_conv if self.subm else Fsp.indice_conv)
+            out_features = fn(features, self.weight, indice_pairs, indice_pair_num, outids.shape[0], table)
+            if self.bias is not None:
+                out_features = out_features + self.bias
+            if scale is not None:
+                out_features = out_features * scale + shift
+            if relu:
+                out_features = torch.relu(out_features)
+        else:
+            out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
+                                                  self.subm and not self.inverse, bias=self.bias, scale=scale,
+                                                  shift=shift, relu=relu)
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

@@ -46,3 +46,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
                 subm=False):
     return _ops.indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
                             inverse, subm)
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    return _ops.indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse, subm)

@@ -169,3 +169,65 @@ def test_empty_inputs():
     out_ids, pairs, num = ops.get_indice_pairs(idx, 1, [5, 5, 5], [5, 5, 5], [3, 3, 3], [1, 1, 1],
                                                [1, 1, 1], [1, 1, 1], True)
     assert pairs.shape == (27, 2, 0) and int(num.sum()) == 0
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (32, 64), (64, 128), (128, 128), (7, 9)])
+def test_conv_backward_vs_oracle(oracle, cin, cout):
+    """pcs_indice_conv_backward_f32 against the oracle (itself pinned to torch's
+    dense conv3d autograd, tests/test_oracle_pinning.py) for subM, strided and inverse convs."""
+    rng = np.random.default_rng(cin * 17 + cout)
+    gs = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_subm3.npz"))
+    gc = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_spconv_s2p1.npz"))
+    cases = [(gs["pairs"], gs["num"], gs["indices"].shape[0], gs["indices"].shape[0], False, True),
+             (gc["pairs"], gc["num"], gc["indices"].shape[0], gc["out_ids"].shape[0], False, False),
+             (gc["pairs"], gc["num"], gc["out_ids"].shape[0], gc["indices"].shape[0], True, False)]
+    for pairs, num, n_in, n_out, inverse, subm in cases:
+        feat = rng.normal(0, 1, (n_in, cin)).astype(np.float32)
+        W = rng.normal(0, 0.05, (3, 3, 3, cin, cout)).astype(np.float32)
+        og = rng.normal(0, 1, (n_out, cout)).astype(np.float32)
+        ib, wb = ops.indice_conv_backward(dev(feat), dev(W), dev(og), dev(pairs), dev(num), inverse, subm)
+        ref_i, ref_w = oracle.indice_conv_backward(feat, W, og, pairs, num, inverse, subm)
+        np.testing.assert_allclose(ib.cpu().numpy(), ref_i, rtol=1e-4, atol=1e-4)
+        # filter gradient sums thousands of products per entry: tolerance relative to its scale
+        tol = 2e-5 * max(1.0, float(np.abs(ref_w).max())) * 10
+        np.testing.assert_allclose(wb.cpu().numpy(), ref_w, rtol=1e-4, atol=tol)
+        ib2, wb2 = ops.indice_conv_backward(dev(feat), dev(W), dev(og), dev(pairs), dev(num), inverse, subm)
+        assert torch.equal(ib, ib2) and torch.equal(wb, wb2)  # no atomics: reproducible
+
+
+def test_conv_modules_autograd_vs_oracle(oracle):
+    """loss.backward() through SubMConv3d -> SparseConv3d -> SparseInverseConv3d (functional.py):
+    parameter and input gradients against the oracle chain."""
+    from pcseqlearning_amd.pcdet.ops import spconv
+    torch.manual_seed(0)
+    rng = np.random.default_rng(2)
+    shape = [8, 30, 30]
+    lin = rng.choice(int(np.prod(shape)), 900, replace=False)
+    idx = np.concatenate([np.zeros((900, 1), np.int64), np.stack(np.unravel_index(lin, shape), 1)], 1).astype(np.int32)
+    feat = rng.normal(size=(900, 6)).astype(np.float32)
+    c1 = spconv.SubMConv3d(6, 16, 3, padding=1, bias=True, indice_key="s1").to(DEV)
+    c2 = spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="d2").to(DEV)
+    c3 = spconv.SparseInverseConv3d(32, 8, 3, indice_key="d2", bias=False).to(DEV)
+    x = dev(feat).requires_grad_(True)
+    t = spconv.SparseConvTensor(x, dev(idx), shape, 1)
+    y = c3(c2(c1(t)))
+    G = rng.normal(size=tuple(y.features.shape)).astype(np.float32)
+    (y.features * dev(G)).sum().backward()
+    # oracle chain
+    k3, p1 = [3, 3, 3], [1, 1, 1]
+    _, sp, sn = oracle.get_indice_pairs(idx, shape, k3, [1, 1, 1], p1, [1, 1, 1], True)
+    oshape = oracle.conv_out_shape(shape, k3, [2, 2, 2], p1, [1, 1, 1])
+    didx, dp, dn = oracle.get_indice_pairs(idx, oshape, k3, [2, 2, 2], p1, [1, 1, 1], False)
+    W1, b1 = c1.weight.detach().cpu().numpy(), c1.bias.detach().cpu().numpy()
+    W2, W3 = c2.weight.detach().cpu().numpy(), c3.weight.detach().cpu().numpy()
+    h1 = oracle.indice_conv(feat, W1, sp, sn, 900, False, True) + b1
+    h2 = oracle.indice_conv(h1, W2, dp, dn, didx.shape[0], False, False)
+    h3 = oracle.indice_conv(h2, W3, dp, dn, 900, True, False)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), h3, rtol=1e-4, atol=1e-4)
+    g2, gW3 = oracle.indice_conv_backward(h2, W3, G, dp, dn, True, False)
+    g1, gW2 = oracle.indice_conv_backward(h1, W2, g2, dp, dn, False, False)
+    g0, gW1 = oracle.indice_conv_backward(feat, W1, g1, sp, sn, False, True)
+    for got, want in ((c3.weight.grad, gW3), (c2.weight.grad, gW2), (c1.weight.grad, gW1), (x.grad, g0),
+                      (c1.bias.grad, g1.sum(0))):
+        want = np.asarray(want)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(want).max())))

@@ -111,3 +111,50 @@ def test_grid_sampling_properties(oracle):
     # sorted: voxel rank increases with id
     ids, _ = oracle.grid_cluster_ids(pts, size, 0.5)
     assert (np.diff(ids[order]) >= 0).all()
+
+
+@pytest.mark.parametrize("subm,stride,pad", [(True, 1, 1), (False, 2, 1), (False, 1, 0)])
+def test_sparse_conv_forward_backward_vs_dense_autograd(oracle, subm, stride, pad):
+    """The oracle's indice_conv / indice_conv_backward (spconv_ops.h:260-449) against torch's dense
+    conv3d and its autograd: a sparse conv without bias is the dense conv of the zero-filled grid
+    read at the output sites, and gradients flow only between active sites."""
+    import torch
+    rng = np.random.default_rng(4)
+    shape, cin, cout = [6, 9, 10], 5, 7
+    lin = rng.choice(int(np.prod(shape)), 120, replace=False)
+    idx = np.concatenate([np.zeros((120, 1), np.int64), np.stack(np.unravel_index(lin, shape), 1)], 1).astype(np.int32)
+    feat = rng.normal(size=(120, cin)).astype(np.float32)
+    W = rng.normal(size=(3, 3, 3, cin, cout)).astype(np.float32)
+    ks, st, pd = [3] * 3, [stride] * 3, [pad] * 3
+    oshape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+    out_idx, pairs, num = oracle.get_indice_pairs(idx, oshape, ks, st, pd, [1, 1, 1], subm)
+    out = oracle.indice_conv(feat, W, pairs, num, out_idx.shape[0], False, subm)
+    og = rng.normal(size=out.shape).astype(np.float32)
+    in_grad, w_grad = oracle.indice_conv_backward(feat, W, og, pairs, num, False, subm)
+    # dense twin in f64
+    dense = torch.zeros(1, cin, *shape, dtype=torch.float64)
+    dense[0, :, idx[:, 1], idx[:, 2], idx[:, 3]] = torch.from_numpy(feat.T.astype(np.float64))
+    dense.requires_grad_(True)
+    Wt = torch.from_numpy(W.astype(np.float64)).permute(4, 3, 0, 1, 2).contiguous().requires_grad_(True)
+    y = torch.nn.functional.conv3d(dense, Wt, stride=stride, padding=pad)
+    assert list(y.shape[2:]) == list(oshape)
+    o = out_idx.astype(np.int64)
+    y_sites = y[0, :, o[:, 1], o[:, 2], o[:, 3]].T
+    np.testing.assert_allclose(out, y_sites.detach().numpy(), rtol=1e-4, atol=1e-4)
+    (y_sites * torch.from_numpy(og.astype(np.float64))).sum().backward()
+    want_in = dense.grad[0, :, idx[:, 1], idx[:, 2], idx[:, 3]].T.numpy()
+    want_w = Wt.grad.permute(2, 3, 4, 1, 0).numpy()
+    np.testing.assert_allclose(in_grad, want_in, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(w_grad, want_w, rtol=1e-4, atol=1e-4)
+    # inverse conv (outputs -> inputs over the same rulebook) is the adjoint gather / scatter
+    x2 = rng.normal(size=(out_idx.shape[0], cout)).astype(np.float32)
+    W2 = rng.normal(size=(3, 3, 3, cout, cin)).astype(np.float32)
+    y2 = oracle.indice_conv(x2, W2, pairs, num, idx.shape[0], True, False)
+    g2 = rng.normal(size=y2.shape).astype(np.float32)
+    ig2, wg2 = oracle.indice_conv_backward(x2, W2, g2, pairs, num, True, False)
+    # <y2, g2> is bilinear in (x2, W2): its gradients are the two partial contractions
+    eps_x, eps_w = rng.normal(size=x2.shape).astype(np.float32), rng.normal(size=W2.shape).astype(np.float32)
+    lhs_x = float((oracle.indice_conv(eps_x, W2, pairs, num, idx.shape[0], True, False) * g2).sum())
+    lhs_w = float((oracle.indice_conv(x2, eps_w, pairs, num, idx.shape[0], True, False) * g2).sum())
+    assert abs(lhs_x - float((ig2 * eps_x).sum())) < 1e-2 * max(1.0, abs(lhs_x))
+    assert abs(lhs_w - float((wg2 * eps_w).sum())) < 1e-2 * max(1.0, abs(lhs_w))
