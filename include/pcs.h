@@ -142,6 +142,19 @@ int pcs_indice_conv_backward_f32(const float* features, int cin, const float* fi
                                  int subm, float* in_grad, float* filters_grad, void* ws,
                                  size_t ws_bytes, pcs_stream_t stream);
 
+/* sparse_conv_ext.indice_maxpool_fp32 / indice_maxpool_backward_fp32 (src/all.cc:42-47; pool_ops.h:26-98,
+ * src/maxpool.cc:22-64): features [num_in,C] and the pooling window's rulebook ->
+ * out [num_out,C] = max(0, max over paired inputs) (the reference's output starts at zero); backward:
+ * in_grad [num_in,C] = sum over paired outputs whose pooled value equals the input (ties all receive).
+ * ws: pcs_neighbor_table_bytes(num_out | num_in, kv). */
+int pcs_indice_maxpool_f32(const float* features, int C, const int32_t* pairs, int64_t pair_stride,
+                           const int32_t* num, int kv, int64_t num_out, float* out, void* ws,
+                           size_t ws_bytes, pcs_stream_t stream);
+int pcs_indice_maxpool_backward_f32(const float* features, const float* out_features,
+                                    const float* out_grad, int C, const int32_t* pairs,
+                                    int64_t pair_stride, const int32_t* num, int kv, int64_t num_in,
+                                    float* in_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);
+
 /* SparseConvTensor.dense() (pcdet/ops/spconv/structure.py:5-18,55-64) in its channels-first form, as
  * HeightCompression consumes it (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27;
  * SURVEY 8f row f3): features [V,C] at indices [V,4] (b,z,y,x) -> out [B,C,D,H,W] f32, zeros

@@ -178,6 +178,41 @@ def indice_conv_backward(features, filters, out_grad, pairs, num, inverse=False,
     return in_grad, w_grad.reshape(filters.shape)
 
 
+def indice_maxpool(features, pairs, num, num_out):
+    """indiceMaxPool (pcdet/ops/spconv/include/spconv/pool_ops.h:26-60, src/maxpool.cc:22-40): the output
+    starts at ZERO and takes every paired input that is larger, offset by offset."""
+    feat = _c(features, np.float32)
+    out = np.zeros((num_out, feat.shape[1]), np.float32)
+    for k in range(pairs.shape[0]):
+        n = int(num[k])
+        if n > 0:
+            np.maximum.at(out, pairs[k, 1, :n], feat[pairs[k, 0, :n]])
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_grad, pairs, num):
+    """indiceMaxPoolBackward (pool_ops.h:62-98, src/maxpool.cc:43-64): every paired input equal to the
+    pooled value receives the output's gradient (ties all receive it), offsets in ascending order."""
+    feat = _c(features, np.float32)
+    outf = _c(out_features, np.float32)
+    og = _c(out_grad, np.float32)
+    din = np.zeros_like(feat)
+    for k in range(pairs.shape[0]):
+        n = int(num[k])
+        if n <= 0:
+            continue
+        i_in, i_out = pairs[k, 0, :n], pairs[k, 1, :n]
+        hit = outf[i_out] == feat[i_in]
+        np.add.at(din, i_in, np.where(hit, og[i_out], np.float32(0)))
+    return din
+
+
+def ref_maxpool():
+    """The reference's own CPU functors compiled in place (oracle/_ref/libref_maxpool.so), or None."""
+    path = os.path.join(HERE, "_ref", "libref_maxpool.so")
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
 def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, qmin=(0, -1, -1, -1),
                  qmax=(0, 1, 1, 1), want_dists=False):
     """RadiusGraph.build_graph: returns (e_ref, e_query) int64 (and squared dists)."""

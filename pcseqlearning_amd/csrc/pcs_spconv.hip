@@ -494,6 +494,83 @@ extern "C" int pcs_indice_conv_backward_f32(const float* features, int cin, cons
   return PCS_OK;
 }
 
+// ---- indiceMaxPool / indiceMaxPoolBackward (pool_ops.h:26-98, src/maxpool.cc:22-64; row f4) ------
+// The reference runs one scatter pass per kernel offset over an output that starts at zero. Over the
+// output-major table both directions are gathers: out[o][c] = max(0, max_k in[T[o][k]][c]); the input
+// gradient sums, in ascending offset (the reference's order, so the fp32 sum is the same), the
+// gradients of the outputs whose pooled value equals the input -- no atomics.
+namespace pcs {
+__global__ void __launch_bounds__(kBlock)
+maxpool_fwd_kernel(const float* __restrict__ feat, int C, const int32_t* __restrict__ table, int kv,
+                   int64_t num_out, float* __restrict__ out) {
+  int64_t total = num_out * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t o = t / C;
+    int c = (int)(t - o * C);
+    float acc = 0.f;
+    for (int k = 0; k < kv; ++k) {
+      int i = table[o * kv + k];
+      if (i < 0) continue;
+      float v = feat[(int64_t)i * C + c];
+      if (acc < v) acc = v;
+    }
+    out[t] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+maxpool_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ outf,
+                   const float* __restrict__ og, int C, const int32_t* __restrict__ table_t, int kv,
+                   int64_t num_in, float* __restrict__ din) {
+  int64_t total = num_in * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = t / C;
+    int c = (int)(t - i * C);
+    float v = feat[t], acc = 0.f;
+    for (int k = 0; k < kv; ++k) {
+      int o = table_t[i * kv + k];
+      if (o < 0) continue;
+      if (outf[(int64_t)o * C + c] == v) acc = acc + og[(int64_t)o * C + c];
+    }
+    din[t] = acc;
+  }
+}
+}  // namespace pcs
+
+extern "C" int pcs_indice_maxpool_f32(const float* features, int C, const int32_t* pairs, int64_t pair_stride,
+                                      const int32_t* num, int kv, int64_t num_out, float* out, void* ws,
+                                      size_t ws_bytes, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !pairs || !num || !out || C < 1 || kv < 1 || num_out < 0) return PCS_ERR_ARG;
+  if (num_out == 0) return PCS_OK;
+  if (!ws || ws_bytes < pcs_neighbor_table_bytes(num_out, kv)) return PCS_ERR_WORKSPACE;
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, 0, num_out, (int32_t*)ws, s);
+  if (rc) return rc;
+  maxpool_fwd_kernel<<<grid_for(num_out * C), kBlock, 0, s>>>(features, C, (const int32_t*)ws, kv, num_out, out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+extern "C" int pcs_indice_maxpool_backward_f32(const float* features, const float* out_features,
+                                               const float* out_grad, int C, const int32_t* pairs,
+                                               int64_t pair_stride, const int32_t* num, int kv,
+                                               int64_t num_in, float* in_grad, void* ws, size_t ws_bytes,
+                                               hipStream_t s) {
+  using namespace pcs;
+  if (!features || !out_features || !out_grad || !pairs || !num || !in_grad || C < 1 || kv < 1 || num_in < 0)
+    return PCS_ERR_ARG;
+  if (num_in == 0) return PCS_OK;
+  if (!ws || ws_bytes < pcs_neighbor_table_bytes(num_in, kv)) return PCS_ERR_WORKSPACE;
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, 1, num_in, (int32_t*)ws, s);
+  if (rc) return rc;
+  maxpool_bwd_kernel<<<grid_for(num_in * C), kBlock, 0, s>>>(features, out_features, out_grad, C,
+                                                            (const int32_t*)ws, kv, num_in, in_grad);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 // ---- SparseConvTensor.dense() + HeightCompression (pcdet/ops/spconv/structure.py:5-18,55-64;
 // pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27): features [V,C] at
 // indices [V,4] (b,z,y,x) -> channels-first dense [B,C,D,H,W] (== [B, C*D, H, W] viewed), zeros

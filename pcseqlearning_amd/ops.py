@@ -197,6 +197,39 @@ def indice_conv_backward(features, filters, out_bp, pairs, num, inverse=False, s
     return in_bp, w_bp.reshape(filters.shape)
 
 
+def indice_maxpool(features, pairs, num, num_out):
+    """sparse_conv_ext.indice_maxpool_fp32 (pool_ops.h:26-60): [num_out, C], zero floor."""
+    L.require_gpu(features, "indice_maxpool")
+    lib = L.load()
+    features = features.detach().float().contiguous()
+    pairs = pairs.contiguous()
+    kv, C = pairs.shape[0], features.shape[1]
+    out = torch.empty(num_out, C, dtype=torch.float32, device=features.device)
+    ws = L.workspace(lib.pcs_neighbor_table_bytes(L.i64(num_out), L.i32(kv)), features.device)
+    L.check(lib.pcs_indice_maxpool_f32(L.ptr(features), L.i32(C), L.ptr(pairs), L.i64(pairs.shape[2]), L.ptr(num),
+                                       L.i32(kv), L.i64(num_out), L.ptr(out), L.ptr(ws), L.i64(ws.numel()),
+                                       L.stream()), "pcs_indice_maxpool_f32")
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_bp, pairs, num):
+    """sparse_conv_ext.indice_maxpool_backward_fp32 (pool_ops.h:62-98)."""
+    L.require_gpu(features, "indice_maxpool_backward")
+    lib = L.load()
+    features = features.detach().float().contiguous()
+    out_features = out_features.detach().float().contiguous()
+    out_bp = out_bp.detach().float().contiguous()
+    pairs = pairs.contiguous()
+    kv, C, n_in = pairs.shape[0], features.shape[1], features.shape[0]
+    in_bp = torch.empty_like(features)
+    ws = L.workspace(lib.pcs_neighbor_table_bytes(L.i64(n_in), L.i32(kv)), features.device)
+    L.check(lib.pcs_indice_maxpool_backward_f32(L.ptr(features), L.ptr(out_features), L.ptr(out_bp), L.i32(C),
+                                                L.ptr(pairs), L.i64(pairs.shape[2]), L.ptr(num), L.i32(kv),
+                                                L.i64(n_in), L.ptr(in_bp), L.ptr(ws), L.i64(ws.numel()),
+                                                L.stream()), "pcs_indice_maxpool_backward_f32")
+    return in_bp
+
+
 def sparse_to_dense(features, indices, batch_size, spatial_shape):
     """SparseConvTensor.dense(channels_first=True): features [V,C] f32 at indices [V,4] int32
     (b,z,y,x) -> [B,C,D,H,W] f32."""

@@ -64,6 +64,23 @@ class SubMConvFunction(_IndiceConv):
         return SubMConvFunction._backward(ctx, grad_output)
 
 
+class SparseMaxPoolFunction(Function):
+    """functional.py:75-92 of the reference."""
+
+    @staticmethod
+    def forward(ctx, features, indice_pairs, indice_pair_num, num_activate_out):
+        out = ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, out = ctx.saved_tensors
+        input_bp = ops.indice_maxpool_backward(features, out, grad_output, indice_pairs, indice_pair_num)
+        return input_bp, None, None, None
+
+
 indice_conv = SparseConvFunction.apply
 indice_inverse_conv = SparseInverseConvFunction.apply
 indice_subm_conv = SubMConvFunction.apply
+indice_maxpool = SparseMaxPoolFunction.apply

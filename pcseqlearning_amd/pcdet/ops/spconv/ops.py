@@ -50,3 +50,11 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
 
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
     return _ops.indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse, subm)
+
+
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    return _ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    return _ops.indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num)

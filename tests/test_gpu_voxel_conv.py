@@ -231,3 +231,24 @@ def test_conv_modules_autograd_vs_oracle(oracle):
                       (c1.bias.grad, g1.sum(0))):
         want = np.asarray(want)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("name", ["maxpool_ties", "maxpool_float"])
+def test_maxpool_vs_reference_golden(oracle, name):
+    """pcs_indice_maxpool_f32 / _backward_f32 against the outputs of the
+    reference's own CPU functors (tests/golden/make_golden_maxpool.py). Bit-exact, ties included."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    n_out = g["out_ids"].shape[0]
+    out = ops.indice_maxpool(dev(g["features"]), dev(g["pairs"]), dev(g["num"]), n_out)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["out"])
+    din = ops.indice_maxpool_backward(dev(g["features"]), out, dev(g["out_grad"]), dev(g["pairs"]), dev(g["num"]))
+    np.testing.assert_array_equal(din.cpu().numpy(), g["in_grad"])
+    # module + autograd: SparseMaxPool3d(3, 2, 1) builds the same rulebook and routes the gradient
+    from pcseqlearning_amd.pcdet.ops import spconv
+    x = dev(g["features"]).requires_grad_(True)
+    t = spconv.SparseConvTensor(x, dev(g["indices"]), [7, 20, 22], 1)
+    y = spconv.SparseMaxPool3d(3, stride=2, padding=1)(t)
+    np.testing.assert_array_equal(y.indices.cpu().numpy(), g["out_ids"])
+    np.testing.assert_array_equal(y.features.detach().cpu().numpy(), g["out"])
+    (y.features * dev(g["out_grad"])).sum().backward()
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), g["in_grad"])

@@ -158,3 +158,24 @@ def test_sparse_conv_forward_backward_vs_dense_autograd(oracle, subm, stride, pa
     lhs_w = float((oracle.indice_conv(x2, eps_w, pairs, num, idx.shape[0], True, False) * g2).sum())
     assert abs(lhs_x - float((ig2 * eps_x).sum())) < 1e-2 * max(1.0, abs(lhs_x))
     assert abs(lhs_w - float((wg2 * eps_w).sum())) < 1e-2 * max(1.0, abs(lhs_w))
+
+
+@pytest.mark.parametrize("name", ["maxpool_ties", "maxpool_float"])
+def test_maxpool_oracle_vs_reference(oracle, name):
+    """oracle.indice_maxpool / _backward against the reference's own CPU functors: committed golden
+    vectors (tests/golden/make_golden_maxpool.py) and, when oracle/_ref is built, the compiled
+    functors on fresh random data. Bit-exact."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    out = oracle.indice_maxpool(g["features"], g["pairs"], g["num"], g["out_ids"].shape[0])
+    np.testing.assert_array_equal(out, g["out"])
+    din = oracle.indice_maxpool_backward(g["features"], out, g["out_grad"], g["pairs"], g["num"])
+    np.testing.assert_array_equal(din, g["in_grad"])
+    lib = oracle.ref_maxpool()
+    if lib is None:
+        return
+    from tests.golden.make_golden_maxpool import make_case, reference_maxpool
+    c = make_case(99 if name == "maxpool_ties" else 98, name == "maxpool_ties")
+    want_out, want_din = reference_maxpool(lib, c["features"], c["pairs"], c["num"], c["out_ids"].shape[0], c["out_grad"])
+    got = oracle.indice_maxpool(c["features"], c["pairs"], c["num"], c["out_ids"].shape[0])
+    np.testing.assert_array_equal(got, want_out)
+    np.testing.assert_array_equal(oracle.indice_maxpool_backward(c["features"], got, c["out_grad"], c["pairs"], c["num"]), want_din)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--mfma", default="both")
+    ap.add_argument("--train", action="store_true", help="also time one forward + backward step")
     args = ap.parse_args()
     dev = "cuda:0"
     lib = L.load()
@@ -80,6 +81,31 @@ def main():
             "conv_gflop": round(flops / 1e9, 3),
             "conv_tflops_mfma_path": round(flops / (results.get("mfma", results.get("fma")) * 1e-3) / 1e12, 3),
             "output_voxels_per_rulebook": voxels, "bit_identical_mfma_vs_fma": len(modes) == 2}
+    if args.train:
+        # one training-mode forward + backward through the same network (batch-stat
+        # BatchNorm in torch, conv forward on the table kernel, conv backward on
+        # pcs_indice_conv_backward_f32); loss = sum of the encoded features
+        net.train()
+        batch0 = vfe({"points": pts, "batch_size": 1})
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            out_t = net(dict(batch0))
+            out_t["encoded_spconv_tensor"].features.sum().backward()
+
+        step()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+            step()
+        e.record()
+        torch.cuda.synchronize()
+        line["ms_per_train_step_fwd_bwd"] = round(s.elapsed_time(e) / args.reps, 3)
+        line["conv_backward_gflop"] = round(2 * flops / 1e9, 3)
+        g0 = net.conv_input[0].weight.grad.clone()
+        step()
+        line["backward_reproducible"] = bool(torch.equal(g0, net.conv_input[0].weight.grad))
     print(json.dumps(line))
 
 
