@@ -149,6 +149,7 @@ def main():
     lib.pcs_profile_icp_nn_read(prof)
     lib.pcs_profile_icp_nn(ctypes.c_int(0))
 
+    units_in_flight = int(getattr(model.preprocessors[2], "last_num_workers", 0))
     # cross-check for profiles/: one extra, untimed step on the serial schedule (one stream), where a
     # launch has the chip to itself as it does under rocprofv3 (which cannot trace the threaded
     # schedule on this image); reported beside the timed-region figure, never instead of it
@@ -209,6 +210,7 @@ def main():
                 "points_after_subsample": int(out["full_point_fxyz"].shape[0]),
                 "points_after_ground_removal": int(out["point_fxyz"].shape[0]),
                 "parallelism": f"one sequence per GPU x{world}",
+                "tracking_units_in_flight": units_in_flight,
                 # host wall spans (not device-synchronised; concurrent units overlap, so they do not add up)
                 "stage_seconds_per_step": {k: round(v / args.steps, 3) for k, v in timer.RECORDS.items()
                                            if not k.startswith(("unit ", "Tracking Frame", "ground:"))},

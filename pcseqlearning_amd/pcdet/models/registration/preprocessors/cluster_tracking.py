@@ -603,6 +603,15 @@ class ClusterTracking(nn.Module):
         # 4 concurrent units: beyond that the kernels of different streams no longer overlap on this
         # hardware and every unit only gets slower (see pcseqlearning_amd/__init__.py)
         n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 4)), len(units)))
+        if n_workers > 1 and os.environ.get("ROCP_TOOL_LIBRARIES"):
+            # rocprofv3 is attached: rocprofiler-sdk on this image segfaults when kernels are launched
+            # from several native threads at once, so a profiled run takes the serial schedule (same
+            # kernels, same results)
+            if not getattr(self, "_warned_profiler", False):
+                print("ClusterTracking: rocprofiler attached -> serial schedule of the tracking units", flush=True)
+                self._warned_profiler = True
+            n_workers = 1
+        self.last_num_workers = n_workers
         results, best = {}, []
         if n_workers == 1 or not seq_points.fxyz.is_cuda:
             for comp_key, frame_id in units:
