@@ -113,7 +113,7 @@ indice_conv_tile_kernel(const float* __restrict__ feat, int cin, const float* __
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int A_LD = CIN_MAX + 4;  // row stride 68: 4*row + k spreads the 16x4 fragment over banks
 
-template <int NC>
+template <int NC, bool WIDE = false>
 __global__ void __launch_bounds__(kBlock)
 indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
                         int kv, int centre, const int32_t* __restrict__ table, int64_t num_out,
@@ -148,36 +148,47 @@ indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __
     if (tid == 0) nsteps = n;
   }
   __syncthreads();
-  int ns = nsteps;
-  int cin4 = cin >> 2;
-  int a_cnt = TM * cin4;        // float4 elements of the A tile
-  int w_cnt = cin * COUT / 4;   // float4 elements of W[k]
+  // more than CIN_MAX input channels: an offset is staged in slices of CIN_MAX channels (a step is an
+  // (offset, slice) pair; up to CIN_MAX channels the loop below is what it always was)
+  const int slices = WIDE ? (cin + CIN_MAX - 1) / CIN_MAX : 1;
+  int ns = nsteps * slices;
+  int cs = 0, cin4 = 0, a_cnt = 0, w_cnt = 0;  // channels / float4 counts of the slice being staged
   float4 ra[NA], rw[NW];
-  auto prefetch = [&](int k) {
+  auto prefetch = [&](int step) {
+    const int k = steps[step / slices], h = step - (step / slices) * slices;
+    const int ch = min(CIN_MAX, cin - h * CIN_MAX), ch4 = ch >> 2;
+    const int na = TM * ch4, nw = ch * COUT / 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int e = tid + i * kBlock;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < a_cnt) {
-        int r = e / cin4, c4 = e - r * cin4;
+      if (e < na) {
+        int r = e / ch4, c4 = e - r * ch4;
         int in = Tt[r][k];
-        if (in >= 0) v = *(const float4*)(feat + (int64_t)in * cin + c4 * 4);
+        if (in >= 0) v = *(const float4*)(feat + (int64_t)in * cin + h * CIN_MAX + c4 * 4);
       }
       ra[i] = v;
     }
-    const float4* Wk = (const float4*)(W + (int64_t)k * cin * COUT);
+    const float4* Wk = (const float4*)(W + ((int64_t)k * cin + h * CIN_MAX) * COUT);
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       int e = tid + i * kBlock;
-      rw[i] = e < w_cnt ? Wk[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = e < nw ? Wk[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   f32x4 acc[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (ns > 0) prefetch(steps[0]);
+  if (ns > 0) prefetch(0);
   for (int si = 0; si < ns; ++si) {
-    // stage the prefetched tiles, then put the next offset's loads in flight under the MFMAs
+    // stage the prefetched tiles, then put the next step's loads in flight under the MFMAs
+    {
+      const int h = si - (si / slices) * slices;
+      cs = min(CIN_MAX, cin - h * CIN_MAX);
+      cin4 = cs >> 2;
+      a_cnt = TM * cin4;
+      w_cnt = cs * COUT / 4;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int e = tid + i * kBlock;
@@ -189,8 +200,8 @@ indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __
       if (e < w_cnt) { int r = (e * 4) / COUT, c = (e * 4) - r * COUT; *(float4*)&Ws[r][c] = rw[i]; }
     }
     __syncthreads();
-    if (si + 1 < ns) prefetch(steps[si + 1]);
-    for (int c0 = 0; c0 < cin; c0 += 4) {
+    if (si + 1 < ns) prefetch(si + 1);
+    for (int c0 = 0; c0 < cs; c0 += 4) {
       float a = As[wv * 16 + fi][c0 + fk];
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
@@ -290,24 +301,31 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
   if (num_out == 0) return PCS_OK;
   int64_t nb = (num_out + TM - 1) / TM;
   if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
-  bool tiled = cin <= CIN_MAX && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
+  bool cout_ok = cout == 16 || cout == 32 || cout == 64 || cout == 128;
+  bool tiled = cin <= CIN_MAX && cout_ok;
   // matrix cores where the tile is dense enough to feed them: 4-aligned input channels (the
-  // first layer, Cin = 3..5, stays on the FMA path: it is bandwidth-bound)
-  if (tiled && g_use_mfma && (cin % 4 == 0) && cin >= 16) {
+  // first layer, Cin = 3..5, stays on the FMA path: it is bandwidth-bound); wider
+  // inputs (the 128-channel residual stage, the input gradient of 64 -> 128) in slices of CIN_MAX
+  if (cout_ok && g_use_mfma && (cin % 4 == 0) && cin >= 16 && cin <= 8 * CIN_MAX) {
+#define PCS_MFMA_LAUNCH(NCV, WIDEV)                                                                   \
+  indice_conv_mfma_kernel<NCV, WIDEV><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, \
+                                                                 table, num_out, bias, scale, shift, relu, out)
+    const bool wide = cin > CIN_MAX;
     switch (cout) {
       case 16:
-        indice_conv_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        if (wide) PCS_MFMA_LAUNCH(1, true); else PCS_MFMA_LAUNCH(1, false);
         break;
       case 32:
-        indice_conv_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        if (wide) PCS_MFMA_LAUNCH(2, true); else PCS_MFMA_LAUNCH(2, false);
         break;
       case 64:
-        indice_conv_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        if (wide) PCS_MFMA_LAUNCH(4, true); else PCS_MFMA_LAUNCH(4, false);
         break;
       default:
-        indice_conv_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        if (wide) PCS_MFMA_LAUNCH(8, true); else PCS_MFMA_LAUNCH(8, false);
         break;
     }
+#undef PCS_MFMA_LAUNCH
     PCS_LAUNCH_CHECK();
     return PCS_OK;
   }

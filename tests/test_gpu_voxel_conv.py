@@ -126,7 +126,7 @@ def test_rulebook_and_conv_full_frame(oracle):
         np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (7, 10)])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 64), (96, 32), (7, 10)])
 def test_conv_channel_configs(oracle, cin, cout):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_subm3.npz"))
     rng = np.random.default_rng(cin * 131 + cout)
