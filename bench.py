@@ -55,6 +55,15 @@ def load_sequence(seed, frames, points):
     return batch
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the file sits next to this script)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking, 1\u21928 MI355X + HBM-roofline %"
+
+
 def cpu_baseline(batch, out, n_reg_calls):
     """Oracle timed on: 8 cm subsample of the whole sequence, one 10-frame proposal chunk at
     r = 0.25, and the 3 ICP levels of ONE anchor->next-frame pair; scaled by the number of such
@@ -190,7 +199,7 @@ def main():
             traffic = round((pmc["FETCH_SIZE_KB_per_dispatch"] + pmc["WRITE_SIZE_KB_per_dispatch"]) * 1024.0, 1)
             traffic_src = "profiles/r01_icp_nn_hbm_pmc_v10.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, serial schedule)"
         line = {
-            "metric": "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking",
+            "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
             "unit": "sequences/s",
             "n_gpus": world,
