@@ -441,6 +441,90 @@ filter_grad_partial_kernel(const float* __restrict__ feat, int cin, const float*
   if (ci + 1 < cin && cj + 1 < cout) dst[(int64_t)(ci + 1) * cout + cj + 1] = a11;
 }
 
+// The same partial sums on the matrix cores (v_mfma_f32_16x16x4_f32): dW[k] = in^T . out_grad is a
+// GEMM with M = input channels, N = output channels, K = pairs. A workgroup owns a (RB*16) x (NC*16)
+// tile; its four waves are RB row blocks x (4 / RB) pair slices, the slices summed in LDS in fixed
+// order at the end. 32 pairs are staged per round, [pair][channel], row stride + 16 floats so that the
+// two 16-lane halves of an LDS access land 16 banks apart.
+template <int NC, int RB>
+__global__ void __launch_bounds__(kBlock)
+filter_grad_mfma_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ og, int cout,
+                        const int32_t* __restrict__ pairs, int64_t pair_stride,
+                        const int32_t* __restrict__ num, int side_in, int tiles_j,
+                        float* __restrict__ partial, int kv) {
+  constexpr int PS = 4 / RB, TI = RB * 16, TJ = NC * 16, PB = 32;
+  constexpr int LDI = TI + 16, LDJ = TJ + 16;
+  const int chunk = blockIdx.x, k = blockIdx.y;
+  const int ti0 = (blockIdx.z / tiles_j) * TI, tj0 = (blockIdx.z % tiles_j) * TJ;
+  const int n = num[k];
+  const int p0 = chunk * kGradChunk;
+  if (p0 >= n) return;
+  const int p1 = min(n, p0 + kGradChunk);
+  const int32_t* pin = pairs + ((int64_t)k * 2 + side_in) * pair_stride;
+  const int32_t* pout = pairs + ((int64_t)k * 2 + (1 - side_in)) * pair_stride;
+  __shared__ __align__(16) float s_in[PB][LDI];
+  __shared__ __align__(16) float s_og[PB][LDJ];
+  __shared__ float s_red[PS > 1 ? 4 : 1][NC][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int rb = wv % RB, ps = wv / RB;
+  f32x4 acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int pb = p0; pb < p1; pb += PB) {
+    for (int e = tid; e < PB * (TI / 4); e += kBlock) {
+      int pr = e / (TI / 4), c4 = e - pr * (TI / 4);
+      int p = pb + pr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < p1 && ti0 + c4 * 4 < cin) v = *(const float4*)(feat + (int64_t)pin[p] * cin + ti0 + c4 * 4);
+      *(float4*)&s_in[pr][c4 * 4] = v;
+    }
+    for (int e = tid; e < PB * (TJ / 4); e += kBlock) {
+      int pr = e / (TJ / 4), c4 = e - pr * (TJ / 4);
+      int p = pb + pr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < p1 && tj0 + c4 * 4 < cout) v = *(const float4*)(og + (int64_t)pout[p] * cout + tj0 + c4 * 4);
+      *(float4*)&s_og[pr][c4 * 4] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PB / PS; q += 4) {
+      int pp = ps * (PB / PS) + q + fk;
+      float a = s_in[pp][rb * 16 + fi];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float b = s_og[pp][c * 16 + fi];
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (PS > 1) {
+    // pair slices of one row block: slice 0 adds the others in ascending order
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_red[wv][c][lane][j] = acc[c][j];
+    __syncthreads();
+    if (ps != 0) return;
+    for (int o = 1; o < PS; ++o)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = acc[c][j] + s_red[o * RB + rb][c][lane][j];
+  }
+  float* dst = partial + ((int64_t)chunk * kv + k) * cin * cout;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int col = tj0 + c * 16 + fi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row = ti0 + rb * 16 + fk * 4 + j;
+      if (row < cin && col < cout) dst[(int64_t)row * cout + col] = acc[c][j];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 filter_grad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ num, int kv,
                           int cin, int cout, float* __restrict__ dW) {
@@ -504,8 +588,21 @@ extern "C" int pcs_indice_conv_backward_f32(const float* features, int cin, cons
   int64_t chunks = (pair_stride + kGradChunk - 1) / kGradChunk;
   int tiles_i = (cin + kGT - 1) / kGT, tiles_j = (cout + kGT - 1) / kGT;
   if (chunks >= 65536 || kv >= 65536) return PCS_ERR_RANGE;
-  filter_grad_partial_kernel<<<dim3((unsigned)chunks, kv, tiles_i * tiles_j), kBlock, 0, s>>>(
-      features, cin, out_grad, cout, pairs, pair_stride, num, inverse ? 1 : 0, tiles_j, partial, kv);
+  const int rbv = cin >= 64 ? 4 : (cin >= 32 ? 2 : 1), ncv = cout >= 64 ? 4 : (cout >= 32 ? 2 : 1);
+  if (g_use_mfma && cin >= 16 && cin % (rbv * 16) == 0 && cout >= 16 && cout % (ncv * 16) == 0) {
+    const int mi = cin / (rbv * 16), mj = cout / (ncv * 16);
+    dim3 grid((unsigned)chunks, kv, mi * mj);
+#define PCS_FG_LAUNCH(NCV, RBV)                                                                       \
+  filter_grad_mfma_kernel<NCV, RBV><<<grid, kBlock, 0, s>>>(features, cin, out_grad, cout, pairs,      \
+                                                            pair_stride, num, inverse ? 1 : 0, mj, partial, kv)
+    if (ncv == 4) { if (rbv == 4) PCS_FG_LAUNCH(4, 4); else if (rbv == 2) PCS_FG_LAUNCH(4, 2); else PCS_FG_LAUNCH(4, 1); }
+    else if (ncv == 2) { if (rbv == 4) PCS_FG_LAUNCH(2, 4); else if (rbv == 2) PCS_FG_LAUNCH(2, 2); else PCS_FG_LAUNCH(2, 1); }
+    else { if (rbv == 4) PCS_FG_LAUNCH(1, 4); else if (rbv == 2) PCS_FG_LAUNCH(1, 2); else PCS_FG_LAUNCH(1, 1); }
+#undef PCS_FG_LAUNCH
+  } else {
+    filter_grad_partial_kernel<<<dim3((unsigned)chunks, kv, tiles_i * tiles_j), kBlock, 0, s>>>(
+        features, cin, out_grad, cout, pairs, pair_stride, num, inverse ? 1 : 0, tiles_j, partial, kv);
+  }
   filter_grad_reduce_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>(partial, num, kv, cin,
                                                                                  cout, filters_grad);
   PCS_LAUNCH_CHECK();
