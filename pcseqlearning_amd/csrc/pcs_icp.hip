@@ -968,6 +968,26 @@ int pcs_profile_busy_loop(int64_t n, int ticks, int blocks, hipStream_t s) {
   return PCS_OK;
 }
 
+// the same chain of dependent kernels as one captured graph launched n / nodes times: does the graph
+// executor shorten the device-side gap between dependent kernels? (tools/launch_scaling.py, mode graphN)
+int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, hipStream_t s) {
+  if (nodes < 1) nodes = 1;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  PCS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < nodes; ++i) {
+    if (ticks > 0) busy_kernel<<<blocks, 64, 0, s>>>(ticks);
+    else pcs::noop_kernel<<<1, 64, 0, s>>>();
+  }
+  PCS_CHECK_HIP(hipStreamEndCapture(s, &graph));
+  PCS_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  for (int64_t i = 0; i < n; i += nodes) PCS_CHECK_HIP(hipGraphLaunch(exec, s));
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  hipGraphExecDestroy(exec);
+  hipGraphDestroy(graph);
+  return PCS_OK;
+}
+
 int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
   for (int64_t i = 0; i < n; ++i) pcs::noop_kernel<<<1, 64, 0, s>>>();
   PCS_LAUNCH_CHECK();

@@ -38,6 +38,13 @@ def run(mode, T, n):
                 rc = lib.pcs_profile_busy_loop(ctypes.c_int64(n), ctypes.c_int(ticks), ctypes.c_int(blocks),
                                                ctypes.c_void_p(streams[i].cuda_stream))
                 assert rc == 0
+            elif mode.startswith("graph"):
+                # graph<nodes>[:<ticks>x<blocks>]: the chain captured once, launched n / nodes times
+                spec = mode[5:].split(":")
+                ticks, blocks = (int(x) for x in spec[1].split("x")) if len(spec) > 1 else (0, 1)
+                rc = lib.pcs_profile_graph_loop(ctypes.c_int64(n), ctypes.c_int(int(spec[0])), ctypes.c_int(ticks),
+                                                ctypes.c_int(blocks), ctypes.c_void_p(streams[i].cuda_stream))
+                assert rc == 0
             elif mode.startswith("sync"):
                 rc = lib.pcs_profile_sync_loop(ctypes.c_int64(n), ctypes.c_int(int(mode[4:])),
                                                ctypes.c_void_p(streams[i].cuda_stream))
@@ -63,8 +70,17 @@ def run(mode, T, n):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--graphs", action="store_true", help="only: dependent chains as stream launches vs captured graphs")
     args = ap.parse_args()
     run("native", 1, 1000)
+    if args.graphs:
+        # 500 ticks = 5 us kernels, 64 workgroups: the size of an ICP iteration kernel
+        for mode in ("native", "graph24", "busy500x64", "graph24:500x64", "graph96:500x64"):
+            for T in (1, 4):
+                r = run(mode, T, 9600)
+                print(f"{mode:16s} threads={T}  {1e6 / r * T:7.2f} us per kernel per chain  (aggregate {r / 1e3:7.1f} k kernels/s)",
+                      flush=True)
+        sys.exit(0)
     for mode in ("torch", "native"):
         for T in (1, 2, 3, 5, 9):
             r = run(mode, T, args.n)
