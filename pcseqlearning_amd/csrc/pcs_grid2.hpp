@@ -200,7 +200,8 @@ __device__ __forceinline__ uint64_t g2_box_mask(int X, int Y, int Z, int cx, int
 // query. The result (original index or -1) is returned in every lane of the half.
 __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g, float4 p, int df,
                                                bool valid, int* __restrict__ overflow,
-                                               float* __restrict__ best_dist2 = nullptr) {
+                                               float* __restrict__ best_dist2 = nullptr,
+                                               int probe_stage = 0) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 31;
   const int half_base = lane & 32;
@@ -230,6 +231,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     }
   }
   unsigned long long occ = __ballot(mymask != 0);
+  if (probe_stage == 2) return (int)(mymask & 1);  // timing probe: stop after the coarse masks
   valid = valid && ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
   int cand = -1;
   float cd = 0.f;
@@ -296,6 +298,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     }
   };
   reduce_half();
+  if (probe_stage == 3) return cand;  // timing probe: stop after the near cells
   // ---- far cells: everything at Chebyshev distance >= 2 is at least h away
   float bound = (cand >= 0 ? cd : d.radius2) - dfsq + margin;  // admissible |dxyz|^2 of a better point
   bool more = valid && rings >= 2 && !(d.h * d.h > bound);
