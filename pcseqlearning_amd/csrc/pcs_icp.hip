@@ -993,6 +993,16 @@ int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, hipStrea
   return PCS_OK;
 }
 
+// a stream whose kernels run on the compute units of `mask` only (hipExtStreamCreateWithCUMask):
+// probe for confining each tracking unit to its own XCDs (tools/icp_concurrency.py --cu-mask)
+int pcs_stream_create_cu_mask(const uint32_t* mask, int words, void** out) {
+  if (!mask || !out || words < 1) return PCS_ERR_ARG;
+  hipStream_t s = nullptr;
+  PCS_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *out = (void*)s;
+  return PCS_OK;
+}
+
 int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
   for (int64_t i = 0; i < n; ++i) pcs::noop_kernel<<<1, 64, 0, s>>>();
   PCS_LAUNCH_CHECK();

@@ -20,6 +20,32 @@ from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tr
 from pcseqlearning_amd.pcdet.utils.common_utils import EasyDict  # noqa: E402
 from tools.run_sequence import build_model  # noqa: E402
 
+MASK_MODE = os.environ.get("PCS_CU_MASK", "")   # "", "block" (contiguous 256/K bits) or "xcd" (bit i -> XCD i % 8)
+
+
+def make_streams(K):
+    if not MASK_MODE or K == 1:
+        return [torch.cuda.Stream() for _ in range(K)]
+    lib_ = L.load()
+    out = []
+    per = 256 // K
+    for w in range(K):
+        bits = [0] * 8
+        for i in range(256):
+            if MASK_MODE == "block":
+                on = w * per <= i < (w + 1) * per
+            else:
+                on = (i % 8) * K // 8 == w
+            if on:
+                bits[i // 32] |= 1 << (i % 32)
+        arr = (ctypes.c_uint32 * 8)(*bits)
+        h = ctypes.c_void_p()
+        rc = lib_.pcs_stream_create_cu_mask(arr, ctypes.c_int(8), ctypes.byref(h))
+        assert rc == 0, rc
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
 model = build_model(streams=1)
 with torch.no_grad():
@@ -46,9 +72,9 @@ for radius, vs in ((2.5, [0.4, 0.4, 0.6]), (1.0, [0.1, 0.1, 0.15])):
     ref = sb.fxyz[~sb.stationary].contiguous()
     deg = torch.bincount(sa.component.long(), minlength=C)
     print(f"r={radius}: C={C} Mn={mov.shape[0]} Rn={ref.shape[0]} Ra={sb.fxyz.shape[0]}", flush=True)
-    for share in (0, 1):
-        for K in (1, 2, 4, 8):
-            streams = [torch.cuda.Stream() for _ in range(K)]
+    for share in ((0,) if MASK_MODE else (0, 1)):
+        for K in ((1, 2, 4, 8) if not MASK_MODE else (2, 4, 8)):
+            streams = make_streams(K)
             res = [None] * K
             bar = threading.Barrier(K)
 
