@@ -81,7 +81,10 @@ for radius, vs in ((2.5, [0.4, 0.4, 0.6]), (1.0, [0.1, 0.1, 0.15])):
             def job(i, reps=6):
                 with torch.cuda.stream(streams[i]):
                     if share:
-                        lib.pcs_icp_share_launches(ctypes.c_int(1))
+                        # PCS_SHARE_PAIRS=1: launcher groups of two (threads 2g, 2g+1): K/2 streams of
+                        # two-problem launches instead of one stream of K-problem launches
+                        group = 1 + i // 2 if os.environ.get("PCS_SHARE_PAIRS") else 1
+                        lib.pcs_icp_share_launches(ctypes.c_int(group))
                     ts = []
                     for rep in range(reps):
                         m = mov.clone()
