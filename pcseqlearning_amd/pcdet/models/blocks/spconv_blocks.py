@@ -1,24 +1,37 @@
-"""post_act_block / SparseBasicBlock (pcdet/models/blocks/spconv_blocks.py:8-64)."""
+"""The two building blocks of the sparse backbones (reference: pcdet/models/blocks/spconv_blocks.py:8-64).
+
+`post_act_block(cin, cout, k, ...)`   conv -> norm -> ReLU as a SparseSequential (children "0", "1", "2");
+                                      conv_type picks subM / strided / inverse conv, all without bias
+`SparseBasicBlock(inplanes, planes)`  residual pair of 3x3x3 subM convs on one rulebook (children conv1,
+                                      bn1, relu, conv2, bn2, downsample): relu(bn2(conv2(relu(bn1(conv1 x)))) + x)
+
+In eval mode under no_grad both normalisations (and the inner ReLU) are folded into the conv kernels'
+epilogues (`fold_batchnorm`); otherwise the modules are applied one by one.
+"""
 import torch
-import torch.nn as nn
+from torch import nn
 
 from ...ops.spconv.modules import fold_batchnorm
 from ...utils.spconv_utils import replace_feature, spconv
 
 
+def _make_conv(conv_type, cin, cout, ksize, stride, padding, key):
+    makers = {
+        "subm": lambda: spconv.SubMConv3d(cin, cout, ksize, bias=False, indice_key=key),
+        "spconv": lambda: spconv.SparseConv3d(cin, cout, ksize, stride=stride, padding=padding, bias=False,
+                                              indice_key=key),
+        "inverseconv": lambda: spconv.SparseInverseConv3d(cin, cout, ksize, indice_key=key, bias=False),
+    }
+    if conv_type not in makers:
+        raise NotImplementedError(conv_type)
+    return makers[conv_type]()
+
+
 def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0,
                    conv_type="subm", norm_fn=None):
-    if conv_type == "subm":
-        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
-    elif conv_type == "spconv":
-        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
-                                   bias=False, indice_key=indice_key)
-    elif conv_type == "inverseconv":
-        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key,
-                                          bias=False)
-    else:
-        raise NotImplementedError
-    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+    layers = (_make_conv(conv_type, in_channels, out_channels, kernel_size, stride, padding, indice_key),
+              norm_fn(out_channels), nn.ReLU())
+    return spconv.SparseSequential(*layers)
 
 
 class SparseBasicBlock(spconv.SparseModule):
@@ -26,28 +39,27 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, indice_key=None, norm_fn=None):
         super().__init__()
-        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1,
-                                       bias=False, indice_key=indice_key)
-        self.bn1 = norm_fn(planes)
-        self.relu = nn.ReLU()
-        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False,
-                                       indice_key=indice_key)
-        self.bn2 = norm_fn(planes)
-        self.downsample = downsample
-        self.stride = stride
+        widths = ((inplanes, planes, stride), (planes, planes, 1))
+        for n, (cin, cout, st) in enumerate(widths, start=1):
+            setattr(self, f"conv{n}", spconv.SubMConv3d(cin, cout, kernel_size=3, stride=st, padding=1, bias=False,
+                                                        indice_key=indice_key))
+            setattr(self, f"bn{n}", norm_fn(cout))
+            if n == 1:
+                self.relu = nn.ReLU()
+        self.downsample, self.stride = downsample, stride
+
+    def _folded(self, x):
+        return (not self.training and x.features.is_cuda and not torch.is_grad_enabled()
+                and self.bn1.track_running_stats and self.bn2.track_running_stats)
 
     def forward(self, x):
-        identity = x.features
-        if (not self.training and x.features.is_cuda and not torch.is_grad_enabled()
-                and self.bn1.track_running_stats and self.bn2.track_running_stats):
-            # eval mode: both normalisations (and the first ReLU) ride in the conv epilogues
-            out = self.conv1(x, *fold_batchnorm(self.bn1), relu=True)
-            out = self.conv2(out, *fold_batchnorm(self.bn2), relu=False)
+        skip = x.features
+        if self._folded(x):
+            y = self.conv2(self.conv1(x, *fold_batchnorm(self.bn1), relu=True), *fold_batchnorm(self.bn2), relu=False)
         else:
-            out = self.conv1(x)
-            out = replace_feature(out, self.relu(self.bn1(out.features)))
-            out = self.conv2(out)
-            out = replace_feature(out, self.bn2(out.features))
+            y = self.conv1(x)
+            y = self.conv2(replace_feature(y, self.relu(self.bn1(y.features))))
+            y = replace_feature(y, self.bn2(y.features))
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return replace_feature(out, self.relu(out.features + identity))
+            skip = self.downsample(x)
+        return replace_feature(y, self.relu(y.features + skip))
