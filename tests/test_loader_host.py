@@ -60,3 +60,31 @@ def test_loader_refuses_what_it_does_not_implement(tmp_path):
     ds = WaymoDataset(LF.dataset_cfg(root, 5, 1, [0, 1]), training=False, root_path=root)
     with pytest.raises(RuntimeError):  # the point path needs the HIP library: no CPU fallback
         ds.load_sample_to_gpu(0, "cpu")
+
+
+def test_collate_batch_keeps_tensors_where_they_are():
+    """The device path hands collate_batch torch tensors (here on the CPU): concatenation and the
+    `point_bxyz` pass-through must give what the numpy path gives."""
+    import torch
+    from pcseqlearning_amd.pcdet.datasets import DatasetTemplate
+    rng = np.random.default_rng(0)
+
+    def sample(n, b, as_tensor):
+        bxyz = np.concatenate([np.full((n, 1), b, np.float32), rng.normal(size=(n, 3)).astype(np.float32)], 1)
+        pw = dict(point_bxyz=bxyz, point_feat=rng.normal(size=(n, 3)).astype(np.float32),
+                  point_sweep=rng.integers(0, 5, (n, 1)).astype(np.int32))
+        if as_tensor:
+            pw = {k: torch.from_numpy(v) for k, v in pw.items()}
+        ow = dict(gt_box_attr=rng.normal(size=(b + 2, 7)).astype(np.float32), obj_ids=np.array(["a"] * (b + 2)))
+        return dict(point_wise=pw, object_wise=ow, scene_wise=dict(frame_id=np.array(["f0", "f1"])))
+
+    rng = np.random.default_rng(0)
+    a = DatasetTemplate.collate_batch([sample(5, 0, False), sample(7, 1, False)])
+    rng = np.random.default_rng(0)
+    b = DatasetTemplate.collate_batch([sample(5, 0, True), sample(7, 1, True)])
+    assert a["batch_size"] == b["batch_size"] == 2 and a["gt_box_attr"].shape == (2, 3, 7)
+    for k in ("point_bxyz", "point_feat", "point_sweep"):
+        assert torch.is_tensor(b[k]) and isinstance(a[k], np.ndarray)
+        np.testing.assert_array_equal(a[k], b[k].numpy())
+    np.testing.assert_array_equal(a["gt_box_attr"], b["gt_box_attr"])
+    assert a["gt_box_attr"][0, 2].sum() == 0  # padded row of the sample with fewer boxes
