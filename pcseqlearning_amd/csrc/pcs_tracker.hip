@@ -248,21 +248,51 @@ trk_sample2_emit_kernel(const float4* __restrict__ a, const float* __restrict__ 
   // first target voxel (or v if there is none)
   if (tgt && (s == 0 || order[seg[s - 1]] < na)) *d_va = s;
   if (!tgt && s == v - 1) *d_va = v;
+  // a coarse voxel holds dozens of rows and every row is two dependent loads (order -> point): eight
+  // rows are requested together and then added in their original order (same sums, an eighth of the
+  // round trips); the anchor's component ids ride along
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, st = 0.f;
-  for (int p = bb; p < e; ++p) {
-    int o = order[p];
-    float4 q = tgt ? b[o - na] : a[o];
-    a0 = a0 + q.x; a1 = a1 + q.y; a2 = a2 + q.z; a3 = a3 + q.w;
-    st = st + (tgt ? stat_b[o - na] : stat_a[o]);
+  int64_t first = 0;
+  bool same = true;
+  for (int p0 = bb; p0 < e; p0 += 8) {
+    int o[8];
+    float4 q[8];
+    float sv[8];
+    int64_t cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (p0 + j < e) ? order[p0 + j] : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sv[j] = 0.f;
+      cc[j] = 0;
+      if (o[j] >= 0) {
+        if (tgt) {
+          q[j] = b[o[j] - na];
+          sv[j] = stat_b[o[j] - na];
+        } else {
+          q[j] = a[o[j]];
+          sv[j] = stat_a[o[j]];
+          cc[j] = comp64[o[j]];
+        }
+      }
+    }
+    if (p0 == bb) first = cc[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (o[j] >= 0) {
+        a0 = a0 + q[j].x; a1 = a1 + q[j].y; a2 = a2 + q[j].z; a3 = a3 + q[j].w;
+        st = st + sv[j];
+        same = same && (cc[j] == first);
+      }
+    }
   }
   float cnt = (float)(e - bb);
   sub[s] = make_float4(a0 / cnt, a1 / cnt, a2 / cnt, a3 / cnt);
   flag_ns[s] = !((st / cnt) > 0.5f);
+  int64_t comp_of = -1;  // anchor voxels: the voxel's (median) component
   if (!tgt) {
     int k = (e - bb) / 2;
-    int64_t first = comp64[order[bb]];
-    bool same = true;
-    for (int p = bb + 1; p < e; ++p) if (comp64[order[p]] != first) { same = false; break; }
     int64_t res = first;
     if (!same) {
       for (int p = bb; p < e; ++p) {
@@ -277,7 +307,21 @@ trk_sample2_emit_kernel(const float4* __restrict__ a, const float* __restrict__ 
       }
     }
     sub_comp[s] = (int32_t)res;
-    atomicAdd(&sub_deg[res], 1ULL);
+    comp_of = res;
+  }
+  // per-component voxel counts: neighbouring voxels mostly share a component and a large component
+  // owns thousands of voxels, so one atomic per voxel queues up on a few addresses (~12 ns each);
+  // the lanes of a wave that agree on the component send one add between them
+  {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(comp_of >= 0);
+    while (todo) {
+      int leader = __ffsll((long long)todo) - 1;
+      long long lc = __shfl((long long)comp_of, leader, 64);
+      unsigned long long grp = __ballot(comp_of == lc);
+      if (lane == leader) atomicAdd(&sub_deg[lc], (unsigned long long)__popcll(grp));
+      todo &= ~grp;
+    }
   }
 }
 
