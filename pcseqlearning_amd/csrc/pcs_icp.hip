@@ -305,7 +305,7 @@ __device__ __forceinline__ void icp_nn_kernel_body(const IcpProblem& pr, int j, 
   bool any_fwd = __ballot(valid && fwd) != 0;
   bool any_bwd = __ballot(valid && !fwd) != 0;
   int res = -1;
-  if (pr.probe_stage == 1) {  // timing probe: launch + head loads only
+  if (pr.probe_stage == 1) {  // timing probe: launch + head loads only (stages 11.. belong to apply)
     if (valid && sub == 0 && p.x == 1.2345e30f) pr.nn_f[0] = 0;
     return;
   }
@@ -655,12 +655,21 @@ __device__ __forceinline__ void icp_apply_kernel_body(const IcpProblem& pr, int 
 
   double ls_mine = 0.0;
   float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int probe = pr.probe_stage;  // timing probe, stages 11..13 cut this kernel short
+  if (probe == 11) {  // launch + grid reset + head loads
+    if (i < Mn && comp[i] == -12345) lossp[0] = 0.0;
+    return;
+  }
   if (i < Mn) {
     int c = comp[i];
     const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
     const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
     double R[9], t[3], Tn[16], ls;
     icp_solve_component(a, Tc, reg, R, t, Tn, &ls);
+    if (probe == 12) {  // + moments / transform loads + the solve
+      if (R[0] == -12345.0) lossp[0] = ls;
+      return;
+    }
     float4 p = mov[i];
     prev[i] = p;
     double x = p.y, y = p.z, z = p.w;
@@ -679,6 +688,7 @@ __device__ __forceinline__ void icp_apply_kernel_body(const IcpProblem& pr, int 
       ls_mine = ls;
     }
   }
+  if (probe == 13) return;  // + move and stores, without the grid insert and the loss reduction
   {
     GridDesc d = *gp;
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
@@ -757,16 +767,31 @@ static int icp_launch_chunk(const IcpProblem* d_probs, const IcpProblem* host_pr
                             hipStream_t s, hipEvent_t* ev) {
   for (int j = 0; j < n_max; ++j) {
     if (host_prob) {
-      if (ev) {
-        // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
-        // difference is the kernel's own begin-to-end time, as rocprofv3 reports it
+      // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
+      // difference is the kernel's own begin-to-end time, as rocprofv3 reports it. The search kernel
+      // by default; PCS_PROF_KERNEL=moments|apply moves them (tools/icp_stages.py)
+      static const int target = [] {
+        const char* e = getenv("PCS_PROF_KERNEL");
+        return !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'a' ? 2 : 0));
+      }();
+      if (ev && target == 0) {
         hipExtLaunchKernelGGL(icp_nn_kernel_v, dim3(max_nb_q), dim3(kBlock), 0, s, ev[2 * j], ev[2 * j + 1],
                               0, *host_prob, j, kbase);
       } else {
         icp_nn_kernel_v<<<max_nb_q, kBlock, 0, s>>>(*host_prob, j, kbase);
       }
-      icp_moments_kernel_v<<<max_nb_e, kBlock, 0, s>>>(*host_prob, j, kbase);
-      icp_apply_kernel_v<<<max_nb_m, kBlock, 0, s>>>(*host_prob, j, kbase);
+      if (ev && target == 1) {
+        hipExtLaunchKernelGGL(icp_moments_kernel_v, dim3(max_nb_e), dim3(kBlock), 0, s, ev[2 * j],
+                              ev[2 * j + 1], 0, *host_prob, j, kbase);
+      } else {
+        icp_moments_kernel_v<<<max_nb_e, kBlock, 0, s>>>(*host_prob, j, kbase);
+      }
+      if (ev && target == 2) {
+        hipExtLaunchKernelGGL(icp_apply_kernel_v, dim3(max_nb_m), dim3(kBlock), 0, s, ev[2 * j],
+                              ev[2 * j + 1], 0, *host_prob, j, kbase);
+      } else {
+        icp_apply_kernel_v<<<max_nb_m, kBlock, 0, s>>>(*host_prob, j, kbase);
+      }
     } else {
       if (ev) {
         hipExtLaunchKernelGGL(icp_nn_kernel, dim3(max_nb_q, nprob), dim3(kBlock), 0, s, ev[2 * j],

@@ -5,6 +5,10 @@ cut runs are meaningless; only their launch time is read.
 
   python tools/icp_stages.py --prepare /tmp/icp_probe.pt
   for s in 1 2 3 0; do PCS_NN_PROBE_STAGE=$s python tools/icp_stages.py /tmp/icp_probe.pt; done
+  # the apply launch (stage 11 launch + grid reset + head loads, 12 + moments / transform loads and the
+  # solve, 13 + move and stores, 0 + grid insert and loss reduction) and the moments launch:
+  for s in 11 12 13 0; do PCS_PROF_KERNEL=apply PCS_NN_PROBE_STAGE=$s python tools/icp_stages.py /tmp/icp_probe.pt; done
+  PCS_PROF_KERNEL=moments python tools/icp_stages.py /tmp/icp_probe.pt
 """
 import ctypes
 import os
@@ -71,7 +75,8 @@ def main():
             lib.pcs_profile_icp_nn(ctypes.c_int(0))
             us = prof[0] * 1e3 / max(prof[1], 1)
             best = us if best is None else min(best, us)
-        print(f"stage {stage} r={p['radius']}: Mn={mov.shape[0]} Rn={ref.shape[0]}  icp_nn_kernel {best:6.2f} us per launch "
+        which = {"m": "icp_moments_kernel", "a": "icp_apply_kernel"}.get(os.environ.get("PCS_PROF_KERNEL", "n")[0], "icp_nn_kernel")
+        print(f"stage {stage} r={p['radius']}: Mn={mov.shape[0]} Rn={ref.shape[0]}  {which} {best:6.2f} us per launch "
               f"({int(prof[1])} launches timed, {iters} iterations)", flush=True)
 
 
