@@ -369,6 +369,7 @@ int pcs_profile_icp_nn_read(double* out3);
 /* Diagnostic: enqueue `n` one-wave no-op kernels on `stream` (host launch-rate probe used by
  * tools/launch_scaling.py; no reference counterpart). */
 int pcs_profile_launch_loop(int64_t n, pcs_stream_t stream);
+double pcs_profile_touch_loop(int64_t n_launch, int mode, int rows, pcs_stream_t stream);
 int pcs_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
 int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, pcs_stream_t stream);
 /* Diagnostic: n dependent kernels of `blocks` one-wave workgroups that each spin ~ticks x 10 ns. */

@@ -998,15 +998,29 @@ int pcs_profile_busy_loop(int64_t n, int ticks, int blocks, hipStream_t s) {
   return PCS_OK;
 }
 
+__global__ void touch_kernel(float4* buf, int mode, int n, int flip);
 // the same chain of dependent kernels as one captured graph launched n / nodes times: does the graph
 // executor shorten the device-side gap between dependent kernels? (tools/launch_scaling.py, mode graphN)
 int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, hipStream_t s) {
   if (nodes < 1) nodes = 1;
+  float4* tbuf = nullptr;
+  if (ticks < 0) {  // ticks < 0: the nodes are touch kernels (4096 threads load one row each)
+    PCS_CHECK_HIP(hipMalloc(&tbuf, 4096 * sizeof(float4)));
+    PCS_CHECK_HIP(hipMemsetAsync(tbuf, 0, 4096 * sizeof(float4), s));
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+  }
+  if (nodes == 1 && ticks < 0) {  // no graph: the same chain as plain stream launches
+    for (int64_t i = 0; i < n; ++i) touch_kernel<<<16, 256, 0, s>>>(tbuf, 0, 4096, 0);
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+    hipFree(tbuf);
+    return PCS_OK;
+  }
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   PCS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < nodes; ++i) {
     if (ticks > 0) busy_kernel<<<blocks, 64, 0, s>>>(ticks);
+    else if (ticks < 0) touch_kernel<<<16, 256, 0, s>>>(tbuf, 0, 4096, 0);
     else pcs::noop_kernel<<<1, 64, 0, s>>>();
   }
   PCS_CHECK_HIP(hipStreamEndCapture(s, &graph));
@@ -1015,6 +1029,7 @@ int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, hipStrea
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   hipGraphExecDestroy(exec);
   hipGraphDestroy(graph);
+  if (tbuf) hipFree(tbuf);
   return PCS_OK;
 }
 
@@ -1026,6 +1041,51 @@ int pcs_stream_create_cu_mask(const uint32_t* mask, int words, void** out) {
   PCS_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
   *out = (void*)s;
   return PCS_OK;
+}
+
+// What does a kernel that merely touches memory cost, begin to end, in a dependent chain? mode 0: every
+// thread loads one 16-B row and exits; 1: stores one; 2: kernels alternate store / load of the same
+// buffer; 3: loads a row, then a second one whose address depends on the first (two round trips).
+// Returns the mean begin-to-end time of one launch in microseconds (events on the dispatch).
+__global__ void touch_kernel(float4* buf, int mode, int n, int flip) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 1 || (mode == 2 && !flip)) {
+    buf[i] = make_float4((float)i, 0.f, 0.f, (float)flip);
+    return;
+  }
+  float4 v = buf[i];
+  if (mode == 3) {
+    int j = ((int)v.x + i * 7919) % n;
+    if (j < 0) j = -j;
+    v = buf[j];
+  }
+  if (v.y == 123.456f) buf[i].z = 1.f;  // never true: keeps the loads alive
+}
+double pcs_profile_touch_loop(int64_t n_launch, int mode, int rows, hipStream_t s) {
+  float4* buf = nullptr;
+  if (rows < 256) rows = 256;
+  if (hipMalloc(&buf, (size_t)rows * sizeof(float4)) != hipSuccess) return -1.0;
+  hipMemsetAsync(buf, 0, (size_t)rows * sizeof(float4), s);
+  const int reps = 64;
+  hipEvent_t ev[2 * reps];
+  for (int i = 0; i < 2 * reps; ++i) hipEventCreate(&ev[i]);
+  int blocks = (rows + 255) / 256;
+  double total = 0.0;
+  int64_t timed = 0;
+  for (int64_t done = 0; done < n_launch; done += reps) {
+    for (int r = 0; r < reps; ++r)
+      hipExtLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(256), 0, s, ev[2 * r], ev[2 * r + 1], 0, buf, mode,
+                            rows, r & 1);
+    hipStreamSynchronize(s);
+    for (int r = 0; r < reps; ++r) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]) == hipSuccess) { total += ms; ++timed; }
+    }
+  }
+  for (int i = 0; i < 2 * reps; ++i) hipEventDestroy(ev[i]);
+  hipFree(buf);
+  return timed ? total * 1e3 / (double)timed : -1.0;
 }
 
 int pcs_profile_launch_loop(int64_t n, hipStream_t s) {

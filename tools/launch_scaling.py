@@ -70,12 +70,28 @@ def run(mode, T, n):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--touch", action="store_true", help="only: begin-to-end time of launches that merely touch memory")
     ap.add_argument("--graphs", action="store_true", help="only: dependent chains as stream launches vs captured graphs")
     args = ap.parse_args()
     run("native", 1, 1000)
+    if args.touch:
+        # begin-to-end time of a launch that only touches memory, in a dependent chain on one stream
+        lib = L.load()
+        lib.pcs_profile_touch_loop.restype = ctypes.c_double
+        s = torch.cuda.Stream()
+        names = {0: "load one row per thread", 1: "store one row per thread", 2: "alternate store / load",
+                 3: "two dependent loads"}
+        for rows in (4096, 131072, 1048576):
+            for mode in (0, 1, 2, 3):
+                us = lib.pcs_profile_touch_loop(ctypes.c_int64(1024), ctypes.c_int(mode), ctypes.c_int(rows),
+                                                ctypes.c_void_p(s.cuda_stream))
+                print(f"touch rows={rows:8d} ({rows * 16 / 1e6:6.2f} MB) {names[mode]:26s} {us:6.2f} us per launch", flush=True)
+        sys.exit(0)
     if args.graphs:
         # 500 ticks = 5 us kernels, 64 workgroups: the size of an ICP iteration kernel
-        for mode in ("native", "graph24", "busy500x64", "graph24:500x64", "graph96:500x64"):
+        # graphN:-1x1 = chains of kernels that load one row per thread (N = 1: plain stream launches)
+        for mode in ("native", "graph24", "busy500x64", "graph24:500x64", "graph96:500x64", "graph1:-1x1",
+                     "graph24:-1x1", "graph96:-1x1"):
             for T in (1, 4):
                 r = run(mode, T, 9600)
                 print(f"{mode:16s} threads={T}  {1e6 / r * T:7.2f} us per kernel per chain  (aggregate {r / 1e3:7.1f} k kernels/s)",
