@@ -114,7 +114,6 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=None, help="concurrent tracking units per GPU (default 4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +130,7 @@ def main():
 
     host_batch = load_sequence(rank, args.frames, args.points)  # sequence s -> GPU s mod world
     batch = models.load_data_to_gpu(host_batch, device)
-    model = build_model(save=False, device=device, streams=args.streams)
+    model = build_model(save=False, device=device)
     lib = L.load()
 
     def step():
@@ -146,7 +145,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    lib.pcs_profile_icp_nn(ctypes.c_int(1))
+    lib.pcs_profile_icp(ctypes.c_int(1))
     timer.RECORDS.clear()
     barrier()
     t0 = time.perf_counter()
@@ -154,26 +153,11 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = (ctypes.c_double * 3)()
-    lib.pcs_profile_icp_nn_read(prof)
-    lib.pcs_profile_icp_nn(ctypes.c_int(0))
+    prof = (ctypes.c_double * 9)()
+    lib.pcs_profile_icp_read(prof)
+    lib.pcs_profile_icp(ctypes.c_int(0))
 
     units_in_flight = int(getattr(model.preprocessors[2], "last_num_workers", 0))
-    # cross-check for profiles/: one extra, untimed step on the serial schedule (one stream), where a
-    # launch has the chip to itself as it does under rocprofv3 (which cannot trace the threaded
-    # schedule on this image); reported beside the timed-region figure, never instead of it
-    prof_serial = (ctypes.c_double * 3)()
-    if rank == 0:
-        tracking_cfg = model.preprocessors[2].model_cfg
-        streams_was = tracking_cfg.get("NUM_STREAMS", 4)
-        tracking_cfg["NUM_STREAMS"] = 1
-        lib.pcs_profile_icp_nn(ctypes.c_int(1))
-        step()
-        torch.cuda.synchronize()
-        lib.pcs_profile_icp_nn_read(prof_serial)
-        lib.pcs_profile_icp_nn(ctypes.c_int(0))
-        tracking_cfg["NUM_STREAMS"] = streams_was
-
     total_sequences = float(args.steps)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -229,9 +213,6 @@ def main():
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                # same kernel on the serial schedule (extra untimed step): the figure the rocprofv3 summary
-                # under profiles/ (also serial) has to agree with
-                "avg_us_per_launch_serial": round(prof_serial[0] * 1e3 / max(prof_serial[1], 1), 2),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
             },
         }

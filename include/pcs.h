@@ -245,20 +245,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
                                pcs_stream_t stream);
 
-/* Opt the CALLING THREAD's pcs_register_to_next_frame calls into (group id g >= 1) / out of (0) a
- * shared launcher (one per group; threads that move in lock-step should share a group): concurrent calls from several host threads then hand their iteration chunks to one
- * launcher thread, which issues them as one array of problems per launch (kernels of different
- * streams overlap only 2-3 deep, the iteration kernels of one problem leave the device mostly
- * idle). Results are identical; pcs_track_frame switches it on for its own duration. The launcher
- * owns one stream and ~50 KB of descriptor memory per process (allocated on first use). */
-int pcs_icp_share_launches(int enable);
-/* Diagnostic: {batches, problems, seconds busy, seconds idle} of the shared launcher since the last
- * read (HOST doubles; reset on read). */
-int pcs_profile_batcher_read(double* out4);
-/* Diagnostic: {seconds waiting in the shared launcher, seconds inside pcs_register_to_next_frame} of
- * the calling thread since the last read (reset on read). */
-int pcs_profile_thread_icp_read(double* out2);
-
 /* smooth_velo, pcdet/models/registration/preprocessors/cluster_tracking.py:162-199 (<=300 AdamW
  * steps with MultiStepLR and a 3-strike stop, one persistent kernel). comp_velos [C,F,3] f32 is
  * updated in place (the reference's Parameter aliases its input the same way);
@@ -272,8 +258,8 @@ int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C
  * (with sample_frame :39-51, component_center / component_diameter / filter_components :89-160,
  * dist_compensate :80-87, smooth_velo :162-199 and the harvest through NN_GRAPH :702-741): tracks
  * the components of one anchor frame backward and forward through the sequence. The whole loop
- * runs inside this call on `stream` (BLOCKING: it reads a few words per step), so independent
- * anchors / component keys can be driven from independent host threads.
+ * runs inside this call on `stream` (BLOCKING: it reads a few words per chunk of ICP iterations).
+ * pcs_track_sequence below is the form for all anchors / component keys of a sequence at once.
  *   seq_fxyz [N,4] f32, seq_component [N] int64, seq_stationary [N] uint8: the sub-sampled
  *     sequence, rows grouped by ascending frame; frame_offsets: HOST [num_frames+1] row ranges.
  *   anchor_frame, [min_frame_id, max_frame_id]: the anchor and the window to track through.
@@ -285,8 +271,8 @@ int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C
  *     reg_errors, comp_edge_ratios [C, F] f32 and comp_velos [C, F, 3] f32 with F = max_frame_id + 1;
  *     comp_min_frame_id / comp_max_frame_id [C] int64; moving, valid_comp [C] uint8 (valid_comp =
  *     filter_components of the anchor). info: HOST int64[4] = {rows extracted, registration calls,
- *     frame steps, 0}. Returns PCS_ERR_RANGE when a search grid overflowed (caller falls back to
- *     the op-by-op host path). */
+ *     frame steps, host ticks}. Returns PCS_ERR_RANGE when a search grid overflowed (caller falls
+ *     back to the op-by-op host path). */
 #define PCS_TRACK_MAX_LEVELS 4
 typedef struct PcsTrackParams {
   int32_t num_levels;      /* REGISTRATION.GRAPH.RADIUS / VOXEL_SIZE / STOPPING_DELTA entries */
@@ -302,7 +288,7 @@ typedef struct PcsTrackParams {
   float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
   float max_diameter;      /* filter_components max_diameter (12.5) */
   float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
-  int32_t share_launches;  /* g >= 1: this call's ICP iterations go through pcs_icp_share_launches(g) */
+  int32_t reserved;        /* 0 */
 } PcsTrackParams;
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames);
@@ -314,6 +300,35 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
                     float* comp_velos, int64_t* comp_min_frame_id, int64_t* comp_max_frame_id,
                     uint8_t* moving, uint8_t* valid_comp, int64_t* info, void* ws, size_t ws_bytes,
                     pcs_stream_t stream);
+
+/* The tracking loop of ClusterTracking.forward (cluster_tracking.py:853-884: for every component
+ * key, for every anchor frame, track_frame) for ALL units of a sequence in one call: the units are
+ * independent, and each is a chain of small latency-bound launches, so one host thread advances
+ * them in lock-step -- every launch serves all units that are in the same phase, the ICP iterations
+ * of all units share their three launches -- on ONE stream. A unit's results are those of
+ * pcs_track_frame on the same inputs, bit for bit, whatever other units run beside it.
+ *   seq_fxyz / frame_offsets / num_frames: as for pcs_track_frame (shared by all units);
+ *   units[n_units] (HOST array, n_units <= 32): per unit its key's component ids and stationary
+ *     flags, the anchor and window, comp_base / C, and the output pointers of pcs_track_frame;
+ *     info is written by the call. */
+typedef struct PcsTrackUnit {
+  const int64_t* seq_component;   /* [N] int64 */
+  const uint8_t* seq_stationary;  /* [N] uint8 */
+  int32_t anchor_frame, min_frame_id, max_frame_id, pad_;
+  int64_t comp_base, C;
+  int64_t *ex_index, *ex_local, *ex_component;
+  int64_t ex_cap;
+  double* transforms;
+  float *reg_errors, *comp_edge_ratios, *comp_velos;
+  int64_t *comp_min_frame_id, *comp_max_frame_id;
+  uint8_t *moving, *valid_comp;
+  int64_t info[4];                /* out: rows extracted, registration calls, frame steps, host ticks */
+} PcsTrackUnit;
+size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_frames,
+                                          const PcsTrackUnit* units, int n_units);
+int pcs_track_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
+                       int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
+                       pcs_stream_t stream);
 
 /* points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168 (evaluation
  * side-channel of ClusterProposal / ClusterTracking): points [N,3], boxes [B,7]
@@ -358,25 +373,13 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
                         pcs_stream_t stream);
 
 /* Measurement support for bench.py (not on the data path): HIP-event timing, on the launch
- * stream, of the dominant kernel of the tracking stage (the fused ICP's two-direction 1-NN search +
- * pass-1 reduction). enable=1 resets and starts accumulating; read returns HOST doubles
- * {milliseconds, launches, algorithmic bytes}. The milliseconds are begin-to-end times of the
+ * stream, of the three kernels of a fused-ICP iteration (two-direction 1-NN search, moments, solve +
+ * apply). enable=1 resets and starts accumulating; read returns HOST doubles {milliseconds, launches,
+ * algorithmic bytes} x {search, moments, apply}. The milliseconds are begin-to-end times of the
  * launches themselves: the HIP events ride on the dispatch (hipExtLaunchKernelGGL), which is what
- * rocprofv3 reports as the kernel duration. */
-int pcs_profile_icp_nn(int enable);
-int pcs_profile_icp_nn_read(double* out3);
-
-/* Diagnostic: enqueue `n` one-wave no-op kernels on `stream` (host launch-rate probe used by
- * tools/launch_scaling.py; no reference counterpart). */
-int pcs_profile_launch_loop(int64_t n, pcs_stream_t stream);
-double pcs_profile_touch_loop(int64_t n_launch, int mode, int rows, pcs_stream_t stream);
-int pcs_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
-int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, pcs_stream_t stream);
-/* Diagnostic: n dependent kernels of `blocks` one-wave workgroups that each spin ~ticks x 10 ns. */
-int pcs_profile_busy_loop(int64_t n, int ticks, int blocks, pcs_stream_t stream);
-/* Diagnostic: n x {8 no-op launches, one small device->host read, stream sync}; mode 0 pageable
- * destination, 1 pinned destination, 2 pinned word written by a kernel. Allocates its own scratch. */
-int pcs_profile_sync_loop(int64_t n, int mode, pcs_stream_t stream);
+ * rocprofv3 reports as the kernel duration. Launches in which no problem was live are not counted. */
+int pcs_profile_icp(int enable);
+int pcs_profile_icp_read(double* out9);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per

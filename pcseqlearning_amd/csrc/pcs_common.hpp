@@ -59,6 +59,11 @@ struct Arena {
 // Per-thread page of pinned, device-visible host memory for the few status words a blocking entry
 // point reads back (implemented in pcs_prims.hip): the last kernel of a phase writes them there, so
 // the host needs only the stream synchronisation, not a device-to-host copy. nullptr if pinning fails.
+// Layout: [0, 4 KiB) ICP states, [4 KiB, 8 KiB) tracker states, [8 KiB, 64 KiB) staging of
+// descriptors on their way to the device (hipMemcpyAsync from pinned memory does not block).
+constexpr size_t kPinnedPageBytes = 65536;
+constexpr size_t kPinnedTrackerOff = 4096;
+constexpr size_t kPinnedStageOff = 8192;
 void* thread_pinned_page();
 
 // sorted unique on keys written by the caller into the workspace (pcs_voxel.hip)

@@ -89,14 +89,30 @@ __device__ __forceinline__ int g2_find(const Slot* __restrict__ base, uint32_t h
 // grid-stride reset of one grid (keys <- empty, counters / masks / spill count <- 0, frame ranges):
 // callable from any kernel whose grid is done with the table
 __device__ __forceinline__ void g2_clear(const Grid2& g, int64_t tid, int64_t nthreads) {
-  uint4* w = (uint4*)g.fslot;
   const uint4 empty = make_uint4(~0u, ~0u, 0u, 0u);
-  for (int64_t q = tid; q < (int64_t)g.slot_words; q += nthreads) w[q] = empty;
+  uint4* wf = (uint4*)g.fslot;
+  for (int64_t q = tid; q < (int64_t)g.Hf; q += nthreads) wf[q] = empty;
+  uint4* wc = (uint4*)g.cslot;
+  for (int64_t q = tid; q < (int64_t)g.Hc; q += nthreads) wc[q] = empty;
   for (int64_t q = tid; q < kFrameCells; q += nthreads) {
     g.fr[q] = __builtin_inff();
     g.fr[kFrameCells + q] = -__builtin_inff();
   }
   if (tid == 0) g.ovf[0] = 0;
+}
+
+// The same tables used at the size that `n` points need (n known on the device only): the arrays
+// are allocated for a capacity, hashed and reset at pow2(2 n). Every kernel that touches the grid
+// between two resets must form the view from the same n.
+__device__ __forceinline__ Grid2 g2_view(const Grid2& alloc, int n) {
+  Grid2 g = alloc;
+  uint32_t h = 64;
+  uint64_t want = 2 * (uint64_t)(n < 1 ? 1 : n);
+  while (h < want && h < alloc.Hf) h <<= 1;
+  g.Hf = h;
+  g.Hc = h < alloc.Hc ? h : alloc.Hc;
+  g.slot_words = (size_t)g.Hf + g.Hc;
+  return g;
 }
 
 static __global__ void __launch_bounds__(kBlock) g2_clear_kernel(Grid2 g) {

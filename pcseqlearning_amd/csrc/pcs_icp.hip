@@ -1,18 +1,19 @@
-// Fused per-component ICP ("TLS solve") for gfx950.
+// Fused per-component ICP ("TLS solve") for gfx950, batched.
 //
 // Reference: register_to_next_frame, pcdet/models/registration/preprocessors/
 // registration_utils.py:83-206. Per iteration the reference runs two radius-graph
 // builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
 // scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
 //
-// Here one call owns the whole loop; state stays in the caller's workspace. Iteration k is THREE
-// launches (the concurrent tracking units share a dispatch rate of a few hundred thousand kernels
-// per second, so launches are the currency):
+// Here a call is a descriptor in a device table (pcs_icp.hpp) and iteration k is THREE launches that
+// serve every problem of the batch (blockIdx.y = batch entry):
 //   nn         1-NN both directions, 32 lanes per query (two-level grid, pcs_grid2.hpp); workgroup
-//              0 first settles the stop rule of iteration k-1
+//              0 of each entry first settles the stop rule of iteration k-1
 //   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
-//              component (raw moments in f64; the centred covariance and the loss follow
-//              algebraically, so the reference's second pass over the edges is not needed)
+//              component as 64-bit fixed-point integers (LDS table per workgroup, then one integer
+//              atomic per (workgroup, component, accumulator)): order-free, hence bit-reproducible;
+//              the centred covariance and the loss follow algebraically, so the reference's second
+//              pass over the edges is not needed
 //   apply      every moving point solves its own component's regularised Kabsch step from the
 //              completed moments (cov + reg*T_rot -> rotation by Newton's polar iteration, Jacobi SVD
 //              when det <= 0; R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T) -- a
@@ -20,91 +21,24 @@
 //              reference stores them), the component's first point stores T and the loss term; the
 //              moved points go straight into the grid of iteration k+1 (double-buffered) and the grid
 //              just searched is reset
-// The three kernels take an ARRAY of problem descriptors (blockIdx.y = problem): a stand-alone call is
-// an array of one, concurrent calls can share launches (IcpBatcher below). Every kernel of iteration
-// k returns immediately when k > state.stop_iter, so the host enqueues iterations in chunks and
-// reads one word per chunk (through pinned memory) instead of one loss per iteration.
-// Per-component sums: a small LDS table keyed by component per workgroup, then one f64 hardware
-// atomic per (workgroup, component, accumulator).
-#include "pcs_grid2.hpp"
+// Every kernel of iteration k returns immediately when k > state.stop_iter, so the host enqueues
+// iterations in chunks and reads one word per chunk (through pinned memory) instead of one loss per
+// iteration. All kernels are grid-stride: the launch geometry never changes a result.
+#include "pcs_icp.hpp"
 
 #include <hip/hip_ext.h>
 
-#include <chrono>
-#include <climits>
-#include <condition_variable>
 #include <mutex>
-#include <thread>
-#include <vector>
 
 namespace pcs {
 
-__global__ void noop_kernel() {}
-
-
-struct IcpState {
-  double last_error;
-  double loss;
-  int countdown;
-  int stop_iter;  // iterations > stop_iter do not run (INT_MAX until the stop rule fires)
-  int iters;      // iterations solved so far
-  int err;
-  int decided;    // last iteration whose stop rule has been evaluated
-  int pad;
-};
-
-constexpr int kProfIters = 96;  // iterations per call whose icp_nn_kernel is timed when profiling
-constexpr int kAcc = 20;  // n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2, sum dist, sum clamp, pad
-
-struct IcpProblem;
-
-struct IcpBufs {
-  GridDesc* grid;
-  float *b_ref, *b_mov, *b_all;
-  IcpState* state;
-  Grid2 gr, ga;      // non-stationary reference, all reference (static)
-  Grid2 gm[2];       // moving points: iteration k searches gm[k & 1], its apply fills gm[(k+1) & 1]
-  int32_t *nn_f, *nn_b;  // [2, Mn] / [2, Rn]: buffer k & 1 holds iteration k's neighbours
-  float* prev;   // [Mn,4] positions before the last applied update
-  double* acc;   // [2, C, kAcc] raw moments, buffer k & 1 for iteration k
-  double* Tb;    // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
-  double* lossp; // [ceil(Mn / kBlock)] per-workgroup sums of the component losses, last applied iteration
-  int32_t* first; // [C] smallest moving-point index of the component (INT_MAX: none)
-
-  int32_t* cnt;  // [C] matched moving points in the final coverage query
-};
-
-// One ICP problem as the iteration kernels see it. The kernels take an ARRAY of these and
-// blockIdx.y selects the problem, so the iterations of several calls (the concurrent tracking units)
-// can share launches; a stand-alone call is an array of one.
-struct IcpProblem {
-  float4* mov;
-  float4* prev;
-  const float4* ref;
-  const int32_t* comp;
-  const int32_t* first;
-  int32_t *nn_f, *nn_b;
-  double *acc, *Tb, *lossp;
-  IcpState* st;
-  const GridDesc* grid;
-  Grid2 gr, gm[2];
-  int64_t C;
-  double reg, delta;
-  int Mn, Rn, df, nparts;
-  int k0;    // iteration number of chunk position 0
-  int n_it;  // chunk positions this problem takes part in
-  int probe_stage;  // 0 normal; timing probe (tools/icp_stages.py): the search returns after stage 1..3
-};
-
-static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
+bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
   if (Mn < 1) Mn = 1;
   if (Rn < 1) Rn = 1;
   if (Ra < 1) Ra = 1;
   if (C < 1) C = 1;
-  b.grid = a.take<GridDesc>(1);
-  b.b_ref = a.take<float>(24);  // ref, mov, all: 8 floats each, contiguous
-  b.b_mov = b.b_ref ? b.b_ref + 8 : nullptr;
-  b.b_all = b.b_ref ? b.b_ref + 16 : nullptr;
+  b.geom = a.take<IcpGeom>(1);
+  b.bounds = a.take<float>(24);  // ref, mov, all: 8 floats each
   b.state = a.take<IcpState>(1);
   plan_grid2(a, Rn, b.gr);
   plan_grid2(a, Mn, b.gm[0]);
@@ -113,90 +47,127 @@ static bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, Ic
   b.nn_f = a.take<int32_t>(2 * Mn);
   b.nn_b = a.take<int32_t>(2 * Rn);
   b.prev = a.take<float>(Mn * 4);
-  b.acc = a.take<double>(2 * C * kAcc);
+  b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
-  b.lossp = a.take<double>((Mn + kBlock - 1) / kBlock + 1);
+  b.lsc = a.take<double>(C);
+  b.corg = a.take<float4>(C);
   b.first = a.take<int32_t>(C);
-
-  b.cnt = a.take<int32_t>(C);
+  b.cov = a.take<int32_t>(C);
   return a.ok();
 }
 
-// grid origin padded so that points moved by the registration stay inside the 17-bit cell range
-__global__ void icp_setup_kernel(const float* __restrict__ b_ref, const float* __restrict__ b_mov,
-                                 const float* __restrict__ b_all, float radius, float cell,
-                                 float pad, GridDesc* __restrict__ g, IcpState* __restrict__ st) {
-  if (threadIdx.x != 0) return;
-  float mn[4];
-  for (int d = 0; d < 4; ++d) mn[d] = fminf(fminf(b_ref[d], b_mov[d]), b_all[d]);
-  float vs0 = (float)(1 - 1e-3);
-  g->vs0 = vs0;
-  g->lo0 = mn[0] - vs0 * 2.f;
-  for (int d = 0; d < 3; ++d) g->lo[d] = mn[1 + d] - pad;
-  g->h = cell;
-  g->radius = radius;
-  g->radius2 = radius * radius;
-  g->rings = (int)ceilf(radius / cell);
-  st->last_error = 1e10;
-  st->loss = 0.0;
-  st->countdown = 3;
-  st->stop_iter = INT_MAX;
-  st->iters = 0;
-  st->err = 0;
-  st->decided = 0;
+int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
+  if (!out || !ws || !a.T || !a.l1 || !a.ratio || a.C < 1 || a.Mn < 0 || a.Rn < 0 || a.Ra < 0 ||
+      !a.comp_deg || !(a.radius > 0) || a.max_iter < 0 || (a.Mn > 0 && (!a.mov || !a.comp)) ||
+      (a.Rn > 0 && !a.ref) || (a.Ra > 0 && !a.all))
+    return PCS_ERR_ARG;
+  if (a.Mn + a.Rn >= (1LL << 26)) return PCS_ERR_RANGE;
+  Arena ar(ws, ws_bytes);
+  IcpBufs b;
+  if (!plan_icp(ar, a.Mn, a.Rn, a.Ra, a.C, b)) return PCS_ERR_WORKSPACE;
+  IcpProblem& pr = *out;
+  // graph.radius = (radius^2 + frame_offset^2) ** 0.5, handed to the kernel as fp32
+  const double fo = (double)a.frame_offset;
+  pr.rad = (float)sqrt(a.radius * a.radius + fo * fo);
+  // fine cell = (largest admissible spatial distance) / 4, so that the 3x3x3 coarse blocks cover
+  // the search ball: |dxyz|^2 <= rad^2 - df^2 + margin with df = frame_offset for integer frame
+  // values (the kernel flags PCS_ERR_RANGE if the data violate that). cell_size may enlarge it.
+  double rad2 = (double)pr.rad * (double)pr.rad;
+  double budget = rad2 - fo * fo + (2e-5 * rad2 + 2e-6);
+  if (budget < a.radius * a.radius) budget = a.radius * a.radius;
+  pr.cell = (float)(sqrt(budget) * 0.25 * 1.0005);
+  if (a.cell_size > pr.cell) pr.cell = a.cell_size;
+  pr.pad = 4.f * (float)a.radius + 16.f;
+  pr.mov = (float4*)a.mov;
+  pr.prev = (float4*)b.prev;
+  pr.ref = (const float4*)a.ref;
+  pr.all = (const float4*)a.all;
+  pr.comp = a.comp;
+  pr.comp_deg = a.comp_deg;
+  pr.cnt3 = a.cnt3;
+  pr.first = b.first;
+  pr.nn_f = b.nn_f;
+  pr.nn_b = b.nn_b;
+  pr.acc = b.acc;
+  pr.Tb = b.Tb;
+  pr.lsc = b.lsc;
+  pr.corg = b.corg;
+  pr.cov = b.cov;
+  pr.st = b.state;
+  pr.geom = b.geom;
+  pr.bounds = b.bounds;
+  pr.gr = b.gr;
+  pr.ga = b.ga;
+  pr.gm[0] = b.gm[0];
+  pr.gm[1] = b.gm[1];
+  pr.T_out = a.T;
+  pr.l1_out = a.l1;
+  pr.ratio_out = a.ratio;
+  pr.C = a.C;
+  pr.reg = a.reg;
+  pr.delta = a.delta;
+  pr.Mn = (int)a.Mn;
+  pr.Rn = (int)a.Rn;
+  pr.Ra = (int)a.Ra;
+  pr.capM = (int)(a.Mn > 0 ? a.Mn : 1);
+  pr.capR = (int)(a.Rn > 0 ? a.Rn : 1);
+  pr.df = a.frame_offset;
+  pr.max_iter = a.max_iter;
+  return PCS_OK;
 }
 
-// start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, the three grids
-// <- empty (one launch instead of a dozen memsets)
+__device__ __forceinline__ long long to_fx(double v) { return __double2ll_rn(v * kFx); }
+
+// start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, state <- initial,
+// the four grids <- empty (one launch instead of a dozen memsets)
 __global__ void __launch_bounds__(kBlock)
-icp_clear_kernel(float* __restrict__ bounds24, double* __restrict__ Tb, double* __restrict__ acc,
-                 int32_t* __restrict__ first, int32_t* __restrict__ cnt, int64_t C, Grid2 gr, Grid2 gm0,
-                 Grid2 gm1, Grid2 ga) {
+icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int64_t C = pr.C;
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  if (i < 24) bounds24[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
+  if (i < 24) pr.bounds[i] = ((i & 7) < 4) ? 1e30f : -1e30f;
+  if (i == 0) {
+    IcpState* st = pr.st;
+    st->last_error = 1e10;
+    st->loss = 0.0;
+    st->countdown = 3;
+    st->stop_iter = INT_MAX;
+    st->iters = 0;
+    st->err = 0;
+    st->decided = 0;
+  }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {
     int e = (int)(q & 15);
-    Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
+    pr.Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
   }
-  for (int64_t q = i; q < 2 * C * kAcc; q += stride) acc[q] = 0.0;
-  for (int64_t q = i; q < C; q += stride) { cnt[q] = 0; first[q] = INT_MAX; }
-  g2_clear(gr, i, stride);
-  g2_clear(gm0, i, stride);
-  g2_clear(gm1, i, stride);
-  g2_clear(ga, i, stride);
+  for (int64_t q = i; q < 2 * C * kAcc; q += stride) pr.acc[q] = 0;
+  for (int64_t q = i; q < C; q += stride) { pr.cov[q] = 0; pr.first[q] = INT_MAX; pr.lsc[q] = 0.0; }
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  g2_clear(g2_view(pr.gr, Rn), i, stride);
+  g2_clear(g2_view(pr.gm[0], Mn), i, stride);
+  g2_clear(g2_view(pr.gm[1], Mn), i, stride);
+  g2_clear(g2_view(pr.ga, Ra), i, stride);
 }
 
-// the three grids of a call in one launch: blockIdx.y = 0 non-stationary reference, 1 all reference,
-// 2 the moving points as they arrive (the grid of iteration 1)
+// min / max of the three clouds: blockIdx.z selects the cloud; also the owner (smallest index) of
+// every component among the moving points
 __global__ void __launch_bounds__(kBlock)
-icp_insert3_kernel(const float4* __restrict__ ref, int Rn, const float4* __restrict__ all, int Ra,
-                   const float4* __restrict__ mov, int Mn, const GridDesc* __restrict__ gp, Grid2 gr,
-                   Grid2 ga, Grid2 gm1, IcpState* __restrict__ st) {
-  const float4* pts = blockIdx.y == 0 ? ref : (blockIdx.y == 1 ? all : mov);
-  const int n = blockIdx.y == 0 ? Rn : (blockIdx.y == 1 ? Ra : Mn);
+icp_bounds_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int which = blockIdx.z;
+  const float4* pts = which == 0 ? pr.ref : (which == 1 ? (const float4*)pr.mov : pr.all);
+  const int n = which == 0 ? Rn : (which == 1 ? Mn : Ra);
   if ((int64_t)blockIdx.x * kBlock >= n) return;
-  const Grid2& g = blockIdx.y == 0 ? gr : (blockIdx.y == 1 ? ga : gm1);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  GridDesc d = *gp;
-  bool in = i < n;
-  float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  g2_insert_point(d, g, in, i, p, &st->err);
-}
-
-// min / max of the three clouds in one launch: blockIdx.y selects the cloud
-__global__ void __launch_bounds__(kBlock)
-icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restrict__ mov, int Mn,
-                  const float4* __restrict__ all, int Ra, float* __restrict__ bounds24,
-                  const int32_t* __restrict__ comp, int32_t* __restrict__ first) {
-  const float4* pts = blockIdx.y == 0 ? ref : (blockIdx.y == 1 ? mov : all);
-  int n = blockIdx.y == 0 ? Rn : (blockIdx.y == 1 ? Mn : Ra);
-  float* out8 = bounds24 + 8 * blockIdx.y;
+  float* out8 = pr.bounds + 8 * which;
   float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
   float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pts[i];
-    if (blockIdx.y == 1) atomicMin(&first[comp[i]], i);  // the thread that will own the component's T
+    if (which == 1) atomicMin(&pr.first[pr.comp[i]], i);  // the thread that will own the component's T
     mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
     mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
     mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
@@ -210,7 +181,7 @@ icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restri
     if (lane == 0) { smn[w][d] = a; smx[w][d] = b; }
   }
   __syncthreads();
-  if (threadIdx.x < 4 && n > 0) {
+  if (threadIdx.x < 4) {
     int d = threadIdx.x;
     float a = smn[0][d], b = smx[0][d];
     for (int k = 1; k < kBlock / 64; ++k) { a = fminf(a, smn[k][d]); b = fmaxf(b, smx[k][d]); }
@@ -219,15 +190,67 @@ icp_bounds_kernel(const float4* __restrict__ ref, int Rn, const float4* __restri
   }
 }
 
+// grid origin padded so that points moved by the registration stay inside the 17-bit cell range;
+// origin of every component's fixed-point moments = its first moving point as it arrives (any fixed
+// point near the component would do: the moments are translation-invariant where they are used, the
+// origin only keeps the integers small)
+__global__ void __launch_bounds__(kBlock)
+icp_setup_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < pr.C; c += (int64_t)gridDim.x * blockDim.x) {
+    int f = pr.first[c];
+    pr.corg[c] = f != INT_MAX ? pr.mov[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float* b_ref = pr.bounds;
+  const float* b_mov = pr.bounds + 8;
+  const float* b_all = pr.bounds + 16;
+  GridDesc* g = &pr.geom->g;
+  float mn[4];
+  for (int d = 0; d < 4; ++d) mn[d] = fminf(fminf(b_ref[d], b_mov[d]), b_all[d]);
+  float vs0 = (float)(1 - 1e-3);
+  g->vs0 = vs0;
+  g->lo0 = mn[0] - vs0 * 2.f;
+  for (int d = 0; d < 3; ++d) g->lo[d] = mn[1 + d] - pr.pad;
+  g->h = pr.cell;
+  g->radius = pr.rad;
+  g->radius2 = pr.rad * pr.rad;
+  g->rings = (int)ceilf(pr.rad / pr.cell);
+}
+
+// the three grids of a call in one launch: blockIdx.z = 0 non-stationary reference, 1 all reference,
+// 2 the moving points as they arrive (the grid of iteration 1)
+__global__ void __launch_bounds__(kBlock)
+icp_insert3_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int which = blockIdx.z;
+  const float4* pts = which == 0 ? pr.ref : (which == 1 ? pr.all : (const float4*)pr.mov);
+  const int n = which == 0 ? Rn : (which == 1 ? Ra : Mn);
+  if ((int64_t)blockIdx.x * kBlock >= n) return;
+  const Grid2 g = g2_view(which == 0 ? pr.gr : (which == 1 ? pr.ga : pr.gm[1]), n);
+  GridDesc d = pr.geom->g;
+  const int nround = (n + kBlock - 1) / kBlock;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
+    int i = r * kBlock + threadIdx.x;
+    bool in = i < n;
+    float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    g2_insert_point(d, g, in, i, p, &pr.st->err);
+  }
+}
+
 // loss-delta / 3-strike stop rule of iteration k_done (registration_utils.py:186-193), evaluated by
-// ONE workgroup from the per-workgroup loss partials of the apply launch (fixed reduction tree). It may lower stop_iter to
-// k_done, which still admits every kernel of iteration k_done.
-__device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const double* __restrict__ lossp,
-                                           int nparts, int k_done, double delta) {
+// ONE workgroup from the per-component loss terms of the apply launch, summed in component order by
+// a fixed tree (independent of every launch geometry). It may lower stop_iter to k_done, which still
+// admits every kernel of iteration k_done.
+__device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
   __shared__ double red[kBlock / 64];
+  IcpState* st = pr.st;
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
   double part = 0.0;
-  for (int q = threadIdx.x; q < nparts; q += kBlock) part += lossp[q];
+  const int C = (int)pr.C;
+  for (int q = threadIdx.x; q < C; q += kBlock) part += pr.lsc[q];
   part = wave_sum_f64(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
@@ -235,7 +258,7 @@ __device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const doub
     double loss = 0.0;
     for (int q = 0; q < kBlock / 64; ++q) loss += red[q];
     st->loss = loss;
-    if (st->last_error - loss < delta) st->countdown -= 1;
+    if (st->last_error - loss < pr.delta) st->countdown -= 1;
     else st->countdown = 3;
     if (st->countdown <= 0) st->stop_iter = k_done;
     else st->last_error = loss;
@@ -243,182 +266,161 @@ __device__ __forceinline__ void icp_decide(IcpState* __restrict__ st, const doub
   }
 }
 
-// end of a chunk: the stop rule of every problem's last iteration (the others were settled by the
+// end of a chunk: the stop rule of every entry's last iteration (the others were settled by the
 // next search launch), and the state mirrored where the host reads it (`out` may be pinned host
 // memory: the host then needs no copy, only the stream synchronisation)
 __global__ void __launch_bounds__(kBlock)
-icp_decide_kernel(const IcpProblem* __restrict__ P, int kbase, IcpState* __restrict__ out) {
-  const IcpProblem& pr = P[blockIdx.y];
-  icp_decide(pr.st, pr.lossp, pr.nparts, pr.k0 + kbase + pr.n_it - 1, pr.delta);
+icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int n_it,
+                  IcpState* __restrict__ out) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.x]];
+  int k_last = kbase.v[blockIdx.x] + n_it;
+  if (k_last > pr.max_iter) k_last = pr.max_iter;
+  if (k_last > pr.st->iters) k_last = pr.st->iters;  // iterations that did not run have no loss
+  icp_decide(pr, k_last);
   __syncthreads();
-  if (out && threadIdx.x == 0) out[blockIdx.y] = *pr.st;
-}
-__global__ void __launch_bounds__(kBlock)
-icp_decide_kernel_v(const IcpProblem pr, int kbase, IcpState* __restrict__ out) {
-  icp_decide(pr.st, pr.lossp, pr.nparts, pr.k0 + kbase + pr.n_it - 1, pr.delta);
-  __syncthreads();
-  if (out && threadIdx.x == 0) out[0] = *pr.st;
-}
-
-// one f64 atomic per (wave, component, accumulator): lanes sharing a component are summed by
-// 64-lane butterflies first. All 64 lanes must call this.
-template <int NV>
-__device__ __forceinline__ void grouped_atomic_add(bool active, int key, const double (&v)[NV],
-                                                   double* __restrict__ base, int stride) {
-  int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(active);
-  while (todo) {
-    int leader = __ffsll((long long)todo) - 1;
-    int lkey = __shfl(key, leader, 64);
-    bool mine = active && key == lkey;
-    unsigned long long grp = __ballot(mine);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      double x = wave_sum_f64(mine ? v[i] : 0.0);
-      if (lane == leader) atomicAdd(&base[(int64_t)lkey * stride + i], x);
-    }
-    todo &= ~grp;
-  }
+  if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;
 }
 
 // 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
 // queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
-__device__ __forceinline__ void icp_nn_kernel_body(const IcpProblem& pr, int j, int kbase) {
-  if (j >= pr.n_it) return;
-  const int k = pr.k0 + kbase + j;
+__global__ void __launch_bounds__(kBlock)
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
-  if (k > st->stop_iter) return;
-  const int Mn = pr.Mn, Rn = pr.Rn;
-  if (blockIdx.x != 0 && (int64_t)blockIdx.x * (kBlock / 32) >= (int64_t)Mn + Rn) return;
-  // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss partials
+  if (k > pr.max_iter || k > st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int nq = Mn + Rn;
+  const int nround = (nq + kBlock / 32 - 1) / (kBlock / 32);
+  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (blockIdx.x == 0) icp_decide(st, pr.lossp, pr.nparts, k - 1, pr.delta);
-  GridDesc g = *pr.grid;
-  int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  int sub = threadIdx.x & 31;
-  bool fwd = qid < Mn;
-  bool valid = qid < Mn + Rn;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
-  // a wave may straddle the forward/backward boundary: its two halves then search different grids
-  bool any_fwd = __ballot(valid && fwd) != 0;
-  bool any_bwd = __ballot(valid && !fwd) != 0;
-  int res = -1;
-  if (pr.probe_stage == 1) {  // timing probe: launch + head loads only (stages 11.. belong to apply)
-    if (valid && sub == 0 && p.x == 1.2345e30f) pr.nn_f[0] = 0;
-    return;
+  if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  GridDesc g = pr.geom->g;
+  const int sub = threadIdx.x & 31;
+  int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
+  int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
+  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    int qid = r * (kBlock / 32) + (threadIdx.x >> 5);
+    bool fwd = qid < Mn;
+    bool valid = qid < nq;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
+    // a wave may straddle the forward/backward boundary: its two halves then search different grids
+    bool any_fwd = __ballot(valid && fwd) != 0;
+    bool any_bwd = __ballot(valid && !fwd) != 0;
+    int res = -1;
+    if (any_fwd) {
+      int rr = g2_nearest_coop(g, g_ref, p, pr.df, valid && fwd, &st->err);
+      if (fwd) res = rr;
+    }
+    if (any_bwd) {
+      int rr = g2_nearest_coop(g, g_mov, p, -pr.df, valid && !fwd, &st->err);
+      if (!fwd) res = rr;
+    }
+    if (valid && sub == 0) {
+      if (fwd) nn_f[qid] = res;
+      else nn_b[qid - Mn] = res;
+    }
   }
-  if (any_fwd) {
-    int r = g2_nearest_coop(g, pr.gr, p, pr.df, valid && fwd, &st->err, nullptr, pr.probe_stage);
-    if (fwd) res = r;
-  }
-  if (any_bwd) {
-    int r = g2_nearest_coop(g, pr.gm[k & 1], p, -pr.df, valid && !fwd, &st->err, nullptr, pr.probe_stage);
-    if (!fwd) res = r;
-  }
-  if (valid && sub == 0) {
-    if (fwd) pr.nn_f[(size_t)(k & 1) * (Mn > 0 ? Mn : 1) + qid] = res;
-    else pr.nn_b[(size_t)(k & 1) * (Rn > 0 ? Rn : 1) + (qid - Mn)] = res;
-  }
-}
-
-// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
-// sits in the kernel-argument segment, one dependent global load less at the head of the launch
-__global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  icp_nn_kernel_body(P[blockIdx.y], j, kbase);
-}
-__global__ void __launch_bounds__(kBlock)
-icp_nn_kernel_v(const IcpProblem pr, int j, int kbase) {
-  icp_nn_kernel_body(pr, j, kbase);
 }
 
 // raw moments of the matched pairs per component, one thread per potential edge. Each workgroup
-// first accumulates into a small LDS table keyed by component (ds_add_f64; neighbouring edges
-// mostly share a component), then flushes one global f64 atomic per (component, accumulator).
+// first accumulates into a small LDS table keyed by component (64-bit integer LDS adds; neighbouring
+// edges mostly share a component), then flushes one global integer atomic per (component,
+// accumulator). Integer sums: the result does not depend on any arrival order.
 constexpr int kMomSlots = 64;
-__device__ __forceinline__ void icp_moments_kernel_body(const IcpProblem& pr, int j, int kbase) {
-  if (j >= pr.n_it) return;
-  const int k = pr.k0 + kbase + j;
-  if (k > pr.st->stop_iter) return;
-  const int Mn = pr.Mn, Rn = pr.Rn;
-  if ((int64_t)blockIdx.x * kBlock >= (int64_t)Mn + Rn) return;
+__global__ void __launch_bounds__(kBlock)
+icp_moments_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  if (k > pr.max_iter || k > pr.st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int ne = Mn + Rn;
+  const int nround = (ne + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= nround) return;
   const float4* __restrict__ mov = pr.mov;
   const float4* __restrict__ ref = pr.ref;
   const int32_t* __restrict__ comp = pr.comp;
-  const int32_t* __restrict__ nn_f = pr.nn_f + (size_t)(k & 1) * (Mn > 0 ? Mn : 1);
-  const int32_t* __restrict__ nn_b = pr.nn_b + (size_t)(k & 1) * (Rn > 0 ? Rn : 1);
-  double* __restrict__ acc = pr.acc + (size_t)(k & 1) * pr.C * kAcc;
+  const int32_t* __restrict__ nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
+  const int32_t* __restrict__ nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
+  unsigned long long* __restrict__ acc = (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc;
+  const double lim2 = icp_limit_sq(ne);
   __shared__ int skey[kMomSlots];
-  __shared__ double sacc[kMomSlots][17];
-  for (int q = threadIdx.x; q < kMomSlots; q += kBlock) skey[q] = -1;
-  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) (&sacc[0][0])[q] = 0.0;
-  __syncthreads();
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool active = false;
-  int c = 0, m = -1, r = -1;
-  if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
-  else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
-  if (active) {
-    float4 pf = mov[m], qf = ref[r];
-    c = comp[m];
-    double p[3] = {pf.y, pf.z, pf.w}, q[3] = {qf.y, qf.z, qf.w};
-    double v[17];
-    v[0] = 1.0;
-    double d2 = 0.0;
+  __shared__ unsigned long long sacc[kMomSlots][17];
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    for (int q = threadIdx.x; q < kMomSlots; q += kBlock) skey[q] = -1;
+    for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) (&sacc[0][0])[q] = 0ULL;
+    __syncthreads();
+    int i = r * kBlock + threadIdx.x;
+    bool active = false;
+    int c = 0, m = -1, rr = -1;
+    if (i < Mn) { m = i; rr = nn_f[i]; active = rr >= 0; }
+    else if (i < ne) { rr = i - Mn; m = nn_b[rr]; active = m >= 0; }
+    if (active) {
+      float4 pf = mov[m], qf = ref[rr];
+      c = comp[m];
+      const float4 og = pr.corg[c];
+      double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
+      double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
+      if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
+        pr.st->err = 1;  // a component too large for the fixed-point range
+      unsigned long long v[17];
+      v[0] = 1ULL;
+      double d2 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      v[1 + a] = p[a];
-      v[4 + a] = q[a];
+      for (int a = 0; a < 3; ++a) {
+        v[1 + a] = (unsigned long long)to_fx(p[a]);
+        v[4 + a] = (unsigned long long)to_fx(q[a]);
 #pragma unroll
-      for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = p[a] * q[b];
-      double e = p[a] - q[a];
-      d2 += e * e;
+        for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = (unsigned long long)to_fx(p[a] * q[b]);
+        double e = p[a] - q[a];
+        d2 += e * e;
+      }
+      v[16] = (unsigned long long)to_fx(d2);
+      // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
+      int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
+      int found = -1;
+      for (int t = 0; t < kMomSlots; ++t) {
+        int old = atomicCAS(&skey[slot], -1, c);
+        if (old == -1 || old == c) { found = slot; break; }
+        slot = (slot + 1) & (kMomSlots - 1);
+      }
+      if (found >= 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&sacc[found][q2], v[q2]);
+      } else {
+#pragma unroll
+        for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&acc[(int64_t)c * kAcc + q2], v[q2]);
+      }
     }
-    v[16] = d2;
-    // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
-    int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
-    int found = -1;
-    for (int t = 0; t < kMomSlots; ++t) {
-      int old = atomicCAS(&skey[slot], -1, c);
-      if (old == -1 || old == c) { found = slot; break; }
-      slot = (slot + 1) & (kMomSlots - 1);
+    __syncthreads();
+    for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
+      int sl = q / 17, a = q - sl * 17;
+      int key = skey[sl];
+      if (key >= 0) atomicAdd(&acc[(int64_t)key * kAcc + a], sacc[sl][a]);
     }
-    if (found >= 0) {
-#pragma unroll
-      for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&sacc[found][q2], v[q2]);
-    } else {
-#pragma unroll
-      for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&acc[(int64_t)c * kAcc + q2], v[q2]);
-    }
-  }
-  __syncthreads();
-  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
-    int sl = q / 17, a = q - sl * 17;
-    int key = skey[sl];
-    if (key >= 0) atomicAdd(&acc[(int64_t)key * kAcc + a], sacc[sl][a]);
+    __syncthreads();
   }
 }
 
-// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
-// sits in the kernel-argument segment, one dependent global load less at the head of the launch
-__global__ void __launch_bounds__(kBlock)
-icp_moments_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  icp_moments_kernel_body(P[blockIdx.y], j, kbase);
-}
-__global__ void __launch_bounds__(kBlock)
-icp_moments_kernel_v(const IcpProblem pr, int j, int kbase) {
-  icp_moments_kernel_body(pr, j, kbase);
-}
-
-// centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151)
-__device__ __forceinline__ void centres(const double* __restrict__ a, double* cm, double* cr) {
-  double n = a[0];
+// centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151);
+// cs = the same centres relative to the moment origin
+__device__ __forceinline__ void centres(const long long* __restrict__ a, const double* org,
+                                        double* cm, double* cr, double* sp, double* sq) {
+  double n = (double)a[0];
+  for (int d = 0; d < 3; ++d) {
+    sp[d] = (double)a[1 + d] * kFxInv;
+    sq[d] = (double)a[4 + d] * kFxInv;
+  }
   if (n > 0.5) {
     for (int d = 0; d < 3; ++d) {
-      cm[d] = (double)(float)(a[1 + d] / n);
-      cr[d] = (double)(float)(a[4 + d] / n);
+      cm[d] = (double)(float)(sp[d] / n + org[d]);
+      cr[d] = (double)(float)(sq[d] / n + org[d]);
     }
   } else {
     for (int d = 0; d < 3; ++d) cm[d] = cr[d] = 0.0;
@@ -426,36 +428,50 @@ __device__ __forceinline__ void centres(const double* __restrict__ a, double* cm
 }
 
 // l1 passes on the positions saved before the last update. MODE 0: sum of dist; MODE 1: sum of
-// dist clamped to mean +- trunc (truncated_robust_mean, registration_utils.py:44-58).
+// dist clamped to mean +- trunc (truncated_robust_mean, registration_utils.py:44-58). Fixed-point
+// integer sums, like the moments.
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
-icp_l1_kernel(const float4* __restrict__ mov, int Mn, const float4* __restrict__ ref, int Rn,
-              const int32_t* __restrict__ comp, const int32_t* __restrict__ nn_f,
-              const int32_t* __restrict__ nn_b, double* __restrict__ acc, double trunc) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool active = false;
-  int c = 0, m = -1, r = -1;
-  if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
-  else if (i < Mn + Rn) { r = i - Mn; m = nn_b[r]; active = m >= 0; }
-  double v[1] = {0.0};
-  if (active) {
-    c = comp[m];
+icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int iters = pr.st->iters;
+  if (iters < 1) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int ne = Mn + Rn;
+  const float4* __restrict__ mov = pr.prev;
+  const float4* __restrict__ ref = pr.ref;
+  const int32_t* __restrict__ comp = pr.comp;
+  const int32_t* __restrict__ nn_f = pr.nn_f + (size_t)(iters & 1) * pr.capM;
+  const int32_t* __restrict__ nn_b = pr.nn_b + (size_t)(iters & 1) * pr.capR;
+  long long* __restrict__ acc = pr.acc + (size_t)(iters & 1) * pr.C * kAcc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+    int m = -1, r = -1;
+    bool active = false;
+    if (i < Mn) { m = i; r = nn_f[i]; active = r >= 0; }
+    else { r = i - Mn; m = nn_b[r]; active = m >= 0; }
+    if (!active) continue;
+    int c = comp[m];
     float4 p = mov[m], q = ref[r];
-    const double* a = acc + (int64_t)c * kAcc;
-    double cm[3], cr[3];
-    centres(a, cm, cr);
+    const long long* a = acc + (int64_t)c * kAcc;
+    const float4 og = pr.corg[c];
+    const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
+    double cm[3], cr[3], sp[3], sq[3];
+    centres(a, org, cm, cr, sp, sq);
     double e0 = ((double)p.y - cm[0]) - ((double)q.y - cr[0]);
     double e1 = ((double)p.z - cm[1]) - ((double)q.z - cr[1]);
     double e2 = ((double)p.w - cm[2]) - ((double)q.w - cr[2]);
     double dist = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    double v;
     if (MODE == 0) {
-      v[0] = dist;
+      v = dist;
     } else {
-      double mean = a[17] / a[0];
-      v[0] = fmin(fmax(dist, mean - trunc), mean + trunc);
+      double mean = ((double)a[17] * kFxInv) / (double)a[0];
+      v = fmin(fmax(dist, mean - trunc), mean + trunc);
     }
+    atomicAdd((unsigned long long*)&acc[(int64_t)c * kAcc + (MODE == 0 ? 17 : 18)],
+              (unsigned long long)to_fx(v));
   }
-  grouped_atomic_add<1>(active, c, v, acc + (MODE == 0 ? 17 : 18), kAcc);
 }
 
 // ---- 3x3 SVD by one-sided Jacobi (f64), singular values descending ----
@@ -533,17 +549,21 @@ __device__ inline double det3(const double A[9]) {
 
 // regularised Kabsch step of one component from its raw moments `a` and accumulated transform Tc:
 // rotation R, translation t, updated transform Tn = [R t] Tc and the component's loss term
-__device__ inline void icp_solve_component(const double* __restrict__ a, const double* __restrict__ Tc,
-                                           double reg, double R[9], double t[3], double Tn[16],
-                                           double* ls_out) {
-  double n = a[0];
-  double cm[3], cr[3];
-  centres(a, cm, cr);
+__device__ inline void icp_solve_component(const long long* __restrict__ a, const double* org,
+                                           const double* __restrict__ Tc, double reg, double R[9],
+                                           double t[3], double Tn[16], double* ls_out) {
+  double n = (double)a[0];
+  double cm[3], cr[3], sp[3], sq[3];
+  centres(a, org, cm, cr, sp, sq);
+  double cms[3], crs[3];  // centres relative to the moment origin
+  for (int d = 0; d < 3; ++d) { cms[d] = cm[d] - org[d]; crs[d] = cr[d] - org[d]; }
   double M[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
-      // sum P(x)Q = sum p q^T - cm sum q^T - sum p cr^T + n cm cr^T;  robust_mean divides by n
-      double cov = a[7 + i * 3 + j] - cm[i] * a[4 + j] - a[1 + i] * cr[j] + n * cm[i] * cr[j];
+      // sum P(x)Q = sum p q^T - cm sum q^T - sum p cr^T + n cm cr^T (coordinates relative to the
+      // origin: the expression is translation-invariant);  robust_mean divides by n
+      double spq = (double)a[7 + i * 3 + j] * kFxInv;
+      double cov = spq - cms[i] * sq[j] - sp[i] * crs[j] + n * cms[i] * crs[j];
       if (n > 0.5) cov = cov / n; else cov = 0.0;
       M[i * 3 + j] = cov + Tc[i * 4 + j] * reg;
     }
@@ -612,10 +632,10 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
   // sum |P - Q|^2 = sum |p-q|^2 - 2 d . sum(p-q) + n |d|^2,  d = cm - cr
   double ls = 0.0;
   if (n > 0.5) {
-    ls = a[16];
+    ls = (double)a[16] * kFxInv;
     for (int q = 0; q < 3; ++q) {
       double d = cm[q] - cr[q];
-      ls += -2.0 * d * (a[1 + q] - a[4 + q]) + n * d * d;
+      ls += -2.0 * d * (sp[q] - sq[q]) + n * d * d;
     }
   }
   *ls_out = ls;
@@ -627,356 +647,227 @@ __device__ inline void icp_solve_component(const double* __restrict__ a, const d
 // buffer k) and the loss term. The previous positions are kept for the l1 passes. The moved points go
 // straight into the grid of the next iteration (the moving grid is double-buffered: no separate
 // build launch), and the grid this iteration searched is reset.
-__device__ __forceinline__ void icp_apply_kernel_body(const IcpProblem& pr, int j, int kbase) {
-  if (j >= pr.n_it) return;
-  const int k = pr.k0 + kbase + j;
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
-  if (k > st->stop_iter) return;
-  if ((int)blockIdx.x >= pr.nparts) return;
-  const int Mn = pr.Mn;
+  if (k > pr.max_iter || k > st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
   const int64_t C = pr.C;
   const double reg = pr.reg;
   float4* __restrict__ mov = pr.mov;
   float4* __restrict__ prev = pr.prev;
   const int32_t* __restrict__ comp = pr.comp;
   const int32_t* __restrict__ first = pr.first;
-  double* __restrict__ acc2 = pr.acc;
+  long long* __restrict__ acc2 = pr.acc;
   double* __restrict__ Tb = pr.Tb;
-  double* __restrict__ lossp = pr.lossp;
-  const GridDesc* __restrict__ gp = pr.grid;
-  const Grid2& gm_done = pr.gm[k & 1];
-  const Grid2& gm_next = pr.gm[(k + 1) & 1];
-  __shared__ double red[kBlock / 64];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
+  const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
-  g2_clear(gm_done, i, (int64_t)pr.nparts * blockDim.x);
-  if (i == 0) st->iters = k;
-
-  double ls_mine = 0.0;
-  float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int probe = pr.probe_stage;  // timing probe, stages 11..13 cut this kernel short
-  if (probe == 11) {  // launch + grid reset + head loads
-    if (i < Mn && comp[i] == -12345) lossp[0] = 0.0;
-    return;
-  }
-  if (i < Mn) {
-    int c = comp[i];
-    const double* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
-    const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
-    double R[9], t[3], Tn[16], ls;
-    icp_solve_component(a, Tc, reg, R, t, Tn, &ls);
-    if (probe == 12) {  // + moments / transform loads + the solve
-      if (R[0] == -12345.0) lossp[0] = ls;
-      return;
+  g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
+  if (tid == 0) st->iters = k;
+  const GridDesc d = pr.geom->g;
+  const int nround = (Mn + kBlock - 1) / kBlock;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
+    const int i = r * kBlock + threadIdx.x;
+    float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < Mn) {
+      int c = comp[i];
+      const long long* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
+      const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
+      const float4 og = pr.corg[c];
+      const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
+      double R[9], t[3], Tn[16], ls;
+      icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
+      float4 p = mov[i];
+      prev[i] = p;
+      double x = p.y, y = p.z, z = p.w;
+      float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
+      float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
+      float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
+      moved = make_float4(p.x, nx, ny, nz);
+      mov[i] = moved;
+      if (first[c] == i) {
+        // the component's owner: transform, loss term, and the other moment buffer zeroed for the
+        // next iteration (nothing reads it during this launch)
+        double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
+        for (int q = 0; q < 16; ++q) To[q] = Tn[q];
+        long long* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
+        for (int q = 0; q < kAcc; ++q) an[q] = 0;
+        pr.lsc[c] = ls;
+      }
     }
-    float4 p = mov[i];
-    prev[i] = p;
-    double x = p.y, y = p.z, z = p.w;
-    float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
-    float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
-    float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
-    moved = make_float4(p.x, nx, ny, nz);
-    mov[i] = moved;
-    if (first[c] == i) {
-      // the component's owner: transform, loss term, and the other moment buffer zeroed for the
-      // next iteration (nothing reads it during this launch)
-      double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
-      for (int q = 0; q < 16; ++q) To[q] = Tn[q];
-      double* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
-      for (int q = 0; q < kAcc; ++q) an[q] = 0.0;
-      ls_mine = ls;
-    }
-  }
-  if (probe == 13) return;  // + move and stores, without the grid insert and the loss reduction
-  {
-    GridDesc d = *gp;
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
-
-  // loss partial of this workgroup (fixed order: lanes, then waves)
-  ls_mine = wave_sum_f64(ls_mine);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls_mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int q = 0; q < kBlock / 64; ++q) tot += red[q];
-    lossp[blockIdx.x] = tot;
-  }
-}
-
-// array form (blockIdx.y = problem) and by-value form for a single problem: the descriptor then
-// sits in the kernel-argument segment, one dependent global load less at the head of the launch
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(const IcpProblem* __restrict__ P, int j, int kbase) {
-  icp_apply_kernel_body(P[blockIdx.y], j, kbase);
-}
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel_v(const IcpProblem pr, int j, int kbase) {
-  icp_apply_kernel_body(pr, j, kbase);
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
 __global__ void __launch_bounds__(kBlock)
-icp_coverage_kernel(const float4* __restrict__ mov, int Mn, const int32_t* __restrict__ comp,
-                    const GridDesc* __restrict__ gp, int df, Grid2 ga, IcpState* __restrict__ st,
-                    int32_t* __restrict__ cnt) {
-  GridDesc g = *gp;
-  int qid = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  bool valid = qid < Mn;
-  float4 p = valid ? mov[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
-  int r = g2_nearest_coop(g, ga, p, df, valid, &st->err);
-  if (valid && (threadIdx.x & 31) == 0 && r >= 0) atomicAdd(&cnt[comp[qid]], 1);
+icp_coverage_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  if (Mn < 1 || Ra < 1) return;
+  GridDesc g = pr.geom->g;
+  const Grid2 g_all = g2_view(pr.ga, Ra);
+  const int nround = (Mn + kBlock / 32 - 1) / (kBlock / 32);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    int qid = r * (kBlock / 32) + (threadIdx.x >> 5);
+    bool valid = qid < Mn;
+    float4 p = valid ? pr.mov[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int rr = g2_nearest_coop(g, g_all, p, pr.df, valid, &pr.st->err);
+    if (valid && (threadIdx.x & 31) == 0 && rr >= 0) atomicAdd(&pr.cov[pr.comp[qid]], 1);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
-icp_finish_kernel(int64_t C, const double* __restrict__ acc, const int32_t* __restrict__ cnt,
-                  const int64_t* __restrict__ comp_deg, int have_l1, const double* __restrict__ Tfin,
-                  double* __restrict__ T, double* __restrict__ l1, float* __restrict__ ratio,
-                  const IcpState* __restrict__ st, IcpState* __restrict__ out) {
-  if (out && blockIdx.x == 0 && threadIdx.x == 0) *out = *st;  // err word for the host (pinned)
+icp_finish_kernel(const IcpProblem* __restrict__ tab, Batch bt, IcpState* __restrict__ out) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const IcpState* st = pr.st;
+  if (out && blockIdx.x == 0 && threadIdx.x == 0) out[blockIdx.y] = *st;  // err word for the host (pinned)
+  const int iters = st->iters;
+  const int64_t C = pr.C;
+  const long long* acc = pr.acc + (size_t)(iters & 1) * C * kAcc;  // moments of the last iteration
+  const double* Tfin = pr.Tb + (size_t)(iters & 1) * C * 16;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
-    double n = acc[c * kAcc];
-    l1[c] = (have_l1 && n > 0.5) ? acc[c * kAcc + 18] / n : 0.0;
+    double n = (double)acc[c * kAcc];
+    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[c * kAcc + 18] * kFxInv) / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
-    ratio[c] = (float)cnt[c] / ((float)comp_deg[c] + 1e-6f);
-    for (int q = 0; q < 16; ++q) T[c * 16 + q] = Tfin[c * 16 + q];
+    pr.ratio_out[c] = (float)pr.cov[c] / ((float)pr.comp_deg[c] + 1e-6f);
+    for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[c * 16 + q];
   }
 }
 
-// ---- optional HIP-event timing of the dominant kernel (icp_nn_kernel), for bench.py ----
-struct NnProfile {
+// ---- optional HIP-event timing of the three iteration kernels, for bench.py's roofline ----
+struct KernelProfile {
   double ms = 0.0;
-  int64_t launches = 0;
+  double launches = 0.0;
   double bytes = 0.0;
 };
 static bool g_prof_on = false;
-static NnProfile g_prof_total;
+static KernelProfile g_prof[3];
 static std::mutex g_prof_mu;
-struct NnEvents {
-  hipEvent_t ev[2 * 96];
+constexpr int kProfChunk = 16;  // iterations per chunk that can carry events
+struct ProfEvents {
+  hipEvent_t ev[6 * kProfChunk];
   bool have = false;
 };
-static thread_local NnEvents t_ev;
+static thread_local ProfEvents t_ev;
+static thread_local int t_ev_used = 0;  // iterations of the last chunk that carried events
 
-// launches of one chunk (n_max iteration positions): an array of problems already on the device, or
-// (host_prob != nullptr) ONE problem passed by value
-static int icp_launch_chunk(const IcpProblem* d_probs, const IcpProblem* host_prob, int nprob, int n_max,
-                            int kbase, int max_nb_q, int max_nb_e, int max_nb_m, IcpState* out,
-                            hipStream_t s, hipEvent_t* ev) {
-  for (int j = 0; j < n_max; ++j) {
-    if (host_prob) {
-      // profiling: the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their
-      // difference is the kernel's own begin-to-end time, as rocprofv3 reports it. The search kernel
-      // by default; PCS_PROF_KERNEL=moments|apply moves them (tools/icp_stages.py)
-      static const int target = [] {
-        const char* e = getenv("PCS_PROF_KERNEL");
-        return !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'a' ? 2 : 0));
-      }();
-      if (ev && target == 0) {
-        hipExtLaunchKernelGGL(icp_nn_kernel_v, dim3(max_nb_q), dim3(kBlock), 0, s, ev[2 * j], ev[2 * j + 1],
-                              0, *host_prob, j, kbase);
-      } else {
-        icp_nn_kernel_v<<<max_nb_q, kBlock, 0, s>>>(*host_prob, j, kbase);
-      }
-      if (ev && target == 1) {
-        hipExtLaunchKernelGGL(icp_moments_kernel_v, dim3(max_nb_e), dim3(kBlock), 0, s, ev[2 * j],
-                              ev[2 * j + 1], 0, *host_prob, j, kbase);
-      } else {
-        icp_moments_kernel_v<<<max_nb_e, kBlock, 0, s>>>(*host_prob, j, kbase);
-      }
-      if (ev && target == 2) {
-        hipExtLaunchKernelGGL(icp_apply_kernel_v, dim3(max_nb_m), dim3(kBlock), 0, s, ev[2 * j],
-                              ev[2 * j + 1], 0, *host_prob, j, kbase);
-      } else {
-        icp_apply_kernel_v<<<max_nb_m, kBlock, 0, s>>>(*host_prob, j, kbase);
-      }
-    } else {
-      if (ev) {
-        hipExtLaunchKernelGGL(icp_nn_kernel, dim3(max_nb_q, nprob), dim3(kBlock), 0, s, ev[2 * j],
-                              ev[2 * j + 1], 0, d_probs, j, kbase);
-      } else {
-        icp_nn_kernel<<<dim3(max_nb_q, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
-      }
-      icp_moments_kernel<<<dim3(max_nb_e, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
-      icp_apply_kernel<<<dim3(max_nb_m, nprob), kBlock, 0, s>>>(d_probs, j, kbase);
-    }
+static inline int gx_for(int64_t items, int per_block, int cap) {
+  int64_t g = (items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, hipStream_t s) {
+  if (bt.n < 1) return PCS_OK;
+  int64_t words = 1, nmax = 1, Cmax = 1;
+  for (int e = 0; e < bt.n; ++e) {
+    if (hints[e].C > Cmax) Cmax = hints[e].C;
+    int64_t w = (int64_t)hints[e].clear_words + hints[e].C * kAcc;
+    if (w > words) words = w;
+    int64_t m = hints[e].Mn > hints[e].Rn ? hints[e].Mn : hints[e].Rn;
+    if (hints[e].Ra > m) m = hints[e].Ra;
+    if (m > nmax) nmax = m;
   }
-  // the stop rule of the chunk's last iteration (the others were settled by the next search)
-  if (host_prob) icp_decide_kernel_v<<<1, kBlock, 0, s>>>(*host_prob, kbase, out);
-  else icp_decide_kernel<<<dim3(1, nprob), kBlock, 0, s>>>(d_probs, kbase, out);
+  // one launch resets everything the calls own, one finds the bounding boxes, one writes the grid
+  // descriptions, one fills the three static grids
+  icp_clear_kernel<<<dim3(gx_for(words, kBlock, 2048), bt.n), kBlock, 0, s>>>(tab, bt);
+  icp_bounds_kernel<<<dim3(gx_for(nmax, kBlock, 256), bt.n, 3), kBlock, 0, s>>>(tab, bt);
+  icp_setup_kernel<<<dim3(gx_for(Cmax, kBlock, 64), bt.n), kBlock, 0, s>>>(tab, bt);
+  icp_insert3_kernel<<<dim3(gx_for(nmax, kBlock, 4096), bt.n, 3), kBlock, 0, s>>>(tab, bt);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
 
-// ---- shared launches for concurrent calls ---------------------------------------------------
-// Kernels of different streams overlap only 2-3 deep on this hardware, while the iteration kernels
-// of one problem leave most of the device idle. Threads that registered as participants (the
-// tracking units, pcs_tracker.hip) therefore hand their chunks to ONE launcher thread: whatever is
-// pending when the launcher is free goes out as one array of problems (blockIdx.y = problem), so
-// nine chains of ~50 us iterations become one chain of wider kernels. A caller synchronises its own
-// stream before submitting and continues on it after the launcher has synchronised the shared
-// stream, so no cross-stream ordering is needed. While a batch runs (~0.4 ms) later requests queue
-// up, which is what keeps the batches full without any waiting window.
-constexpr int kMaxBatch = 64;
-constexpr int kMaxGroups = 16;
-static double g_batch_stats[4] = {0, 0, 0, 0};  // batches, problems, busy seconds, idle seconds
-struct IcpRequest {
-  IcpProblem prob;
-  int nb_q, nb_e, nb_m;
-  double bytes_per_launch;
-  IcpState result;
-  int rc = 0;
-  bool done = false;
-};
-
-class IcpBatcher {
- public:
-  // one launcher (thread + stream) per group id: callers that move in lock-step -- the component
-  // keys of one anchor frame -- share a group, independent groups run side by side
-  static IcpBatcher& get(int group) {
-    static std::mutex gmu;
-    static IcpBatcher* inst[kMaxGroups] = {};  // never destroyed: the launcher threads outlive main
-    std::lock_guard<std::mutex> lk(gmu);
-    int g = group < 0 ? 0 : group % kMaxGroups;
-    if (!inst[g]) inst[g] = new IcpBatcher();
-    return *inst[g];
+int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
+                      const IcpHint* hints, IcpState* out, hipStream_t s) {
+  if (bt.n < 1 || n_it < 1) return PCS_OK;
+  int64_t q = 1, m = 1;
+  for (int e = 0; e < bt.n; ++e) {
+    int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
+    if (qe > q) q = qe;
+    if (hints[e].Mn > m) m = hints[e].Mn;
   }
-  void add_participant() {
-    std::lock_guard<std::mutex> lk(mu_);
-    ++participants_;
+  const int nb_q = gx_for(q * 32, kBlock, 8192);  // 32 lanes per query
+  const int nb_e = gx_for(q, kBlock, 4096);
+  const int nb_m = gx_for(m, kBlock, 4096);
+  bool prof = g_prof_on && n_it <= kProfChunk;
+  if (prof && !t_ev.have) {
+    for (int i = 0; i < 6 * kProfChunk; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
+    t_ev.have = true;
   }
-  void remove_participant() {
-    std::lock_guard<std::mutex> lk(mu_);
-    --participants_;
-  }
-  // a participant is between the start of an ICP call and the end of its iteration loop: it WILL
-  // submit a chunk shortly, so the launcher holds the next batch until all of these have
-  void enter_icp() {
-    std::lock_guard<std::mutex> lk(mu_);
-    ++in_icp_;
-  }
-  void leave_icp() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      --in_icp_;
-    }
-    cv_work_.notify_one();
-  }
-  int run(IcpRequest* req) {
-    std::unique_lock<std::mutex> lk(mu_);
-    if (!started_) {
-      if (hipGetDevice(&device_) != hipSuccess) return PCS_ERR_HIP;
-      started_ = true;
-      std::thread(&IcpBatcher::loop, this).detach();
-    }
-    req->done = false;
-    pending_.push_back(req);
-    cv_work_.notify_one();
-    cv_done_.wait(lk, [&] { return req->done; });
-    return req->rc;
-  }
-
- private:
-  void loop() {
-    bool ok = hipSetDevice(device_) == hipSuccess &&
-              hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc(&d_probs_, kMaxBatch * sizeof(IcpProblem)) == hipSuccess &&
-              hipHostMalloc(&h_probs_, kMaxBatch * sizeof(IcpProblem)) == hipSuccess &&
-              hipHostMalloc(&h_state_, kMaxBatch * sizeof(IcpState)) == hipSuccess;
-    hipEvent_t ev[2 * 16];
-    bool have_ev = false;
-    std::vector<IcpRequest*> batch;
-    auto t_free = std::chrono::steady_clock::now();
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        // go when every participant that is inside an ICP call has submitted its chunk (those that
-        // were in the previous batch need a few microseconds to come back); 2 ms safety net
-        for (;;) {
-          bool ready = cv_work_.wait_for(lk, std::chrono::milliseconds(2), [&] {
-            return !pending_.empty() && (int)pending_.size() >= in_icp_;
-          });
-          if (ready || !pending_.empty()) break;
-        }
-        batch.clear();
-        while (!pending_.empty() && (int)batch.size() < kMaxBatch) {
-          batch.push_back(pending_.front());
-          pending_.erase(pending_.begin());
-        }
-      }
-      auto t_start = std::chrono::steady_clock::now();
-      int rc = ok ? PCS_OK : PCS_ERR_HIP;
-      int n = (int)batch.size(), n_max = 0, q = 1, e = 1, m = 1;
-      double bytes = 0.0;
-      if (rc == PCS_OK) {
-        for (int i = 0; i < n; ++i) {
-          h_probs_[i] = batch[i]->prob;
-          if (batch[i]->prob.n_it > n_max) n_max = batch[i]->prob.n_it;
-          if (batch[i]->nb_q > q) q = batch[i]->nb_q;
-          if (batch[i]->nb_e > e) e = batch[i]->nb_e;
-          if (batch[i]->nb_m > m) m = batch[i]->nb_m;
-          bytes += batch[i]->bytes_per_launch;
-        }
-        bool prof = g_prof_on && n_max <= 16;
-        if (prof && !have_ev) {
-          for (int i = 0; i < 32; ++i) prof = prof && hipEventCreate(&ev[i]) == hipSuccess;
-          have_ev = prof;
-        }
-        if (hipMemcpyAsync(d_probs_, h_probs_, (size_t)n * sizeof(IcpProblem), hipMemcpyHostToDevice,
-                           stream_) != hipSuccess)
-          rc = PCS_ERR_HIP;
-        if (rc == PCS_OK)
-          rc = icp_launch_chunk(d_probs_, nullptr, n, n_max, 0, q, e, m, h_state_, stream_, prof ? ev : nullptr);
-        if (rc == PCS_OK && hipStreamSynchronize(stream_) != hipSuccess) rc = PCS_ERR_HIP;
-        if (rc == PCS_OK && prof) {
-          double ms_sum = 0.0;
-          for (int j = 0; j < n_max; ++j) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]) == hipSuccess) ms_sum += ms;
-          }
-          std::lock_guard<std::mutex> lk(g_prof_mu);
-          g_prof_total.ms += ms_sum;
-          g_prof_total.launches += n_max;
-          g_prof_total.bytes += bytes * n_max;
-        }
-      }
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        auto t_end = std::chrono::steady_clock::now();
-        g_batch_stats[0] += 1;
-        g_batch_stats[1] += n;
-        g_batch_stats[2] += std::chrono::duration<double>(t_end - t_start).count();
-        g_batch_stats[3] += std::chrono::duration<double>(t_start - t_free).count();
-        t_free = t_end;
-        for (int i = 0; i < n; ++i) {
-          if (rc == PCS_OK) batch[i]->result = h_state_[i];
-          batch[i]->rc = rc;
-          batch[i]->done = true;
-        }
-      }
-      cv_done_.notify_all();
+  t_ev_used = prof ? n_it : 0;
+  for (int j = 0; j < n_it; ++j) {
+    if (prof) {
+      // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
+      // kernel's own begin-to-end time, as rocprofv3 reports it
+      hipEvent_t* e = &t_ev.ev[6 * j];
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], e[1], 0, tab, bt, kbase, j);
+      hipExtLaunchKernelGGL(icp_moments_kernel, dim3(nb_e, bt.n), dim3(kBlock), 0, s, e[2], e[3], 0, tab, bt,
+                            kbase, j);
+      hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
+                            j);
+    } else {
+      icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_moments_kernel<<<dim3(nb_e, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }
-  std::mutex mu_;
-  std::condition_variable cv_work_, cv_done_;
-  std::vector<IcpRequest*> pending_;
-  int participants_ = 0;
-  int in_icp_ = 0;
-  bool started_ = false;
-  int device_ = 0;
-  hipStream_t stream_ = nullptr;
-  IcpProblem* d_probs_ = nullptr;
-  IcpProblem* h_probs_ = nullptr;
-  IcpState* h_state_ = nullptr;
-};
+  // the stop rule of the chunk's last iteration (the others were settled by the next search)
+  icp_decide_kernel<<<bt.n, kBlock, 0, s>>>(tab, bt, kbase, n_it, out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
 
-// set by pcs_icp_share_launches(): the calling thread's ICP calls go through the shared launcher
-static thread_local bool t_share_launches = false;
-static thread_local int t_share_group = 0;
-static thread_local double t_share_wait_s = 0.0;  // time this thread spent inside IcpBatcher::run
-static thread_local double t_icp_s = 0.0;         // time this thread spent inside the ICP entry point
+// after the stream has been synchronised: add the chunk's launches to the profile. live[j] = number
+// of entries that really ran iteration position j; bytes3[j*3 + {0,1,2}] = their algorithmic bytes in
+// the search / moments / apply launch. Launches in which no entry was live are not counted.
+void icp_profile_account(int n_it, const int* live, const double* bytes3) {
+  if (!g_prof_on || t_ev_used < 1) return;
+  int n = n_it < t_ev_used ? n_it : t_ev_used;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int j = 0; j < n; ++j) {
+    if (live[j] < 1) continue;
+    for (int q = 0; q < 3; ++q) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, t_ev.ev[6 * j + 2 * q], t_ev.ev[6 * j + 2 * q + 1]) != hipSuccess) continue;
+      g_prof[q].ms += ms;
+      g_prof[q].launches += 1.0;
+      g_prof[q].bytes += bytes3[j * 3 + q];
+    }
+  }
+  t_ev_used = 0;
+}
+
+int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
+                       hipStream_t s) {
+  if (bt.n < 1) return PCS_OK;
+  int64_t q = 1, m = 1, C = 1;
+  for (int e = 0; e < bt.n; ++e) {
+    int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
+    if (qe > q) q = qe;
+    if (hints[e].Mn > m) m = hints[e].Mn;
+    if (hints[e].C > C) C = hints[e].C;
+  }
+  // l1 error of the last iteration: positions before its update are in `prev`
+  const int nb_e = gx_for(q, kBlock, 2048);
+  icp_l1_kernel<0><<<dim3(nb_e, bt.n), kBlock, 0, s>>>(tab, bt, 0.3);
+  icp_l1_kernel<1><<<dim3(nb_e, bt.n), kBlock, 0, s>>>(tab, bt, 0.3);
+  icp_coverage_kernel<<<dim3(gx_for(m * 32, kBlock, 8192), bt.n), kBlock, 0, s>>>(tab, bt);
+  // NB: the coverage kernel may still raise st->err; it runs before this launch on the same stream
+  icp_finish_kernel<<<dim3(gx_for(C, kBlock, 256), bt.n), kBlock, 0, s>>>(tab, bt, out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
 
 }  // namespace pcs
 
@@ -984,184 +875,25 @@ using namespace pcs;
 
 extern "C" {
 
-int pcs_minmax4_f32(const float* pts, int64_t n, float* out8, hipStream_t s);
-
-// bench.py support: time icp_nn_kernel with HIP events on the launch stream (any number of host
-// threads / streams; totals are accumulated under a mutex).
-__global__ void busy_kernel(int ticks) {  // ~ticks x 10 ns on the 100 MHz wall clock
-  long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) {}
-}
-int pcs_profile_busy_loop(int64_t n, int ticks, int blocks, hipStream_t s) {
-  for (int64_t i = 0; i < n; ++i) busy_kernel<<<blocks, 64, 0, s>>>(ticks);
-  PCS_LAUNCH_CHECK();
-  return PCS_OK;
-}
-
-__global__ void touch_kernel(float4* buf, int mode, int n, int flip);
-// the same chain of dependent kernels as one captured graph launched n / nodes times: does the graph
-// executor shorten the device-side gap between dependent kernels? (tools/launch_scaling.py, mode graphN)
-int pcs_profile_graph_loop(int64_t n, int nodes, int ticks, int blocks, hipStream_t s) {
-  if (nodes < 1) nodes = 1;
-  float4* tbuf = nullptr;
-  if (ticks < 0) {  // ticks < 0: the nodes are touch kernels (4096 threads load one row each)
-    PCS_CHECK_HIP(hipMalloc(&tbuf, 4096 * sizeof(float4)));
-    PCS_CHECK_HIP(hipMemsetAsync(tbuf, 0, 4096 * sizeof(float4), s));
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
-  }
-  if (nodes == 1 && ticks < 0) {  // no graph: the same chain as plain stream launches
-    for (int64_t i = 0; i < n; ++i) touch_kernel<<<16, 256, 0, s>>>(tbuf, 0, 4096, 0);
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
-    hipFree(tbuf);
-    return PCS_OK;
-  }
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  PCS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < nodes; ++i) {
-    if (ticks > 0) busy_kernel<<<blocks, 64, 0, s>>>(ticks);
-    else if (ticks < 0) touch_kernel<<<16, 256, 0, s>>>(tbuf, 0, 4096, 0);
-    else pcs::noop_kernel<<<1, 64, 0, s>>>();
-  }
-  PCS_CHECK_HIP(hipStreamEndCapture(s, &graph));
-  PCS_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  for (int64_t i = 0; i < n; i += nodes) PCS_CHECK_HIP(hipGraphLaunch(exec, s));
-  PCS_CHECK_HIP(hipStreamSynchronize(s));
-  hipGraphExecDestroy(exec);
-  hipGraphDestroy(graph);
-  if (tbuf) hipFree(tbuf);
-  return PCS_OK;
-}
-
-// a stream whose kernels run on the compute units of `mask` only (hipExtStreamCreateWithCUMask):
-// probe for confining each tracking unit to its own XCDs (tools/icp_concurrency.py --cu-mask)
-int pcs_stream_create_cu_mask(const uint32_t* mask, int words, void** out) {
-  if (!mask || !out || words < 1) return PCS_ERR_ARG;
-  hipStream_t s = nullptr;
-  PCS_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
-  *out = (void*)s;
-  return PCS_OK;
-}
-
-// What does a kernel that merely touches memory cost, begin to end, in a dependent chain? mode 0: every
-// thread loads one 16-B row and exits; 1: stores one; 2: kernels alternate store / load of the same
-// buffer; 3: loads a row, then a second one whose address depends on the first (two round trips).
-// Returns the mean begin-to-end time of one launch in microseconds (events on the dispatch).
-__global__ void touch_kernel(float4* buf, int mode, int n, int flip) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (mode == 1 || (mode == 2 && !flip)) {
-    buf[i] = make_float4((float)i, 0.f, 0.f, (float)flip);
-    return;
-  }
-  float4 v = buf[i];
-  if (mode == 3) {
-    int j = ((int)v.x + i * 7919) % n;
-    if (j < 0) j = -j;
-    v = buf[j];
-  }
-  if (v.y == 123.456f) buf[i].z = 1.f;  // never true: keeps the loads alive
-}
-double pcs_profile_touch_loop(int64_t n_launch, int mode, int rows, hipStream_t s) {
-  float4* buf = nullptr;
-  if (rows < 256) rows = 256;
-  if (hipMalloc(&buf, (size_t)rows * sizeof(float4)) != hipSuccess) return -1.0;
-  hipMemsetAsync(buf, 0, (size_t)rows * sizeof(float4), s);
-  const int reps = 64;
-  hipEvent_t ev[2 * reps];
-  for (int i = 0; i < 2 * reps; ++i) hipEventCreate(&ev[i]);
-  int blocks = (rows + 255) / 256;
-  double total = 0.0;
-  int64_t timed = 0;
-  for (int64_t done = 0; done < n_launch; done += reps) {
-    for (int r = 0; r < reps; ++r)
-      hipExtLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(256), 0, s, ev[2 * r], ev[2 * r + 1], 0, buf, mode,
-                            rows, r & 1);
-    hipStreamSynchronize(s);
-    for (int r = 0; r < reps; ++r) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]) == hipSuccess) { total += ms; ++timed; }
-    }
-  }
-  for (int i = 0; i < 2 * reps; ++i) hipEventDestroy(ev[i]);
-  hipFree(buf);
-  return timed ? total * 1e3 / (double)timed : -1.0;
-}
-
-int pcs_profile_launch_loop(int64_t n, hipStream_t s) {
-  for (int64_t i = 0; i < n; ++i) pcs::noop_kernel<<<1, 64, 0, s>>>();
-  PCS_LAUNCH_CHECK();
-  return PCS_OK;
-}
-
-// n x {8 no-op launches, one small device->host read, stream sync}; mode 0: pageable destination
-// (hipMemcpyAsync), mode 1: pinned destination, mode 2: pinned word written by the kernel itself
-__global__ void probe_write_kernel(int* dst, int v) { *dst = v; }
-int pcs_profile_sync_loop(int64_t n, int mode, hipStream_t s) {
-  int* dev = nullptr;
-  int* pinned = nullptr;
-  PCS_CHECK_HIP(hipMalloc(&dev, 64));
-  PCS_CHECK_HIP(hipHostMalloc(&pinned, 64));
-  int host[16];
-  for (int64_t i = 0; i < n; ++i) {
-    for (int j = 0; j < 8; ++j) pcs::noop_kernel<<<1, 64, 0, s>>>();
-    if (mode == 0) {
-      PCS_CHECK_HIP(hipMemcpyAsync(host, dev, 56, hipMemcpyDeviceToHost, s));
-    } else if (mode == 1) {
-      PCS_CHECK_HIP(hipMemcpyAsync(pinned, dev, 56, hipMemcpyDeviceToHost, s));
-    } else {
-      probe_write_kernel<<<1, 1, 0, s>>>(pinned, (int)i);
-    }
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
-  }
-  hipFree(dev);
-  hipHostFree(pinned);
-  return PCS_OK;
-}
-
-// the calling thread's pcs_register_to_next_frame calls use (1) / stop using (0) the shared launcher
-int pcs_icp_share_launches(int enable) {
-  // enable = 0: off; enable = g >= 1: share launches with the other threads of group g
-  if (t_share_launches) IcpBatcher::get(t_share_group).remove_participant();
-  t_share_launches = enable != 0;
-  t_share_group = enable;
-  if (t_share_launches) IcpBatcher::get(t_share_group).add_participant();
-  return PCS_OK;
-}
-
-// diagnostic: {batches, problems, seconds launching + waiting for batches, seconds idle} of the
-// shared launcher since the last call (reset on read)
-// diagnostic: seconds the calling thread has spent waiting in the shared launcher / inside
-// pcs_register_to_next_frame since the last call (reset on read)
-int pcs_profile_thread_icp_read(double* out2) {
-  if (!out2) return PCS_ERR_ARG;
-  out2[0] = t_share_wait_s;
-  out2[1] = t_icp_s;
-  t_share_wait_s = 0.0;
-  t_icp_s = 0.0;
-  return PCS_OK;
-}
-
-int pcs_profile_batcher_read(double* out4) {
-  if (!out4) return PCS_ERR_ARG;
-  for (int i = 0; i < 4; ++i) { out4[i] = g_batch_stats[i]; g_batch_stats[i] = 0; }
-  return PCS_OK;
-}
-
-int pcs_profile_icp_nn(int enable) {
+// bench.py support: HIP-event timing of the three iteration kernels of the fused ICP on their launch
+// stream. enable = 1 resets and starts accumulating.
+int pcs_profile_icp(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
-  g_prof_total = NnProfile();
+  for (int q = 0; q < 3; ++q) g_prof[q] = KernelProfile();
   return PCS_OK;
 }
 
-// out3 (host): {milliseconds, launches, algorithmic bytes} accumulated since the last enable.
-int pcs_profile_icp_nn_read(double* out3) {
-  if (!out3) return PCS_ERR_ARG;
+// out9 (host): {milliseconds, launches, algorithmic bytes} of icp_nn_kernel, icp_moments_kernel,
+// icp_apply_kernel accumulated since the last enable.
+int pcs_profile_icp_read(double* out9) {
+  if (!out9) return PCS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  out3[0] = g_prof_total.ms;
-  out3[1] = (double)g_prof_total.launches;
-  out3[2] = g_prof_total.bytes;
+  for (int q = 0; q < 3; ++q) {
+    out9[3 * q + 0] = g_prof[q].ms;
+    out9[3 * q + 1] = g_prof[q].launches;
+    out9[3 * q + 2] = g_prof[q].bytes;
+  }
   return PCS_OK;
 }
 
@@ -1169,6 +901,7 @@ size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_
   Arena a(nullptr, 0);
   IcpBufs b;
   plan_icp(a, Mn, Rn, Ra, C, b);
+  a.take<IcpProblem>(1);
   return a.off;
 }
 
@@ -1187,183 +920,84 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
                                float cell_size, int chunk, double* T, double* l1_err,
                                float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
                                hipStream_t s) {
-  if (!T || !l1_err || !edge_ratio || !ws || !info || C < 1 || Mn < 0 || Rn < 0 || Ra < 0 ||
-      !comp_deg || !(radius > 0) || max_iter < 0 || (Mn > 0 && (!mov_fxyz || !mov_comp)) ||
-      (Rn > 0 && !ref_fxyz) || (Ra > 0 && !ref_all))
-    return PCS_ERR_ARG;
-  if (Mn + Rn >= (1LL << 26)) return PCS_ERR_RANGE;
-  struct CallTimer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    ~CallTimer() { t_icp_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-  } call_timer;
-  Arena a(ws, ws_bytes);
-  IcpBufs b;
-  if (!plan_icp(a, Mn, Rn, Ra, C, b)) return PCS_ERR_WORKSPACE;
-  // graph.radius = (radius^2 + frame_offset^2) ** 0.5, handed to the kernel as fp32
-  float rad = (float)sqrt(radius * radius + (double)frame_offset * (double)frame_offset);
-  // fine cell = (largest admissible spatial distance) / 4, so that the 3x3x3 coarse blocks cover
-  // the search ball: |dxyz|^2 <= rad^2 - df^2 + margin with df = frame_offset for integer frame
-  // values (the kernel flags PCS_ERR_RANGE if the data violate that). cell_size may enlarge it.
-  double rad2 = (double)rad * (double)rad;
-  double budget = rad2 - (double)frame_offset * (double)frame_offset + (2e-5 * rad2 + 2e-6);
-  if (budget < radius * radius) budget = radius * radius;
-  float cell = (float)(sqrt(budget) * 0.25 * 1.0005);
-  if (cell_size > cell) cell = cell_size;
-  float pad = 4.f * (float)radius + 16.f;
+  if (!info || !ws) return PCS_ERR_ARG;
+  IcpArgs a;
+  a.mov = mov_fxyz; a.comp = mov_comp; a.ref = ref_fxyz; a.all = ref_all; a.comp_deg = comp_deg;
+  a.cnt3 = nullptr;
+  a.Mn = Mn; a.Rn = Rn; a.Ra = Ra; a.C = C;
+  a.radius = radius; a.frame_offset = frame_offset; a.reg = angle_regularizer; a.delta = stopping_delta;
+  a.max_iter = max_iter; a.cell_size = cell_size;
+  a.T = T; a.l1 = l1_err; a.ratio = edge_ratio;
+  IcpProblem host_pr;
+  int rc = icp_describe(a, ws, ws_bytes, &host_pr);
+  if (rc) return rc;
+  // the descriptor table (one slot) sits behind the call's buffers
+  IcpProblem* tab = nullptr;
+  {
+    Arena ar(ws, ws_bytes);
+    IcpBufs b;
+    plan_icp(ar, Mn, Rn, Ra, C, b);
+    tab = ar.take<IcpProblem>(1);
+    if (!ar.ok() || !tab) return PCS_ERR_WORKSPACE;
+  }
+  // status words come back through pinned memory written by the kernels (no device-to-host copy);
+  // the descriptor goes up from the pinned staging area (the call ends with a synchronisation, so
+  // the next call of this thread cannot overwrite it early)
+  char* page = (char*)thread_pinned_page();
+  IcpState* pin = (IcpState*)page;
+  if (page) {
+    IcpProblem* stage = (IcpProblem*)(page + kPinnedStageOff);
+    *stage = host_pr;
+    PCS_CHECK_HIP(hipMemcpyAsync(tab, stage, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
+  } else {
+    PCS_CHECK_HIP(hipMemcpyAsync(tab, &host_pr, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+  }
   if (chunk < 1) chunk = 8;
-
-  // one launch resets everything the call owns, one finds the three bounding boxes
-  {
-    int64_t words = (int64_t)(b.gr.slot_words + b.ga.slot_words + 2 * b.gm[0].slot_words) + C * kAcc;
-    icp_clear_kernel<<<grid_for(words), kBlock, 0, s>>>(b.b_ref, b.Tb, b.acc, b.first, b.cnt, C, b.gr,
-                                                        b.gm[0], b.gm[1], b.ga);
-    int64_t nmax = Mn > Rn ? Mn : Rn;
-    if (Ra > nmax) nmax = Ra;
-    int gb = (int)((nmax + kBlock - 1) / kBlock);
-    if (gb < 1) gb = 1;
-    if (gb > 256) gb = 256;
-    icp_bounds_kernel<<<dim3(gb, 3), kBlock, 0, s>>>((const float4*)ref_fxyz, (int)Rn,
-                                                     (const float4*)mov_fxyz, (int)Mn,
-                                                     (const float4*)ref_all, (int)Ra, b.b_ref, mov_comp,
-                                                     b.first);
-  }
-  int nb_m = (int)((Mn + kBlock - 1) / kBlock);
-  if (nb_m < 1) nb_m = 1;
-  int nb_e = (int)((Mn + Rn + kBlock - 1) / kBlock);
-  if (nb_e < 1) nb_e = 1;
-  int nb_q = (int)(((Mn + Rn) * 32 + kBlock - 1) / kBlock);  // 32 lanes per query
-  if (nb_q < 1) nb_q = 1;
-
-  // this call's problem descriptor
-  IcpRequest req;
-  {
-    IcpProblem& pr = req.prob;
-    pr.mov = (float4*)mov_fxyz;
-    pr.prev = (float4*)b.prev;
-    pr.ref = (const float4*)ref_fxyz;
-    pr.comp = mov_comp;
-    pr.first = b.first;
-    pr.nn_f = b.nn_f;
-    pr.nn_b = b.nn_b;
-    pr.acc = b.acc;
-    pr.Tb = b.Tb;
-    pr.lossp = b.lossp;
-    pr.st = b.state;
-    pr.grid = b.grid;
-    pr.gr = b.gr;
-    pr.gm[0] = b.gm[0];
-    pr.gm[1] = b.gm[1];
-    pr.C = C;
-    pr.reg = angle_regularizer;
-    pr.delta = stopping_delta;
-    pr.Mn = (int)Mn;
-    pr.Rn = (int)Rn;
-    pr.df = frame_offset;
-    pr.nparts = nb_m;
-    pr.k0 = 1;
-    pr.n_it = 0;
-    {
-      static const int probe = [] { const char* e = getenv("PCS_NN_PROBE_STAGE"); return e ? atoi(e) : 0; }();
-      pr.probe_stage = probe;
-    }
-    req.nb_q = nb_q;
-    req.nb_e = nb_e;
-    req.nb_m = nb_m;
-    // per launch: read every query point and every hashed point (16 B rows), write one int32
-    // neighbour per query (16 N + 16 M per graph, two graphs per iteration)
-    req.bytes_per_launch = 2.0 * 16.0 * (double)(Mn + Rn) + 4.0 * (double)(Mn + Rn);
-  }
-  const bool shared = t_share_launches;
-  // grid description, then the three grids in one launch
-  icp_setup_kernel<<<1, 64, 0, s>>>(b.b_ref, b.b_mov, b.b_all, rad, cell, pad, b.grid, b.state);
-  {
-    int64_t nmax = Mn > Rn ? Mn : Rn;
-    if (Ra > nmax) nmax = Ra;
-    if (nmax > 0)
-      icp_insert3_kernel<<<dim3((unsigned)((nmax + kBlock - 1) / kBlock), 3), kBlock, 0, s>>>(
-          (const float4*)ref_fxyz, (int)Rn, (const float4*)ref_all, (int)Ra, (const float4*)mov_fxyz,
-          (int)Mn, b.grid, b.gr, b.ga, b.gm[1], b.state);
-  }
-  // status words come back through pinned memory written by the kernels (no device-to-host copy)
-  IcpState* pin = (IcpState*)thread_pinned_page();
-  struct IcpPhase {  // tells the shared launcher that this thread is about to submit chunks
-    bool on;
-    explicit IcpPhase(bool o) : on(o) { if (on) IcpBatcher::get(t_share_group).enter_icp(); }
-    void end() { if (on) { IcpBatcher::get(t_share_group).leave_icp(); on = false; } }
-    ~IcpPhase() { end(); }
-  } phase(shared);
-  bool prof = g_prof_on && !shared;
-  if (prof && !t_ev.have) {
-    for (int i = 0; i < 2 * 96; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
-    t_ev.have = true;
-  }
+  if (chunk > kProfChunk) chunk = kProfChunk;
+  Batch bt;
+  bt.n = 1;
+  bt.idx[0] = 0;
+  IcpHint hint;
+  hint.Mn = (int)Mn; hint.Rn = (int)Rn; hint.Ra = (int)Ra; hint.C = C;
+  hint.clear_words = host_pr.gr.slot_words + host_pr.ga.slot_words + 2 * host_pr.gm[0].slot_words;
+  rc = icp_enqueue_begin(tab, bt, &hint, s);
+  if (rc) return rc;
   IcpState host;
   host.stop_iter = INT_MAX;
   host.iters = 0;
   host.err = 0;
   int it = 0;
+  const double by_nn = 36.0 * (double)(Mn + Rn), by_mom = 40.0 * (double)(Mn + Rn) + 272.0 * (double)C,
+               by_app = 68.0 * (double)Mn + 416.0 * (double)C;
   while (it < max_iter) {
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
-    if (shared) {
-      // everything this call enqueued so far must be complete before the shared stream touches it
-      PCS_CHECK_HIP(hipStreamSynchronize(s));
-      req.prob.k0 = it + 1;
-      req.prob.n_it = n_it;
-      auto tw = std::chrono::steady_clock::now();
-      int rc2 = IcpBatcher::get(t_share_group).run(&req);
-      t_share_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-      if (rc2) return rc2;
-      host = req.result;
-    } else {
-      // the descriptor travels by value (k0 = 1; the chunk's first iteration is passed as kbase)
-      req.prob.n_it = n_it;
-      bool pk = prof && it + n_it <= kProfIters;
-      int rc2 = icp_launch_chunk(nullptr, &req.prob, 1, n_it, it, nb_q, nb_e, nb_m, pin, s,
-                                 pk ? &t_ev.ev[2 * it] : nullptr);
-      if (rc2) return rc2;
-      if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
-      PCS_CHECK_HIP(hipStreamSynchronize(s));
-      if (pin) host = *pin;
+    BatchInts kb;
+    kb.v[0] = it;
+    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s);
+    if (rc) return rc;
+    if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+    if (pin) host = *pin;
+    {
+      int live[kProfChunk];
+      double b3[3 * kProfChunk];
+      for (int j = 0; j < n_it; ++j) {
+        live[j] = (it + 1 + j <= host.iters) ? 1 : 0;
+        b3[3 * j] = by_nn; b3[3 * j + 1] = by_mom; b3[3 * j + 2] = by_app;
+      }
+      icp_profile_account(n_it, live, b3);
     }
     it += n_it;
     if (host.err) return PCS_ERR_RANGE;
     if (host.stop_iter != INT_MAX) break;
   }
-  phase.end();
-  if (prof) {
-    int n_done = host.iters < kProfIters ? host.iters : kProfIters;
-    double ms_sum = 0.0;
-    for (int k = 0; k < n_done; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, t_ev.ev[2 * k], t_ev.ev[2 * k + 1]) == hipSuccess) ms_sum += ms;
-    }
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_total.ms += ms_sum;
-    g_prof_total.launches += n_done;
-    g_prof_total.bytes += (double)n_done * req.bytes_per_launch;
-  }
   info[0] = host.iters;
   info[1] = host.stop_iter != INT_MAX ? 1 : 0;
   info[2] = info[3] = 0;
-  double* acc_fin = b.acc + (size_t)(host.iters & 1) * C * kAcc;  // moments of the last iteration
-  const int32_t* nnf_fin = b.nn_f + (size_t)(host.iters & 1) * (Mn > 0 ? Mn : 1);
-  const int32_t* nnb_fin = b.nn_b + (size_t)(host.iters & 1) * (Rn > 0 ? Rn : 1);
-  const double* T_fin = b.Tb + (size_t)(host.iters & 1) * C * 16;
-  if (host.iters > 0) {
-    // l1 error of the last iteration: positions before its update are in `prev`
-    icp_l1_kernel<0><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, nnf_fin, nnb_fin, acc_fin, 0.3);
-    icp_l1_kernel<1><<<nb_e, kBlock, 0, s>>>((const float4*)b.prev, (int)Mn, (const float4*)ref_fxyz,
-                                             (int)Rn, mov_comp, nnf_fin, nnb_fin, acc_fin, 0.3);
-  }
-  if (Mn > 0 && Ra > 0)
-    icp_coverage_kernel<<<(int)((Mn * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-        (const float4*)mov_fxyz, (int)Mn, mov_comp, b.grid, frame_offset, b.ga, b.state, b.cnt);
-  // NB: the coverage kernel may still raise st->err; it runs before this launch on the same stream
-  icp_finish_kernel<<<grid_for(C), kBlock, 0, s>>>(C, acc_fin, b.cnt, comp_deg, host.iters > 0, T_fin, T,
-                                                   l1_err, edge_ratio, b.state, pin);
-  PCS_LAUNCH_CHECK();
-  if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, b.state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+  rc = icp_enqueue_finish(tab, bt, &hint, pin, s);
+  if (rc) return rc;
+  if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   if (pin) host = *pin;
   if (host.err) return PCS_ERR_RANGE;

@@ -1,0 +1,159 @@
+// Batched form of the fused per-component ICP ("TLS solve", registration_utils.py:83-206): shared
+// between the stand-alone entry point (pcs_icp.hip: a batch of one) and the sequence tracker
+// (pcs_tracker.hip: every tracking unit that is inside a registration joins the same launches).
+//
+// A registration call is described ONCE by an IcpProblem stored in a device table; every kernel of
+// the loop takes (table, Batch) -- Batch is a by-value list of table slots, blockIdx.y selects the
+// entry -- so one launch advances all problems that are iterating at that moment and one host thread
+// drives them all. Sizes (Mn, Rn, Ra) may be given as pointers to device words (the tracker's
+// sampling kernels write them; the host never reads them): the kernels are grid-stride over their
+// work items, so the launch geometry is only an estimate and never changes a result.
+#pragma once
+#include "pcs_grid2.hpp"
+
+#include <climits>
+
+namespace pcs {
+
+constexpr int kMaxBatch = 32;  // table slots one launch can address
+
+struct Batch {
+  int n;
+  int idx[kMaxBatch];
+};
+struct BatchInts {  // one by-value int per batch entry (iteration base of the chunk)
+  int v[kMaxBatch];
+};
+
+struct IcpState {
+  double last_error;
+  double loss;
+  int countdown;
+  int stop_iter;  // iterations > stop_iter do not run (INT_MAX until the stop rule fires)
+  int iters;      // iterations solved so far
+  int err;
+  int decided;    // last iteration whose stop rule has been evaluated
+  int pad;
+};
+
+// per-component accumulators of one iteration: n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2,
+// sum dist, sum clamped dist, pad. ALL are 64-bit integers: n a count, the rest fixed point with
+// kFxBits fractional bits of coordinates taken relative to the component's origin (the position its
+// first moving point had when the call began: components are metres across, so the products stay
+// small and 2^-36 resolves them as finely as f64 resolves raw moments about a global origin).
+// Integer adds commute, so the sums do not depend on the order in which lanes, waves or workgroups
+// arrive: bit-identical run to run and schedule to schedule by construction. A coordinate too far
+// from its origin for the 64-bit range (limit_sq below) raises the call's error word.
+constexpr int kAcc = 20;
+constexpr int kFxBits = 36;
+constexpr double kFx = 68719476736.0;        // 2^36
+constexpr double kFxInv = 1.0 / 68719476736.0;
+
+struct IcpGeom {
+  GridDesc g;
+};
+// largest admissible squared distance of a point from its component origin: ne products of that size
+// stay below 2^62 in fixed point
+__host__ __device__ inline double icp_limit_sq(int ne) {
+  return 4611686018427387904.0 / kFx / (double)(ne < 1 ? 1 : ne);
+}
+
+struct IcpProblem {
+  float4* mov;          // [Mn] moving points, updated in place
+  float4* prev;         // [Mn] positions before the last applied update
+  const float4* ref;    // [Rn] non-stationary reference points
+  const float4* all;    // [Ra] every reference point (coverage ratio)
+  const int32_t* comp;  // [Mn] component of each moving point
+  const int64_t* comp_deg;  // [C] moving points per component, stationary included
+  const int64_t* cnt3;  // device {Mn, Ra, Rn} or nullptr (then the immediates below hold)
+  int32_t* first;       // [C] smallest moving-point index of the component (INT_MAX: none)
+  int32_t *nn_f, *nn_b; // [2, capM] / [2, capR]: buffer k & 1 holds iteration k's neighbours
+  long long* acc;       // [2, C, kAcc]
+  double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
+  double* lsc;          // [C] loss term of each component, last applied iteration
+  float4* corg;         // [C] origin of the component's fixed-point moments
+  int32_t* cov;         // [C] matched moving points in the final coverage query
+  IcpState* st;
+  IcpGeom* geom;
+  float* bounds;        // [24] min/max of ref, mov, all
+  Grid2 gr, ga, gm[2];  // reference (non-stationary / all), moving (double-buffered)
+  double* T_out;        // [C,16]
+  double* l1_out;       // [C]
+  float* ratio_out;     // [C]
+  int64_t C;
+  double reg, delta;
+  float rad, cell, pad;
+  int Mn, Rn, Ra;       // immediates (cnt3 == nullptr) / capacities of nn_f, nn_b (cnt3 != nullptr)
+  int capM, capR;
+  int df, max_iter;
+};
+
+__device__ __forceinline__ void icp_sizes(const IcpProblem& pr, int& Mn, int& Rn, int& Ra) {
+  if (pr.cnt3) {
+    Mn = (int)pr.cnt3[0];
+    Ra = (int)pr.cnt3[1];
+    Rn = (int)pr.cnt3[2];
+  } else {
+    Mn = pr.Mn;
+    Rn = pr.Rn;
+    Ra = pr.Ra;
+  }
+}
+
+// host-side layout of one call's workspace
+struct IcpBufs {
+  IcpGeom* geom;
+  float* bounds;
+  IcpState* state;
+  Grid2 gr, ga, gm[2];
+  int32_t *nn_f, *nn_b;
+  float* prev;
+  long long* acc;
+  double *Tb, *lsc;
+  float4* corg;
+  int32_t *first, *cov;
+};
+bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b);
+
+// what a caller fills in for one registration (device pointers; sizes are capacities when cnt3 is set)
+struct IcpArgs {
+  float* mov;
+  const int32_t* comp;
+  const float* ref;
+  const float* all;
+  const int64_t* comp_deg;
+  const int64_t* cnt3;
+  int64_t Mn, Rn, Ra, C;
+  double radius;
+  int frame_offset;
+  double reg, delta;
+  int max_iter;
+  float cell_size;
+  double *T, *l1;
+  float* ratio;
+};
+// descriptor of a call on workspace `ws` (host side only; the caller uploads it into its table slot)
+int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out);
+
+// launch geometry hints of one batch entry: expected sizes (only the grid dimensions derive from them)
+struct IcpHint {
+  int Mn, Rn, Ra;
+  int64_t C;
+  size_t clear_words;
+};
+// optional HIP-event timing of the three iteration kernels (bench.py's roofline): after the stream
+// has been synchronised, account the launches of the calling thread's last chunk
+constexpr int kIcpMaxChunk = 16;
+void icp_profile_account(int n_it, const int* live, const double* bytes3);
+// enqueue: reset + bounds + grid description + the three grids of every entry
+int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, hipStream_t s);
+// enqueue n_it iterations (entry e runs iterations kbase[e]+1 .. kbase[e]+n_it, gated by its stop
+// word and max_iter), then the stop rule of the last one; the states are mirrored to out[e] (may be
+// pinned host memory, may be nullptr)
+int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
+                      const IcpHint* hints, IcpState* out, hipStream_t s);
+// enqueue: l1 error of the last iteration, coverage ratio, outputs
+int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
+                       hipStream_t s);
+
+}  // namespace pcs

@@ -86,7 +86,7 @@ void* thread_pinned_page() {
   static thread_local bool tried = false;
   if (!tried) {
     tried = true;
-    if (hipHostMalloc(&page, 4096, hipHostMallocDefault) != hipSuccess) page = nullptr;
+    if (hipHostMalloc(&page, kPinnedPageBytes, hipHostMallocDefault) != hipSuccess) page = nullptr;
   }
   return page;
 }

@@ -17,6 +17,22 @@ struct SmoothState {
   int iters;
   float last_loss;
 };
+struct SmoothGrid;
+// one smooth_velo problem of a batched launch (the sequence tracker, pcs_tracker.hip)
+struct SvJob {
+  float* v;
+  const float* d;
+  SmoothState* st;
+  SmoothGrid* grid;
+  float *m, *sq;
+  int* err;
+  int C, F, a, b, cpb, blocks, kind;  // kind 0: LDS-resident, 1: multi-workgroup, 2: generic
+};
+constexpr int kSvMaxBatch = 32;
+struct SvBatch {
+  int n;
+  SvJob j[kSvMaxBatch];
+};
 
 // MultiStepLR([100, 200, 300], gamma 0.1); the optimiser forms its scalars in double (Python
 // floats) and hands them to fp32 tensor ops
@@ -32,10 +48,10 @@ constexpr int SV_BLOCK = 1024;
 
 // v, d: [C, F, 3] f32. In-range elements: (c, t in [a, b], k in {0,1}). m, s: Adam moments for the
 // in-range elements, laid out [C, nf, 2].
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                   float weight0, float weight, int num_itr, float stopping,
-                   float* __restrict__ m, float* __restrict__ s, SmoothState* __restrict__ st) {
+__device__ __forceinline__ void
+smooth_velo_body(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                 float weight0, float weight, int num_itr, float stopping,
+                 float* __restrict__ m, float* __restrict__ s, SmoothState* __restrict__ st) {
   __shared__ double red[SV_BLOCK / 64];
   __shared__ int stop_flag;
   int nf = b - a + 1;
@@ -133,11 +149,10 @@ smooth_velo_kernel(float* __restrict__ v, const float* __restrict__ d, int C, in
 constexpr int SV_ELEMS = 8;
 constexpr int SV_MAX_ITR = 512;
 
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_lds_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                       float weight0, float weight, int num_itr, float stopping,
-                       SmoothState* __restrict__ st) {
-  extern __shared__ float sv[];               // [n_in] current iterate
+__device__ __forceinline__ void
+smooth_velo_lds_body(float* __restrict__ sv /* LDS [n_in] current iterate */, float* __restrict__ v,
+                     const float* __restrict__ d, int C, int F, int a, int b, float weight0, float weight,
+                     int num_itr, float stopping, SmoothState* __restrict__ st) {
   __shared__ double red[SV_BLOCK / 64];
   __shared__ float t_step[SV_MAX_ITR], t_bc2[SV_MAX_ITR], t_decay[SV_MAX_ITR];
   __shared__ int stop_flag;
@@ -253,20 +268,18 @@ struct SmoothGrid {
   double partial[2][SV_MAX_BLOCKS];
 };
 
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                        float weight0, float weight, int num_itr, float stopping, int cpb,
-                        SmoothGrid* __restrict__ g, SmoothState* __restrict__ st,
-                        int* __restrict__ err) {
-  extern __shared__ float sv[];               // this workgroup's slice of the iterate
+__device__ __forceinline__ void
+smooth_velo_grid_body(float* __restrict__ sv /* LDS: this workgroup's slice of the iterate */, int bx, int B,
+                      float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                      float weight0, float weight, int num_itr, float stopping, int cpb,
+                      SmoothGrid* __restrict__ g, SmoothState* __restrict__ st, int* __restrict__ err) {
   __shared__ double red[SV_BLOCK / 64];
   __shared__ float t_step[SV_MAX_ITR], t_bc2[SV_MAX_ITR], t_decay[SV_MAX_ITR];
   __shared__ int stop_flag;
   const int nf = b - a + 1;
-  const int c0 = blockIdx.x * cpb;
+  const int c0 = bx * cpb;
   const int c1 = min(C, c0 + cpb);
   const int n_loc = (c1 - c0) * nf * 2;
-  const int B = gridDim.x;
   const float inv_fit = 1.0f / (float)(C * nf * 2);
   const float inv_sm = 1.0f / (float)(C * (nf - 1) * 2);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -329,7 +342,7 @@ smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int 
     if (tid == 0) {
       double tot = 0.0;
       for (int q = 0; q < SV_BLOCK / 64; ++q) tot += red[q];
-      __hip_atomic_store(&g->partial[it & 1][blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g->partial[it & 1][bx], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&g->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     const float step_size = t_step[it], bc2_sqrt = t_bc2[it], decay = t_decay[it];
@@ -380,13 +393,13 @@ smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int 
       v[((int64_t)c * F + (a + t)) * 3 + k] = sv[e];
     }
   }
-  if (blockIdx.x == 0 && tid == 0) { st->iters = it; st->last_loss = last_loss; }
+  if (bx == 0 && tid == 0) { st->iters = it; st->last_loss = last_loss; }
 }
 
 // elements outside (c, [a,b], {0,1}) only see the decoupled weight decay of every executed step
-__global__ void __launch_bounds__(kBlock)
-smooth_velo_decay_kernel(float* __restrict__ v, int64_t total, int F, int a, int b,
-                         const SmoothState* __restrict__ st) {
+__device__ __forceinline__ void
+smooth_velo_decay_body(float* __restrict__ v, int64_t total, int F, int a, int b,
+                       const SmoothState* __restrict__ st) {
   int n = st->iters;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -397,6 +410,67 @@ smooth_velo_decay_kernel(float* __restrict__ v, int64_t total, int F, int a, int
     for (int it = 0; it < n; ++it) x = x * (float)(1.0 - lr_at(it) * 1e-2);
     v[i] = x;
   }
+}
+
+// ---- single-problem launches (pcs_smooth_velo) and batched launches (the sequence tracker: one
+//      entry per tracking unit, blockIdx.y = entry) of the same bodies
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                   float weight0, float weight, int num_itr, float stopping,
+                   float* __restrict__ m, float* __restrict__ s, SmoothState* __restrict__ st) {
+  smooth_velo_body(v, d, C, F, a, b, weight0, weight, num_itr, stopping, m, s, st);
+}
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_lds_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                       float weight0, float weight, int num_itr, float stopping,
+                       SmoothState* __restrict__ st) {
+  extern __shared__ float sv_dyn[];
+  smooth_velo_lds_body(sv_dyn, v, d, C, F, a, b, weight0, weight, num_itr, stopping, st);
+}
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
+                        float weight0, float weight, int num_itr, float stopping, int cpb,
+                        SmoothGrid* __restrict__ g, SmoothState* __restrict__ st,
+                        int* __restrict__ err) {
+  extern __shared__ float sv_dyn[];
+  smooth_velo_grid_body(sv_dyn, blockIdx.x, gridDim.x, v, d, C, F, a, b, weight0, weight, num_itr, stopping,
+                        cpb, g, st, err);
+}
+__global__ void __launch_bounds__(kBlock)
+smooth_velo_decay_kernel(float* __restrict__ v, int64_t total, int F, int a, int b,
+                         const SmoothState* __restrict__ st) {
+  smooth_velo_decay_body(v, total, F, a, b, st);
+}
+
+__global__ void __launch_bounds__(SV_BLOCK)
+smooth_velo_batch_kernel(SvBatch sb, int kind, float weight0, float weight, int num_itr, float stopping) {
+  extern __shared__ float sv_dyn[];
+  const SvJob& j = sb.j[blockIdx.y];
+  if (j.kind != kind) return;
+  if (kind == 0) {
+    if (blockIdx.x == 0)
+      smooth_velo_lds_body(sv_dyn, j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.st);
+  } else if (kind == 1) {
+    if ((int)blockIdx.x < j.blocks)
+      smooth_velo_grid_body(sv_dyn, blockIdx.x, j.blocks, j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr,
+                            stopping, j.cpb, j.grid, j.st, j.err);
+  } else {
+    if (blockIdx.x == 0)
+      smooth_velo_body(j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.m, j.sq, j.st);
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+smooth_velo_batch_reset_kernel(SvBatch sb) {
+  const SvJob& j = sb.j[blockIdx.x];
+  if (threadIdx.x == 0 && j.kind == 1) {
+    j.grid->arrive = 0;
+    j.grid->timeout = 0;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+smooth_velo_batch_decay_kernel(SvBatch sb) {
+  const SvJob& j = sb.j[blockIdx.y];
+  smooth_velo_decay_body(j.v, (int64_t)j.C * j.F * 3, j.F, j.a, j.b, j.st);
 }
 
 
@@ -1014,6 +1088,90 @@ int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C
   }
   smooth_velo_decay_kernel<<<grid_for(C * (int64_t)F * 3), kBlock, 0, s>>>(
       comp_velos, C * (int64_t)F * 3, F, frame_lo, frame_hi, st);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// The same for several problems at once (one per tracking unit; every problem takes the kernel form
+// and geometry pcs_smooth_velo would give it, so the results are those of separate calls).
+// ws[e] / ws_bytes[e]: each problem's own workspace (pcs_smooth_velo_workspace_bytes).
+int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
+                          const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
+                          float weight0, float weight, int num_itr, float stopping, void* const* ws,
+                          const size_t* ws_bytes, int* const* err, hipStream_t s) {
+  if (n < 1) return PCS_OK;
+  if (n > kSvMaxBatch) return PCS_ERR_ARG;
+  SvBatch sb;
+  sb.n = 0;
+  size_t lds[3] = {0, 0, 0};
+  int nblk[3] = {0, 0, 0}, have[3] = {0, 0, 0};
+  int64_t tot_max = 1;
+  int resident = 0;
+  for (int e = 0; e < n; ++e) {
+    if (!comp_velos[e] || !comp_center_diffs[e] || !ws[e] || C[e] < 1 || F[e] < 1 || frame_lo[e] < 0 ||
+        frame_hi[e] >= F[e] || frame_lo[e] > frame_hi[e] || num_itr < 0)
+      return PCS_ERR_ARG;
+    if (frame_lo[e] == frame_hi[e]) continue;  // cluster_tracking.py:166-167
+    if (C[e] * (int64_t)F[e] * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
+    Arena a(ws[e], ws_bytes[e]);
+    SvJob& j = sb.j[sb.n];
+    j.st = a.take<SmoothState>(1);
+    j.grid = a.take<SmoothGrid>(1);
+    j.m = a.take<float>((size_t)C[e] * F[e] * 2);
+    j.sq = a.take<float>((size_t)C[e] * F[e] * 2);
+    if (!a.ok()) return PCS_ERR_WORKSPACE;
+    j.v = comp_velos[e];
+    j.d = comp_center_diffs[e];
+    j.err = err ? err[e] : nullptr;
+    j.C = (int)C[e];
+    j.F = F[e];
+    j.a = frame_lo[e];
+    j.b = frame_hi[e];
+    const int nf = frame_hi[e] - frame_lo[e] + 1;
+    int64_t n_in = C[e] * (int64_t)nf * 2;
+    j.cpb = (SV_BLOCK * SV_ELEMS) / (nf * 2);
+    const int64_t blocks = j.cpb > 0 ? (C[e] + j.cpb - 1) / j.cpb : (int64_t)SV_MAX_BLOCKS + 1;
+    j.blocks = 1;
+    size_t need = 0;
+    if (n_in <= (int64_t)SV_BLOCK * SV_ELEMS && num_itr <= SV_MAX_ITR) {
+      j.kind = 0;
+      need = (size_t)n_in * sizeof(float);
+    } else if (blocks <= SV_MAX_BLOCKS && num_itr <= SV_MAX_ITR) {
+      j.kind = 1;
+      j.blocks = (int)blocks;
+      need = (size_t)j.cpb * nf * 2 * sizeof(float);
+      resident += (int)blocks;
+    } else {
+      j.kind = 2;
+    }
+    if (need > lds[j.kind]) lds[j.kind] = need;
+    if (j.blocks > nblk[j.kind]) nblk[j.kind] = j.blocks;
+    have[j.kind] = 1;
+    int64_t tot = C[e] * (int64_t)F[e] * 3;
+    if (tot > tot_max) tot_max = tot;
+    ++sb.n;
+  }
+  if (sb.n == 0) return PCS_OK;
+  // the multi-workgroup form spins at a grid barrier: all its workgroups must be resident together
+  // (256 CUs x 2 workgroups of 1024 threads); beyond that the problems go one launch at a time
+  if (have[1]) smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
+  for (int kind = 0; kind < 3; ++kind) {
+    if (!have[kind]) continue;
+    if (kind == 1 && resident > 384) {
+      for (int e = 0; e < sb.n; ++e) {
+        if (sb.j[e].kind != 1) continue;
+        SvBatch one;
+        one.n = 1;
+        one.j[0] = sb.j[e];
+        smooth_velo_batch_kernel<<<dim3(one.j[0].blocks, 1), SV_BLOCK, lds[1], s>>>(one, 1, weight0, weight, num_itr,
+                                                                                    stopping);
+      }
+      continue;
+    }
+    smooth_velo_batch_kernel<<<dim3(nblk[kind], sb.n), SV_BLOCK, lds[kind], s>>>(sb, kind, weight0, weight, num_itr,
+                                                                                stopping);
+  }
+  smooth_velo_batch_decay_kernel<<<dim3(grid_for(tot_max), sb.n), kBlock, 0, s>>>(sb);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

@@ -1,55 +1,223 @@
-// Native host runtime + kernels of ClusterTracking.track_frame for gfx950.
+// Sequence tracker for gfx950: ClusterTracking.track_frame for EVERY tracking unit of a sequence,
+// driven in lock-step by one host thread on one stream.
 //
 // Reference: pcdet/models/registration/preprocessors/cluster_tracking.py:430-787 (track_frame;
 // SURVEY.md A.6) with its helpers sample_frame (:39-51), component_center / component_diameter /
-// filter_components (:89-160), dist_compensate (:80-87) and smooth_velo (:162-199).
+// filter_components (:89-160), dist_compensate (:80-87) and smooth_velo (:162-199); the units are
+// the (component key, anchor frame) pairs ClusterTracking.forward loops over (:853-884).
 //
 // In the reference every step of the tracking loop is ~450 small framework ops issued from the
-// interpreter. A tracking unit (anchor frame x component key) is a chain of small, latency-bound
-// launches, and 9 independent units exist per sequence; issued from interpreter threads they
-// serialise on the interpreter lock (tools/launch_scaling.py: 115 k launches/s from 9 threads),
-// issued from native threads they scale (1.7 M launches/s). So the whole loop of one unit lives
-// here: one call, one stream, all state in the caller's workspace, a handful of fused kernels per
-// step and three small host reads per step (loop condition, sample counts, ICP stop word).
+// interpreter, one unit after the other. A unit is a chain of small, latency-bound launches, and the
+// units of a sequence are independent (within a unit the backward pass must end before the forward
+// pass starts: smooth_velo's decoupled weight decay touches the whole velocity tensor). So the
+// units advance TOGETHER: every kernel below takes a by-value list of units (blockIdx.y = entry) and
+// serves all units that are in the same phase, and the registrations of all units share the three
+// launches of an ICP iteration (pcs_icp.hpp). Per "tick" the host enqueues, in this order,
+//   finish of the registrations that stopped -> apply T -> (last level) component motion,
+//   smooth_velo, stop rules, harvest -> direction / step set-up -> sampling of anchor and target
+//   frame -> start of the next registrations -> one chunk of ICP iterations for every unit that is
+//   registering -> state mirror into pinned memory,
+// then synchronises once and reads a few words per unit. No kernel geometry depends on data the
+// host has not seen: sizes that are born on the device (voxel counts) stay there, the kernels are
+// grid-stride and the launch sizes are estimates from the previous step.
 //
 // Arithmetic follows the host-side restatement (pcdet/.../cluster_tracking.py of this package) op
-// for op: fp32 where torch computes in fp32, f64 for the transforms, the same fixed-order segment
-// reductions (pcs_segment_reduce_f32 serial / wave modes), so both produce identical ids.
-#include "pcs_common.hpp"
+// for op: fp32 where torch computes in fp32, f64 for the transforms, fixed-order segment sums, so
+// both produce identical ids; a unit's results do not depend on which other units share its launches.
+#include "pcs_icp.hpp"
 
 #include "pcs.h"
+
+#include <cstdlib>
 
 namespace pcs {
 
 constexpr int kMaxLevels = 4;
+constexpr int kWg = 1024;  // one-workgroup kernels (sort, compaction)
 
 struct TrkState {
-  int32_t active;      // any component still tracked (loop condition of the next step)
+  int32_t active;     // any component still tracked (loop condition of the next step)
   int32_t err;
-  int64_t ex_count;    // extracted points so far
-  int64_t counts[4];   // per level: voxels(anchor), non-stationary(anchor), voxels(next), non-stationary(next)
+  int64_t ex_count;   // extracted points so far
+  int64_t counts[4];  // anchor voxels, anchor non-stationary (Mn), target voxels (Ra), target non-stationary (Rn)
 };
 
-// ------------------------------------------------------------------ anchor set-up
+// one point set of a unit's sampling (anchor frame as moved so far / target frame)
+struct SmpSet {
+  uint64_t *k0, *k1;      // sort keys, ping-pong
+  int32_t *v0, *v1;       // original indices, ping-pong
+  int32_t *order, *seg;   // sorted original indices; voxel boundaries [v + 1]
+  int64_t* d_num;         // voxels
+  float4* sub;            // [v] voxel means
+  int32_t* sub_comp;      // [v] voxel component (anchor only)
+  int32_t* flag;          // [v] non-stationary
+  float4* out;            // compacted non-stationary voxels
+  int32_t* out_comp;      // their components (anchor only)
+};
+
+struct UnitDev {
+  const float4* seq;
+  const int64_t* seq_comp;
+  const uint8_t* seq_stat;
+  int64_t off_a, comp_base, ex_cap;
+  int na, C, F, W, anchor, min_f;
+  float4 *xyzf, *last;
+  int64_t* comp64;
+  int32_t* comp32;
+  int32_t *order_c, *seg_c;
+  int64_t *uniq_c, *d_numc;
+  float *deg_f, *diam, *ctr, *centers, *diffs, *velo_pre, *ratio, *ratio_tmp, *red4, *red1, *dist;
+  int64_t* deg_i;
+  unsigned long long* sub_deg;
+  uint8_t* stopped;
+  double *Tl, *l1, *l1_tmp;
+  SmpSet sa, sb;
+  Grid2 hg;
+  const GridDesc* hdesc;
+  int32_t *hv_nbr, *hv_deg;
+  TrkState* st;
+  double* transforms;
+  float *reg_errors, *edge_ratios, *velos;
+  int64_t *cmin, *cmax;
+  uint8_t *moving, *vcm;
+  int64_t *ex_index, *ex_local, *ex_comp;
+};
+
+struct StepArg {
+  int dir, next, col, last_col, lv, nn;
+  long long off_n;
+};
+struct Steps {
+  StepArg a[kMaxBatch];
+};
+struct LevelSizes {
+  float v[kMaxLevels][3];
+};
+
+// ------------------------------------------------------------------ block-wide helpers (1024 threads)
+// exclusive scan of one int per thread; *total receives the sum. `sh` is LDS scratch [kWg / 64 + 1].
+__device__ __forceinline__ int wg_excl_scan(int v, int* total, int* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();  // sh may still be read from a previous call
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int q = 0; q < kWg / 64; ++q) { int t = sh[q]; sh[q] = run; run += t; }
+    sh[kWg / 64] = run;
+  }
+  __syncthreads();
+  *total = sh[kWg / 64];
+  return sh[w] + incl - v;
+}
+
+// Stable LSD radix sort of n (key, value) pairs by key bits [0, nbits), 8 bits per pass, by ONE
+// workgroup of 16 waves: wave w owns a contiguous slice of the input, so "digit-major, wave-minor,
+// position within the slice" is the stable order. Returns 0 if the result is in (k0, v0), 1 if in
+// (k1, v1). hist: LDS [16 * 256]; sh: LDS [kWg / 64 + 1].
+__device__ __forceinline__ int wg_radix_sort(uint64_t* k0, int32_t* v0, uint64_t* k1, int32_t* v1, int n,
+                                             int nbits, int* hist, int* sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per_wave = ((n + kWg - 1) / kWg) * 64;
+  const int begin = w * per_wave;
+  const int end = begin + per_wave < n ? begin + per_wave : n;
+  uint64_t *kin = k0, *kout = k1;
+  int32_t *vin = v0, *vout = v1;
+  int which = 0;
+  constexpr int U = 8;  // rounds whose loads are issued together
+  for (int b = 0; b < nbits; b += 8) {
+    for (int q = tid; q < 16 * 256; q += kWg) hist[q] = 0;
+    __syncthreads();
+    for (int i0 = begin; i0 < end; i0 += 64 * U) {
+      uint64_t kk[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        kk[r] = i < end ? kin[i] : ~0ULL;
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        if (i < end) atomicAdd(&hist[w * 256 + (int)((kk[r] >> b) & 255)], 1);
+      }
+    }
+    __syncthreads();
+    // exclusive scan in (digit, wave) order: thread t owns entries 4t .. 4t+3 of that order
+    int c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int e = 4 * tid + q;
+      c[q] = hist[(e & 15) * 256 + (e >> 4)];
+      sum += c[q];
+    }
+    int tot;
+    int run = wg_excl_scan(sum, &tot, sh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int e = 4 * tid + q;
+      hist[(e & 15) * 256 + (e >> 4)] = run;
+      run += c[q];
+    }
+    __syncthreads();
+    for (int i0 = begin; i0 < end; i0 += 64 * U) {
+      uint64_t kk[U];
+      int32_t vv[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        kk[r] = i < end ? kin[i] : ~0ULL;
+        vv[r] = i < end ? vin[i] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        bool in = i < end;
+        int d = (int)((kk[r] >> b) & 255);
+        unsigned long long same = __ballot(in);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          unsigned long long bm = __ballot((d >> bit) & 1);
+          same &= ((d >> bit) & 1) ? bm : ~bm;
+        }
+        int rank = __popcll(same & ((1ULL << lane) - 1ULL));
+        int cnt = __popcll(same);
+        int base = 0;
+        if (in) base = hist[w * 256 + d];
+        if (in && rank == 0) hist[w * 256 + d] = base + cnt;  // after every lane of the group has read
+        if (in) {
+          kout[base + rank] = kk[r];
+          vout[base + rank] = vv[r];
+        }
+      }
+    }
+    __syncthreads();
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    int32_t* tv = vin; vin = vout; vout = tv;
+    which ^= 1;
+  }
+  return which;
+}
+
+// ------------------------------------------------------------------ anchor set-up (per unit)
 __global__ void __launch_bounds__(kBlock)
-trk_load_anchor_kernel(const float4* __restrict__ src, const int64_t* __restrict__ comp_in,
-                       const uint8_t* __restrict__ stat_in, int64_t base, int n,
-                       float4* __restrict__ xyzf, int64_t* __restrict__ comp64,
-                       int32_t* __restrict__ comp32, float* __restrict__ stat_f) {
+trk_load_anchor_kernel(const float4* __restrict__ src, const int64_t* __restrict__ comp_in, int64_t base,
+                       int n, float4* __restrict__ xyzf, int64_t* __restrict__ comp64,
+                       int32_t* __restrict__ comp32) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   xyzf[i] = src[i];
   int64_t c = comp_in[i] - base;
   comp64[i] = c;
   comp32[i] = (int32_t)c;
-  stat_f[i] = stat_in[i] ? 1.f : 0.f;
 }
 
-__global__ void __launch_bounds__(kBlock)
-trk_stat_to_float_kernel(const uint8_t* __restrict__ stat_in, int n, float* __restrict__ stat_f) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) stat_f[i] = stat_in[i] ? 1.f : 0.f;
-}
+__global__ void trk_copy_i64_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst) { *dst = *src; }
 
 // per present component u (id c = uniq[u]): count, centre = fl32(sum) / fl32(count)
 __global__ void __launch_bounds__(kBlock)
@@ -61,7 +229,8 @@ trk_comp_center_kernel(const int64_t* __restrict__ uniq, const int32_t* __restri
   int64_t c = uniq[u];
   int n = seg[u + 1] - seg[u];
   float nf = (float)n;
-  if (deg_f) { deg_f[c] = nf; deg_i[c] = n; }
+  deg_f[c] = nf;
+  deg_i[c] = n;
   ctr[c * 4 + 0] = red4[u * 4 + 0] / nf;
   ctr[c * 4 + 1] = red4[u * 4 + 1] / nf;
   ctr[c * 4 + 2] = red4[u * 4 + 2] / nf;
@@ -85,18 +254,20 @@ trk_comp_diam_kernel(const int64_t* __restrict__ uniq, int Cu, const float* __re
   if (u < Cu) diam[uniq[u]] = red1[u] * 2.f;
 }
 
-// per component: masks, identity transforms, output defaults, centre of the anchor frame
+// per component: masks, identity transforms, output defaults, centre of the anchor frame; the
+// unit's `active` word says whether any component passed filter_components
 __global__ void __launch_bounds__(kBlock)
 trk_comp_init_kernel(int C, int F, int W, int frame_id, float max_diam, const float* __restrict__ deg_f,
                      const float* __restrict__ diam, const float* __restrict__ ctr,
                      uint8_t* __restrict__ vcm, double* __restrict__ transforms,
                      int64_t* __restrict__ cmin, int64_t* __restrict__ cmax,
-                     float* __restrict__ centers) {
+                     float* __restrict__ centers, TrkState* __restrict__ st) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   bool valid = deg_f[c] > 0.5f;
   if (max_diam > 0.f) valid = valid && (diam[c] < max_diam);
   vcm[c] = valid;
+  if (valid) st->active = 1;
   cmin[c] = frame_id;
   cmax[c] = frame_id;
   for (int w = 0; w < W; ++w) {
@@ -109,322 +280,399 @@ trk_comp_init_kernel(int C, int F, int W, int frame_id, float max_diam, const fl
   cc[2] = ctr[c * 4 + 2];
 }
 
-// ------------------------------------------------------------------ per direction
-__global__ void __launch_bounds__(kBlock)
-trk_dir_init_kernel(int C, int n, const uint8_t* __restrict__ vcm, uint8_t* __restrict__ stopped,
-                    uint8_t* __restrict__ moving, const float4* __restrict__ anchor,
-                    float4* __restrict__ xyzf, float4* __restrict__ last, TrkState* st) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < C) {
-    bool v = vcm[i];
-    stopped[i] = !v;
-    moving[i] = v;
-    if (v) st->active = 1;
+// grid description of the harvest searches (1-NN of the target frame's points among the moved
+// anchor points, radius NN_GRAPH.RADIUS): one for the whole sequence, padded so that tracked points
+// stay inside the cell range
+__global__ void trk_hdesc_kernel(const float* __restrict__ b8, float radius, float cell, float pad,
+                                 GridDesc* __restrict__ g) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float vs0 = (float)(1 - 1e-3);
+  g->vs0 = vs0;
+  g->lo0 = 0.f - vs0 * 2.f;
+  for (int d = 0; d < 3; ++d) g->lo[d] = b8[1 + d] - pad;
+  g->h = cell;
+  g->radius = radius;
+  g->radius2 = radius * radius;
+  g->rings = (int)ceilf(radius / cell);
+}
+
+// ------------------------------------------------------------------ batched kernels
+// mirror of the units' state words into pinned host memory (the host then needs the stream
+// synchronisation only)
+__global__ void trk_publish_kernel(const UnitDev* __restrict__ U, Batch bt, TrkState* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < bt.n) out[e] = *U[bt.idx[e]].st;
+}
+
+// the anchor's own points: kept when their component passed filter_components (one workgroup per unit)
+__global__ void __launch_bounds__(kWg)
+trk_anchor_emit_kernel(const UnitDev* __restrict__ U, Batch bt) {
+  __shared__ int sh[kWg / 64 + 1];
+  const UnitDev& u = U[bt.idx[blockIdx.x]];
+  const int n = u.na;
+  const int ch = (n + kWg - 1) / kWg;
+  const int b = threadIdx.x * ch, e = min(n, b + ch);
+  int cnt = 0;
+  for (int i = b; i < e; ++i) cnt += u.vcm[u.comp32[i]] ? 1 : 0;
+  int tot;
+  int pos = wg_excl_scan(cnt, &tot, sh);
+  for (int i = b; i < e; ++i) {
+    int c = u.comp32[i];
+    if (u.vcm[c]) {
+      if (pos < u.ex_cap) {
+        u.ex_index[pos] = u.off_a + i;
+        u.ex_local[pos] = i;
+        u.ex_comp[pos] = c;
+      } else {
+        u.st->err = 2;
+      }
+      ++pos;
+    }
   }
-  if (i < n) {
-    float4 p = anchor[i];
-    xyzf[i] = p;
-    last[i] = p;
+  if (threadIdx.x == 0) u.st->ex_count = tot;
+}
+
+// start of a direction: nothing stopped but the components that failed filter_components, the
+// anchor's points back where they were
+__global__ void __launch_bounds__(kBlock)
+trk_dir_init_kernel(const UnitDev* __restrict__ U, Batch bt) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const float4* anchor = u.seq + u.off_a;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(u.C, u.na); i += gridDim.x * blockDim.x) {
+    if (i < u.C) {
+      bool v = u.vcm[i];
+      u.stopped[i] = !v;
+      u.moving[i] = v;
+    }
+    if (i < u.na) {
+      float4 p = anchor[i];
+      u.xyzf[i] = p;
+      u.last[i] = p;
+    }
   }
 }
 
-// ------------------------------------------------------------------ per step
 // transforms[:, col] = transforms[:, col - dir]; constant-velocity prediction for the components
 // still tracked (cluster_tracking.py:520-534)
 __global__ void __launch_bounds__(kBlock)
-trk_step_begin_kernel(int C, int n, int F, int W, int col, int dir, int last_col,
-                      const uint8_t* __restrict__ stopped, const float* __restrict__ velos,
-                      const int32_t* __restrict__ comp, float4* __restrict__ xyzf,
-                      double* __restrict__ transforms) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < C) {
-    double* dst = transforms + ((int64_t)i * W + col) * 16;
-    const double* src = transforms + ((int64_t)i * W + (col - dir)) * 16;
-    for (int k = 0; k < 16; ++k) dst[k] = src[k];
-    if (last_col >= 0 && !stopped[i]) {
-      const float* v = velos + ((int64_t)i * F + last_col) * 3;
-      float fd = (float)dir;
-      dst[3] += (double)(v[0] * fd);
-      dst[7] += (double)(v[1] * fd);
-      dst[11] += (double)(v[2] * fd);
+trk_step_begin_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int F = u.F, W = u.W;
+  const float fd = (float)a.dir;
+  if (blockIdx.x == 0 && threadIdx.x == 0) u.st->active = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(u.C, u.na); i += gridDim.x * blockDim.x) {
+    if (i < u.C) {
+      double* dst = u.transforms + ((int64_t)i * W + a.col) * 16;
+      const double* src = u.transforms + ((int64_t)i * W + (a.col - a.dir)) * 16;
+      for (int k = 0; k < 16; ++k) dst[k] = src[k];
+      if (a.last_col >= 0 && !u.stopped[i]) {
+        const float* v = u.velos + ((int64_t)i * F + a.last_col) * 3;
+        dst[3] += (double)(v[0] * fd);
+        dst[7] += (double)(v[1] * fd);
+        dst[11] += (double)(v[2] * fd);
+      }
+    }
+    if (i < u.na && a.last_col >= 0) {
+      int c = u.comp32[i];
+      if (!u.stopped[c]) {
+        const float* v = u.velos + ((int64_t)c * F + a.last_col) * 3;
+        float4 p = u.xyzf[i];
+        p.y = p.y + v[0] * fd;
+        p.z = p.z + v[1] * fd;
+        p.w = p.w + v[2] * fd;
+        u.xyzf[i] = p;
+      }
     }
   }
-  if (i < n && last_col >= 0) {
-    int c = comp[i];
-    if (!stopped[c]) {
-      const float* v = velos + ((int64_t)c * F + last_col) * 3;
-      float fd = (float)dir;
-      float4 p = xyzf[i];
-      p.y = p.y + v[0] * fd;
-      p.z = p.z + v[1] * fd;
-      p.w = p.w + v[2] * fd;
-      xyzf[i] = p;
+}
+
+// ---- sample_frame, part 1: grid_cluster ids (same arithmetic as grid_ids_kernel: start / end =
+// min / max of the cloud, frame axis widened by 0.5), sorted unique. ONE workgroup per (unit, set):
+// bounds, keys, stable radix sort on exactly the bits the ids can have, voxel boundaries.
+// blockIdx.x = set (0: the anchor's points as moved so far, 1: the target frame).
+__global__ void __launch_bounds__(kWg)
+smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls) {
+  __shared__ int hist[16 * 256];
+  __shared__ int sh[kWg / 64 + 1];
+  __shared__ float smn[kWg / 64][4], smx[kWg / 64][4];
+  __shared__ float bnd[8];
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int set = blockIdx.x;
+  const SmpSet& S = set ? u.sb : u.sa;
+  const float4* __restrict__ pts = set ? u.seq + a.off_n : (const float4*)u.xyzf;
+  const int n = set ? a.nn : u.na;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (set == 0)
+    for (int c = tid; c < u.C; c += kWg) u.sub_deg[c] = 0ULL;
+  if (n < 1) {
+    if (tid == 0) { *S.d_num = 0; S.seg[0] = 0; }
+    return;
+  }
+  // bounds
+  {
+    float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < n; i += kWg) {
+      float4 p = pts[i];
+      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+      mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
     }
-  }
-}
-
-// ---- anchor + target frame sampled by ONE key / sort / segment pipeline -------------------------
-// Both clouds get their grid_cluster ids (same arithmetic as grid_ids_kernel, each with its own
-// bounds) under a set bit on top of the key, so one sort yields the anchor's voxels first, then the
-// target's, every voxel's rows in ascending original index: exactly the two separate pipelines,
-// half the launches.
-__global__ void __launch_bounds__(kBlock)
-trk_bounds2_kernel(const float4* __restrict__ a, int na, const float4* __restrict__ b, int nb,
-                   float* __restrict__ out16) {
-  const float4* pts = blockIdx.y == 0 ? a : b;
-  int n = blockIdx.y == 0 ? na : nb;
-  float* out8 = out16 + 8 * blockIdx.y;
-  float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
-  float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 p = pts[i];
-    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-    mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
-  }
-  __shared__ float smn[kBlock / 64][4], smx[kBlock / 64][4];
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    float x = wave_min(mn[d]), y = wave_max(mx[d]);
-    if (lane == 0) { smn[w][d] = x; smx[w][d] = y; }
+    for (int d = 0; d < 4; ++d) {
+      float x = wave_min(mn[d]), y = wave_max(mx[d]);
+      if (lane == 0) { smn[w][d] = x; smx[w][d] = y; }
+    }
+    __syncthreads();
+    if (tid < 4) {
+      float x = smn[0][tid], y = smx[0][tid];
+      for (int k = 1; k < kWg / 64; ++k) { x = fminf(x, smn[k][tid]); y = fmaxf(y, smx[k][tid]); }
+      bnd[tid] = x;
+      bnd[4 + tid] = y;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (threadIdx.x < 4 && n > 0) {
-    int d = threadIdx.x;
-    float x = smn[0][d], y = smx[0][d];
-    for (int k = 1; k < kBlock / 64; ++k) { x = fminf(x, smn[k][d]); y = fmaxf(y, smx[k][d]); }
-    atomic_min_f32(&out8[d], x);
-    atomic_max_f32(&out8[4 + d], y);
-  }
-}
-
-__global__ void trk_bounds_reset_kernel(float* out16) {
-  int t = threadIdx.x;
-  if (t < 16) out16[t] = ((t & 7) < 4) ? __builtin_inff() : -__builtin_inff();
-}
-
-__global__ void __launch_bounds__(kBlock)
-trk_keys2_kernel(const float4* __restrict__ a, int na, const float4* __restrict__ b, int nb,
-                 const float* __restrict__ bounds16, float4 size, float margin0,
-                 uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= na + nb) return;
-  int set = i >= na;
-  const float* b8 = bounds16 + 8 * set;
-  float st[4], en[4], sz[4] = {size.x, size.y, size.z, size.w};
+  float st[4], en[4], sz[4] = {1.f, ls.v[a.lv][0], ls.v[a.lv][1], ls.v[a.lv][2]};
 #pragma unroll
-  for (int d = 0; d < 4; ++d) { st[d] = b8[d]; en[d] = b8[4 + d]; }
-  st[0] = st[0] - margin0;
-  en[0] = en[0] + margin0;
-  int64_t stride[4];
+  for (int d = 0; d < 4; ++d) { st[d] = bnd[d]; en[d] = bnd[4 + d]; }
+  st[0] = st[0] - 0.5f;
+  en[0] = en[0] + 0.5f;
+  int64_t stride[5];
   stride[0] = 1;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / sz[d]) + 1);
-  float4 p = set ? b[i - na] : a[i];
-  int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
-               (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
-  keys[i] = ((uint64_t)set << 62) | (uint64_t)id;
-  vals[i] = i;
+  for (int d = 0; d < 4; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / sz[d]) + 1);
+  int nbits = 1;
+  while (nbits < 62 && (1LL << nbits) < stride[4]) ++nbits;
+  for (int i = tid; i < n; i += kWg) {
+    float4 p = pts[i];
+    int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
+                 (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
+    S.k0[i] = (uint64_t)id;
+    S.v0[i] = i;
+  }
+  __syncthreads();
+  int which = wg_radix_sort(S.k0, S.v0, S.k1, S.v1, n, nbits, hist, sh);
+  const uint64_t* __restrict__ sk = which ? S.k1 : S.k0;
+  const int32_t* __restrict__ sv = which ? S.v1 : S.v0;
+  // voxel boundaries + the sorted order in its final place
+  const int ch = (n + kWg - 1) / kWg;
+  const int b = tid * ch, e = min(n, b + ch);
+  int heads = 0;
+  for (int i = b; i < e; ++i) heads += (i == 0 || sk[i] != sk[i - 1]) ? 1 : 0;
+  int tot;
+  int rank = wg_excl_scan(heads, &tot, sh);
+  for (int i = b; i < e; ++i) {
+    if (i == 0 || sk[i] != sk[i - 1]) S.seg[rank++] = i;
+    S.order[i] = sv[i];
+  }
+  if (tid == 0) { S.seg[tot] = n; *S.d_num = tot; }
 }
 
-// per voxel of the combined structure: serial mean of fxyz, stationary vote, (anchor only) median
-// component and the per-component voxel count; also finds where the target's voxels begin
+// ---- sample_frame, part 2: per voxel the serial mean of fxyz, the stationary vote and (anchor) the
+// median component and the per-component voxel count. blockIdx.z = set.
 __global__ void __launch_bounds__(kBlock)
-trk_sample2_emit_kernel(const float4* __restrict__ a, const float* __restrict__ stat_a,
-                        const int64_t* __restrict__ comp64, int na, const float4* __restrict__ b,
-                        const float* __restrict__ stat_b, const int32_t* __restrict__ order,
-                        const int32_t* __restrict__ seg, const int64_t* __restrict__ d_num, int n,
-                        float4* __restrict__ sub, int32_t* __restrict__ sub_comp,
-                        int32_t* __restrict__ flag_ns, unsigned long long* __restrict__ sub_deg,
-                        int64_t* __restrict__ d_va) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  int64_t v = *d_num;
-  if (s >= v) { flag_ns[s] = 0; return; }
-  int bb = seg[s], e = seg[s + 1];
-  bool tgt = order[bb] >= na;
-  // first target voxel (or v if there is none)
-  if (tgt && (s == 0 || order[seg[s - 1]] < na)) *d_va = s;
-  if (!tgt && s == v - 1) *d_va = v;
-  // a coarse voxel holds dozens of rows and every row is two dependent loads (order -> point): eight
-  // rows are requested together and then added in their original order (same sums, an eighth of the
-  // round trips); the anchor's component ids ride along
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, st = 0.f;
-  int64_t first = 0;
-  bool same = true;
-  for (int p0 = bb; p0 < e; p0 += 8) {
-    int o[8];
-    float4 q[8];
-    float sv[8];
-    int64_t cc[8];
+smp_emit_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int set = blockIdx.z;
+  const SmpSet& S = set ? u.sb : u.sa;
+  const int v = (int)*S.d_num;
+  const int nround = (v + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= nround) return;
+  const float4* __restrict__ pts = set ? u.seq + a.off_n : (const float4*)u.xyzf;
+  const uint8_t* __restrict__ stat = u.seq_stat + (set ? a.off_n : u.off_a);
+  const int64_t* __restrict__ comp64 = u.comp64;
+  const int32_t* __restrict__ order = S.order;
+  const int32_t* __restrict__ seg = S.seg;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+    const int s = r * kBlock + threadIdx.x;
+    int64_t comp_of = -1;  // anchor voxels: the voxel's (median) component
+    if (s < v) {
+      const int bb = seg[s], e = seg[s + 1];
+      // a coarse voxel holds dozens of rows and every row is two dependent loads (order -> point):
+      // eight rows are requested together and then added in their original order (same sums, an
+      // eighth of the round trips); the anchor's component ids ride along
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, stv = 0.f;
+      int64_t first = 0;
+      bool same = true;
+      for (int p0 = bb; p0 < e; p0 += 8) {
+        int o[8];
+        float4 q[8];
+        float sv[8];
+        int64_t cc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (p0 + j < e) ? order[p0 + j] : -1;
+        for (int j = 0; j < 8; ++j) o[j] = (p0 + j < e) ? order[p0 + j] : -1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      sv[j] = 0.f;
-      cc[j] = 0;
-      if (o[j] >= 0) {
-        if (tgt) {
-          q[j] = b[o[j] - na];
-          sv[j] = stat_b[o[j] - na];
-        } else {
-          q[j] = a[o[j]];
-          sv[j] = stat_a[o[j]];
-          cc[j] = comp64[o[j]];
+        for (int j = 0; j < 8; ++j) {
+          q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          sv[j] = 0.f;
+          cc[j] = 0;
+          if (o[j] >= 0) {
+            q[j] = pts[o[j]];
+            sv[j] = stat[o[j]] ? 1.f : 0.f;
+            if (!set) cc[j] = comp64[o[j]];
+          }
+        }
+        if (p0 == bb) first = cc[0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (o[j] >= 0) {
+            a0 = a0 + q[j].x; a1 = a1 + q[j].y; a2 = a2 + q[j].z; a3 = a3 + q[j].w;
+            stv = stv + sv[j];
+            same = same && (cc[j] == first);
+          }
         }
       }
-    }
-    if (p0 == bb) first = cc[0];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (o[j] >= 0) {
-        a0 = a0 + q[j].x; a1 = a1 + q[j].y; a2 = a2 + q[j].z; a3 = a3 + q[j].w;
-        st = st + sv[j];
-        same = same && (cc[j] == first);
-      }
-    }
-  }
-  float cnt = (float)(e - bb);
-  sub[s] = make_float4(a0 / cnt, a1 / cnt, a2 / cnt, a3 / cnt);
-  flag_ns[s] = !((st / cnt) > 0.5f);
-  int64_t comp_of = -1;  // anchor voxels: the voxel's (median) component
-  if (!tgt) {
-    int k = (e - bb) / 2;
-    int64_t res = first;
-    if (!same) {
-      for (int p = bb; p < e; ++p) {
-        int64_t x = comp64[order[p]];
-        int lt = 0, eq = 0;
-        for (int q = bb; q < e; ++q) {
-          int64_t y = comp64[order[q]];
-          lt += (y < x);
-          eq += (y == x);
+      float cnt = (float)(e - bb);
+      S.sub[s] = make_float4(a0 / cnt, a1 / cnt, a2 / cnt, a3 / cnt);
+      S.flag[s] = !((stv / cnt) > 0.5f);
+      if (!set) {
+        int k = (e - bb) / 2;
+        int64_t res = first;
+        if (!same) {
+          for (int p = bb; p < e; ++p) {
+            int64_t x = comp64[order[p]];
+            int lt = 0, eq = 0;
+            for (int q2 = bb; q2 < e; ++q2) {
+              int64_t y = comp64[order[q2]];
+              lt += (y < x);
+              eq += (y == x);
+            }
+            if (lt <= k && k < lt + eq) { res = x; break; }
+          }
         }
-        if (lt <= k && k < lt + eq) { res = x; break; }
+        S.sub_comp[s] = (int32_t)res;
+        comp_of = res;
       }
     }
-    sub_comp[s] = (int32_t)res;
-    comp_of = res;
-  }
-  // per-component voxel counts: neighbouring voxels mostly share a component and a large component
-  // owns thousands of voxels, so one atomic per voxel queues up on a few addresses (~12 ns each);
-  // the lanes of a wave that agree on the component send one add between them
-  {
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(comp_of >= 0);
-    while (todo) {
-      int leader = __ffsll((long long)todo) - 1;
-      long long lc = __shfl((long long)comp_of, leader, 64);
-      unsigned long long grp = __ballot(comp_of == lc);
-      if (lane == leader) atomicAdd(&sub_deg[lc], (unsigned long long)__popcll(grp));
-      todo &= ~grp;
+    // per-component voxel counts: neighbouring voxels mostly share a component and a large component
+    // owns thousands of voxels, so one atomic per voxel queues up on a few addresses (~12 ns each);
+    // the lanes of a wave that agree on the component send one add between them
+    if (!set) {
+      const int lane = threadIdx.x & 63;
+      unsigned long long todo = __ballot(comp_of >= 0);
+      while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        long long lc = __shfl((long long)comp_of, leader, 64);
+        unsigned long long grp = __ballot(comp_of == lc);
+        if (lane == leader) atomicAdd(&u.sub_deg[lc], (unsigned long long)__popcll(grp));
+        todo &= ~grp;
+      }
     }
   }
 }
 
-// split + compact: anchor voxels -> mov (the non-stationary ones), target -> sub_n (all) / ref_ns;
-// counts = {anchor voxels, anchor non-stationary, target voxels, target non-stationary}
-__global__ void __launch_bounds__(kBlock)
-trk_compact2_kernel(const float4* __restrict__ sub, const int32_t* __restrict__ sub_comp,
-                    const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int n,
-                    const int64_t* __restrict__ d_num, const int64_t* __restrict__ d_va,
-                    float4* __restrict__ mov, int32_t* __restrict__ mov_comp,
-                    float4* __restrict__ sub_n, float4* __restrict__ ref_ns,
-                    int64_t* __restrict__ counts) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  int64_t v = *d_num, va = *d_va;
-  int total_ns = pos[n - 1] + flag[n - 1];
-  int ns_a = va < n ? pos[va] : total_ns;  // non-stationary anchor voxels = rank of the first target voxel
-  if (s < v) {
-    float4 q = sub[s];
-    if (s < va) {
-      if (flag[s]) { mov[pos[s]] = q; mov_comp[pos[s]] = sub_comp[s]; }
-    } else {
-      sub_n[s - va] = q;
-      if (flag[s]) ref_ns[pos[s] - ns_a] = q;
+// ---- sample_frame, part 3: the non-stationary voxels, compacted in voxel order, and the counts the
+// registration reads. One workgroup per (unit, set); blockIdx.x = set.
+__global__ void __launch_bounds__(kWg)
+smp_compact_kernel(const UnitDev* __restrict__ U, Batch bt) {
+  __shared__ int sh[kWg / 64 + 1];
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const int set = blockIdx.x;
+  const SmpSet& S = set ? u.sb : u.sa;
+  const int v = (int)*S.d_num;
+  const int ch = (v + kWg - 1) / kWg;
+  const int b = threadIdx.x * ch, e = min(v, b + ch);
+  int cnt = 0;
+  for (int s = b; s < e; ++s) cnt += S.flag[s] ? 1 : 0;
+  int tot;
+  int pos = wg_excl_scan(cnt, &tot, sh);
+  for (int s = b; s < e; ++s) {
+    if (S.flag[s]) {
+      S.out[pos] = S.sub[s];
+      if (!set) S.out_comp[pos] = S.sub_comp[s];
+      ++pos;
     }
   }
-  if (s == 0) {
-    counts[0] = va;
-    counts[1] = ns_a;
-    counts[2] = v - va;
-    counts[3] = total_ns - ns_a;
+  if (threadIdx.x == 0) {
+    u.st->counts[2 * set] = v;
+    u.st->counts[2 * set + 1] = tot;
   }
 }
 
 // frame.fxyz[:, 1:] = (R @ xyz.double()).float() + t.float(); transforms[:, col] = T @ transforms[:, col]
 __global__ void __launch_bounds__(kBlock)
-trk_apply_T_kernel(int C, int n, int W, int col, const double* __restrict__ T,
-                   const int32_t* __restrict__ comp, float4* __restrict__ xyzf,
-                   double* __restrict__ transforms) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const double* M = T + (int64_t)comp[i] * 16;
-    float4 p = xyzf[i];
-    double x = (double)p.y, y = (double)p.z, z = (double)p.w;
-    float rx = (float)((M[0] * x + M[1] * y) + M[2] * z);
-    float ry = (float)((M[4] * x + M[5] * y) + M[6] * z);
-    float rz = (float)((M[8] * x + M[9] * y) + M[10] * z);
-    p.y = rx + (float)M[3];
-    p.z = ry + (float)M[7];
-    p.w = rz + (float)M[11];
-    xyzf[i] = p;
+trk_apply_T_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const double* __restrict__ T = u.Tl;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(u.C, u.na); i += gridDim.x * blockDim.x) {
+    if (i < u.na) {
+      const double* M = T + (int64_t)u.comp32[i] * 16;
+      float4 p = u.xyzf[i];
+      double x = (double)p.y, y = (double)p.z, z = (double)p.w;
+      float rx = (float)((M[0] * x + M[1] * y) + M[2] * z);
+      float ry = (float)((M[4] * x + M[5] * y) + M[6] * z);
+      float rz = (float)((M[8] * x + M[9] * y) + M[10] * z);
+      p.y = rx + (float)M[3];
+      p.z = ry + (float)M[7];
+      p.w = rz + (float)M[11];
+      u.xyzf[i] = p;
+    }
+    if (i < u.C) {
+      const double* A = T + (int64_t)i * 16;
+      double* B = u.transforms + ((int64_t)i * u.W + a.col) * 16;
+      double R[16];
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+          double acc = A[r * 4 + 0] * B[0 * 4 + c];
+          acc = acc + A[r * 4 + 1] * B[1 * 4 + c];
+          acc = acc + A[r * 4 + 2] * B[2 * 4 + c];
+          acc = acc + A[r * 4 + 3] * B[3 * 4 + c];
+          R[r * 4 + c] = acc;
+        }
+      for (int k = 0; k < 16; ++k) B[k] = R[k];
+    }
   }
-  if (i < C) {
-    const double* A = T + (int64_t)i * 16;
-    double* B = transforms + ((int64_t)i * W + col) * 16;
-    double R[16];
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) {
-        double acc = A[r * 4 + 0] * B[0 * 4 + c];
-        acc = acc + A[r * 4 + 1] * B[1 * 4 + c];
-        acc = acc + A[r * 4 + 2] * B[2 * 4 + c];
-        acc = acc + A[r * 4 + 3] * B[3 * 4 + c];
-        R[r * 4 + c] = acc;
+}
+
+// per present component (one wave each): centre of the moved points, mean point velocity
+// (xyz - last_xyz) * dir with z zeroed, centre difference (cluster_tracking.py:629-648). The sums are
+// the ordered wave sums of pcs_segment_reduce_f32 (lane l adds rows l, l + 64, ... in order, then a
+// 64-lane butterfly), so they equal the op-by-op path bit for bit.
+__global__ void __launch_bounds__(kBlock)
+trk_motion_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int Cu = (int)*u.d_numc;
+  const int lane = threadIdx.x & 63;
+  const int F = u.F;
+  const float fd = (float)a.dir;
+  for (int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < Cu; seg += (gridDim.x * blockDim.x) >> 6) {
+    const int b = u.seg_c[seg], e = u.seg_c[seg + 1];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    for (int p = b + lane; p < e; p += 64) {
+      int i = u.order_c[p];
+      float4 x = u.xyzf[i], q = u.last[i];
+      s0 = s0 + x.y; s1 = s1 + x.z; s2 = s2 + x.w;
+      v0 = v0 + (x.y - q.y) * fd; v1 = v1 + (x.z - q.z) * fd; v2 = v2 + (x.w - q.w) * fd;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s0 = s0 + __shfl_xor(s0, o, 64); s1 = s1 + __shfl_xor(s1, o, 64); s2 = s2 + __shfl_xor(s2, o, 64);
+      v0 = v0 + __shfl_xor(v0, o, 64); v1 = v1 + __shfl_xor(v1, o, 64); v2 = v2 + __shfl_xor(v2, o, 64);
+    }
+    if (lane == 0) {
+      const int64_t c = u.uniq_c[seg];
+      const float nf = (float)(e - b);
+      float* cn = u.centers + ((int64_t)c * F + a.next) * 3;
+      const float* cp = u.centers + ((int64_t)c * F + (a.next - a.dir)) * 3;
+      float* vn = u.velos + ((int64_t)c * F + a.next) * 3;
+      float* dn = u.diffs + ((int64_t)c * F + a.next) * 3;
+      const float sum[3] = {s0, s1, s2};
+      const float mean[3] = {v0 / nf, v1 / nf, v2 / nf};
+      for (int k = 0; k < 3; ++k) {
+        float ctr = sum[k] / nf;
+        cn[k] = ctr;
+        dn[k] = (ctr - cp[k]) * fd;
+        float v = k < 2 ? mean[k] : 0.f;
+        vn[k] = v;
+        u.velo_pre[c * 3 + k] = v;
       }
-    for (int k = 0; k < 16; ++k) B[k] = R[k];
-  }
-}
-
-// point_velo = (xyz - last_xyz) * dir, laid out [n,4] (4th column 0) for the d = 4 reductions
-__global__ void __launch_bounds__(kBlock)
-trk_point_velo_kernel(const float4* __restrict__ xyzf, const float4* __restrict__ last, int n, int dir,
-                      float4* __restrict__ pv) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyzf[i], q = last[i];
-  float fd = (float)dir;
-  pv[i] = make_float4((p.y - q.y) * fd, (p.z - q.z) * fd, (p.w - q.w) * fd, 0.f);
-}
-
-// per present component: centre of the moved points, mean point velocity (z zeroed), centre
-// difference (cluster_tracking.py:631-648)
-__global__ void __launch_bounds__(kBlock)
-trk_comp_motion_kernel(const int64_t* __restrict__ uniq, const int32_t* __restrict__ seg, int Cu,
-                       int F, int next, int dir, const float* __restrict__ sum4,
-                       const float* __restrict__ mean4, float* __restrict__ centers,
-                       float* __restrict__ velos, float* __restrict__ diffs,
-                       float* __restrict__ velo_pre) {
-  int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= Cu) return;
-  int64_t c = uniq[u];
-  float nf = (float)(seg[u + 1] - seg[u]);
-  float* cn = centers + ((int64_t)c * F + next) * 3;
-  const float* cp = centers + ((int64_t)c * F + (next - dir)) * 3;
-  float* vn = velos + ((int64_t)c * F + next) * 3;
-  float* dn = diffs + ((int64_t)c * F + next) * 3;
-  float fd = (float)dir;
-  for (int k = 0; k < 3; ++k) {
-    float ctr = sum4[u * 4 + k] / nf;
-    cn[k] = ctr;
-    dn[k] = (ctr - cp[k]) * fd;
-    float v = k < 2 ? mean4[u * 4 + k] : 0.f;
-    vn[k] = v;
-    velo_pre[c * 3 + k] = v;
+    }
   }
 }
 
@@ -444,228 +692,262 @@ __device__ __forceinline__ float dist_compensate(int64_t deg) {
 }
 
 // after smooth_velo: move the points by the smoothing correction, then the stop rules
-// (cluster_tracking.py:650-700) and the per-step records
+// (cluster_tracking.py:650-700) and the per-step records; the harvest grid is reset on the way
 __global__ void __launch_bounds__(kBlock)
-trk_after_smooth_kernel(int C, int n, int F, int W, int col, int frame_id, int next, int dir,
-                        int last_col, int min_move_frame, float reg_coeff, float angle_thr,
-                        const int32_t* __restrict__ comp, float4* __restrict__ xyzf,
-                        float4* __restrict__ last, float* __restrict__ velos,
-                        const float* __restrict__ velo_pre, const float* __restrict__ centers,
-                        const float* __restrict__ diam, const int64_t* __restrict__ deg_i,
-                        const double* __restrict__ l1, const float* __restrict__ ratio,
-                        uint8_t* __restrict__ stopped, uint8_t* __restrict__ moving,
-                        double* __restrict__ transforms, int64_t* __restrict__ cmin,
-                        int64_t* __restrict__ cmax, float* __restrict__ reg_errors,
-                        float* __restrict__ edge_ratios, TrkState* st) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float fd = (float)dir;
-  if (i < n) {
-    int c = comp[i];
-    const float* vn = velos + ((int64_t)c * F + next) * 3;
-    const float* vp = velo_pre + (int64_t)c * 3;
-    float4 p = xyzf[i];
-    p.y = p.y + (vn[0] - vp[0]) * fd;
-    p.z = p.z + (vn[1] - vp[1]) * fd;
-    p.w = p.w + (vn[2] - vp[2]) * fd;
-    xyzf[i] = p;
-    last[i] = p;
-  }
-  if (i < C) {
-    int c = i;
-    float* vn = velos + ((int64_t)c * F + next) * 3;
-    const float* vp = velo_pre + (int64_t)c * 3;
-    double* T = transforms + ((int64_t)c * W + col) * 16;
-    T[3] += (double)((vn[0] - vp[0]) * fd);
-    T[7] += (double)((vn[1] - vp[1]) * fd);
-    T[11] += (double)((vn[2] - vp[2]) * fd);
-    bool stop = stopped[c];
-    float dm = diam[c];
-    float thr = (reg_coeff * dm) * (1.f + dist_compensate(deg_i[c]));
-    stop = stop || (l1[c] > (double)thr);
-    stop = stop || (ratio[c] < 0.5f);
-    if ((next - frame_id) * dir == min_move_frame) {
-      const float* cn = centers + ((int64_t)c * F + next) * 3;
-      const float* c0 = centers + ((int64_t)c * F + frame_id) * 3;
-      float moved = norm3(cn[0] - c0[0], cn[1] - c0[1], cn[2] - c0[2]);
-      moving[c] = moving[c] && (moved > 0.08f * dm);
+trk_after_smooth_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, int min_move_frame,
+                        float reg_coeff, float angle_thr) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int F = u.F, W = u.W, next = a.next, dir = a.dir, frame_id = u.anchor, last_col = a.last_col;
+  const float fd = (float)dir;
+  g2_clear(u.hg, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(u.C, u.na); i += gridDim.x * blockDim.x) {
+    if (i < u.na) {
+      int c = u.comp32[i];
+      const float* vn = u.velos + ((int64_t)c * F + next) * 3;
+      const float* vp = u.velo_pre + (int64_t)c * 3;
+      float4 p = u.xyzf[i];
+      p.y = p.y + (vn[0] - vp[0]) * fd;
+      p.z = p.z + (vn[1] - vp[1]) * fd;
+      p.w = p.w + (vn[2] - vp[2]) * fd;
+      u.xyzf[i] = p;
+      u.last[i] = p;
     }
-    float v0 = vn[0], v1 = vn[1], v2 = vn[2];
-    if (last_col >= 0) {
-      const float* lv = velos + ((int64_t)c * F + last_col) * 3;
-      float dev = norm3(v0 - lv[0], v1 - lv[1], v2 - lv[2]);
-      stop = stop || (dev > 0.24f * dm);
-      const float* pv = velos + ((int64_t)c * F + (next - dir)) * 3;
-      float nrm = norm3(v0, v1, v2) * norm3(pv[0], pv[1], pv[2]);
-      nrm = fmaxf(nrm, 1e-6f);
-      float cosv = ((v0 * pv[0] + v1 * pv[1]) + v2 * pv[2]) / nrm;
-      cosv = fminf(fmaxf(cosv, -1.f), 1.f);
-      float angle = acosf(cosv) / 3.14159265358979323846f * 180.0f;
-      float nxy = sqrtf(v0 * v0 + v1 * v1);
-      stop = stop || ((angle > angle_thr) && (nxy > 0.01f));
-    }
-    if (next == frame_id - 1) {
-      float* vf = velos + ((int64_t)c * F + frame_id) * 3;
-      vf[0] = v0; vf[1] = v1; vf[2] = v2;
-    }
-    stopped[c] = stop;
-    if (!stop) {
-      if (dir == -1) cmin[c] = next; else cmax[c] = next;
-      st->active = 1;
-    }
-    reg_errors[(int64_t)c * F + next] = (float)l1[c];
-    edge_ratios[(int64_t)c * F + next] = ratio[c];
-  }
-}
-
-__global__ void __launch_bounds__(kBlock)
-trk_set_frame_kernel(float4* __restrict__ xyzf, int n, float f) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) xyzf[i].x = f;
-}
-
-// harvest flags: target-frame point q is kept when its nearest moved anchor point belongs to a
-// component that is still tracked (cluster_tracking.py:702-741)
-__global__ void __launch_bounds__(kBlock)
-trk_harvest_flag_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, int m,
-                        const int32_t* __restrict__ comp, const uint8_t* __restrict__ stopped,
-                        int32_t* __restrict__ flag) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= m) return;
-  int f = 0;
-  if (deg[q] > 0) f = !stopped[comp[nbr[q]]];
-  flag[q] = f;
-}
-
-// anchor's own points: kept when their component passed filter_components
-__global__ void __launch_bounds__(kBlock)
-trk_anchor_flag_kernel(const int32_t* __restrict__ comp, const uint8_t* __restrict__ vcm, int n,
-                       int32_t* __restrict__ flag) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = vcm[comp[i]] ? 1 : 0;
-}
-
-// append the kept rows: (index into the sequence, index within the frame, component)
-__global__ void __launch_bounds__(kBlock)
-trk_harvest_emit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int m,
-                        const int32_t* __restrict__ nbr, const int32_t* __restrict__ comp,
-                        int64_t frame_off, int64_t cap, int64_t* __restrict__ ex_index,
-                        int64_t* __restrict__ ex_local, int64_t* __restrict__ ex_comp,
-                        const int64_t* __restrict__ d_base, int64_t* __restrict__ d_next,
-                        TrkState* st) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= m) return;
-  int64_t base = *d_base;
-  if (flag[q]) {
-    int64_t o = base + pos[q];
-    if (o < cap) {
-      ex_index[o] = frame_off + q;
-      ex_local[o] = q;
-      ex_comp[o] = comp[nbr ? nbr[q] : q];
-    } else {
-      st->err = 2;
+    if (i < u.C) {
+      int c = i;
+      float* vn = u.velos + ((int64_t)c * F + next) * 3;
+      const float* vp = u.velo_pre + (int64_t)c * 3;
+      double* T = u.transforms + ((int64_t)c * W + a.col) * 16;
+      T[3] += (double)((vn[0] - vp[0]) * fd);
+      T[7] += (double)((vn[1] - vp[1]) * fd);
+      T[11] += (double)((vn[2] - vp[2]) * fd);
+      bool stop = u.stopped[c];
+      float dm = u.diam[c];
+      float thr = (reg_coeff * dm) * (1.f + dist_compensate(u.deg_i[c]));
+      stop = stop || (u.l1[c] > (double)thr);
+      stop = stop || (u.ratio[c] < 0.5f);
+      if ((next - frame_id) * dir == min_move_frame) {
+        const float* cn = u.centers + ((int64_t)c * F + next) * 3;
+        const float* c0 = u.centers + ((int64_t)c * F + frame_id) * 3;
+        float moved = norm3(cn[0] - c0[0], cn[1] - c0[1], cn[2] - c0[2]);
+        u.moving[c] = u.moving[c] && (moved > 0.08f * dm);
+      }
+      float v0 = vn[0], v1 = vn[1], v2 = vn[2];
+      if (last_col >= 0) {
+        const float* lv = u.velos + ((int64_t)c * F + last_col) * 3;
+        float dev = norm3(v0 - lv[0], v1 - lv[1], v2 - lv[2]);
+        stop = stop || (dev > 0.24f * dm);
+        const float* pv = u.velos + ((int64_t)c * F + (next - dir)) * 3;
+        float nrm = norm3(v0, v1, v2) * norm3(pv[0], pv[1], pv[2]);
+        nrm = fmaxf(nrm, 1e-6f);
+        float cosv = ((v0 * pv[0] + v1 * pv[1]) + v2 * pv[2]) / nrm;
+        cosv = fminf(fmaxf(cosv, -1.f), 1.f);
+        float angle = acosf(cosv) / 3.14159265358979323846f * 180.0f;
+        float nxy = sqrtf(v0 * v0 + v1 * v1);
+        stop = stop || ((angle > angle_thr) && (nxy > 0.01f));
+      }
+      if (next == frame_id - 1) {
+        float* vf = u.velos + ((int64_t)c * F + frame_id) * 3;
+        vf[0] = v0; vf[1] = v1; vf[2] = v2;
+      }
+      u.stopped[c] = stop;
+      if (!stop) {
+        if (dir == -1) u.cmin[c] = next; else u.cmax[c] = next;
+        u.st->active = 1;
+      }
+      u.reg_errors[(int64_t)c * F + next] = (float)u.l1[c];
+      u.edge_ratios[(int64_t)c * F + next] = u.ratio[c];
     }
   }
-  if (q == m - 1) *d_next = base + pos[q] + flag[q];
 }
 
-__global__ void trk_copy_count_kernel(const int64_t* src, int64_t* dst) { *dst = *src; }
+// ---- harvest (cluster_tracking.py:702-741): the target frame's points whose nearest moved anchor
+// point (NN_GRAPH: 1-NN within the radius, same frame) belongs to a component still tracked
+__global__ void __launch_bounds__(kBlock)
+hv_insert_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  if (a.nn < 1) return;
+  const GridDesc d = *u.hdesc;
+  const int nround = (u.na + kBlock - 1) / kBlock;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    int i = r * kBlock + threadIdx.x;
+    bool in = i < u.na;
+    float4 p = in ? u.xyzf[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    p.x = (float)a.next;  // frame.fxyz[:, 0] = next_frame_id for the duration of the query
+    g2_insert_point(d, u.hg, in, i, p, &u.st->err);
+  }
+}
 
-// the state words the host is about to read, mirrored into pinned host memory (the host then needs
-// the stream synchronisation only)
-__global__ void trk_publish_kernel(const TrkState* __restrict__ st, TrkState* __restrict__ out) { *out = *st; }
+__global__ void __launch_bounds__(kBlock)
+hv_search_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  const UnitDev& u = U[bt.idx[blockIdx.y]];
+  const StepArg a = sa.a[blockIdx.y];
+  const int M = a.nn;
+  const GridDesc d = *u.hdesc;
+  const float4* __restrict__ qry = u.seq + a.off_n;
+  const int nround = (M + kBlock / 32 - 1) / (kBlock / 32);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    int qid = r * (kBlock / 32) + (threadIdx.x >> 5);
+    bool valid = qid < M;
+    float4 p = valid ? qry[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int rr = g2_nearest_coop(d, u.hg, p, 0, valid, &u.st->err);
+    if (valid && (threadIdx.x & 31) == 0) {
+      u.hv_deg[qid] = rr >= 0;
+      u.hv_nbr[qid] = rr;
+    }
+  }
+}
 
-int radius_nn1_view(int64_t N, int64_t M, void* ws, size_t ws_bytes, const int32_t** nbr_idx,
-                    const int32_t** deg, const int32_t** err);
-int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo,
-                    int frame_hi, float weight0, float weight, int num_itr, float stopping, void* ws,
-                    size_t ws_bytes, int* err, hipStream_t s);
+// kept rows appended in point order: (index into the sequence, index within the frame, component).
+// One workgroup per unit.
+__global__ void __launch_bounds__(kWg)
+hv_compact_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
+  __shared__ int sh[kWg / 64 + 1];
+  const UnitDev& u = U[bt.idx[blockIdx.x]];
+  const StepArg a = sa.a[blockIdx.x];
+  const int m = a.nn;
+  if (m < 1) return;
+  const int ch = (m + kWg - 1) / kWg;
+  const int b = threadIdx.x * ch, e = min(m, b + ch);
+  int cnt = 0;
+  for (int q = b; q < e; ++q)
+    if (u.hv_deg[q] > 0 && !u.stopped[u.comp32[u.hv_nbr[q]]]) ++cnt;
+  int tot;
+  int64_t pos = u.st->ex_count + wg_excl_scan(cnt, &tot, sh);
+  for (int q = b; q < e; ++q) {
+    if (u.hv_deg[q] > 0) {
+      int c = u.comp32[u.hv_nbr[q]];
+      if (!u.stopped[c]) {
+        if (pos < u.ex_cap) {
+          u.ex_index[pos] = a.off_n + q;
+          u.ex_local[pos] = q;
+          u.ex_comp[pos] = c;
+        } else {
+          u.st->err = 2;
+        }
+        ++pos;
+      }
+    }
+  }
+  __syncthreads();  // every thread has read ex_count
+  if (threadIdx.x == 0) u.st->ex_count += tot;
+}
 
-struct TrkPlan {
-  TrkState* st;
-  int64_t* exc;  // [2] ping-pong extraction counters
-  // anchor
-  float4 *xyzf, *last, *pv;
-  int64_t* comp64;
-  int32_t* comp32;
-  float *stat_a, *dist;
-  int32_t *order_c, *seg_c;
-  int64_t *uniq_c, *d_numc;
-  // per component
-  float *deg_f, *diam, *ctr, *centers, *diffs, *velo_pre, *ratio, *ratio_tmp, *red4a, *red4b, *red1;
-  int64_t* deg_i;
-  unsigned long long* sub_deg;
-  uint8_t* stopped;
-  double *Tl, *l1, *l1_tmp;
-  // sampling (a = anchor, n = target frame)
-  float *b8;
-  int32_t* seg_s;
-  int64_t* d_nums;
-  float4 *mov, *sub_n, *ref_ns, *sub2;
-  int32_t *sub_comp, *mov_comp, *flag, *pos;
-  float* stat_n;
-  void *ws_unique, *ws_icp, *ws_rg, *ws_sv, *tmp_scan;
-  size_t unique_bytes, icp_bytes, rg_bytes, sv_bytes, scan_bytes;
-  size_t comp_zero_begin, comp_zero_end;
+int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
+                          const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
+                          float weight0, float weight, int num_itr, float stopping, void* const* ws,
+                          const size_t* ws_bytes, int* const* err, hipStream_t s);
+
+// ------------------------------------------------------------------ host side
+struct UnitPlan {
+  UnitDev d;
+  void *ws_unique, *ws_icp, *ws_sv;
+  size_t unique_bytes, icp_bytes, sv_bytes;
+  size_t zero_begin, zero_end;
 };
 
-static bool plan_track(Arena& a, int64_t na, int64_t nm, int64_t C, int F, TrkPlan& p) {
+static void plan_set(Arena& a, int64_t n, bool anchor, SmpSet& S) {
+  S.k0 = a.take<uint64_t>(n);
+  S.k1 = a.take<uint64_t>(n);
+  S.v0 = a.take<int32_t>(n);
+  S.v1 = a.take<int32_t>(n);
+  S.order = a.take<int32_t>(n);
+  S.seg = a.take<int32_t>(n + 1);
+  S.d_num = a.take<int64_t>(1);
+  S.sub = a.take<float4>(n);
+  S.sub_comp = anchor ? a.take<int32_t>(n) : nullptr;
+  S.flag = a.take<int32_t>(n);
+  S.out = a.take<float4>(n);
+  S.out_comp = anchor ? a.take<int32_t>(n) : nullptr;
+}
+
+static bool plan_unit(Arena& a, int64_t na, int64_t nm, int64_t C, int F, UnitPlan& p) {
   if (na < 1) na = 1;
   if (nm < 1) nm = 1;
-  p.st = a.take<TrkState>(1);
-  p.exc = a.take<int64_t>(2);
-  p.xyzf = a.take<float4>(na + 1);  // + 1: the d = 4 reductions read one float past the last row
-  p.last = a.take<float4>(na);
-  p.pv = a.take<float4>(na);
-  p.comp64 = a.take<int64_t>(na);
-  p.comp32 = a.take<int32_t>(na);
-  p.stat_a = a.take<float>(na);
-  p.dist = a.take<float>(na);
-  p.order_c = a.take<int32_t>(na);
-  p.seg_c = a.take<int32_t>(na + 1);
-  p.uniq_c = a.take<int64_t>(na);
-  p.d_numc = a.take<int64_t>(1);
-  p.comp_zero_begin = a.off;
-  p.deg_f = a.take<float>(C);
-  p.diam = a.take<float>(C);
-  p.ctr = a.take<float>(C * 4);
-  p.centers = a.take<float>(C * (int64_t)F * 3);
-  p.diffs = a.take<float>(C * (int64_t)F * 3);
-  p.velo_pre = a.take<float>(C * 3);
-  p.ratio = a.take<float>(C);
-  p.ratio_tmp = a.take<float>(C);
-  p.deg_i = a.take<int64_t>(C);
-  p.sub_deg = a.take<unsigned long long>(C);
-  p.stopped = a.take<uint8_t>(C);
-  p.l1 = a.take<double>(C);
-  p.l1_tmp = a.take<double>(C);
-  p.comp_zero_end = a.off;
-  p.Tl = a.take<double>(C * 16);
-  p.red4a = a.take<float>(na * 4);
-  p.red4b = a.take<float>(na * 4);
-  p.red1 = a.take<float>(na);
-  p.b8 = a.take<float>(16);
-  p.seg_s = a.take<int32_t>(na + nm + 1);
-  p.d_nums = a.take<int64_t>(2);
-  p.sub2 = a.take<float4>(na + nm);
-  p.mov = a.take<float4>(na);
-  p.sub_n = a.take<float4>(nm);
-  p.ref_ns = a.take<float4>(nm);
-  p.sub_comp = a.take<int32_t>(na + nm);
-  p.mov_comp = a.take<int32_t>(na);
-  p.flag = a.take<int32_t>(na + nm);
-  p.pos = a.take<int32_t>(na + nm);
-  p.stat_n = a.take<float>(nm);
-  p.scan_bytes = scan_i32_temp_bytes(na + nm);
-  p.tmp_scan = a.take<char>(p.scan_bytes);
-  p.unique_bytes = pcs_unique_i64_workspace_bytes(na + nm);
+  UnitDev& d = p.d;
+  d.st = a.take<TrkState>(1);
+  d.xyzf = a.take<float4>(na + 1);  // + 1: the d = 4 reductions read one float past the last row
+  d.last = a.take<float4>(na);
+  d.comp64 = a.take<int64_t>(na);
+  d.comp32 = a.take<int32_t>(na);
+  d.dist = a.take<float>(na);
+  d.order_c = a.take<int32_t>(na);
+  d.seg_c = a.take<int32_t>(na + 1);
+  d.uniq_c = a.take<int64_t>(na);
+  d.d_numc = a.take<int64_t>(1);
+  p.zero_begin = a.off;
+  d.deg_f = a.take<float>(C);
+  d.diam = a.take<float>(C);
+  d.ctr = a.take<float>(C * 4);
+  d.centers = a.take<float>(C * (int64_t)F * 3);
+  d.diffs = a.take<float>(C * (int64_t)F * 3);
+  d.velo_pre = a.take<float>(C * 3);
+  d.ratio = a.take<float>(C);
+  d.ratio_tmp = a.take<float>(C);
+  d.deg_i = a.take<int64_t>(C);
+  d.sub_deg = a.take<unsigned long long>(C);
+  d.stopped = a.take<uint8_t>(C);
+  d.l1 = a.take<double>(C);
+  d.l1_tmp = a.take<double>(C);
+  p.zero_end = a.off;
+  d.Tl = a.take<double>(C * 16);
+  d.red4 = a.take<float>(na * 4);
+  d.red1 = a.take<float>(na);
+  plan_set(a, na, true, d.sa);
+  plan_set(a, nm, false, d.sb);
+  plan_grid2(a, na, d.hg);
+  d.hv_nbr = a.take<int32_t>(nm);
+  d.hv_deg = a.take<int32_t>(nm);
+  p.unique_bytes = pcs_unique_i64_workspace_bytes(na);
   p.ws_unique = a.take<char>(p.unique_bytes);
   p.icp_bytes = pcs_register_to_next_frame_workspace_bytes(na, nm, nm, C);
   p.ws_icp = a.take<char>(p.icp_bytes);
-  p.rg_bytes = pcs_radius_graph_workspace_bytes(na, nm, 1);
-  p.ws_rg = a.take<char>(p.rg_bytes);
   p.sv_bytes = pcs_smooth_velo_workspace_bytes(C, F);
   p.ws_sv = a.take<char>(p.sv_bytes);
   return a.ok();
+}
+
+struct EnginePlan {
+  UnitDev* d_units;
+  IcpProblem* d_icp;
+  float* seq_b8;
+  GridDesc* hdesc;
+};
+
+static bool plan_engine(Arena& a, EnginePlan& e) {
+  e.d_units = a.take<UnitDev>(kMaxBatch);
+  e.d_icp = a.take<IcpProblem>(kMaxBatch);
+  e.seq_b8 = a.take<float>(8);
+  e.hdesc = a.take<GridDesc>(1);
+  return a.ok();
+}
+
+enum Phase { PH_START, PH_ICP, PH_POSTWAIT, PH_FINALWAIT, PH_DONE };
+
+struct HostUnit {
+  PcsTrackUnit* io;
+  UnitPlan p;
+  int na, nm, C, F, W, anchor, min_f, max_f;
+  int64_t off_a;
+  int phase, dir, next, last_col, lv;
+  int it;         // ICP iterations enqueued for the current registration
+  int it_before;  // iterations enqueued before the last chunk
+  bool any_valid;
+  int Cu;
+  int64_t steps, reg_calls;
+  int seen[kMaxLevels][3];  // {Mn, Ra, Rn} of the last sampling at each level (launch-size estimates)
+  IcpHint hint;
+  TrkState host;
+  IcpState icp;
+};
+
+static inline int nblk(int64_t n) { return (int)(((n < 1 ? 1 : n) + kBlock - 1) / kBlock); }
+
+static inline int pow2_words(int64_t n) {
+  int64_t h = 64;
+  while (h < 2 * n) h <<= 1;
+  return (int)h;
 }
 
 }  // namespace pcs
@@ -678,15 +960,483 @@ using namespace pcs;
     if (_rc) return _rc;        \
   } while (0)
 
-static inline int nblk(int64_t n) { return (int)((n < 1 ? 1 : n) + kBlock - 1) / kBlock; }
+static_assert(kPinnedStageOff + kMaxBatch * (sizeof(UnitDev) + sizeof(IcpProblem)) <= kPinnedPageBytes,
+              "descriptor staging does not fit the pinned page");
+static_assert(kMaxBatch * sizeof(TrkState) <= kPinnedStageOff - kPinnedTrackerOff, "tracker state mirror");
+static_assert(kMaxBatch * sizeof(IcpState) <= 2048, "ICP state mirrors");
+
+static int64_t unit_frame_max(const int64_t* frame_offsets, int anchor, int min_f, int max_f) {
+  int64_t nm = 1;
+  for (int f = min_f; f <= max_f; ++f) {
+    int64_t c = frame_offsets[f + 1] - frame_offsets[f];
+    if (f != anchor && c > nm) nm = c;
+  }
+  return nm;
+}
+
+static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
+                        int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
+  if (!prm || !seq_fxyz || !frame_offsets || !units || !ws) return PCS_ERR_ARG;
+  if (n_units < 1 || n_units > kMaxBatch || num_frames < 1 || prm->num_levels < 1 ||
+      prm->num_levels > kMaxLevels || prm->max_iter < 0)
+    return PCS_ERR_ARG;
+  const int L = prm->num_levels;
+  char* page = (char*)thread_pinned_page();
+  if (!page) return PCS_ERR_HIP;
+  IcpState* pin_icp = (IcpState*)page;
+  IcpState* pin_fin = (IcpState*)(page + 2048);  // states of the registrations that finished this tick
+  TrkState* pin_trk = (TrkState*)(page + kPinnedTrackerOff);
+  UnitDev* stage_units = (UnitDev*)(page + kPinnedStageOff);
+  IcpProblem* stage_icp = (IcpProblem*)(page + kPinnedStageOff + kMaxBatch * sizeof(UnitDev));
+
+  Arena a(ws, ws_bytes);
+  EnginePlan eng;
+  if (!plan_engine(a, eng)) return PCS_ERR_WORKSPACE;
+  static thread_local HostUnit hu[kMaxBatch];
+  const int64_t n_seq = frame_offsets[num_frames];
+  for (int i = 0; i < n_units; ++i) {
+    PcsTrackUnit& io = units[i];
+    HostUnit& h = hu[i];
+    if (!io.seq_component || !io.seq_stationary || !io.ex_index || !io.ex_local || !io.ex_component ||
+        !io.transforms || !io.reg_errors || !io.comp_edge_ratios || !io.comp_velos ||
+        !io.comp_min_frame_id || !io.comp_max_frame_id || !io.moving || !io.valid_comp)
+      return PCS_ERR_ARG;
+    if (io.C < 1 || io.anchor_frame < 0 || io.anchor_frame >= num_frames || io.min_frame_id < 0 ||
+        io.max_frame_id >= num_frames || io.min_frame_id > io.anchor_frame ||
+        io.max_frame_id < io.anchor_frame)
+      return PCS_ERR_ARG;
+    h.io = &io;
+    h.anchor = io.anchor_frame;
+    h.min_f = io.min_frame_id;
+    h.max_f = io.max_frame_id;
+    h.F = h.max_f + 1;
+    h.W = h.max_f - h.min_f + 1;
+    h.C = (int)io.C;
+    h.off_a = frame_offsets[h.anchor];
+    int64_t na = frame_offsets[h.anchor + 1] - h.off_a;
+    if (na < 1) return PCS_ERR_ARG;
+    for (int f = h.min_f; f <= h.max_f; ++f)
+      if (frame_offsets[f + 1] < frame_offsets[f]) return PCS_ERR_ARG;
+    int64_t nm = unit_frame_max(frame_offsets, h.anchor, h.min_f, h.max_f);
+    if (na >= (1LL << 30) || nm >= (1LL << 30) || io.C >= (1LL << 30)) return PCS_ERR_RANGE;
+    h.na = (int)na;
+    h.nm = (int)nm;
+    if (!plan_unit(a, na, nm, io.C, h.F, h.p)) return PCS_ERR_WORKSPACE;
+    UnitDev& d = h.p.d;
+    d.seq = (const float4*)seq_fxyz;
+    d.seq_comp = io.seq_component;
+    d.seq_stat = io.seq_stationary;
+    d.off_a = h.off_a;
+    d.comp_base = io.comp_base;
+    d.ex_cap = io.ex_cap;
+    d.na = h.na;
+    d.C = h.C;
+    d.F = h.F;
+    d.W = h.W;
+    d.anchor = h.anchor;
+    d.min_f = h.min_f;
+    d.hdesc = eng.hdesc;
+    d.transforms = io.transforms;
+    d.reg_errors = io.reg_errors;
+    d.edge_ratios = io.comp_edge_ratios;
+    d.velos = io.comp_velos;
+    d.cmin = io.comp_min_frame_id;
+    d.cmax = io.comp_max_frame_id;
+    d.moving = io.moving;
+    d.vcm = io.valid_comp;
+    d.ex_index = io.ex_index;
+    d.ex_local = io.ex_local;
+    d.ex_comp = io.ex_component;
+    h.phase = PH_START;
+    h.steps = h.reg_calls = 0;
+    h.it = h.it_before = 0;
+    for (int l = 0; l < kMaxLevels; ++l) h.seen[l][0] = h.seen[l][1] = h.seen[l][2] = -1;
+    io.info[0] = io.info[1] = io.info[2] = io.info[3] = 0;
+    stage_units[i] = d;
+  }
+  PCS_CHECK_HIP(hipMemcpyAsync(eng.d_units, stage_units, (size_t)n_units * sizeof(UnitDev),
+                               hipMemcpyHostToDevice, s));
+
+  // ---- set-up, pass 1: the anchors' components (sorted unique), everything zeroed
+  const float nn_radius = prm->nn_radius;
+  {
+    const double nn_r = (double)nn_radius;
+    const float nn_cell = (float)(sqrt(nn_r * nn_r + 3e-5 * nn_r * nn_r + 3e-6) / 4 * 1.0005);
+    TRK_RC(pcs_minmax4_f32(seq_fxyz, n_seq, eng.seq_b8, s));
+    trk_hdesc_kernel<<<1, 64, 0, s>>>(eng.seq_b8, nn_radius, nn_cell, 64.f + 4.f * nn_radius, eng.hdesc);
+  }
+  for (int i = 0; i < n_units; ++i) {
+    HostUnit& h = hu[i];
+    UnitDev& d = h.p.d;
+    PcsTrackUnit& io = *h.io;
+    PCS_CHECK_HIP(hipMemsetAsync(d.st, 0, sizeof(TrkState), s));
+    PCS_CHECK_HIP(hipMemsetAsync((char*)ws + h.p.zero_begin, 0, h.p.zero_end - h.p.zero_begin, s));
+    PCS_CHECK_HIP(hipMemsetAsync(d.xyzf + h.na, 0, sizeof(float4), s));
+    PCS_CHECK_HIP(hipMemsetAsync(io.comp_velos, 0, (size_t)h.C * h.F * 3 * sizeof(float), s));
+    PCS_CHECK_HIP(hipMemsetAsync(io.reg_errors, 0, (size_t)h.C * h.F * sizeof(float), s));
+    PCS_CHECK_HIP(hipMemsetAsync(io.comp_edge_ratios, 0, (size_t)h.C * h.F * sizeof(float), s));
+    trk_load_anchor_kernel<<<nblk(h.na), kBlock, 0, s>>>(d.seq + h.off_a, io.seq_component + h.off_a,
+                                                         io.comp_base, h.na, d.xyzf, d.comp64, d.comp32);
+    TRK_RC(pcs_unique_i64(d.comp64, h.na, 64, d.uniq_c, nullptr, d.order_c, d.seg_c, d.d_numc,
+                          h.p.ws_unique, h.p.unique_bytes, s));
+    g2_clear_kernel<<<grid_for((int64_t)d.hg.slot_words), kBlock, 0, s>>>(d.hg);
+    // the number of present components comes back through the state mirror (counts[0])
+    trk_copy_i64_kernel<<<1, 1, 0, s>>>(d.d_numc, &d.st->counts[0]);
+  }
+  Batch all;
+  all.n = n_units;
+  for (int i = 0; i < n_units; ++i) all.idx[i] = i;
+  trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+  PCS_LAUNCH_CHECK();
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  // ---- set-up, pass 2: component size, centre, diameter and validity; the anchors' own points
+  for (int i = 0; i < n_units; ++i) {
+    HostUnit& h = hu[i];
+    UnitDev& d = h.p.d;
+    h.Cu = (int)pin_trk[i].counts[0];
+    if (h.Cu < 1 || h.Cu > h.C) return PCS_ERR_ARG;
+    const int gU = nblk(h.Cu);
+    const float* xyz1 = (const float*)d.xyzf + 1;  // rows (x, y, z, next row's frame) with stride 4
+    TRK_RC(pcs_segment_reduce_f32(xyz1, 4, d.order_c, d.seg_c, h.Cu, 2, d.red4, s));
+    trk_comp_center_kernel<<<gU, kBlock, 0, s>>>(d.uniq_c, d.seg_c, h.Cu, d.red4, d.deg_f, d.deg_i, d.ctr);
+    trk_point_dist_kernel<<<nblk(h.na), kBlock, 0, s>>>(d.xyzf, d.comp32, h.na, d.ctr, d.dist);
+    TRK_RC(pcs_segment_minmax_f32(d.dist, 1, d.order_c, d.seg_c, h.Cu, 1, d.red1, s));
+    trk_comp_diam_kernel<<<gU, kBlock, 0, s>>>(d.uniq_c, h.Cu, d.red1, d.diam);
+    trk_comp_init_kernel<<<nblk(h.C), kBlock, 0, s>>>(h.C, h.F, h.W, h.anchor, prm->max_diameter, d.deg_f,
+                                                      d.diam, d.ctr, d.vcm, d.transforms, d.cmin, d.cmax,
+                                                      d.centers, d.st);
+  }
+  trk_anchor_emit_kernel<<<n_units, kWg, 0, s>>>(eng.d_units, all);
+  trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+  PCS_LAUNCH_CHECK();
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < n_units; ++i) {
+    hu[i].host = pin_trk[i];
+    if (hu[i].host.err) return PCS_ERR_RANGE;
+    hu[i].any_valid = hu[i].host.active != 0;
+  }
+
+  // ---- the lock-step loop
+  static const int chunk_env = [] {
+    const char* e = getenv("PCS_TRACK_CHUNK");
+    int c = e ? atoi(e) : 0;
+    return (c >= 1 && c <= kIcpMaxChunk) ? c : 8;
+  }();
+  const int chunk = chunk_env;
+  LevelSizes ls;
+  for (int l = 0; l < kMaxLevels; ++l)
+    for (int k = 0; k < 3; ++k) ls.v[l][k] = l < L ? prm->voxel_size[l][k] : 1.f;
+  auto in_range = [](const HostUnit& h, int f) { return f >= h.min_f && f <= h.max_f; };
+  auto step_arg = [&](const HostUnit& h) {
+    StepArg a;
+    a.dir = h.dir;
+    a.next = h.next;
+    a.col = h.next - h.min_f;
+    a.last_col = h.last_col;
+    a.lv = h.lv;
+    a.off_n = in_range(h, h.next) ? frame_offsets[h.next] : 0;
+    a.nn = in_range(h, h.next) ? (int)(frame_offsets[h.next + 1] - frame_offsets[h.next]) : 0;
+    return a;
+  };
+  int live = n_units;
+  int64_t ticks = 0;
+  while (live > 0) {
+    ++ticks;
+    Batch b_fin, b_post, b_dir, b_step, b_smp, b_begin, b_iter;
+    Steps s_fin, s_post, s_step, s_smp;
+    b_fin.n = b_post.n = b_dir.n = b_step.n = b_smp.n = b_begin.n = b_iter.n = 0;
+    IcpHint h_fin[kMaxBatch], h_begin[kMaxBatch], h_iter[kMaxBatch];
+    BatchInts kb;
+    auto start_level = [&](int i) {  // sampling + start of the registration at hu[i].lv
+      HostUnit& h = hu[i];
+      s_smp.a[b_smp.n] = step_arg(h);
+      b_smp.idx[b_smp.n++] = i;
+      b_begin.idx[b_begin.n++] = i;
+      h.it = h.it_before = 0;
+      h.icp.iters = 0;
+      h.icp.stop_iter = INT_MAX;
+      h.icp.err = 0;
+      h.phase = PH_ICP;
+    };
+    auto start_step = [&](int i) {
+      HostUnit& h = hu[i];
+      h.lv = 0;
+      ++h.steps;
+      s_step.a[b_step.n] = step_arg(h);
+      b_step.idx[b_step.n++] = i;
+      start_level(i);
+    };
+    auto start_dir = [&](int i, int dir) -> bool {  // true if the direction has a first step
+      HostUnit& h = hu[i];
+      h.dir = dir;
+      h.next = h.anchor + dir;
+      h.last_col = (dir == 1 && h.anchor > 0) ? h.anchor : -1;
+      return in_range(h, h.next) && h.any_valid;
+    };
+    for (int i = 0; i < n_units; ++i) {
+      HostUnit& h = hu[i];
+      switch (h.phase) {
+        case PH_START: {
+          // a backward pass without a step leaves nothing behind that the forward set-up does not redo
+          bool go = start_dir(i, -1);
+          if (!go) go = start_dir(i, 1);
+          b_dir.idx[b_dir.n++] = i;
+          if (go) start_step(i);
+          else h.phase = PH_FINALWAIT;
+          break;
+        }
+        case PH_ICP: {
+          if (h.icp.err) return PCS_ERR_RANGE;
+          if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
+            s_fin.a[b_fin.n] = step_arg(h);
+            h_fin[b_fin.n] = h.hint;
+            b_fin.idx[b_fin.n++] = i;
+            ++h.reg_calls;
+            ++h.lv;
+            if (h.lv < L) {
+              start_level(i);
+            } else {
+              h.lv = L - 1;
+              s_post.a[b_post.n] = step_arg(h);
+              b_post.idx[b_post.n++] = i;
+              h.phase = PH_POSTWAIT;
+            }
+          }
+          break;
+        }
+        case PH_POSTWAIT: {
+          if (h.host.err) return PCS_ERR_RANGE;
+          h.last_col = h.next;
+          h.next += h.dir;
+          if (in_range(h, h.next) && h.host.active) {
+            start_step(i);
+          } else if (h.dir == -1) {
+            bool go = start_dir(i, 1);
+            b_dir.idx[b_dir.n++] = i;
+            if (go) start_step(i);
+            else h.phase = PH_FINALWAIT;
+          } else {
+            h.phase = PH_FINALWAIT;
+          }
+          break;
+        }
+        case PH_FINALWAIT: {
+          if (h.host.err) return PCS_ERR_RANGE;
+          h.io->info[0] = h.host.ex_count;
+          h.io->info[1] = h.reg_calls;
+          h.io->info[2] = h.steps;
+          h.io->info[3] = ticks;
+          h.phase = PH_DONE;
+          --live;
+          break;
+        }
+        default:
+          break;
+      }
+    }
+    if (live == 0) break;
+    // ---- 1. registrations that stopped: l1 error, coverage, outputs; then frame <- T frame
+    if (b_fin.n) {
+      TRK_RC(icp_enqueue_finish(eng.d_icp, b_fin, h_fin, pin_fin, s));
+      int g = 1;
+      for (int e = 0; e < b_fin.n; ++e) g = max(g, nblk(max(hu[b_fin.idx[e]].na, hu[b_fin.idx[e]].C)));
+      trk_apply_T_kernel<<<dim3(g, b_fin.n), kBlock, 0, s>>>(eng.d_units, b_fin, s_fin);
+    }
+    // ---- 2. after the last level: component motion, velocity smoothing, stop rules, harvest
+    if (b_post.n) {
+      int gc = 1, gp = 1, gq = 1;
+      float* sv_v[kMaxBatch];
+      const float* sv_d[kMaxBatch];
+      int64_t sv_C[kMaxBatch];
+      int sv_F[kMaxBatch], sv_lo[kMaxBatch], sv_hi[kMaxBatch];
+      void* sv_ws[kMaxBatch];
+      size_t sv_wsb[kMaxBatch];
+      int* sv_err[kMaxBatch];
+      int nsv = 0;
+      for (int e = 0; e < b_post.n; ++e) {
+        HostUnit& h = hu[b_post.idx[e]];
+        gc = max(gc, nblk((int64_t)h.Cu * 64));
+        gp = max(gp, nblk(max(h.na, h.C)));
+        gq = max(gq, nblk((int64_t)s_post.a[e].nn * 32));
+        int a0 = h.anchor + h.dir, b0 = h.next;
+        if (a0 != b0) {
+          sv_v[nsv] = h.p.d.velos;
+          sv_d[nsv] = h.p.d.diffs;
+          sv_C[nsv] = h.C;
+          sv_F[nsv] = h.F;
+          sv_lo[nsv] = a0 < b0 ? a0 : b0;
+          sv_hi[nsv] = a0 < b0 ? b0 : a0;
+          sv_ws[nsv] = h.p.ws_sv;
+          sv_wsb[nsv] = h.p.sv_bytes;
+          sv_err[nsv] = &h.p.d.st->err;
+          ++nsv;
+        }
+      }
+      if (gc > 2048) gc = 2048;
+      if (gq > 8192) gq = 8192;
+      trk_motion_kernel<<<dim3(gc, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
+      TRK_RC(smooth_velo_run_batch(nsv, sv_v, sv_d, sv_C, sv_F, sv_lo, sv_hi, prm->smooth_weight0,
+                                   prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping, sv_ws,
+                                   sv_wsb, sv_err, s));
+      trk_after_smooth_kernel<<<dim3(gp, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post,
+                                                                    prm->min_move_frame, prm->reg_error_coeff,
+                                                                    prm->angle_threshold);
+      hv_insert_kernel<<<dim3(gp, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
+      hv_search_kernel<<<dim3(gq, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
+      hv_compact_kernel<<<b_post.n, kWg, 0, s>>>(eng.d_units, b_post, s_post);
+    }
+    // ---- 3. direction / step set-up
+    if (b_dir.n) {
+      int g = 1;
+      for (int e = 0; e < b_dir.n; ++e) g = max(g, nblk(max(hu[b_dir.idx[e]].na, hu[b_dir.idx[e]].C)));
+      trk_dir_init_kernel<<<dim3(g, b_dir.n), kBlock, 0, s>>>(eng.d_units, b_dir);
+    }
+    if (b_step.n) {
+      int g = 1;
+      for (int e = 0; e < b_step.n; ++e) g = max(g, nblk(max(hu[b_step.idx[e]].na, hu[b_step.idx[e]].C)));
+      trk_step_begin_kernel<<<dim3(g, b_step.n), kBlock, 0, s>>>(eng.d_units, b_step, s_step);
+    }
+    // ---- 4. sampling of the anchor (as moved so far) and of the target frame
+    if (b_smp.n) {
+      int gv = 1;
+      for (int e = 0; e < b_smp.n; ++e) {
+        HostUnit& h = hu[b_smp.idx[e]];
+        int est = h.seen[h.lv][1] > 0 ? (int)(h.seen[h.lv][1] * 1.25) : max(h.na, h.nm) / 2;
+        gv = max(gv, nblk(est));
+      }
+      smp_sort_kernel<<<dim3(2, b_smp.n), kWg, 0, s>>>(eng.d_units, b_smp, s_smp, ls);
+      smp_emit_kernel<<<dim3(gv, b_smp.n, 2), kBlock, 0, s>>>(eng.d_units, b_smp, s_smp);
+      smp_compact_kernel<<<dim3(2, b_smp.n), kWg, 0, s>>>(eng.d_units, b_smp);
+    }
+    // ---- 5. registrations that start: descriptor, reset, grids
+    if (b_begin.n) {
+      for (int e = 0; e < b_begin.n; ++e) {
+        const int i = b_begin.idx[e];
+        HostUnit& h = hu[i];
+        UnitDev& d = h.p.d;
+        IcpArgs ia;
+        ia.mov = (float*)d.sa.out;
+        ia.comp = d.sa.out_comp;
+        ia.ref = (const float*)d.sb.out;
+        ia.all = (const float*)d.sb.sub;
+        ia.comp_deg = (const int64_t*)d.sub_deg;
+        ia.cnt3 = &d.st->counts[1];
+        ia.Mn = h.na;
+        ia.Rn = h.nm;
+        ia.Ra = h.nm;
+        ia.C = h.C;
+        ia.radius = prm->radius[h.lv];
+        ia.frame_offset = h.next - h.anchor;
+        ia.reg = prm->angle_regularizer;
+        ia.delta = prm->stopping_delta[h.lv];
+        ia.max_iter = prm->max_iter;
+        ia.cell_size = 0.f;
+        ia.T = d.Tl;
+        ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
+        ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
+        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &stage_icp[i]));
+        PCS_CHECK_HIP(hipMemcpyAsync(eng.d_icp + i, &stage_icp[i], sizeof(IcpProblem), hipMemcpyHostToDevice, s));
+        // launch sizes: what this level had at the previous step, else a guess
+        const int* sn = h.seen[h.lv];
+        h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
+        h.hint.Ra = sn[1] >= 0 ? (int)(sn[1] * 1.25) + 256 : h.nm / 2 + 256;
+        h.hint.Rn = sn[2] >= 0 ? (int)(sn[2] * 1.25) + 256 : h.nm / 4 + 256;
+        h.hint.C = h.C;
+        h.hint.clear_words = 4 * (size_t)pow2_words(h.hint.Mn) + 2 * (size_t)pow2_words(h.hint.Rn) +
+                             2 * (size_t)pow2_words(h.hint.Ra);
+        h_begin[e] = h.hint;
+      }
+      TRK_RC(icp_enqueue_begin(eng.d_icp, b_begin, h_begin, s));
+    }
+    // ---- 6. one chunk of iterations for every unit that is registering
+    for (int i = 0; i < n_units; ++i) {
+      HostUnit& h = hu[i];
+      if (h.phase != PH_ICP) continue;
+      kb.v[b_iter.n] = h.it;
+      h_iter[b_iter.n] = h.hint;
+      b_iter.idx[b_iter.n++] = i;
+    }
+    if (b_iter.n) {
+      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, pin_icp, s));
+      for (int e = 0; e < b_iter.n; ++e) {
+        HostUnit& h = hu[b_iter.idx[e]];
+        h.it_before = h.it;
+        h.it = min(h.it + chunk, prm->max_iter);
+      }
+    }
+    // ---- 7. state mirror, one synchronisation
+    trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+    PCS_LAUNCH_CHECK();
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+    for (int e = 0; e < b_fin.n; ++e)
+      if (pin_fin[e].err) return PCS_ERR_RANGE;  // the coverage query can still overflow a grid
+    for (int i = 0; i < n_units; ++i) {
+      HostUnit& h = hu[i];
+      if (h.phase == PH_DONE) continue;
+      h.host = pin_trk[i];
+      if (h.phase == PH_ICP) {
+        h.seen[h.lv][0] = (int)h.host.counts[1];
+        h.seen[h.lv][1] = (int)h.host.counts[2];
+        h.seen[h.lv][2] = (int)h.host.counts[3];
+      }
+    }
+    if (b_iter.n) {
+      int live_j[kIcpMaxChunk];
+      double b3[3 * kIcpMaxChunk];
+      for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
+      for (int e = 0; e < b_iter.n; ++e) {
+        HostUnit& h = hu[b_iter.idx[e]];
+        h.icp = pin_icp[e];
+        const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
+        for (int j = 0; j < chunk; ++j) {
+          if (h.it_before + 1 + j > h.icp.iters) break;
+          live_j[j] += 1;
+          b3[3 * j] += 36.0 * (Mn + Rn);
+          b3[3 * j + 1] += 40.0 * (Mn + Rn) + 272.0 * C;
+          b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
+        }
+      }
+      icp_profile_account(chunk, live_j, b3);
+    }
+  }
+  return PCS_OK;
+}
 
 extern "C" {
+
+size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_frames,
+                                          const PcsTrackUnit* units, int n_units) {
+  if (!frame_offsets || !units || n_units < 1 || num_frames < 1) return 0;
+  Arena a(nullptr, 0);
+  EnginePlan eng;
+  plan_engine(a, eng);
+  for (int i = 0; i < n_units; ++i) {
+    const PcsTrackUnit& io = units[i];
+    if (io.anchor_frame < 0 || io.anchor_frame >= num_frames || io.min_frame_id < 0 ||
+        io.max_frame_id >= num_frames || io.min_frame_id > io.max_frame_id)
+      return 0;
+    int64_t na = frame_offsets[io.anchor_frame + 1] - frame_offsets[io.anchor_frame];
+    int64_t nm = unit_frame_max(frame_offsets, io.anchor_frame, io.min_frame_id, io.max_frame_id);
+    UnitPlan p;
+    plan_unit(a, na, nm, io.C < 1 ? 1 : io.C, io.max_frame_id + 1, p);
+  }
+  return a.off;
+}
+
+int pcs_track_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
+                       int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+  return run_sequence(prm, seq_fxyz, frame_offsets, num_frames, units, n_units, ws, ws_bytes, s);
+}
 
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames) {
   Arena a(nullptr, 0);
-  TrkPlan p;
-  plan_track(a, n_anchor, n_frame_max, C < 1 ? 1 : C, num_frames < 1 ? 1 : num_frames, p);
+  EnginePlan eng;
+  plan_engine(a, eng);
+  UnitPlan p;
+  plan_unit(a, n_anchor, n_frame_max, C < 1 ? 1 : C, num_frames < 1 ? 1 : num_frames, p);
   return a.off;
 }
 
@@ -698,220 +1448,30 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
                     float* comp_velos, int64_t* comp_min_frame_id, int64_t* comp_max_frame_id,
                     uint8_t* moving, uint8_t* valid_comp, int64_t* info, void* ws, size_t ws_bytes,
                     hipStream_t s) {
-  if (!prm || !seq_fxyz || !seq_component || !seq_stationary || !frame_offsets || !ex_index ||
-      !ex_local || !ex_component || !transforms || !reg_errors || !comp_edge_ratios || !comp_velos ||
-      !comp_min_frame_id || !comp_max_frame_id || !moving || !valid_comp || !info || !ws)
-    return PCS_ERR_ARG;
-  if (C < 1 || num_frames < 1 || anchor_frame < 0 || anchor_frame >= num_frames ||
-      min_frame_id < 0 || max_frame_id >= num_frames || min_frame_id > anchor_frame ||
-      max_frame_id < anchor_frame || prm->num_levels < 1 || prm->num_levels > kMaxLevels)
-    return PCS_ERR_ARG;
-  const int F = max_frame_id + 1;
-  const int W = max_frame_id - min_frame_id + 1;
-  const int L = prm->num_levels;
-  const int64_t off_a = frame_offsets[anchor_frame];
-  const int64_t na = frame_offsets[anchor_frame + 1] - off_a;
-  if (na < 1) return PCS_ERR_ARG;
-  int64_t nm = 1;
-  for (int f = min_frame_id; f <= max_frame_id; ++f) {
-    int64_t c = frame_offsets[f + 1] - frame_offsets[f];
-    if (c < 0) return PCS_ERR_ARG;
-    if (f != anchor_frame && c > nm) nm = c;
-  }
-  if (na >= (1LL << 30) || nm >= (1LL << 30) || C >= (1LL << 30)) return PCS_ERR_RANGE;
-  Arena a(ws, ws_bytes);
-  TrkPlan p;
-  if (!plan_track(a, na, nm, C, F, p)) return PCS_ERR_WORKSPACE;
-  // optional: the ICP iterations of the concurrent tracking units share launches for the duration
-  // of the call (prm->share_launches; see IcpBatcher in pcs_icp.hip for when that pays)
-  struct ShareGuard {
-    bool on;
-    explicit ShareGuard(int group) : on(group != 0) { if (on) pcs_icp_share_launches(group); }
-    ~ShareGuard() { if (on) pcs_icp_share_launches(0); }
-  } share_guard(prm->share_launches);
-
-  const float4* anchor = (const float4*)seq_fxyz + off_a;
-  const int gA = nblk(na), gC = nblk(C);
-  const int gAC = nblk(na > C ? na : C);
-  info[0] = info[1] = info[2] = info[3] = 0;
-
-  // ---- set-up: components of the anchor frame, their size, centre, diameter and validity
-  PCS_CHECK_HIP(hipMemsetAsync(p.st, 0, sizeof(TrkState), s));
-  PCS_CHECK_HIP(hipMemsetAsync(p.exc, 0, 2 * sizeof(int64_t), s));
-  PCS_CHECK_HIP(hipMemsetAsync((char*)ws + p.comp_zero_begin, 0, p.comp_zero_end - p.comp_zero_begin, s));
-  PCS_CHECK_HIP(hipMemsetAsync(p.xyzf + na, 0, sizeof(float4), s));
-  PCS_CHECK_HIP(hipMemsetAsync(comp_velos, 0, (size_t)C * F * 3 * sizeof(float), s));
-  PCS_CHECK_HIP(hipMemsetAsync(reg_errors, 0, (size_t)C * F * sizeof(float), s));
-  PCS_CHECK_HIP(hipMemsetAsync(comp_edge_ratios, 0, (size_t)C * F * sizeof(float), s));
-  trk_load_anchor_kernel<<<gA, kBlock, 0, s>>>(anchor, seq_component + off_a, seq_stationary + off_a,
-                                               comp_base, (int)na, p.xyzf, p.comp64, p.comp32, p.stat_a);
-  TRK_RC(pcs_unique_i64(p.comp64, na, 64, p.uniq_c, nullptr, p.order_c, p.seg_c, p.d_numc,
-                        p.ws_unique, p.unique_bytes, s));
-  int64_t Cu64 = 0;
-  PCS_CHECK_HIP(hipMemcpyAsync(&Cu64, p.d_numc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  PCS_CHECK_HIP(hipStreamSynchronize(s));
-  const int Cu = (int)Cu64;
-  if (Cu < 1 || Cu > C) return PCS_ERR_ARG;
-  const int gU = nblk(Cu);
-  const float* xyz1 = (const float*)p.xyzf + 1;  // rows (x, y, z, next row's frame) with stride 4
-  TRK_RC(pcs_segment_reduce_f32(xyz1, 4, p.order_c, p.seg_c, Cu, 2, p.red4a, s));
-  trk_comp_center_kernel<<<gU, kBlock, 0, s>>>(p.uniq_c, p.seg_c, Cu, p.red4a, p.deg_f, p.deg_i, p.ctr);
-  trk_point_dist_kernel<<<gA, kBlock, 0, s>>>(p.xyzf, p.comp32, (int)na, p.ctr, p.dist);
-  TRK_RC(pcs_segment_minmax_f32(p.dist, 1, p.order_c, p.seg_c, Cu, 1, p.red1, s));
-  trk_comp_diam_kernel<<<gU, kBlock, 0, s>>>(p.uniq_c, Cu, p.red1, p.diam);
-  trk_comp_init_kernel<<<gC, kBlock, 0, s>>>((int)C, F, W, anchor_frame, prm->max_diameter, p.deg_f,
-                                             p.diam, p.ctr, valid_comp, transforms,
-                                             comp_min_frame_id, comp_max_frame_id, p.centers);
-  // the anchor's own points
-  int ex_par = 0;
-  trk_anchor_flag_kernel<<<gA, kBlock, 0, s>>>(p.comp32, valid_comp, (int)na, p.flag);
-  TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, na, s));
-  trk_harvest_emit_kernel<<<gA, kBlock, 0, s>>>(p.flag, p.pos, (int)na, nullptr, p.comp32, off_a,
-                                                ex_cap, ex_index, ex_local, ex_component,
-                                                p.exc + ex_par, p.exc + (ex_par ^ 1), p.st);
-  ex_par ^= 1;
-
-  const float nn_radius = prm->nn_radius;
-  const double nn_r = (double)nn_radius;
-  const float nn_cell = (float)(sqrt(nn_r * nn_r + 3e-5 * nn_r * nn_r + 3e-6) / 4 * 1.0005);
-  int64_t steps = 0, reg_calls = 0;
-  TrkState host;
-  // pinned page: bytes [0, 256) are the ICP's, the tracker's mirror sits behind them
-  char* page = (char*)thread_pinned_page();
-  TrkState* pin = page ? (TrkState*)(page + 1024) : nullptr;
-  auto read_state = [&]() -> int {
-    if (pin) {
-      trk_publish_kernel<<<1, 1, 0, s>>>(p.st, pin);
-    } else if (hipMemcpyAsync(&host, p.st, sizeof(TrkState), hipMemcpyDeviceToHost, s) != hipSuccess) {
-      return PCS_ERR_HIP;
-    }
-    if (hipStreamSynchronize(s) != hipSuccess) return PCS_ERR_HIP;
-    if (pin) host = *pin;
-    return PCS_OK;
-  };
-
-  for (int dir = -1; dir <= 1; dir += 2) {
-    int next = anchor_frame + dir;
-    int last_col = (dir == 1 && anchor_frame > 0) ? anchor_frame : -1;
-    PCS_CHECK_HIP(hipMemsetAsync(&p.st->active, 0, sizeof(int32_t), s));
-    trk_dir_init_kernel<<<gAC, kBlock, 0, s>>>((int)C, (int)na, valid_comp, p.stopped, moving, anchor,
-                                               p.xyzf, p.last, p.st);
-    while (next >= min_frame_id && next <= max_frame_id) {
-      TRK_RC(read_state());
-      if (host.err || host.counts[0] < 0) return PCS_ERR_RANGE;
-      if (!host.active) break;
-      PCS_CHECK_HIP(hipMemsetAsync(&p.st->active, 0, sizeof(int32_t), s));
-      ++steps;
-      const int64_t off_n = frame_offsets[next];
-      const int64_t nn = frame_offsets[next + 1] - off_n;
-      const float4* nxt = (const float4*)seq_fxyz + off_n;
-      const int col = next - min_frame_id;
-      const int gN = nblk(nn);
-      trk_step_begin_kernel<<<gAC, kBlock, 0, s>>>((int)C, (int)na, F, W, col, dir, last_col, p.stopped,
-                                                   comp_velos, p.comp32, p.xyzf, transforms);
-      if (nn > 0)
-        trk_stat_to_float_kernel<<<gN, kBlock, 0, s>>>(seq_stationary + off_n, (int)nn, p.stat_n);
-      for (int lv = 0; lv < L; ++lv) {
-        float size4[4] = {1.f, prm->voxel_size[lv][0], prm->voxel_size[lv][1], prm->voxel_size[lv][2]};
-        // ---- sample_frame(anchor) and sample_frame(target) in one pipeline: combined keys, one
-        //      sort, one segment pass; then the non-stationary subsets and the per-component counts
-        {
-          const int64_t n2 = na + nn;
-          const int g2 = nblk(n2);
-          uint64_t* keys = nullptr;
-          int32_t* vals = nullptr;
-          TRK_RC(unique_prepared_ptrs(p.ws_unique, p.unique_bytes, n2, &keys, &vals));
-          trk_bounds_reset_kernel<<<1, 64, 0, s>>>(p.b8);
-          {
-            int64_t nmax2 = na > nn ? na : nn;
-            int gb = nblk(nmax2);
-            if (gb > 128) gb = 128;
-            trk_bounds2_kernel<<<dim3(gb, 2), kBlock, 0, s>>>(p.xyzf, (int)na, nxt, (int)nn, p.b8);
-          }
-          trk_keys2_kernel<<<g2, kBlock, 0, s>>>(p.xyzf, (int)na, nxt, (int)nn, p.b8,
-                                                 make_float4(size4[0], size4[1], size4[2], size4[3]), 0.5f,
-                                                 keys, vals);
-          const int32_t* order2 = nullptr;
-          TRK_RC(unique_prepared_run(p.ws_unique, p.unique_bytes, n2, 64, p.seg_s, p.d_nums, &order2, s));
-          PCS_CHECK_HIP(hipMemsetAsync(p.sub_deg, 0, (size_t)C * sizeof(unsigned long long), s));
-          trk_sample2_emit_kernel<<<g2, kBlock, 0, s>>>(p.xyzf, p.stat_a, p.comp64, (int)na, nxt, p.stat_n,
-                                                        order2, p.seg_s, p.d_nums, (int)n2, p.sub2,
-                                                        p.sub_comp, p.flag, p.sub_deg, p.d_nums + 1);
-          TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, n2, s));
-          trk_compact2_kernel<<<g2, kBlock, 0, s>>>(p.sub2, p.sub_comp, p.flag, p.pos, (int)n2, p.d_nums,
-                                                    p.d_nums + 1, p.mov, p.mov_comp, p.sub_n, p.ref_ns,
-                                                    &p.st->counts[0]);
-        }
-        TRK_RC(read_state());
-        const int64_t Mn = host.counts[1], Ra = host.counts[2], Rn = host.counts[3];
-        // ---- register_to_next_frame
-        int32_t icp_info[4];
-        double* l1_out = (lv == L - 1) ? p.l1 : p.l1_tmp;
-        float* ratio_out = (lv == 0) ? p.ratio : p.ratio_tmp;
-        TRK_RC(pcs_register_to_next_frame((float*)p.mov, p.mov_comp, Mn, (const float*)p.ref_ns, Rn,
-                                          (const float*)p.sub_n, Ra, (const int64_t*)p.sub_deg, C,
-                                          prm->radius[lv], next - anchor_frame, prm->angle_regularizer,
-                                          prm->max_iter, prm->stopping_delta[lv], 0.f, 8, p.Tl, l1_out,
-                                          ratio_out, icp_info, p.ws_icp, p.icp_bytes, s));
-        ++reg_calls;
-        trk_apply_T_kernel<<<gAC, kBlock, 0, s>>>((int)C, (int)na, W, col, p.Tl, p.comp32, p.xyzf,
-                                                  transforms);
-      }
-      // ---- component motion, velocity smoothing, stop rules
-      TRK_RC(pcs_segment_reduce_f32(xyz1, 4, p.order_c, p.seg_c, Cu, 2, p.red4a, s));
-      trk_point_velo_kernel<<<gA, kBlock, 0, s>>>(p.xyzf, p.last, (int)na, dir, p.pv);
-      TRK_RC(pcs_segment_reduce_f32((const float*)p.pv, 4, p.order_c, p.seg_c, Cu, 3, p.red4b, s));
-      trk_comp_motion_kernel<<<gU, kBlock, 0, s>>>(p.uniq_c, p.seg_c, Cu, F, next, dir, p.red4a,
-                                                   p.red4b, p.centers, comp_velos, p.diffs, p.velo_pre);
-      {
-        int a0 = anchor_frame + dir, b0 = next;
-        if (a0 != b0) {
-          int lo = a0 < b0 ? a0 : b0, hi = a0 < b0 ? b0 : a0;
-          TRK_RC(smooth_velo_run(comp_velos, p.diffs, C, F, lo, hi, prm->smooth_weight0,
-                                 prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping,
-                                 p.ws_sv, p.sv_bytes, &p.st->err, s));
-        }
-      }
-      trk_after_smooth_kernel<<<gAC, kBlock, 0, s>>>(
-          (int)C, (int)na, F, W, col, anchor_frame, next, dir, last_col, prm->min_move_frame,
-          prm->reg_error_coeff, prm->angle_threshold, p.comp32, p.xyzf, p.last, comp_velos,
-          p.velo_pre, p.centers, p.diam, p.deg_i, p.l1, p.ratio, p.stopped, moving, transforms,
-          comp_min_frame_id, comp_max_frame_id, reg_errors, comp_edge_ratios, p.st);
-      last_col = next;
-      // ---- harvest the target frame's points next to the moved anchor points
-      if (nn > 0) {
-        trk_set_frame_kernel<<<gA, kBlock, 0, s>>>(p.xyzf, (int)na, (float)next);
-        int64_t* d_edges = &p.st->counts[0];  // scratch word, rewritten by the next level-0 sample
-        TRK_RC(pcs_radius_graph_search((const float*)p.xyzf, na, (const float*)nxt, nn, nn_radius,
-                                       nn_cell, 0, 0, 1, 1, d_edges, p.ws_rg, p.rg_bytes, s));
-        const int32_t *nbr = nullptr, *deg = nullptr, *rerr = nullptr;
-        TRK_RC(radius_nn1_view(na, nn, p.ws_rg, p.rg_bytes, &nbr, &deg, &rerr));
-        trk_harvest_flag_kernel<<<gN, kBlock, 0, s>>>(nbr, deg, (int)nn, p.comp32, p.stopped, p.flag);
-        TRK_RC(exclusive_scan_i32(p.tmp_scan, p.scan_bytes, p.flag, p.pos, nn, s));
-        trk_harvest_emit_kernel<<<gN, kBlock, 0, s>>>(p.flag, p.pos, (int)nn, nbr, p.comp32, off_n,
-                                                      ex_cap, ex_index, ex_local, ex_component,
-                                                      p.exc + ex_par, p.exc + (ex_par ^ 1), p.st);
-        ex_par ^= 1;
-        trk_set_frame_kernel<<<gA, kBlock, 0, s>>>(p.xyzf, (int)na, (float)anchor_frame);
-        // a fine-cell overflow of the 1-NN grid leaves a negative edge count in counts[0]: seen by
-        // the next read of the state (top of the loop / end of the call)
-      }
-      next += dir;
-    }
-  }
-  trk_copy_count_kernel<<<1, 1, 0, s>>>(p.exc + ex_par, &p.st->ex_count);
-  PCS_LAUNCH_CHECK();
-  TRK_RC(read_state());
-  if (host.err || host.counts[0] < 0) return PCS_ERR_RANGE;
-  info[0] = host.ex_count;
-  info[1] = reg_calls;
-  info[2] = steps;
-  {
-    double t2[2] = {0, 0};
-    pcs_profile_thread_icp_read(t2);
-    info[3] = (int64_t)(t2[0] * 1e6) * 1000000LL + (int64_t)(t2[1] * 1e6);  // us in launcher | us in ICP
-  }
-  return PCS_OK;
+  if (!info) return PCS_ERR_ARG;
+  PcsTrackUnit u;
+  u.seq_component = seq_component;
+  u.seq_stationary = seq_stationary;
+  u.anchor_frame = anchor_frame;
+  u.min_frame_id = min_frame_id;
+  u.max_frame_id = max_frame_id;
+  u.comp_base = comp_base;
+  u.C = C;
+  u.ex_index = ex_index;
+  u.ex_local = ex_local;
+  u.ex_component = ex_component;
+  u.ex_cap = ex_cap;
+  u.transforms = transforms;
+  u.reg_errors = reg_errors;
+  u.comp_edge_ratios = comp_edge_ratios;
+  u.comp_velos = comp_velos;
+  u.comp_min_frame_id = comp_min_frame_id;
+  u.comp_max_frame_id = comp_max_frame_id;
+  u.moving = moving;
+  u.valid_comp = valid_comp;
+  int rc = run_sequence(prm, seq_fxyz, frame_offsets, num_frames, &u, 1, ws, ws_bytes, s);
+  for (int k = 0; k < 4; ++k) info[k] = u.info[k];
+  return rc;
 }
 
 }  // extern "C"

@@ -616,15 +616,15 @@ class TrackParams(__import__("ctypes").Structure):
         ("voxel_size", (_c.c_float * 3) * 4),
         ("nn_radius", _c.c_float), ("reg_error_coeff", _c.c_float), ("angle_threshold", _c.c_float),
         ("max_diameter", _c.c_float), ("smooth_weight0", _c.c_float), ("smooth_weight", _c.c_float),
-        ("smooth_stopping", _c.c_float), ("share_launches", _c.c_int32),
+        ("smooth_stopping", _c.c_float), ("reserved", _c.c_int32),
     ]
 
 
 def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
-                 smooth=(1.0, 10.0, 300, 1e-3), share_launches=False):
+                 smooth=(1.0, 10.0, 300, 1e-3)):
     prm = TrackParams()
-    prm.share_launches = int(share_launches)  # 0 off, g >= 1: launcher group
+    prm.reserved = 0
     L_ = len(radius_list)
     if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
         raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")
@@ -644,6 +644,92 @@ def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer
     prm.max_diameter = float(max_diameter)
     prm.smooth_weight0, prm.smooth_weight, prm.smooth_stopping = float(smooth[0]), float(smooth[1]), float(smooth[3])
     return prm
+
+
+class TrackUnit(__import__("ctypes").Structure):
+    """Mirror of PcsTrackUnit (include/pcs.h)."""
+    import ctypes as _c
+    _fields_ = [
+        ("seq_component", _c.c_void_p), ("seq_stationary", _c.c_void_p),
+        ("anchor_frame", _c.c_int32), ("min_frame_id", _c.c_int32), ("max_frame_id", _c.c_int32),
+        ("pad_", _c.c_int32),
+        ("comp_base", _c.c_int64), ("C", _c.c_int64),
+        ("ex_index", _c.c_void_p), ("ex_local", _c.c_void_p), ("ex_component", _c.c_void_p),
+        ("ex_cap", _c.c_int64),
+        ("transforms", _c.c_void_p),
+        ("reg_errors", _c.c_void_p), ("comp_edge_ratios", _c.c_void_p), ("comp_velos", _c.c_void_p),
+        ("comp_min_frame_id", _c.c_void_p), ("comp_max_frame_id", _c.c_void_p),
+        ("moving", _c.c_void_p), ("valid_comp", _c.c_void_p),
+        ("info", _c.c_int64 * 4),
+    ]
+
+
+MAX_TRACK_UNITS = 32  # kMaxBatch of the native tracker
+
+
+def track_sequence(prm, seq_fxyz, frame_offsets, units):
+    """All tracking units of a sequence in ONE native call (pcs_track_sequence): one host thread
+    advances them in lock-step on the current stream, every launch serves all units in the same
+    phase. `units`: list of dicts with keys component (int64 [N]), stationary (bool/uint8 [N]),
+    anchor_frame, min_frame_id, max_frame_id, comp_base, num_components. Returns one
+    (out dict, (rows, registration calls, frame steps)) per unit, as ops.track_frame would."""
+    import ctypes
+    L.require_gpu(seq_fxyz, "track_sequence")
+    lib = L.load()
+    dev = seq_fxyz.device
+    assert seq_fxyz.is_contiguous() and seq_fxyz.dtype == torch.float32 and seq_fxyz.shape[1] == 4
+    if not (1 <= len(units) <= MAX_TRACK_UNITS):
+        raise L.PcsError(f"track_sequence: 1..{MAX_TRACK_UNITS} units per call")
+    nf = len(frame_offsets) - 1
+    offs = (ctypes.c_int64 * (nf + 1))(*[int(v) for v in frame_offsets])
+    arr = (TrackUnit * len(units))()
+    outs, keep = [], []
+    for i, u in enumerate(units):
+        a, lo, hi = int(u["anchor_frame"]), int(u["min_frame_id"]), int(u["max_frame_id"])
+        C, F, W = int(u["num_components"]), hi + 1, hi - lo + 1
+        comp = u["component"].long().contiguous()
+        stat = u["stationary"].to(torch.uint8).contiguous()
+        cap = int(frame_offsets[hi + 1] - frame_offsets[lo])
+        out = dict(
+            ex_index=torch.empty(cap, dtype=torch.int64, device=dev),
+            ex_local=torch.empty(cap, dtype=torch.int64, device=dev),
+            ex_component=torch.empty(cap, dtype=torch.int64, device=dev),
+            transforms=torch.empty(C, W, 4, 4, dtype=torch.float64, device=dev),
+            reg_errors=torch.empty(C, F, dtype=torch.float32, device=dev),
+            comp_edge_ratios=torch.empty(C, F, dtype=torch.float32, device=dev),
+            comp_velos=torch.empty(C, F, 3, dtype=torch.float32, device=dev),
+            comp_min_frame_id=torch.empty(C, dtype=torch.int64, device=dev),
+            comp_max_frame_id=torch.empty(C, dtype=torch.int64, device=dev),
+            moving=torch.empty(C, dtype=torch.uint8, device=dev),
+            valid_comp=torch.empty(C, dtype=torch.uint8, device=dev),
+        )
+        keep.append((comp, stat))
+        t = arr[i]
+        t.seq_component, t.seq_stationary = comp.data_ptr(), stat.data_ptr()
+        t.anchor_frame, t.min_frame_id, t.max_frame_id = a, lo, hi
+        t.comp_base, t.C, t.ex_cap = int(u["comp_base"]), C, cap
+        for k in ("ex_index", "ex_local", "ex_component", "transforms", "reg_errors", "comp_edge_ratios",
+                  "comp_velos", "comp_min_frame_id", "comp_max_frame_id", "moving", "valid_comp"):
+            setattr(t, k, out[k].data_ptr())
+        outs.append(out)
+    nbytes = lib.pcs_track_sequence_workspace_bytes(offs, L.i32(nf), arr, L.i32(len(units)))
+    if nbytes == 0:
+        raise L.PcsError("pcs_track_sequence_workspace_bytes: bad unit description")
+    ws = L.workspace(nbytes, dev)
+    L.check(lib.pcs_track_sequence(ctypes.byref(prm), L.ptr(seq_fxyz), offs, L.i32(nf), arr,
+                                   L.i32(len(units)), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_track_sequence")
+    res = []
+    for i, out in enumerate(outs):
+        info = arr[i].info
+        n_ex = int(info[0])
+        for k in ("ex_index", "ex_local", "ex_component"):
+            out[k] = out[k][:n_ex]
+        out["moving"] = out["moving"].bool()
+        out["valid_comp"] = out["valid_comp"].bool()
+        out["_ticks"] = int(info[3])
+        res.append((out, (n_ex, int(info[1]), int(info[2]))))
+    return res
 
 
 def track_frame(prm, seq_fxyz, seq_component, seq_stationary, frame_offsets, anchor_frame,
@@ -696,5 +782,5 @@ def track_frame(prm, seq_fxyz, seq_component, seq_stationary, frame_offsets, anc
         out[k] = out[k][:n_ex]
     out["moving"] = out["moving"].bool()
     out["valid_comp"] = out["valid_comp"].bool()
-    out["_icp_us"] = (int(info[3]) // 1000000, int(info[3]) % 1000000)  # diagnostic: in launcher, in ICP
+    out["_ticks"] = int(info[3])
     return out, (n_ex, int(info[1]), int(info[2]))

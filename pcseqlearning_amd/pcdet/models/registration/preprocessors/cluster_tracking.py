@@ -281,34 +281,22 @@ class ClusterTracking(nn.Module):
         bounds = torch.searchsorted(fr, torch.arange(num_frames + 1, device=fr.device))
         return bounds.tolist(), perm
 
-    def _track_frame_native(self, seq_points, frame, offsets):
-        frame_id = int(frame.frame[0].long().item())
-        n_a = offsets[frame_id + 1] - offsets[frame_id]
-        assert frame.fxyz.shape[0] == n_a, "anchor rows must be the frame's rows of seq_points"
-        perm = seq_points.get("frame_perm", None)
-        s_fxyz, s_comp, s_stat = seq_points.fxyz, seq_points.component, seq_points.stationary
-        if perm is not None:  # rows not grouped by frame: track on the grouped copy, map rows back
-            s_fxyz, s_comp, s_stat = s_fxyz[perm].contiguous(), s_comp[perm], s_stat[perm]
-        num_components = int(frame.component.max().long().item()) + 1
-        comp_base = int((s_comp[offsets[frame_id]] - frame.component[0]).long().item())
-        present = [f for f in range(len(offsets) - 1) if offsets[f + 1] > offsets[f]]
-        min_frame_id = max(present[0], frame_id - self.track_interval)
-        max_frame_id = min(present[-1], frame_id + self.track_interval)
-        if self.verbose:
-            print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components (native)")
-        share = self.model_cfg.get("SHARE_ICP_LAUNCHES", False)
-        group = 0 if not share else (1 if share is True else 1 + frame_id // max(self.track_interval, 1))
-        if self._track_params is None or self._track_params.share_launches != group:
+    def _native_params(self):
+        if self._track_params is None:
             self._track_params = ops.track_params(
                 self.radius_list, self.voxel_size_list, self.stopping_delta,
                 self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
-                self.angle_threshold, self.min_move_frame, max_iter=80, share_launches=group)
-        out, (_, reg_calls, _) = ops.track_frame(
-            self._track_params, s_fxyz, s_comp, s_stat, offsets,
-            frame_id, min_frame_id, max_frame_id, comp_base, num_components)
-        self.num_registration_calls += reg_calls
-        icp_us = out.pop("_icp_us")  # diagnostic: microseconds (in the shared launcher, in ICP calls)
-        idx, comp, moving = out["ex_index"], out["ex_component"].to(frame.component.dtype), out["moving"]
+                self.angle_threshold, self.min_move_frame, max_iter=80)
+        return self._track_params
+
+    def _native_window(self, offsets, frame_id):
+        present = [f for f in range(len(offsets) - 1) if offsets[f + 1] > offsets[f]]
+        return (max(present[0], frame_id - self.track_interval),
+                min(present[-1], frame_id + self.track_interval))
+
+    def _extracted_from_native(self, seq_points, frame_id, out, perm, comp_dtype):
+        """The reference's `extracted` dictionary from the native tracker's outputs."""
+        idx, comp, moving = out["ex_index"], out["ex_component"].to(comp_dtype), out["moving"]
         if perm is not None:
             idx = perm[idx]
         extracted = EasyDict(dict(
@@ -326,12 +314,31 @@ class ClusterTracking(nn.Module):
         extracted = EasyDict(filter_dict(extracted, valid[extracted.component]))
         extracted.transforms = out["transforms"]
         seq_points.extracted[extracted.original_indices] = True
-        self.last_track_debug = dict(icp_us=icp_us, reg_errors=out["reg_errors"],
+        self.last_track_debug = dict(ticks=out.get("_ticks", 0), reg_errors=out["reg_errors"],
                                      comp_edge_ratios=out["comp_edge_ratios"],
                                      comp_velos=out["comp_velos"],
                                      comp_min_frame_id=out["comp_min_frame_id"],
                                      comp_max_frame_id=out["comp_max_frame_id"])
         return extracted
+
+    def _track_frame_native(self, seq_points, frame, offsets):
+        frame_id = int(frame.frame[0].long().item())
+        n_a = offsets[frame_id + 1] - offsets[frame_id]
+        assert frame.fxyz.shape[0] == n_a, "anchor rows must be the frame's rows of seq_points"
+        perm = seq_points.get("frame_perm", None)
+        s_fxyz, s_comp, s_stat = seq_points.fxyz, seq_points.component, seq_points.stationary
+        if perm is not None:  # rows not grouped by frame: track on the grouped copy, map rows back
+            s_fxyz, s_comp, s_stat = s_fxyz[perm].contiguous(), s_comp[perm], s_stat[perm]
+        num_components = int(frame.component.max().long().item()) + 1
+        comp_base = int((s_comp[offsets[frame_id]] - frame.component[0]).long().item())
+        min_frame_id, max_frame_id = self._native_window(offsets, frame_id)
+        if self.verbose:
+            print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components (native)")
+        out, (_, reg_calls, _) = ops.track_frame(
+            self._native_params(), s_fxyz, s_comp, s_stat, offsets,
+            frame_id, min_frame_id, max_frame_id, comp_base, num_components)
+        self.num_registration_calls += reg_calls
+        return self._extracted_from_native(seq_points, frame_id, out, perm, frame.component.dtype)
 
     def track_frame_host(self, seq_points, frame, seq_boxes):
         """track_frame op by op (one framework call per step of cluster_tracking.py:430-787)."""
@@ -485,42 +492,67 @@ class ClusterTracking(nn.Module):
                                      comp_max_frame_id=comp_max_frame_id)
         return extracted
 
-    @staticmethod
-    def plan_units(units, cost, n_workers):
-        """Units -> per-worker lists (each longest first) with a small makespan: LPT, then moves and
-        swaps away from the fullest worker while they help."""
-        plan = [[] for _ in range(n_workers)]
-        load = [0.0] * n_workers
-        for u in sorted(units, key=lambda u: -cost[u]):
-            w = min(range(n_workers), key=lambda i: load[i])
-            plan[w].append(u)
-            load[w] += cost[u]
-        improved = True
-        while improved:
-            improved = False
-            a = max(range(n_workers), key=lambda i: load[i])
-            for b in range(n_workers):
-                if b == a:
-                    continue
-                for ua in list(plan[a]):
-                    if max(load[a] - cost[ua], load[b] + cost[ua]) < load[a] - 1e-9:      # move
-                        plan[a].remove(ua); plan[b].append(ua)
-                        load[a] -= cost[ua]; load[b] += cost[ua]
-                        improved = True
-                        break
-                    for ub in list(plan[b]):
-                        d = cost[ua] - cost[ub]
-                        if d > 0 and max(load[a] - d, load[b] + d) < load[a] - 1e-9:      # swap
-                            plan[a].remove(ua); plan[b].remove(ub)
-                            plan[a].append(ub); plan[b].append(ua)
-                            load[a] -= d; load[b] += d
-                            improved = True
-                            break
-                    if improved:
-                        break
-                if improved:
-                    break
-        return [sorted(p, key=lambda u: -cost[u]) for p in plan]
+    def _track_units_native(self, seq_dict, key_points, units, offsets, perm):
+        """All (component key, anchor frame) units through ops.track_sequence. While the native call
+        runs (GIL released) a helper thread does the parked host-side work (ClusterProposal's
+        evaluation) on a side stream."""
+        import threading
+        descs, dtypes = [], []
+        grouped = {}
+        for comp_key, frame_id in units:
+            sp = key_points[comp_key]
+            if comp_key not in grouped:
+                s_comp, s_stat = sp.component, sp.stationary
+                if perm is not None:
+                    s_comp, s_stat = s_comp[perm], s_stat[perm]
+                grouped[comp_key] = (s_comp.long().contiguous(), s_stat.to(torch.uint8).contiguous())
+            s_comp, s_stat = grouped[comp_key]
+            lo, hi = offsets[frame_id], offsets[frame_id + 1]
+            cmin, cmax = torch.aminmax(s_comp[lo:hi])
+            comp_base = int(cmin.item())
+            min_frame_id, max_frame_id = self._native_window(offsets, frame_id)
+            descs.append(dict(component=s_comp, stationary=s_stat, anchor_frame=frame_id,
+                              min_frame_id=min_frame_id, max_frame_id=max_frame_id, comp_base=comp_base,
+                              num_components=int(cmax.item()) - comp_base + 1))
+            dtypes.append(sp.component.dtype)
+        s_fxyz = key_points[units[0][0]].fxyz
+        if perm is not None:
+            s_fxyz = s_fxyz[perm].contiguous()
+        helper = None
+        if seq_dict.get("_deferred"):
+            device = s_fxyz.device
+            main = torch.cuda.current_stream(device)
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(main)
+            grad = torch.is_grad_enabled()
+            err = []
+
+            def side_job():
+                try:
+                    with torch.cuda.device(device), torch.cuda.stream(side), torch.set_grad_enabled(grad):
+                        run_deferred(seq_dict)
+                except BaseException as e:  # re-raised on the main thread
+                    err.append(e)
+
+            helper = threading.Thread(target=side_job, name="pcs-deferred")
+            helper.start()
+        # UNITS_PER_CALL (default: all): how many units share a native call; 1 = one unit after the
+        # other (same results bit for bit -- a unit never depends on what runs beside it)
+        per_call = int(self.model_cfg.get("UNITS_PER_CALL", 0)) or len(descs)
+        per_call = max(1, min(per_call, ops.MAX_TRACK_UNITS))
+        try:
+            res = []
+            for b in range(0, len(descs), per_call):
+                res += ops.track_sequence(self._native_params(), s_fxyz, offsets, descs[b:b + per_call])
+        finally:
+            if helper is not None:
+                helper.join()
+                main.wait_stream(side)
+                if err:
+                    raise err[0]
+        self.num_registration_calls += sum(r[1][1] for r in res)
+        self.last_ticks = max(r[0]["_ticks"] for r in res)
+        return [(r[0], dt) for r, dt in zip(res, dtypes)]
 
     # ------------------------------------------------------------------ whole sequence
     def forward(self, seq_dict):
@@ -561,10 +593,11 @@ class ClusterTracking(nn.Module):
         seq_boxes.best_iou = torch.zeros_like(seq_boxes.attr[:, 0])
 
         # The 3 keys x anchors {0, 8, 16, ...} are independent units (the reference runs them one
-        # after the other). Each unit is a chain of small, latency-bound launches, so units run
-        # concurrently: one host thread + one HIP stream per unit, every thread on its own clone of
-        # the graph / sampler modules (their radius / qmin / qmax are mutated during registration).
-        # best_iou is a running maximum, so per-unit copies merged by max equal the serial result.
+        # after the other). Each unit is a chain of small, latency-bound launches, so the native
+        # tracker advances ALL of them in lock-step from one host thread on one stream
+        # (ops.track_sequence -> pcs_track_sequence): every launch serves all units that are in the
+        # same phase. best_iou is a running maximum, so per-unit copies merged by max equal the
+        # serial result.
         frame_offsets, frame_perm = self.frame_offsets_of(seq_points.frame) if self.native else (None, None)
         key_points = {}
         for comp_key in self.component_keys:
@@ -576,147 +609,58 @@ class ClusterTracking(nn.Module):
             sp.stationary = sp.component_diameter > 12.5
             key_points[comp_key] = sp
         units = []
+        present = torch.unique(seq_points.fxyz[:, 0]).long().tolist()
         for comp_key in self.component_keys:
-            sp = key_points[comp_key]
-            present = torch.unique(sp.fxyz[:, 0]).long().tolist()
             for frame_id in range(0, num_frames, self.track_interval):
                 if frame_id in present:
                     units.append((comp_key, frame_id))
 
         views = self.sequence_views(all_points, seq_boxes)
 
-        def run_unit(worker, comp_key, frame_id):
+        def unit_points(comp_key):
             sp = EasyDict(dict(key_points[comp_key]))
             sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
+            return sp
+
+        def finish_unit(extracted):
+            boxes = EasyDict(dict(seq_boxes))
+            boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)
+            with Timer("Extract Traces from all points"):
+                if extracted.fxyz.shape[0] > 0:
+                    extracted, boxes = self.extract_traces_and_update_boxes(all_points, extracted, boxes, views)
+            return extracted, boxes.best_iou
+
+        def run_unit_host(comp_key, frame_id):
+            sp = unit_points(comp_key)
             frame_mask = (sp.fxyz[:, 0] == frame_id).reshape(-1)
             frame_points = EasyDict(filter_dict(sp, frame_mask, ignore_keys=("frame_offsets", "frame_perm")))
             frame_points.component = frame_points.component - frame_points.component.min()
-            boxes = EasyDict(dict(seq_boxes))
-            boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)
-            with Timer(f"Tracking Frame {frame_id}"), Timer(f"unit {comp_key}@{frame_id} track"):
-                extracted = worker.track_frame(sp, frame_points, boxes)
-            with Timer("Extract Traces from all points"), Timer(f"unit {comp_key}@{frame_id} extract"):
-                if extracted.fxyz.shape[0] > 0:
-                    extracted, boxes = worker.extract_traces_and_update_boxes(all_points, extracted, boxes, views)
-            return extracted, boxes.best_iou
+            with Timer(f"Tracking Frame {frame_id}"):
+                extracted = self.track_frame_host(sp, frame_points, None)
+            return finish_unit(extracted)
 
-        # 4 concurrent units: beyond that the kernels of different streams no longer overlap on this
-        # hardware and every unit only gets slower (see pcseqlearning_amd/__init__.py)
-        n_workers = max(1, min(int(self.model_cfg.get("NUM_STREAMS", 4)), len(units)))
-        if n_workers > 1 and os.environ.get("ROCP_TOOL_LIBRARIES"):
-            # rocprofv3 is attached: rocprofiler-sdk on this image segfaults when kernels are launched
-            # from several native threads at once, so a profiled run takes the serial schedule (same
-            # kernels, same results)
-            if not getattr(self, "_warned_profiler", False):
-                print("ClusterTracking: rocprofiler attached -> serial schedule of the tracking units", flush=True)
-                self._warned_profiler = True
-            n_workers = 1
-        self.last_num_workers = n_workers
         results, best = {}, []
-        if n_workers == 1 or not seq_points.fxyz.is_cuda:
-            for comp_key, frame_id in units:
-                ex, biou = run_unit(self, comp_key, frame_id)
-                results[(frame_id, comp_key)] = ex
-                best.append(biou)
-        else:
-            import copy
-            import queue
-            from concurrent.futures import ThreadPoolExecutor
-            device = seq_points.fxyz.device
-            if len(getattr(self, "_workers", [])) < n_workers:
-                self._workers = []
-                for _ in range(n_workers):
-                    w = copy.copy(self)
-                    w._modules = {k: copy.deepcopy(m) for k, m in self._modules.items()}
-                    w.num_registration_calls = 0
-                    w._stream = torch.cuda.Stream(device=device)
-                    self._workers.append(w)
-            main_stream = torch.cuda.current_stream(device)
-            free = queue.Queue()
-            for w in self._workers[:n_workers]:
-                w.num_registration_calls = 0
-                w._stream.wait_stream(main_stream)
-                free.put(w)
-            # A unit costs about as much as the frames it tracks through (an anchor in mid-sequence:
-            # twice as many as one at either end). The units are planned onto the workers up front
-            # (longest-processing-time first, then moves / swaps off the fullest worker): taking
-            # them from a common queue leaves one worker with three medium units at the end.
-            # (High-priority HIP streams for the long units were measured and made every unit slower.)
-            span = {u: 1 + min(num_frames - 1, u[1] + self.track_interval) - max(0, u[1] - self.track_interval)
-                    for u in units}
-            # ... scaled by what a unit of the same (key, window length) took in the previous sequence
-            # (keys with thousands of small components are dearer per frame), when there is one
-            seen = getattr(self, "_unit_seconds", {})
-            per_frame = [seen[(u[0], span[u])] / span[u] for u in units if (u[0], span[u]) in seen]
-            default = sum(per_frame) / len(per_frame) if per_frame else 1.0
-            cost = {u: seen.get((u[0], span[u]), default * span[u]) for u in units}
-            plan = self.plan_units(units, cost, n_workers)
-            took = {}
-
-            import threading
-            plan_lock = threading.Lock()
-
-            def next_unit(i):
-                """Own list first (longest first); an idle worker takes the shortest unit still
-                waiting on the fullest list, so a slow stream does not hold the stage up."""
-                with plan_lock:
-                    if plan[i]:
-                        return plan[i].pop(0)
-                    rest = [(sum(cost[u] for u in plan[j]), j) for j in range(len(plan)) if plan[j]]
-                    if not rest:
-                        return None
-                    return plan[max(rest)[1]].pop()
-
-            def worker_job(w, i):
-                outs, work = [], 0.0
-                t_start = time.perf_counter()
-                with torch.cuda.device(device), torch.cuda.stream(w._stream):
-                    while True:
-                        unit = next_unit(i)
-                        if unit is None:
-                            break
-                        t0 = time.perf_counter()
-                        outs.append((unit, run_unit(w, *unit)))
-                        took[(unit[0], span[unit])] = time.perf_counter() - t0
-                        work += cost[unit]
-                    w._stream.synchronize()
-                # planned work per second: a stream that landed on a hardware queue it has to share
-                # runs its units about twice as slowly as the others
-                w._rate = work / max(time.perf_counter() - t_start, 1e-6) if work else None
-                return outs
-
-            # one pool for the life of the module: its threads keep their pinned status page and
-            # profiling events (thread-local in the native library) from sequence to sequence
-            if getattr(self, "_pool_size", 0) != n_workers:
-                if getattr(self, "_pool", None) is not None:
-                    self._pool.shutdown(wait=True)
-                self._pool = ThreadPoolExecutor(max_workers=n_workers, thread_name_prefix="pcs-track")
-                self._pool_size = n_workers
-            pool = self._pool
-            if True:
-                futs = [pool.submit(worker_job, free.get(), i) for i in range(len(plan)) if plan[i]]
-                # the units are now in native code on their own threads: the main thread does the
-                # parked host-side work (ClusterProposal's evaluation) meanwhile
-                run_deferred(seq_dict)
-                done = {}
-                for fut in futs:
-                    for unit, out in fut.result():
-                        done[unit] = out
-                self._unit_seconds = took
-                # re-roll the stream of a worker that was markedly slower than the median one (streams
-                # map onto hardware queues round-robin; a fresh stream takes another queue)
-                active = [w for w in self._workers[:n_workers] if getattr(w, "_rate", None)]
-                if len(active) >= 3 and seen:
-                    rates = sorted(w._rate for w in active)
-                    median = rates[len(rates) // 2]
-                    for w in active:
-                        if w._rate < 0.6 * median:
-                            w._stream = torch.cuda.Stream(device=device)
-                for comp_key, frame_id in units:      # results in the reference's unit order
-                    ex, biou = done[(comp_key, frame_id)]
-                    results[(frame_id, comp_key)] = ex
-                    best.append(biou)
-            self.num_registration_calls = sum(w.num_registration_calls for w in self._workers[:n_workers])
+        tracked = None
+        self.last_num_workers = 1
+        if frame_offsets is not None and seq_points.fxyz.is_cuda:
+            try:
+                with Timer("Track all units (native, lock-step)"):
+                    tracked = self._track_units_native(seq_dict, key_points, units, frame_offsets, frame_perm)
+                self.last_num_workers = len(units)
+            except PcsError as err:
+                if "PCS_ERR_RANGE" not in str(err):
+                    raise
+        run_deferred(seq_dict)  # (already done beside the native call when that ran)
+        for i, (comp_key, frame_id) in enumerate(units):
+            if tracked is not None:
+                sp = unit_points(comp_key)
+                out, comp_dtype = tracked[i]
+                extracted = self._extracted_from_native(sp, frame_id, out, frame_perm, comp_dtype)
+                ex, biou = finish_unit(extracted)
+            else:
+                ex, biou = run_unit_host(comp_key, frame_id)
+            results[(frame_id, comp_key)] = ex
+            best.append(biou)
         for biou in best:
             seq_boxes.best_iou = torch.maximum(seq_boxes.best_iou, biou)
         for (frame_id, comp_key), extracted in results.items():

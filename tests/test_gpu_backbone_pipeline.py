@@ -110,22 +110,17 @@ def test_points_in_boxes_vs_oracle(oracle):
     np.testing.assert_array_equal(got, oracle.points_in_boxes(pts, boxes))
 
 
-def test_full_pipeline_streams_vs_serial():
-    """SimpleReg end to end on a small sequence: the concurrent (one stream per tracking unit)
-    schedule, the shared-launch schedule and the op-by-op host loop must all give bit-identical
-    results to the serial native schedule, run to run."""
+def test_full_pipeline_lockstep_vs_unit_by_unit():
+    """SimpleReg end to end on a small sequence: all tracking units in lock-step in one native call,
+    the same twice (run to run), one unit per native call, and the op-by-op host loop must all give
+    bit-identical results."""
     from pcseqlearning_amd.pcdet import models
     from tools.run_sequence import build_model
     batch = synthetic.gen_sequence(5, 10, 12000, n_static=14, n_vehicle=8, n_ped=4)
     batch = models.load_data_to_gpu(batch, DEV)
     outs = []
-    # serial, concurrent, concurrent again, concurrent with the ICP iterations of the units sharing
-    # launches (pcs_icp_share_launches), and the op-by-op host loop instead of the native tracker
-    for streams, share, native in ((1, False, True), (9, False, True), (9, False, True), (9, True, True),
-                                   (9, False, False)):
-        model = build_model(save=False, device=DEV)
-        model.preprocessors[2].model_cfg["NUM_STREAMS"] = streams
-        model.preprocessors[2].model_cfg["SHARE_ICP_LAUNCHES"] = share
+    for per_call, native in ((0, True), (0, True), (1, True), (4, True), (0, False)):
+        model = build_model(save=False, device=DEV, units_per_call=per_call)
         model.preprocessors[2].native = native
         with torch.no_grad():
             model(batch)

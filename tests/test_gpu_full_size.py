@@ -1,6 +1,7 @@
 """BASELINE configs[2] at full size (20 frames x 160 k points): the oracle cannot walk this in
 seconds, so parity is checked through size-independent properties of the outputs and through the
-schedule equivalence (serial native tracker == 9 concurrent units, bit for bit)."""
+schedule equivalence (all 9 tracking units in lock-step in one native call == one unit per call, bit
+for bit)."""
 import numpy as np
 import pytest
 import torch
@@ -17,8 +18,8 @@ def full_runs():
     from tools.run_sequence import build_model
     batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
     outs = []
-    for streams in (9, 1):
-        model = build_model(save=False, device=DEV, streams=streams)
+    for per_call in (0, 1):
+        model = build_model(save=False, device=DEV, units_per_call=per_call)
         with torch.no_grad():
             model(batch)
         outs.append(model.last_outputs[0])
@@ -98,7 +99,7 @@ def test_full_size_transforms_are_rigid():
     from pcseqlearning_amd.pcdet import models
     from tools.run_sequence import build_model
     batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
-    model = build_model(save=True, device=DEV, streams=9)
+    model = build_model(save=True, device=DEV)
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         for p in model.model_cfg.PREPROCESSORS:

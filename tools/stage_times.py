@@ -18,18 +18,15 @@ from tools.run_sequence import build_model  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--streams", type=int, default=None)
+    ap.add_argument("--units-per-call", type=int, default=None)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--units", action="store_true", help="print the per-unit track / extract spans")
-    ap.add_argument("--share", default=None, help="SHARE_ICP_LAUNCHES: 'all' (one launcher) or 'anchor' (one per anchor)")
     ap.add_argument("--detail", action="store_true", help="device-synchronised spans inside the stages")
     args = ap.parse_args()
     timer.SYNC = args.detail
     batch = bench.load_sequence(0, 20, 160000)
-    model = build_model(streams=args.streams)
+    model = build_model(units_per_call=args.units_per_call)
     batch = models.load_data_to_gpu(batch)
-    if args.share:
-        model.preprocessors[2].model_cfg["SHARE_ICP_LAUNCHES"] = True if args.share == "all" else args.share
     spans = {}
 
     def wrap(mod, name):
@@ -62,13 +59,8 @@ def main():
         trk = sum(v for k, v in timer.RECORDS.items() if k.startswith("Tracking Frame"))
         ext = timer.RECORDS.get("Extract Traces from all points", 0.0)
         print(f"   sum over units: track_frame {trk * 1e3:.1f} ms, extract traces {ext * 1e3:.1f} ms")
-        import ctypes
-        from pcseqlearning_amd import lib as L
-        st = (ctypes.c_double * 4)()
-        L.load().pcs_profile_batcher_read(st)
-        if st[0] > 0:
-            print(f"   shared launcher: {int(st[0])} batches, {st[1] / st[0]:.2f} problems per batch, "
-                  f"{st[2] / st[0] * 1e6:.0f} us per batch, busy {st[2] * 1e3:.1f} ms, idle {st[3] * 1e3:.1f} ms")
+        print(f"   native tracker: {getattr(model.preprocessors[2], 'last_ticks', 0)} host ticks, "
+              f"{model.preprocessors[2].num_registration_calls} registrations")
         if args.detail:
             for k in sorted(timer.RECORDS):
                 if not k.startswith(("unit ", "Tracking Frame", "REGISTRATION")):
