@@ -203,6 +203,24 @@ __device__ __forceinline__ uint64_t g2_box_mask(int X, int Y, int Z, int cx, int
   return (uint64_t)row16 * zs;
 }
 
+// ---- verified cache of the fused ICP: how far things may move before a search result can change.
+// Distances are SPATIAL and squared on input: a2 = nearest, b2 = lower bound of every other point.
+// A full search compares fp32 sums of four squares whose relative rounding error is below 2.4e-7,
+// so two candidates are reliably ordered only when their squared distances differ by more than
+// E = 1e-6 x (radius^2): the budget D solves (sqrt(b2) - D)^2 - (sqrt(a2) + D)^2 > E, less a safety.
+__device__ __forceinline__ float icp_cache_budget(float a2, float b2, float radius2_4d) {
+  const float E = 1e-6f * radius2_4d + 1e-9f;
+  const float s1 = sqrtf(fmaxf(a2, 0.f) + E), s2 = sqrtf(fmaxf(b2 - E, 0.f));
+  const float bud = 0.5f * (s2 - s1) - E / (2.f * (s1 + s2) + 1e-12f);
+  return bud * 0.999999f - 2e-5f;
+}
+// no partner: every point is at least sqrt(lb2) away, the spatial search radius is sqrt(rs2)
+__device__ __forceinline__ float icp_cache_budget_none(float lb2, float rs2, float radius2_4d) {
+  const float E = 1e-6f * radius2_4d + 1e-9f;
+  const float bud = sqrtf(fmaxf(lb2 - E, 0.f)) - sqrtf(fmaxf(rs2, 0.f) + E);
+  return bud * 0.999999f - 2e-5f;
+}
+
 // Cooperative form: the 32 lanes of a half-wave serve ONE query (two queries per wave).
 //   1. lanes 0..26 fetch the occupancy masks of the 3x3x3 coarse blocks around the query;
 //   2. the 27 fine cells at Chebyshev distance <= 1 are dealt to 27 lanes (one round of memory
@@ -214,10 +232,21 @@ __device__ __forceinline__ uint64_t g2_box_mask(int X, int Y, int Z, int cx, int
 // canonical order (dist2, original index), whatever the traversal order. Every lane of the wave
 // must call this (shuffles); the lanes of a half pass the same p / df, `valid` = this half has a
 // query. The result (original index or -1) is returned in every lane of the half.
+//
+// BUD = true (the fused ICP's verified cache): the search also says for how long its answer stays
+// exact. The hashed cloud then has ONE frame value, so the frame term of the 4-D distance is the
+// same constant for every candidate and "nearest" is decided by the spatial distance. Every pruning
+// bound is widened by `mu` (spatial), so that all points within (nearest spatial distance + mu) --
+// or, for a query without partner, within the spatial radius + mu -- have been looked at;
+// *bud_out is then a distance: as long as neither the query nor any hashed point has moved further
+// than that in total, a full search would return the same partner (or "none") again -- the fp32
+// rounding of the 4-term distance sum is part of the bound (icp_cache_budget). The cell size must
+// admit spatial radius + mu.
+template <bool BUD = false>
 __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g, float4 p, int df,
                                                bool valid, int* __restrict__ overflow,
                                                float* __restrict__ best_dist2 = nullptr,
-                                               int probe_stage = 0) {
+                                               float mu = 0.f, float* __restrict__ bud_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 31;
   const int half_base = lane & 32;
@@ -228,8 +257,12 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
   float dfsq = dfl * dfl;
   const float margin = 1e-5f * d.radius2 + 1e-6f;
-  float budget = d.radius2 - dfsq + margin;
+  // spatial radius (squared) inside which everything is examined
+  const float rs = sqrtf(fmaxf(d.radius2 - dfsq, 0.f));
+  const float rinf2 = BUD ? (rs + mu) * (rs + mu) : d.radius2 - dfsq;
+  float budget = rinf2 + margin;
   valid = valid && budget >= 0.f;
+  const bool valid0 = valid;
   int rings = valid ? (int)ceilf(sqrtf(budget) / d.h) : 0;
   if (rings > 4) { if (sub == 0) atomicExch(overflow, 1); rings = 4; }
   int cx = (int)floorf((p.y - d.lo[0]) / d.h);
@@ -247,10 +280,16 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     }
   }
   unsigned long long occ = __ballot(mymask != 0);
-  if (probe_stage == 2) return (int)(mymask & 1);  // timing probe: stop after the coarse masks
-  valid = valid && ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
+  const bool any_block = ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
+  valid = valid && any_block;
   int cand = -1;
   float cd = 0.f;
+  float cd2 = __builtin_inff();  // BUD: smallest squared distance seen other than the best's
+  auto widen = [&](float x2) {   // squared SPATIAL radius that must be examined around a best of x2 (4-D)
+    if (!BUD) return x2 - dfsq;
+    float r = sqrtf(fmaxf(x2 - dfsq, 0.f)) + mu;
+    return r * r;
+  };
 
   auto consider = [&](float4 c, int oi) {
     float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
@@ -259,7 +298,13 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     dist2 = dist2 + d1 * d1;
     dist2 = dist2 + d2 * d2;
     dist2 = dist2 + d3 * d3;
-    if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) { cand = oi; cd = dist2; }
+    if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) {
+      if (BUD && cand >= 0) cd2 = fminf(cd2, cd);
+      cand = oi;
+      cd = dist2;
+    } else if (BUD) {
+      cd2 = fminf(cd2, dist2);
+    }
   };
   // a cell's run is kCellCap contiguous rows: four rows and their indices are requested together
   // (one round of memory latency per four points instead of one per point)
@@ -313,10 +358,16 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       if (take) { cand = oc; cd = od; }
     }
   };
-  reduce_half();
-  if (probe_stage == 3) return cand;  // timing probe: stop after the near cells
+  // (BUD: the lanes keep their own second-best; the best is exchanged, so a lane may hold the half's
+  //  best without having seen it -- its own former best then counts as a non-best distance)
+  {
+    const int mine = cand;
+    const float mine_d = cd;
+    reduce_half();
+    if (BUD && mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
+  }
   // ---- far cells: everything at Chebyshev distance >= 2 is at least h away
-  float bound = (cand >= 0 ? cd : d.radius2) - dfsq + margin;  // admissible |dxyz|^2 of a better point
+  float bound = (cand >= 0 ? widen(cd) : rinf2) + margin;  // admissible |dxyz|^2 of a point that matters
   bool more = valid && rings >= 2 && !(d.h * d.h > bound);
   uint64_t rem = 0;
   if (more && sub < 27) rem = mymask & ~g2_box_mask(X, Y, Z, cx, cy, cz, 1);
@@ -403,14 +454,176 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
         float ax = (float)max(abs(x - cx) - 1, 0), ay = (float)max(abs(y - cy) - 1, 0),
               az = (float)max(abs(z - cz) - 1, 0);
         float lb2 = ((ax * ax + ay * ay) + az * az) * h2;
-        float bnd = (cand >= 0 ? cd : d.radius2) - dfsq + margin;
+        float bnd = (cand >= 0 ? widen(cd) : rinf2) + margin;
         if (!(lb2 > bnd)) scan_cell(x, y, z);
       }
     }
-    reduce_half();
+    {
+      const int mine = cand;
+      const float mine_d = cd;
+      reduce_half();
+      if (BUD && mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
+    }
   }
   if (best_dist2) *best_dist2 = cand >= 0 ? cd : d.radius2;
+  if (BUD) {
+    // smallest non-best distance over the half
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) cd2 = fminf(cd2, __shfl_xor(cd2, o, 64));
+    float bud = 0.f;
+    if (valid0 && fa == fb) {  // (several frame values in the cell: no statement, search again next time)
+      if (cand >= 0) {
+        // every point within spatial distance s1 + mu has been looked at: the runner-up is at least that far
+        bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, widen(cd)), d.radius2);
+      } else if (!any_block) {
+        // nothing at all in the 3 x 3 x 3 blocks: the nearest point lies beyond their boundary
+        float fx = (p.y - d.lo[0]) / d.h, fy = (p.z - d.lo[1]) / d.h, fz = (p.w - d.lo[2]) / d.h;
+        float ex = fminf(fx - (float)(4 * (bx - 1)), (float)(4 * (bx + 2)) - fx);
+        float ey = fminf(fy - (float)(4 * (by - 1)), (float)(4 * (by + 2)) - fy);
+        float ez = fminf(fz - (float)(4 * (bz - 1)), (float)(4 * (bz + 2)) - fz);
+        float e = fmaxf(fminf(fminf(ex, ey), ez), 0.f) * d.h;
+        bud = icp_cache_budget_none(e * e, d.radius2 - dfsq, d.radius2);
+      } else {
+        bud = icp_cache_budget_none(fminf(cd2 - dfsq, rinf2), d.radius2 - dfsq, d.radius2);
+      }
+    }
+    if (bud_out) *bud_out = bud;
+  }
   return cand;
+}
+
+// Can g2_nearest_seeded8 settle this query? (One lane; the same arithmetic as the search itself, so
+// the answer is the search's own. dist2 = the candidate's 4-D squared distance as the search forms it.)
+__device__ __forceinline__ bool g2_seed_admissible(const GridDesc& d, const Grid2& g, float4 p, int df,
+                                                   float dist2, float mu) {
+  int fc = frame_cell(d, p.x) + df;
+  if (fc < 0 || fc >= kFrameCells) return false;
+  const float fa = g.fr[fc], fb = g.fr[kFrameCells + fc];
+  if (!(fa == fb) || !(dist2 <= d.radius2)) return false;
+  const float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+  const float dfsq = dfl * dfl;
+  const float margin = 1e-5f * d.radius2 + 1e-6f;
+  const float rho = sqrtf(fmaxf(dist2 - dfsq, 0.f)) + mu;
+  const float bound2 = rho * rho + margin;
+  const float bound = sqrtf(bound2) * 1.000001f + 1e-6f;
+  const float fx = (p.y - d.lo[0]) / d.h, fy = (p.z - d.lo[1]) / d.h, fz = (p.w - d.lo[2]) / d.h;
+  const float br = bound / d.h;
+  const int x0 = (int)floorf(fx - br), x1 = (int)floorf(fx + br);
+  const int y0 = (int)floorf(fy - br), y1 = (int)floorf(fy + br);
+  const int z0 = (int)floorf(fz - br), z1 = (int)floorf(fz + br);
+  return x1 - x0 <= 2 && y1 - y0 <= 2 && z1 - z0 <= 2 && x0 >= 0 && y0 >= 0 && z0 >= 0;
+}
+
+// EIGHT lanes serve one query that comes with a candidate (in the ICP: its partner of the previous
+// iteration, a real point of the hashed set): only the fine cells that intersect the ball through
+// the candidate (widened by mu, see g2_nearest_coop<true>) can hold a point that matters, and once
+// the loop has converged that is a handful of cells instead of the 27 + far walk of the cooperative
+// search -- a few dozen bytes per query instead of a kilobyte, and eight queries per wave instead of
+// two. The cells of the box around the ball (at most 3 x 3 x 3) are dealt to the eight lanes; cells
+// the ball does not reach are never probed. Exact under the same canonical order (dist2, original
+// index). The eight lanes of an aligned group pass the same arguments; all 64 lanes of the wave
+// must call this (shuffles). Returns true when the search is complete (*res = the nearest point's
+// index, possibly the seed's, *bud_out = how far things may move before the answer can change, in
+// every lane of the group), false when the seed is not admissible or the box is larger (the caller
+// then runs the cooperative search for this query).
+__device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid2& g, float4 p, int df,
+                                                   float4 seed_pt, int seed_idx, bool valid, float mu,
+                                                   int* __restrict__ res, float* __restrict__ bud_out) {
+  const int sub = threadIdx.x & 7;
+  int fc = frame_cell(d, p.x) + df;
+  bool ok = valid && seed_idx >= 0 && fc >= 0 && fc < kFrameCells;
+  float fa = 1.f, fb = 0.f;
+  if (ok) { fa = g.fr[fc]; fb = g.fr[kFrameCells + fc]; }
+  ok = ok && fa <= fb;
+  const float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+  const float dfsq = dfl * dfl;
+  const float margin = 1e-5f * d.radius2 + 1e-6f;
+  int cand = -1;
+  float cd = 0.f;
+  float cd2 = __builtin_inff();  // smallest squared distance seen other than the best's
+  auto consider = [&](float4 c, int oi) {
+    float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+    float dist2 = 0.f;
+    dist2 = dist2 + d0 * d0;
+    dist2 = dist2 + d1 * d1;
+    dist2 = dist2 + d2 * d2;
+    dist2 = dist2 + d3 * d3;
+    if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) {
+      if (cand >= 0) cd2 = fminf(cd2, cd);
+      cand = oi;
+      cd = dist2;
+    } else if (oi != cand) {  // (the seed is met again in its cell)
+      cd2 = fminf(cd2, dist2);
+    }
+  };
+  if (ok) consider(seed_pt, seed_idx);
+  ok = ok && cand >= 0 && fa == fb;  // else the partner has left the search radius
+  const float rho = sqrtf(fmaxf(cd - dfsq, 0.f)) + mu;  // everything within (spatial) rho of the query is examined
+  const float cover2 = rho * rho;
+  const float bound2 = cover2 + margin;
+  const float bound = ok ? sqrtf(bound2) * 1.000001f + 1e-6f : 0.f;
+  const float fx = (p.y - d.lo[0]) / d.h, fy = (p.z - d.lo[1]) / d.h, fz = (p.w - d.lo[2]) / d.h;
+  const float br = bound / d.h;
+  const int x0 = (int)floorf(fx - br), x1 = (int)floorf(fx + br);
+  const int y0 = (int)floorf(fy - br), y1 = (int)floorf(fy + br);
+  const int z0 = (int)floorf(fz - br), z1 = (int)floorf(fz + br);
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+  ok = ok && nx <= 3 && ny <= 3 && nz <= 3 && x0 >= 0 && y0 >= 0 && z0 >= 0;
+  const int ncell = ok ? nx * ny * nz : 0;
+  const float h2 = d.h * d.h;
+  const float lim = (bound2 / h2) * 1.00001f + 1e-5f;
+  // spilled points (cells with more than kCellCap points; normally none)
+  {
+    const int no = ok ? *g.ovf : 0;
+    for (int j = sub; j < no; j += 8) {
+      float4 c = g.ovf_pts[j];
+      if (frame_cell(d, c.x) != fc) continue;
+      consider(c, g.ovf_idx[j]);
+    }
+  }
+  for (int ci = sub; ci < ncell; ci += 8) {
+    const int ix = ci % nx, iy = (ci / nx) % ny, iz = ci / (nx * ny);
+    const int x = x0 + ix, y = y0 + iy, z = z0 + iz;
+    // squared distance (in cells) from the query to the cell's box; beyond the ball: skip
+    const float ax = fmaxf(fmaxf((float)x - fx, fx - (float)(x + 1)), 0.f);
+    const float ay = fmaxf(fmaxf((float)y - fy, fy - (float)(y + 1)), 0.f);
+    const float az = fmaxf(fmaxf((float)z - fz, fz - (float)(z + 1)), 0.f);
+    if ((ax * ax + ay * ay) + az * az > lim) continue;
+    uint32_t cnt_w = 0, pad_w = 0;
+    int fs = g2_find(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z), &cnt_w, &pad_w);
+    if (fs < 0) continue;
+    const int cnt = min((int)cnt_w, kCellCap);
+    const float4* run = g.spts + (size_t)fs * kCellCap;
+    const int4* idx = (const int4*)(g.sidx + (size_t)fs * kCellCap);
+    for (int j = 0; j < cnt; j += 4) {
+      float4 c0 = run[j], c1 = run[j + 1], c2 = run[j + 2], c3 = run[j + 3];
+      int4 oi = idx[j >> 2];
+      consider(c0, oi.x);
+      if (j + 1 < cnt) consider(c1, oi.y);
+      if (j + 2 < cnt) consider(c2, oi.z);
+      if (j + 3 < cnt) consider(c3, oi.w);
+    }
+  }
+  // best of the eight lanes; a lane whose own best lost keeps it as a non-best distance
+  {
+    const int mine = cand;
+    const float mine_d = cd;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      int oc = __shfl_xor(cand, o, 64);
+      float od = __shfl_xor(cd, o, 64);
+      bool take = oc >= 0 && (cand < 0 || od < cd || (od == cd && oc < cand));
+      if (take) { cand = oc; cd = od; }
+    }
+    if (mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) cd2 = fminf(cd2, __shfl_xor(cd2, o, 64));
+  }
+  *res = cand;
+  float bud = 0.f;
+  if (ok && cand >= 0) bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, cover2), d.radius2);
+  *bud_out = bud;
+  return ok;
 }
 
 }  // namespace pcs

@@ -46,6 +46,11 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   plan_grid2(a, Ra, b.ga);
   b.nn_f = a.take<int32_t>(2 * Mn);
   b.nn_b = a.take<int32_t>(2 * Rn);
+  b.bud_f = a.take<float>(2 * Mn);
+  b.bud_b = a.take<float>(2 * Rn);
+  b.wl = a.take<int32_t>(Mn + Rn);
+  b.wls = a.take<int32_t>(Mn + Rn);
+  b.sstep = a.take<unsigned int>(2 * kStepH);
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
@@ -72,8 +77,11 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   // fine cell = (largest admissible spatial distance) / 4, so that the 3x3x3 coarse blocks cover
   // the search ball: |dxyz|^2 <= rad^2 - df^2 + margin with df = frame_offset for integer frame
   // values (the kernel flags PCS_ERR_RANGE if the data violate that). cell_size may enlarge it.
+  // every search is widened by mu (1/16 of the spatial radius) so that it can say how long its
+  // answer stays valid; the cells must admit the widened ball
+  pr.mu = (float)(a.radius / 16.0);
   double rad2 = (double)pr.rad * (double)pr.rad;
-  double budget = rad2 - fo * fo + (2e-5 * rad2 + 2e-6);
+  double budget = (a.radius + pr.mu) * (a.radius + pr.mu) + (2e-5 * rad2 + 2e-6);
   if (budget < a.radius * a.radius) budget = a.radius * a.radius;
   pr.cell = (float)(sqrt(budget) * 0.25 * 1.0005);
   if (a.cell_size > pr.cell) pr.cell = a.cell_size;
@@ -88,6 +96,11 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.first = b.first;
   pr.nn_f = b.nn_f;
   pr.nn_b = b.nn_b;
+  pr.bud_f = b.bud_f;
+  pr.bud_b = b.bud_b;
+  pr.wl = b.wl;
+  pr.wls = b.wls;
+  pr.sstep = b.sstep;
   pr.acc = b.acc;
   pr.Tb = b.Tb;
   pr.lsc = b.lsc;
@@ -136,12 +149,16 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->iters = 0;
     st->err = 0;
     st->decided = 0;
+    st->wl_n = 0;
+    st->ws_n = 0;
+    st->dmax[0] = st->dmax[1] = 0u;
   }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {
     int e = (int)(q & 15);
     pr.Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
   }
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) pr.acc[q] = 0;
+  for (int64_t q = i; q < 2 * kStepH; q += stride) pr.sstep[q] = 0u;
   for (int64_t q = i; q < C; q += stride) { pr.cov[q] = 0; pr.first[q] = INT_MAX; pr.lsc[q] = 0.0; }
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
@@ -281,8 +298,20 @@ icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase,
   if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;
 }
 
-// 32 lanes per query. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
-// queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset).
+// Queries [0,Mn): forward (moving -> reference, df = +frame_offset); queries [Mn, Mn+Rn): backward
+// (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED CACHE: every search also
+// returns how far things may move before its answer can change (half the gap to the runner-up, or
+// the distance by which the nearest point misses the radius). From iteration 2 on a query first
+// subtracts what has moved since -- its own last step (forward) or the largest step of any moving
+// point (backward) -- and keeps its neighbour without touching the grid while the budget lasts
+// (98 % of the searches of a converging loop return the partner they returned before).
+//   icp_nn_kernel         one LANE per query: the budget test; the queries that must search again
+//                         are compacted into two work lists (one atomic per wave and list)
+//   icp_nn_search_kernel  blockIdx.z = 0: eight lanes per query around the old partner
+//                         (g2_nearest_seeded8) for the list of queries whose partner is within a
+//                         cell or so; blockIdx.z = 1: the cooperative search (32 lanes per query)
+//                         for the rest -- and for every query in iteration 1.
+// Exact: the same neighbours as a full search, always.
 __global__ void __launch_bounds__(kBlock)
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
@@ -292,38 +321,187 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
-  const int nround = (nq + kBlock / 32 - 1) / (kBlock / 32);
+  const int nround = (nq + kBlock - 1) / kBlock;
   if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
   // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
   if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  if (k == 1) {  // no neighbours yet: every query takes the cooperative search
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->wl_n = nq;
+    return;
+  }
   GridDesc g = pr.geom->g;
-  const int sub = threadIdx.x & 31;
+  const int lane = threadIdx.x & 63;
   int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
   int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
+  float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
+  float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
+  const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
+  const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+  const float* __restrict__ sbud_f = pr.bud_f + (size_t)((k - 1) & 1) * pr.capM;
+  const float* __restrict__ sbud_b = pr.bud_b + (size_t)((k - 1) & 1) * pr.capR;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
-    int qid = r * (kBlock / 32) + (threadIdx.x >> 5);
-    bool fwd = qid < Mn;
-    bool valid = qid < nq;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
-    // a wave may straddle the forward/backward boundary: its two halves then search different grids
-    bool any_fwd = __ballot(valid && fwd) != 0;
-    bool any_bwd = __ballot(valid && !fwd) != 0;
+  // steps of the moving points in iteration k-1, by the place they moved into
+  const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+    const int qid = r * kBlock + threadIdx.x;
+    const bool valid = qid < nq;
+    const bool fwd = qid < Mn;
+    bool to_seeded = false, to_coop = false;
+    if (valid) {
+      float4 p, sp = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s;
+      float bud, disp;
+      if (fwd) {
+        p = pr.mov[qid];
+        float4 o = pr.prev[qid];
+        s = seed_f[qid];
+        bud = sbud_f[qid];
+        float dx = p.y - o.y, dy = p.z - o.z, dz = p.w - o.w;
+        disp = sqrtf((dx * dx + dy * dy) + dz * dz);
+      } else {
+        p = pr.ref[qid - Mn];
+        s = seed_b[qid - Mn];
+        bud = sbud_b[qid - Mn];
+        // a moving point that can matter for this query lies in the 3 x 3 x 3 blocks of 4^3 cells
+        // around it -- 12 cells per axis, i.e. at most 2 x 2 x 2 blocks of 8^3 cells: the largest
+        // step recorded there bounds how far any such point has moved since iteration k-1
+        const int cx = (int)floorf((p.y - g.lo[0]) / g.h), cy = (int)floorf((p.z - g.lo[1]) / g.h),
+                  cz = (int)floorf((p.w - g.lo[2]) / g.h);
+        const int sx = (4 * ((cx >> 2) - 1)) >> 3, sy = (4 * ((cy >> 2) - 1)) >> 3, sz = (4 * ((cz >> 2) - 1)) >> 3;
+        unsigned int m = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          m = max(m, sstep[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
+        disp = __uint_as_float(m);
+      }
+      bud = bud - disp * 1.000001f - 1e-7f;
+      float dist2 = __builtin_inff();
+      if (s >= 0) {
+        sp = fwd ? pr.ref[s] : pr.mov[s];
+        float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
+        dist2 = 0.f;
+        dist2 = dist2 + d0 * d0;
+        dist2 = dist2 + d1 * d1;
+        dist2 = dist2 + d2 * d2;
+        dist2 = dist2 + d3 * d3;
+      }
+      if (bud > 1e-5f) {
+        // still exact: nothing has moved far enough to change the answer
+        int res = -1;
+        if (s >= 0) {
+          if (dist2 <= g.radius2) res = s;
+          else bud = 0.f;  // the partner left the radius (so did everything else): search next time
+        }
+        if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
+        else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+      } else if (s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
+        to_seeded = true;
+      } else {
+        to_coop = true;
+      }
+    }
+    const unsigned long long ms = __ballot(to_seeded), mc = __ballot(to_coop);
+    if (ms) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&st->ws_n, __popcll(ms));
+      base = __shfl(base, 0, 64);
+      if (to_seeded) pr.wls[base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
+    }
+    if (mc) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&st->wl_n, __popcll(mc));
+      base = __shfl(base, 0, 64);
+      if (to_coop) pr.wl[base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  IcpState* st = pr.st;
+  if (k > pr.max_iter || k > st->stop_iter) return;
+  const bool coop = blockIdx.z == 1;
+  const int nw = coop ? st->wl_n : st->ws_n;
+  const int per_block = coop ? kBlock / 32 : kBlock / 8;
+  const int nround = (nw + per_block - 1) / per_block;
+  if ((int)blockIdx.x >= nround) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  GridDesc g = pr.geom->g;
+  int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
+  int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
+  float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
+  float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
+  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  if (coop) {
+    const int sub = threadIdx.x & 31;
+    for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+      const int w = r * (kBlock / 32) + (threadIdx.x >> 5);
+      const bool valid = w < nw;
+      const int qid = valid ? pr.wl[w] : 0;
+      const bool fwd = qid < Mn;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
+      // the two halves of a wave may search different grids
+      const bool any_fwd = __ballot(valid && fwd) != 0;
+      const bool any_bwd = __ballot(valid && !fwd) != 0;
+      int res = -1;
+      float bud = 0.f;
+      if (any_fwd) {
+        float tb;
+        int rr = g2_nearest_coop<true>(g, g_ref, p, pr.df, valid && fwd, &st->err, nullptr, pr.mu, &tb);
+        if (fwd) { res = rr; bud = tb; }
+      }
+      if (any_bwd) {
+        float tb;
+        int rr = g2_nearest_coop<true>(g, g_mov, p, -pr.df, valid && !fwd, &st->err, nullptr, pr.mu, &tb);
+        if (!fwd) { res = rr; bud = tb; }
+      }
+      if (valid && sub == 0) {
+        if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
+        else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+      }
+    }
+    return;
+  }
+  const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
+  const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles inside)
+    const int w = r * (kBlock / 8) + (threadIdx.x >> 3);
+    const bool valid = w < nw;
+    const int qid = valid ? pr.wls[w] : 0;
+    const bool fwd = qid < Mn;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
+    int s = -1;
+    if (valid) {
+      p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
+      s = fwd ? seed_f[qid] : seed_b[qid - Mn];
+      sp = fwd ? pr.ref[s] : pr.mov[s];
+    }
     int res = -1;
-    if (any_fwd) {
-      int rr = g2_nearest_coop(g, g_ref, p, pr.df, valid && fwd, &st->err);
-      if (fwd) res = rr;
+    float bud = 0.f;
+    bool ok = true;
+    if (__ballot(valid && fwd) != 0) {
+      int t;
+      float tb;
+      bool o = g2_nearest_seeded8(g, g_ref, p, pr.df, sp, s, valid && fwd, pr.mu, &t, &tb);
+      if (valid && fwd) { res = t; bud = tb; ok = o; }
     }
-    if (any_bwd) {
-      int rr = g2_nearest_coop(g, g_mov, p, -pr.df, valid && !fwd, &st->err);
-      if (!fwd) res = rr;
+    if (__ballot(valid && !fwd) != 0) {
+      int t;
+      float tb;
+      bool o = g2_nearest_seeded8(g, g_mov, p, -pr.df, sp, s, valid && !fwd, pr.mu, &t, &tb);
+      if (valid && !fwd) { res = t; bud = tb; ok = o; }
     }
-    if (valid && sub == 0) {
-      if (fwd) nn_f[qid] = res;
-      else nn_b[qid - Mn] = res;
+    if (valid && (threadIdx.x & 7) == 0) {
+      if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
+      if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
+      else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
     }
   }
 }
@@ -669,7 +847,18 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
   g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
-  if (tid == 0) st->iters = k;
+  if (tid == 0) {
+    st->iters = k;
+    st->wl_n = 0;                 // the work lists of iteration k have been served
+    st->ws_n = 0;
+    st->dmax[(k + 1) & 1] = 0u;   // takes the steps of iteration k+1
+  }
+  {  // the step table of iteration k+1 (nothing reads it during this launch)
+    unsigned int* nxt = pr.sstep + (size_t)((k + 1) & 1) * kStepH;
+    for (int64_t q = tid; q < kStepH; q += (int64_t)gridDim.x * blockDim.x) nxt[q] = 0u;
+  }
+  unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
+  float step = 0.f;  // largest step of this thread's points
   const GridDesc d = pr.geom->g;
   const int nround = (Mn + kBlock - 1) / kBlock;
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
@@ -691,6 +880,15 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
       float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
       moved = make_float4(p.x, nx, ny, nz);
       mov[i] = moved;
+      {
+        // the verified cache's budget unit: how far this point moved, filed under the place it moved to
+        float dx = nx - p.y, dy = ny - p.z, dz = nz - p.w;
+        float st1 = sqrtf((dx * dx + dy * dy) + dz * dz) * 1.000001f + 1e-7f;
+        step = fmaxf(step, st1);
+        const int fx = (int)floorf((nx - d.lo[0]) / d.h), fy = (int)floorf((ny - d.lo[1]) / d.h),
+                  fz = (int)floorf((nz - d.lo[2]) / d.h);
+        atomicMax(&sstep[icp_step_slot(fx >> 3, fy >> 3, fz >> 3)], __float_as_uint(st1));
+      }
       if (first[c] == i) {
         // the component's owner: transform, loss term, and the other moment buffer zeroed for the
         // next iteration (nothing reads it during this launch)
@@ -703,6 +901,8 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     }
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
+  step = wave_max(step);
+  if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
@@ -757,8 +957,9 @@ struct ProfEvents {
   hipEvent_t ev[6 * kProfChunk];
   bool have = false;
 };
-static thread_local ProfEvents t_ev;
-static thread_local int t_ev_used = 0;  // iterations of the last chunk that carried events
+constexpr int kProfSlots = 8;  // chunks one thread may have in flight (one per lock-step group)
+static thread_local ProfEvents t_evs[kProfSlots];
+static thread_local int t_ev_useds[kProfSlots];  // iterations of the slot's last chunk that carried events
 
 static inline int gx_for(int64_t items, int per_block, int cap) {
   int64_t g = (items + per_block - 1) / per_block;
@@ -789,15 +990,22 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
 }
 
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s) {
+                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot) {
   if (bt.n < 1 || n_it < 1) return PCS_OK;
+  if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
+  ProfEvents& t_ev = t_evs[prof_slot];
+  int& t_ev_used = t_ev_useds[prof_slot];
   int64_t q = 1, m = 1;
   for (int e = 0; e < bt.n; ++e) {
     int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
     if (qe > q) q = qe;
     if (hints[e].Mn > m) m = hints[e].Mn;
   }
-  const int nb_q = gx_for(q * 32, kBlock, 8192);  // 32 lanes per query
+  bool any_first = false;
+  for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
+  const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
+  const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
+  const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
   const int nb_e = gx_for(q, kBlock, 4096);
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on && n_it <= kProfChunk;
@@ -807,17 +1015,22 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   }
   t_ev_used = prof ? n_it : 0;
   for (int j = 0; j < n_it; ++j) {
+    const int nb_c = (j == 0 && any_first) ? nb_c1 : nb_cs;
     if (prof) {
       // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
       // kernel's own begin-to-end time, as rocprofv3 reports it
       hipEvent_t* e = &t_ev.ev[6 * j];
-      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], e[1], 0, tab, bt, kbase, j);
+      // (the search is two launches; the pair is timed as one kernel, first start to last stop)
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 2), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
+                            bt, kbase, j);
       hipExtLaunchKernelGGL(icp_moments_kernel, dim3(nb_e, bt.n), dim3(kBlock), 0, s, e[2], e[3], 0, tab, bt,
                             kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
       icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_nn_search_kernel<<<dim3(nb_c, bt.n, 2), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_moments_kernel<<<dim3(nb_e, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
@@ -831,7 +1044,10 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
 // after the stream has been synchronised: add the chunk's launches to the profile. live[j] = number
 // of entries that really ran iteration position j; bytes3[j*3 + {0,1,2}] = their algorithmic bytes in
 // the search / moments / apply launch. Launches in which no entry was live are not counted.
-void icp_profile_account(int n_it, const int* live, const double* bytes3) {
+void icp_profile_account(int n_it, const int* live, const double* bytes3, int prof_slot) {
+  if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
+  ProfEvents& t_ev = t_evs[prof_slot];
+  int& t_ev_used = t_ev_useds[prof_slot];
   if (!g_prof_on || t_ev_used < 1) return;
   int n = n_it < t_ev_used ? n_it : t_ev_used;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -974,7 +1190,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
     BatchInts kb;
     kb.v[0] = it;
-    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s);
+    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s, 0);
     if (rc) return rc;
     if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
@@ -986,7 +1202,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
         live[j] = (it + 1 + j <= host.iters) ? 1 : 0;
         b3[3 * j] = by_nn; b3[3 * j + 1] = by_mom; b3[3 * j + 2] = by_app;
       }
-      icp_profile_account(n_it, live, b3);
+      icp_profile_account(n_it, live, b3, 0);
     }
     it += n_it;
     if (host.err) return PCS_ERR_RANGE;

@@ -33,7 +33,10 @@ struct IcpState {
   int iters;      // iterations solved so far
   int err;
   int decided;    // last iteration whose stop rule has been evaluated
+  int wl_n;       // queries waiting for the cooperative search of the current iteration
+  int ws_n;       // queries waiting for the search around their old partner
   int pad;
+  unsigned int dmax[2];  // float bits: largest displacement of a moving point in iteration k (slot k & 1)
 };
 
 // per-component accumulators of one iteration: n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2,
@@ -48,6 +51,15 @@ constexpr int kAcc = 20;
 constexpr int kFxBits = 36;
 constexpr double kFx = 68719476736.0;        // 2^36
 constexpr double kFxInv = 1.0 / 68719476736.0;
+
+// Steps of the moving points, by place: slot = hash of the 8 x 8 x 8-cell block the point moved INTO.
+// Colliding blocks share a slot and hence the larger step: the table can only over-estimate.
+constexpr int kStepH = 4096;
+__host__ __device__ inline int icp_step_slot(int sx, int sy, int sz) {
+  unsigned h = (unsigned)sx * 73856093u ^ (unsigned)sy * 19349663u ^ (unsigned)sz * 83492791u;
+  h ^= h >> 15;
+  return (int)(h & (unsigned)(kStepH - 1));
+}
 
 struct IcpGeom {
   GridDesc g;
@@ -68,6 +80,10 @@ struct IcpProblem {
   const int64_t* cnt3;  // device {Mn, Ra, Rn} or nullptr (then the immediates below hold)
   int32_t* first;       // [C] smallest moving-point index of the component (INT_MAX: none)
   int32_t *nn_f, *nn_b; // [2, capM] / [2, capR]: buffer k & 1 holds iteration k's neighbours
+  float *bud_f, *bud_b; // same shape: how far things may still move before the neighbour can change
+  int32_t* wl;          // [capM + capR] queries handed to the cooperative search
+  int32_t* wls;         // [capM + capR] queries handed to the search around their old partner
+  unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
   long long* acc;       // [2, C, kAcc]
   double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
   double* lsc;          // [C] loss term of each component, last applied iteration
@@ -83,6 +99,7 @@ struct IcpProblem {
   int64_t C;
   double reg, delta;
   float rad, cell, pad;
+  float mu;             // widening of every search (see g2_nearest_coop<true>)
   int Mn, Rn, Ra;       // immediates (cnt3 == nullptr) / capacities of nn_f, nn_b (cnt3 != nullptr)
   int capM, capR;
   int df, max_iter;
@@ -106,7 +123,9 @@ struct IcpBufs {
   float* bounds;
   IcpState* state;
   Grid2 gr, ga, gm[2];
-  int32_t *nn_f, *nn_b;
+  int32_t *nn_f, *nn_b, *wl, *wls;
+  unsigned int* sstep;
+  float *bud_f, *bud_b;
   float* prev;
   long long* acc;
   double *Tb, *lsc;
@@ -144,14 +163,14 @@ struct IcpHint {
 // optional HIP-event timing of the three iteration kernels (bench.py's roofline): after the stream
 // has been synchronised, account the launches of the calling thread's last chunk
 constexpr int kIcpMaxChunk = 16;
-void icp_profile_account(int n_it, const int* live, const double* bytes3);
+void icp_profile_account(int n_it, const int* live, const double* bytes3, int prof_slot);
 // enqueue: reset + bounds + grid description + the three grids of every entry
 int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, hipStream_t s);
 // enqueue n_it iterations (entry e runs iterations kbase[e]+1 .. kbase[e]+n_it, gated by its stop
 // word and max_iter), then the stop rule of the last one; the states are mirrored to out[e] (may be
 // pinned host memory, may be nullptr)
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s);
+                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot);
 // enqueue: l1 error of the last iteration, coverage ratio, outputs
 int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
                        hipStream_t s);

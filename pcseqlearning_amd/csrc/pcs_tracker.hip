@@ -29,11 +29,16 @@
 #include "pcs.h"
 
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace pcs {
 
 constexpr int kMaxLevels = 4;
 constexpr int kWg = 1024;  // one-workgroup kernels (sort, compaction)
+constexpr int kMaxGroups = 8;  // lock-step groups (streams) one call may drive
 
 struct TrkState {
   int32_t active;     // any component still tracked (loop condition of the next step)
@@ -115,6 +120,55 @@ __device__ __forceinline__ int wg_excl_scan(int v, int* total, int* sh) {
   __syncthreads();
   *total = sh[kWg / 64];
   return sh[w] + incl - v;
+}
+
+// Stream compaction by one workgroup: the n items are cut into 16 contiguous wave slices; flag(i)
+// says whether item i is kept, emit(i, pos) receives its rank among the kept ones (ascending i).
+// Loads inside flag() of eight rounds are issued together. Returns the number kept (all threads).
+template <class FlagFn, class EmitFn>
+__device__ __forceinline__ int wg_compact(int n, FlagFn flag, EmitFn emit, int* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per_wave = ((n + kWg - 1) / kWg) * 64;
+  const int begin = w * per_wave;
+  const int end = begin + per_wave < n ? begin + per_wave : n;
+  constexpr int U = 8;
+  int cnt = 0;
+  for (int i0 = begin; i0 < end; i0 += 64 * U) {
+    bool f[U];
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      int i = i0 + r * 64 + lane;
+      f[r] = i < end && flag(i);
+    }
+#pragma unroll
+    for (int r = 0; r < U; ++r) cnt += __popcll(__ballot(f[r]));
+  }
+  __syncthreads();  // sh may still be read from a previous call
+  if (lane == 0) sh[w] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int q = 0; q < kWg / 64; ++q) { int t = sh[q]; sh[q] = run; run += t; }
+    sh[kWg / 64] = run;
+  }
+  __syncthreads();
+  const int total = sh[kWg / 64];
+  int run = sh[w];
+  for (int i0 = begin; i0 < end; i0 += 64 * U) {
+    bool f[U];
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      int i = i0 + r * 64 + lane;
+      f[r] = i < end && flag(i);
+    }
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      unsigned long long b = __ballot(f[r]);
+      if (f[r]) emit(i0 + r * 64 + lane, run + __popcll(b & ((1ULL << lane) - 1ULL)));
+      run += __popcll(b);
+    }
+  }
+  return total;
 }
 
 // Stable LSD radix sort of n (key, value) pairs by key bits [0, nbits), 8 bits per pass, by ONE
@@ -301,7 +355,7 @@ __global__ void trk_hdesc_kernel(const float* __restrict__ b8, float radius, flo
 // synchronisation only)
 __global__ void trk_publish_kernel(const UnitDev* __restrict__ U, Batch bt, TrkState* __restrict__ out) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < bt.n) out[e] = *U[bt.idx[e]].st;
+  if (e < bt.n) out[bt.idx[e]] = *U[bt.idx[e]].st;  // slot = unit index
 }
 
 // the anchor's own points: kept when their component passed filter_components (one workgroup per unit)
@@ -309,26 +363,18 @@ __global__ void __launch_bounds__(kWg)
 trk_anchor_emit_kernel(const UnitDev* __restrict__ U, Batch bt) {
   __shared__ int sh[kWg / 64 + 1];
   const UnitDev& u = U[bt.idx[blockIdx.x]];
-  const int n = u.na;
-  const int ch = (n + kWg - 1) / kWg;
-  const int b = threadIdx.x * ch, e = min(n, b + ch);
-  int cnt = 0;
-  for (int i = b; i < e; ++i) cnt += u.vcm[u.comp32[i]] ? 1 : 0;
-  int tot;
-  int pos = wg_excl_scan(cnt, &tot, sh);
-  for (int i = b; i < e; ++i) {
-    int c = u.comp32[i];
-    if (u.vcm[c]) {
-      if (pos < u.ex_cap) {
-        u.ex_index[pos] = u.off_a + i;
-        u.ex_local[pos] = i;
-        u.ex_comp[pos] = c;
-      } else {
-        u.st->err = 2;
-      }
-      ++pos;
-    }
-  }
+  int tot = wg_compact(
+      u.na, [&](int i) { return u.vcm[u.comp32[i]] != 0; },
+      [&](int i, int pos) {
+        if (pos < u.ex_cap) {
+          u.ex_index[pos] = u.off_a + i;
+          u.ex_local[pos] = i;
+          u.ex_comp[pos] = u.comp32[i];
+        } else {
+          u.st->err = 2;
+        }
+      },
+      sh);
   if (threadIdx.x == 0) u.st->ex_count = tot;
 }
 
@@ -410,16 +456,25 @@ smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls
     if (tid == 0) { *S.d_num = 0; S.seg[0] = 0; }
     return;
   }
-  // bounds
+  // bounds (eight rows requested together: the loop is a chain of memory round trips otherwise)
   {
     float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int i = tid; i < n; i += kWg) {
-      float4 p = pts[i];
-      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-      mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
+    for (int i0 = tid; i0 < n; i0 += kWg * 8) {
+      float4 q[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int i = i0 + r * kWg;
+        q[r] = pts[i < n ? i : i0];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float4 p = q[r];
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+        mn[3] = fminf(mn[3], p.w); mx[3] = fmaxf(mx[3], p.w);
+      }
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -446,27 +501,43 @@ smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls
   for (int d = 0; d < 4; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / sz[d]) + 1);
   int nbits = 1;
   while (nbits < 62 && (1LL << nbits) < stride[4]) ++nbits;
-  for (int i = tid; i < n; i += kWg) {
-    float4 p = pts[i];
-    int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
-                 (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
-    S.k0[i] = (uint64_t)id;
-    S.v0[i] = i;
+  for (int i0 = tid; i0 < n; i0 += kWg * 8) {
+    float4 q[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int i = i0 + r * kWg;
+      q[r] = pts[i < n ? i : i0];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int i = i0 + r * kWg;
+      if (i >= n) continue;
+      float4 p = q[r];
+      int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
+                   (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
+      S.k0[i] = (uint64_t)id;
+      S.v0[i] = i;
+    }
   }
   __syncthreads();
   int which = wg_radix_sort(S.k0, S.v0, S.k1, S.v1, n, nbits, hist, sh);
   const uint64_t* __restrict__ sk = which ? S.k1 : S.k0;
   const int32_t* __restrict__ sv = which ? S.v1 : S.v0;
   // voxel boundaries + the sorted order in its final place
-  const int ch = (n + kWg - 1) / kWg;
-  const int b = tid * ch, e = min(n, b + ch);
-  int heads = 0;
-  for (int i = b; i < e; ++i) heads += (i == 0 || sk[i] != sk[i - 1]) ? 1 : 0;
-  int tot;
-  int rank = wg_excl_scan(heads, &tot, sh);
-  for (int i = b; i < e; ++i) {
-    if (i == 0 || sk[i] != sk[i - 1]) S.seg[rank++] = i;
-    S.order[i] = sv[i];
+  int tot = wg_compact(
+      n, [&](int i) { return i == 0 || sk[i] != sk[i - 1]; }, [&](int i, int pos) { S.seg[pos] = i; }, sh);
+  for (int i0 = tid; i0 < n; i0 += kWg * 8) {
+    int32_t vv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int i = i0 + r * kWg;
+      vv[r] = sv[i < n ? i : i0];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int i = i0 + r * kWg;
+      if (i < n) S.order[i] = vv[r];
+    }
   }
   if (tid == 0) { S.seg[tot] = n; *S.d_num = tot; }
 }
@@ -574,19 +645,13 @@ smp_compact_kernel(const UnitDev* __restrict__ U, Batch bt) {
   const int set = blockIdx.x;
   const SmpSet& S = set ? u.sb : u.sa;
   const int v = (int)*S.d_num;
-  const int ch = (v + kWg - 1) / kWg;
-  const int b = threadIdx.x * ch, e = min(v, b + ch);
-  int cnt = 0;
-  for (int s = b; s < e; ++s) cnt += S.flag[s] ? 1 : 0;
-  int tot;
-  int pos = wg_excl_scan(cnt, &tot, sh);
-  for (int s = b; s < e; ++s) {
-    if (S.flag[s]) {
-      S.out[pos] = S.sub[s];
-      if (!set) S.out_comp[pos] = S.sub_comp[s];
-      ++pos;
-    }
-  }
+  int tot = wg_compact(
+      v, [&](int s) { return S.flag[s] != 0; },
+      [&](int s, int pos) {
+        S.out[pos] = S.sub[s];
+        if (!set) S.out_comp[pos] = S.sub_comp[s];
+      },
+      sh);
   if (threadIdx.x == 0) {
     u.st->counts[2 * set] = v;
     u.st->counts[2 * set + 1] = tot;
@@ -793,8 +858,10 @@ hv_search_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
     float4 p = valid ? qry[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
     int rr = g2_nearest_coop(d, u.hg, p, 0, valid, &u.st->err);
     if (valid && (threadIdx.x & 31) == 0) {
-      u.hv_deg[qid] = rr >= 0;
-      u.hv_nbr[qid] = rr;
+      // kept when the nearest moved anchor point belongs to a component that is still tracked
+      int c = rr >= 0 ? u.comp32[rr] : -1;
+      u.hv_deg[qid] = (c >= 0 && !u.stopped[c]) ? 1 : 0;
+      u.hv_nbr[qid] = c;
     }
   }
 }
@@ -808,30 +875,22 @@ hv_compact_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
   const StepArg a = sa.a[blockIdx.x];
   const int m = a.nn;
   if (m < 1) return;
-  const int ch = (m + kWg - 1) / kWg;
-  const int b = threadIdx.x * ch, e = min(m, b + ch);
-  int cnt = 0;
-  for (int q = b; q < e; ++q)
-    if (u.hv_deg[q] > 0 && !u.stopped[u.comp32[u.hv_nbr[q]]]) ++cnt;
-  int tot;
-  int64_t pos = u.st->ex_count + wg_excl_scan(cnt, &tot, sh);
-  for (int q = b; q < e; ++q) {
-    if (u.hv_deg[q] > 0) {
-      int c = u.comp32[u.hv_nbr[q]];
-      if (!u.stopped[c]) {
-        if (pos < u.ex_cap) {
-          u.ex_index[pos] = a.off_n + q;
-          u.ex_local[pos] = q;
-          u.ex_comp[pos] = c;
+  const int64_t base = u.st->ex_count;
+  int tot = wg_compact(
+      m, [&](int q) { return u.hv_deg[q] != 0; },
+      [&](int q, int pos) {
+        int64_t o = base + pos;
+        if (o < u.ex_cap) {
+          u.ex_index[o] = a.off_n + q;
+          u.ex_local[o] = q;
+          u.ex_comp[o] = u.hv_nbr[q];
         } else {
           u.st->err = 2;
         }
-        ++pos;
-      }
-    }
-  }
+      },
+      sh);
   __syncthreads();  // every thread has read ex_count
-  if (threadIdx.x == 0) u.st->ex_count += tot;
+  if (threadIdx.x == 0) u.st->ex_count = base + tot;
 }
 
 int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
@@ -950,6 +1009,61 @@ static inline int pow2_words(int64_t n) {
   return (int)h;
 }
 
+// Helper threads of a call: group 0 is driven by the caller, every further lock-step group by one of
+// these (kernels of different streams overlap on the device, but one host thread cannot issue the
+// launches of several groups fast enough). The threads live as long as the process: they keep their
+// stream, event and pinned status page from call to call.
+class GroupWorkers {
+ public:
+  static GroupWorkers& get() {
+    static GroupWorkers* inst = new GroupWorkers();  // never destroyed: the threads outlive main
+    return *inst;
+  }
+  void start(int slot, std::function<void()> job) {
+    W& w = w_[slot];
+    std::unique_lock<std::mutex> lk(w.mu);
+    if (!w.started) {
+      w.started = true;
+      std::thread([&w] {
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> lk2(w.mu);
+            w.cv.wait(lk2, [&] { return w.has_job; });
+            f = std::move(w.job);
+            w.has_job = false;
+          }
+          f();
+          {
+            std::lock_guard<std::mutex> lk2(w.mu);
+            w.done = true;
+          }
+          w.cv_done.notify_all();
+        }
+      }).detach();
+    }
+    w.job = std::move(job);
+    w.has_job = true;
+    w.done = false;
+    lk.unlock();
+    w.cv.notify_all();
+  }
+  void wait(int slot) {
+    W& w = w_[slot];
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv_done.wait(lk, [&] { return w.done; });
+  }
+
+ private:
+  struct W {
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::function<void()> job;
+    bool started = false, has_job = false, done = true;
+  };
+  W w_[kMaxGroups];
+};
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -993,7 +1107,8 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   Arena a(ws, ws_bytes);
   EnginePlan eng;
   if (!plan_engine(a, eng)) return PCS_ERR_WORKSPACE;
-  static thread_local HostUnit hu[kMaxBatch];
+  static thread_local HostUnit hu_store[kMaxBatch];
+  HostUnit* const hu = hu_store;  // (the helper threads must see the CALLER's array, not their own)
   const int64_t n_seq = frame_offsets[num_frames];
   for (int i = 0; i < n_units; ++i) {
     PcsTrackUnit& io = units[i];
@@ -1117,13 +1232,57 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     hu[i].any_valid = hu[i].host.active != 0;
   }
 
-  // ---- the lock-step loop
+  // ---- the lock-step loop. The units are cut into a few GROUPS; a group advances in lock-step on
+  // its own stream (every launch serves all its units), and the one host thread keeps every group's
+  // next tick enqueued: while it waits for group A's state words, the ticks of groups B, C, ... run,
+  // so the single-workgroup phases of one group (sort, smooth_velo, compaction) hide behind the ICP
+  // iterations of the others.
   static const int chunk_env = [] {
     const char* e = getenv("PCS_TRACK_CHUNK");
     int c = e ? atoi(e) : 0;
     return (c >= 1 && c <= kIcpMaxChunk) ? c : 8;
   }();
+  static const int groups_env = [] {
+    const char* e = getenv("PCS_TRACK_GROUPS");
+    int c = e ? atoi(e) : 0;
+    return (c >= 1 && c <= kMaxGroups) ? c : 4;
+  }();
   const int chunk = chunk_env;
+  // rocprofiler-sdk on this image faults when kernels are launched from several native threads at
+  // once: a profiled run takes one group (same kernels, same results)
+  static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+  const int G = profiled ? 1 : (groups_env < n_units ? groups_env : n_units);
+  struct Group {
+    int n, base, live;
+    int unit[kMaxBatch];
+    bool inflight;
+    Batch all, b_iter, b_fin;
+    int64_t ticks;
+    // owned by the thread that drives the group
+    hipStream_t st;
+    hipEvent_t ev;
+    IcpState *pin_icp, *pin_fin;
+    TrkState* pin_trk;
+    IcpProblem* stage_icp;
+    int rc;
+  };
+  Group grp[kMaxGroups];
+  for (int g = 0; g < G; ++g) {
+    grp[g].n = 0;
+    grp[g].inflight = false;
+    grp[g].ticks = 0;
+    grp[g].b_iter.n = grp[g].b_fin.n = 0;
+  }
+  for (int i = 0; i < n_units; ++i) {
+    Group& g = grp[(int64_t)i * G / n_units];
+    if (g.n == 0) g.base = i;
+    g.unit[g.n++] = i;
+  }
+  for (int g = 0; g < G; ++g) {
+    grp[g].live = grp[g].n;
+    grp[g].all.n = grp[g].n;
+    for (int e = 0; e < grp[g].n; ++e) grp[g].all.idx[e] = grp[g].unit[e];
+  }
   LevelSizes ls;
   for (int l = 0; l < kMaxLevels; ++l)
     for (int k = 0; k < 3; ++k) ls.v[l][k] = l < L ? prm->voxel_size[l][k] : 1.f;
@@ -1139,10 +1298,12 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     a.nn = in_range(h, h.next) ? (int)(frame_offsets[h.next + 1] - frame_offsets[h.next]) : 0;
     return a;
   };
-  int live = n_units;
-  int64_t ticks = 0;
-  while (live > 0) {
-    ++ticks;
+
+  // decide every unit's next phase from the state words read last, enqueue the group's next tick
+  auto enqueue_tick = [&](int gi) -> int {
+    Group& gr = grp[gi];
+    hipStream_t gs = gr.st;
+    ++gr.ticks;
     Batch b_fin, b_post, b_dir, b_step, b_smp, b_begin, b_iter;
     Steps s_fin, s_post, s_step, s_smp;
     b_fin.n = b_post.n = b_dir.n = b_step.n = b_smp.n = b_begin.n = b_iter.n = 0;
@@ -1174,7 +1335,8 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
       h.last_col = (dir == 1 && h.anchor > 0) ? h.anchor : -1;
       return in_range(h, h.next) && h.any_valid;
     };
-    for (int i = 0; i < n_units; ++i) {
+    for (int e = 0; e < gr.n; ++e) {
+      const int i = gr.unit[e];
       HostUnit& h = hu[i];
       switch (h.phase) {
         case PH_START: {
@@ -1226,22 +1388,24 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           h.io->info[0] = h.host.ex_count;
           h.io->info[1] = h.reg_calls;
           h.io->info[2] = h.steps;
-          h.io->info[3] = ticks;
+          h.io->info[3] = gr.ticks;
           h.phase = PH_DONE;
-          --live;
+          --gr.live;
           break;
         }
         default:
           break;
       }
     }
-    if (live == 0) break;
+    gr.b_fin = b_fin;
+    gr.b_iter.n = 0;
+    if (gr.live == 0) return PCS_OK;
     // ---- 1. registrations that stopped: l1 error, coverage, outputs; then frame <- T frame
     if (b_fin.n) {
-      TRK_RC(icp_enqueue_finish(eng.d_icp, b_fin, h_fin, pin_fin, s));
+      TRK_RC(icp_enqueue_finish(eng.d_icp, b_fin, h_fin, gr.pin_fin, gs));
       int g = 1;
       for (int e = 0; e < b_fin.n; ++e) g = max(g, nblk(max(hu[b_fin.idx[e]].na, hu[b_fin.idx[e]].C)));
-      trk_apply_T_kernel<<<dim3(g, b_fin.n), kBlock, 0, s>>>(eng.d_units, b_fin, s_fin);
+      trk_apply_T_kernel<<<dim3(g, b_fin.n), kBlock, 0, gs>>>(eng.d_units, b_fin, s_fin);
     }
     // ---- 2. after the last level: component motion, velocity smoothing, stop rules, harvest
     if (b_post.n) {
@@ -1275,27 +1439,27 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
       }
       if (gc > 2048) gc = 2048;
       if (gq > 8192) gq = 8192;
-      trk_motion_kernel<<<dim3(gc, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
+      trk_motion_kernel<<<dim3(gc, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
       TRK_RC(smooth_velo_run_batch(nsv, sv_v, sv_d, sv_C, sv_F, sv_lo, sv_hi, prm->smooth_weight0,
                                    prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping, sv_ws,
-                                   sv_wsb, sv_err, s));
-      trk_after_smooth_kernel<<<dim3(gp, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post,
-                                                                    prm->min_move_frame, prm->reg_error_coeff,
-                                                                    prm->angle_threshold);
-      hv_insert_kernel<<<dim3(gp, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
-      hv_search_kernel<<<dim3(gq, b_post.n), kBlock, 0, s>>>(eng.d_units, b_post, s_post);
-      hv_compact_kernel<<<b_post.n, kWg, 0, s>>>(eng.d_units, b_post, s_post);
+                                   sv_wsb, sv_err, gs));
+      trk_after_smooth_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post,
+                                                                     prm->min_move_frame, prm->reg_error_coeff,
+                                                                     prm->angle_threshold);
+      hv_insert_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
+      hv_search_kernel<<<dim3(gq, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
+      hv_compact_kernel<<<b_post.n, kWg, 0, gs>>>(eng.d_units, b_post, s_post);
     }
     // ---- 3. direction / step set-up
     if (b_dir.n) {
       int g = 1;
       for (int e = 0; e < b_dir.n; ++e) g = max(g, nblk(max(hu[b_dir.idx[e]].na, hu[b_dir.idx[e]].C)));
-      trk_dir_init_kernel<<<dim3(g, b_dir.n), kBlock, 0, s>>>(eng.d_units, b_dir);
+      trk_dir_init_kernel<<<dim3(g, b_dir.n), kBlock, 0, gs>>>(eng.d_units, b_dir);
     }
     if (b_step.n) {
       int g = 1;
       for (int e = 0; e < b_step.n; ++e) g = max(g, nblk(max(hu[b_step.idx[e]].na, hu[b_step.idx[e]].C)));
-      trk_step_begin_kernel<<<dim3(g, b_step.n), kBlock, 0, s>>>(eng.d_units, b_step, s_step);
+      trk_step_begin_kernel<<<dim3(g, b_step.n), kBlock, 0, gs>>>(eng.d_units, b_step, s_step);
     }
     // ---- 4. sampling of the anchor (as moved so far) and of the target frame
     if (b_smp.n) {
@@ -1305,9 +1469,9 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         int est = h.seen[h.lv][1] > 0 ? (int)(h.seen[h.lv][1] * 1.25) : max(h.na, h.nm) / 2;
         gv = max(gv, nblk(est));
       }
-      smp_sort_kernel<<<dim3(2, b_smp.n), kWg, 0, s>>>(eng.d_units, b_smp, s_smp, ls);
-      smp_emit_kernel<<<dim3(gv, b_smp.n, 2), kBlock, 0, s>>>(eng.d_units, b_smp, s_smp);
-      smp_compact_kernel<<<dim3(2, b_smp.n), kWg, 0, s>>>(eng.d_units, b_smp);
+      smp_sort_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(eng.d_units, b_smp, s_smp, ls);
+      smp_emit_kernel<<<dim3(gv, b_smp.n, 2), kBlock, 0, gs>>>(eng.d_units, b_smp, s_smp);
+      smp_compact_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(eng.d_units, b_smp);
     }
     // ---- 5. registrations that start: descriptor, reset, grids
     if (b_begin.n) {
@@ -1335,8 +1499,8 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         ia.T = d.Tl;
         ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
         ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
-        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &stage_icp[i]));
-        PCS_CHECK_HIP(hipMemcpyAsync(eng.d_icp + i, &stage_icp[i], sizeof(IcpProblem), hipMemcpyHostToDevice, s));
+        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &gr.stage_icp[i]));
+        PCS_CHECK_HIP(hipMemcpyAsync(eng.d_icp + i, &gr.stage_icp[i], sizeof(IcpProblem), hipMemcpyHostToDevice, gs));
         // launch sizes: what this level had at the previous step, else a guess
         const int* sn = h.seen[h.lv];
         h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
@@ -1347,10 +1511,11 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
                              2 * (size_t)pow2_words(h.hint.Ra);
         h_begin[e] = h.hint;
       }
-      TRK_RC(icp_enqueue_begin(eng.d_icp, b_begin, h_begin, s));
+      TRK_RC(icp_enqueue_begin(eng.d_icp, b_begin, h_begin, gs));
     }
-    // ---- 6. one chunk of iterations for every unit that is registering
-    for (int i = 0; i < n_units; ++i) {
+    // ---- 6. one chunk of iterations for every unit of the group that is registering
+    for (int e = 0; e < gr.n; ++e) {
+      const int i = gr.unit[e];
       HostUnit& h = hu[i];
       if (h.phase != PH_ICP) continue;
       kb.v[b_iter.n] = h.it;
@@ -1358,36 +1523,45 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
       b_iter.idx[b_iter.n++] = i;
     }
     if (b_iter.n) {
-      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, pin_icp, s));
+      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0));
       for (int e = 0; e < b_iter.n; ++e) {
         HostUnit& h = hu[b_iter.idx[e]];
         h.it_before = h.it;
         h.it = min(h.it + chunk, prm->max_iter);
       }
     }
-    // ---- 7. state mirror, one synchronisation
-    trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+    gr.b_iter = b_iter;
+    // ---- 7. state mirror; the event tells the host when the tick's words can be read
+    trk_publish_kernel<<<1, 64, 0, gs>>>(eng.d_units, gr.all, gr.pin_trk);
     PCS_LAUNCH_CHECK();
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
-    for (int e = 0; e < b_fin.n; ++e)
-      if (pin_fin[e].err) return PCS_ERR_RANGE;  // the coverage query can still overflow a grid
-    for (int i = 0; i < n_units; ++i) {
-      HostUnit& h = hu[i];
+    PCS_CHECK_HIP(hipEventRecord(gr.ev, gs));
+    gr.inflight = true;
+    return PCS_OK;
+  };
+
+  // the group's tick has completed: take its state words
+  auto collect_tick = [&](int gi) -> int {
+    Group& gr = grp[gi];
+    gr.inflight = false;
+    for (int e = 0; e < gr.b_fin.n; ++e)
+      if (gr.pin_fin[e].err) return PCS_ERR_RANGE;  // the coverage query can still overflow a grid
+    for (int e = 0; e < gr.n; ++e) {
+      HostUnit& h = hu[gr.unit[e]];
       if (h.phase == PH_DONE) continue;
-      h.host = pin_trk[i];
+      h.host = gr.pin_trk[gr.unit[e]];
       if (h.phase == PH_ICP) {
         h.seen[h.lv][0] = (int)h.host.counts[1];
         h.seen[h.lv][1] = (int)h.host.counts[2];
         h.seen[h.lv][2] = (int)h.host.counts[3];
       }
     }
-    if (b_iter.n) {
+    if (gr.b_iter.n) {
       int live_j[kIcpMaxChunk];
       double b3[3 * kIcpMaxChunk];
       for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
-      for (int e = 0; e < b_iter.n; ++e) {
-        HostUnit& h = hu[b_iter.idx[e]];
-        h.icp = pin_icp[e];
+      for (int e = 0; e < gr.b_iter.n; ++e) {
+        HostUnit& h = hu[gr.b_iter.idx[e]];
+        h.icp = gr.pin_icp[e];
         const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
         for (int j = 0; j < chunk; ++j) {
           if (h.it_before + 1 + j > h.icp.iters) break;
@@ -1397,9 +1571,49 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
         }
       }
-      icp_profile_account(chunk, live_j, b3);
+      icp_profile_account(chunk, live_j, b3, 0);
     }
-  }
+    return PCS_OK;
+  };
+
+  // one thread per group: the group's own stream, event and pinned status page
+  int device = 0;
+  PCS_CHECK_HIP(hipGetDevice(&device));
+  auto drive = [&](int gi) {
+    Group& gr = grp[gi];
+    gr.rc = PCS_OK;
+    static thread_local hipStream_t t_stream = nullptr;
+    static thread_local hipEvent_t t_event = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { gr.rc = PCS_ERR_HIP; return; }
+    if (!t_stream) {
+      if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&t_event, hipEventDisableTiming) != hipSuccess) {
+        gr.rc = PCS_ERR_HIP;
+        return;
+      }
+    }
+    char* pg = (char*)thread_pinned_page();
+    if (!pg) { gr.rc = PCS_ERR_HIP; return; }
+    gr.st = t_stream;
+    gr.ev = t_event;
+    gr.pin_icp = (IcpState*)pg;
+    gr.pin_fin = (IcpState*)(pg + 2048);
+    gr.pin_trk = (TrkState*)(pg + kPinnedTrackerOff);
+    gr.stage_icp = (IcpProblem*)(pg + kPinnedStageOff + kMaxBatch * sizeof(UnitDev));
+    int rc = enqueue_tick(gi);
+    while (rc == PCS_OK && gr.inflight) {
+      if (hipEventSynchronize(gr.ev) != hipSuccess) { rc = PCS_ERR_HIP; break; }
+      rc = collect_tick(gi);
+      if (rc == PCS_OK && gr.live > 0) rc = enqueue_tick(gi);
+    }
+    (void)hipStreamSynchronize(gr.st);  // nothing may still run on the workspace when the call returns
+    gr.rc = rc;
+  };
+  for (int g = 1; g < G; ++g) GroupWorkers::get().start(g, [&drive, g] { drive(g); });
+  drive(0);
+  for (int g = 1; g < G; ++g) GroupWorkers::get().wait(g);
+  for (int g = 0; g < G; ++g)
+    if (grp[g].rc) return grp[g].rc;
   return PCS_OK;
 }
 
