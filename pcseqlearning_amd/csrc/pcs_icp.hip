@@ -298,6 +298,119 @@ icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase,
   if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;
 }
 
+// ---- raw moments of the matched pairs per component (n, sum p, sum q, sum p(x)q, sum |p-q|^2),
+// added by whichever kernel settles a query's neighbour: the budget test for the cached ones, the
+// search kernel for the rest -- no launch of their own. Each workgroup first accumulates into a small
+// LDS table keyed by component (64-bit integer LDS adds; neighbouring queries mostly share a
+// component), then flushes one global integer atomic per (component, accumulator). Integer sums:
+// the result does not depend on any arrival order.
+constexpr int kMomSlots = 64;
+struct MomTable {
+  int* skey;                      // LDS [kMomSlots]
+  unsigned long long* sacc;       // LDS [kMomSlots * 17]
+  unsigned long long* acc;        // global [C, kAcc] of the iteration
+};
+__device__ __forceinline__ void mom_init(const MomTable& t) {  // every thread of the workgroup; then a barrier
+  for (int q = threadIdx.x; q < kMomSlots; q += kBlock) t.skey[q] = -1;
+  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) t.sacc[q] = 0ULL;
+}
+// the pair (moving point pf of component c, reference point qf)
+__device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
+                                        double lim2) {
+  const float4 og = pr.corg[c];
+  double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
+  double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
+  if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
+    pr.st->err = 1;  // a component too large for the fixed-point range
+  unsigned long long v[17];
+  v[0] = 1ULL;
+  double d2 = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    v[1 + a] = (unsigned long long)to_fx(p[a]);
+    v[4 + a] = (unsigned long long)to_fx(q[a]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = (unsigned long long)to_fx(p[a] * q[b]);
+    double e = p[a] - q[a];
+    d2 += e * e;
+  }
+  v[16] = (unsigned long long)to_fx(d2);
+  // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
+  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
+  int found = -1;
+  for (int i = 0; i < kMomSlots; ++i) {
+    int old = atomicCAS(&t.skey[slot], -1, c);
+    if (old == -1 || old == c) { found = slot; break; }
+    slot = (slot + 1) & (kMomSlots - 1);
+  }
+  if (found >= 0) {
+#pragma unroll
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.sacc[found * 17 + q2], v[q2]);
+  } else {
+#pragma unroll
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)c * kAcc + q2], v[q2]);
+  }
+}
+// The same for a whole wave (every lane calls; `active` lanes hold a pair). Neighbouring queries
+// mostly belong to one component: when all active lanes agree on it their terms are summed by
+// shuffles first and ONE lane adds the 17 totals (otherwise 64 lanes queue up on the same 17 words).
+__device__ __forceinline__ void mom_add_wave(const IcpProblem& pr, const MomTable& t, bool active, float4 pf,
+                                             float4 qf, int c, double lim2) {
+  const unsigned long long am = __ballot(active);
+  if (am == 0) return;
+  const int leader = __ffsll((long long)am) - 1;
+  const int c0 = __shfl(c, leader, 64);
+  const bool uniform = __ballot(active && c != c0) == 0 && __popcll(am) >= 8;
+  if (!uniform) {
+    if (active) mom_add(pr, t, pf, qf, c, lim2);
+    return;
+  }
+  const float4 og = pr.corg[c0];
+  long long v[17];
+#pragma unroll
+  for (int q = 0; q < 17; ++q) v[q] = 0;
+  if (active) {
+    double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
+    double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
+    if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
+      pr.st->err = 1;  // a component too large for the fixed-point range
+    v[0] = 1;
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v[1 + a] = to_fx(p[a]);
+      v[4 + a] = to_fx(q[a]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = to_fx(p[a] * q[b]);
+      double e = p[a] - q[a];
+      d2 += e * e;
+    }
+    v[16] = to_fx(d2);
+  }
+#pragma unroll
+  for (int q = 0; q < 17; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+  }
+  // lanes 0..16 add one total each
+  const int lane = threadIdx.x & 63;
+  if (lane < 17) {
+    long long mine = v[0];
+#pragma unroll
+    for (int q = 1; q < 17; ++q)
+      if (lane == q) mine = v[q];
+    atomicAdd(&t.acc[(int64_t)c0 * kAcc + lane], (unsigned long long)mine);
+  }
+}
+
+__device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barrier; every thread
+  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
+    int sl = q / 17, a = q - sl * 17;
+    int key = t.skey[sl];
+    if (key >= 0) atomicAdd(&t.acc[(int64_t)key * kAcc + a], t.sacc[q]);
+  }
+}
+
 // Queries [0,Mn): forward (moving -> reference, df = +frame_offset); queries [Mn, Mn+Rn): backward
 // (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED CACHE: every search also
 // returns how far things may move before its answer can change (half the gap to the runner-up, or
@@ -332,6 +445,12 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
     if (blockIdx.x == 0 && threadIdx.x == 0) st->wl_n = nq;
     return;
   }
+  __shared__ int skey[kMomSlots];
+  __shared__ unsigned long long sacc[kMomSlots * 17];
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc};
+  const double lim2 = icp_limit_sq(nq);
+  mom_init(mt);
+  __syncthreads();
   GridDesc g = pr.geom->g;
   const int lane = threadIdx.x & 63;
   int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
@@ -350,6 +469,9 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
     bool to_seeded = false, to_coop = false;
+    bool m_act = false;  // a settled pair whose moments are due: (moving point, reference point, component)
+    float4 m_p = make_float4(0.f, 0.f, 0.f, 0.f), m_q = m_p;
+    int m_c = 0;
     if (valid) {
       float4 p, sp = make_float4(0.f, 0.f, 0.f, 0.f);
       int s;
@@ -397,12 +519,19 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
         }
         if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
         else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+        if (res >= 0) {  // the pair's moments (forward: this moving point; backward: the partner)
+          m_act = true;
+          m_p = fwd ? p : sp;
+          m_q = fwd ? sp : p;
+          m_c = pr.comp[fwd ? qid : s];
+        }
       } else if (s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
         to_seeded = true;
       } else {
         to_coop = true;
       }
     }
+    mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
     const unsigned long long ms = __ballot(to_seeded), mc = __ballot(to_coop);
     if (ms) {
       int base = 0;
@@ -417,6 +546,8 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
       if (to_coop) pr.wl[base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
     }
   }
+  __syncthreads();
+  mom_flush(mt);
 }
 
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
@@ -438,6 +569,12 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
   float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
   float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  __shared__ int skey[kMomSlots];
+  __shared__ unsigned long long sacc[kMomSlots * 17];
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc};
+  const double lim2 = icp_limit_sq(Mn + Rn);
+  mom_init(mt);
+  __syncthreads();
   if (coop) {
     const int sub = threadIdx.x & 31;
     for (int r = blockIdx.x; r < nround; r += gridDim.x) {
@@ -465,8 +602,14 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
       if (valid && sub == 0) {
         if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
         else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+        if (res >= 0) {
+          if (fwd) mom_add(pr, mt, p, pr.ref[res], pr.comp[qid], lim2);
+          else mom_add(pr, mt, pr.mov[res], p, pr.comp[res], lim2);
+        }
       }
     }
+    __syncthreads();
+    mom_flush(mt);
     return;
   }
   const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
@@ -502,88 +645,14 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
       if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
       if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
       else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+      if (res >= 0) {
+        if (fwd) mom_add(pr, mt, p, pr.ref[res], pr.comp[qid], lim2);
+        else mom_add(pr, mt, pr.mov[res], p, pr.comp[res], lim2);
+      }
     }
   }
-}
-
-// raw moments of the matched pairs per component, one thread per potential edge. Each workgroup
-// first accumulates into a small LDS table keyed by component (64-bit integer LDS adds; neighbouring
-// edges mostly share a component), then flushes one global integer atomic per (component,
-// accumulator). Integer sums: the result does not depend on any arrival order.
-constexpr int kMomSlots = 64;
-__global__ void __launch_bounds__(kBlock)
-icp_moments_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
-  if (k > pr.max_iter || k > pr.st->stop_iter) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
-  const int ne = Mn + Rn;
-  const int nround = (ne + kBlock - 1) / kBlock;
-  if ((int)blockIdx.x >= nround) return;
-  const float4* __restrict__ mov = pr.mov;
-  const float4* __restrict__ ref = pr.ref;
-  const int32_t* __restrict__ comp = pr.comp;
-  const int32_t* __restrict__ nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
-  const int32_t* __restrict__ nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
-  unsigned long long* __restrict__ acc = (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc;
-  const double lim2 = icp_limit_sq(ne);
-  __shared__ int skey[kMomSlots];
-  __shared__ unsigned long long sacc[kMomSlots][17];
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
-    for (int q = threadIdx.x; q < kMomSlots; q += kBlock) skey[q] = -1;
-    for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) (&sacc[0][0])[q] = 0ULL;
-    __syncthreads();
-    int i = r * kBlock + threadIdx.x;
-    bool active = false;
-    int c = 0, m = -1, rr = -1;
-    if (i < Mn) { m = i; rr = nn_f[i]; active = rr >= 0; }
-    else if (i < ne) { rr = i - Mn; m = nn_b[rr]; active = m >= 0; }
-    if (active) {
-      float4 pf = mov[m], qf = ref[rr];
-      c = comp[m];
-      const float4 og = pr.corg[c];
-      double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
-      double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
-      if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
-        pr.st->err = 1;  // a component too large for the fixed-point range
-      unsigned long long v[17];
-      v[0] = 1ULL;
-      double d2 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        v[1 + a] = (unsigned long long)to_fx(p[a]);
-        v[4 + a] = (unsigned long long)to_fx(q[a]);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = (unsigned long long)to_fx(p[a] * q[b]);
-        double e = p[a] - q[a];
-        d2 += e * e;
-      }
-      v[16] = (unsigned long long)to_fx(d2);
-      // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
-      int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
-      int found = -1;
-      for (int t = 0; t < kMomSlots; ++t) {
-        int old = atomicCAS(&skey[slot], -1, c);
-        if (old == -1 || old == c) { found = slot; break; }
-        slot = (slot + 1) & (kMomSlots - 1);
-      }
-      if (found >= 0) {
-#pragma unroll
-        for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&sacc[found][q2], v[q2]);
-      } else {
-#pragma unroll
-        for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&acc[(int64_t)c * kAcc + q2], v[q2]);
-      }
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
-      int sl = q / 17, a = q - sl * 17;
-      int key = skey[sl];
-      if (key >= 0) atomicAdd(&acc[(int64_t)key * kAcc + a], sacc[sl][a]);
-    }
-    __syncthreads();
-  }
+  __syncthreads();
+  mom_flush(mt);
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151);
@@ -1006,7 +1075,6 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
   const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
   const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
-  const int nb_e = gx_for(q, kBlock, 4096);
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on && n_it <= kProfChunk;
   if (prof && !t_ev.have) {
@@ -1024,14 +1092,11 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 2), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
-      hipExtLaunchKernelGGL(icp_moments_kernel, dim3(nb_e, bt.n), dim3(kBlock), 0, s, e[2], e[3], 0, tab, bt,
-                            kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
       icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_nn_search_kernel<<<dim3(nb_c, bt.n, 2), kBlock, 0, s>>>(tab, bt, kbase, j);
-      icp_moments_kernel<<<dim3(nb_e, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }

@@ -28,6 +28,7 @@
 
 #include "pcs.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <condition_variable>
 #include <functional>
@@ -1273,10 +1274,21 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     grp[g].ticks = 0;
     grp[g].b_iter.n = grp[g].b_fin.n = 0;
   }
-  for (int i = 0; i < n_units; ++i) {
-    Group& g = grp[(int64_t)i * G / n_units];
-    if (g.n == 0) g.base = i;
-    g.unit[g.n++] = i;
+  {
+    // groups = runs of the caller's unit order (keys outermost: a group then holds units of like
+    // size); PCS_TRACK_GROUP_BY_SPAN=1 orders by window length first (measured: 216 ms against 192)
+    int order[kMaxBatch];
+    for (int i = 0; i < n_units; ++i) order[i] = i;
+    static const bool by_span = [] { const char* e = getenv("PCS_TRACK_GROUP_BY_SPAN"); return e && atoi(e) != 0; }();
+    if (by_span)
+      std::stable_sort(order, order + n_units, [&](int a, int b) {
+        return hu[a].max_f - hu[a].min_f > hu[b].max_f - hu[b].min_f;
+      });
+    for (int q = 0; q < n_units; ++q) {
+      Group& g = grp[(int64_t)q * G / n_units];
+      if (g.n == 0) g.base = order[q];
+      g.unit[g.n++] = order[q];
+    }
   }
   for (int g = 0; g < G; ++g) {
     grp[g].live = grp[g].n;
