@@ -1,46 +1,80 @@
 """bench.py -- end-to-end cluster-tracking throughput on synthetic Waymo-shaped sequences.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[2]: a 20-frame x 160k-pt sequence through the reference's
 cluster_tracking_TLS_multiradius_every8 pipeline (8 cm subsample -> GroundPlaneRemover ->
 ClusterProposal at 3 radii -> ClusterTracking: 3 keys x anchors {0, 8, 16} x +-8 frames x 3 ICP
 levels), one sequence per GPU per step, inputs resident in HBM before the timed region, nothing
-written to disk. N GPUs process N different sequences (weak scaling); the only collective is the
-final all-reduce of {max wall time, sequences done} over RCCL.
+written to disk. N GPUs process N different sequences (sequence s -> rank s mod N, weak scaling);
+the only collective is the final all-reduce of the metric vector over RCCL.
+
+With N > 1 and no launcher in the environment, this script starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ...` as a CHILD process, before anything
+touches the GPU); started by a launcher it checks WORLD_SIZE against --gpus. `--backend gloo
+--dry-run` runs the same rank / sequence assignment and the same reduction on CPU tensors without
+a GPU (tests/test_distributed.py).
 
 Rank 0 prints ONE JSON line: whole-job sequences/s plus
-  roofline      dominant kernel of the tracking stage (icp_nn_kernel: two-direction 1-NN
-                search of the fused ICP), timed with HIP events on its launch
-                stream inside the timed steps; achieved = algorithmic bytes / kernel time.
-  cpu_baseline  the CPU oracle (serial numpy/C++ restatement, kind "port") timed on a bounded
-                sample of the same sequence and scaled to sequences/s (rank 0, N = 1 only).
+  roofline      dominant kernels of the tracking stage (the fused ICP's neighbour kernels, which
+                also accumulate the moments): HIP events on their launch stream inside the timed
+                steps; achieved = algorithmic bytes / kernel time. `stages` lists the other stages
+                (one extra, untimed, device-synchronised step).
+  cpu_baseline  the CPU oracle (C++ restatement, kind "port"), serial and OpenMP over the host's
+                cores, timed on a bounded sample of the same sequence and scaled to sequences/s
+                (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pcseqlearning_amd import lib as L  # noqa: E402
-from pcseqlearning_amd import synthetic  # noqa: E402
-from pcseqlearning_amd.pcdet import models  # noqa: E402
-from pcseqlearning_amd.pcdet.utils import timer  # noqa: E402
-from tools.run_sequence import build_model  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+# ---------------------------------------------------------------------------------- distribution
+def sequences_of_rank(rank, world, steps):
+    """Synthetic-sequence seeds a rank processes: sequence s -> rank s mod world (the reference's
+    DistributedSampler striding, pcdet/datasets/__init__.py:61-64); one sequence per step."""
+    return [rank + world * k for k in range(steps)]
+
+
+def reduce_metrics(dist, device, seconds, values):
+    """The job's metric vector: wall time = MAX over ranks, everything else = SUM over ranks.
+    `values`: list of floats (sequences done, points in, ...). Returns (seconds, values)."""
+    import torch
+    if dist is None:
+        return float(seconds), [float(v) for v in values]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    v = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in v.tolist()]
+
+
+def spawn_ranks(args):
+    """Start the N ranks as a child job and pass its output / exit code through. Nothing in this
+    process has touched the GPU yet (no torch.cuda call), and the child is a fresh process: a
+    process that initialised the GPU is never re-exec'ed."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------- workload
 def load_sequence(seed, frames, points):
     """Synthetic sequence, cached under /tmp (generation is ~2 s of numpy ray casting per frame)."""
     import pickle
+    from pcseqlearning_amd import synthetic
     path = f"/tmp/pcs_seq_s{seed}_f{frames}_p{points}.pkl"
     if os.path.exists(path):
         with open(path, "rb") as f:
@@ -61,14 +95,28 @@ def baseline_metric():
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f)["metric"]
     except (OSError, KeyError, ValueError):
-        return "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking, 1\u21928 MI355X + HBM-roofline %"
+        return "Waymo sequences/s (20-frame, 160k-pt) cluster-tracking, 1→8 MI355X + HBM-roofline %"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(batch, out, n_reg_calls):
-    """Oracle timed on: 8 cm subsample of the whole sequence, one 10-frame proposal chunk at
-    r = 0.25, and the 3 ICP levels of ONE anchor->next-frame pair; scaled by the number of such
-    units the GPU run executed. Ground removal has no CPU oracle (its third-party leaves are
-    unpinned) and is left out of the CPU estimate, which therefore flatters the CPU."""
+    """The C++ oracle timed on a bounded sample of this sequence, once on ONE core and once with
+    OpenMP over all cores: the 8 cm subsample of the whole sequence, one 10-frame proposal chunk
+    (32-NN radius graph + components at r = 0.25), and -- the bulk of the job -- the registrations
+    of anchor frame 8 against frames 7 and 9 for all three component keys and all three levels
+    (18 of the sequence's ~315 register_to_next_frame calls). Scaled by the call counts of the GPU
+    run. Ground removal has no CPU oracle and is left out, which flatters the CPU."""
+    import numpy as np
     from oracle import oracle as O
     from oracle import reg_oracle as R
     from oracle import track_oracle as T
@@ -79,56 +127,148 @@ def cpu_baseline(batch, out, n_reg_calls):
     t_sub = time.perf_counter() - t0
     pts = out["point_fxyz"].cpu().numpy()
     frame = pts[:, 0].astype(np.int64)
-    comp = out["point_component_rad0x25"].cpu().numpy()
-    # one proposal chunk (10 frames) at the finest radius, 32-NN graph + components
     m = frame < 10
+    n_prop = min(int(m.sum()), 60000)
     t0 = time.perf_counter()
-    e0, e1 = O.radius_graph(pts[m][:60000], pts[m][:60000], 0.25, 32, True)
-    O.connected_components(e0, e1, min(int(m.sum()), 60000))
-    t_prop = (time.perf_counter() - t0) * (m.sum() / min(int(m.sum()), 60000))
-    # one frame pair, 3 levels
-    diam = T.component_diameter(pts, comp, int(comp.max()) + 1)
-    stat = diam[comp] > 12.5
-    f0 = dict(fxyz=pts[frame == 0].copy(), component=comp[frame == 0] - comp[frame == 0].min(),
-              stationary=stat[frame == 0], frame=frame[frame == 0])
-    f1 = dict(fxyz=pts[frame == 1], component=comp[frame == 1], stationary=stat[frame == 1], frame=frame[frame == 1])
-    C = int(f0["component"].max()) + 1
-    t0 = time.perf_counter()
-    for radius, vs in ((2.5, (0.4, 0.4, 0.6)), (1.25, (0.2, 0.2, 0.3)), (1.0, (0.1, 0.1, 0.15))):
-        a, b = T.sample_frame(vs, f0), T.sample_frame(vs, f1)
-        R.register_to_next_frame(R.Graph(radius), a, b, C, 10.0, 80, 0.05)
-    t_pair = time.perf_counter() - t0
-    n_pairs = n_reg_calls / 3.0
-    est = t_sub + t_prop * 2 * 3 + t_pair * n_pairs  # 2 chunks x 3 radii (coarser radii cost more)
-    return {"value": round(1.0 / est, 6), "unit": "sequences/s", "cores": 1, "kind": "port",
-            "sample": (f"oracle timed {time.perf_counter() - t_all:.1f}s on: 8cm subsample ({t_sub:.1f}s), one "
-                       f"10-frame r=0.25 proposal chunk ({t_prop:.1f}s, x6), one frame pair x 3 ICP levels "
-                       f"({t_pair:.1f}s, x{n_pairs:.0f} pairs); ground removal excluded; scaled to one sequence")}
+    e0, e1 = O.radius_graph(pts[m][:n_prop], pts[m][:n_prop], 0.25, 32, True)
+    O.connected_components(e0, e1, n_prop)
+    t_prop = (time.perf_counter() - t0) * (m.sum() / n_prop)
+    levels = ((2.5, (0.4, 0.4, 0.6)), (1.25, (0.2, 0.2, 0.3)), (1.0, (0.1, 0.1, 0.15)))
+    threads_all = R.cpu_threads()
+    t_reg = {1: 0.0, threads_all: 0.0}
+    n_timed = 0
+    for key in ("point_component_rad1x25", "point_component_rad0x75", "point_component_rad0x25"):
+        comp = out[key].cpu().numpy()
+        diam = T.component_diameter(pts, comp, int(comp.max()) + 1)
+        stat = diam[comp] > 12.5
+        fa = 8 if (frame == 8).any() else int(frame.min())
+        base = comp[frame == fa].min()
+        f0 = dict(fxyz=pts[frame == fa].copy(), component=comp[frame == fa] - base, stationary=stat[frame == fa],
+                  frame=frame[frame == fa])
+        C = int(f0["component"].max()) + 1
+        for fb in (fa - 1, fa + 1):
+            if not (frame == fb).any():
+                continue
+            f1 = dict(fxyz=pts[frame == fb], component=comp[frame == fb], stationary=stat[frame == fb],
+                      frame=frame[frame == fb])
+            for radius, vs in levels:
+                a, b = T.sample_frame(vs, f0), T.sample_frame(vs, f1)
+                for th in t_reg:
+                    t0 = time.perf_counter()
+                    R.register_to_next_frame_cpp(radius, a, b, C, 10.0, 80, 0.05, threads=th)
+                    t_reg[th] += time.perf_counter() - t0
+                n_timed += 1
+    res = {}
+    for th, t in t_reg.items():
+        est = t_sub + t_prop * 2 * 3 + t / max(n_timed, 1) * n_reg_calls  # 2 chunks x 3 radii
+        res[th] = 1.0 / est
+    return {"value": round(res[threads_all], 6), "unit": "sequences/s", "cores": threads_all, "kind": "port",
+            "value_1_core": round(res[1], 6), "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
+            "sample": (f"C++ oracle timed {time.perf_counter() - t_all:.1f}s: 8cm subsample ({t_sub:.2f}s), one "
+                       f"10-frame r=0.25 proposal chunk ({t_prop:.2f}s, x6), {n_timed} of the sequence's "
+                       f"{n_reg_calls} registrations (anchor 8 <-> frames 7 / 9, 3 keys x 3 levels: "
+                       f"{t_reg[1]:.2f}s on 1 core, {t_reg[threads_all]:.2f}s on {threads_all}); sampling between "
+                       "registrations and ground removal excluded; scaled to one sequence")}
+
+
+def stage_rooflines(records, stats, prof, out):
+    """Achieved algorithmic GB/s per stage from device-synchronised spans of ONE extra step and the
+    sizes the stages logged (SURVEY.md 8d formulas). ICP kernels: HIP-event kernel time."""
+    stages = []
+
+    def add(name, seconds, nbytes, note):
+        if seconds and seconds > 0 and nbytes > 0:
+            gbs = nbytes / seconds / 1e9
+            stages.append({"stage": name, "ms": round(seconds * 1e3, 3), "algorithmic_MB": round(nbytes / 1e6, 2),
+                           "achieved_GBs": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": note})
+
+    n, v = stats.get("subsample points in", 0), stats.get("subsample cells out", 0)
+    add("subsample (8 cm grid pick)", records.get("Subsample (8 cm grid pick)"), 16.0 * n + 8.0 * n + 16.0 * v,
+        "16 n + 8 n + 16 v")
+    n_full = int(out["full_point_fxyz"].shape[0])
+    add("ground removal", records.get("Ground Removal"), 50.0 * 16.0 * n_full, "50 x 16 n (IRLS rounds)")
+    e, p = stats.get("proposal graph edges", 0), stats.get("proposal graph points", 0)
+    t_graph = sum(val for key, val in records.items() if key.startswith("Propose Cluster: graph"))
+    add("proposal radius graph (32-NN)", t_graph, 16.0 * p + 20.0 * e, "16 N + 16 M + 16 E + 4 E")
+    e, nn = stats.get("proposal cc edges", 0), stats.get("proposal cc nodes", 0)
+    t_cc = sum(val for key, val in records.items() if key.startswith("Propose Cluster for"))
+    add("proposal components", t_cc, 16.0 * e + 8.0 * nn, "16 E + 8 N")
+    names = ("icp neighbours + moments (budget test + searches)", None, "icp solve + apply")
+    notes = ("36 (Mn + Rn) + 40 (Mn + Rn) + 272 C per launch", None, "68 Mn + 416 C per launch")
+    for q in (0, 2):
+        ms, launches, nbytes = prof[3 * q], prof[3 * q + 1], prof[3 * q + 2]
+        if q == 0:
+            nbytes += prof[5]  # the moments' share rides in the same launches now
+        if ms > 0:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            stages.append({"stage": names[q], "ms": round(ms, 3), "launches": int(launches),
+                           "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                           "algorithmic_MB": round(nbytes / 1e6, 2), "achieved_GBs": round(gbs, 2),
+                           "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": notes[q]})
+    return stages
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: rank / sequence assignment and reduction only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the extra device-synchronised step")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL over xGMI on ROCm
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not args.dry_run and args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.backend)  # "nccl" is RCCL over xGMI on ROCm
+    seeds = sequences_of_rank(rank, world, 1)  # every step re-tracks the rank's sequence
+
+    if args.dry_run:
+        # the N > 1 logic without a GPU: a rank "tracks" for 10 ms x (1 + rank) per step
+        device = torch.device("cpu")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.01 * (1 + rank))
+        dt = time.perf_counter() - t0
+        dt, (nseq, seed_sum) = reduce_metrics(dist, device, dt, [float(args.steps), float(seeds[0])])
+        if rank == 0:
+            print(json.dumps({"metric": baseline_metric(), "value": round(nseq / dt, 5), "unit": "sequences/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "data": "none (dry run)",
+                              "config": {"workload": "dry run: rank / sequence assignment and metric reduction",
+                                         "sequence_seed_sum": seed_sum, "backend": args.backend}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from pcseqlearning_amd import lib as L
+    from pcseqlearning_amd.pcdet import models
+    from pcseqlearning_amd.pcdet.utils import timer
+    from tools.run_sequence import build_model
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-
-    host_batch = load_sequence(rank, args.frames, args.points)  # sequence s -> GPU s mod world
+    host_batch = load_sequence(seeds[0], args.frames, args.points)
     batch = models.load_data_to_gpu(host_batch, device)
     model = build_model(save=False, device=device)
     lib = L.load()
@@ -156,32 +296,36 @@ def main():
     prof = (ctypes.c_double * 9)()
     lib.pcs_profile_icp_read(prof)
     lib.pcs_profile_icp(ctypes.c_int(0))
-
-    units_in_flight = int(getattr(model.preprocessors[2], "last_num_workers", 0))
-    total_sequences = float(args.steps)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        n = torch.tensor([float(args.steps)], dtype=torch.float64, device=device)
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        total_sequences = float(n.item())
+    host_spans = {k: round(v / args.steps, 4) for k, v in timer.RECORDS.items()
+                  if not k.startswith(("Tracking Frame", "ground:"))}
+    tracker = model.preprocessors[2]
+    out = model.last_outputs[0]
+    dt, (total_sequences, points_in) = reduce_metrics(
+        dist, device, dt, [float(args.steps), float(args.steps) * float(host_batch["point_bxyz"].shape[0])])
 
     if rank == 0:
-        out = model.last_outputs[0]
-        # HIP events attached to the dispatch itself (hipExtLaunchKernelGGL): begin-to-end time of the
-        # launch, the quantity rocprofv3 reports as the kernel duration
-        ms, launches, nbytes = prof[0], prof[1], prof[2]
+        # one extra, untimed step with device-synchronised stage spans for the per-stage report
+        stages = []
+        if not args.no_stages:
+            timer.RECORDS.clear()
+            timer.STATS.clear()
+            timer.SYNC = True
+            step()
+            torch.cuda.synchronize()
+            timer.SYNC = False
+            stages = stage_rooflines(dict(timer.RECORDS), dict(timer.STATS), prof, out)
+        # the dominant kernels: the neighbour kernels of the fused ICP (budget test + searches, moments
+        # included). HIP events attached to the dispatches themselves (hipExtLaunchKernelGGL): first
+        # start to last stop of the pair, the quantity rocprofv3 reports as kernel durations
+        ms, launches, nbytes = prof[0], prof[1], prof[2] + prof[5]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
-        # fabric-side bytes per launch from the committed PMC passes of this workload (counters cannot
-        # be read live; see the note in the file for what FETCH_SIZE counts on gfx950)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_icp_nn_hbm_pmc_v10.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_icp_hbm_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            traffic = round((pmc["FETCH_SIZE_KB_per_dispatch"] + pmc["WRITE_SIZE_KB_per_dispatch"]) * 1024.0, 1)
-            traffic_src = "profiles/r01_icp_nn_hbm_pmc_v10.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, serial schedule)"
+            traffic = pmc.get("icp_nn_pair_bytes_per_iteration")
+            traffic_src = "profiles/r02_icp_hbm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
@@ -200,26 +344,30 @@ def main():
                              "cluster_tracking_TLS_multiradius_every8 end to end "
                              "(subsample + ground removal + 3-radius proposal + tracking)"),
                 "frames": args.frames, "points_per_frame": args.points,
+                "points_in_per_second": round(points_in / dt, 1),
                 "points_after_subsample": int(out["full_point_fxyz"].shape[0]),
                 "points_after_ground_removal": int(out["point_fxyz"].shape[0]),
                 "parallelism": f"one sequence per GPU x{world}",
-                "tracking_units_in_flight": units_in_flight,
-                # host wall spans (not device-synchronised; concurrent units overlap, so they do not add up)
-                "stage_seconds_per_step": {k: round(v / args.steps, 3) for k, v in timer.RECORDS.items()
-                                           if not k.startswith(("unit ", "Tracking Frame", "ground:"))},
+                "tracking_units_in_lock_step": int(getattr(tracker, "last_num_workers", 0)),
+                "tracker_host_ticks": int(getattr(tracker, "last_ticks", 0)),
+                "icp_level_calls_per_sequence": int(tracker.num_registration_calls),
+                "profiler_forced_single_group": bool(os.environ.get("ROCP_TOOL_LIBRARIES")),
+                # host wall spans of the timed steps (not device-synchronised)
+                "stage_seconds_per_step": host_spans,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "icp_nn_kernel (fused ICP: two-direction 1-NN search, 32 lanes per query)",
+                "bound": "hbm",
+                "kernel": ("icp_nn_kernel + icp_nn_search_kernel (fused ICP: verified-cache budget test, "
+                           "searches around the old partner / cooperative searches, moments)"),
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
+                "stages": stages,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_reg = model.preprocessors[2].num_registration_calls  # of the last step
-            line["config"]["icp_level_calls_per_sequence"] = n_reg
-            line["cpu_baseline"] = cpu_baseline(host_batch, out, n_reg)
+            line["cpu_baseline"] = cpu_baseline(host_batch, out, int(tracker.num_registration_calls))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

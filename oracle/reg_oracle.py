@@ -120,3 +120,53 @@ def register_to_next_frame(graph, moving, ref, C, angle_regularizer=10.0, max_it
     out = moving["fxyz"].copy()
     out[nsm, 1:] = m_fxyz[:, 1:]
     return out, T, l1, ratio.astype(np.float32), iters
+
+
+_ICP_LIB = None
+
+
+def _icp_lib():
+    global _ICP_LIB
+    if _ICP_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpcs_oracle_icp.so")
+        if not os.path.exists(path):
+            O.build()
+        _ICP_LIB = ctypes.CDLL(path)
+    return _ICP_LIB
+
+
+def cpu_threads():
+    """OpenMP's thread count on this host (what `threads=0` below expands to)."""
+    return int(_icp_lib().orc_max_threads())
+
+
+def register_to_next_frame_cpp(radius, moving, ref, C, angle_regularizer=10.0, max_iter=20,
+                               stopping_delta=5e-2, threads=1):
+    """The same function in C++ (oracle/pcs_oracle_icp.cpp), serial (threads=1) or OpenMP
+    (threads > 1; 0 = all cores): what bench.py's cpu_baseline times. Same arguments and results as
+    register_to_next_frame, `radius` instead of the graph object."""
+    import ctypes
+    lib = _icp_lib()
+    fo = int(ref["frame"][0] - moving["frame"][0])
+    nsm, nsr = ~moving["stationary"], ~ref["stationary"]
+    mov = np.ascontiguousarray(moving["fxyz"][nsm], np.float32).copy()
+    comp = np.ascontiguousarray(moving["component"][nsm], np.int64)
+    r_ns = np.ascontiguousarray(ref["fxyz"][nsr], np.float32)
+    r_all = np.ascontiguousarray(ref["fxyz"], np.float32)
+    deg = np.ascontiguousarray(np.bincount(moving["component"], minlength=C), np.int64)
+    T = np.zeros((C, 4, 4), np.float64)
+    l1 = np.zeros(C, np.float64)
+    ratio = np.zeros(C, np.float32)
+    if threads == 0:
+        threads = cpu_threads()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    iters = lib.orc_register_to_next_frame(
+        p(mov), p(comp), ctypes.c_int64(mov.shape[0]), p(r_ns), ctypes.c_int64(r_ns.shape[0]), p(r_all),
+        ctypes.c_int64(r_all.shape[0]), p(deg), ctypes.c_int64(C), ctypes.c_double(radius), ctypes.c_int(fo),
+        ctypes.c_double(angle_regularizer), ctypes.c_int(max_iter), ctypes.c_double(stopping_delta), p(T), p(l1),
+        p(ratio), ctypes.c_int(threads))
+    out = moving["fxyz"].copy()
+    out[nsm, 1:] = mov[:, 1:]
+    return out, T, l1, ratio, int(iters)

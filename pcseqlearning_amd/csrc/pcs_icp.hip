@@ -1118,7 +1118,7 @@ void icp_profile_account(int n_it, const int* live, const double* bytes3, int pr
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int j = 0; j < n; ++j) {
     if (live[j] < 1) continue;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 3; q += 2) {  // 0: the two neighbour kernels (moments included), 2: solve + apply
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, t_ev.ev[6 * j + 2 * q], t_ev.ev[6 * j + 2 * q + 1]) != hipSuccess) continue;
       g_prof[q].ms += ms;
@@ -1249,7 +1249,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   host.iters = 0;
   host.err = 0;
   int it = 0;
-  const double by_nn = 36.0 * (double)(Mn + Rn), by_mom = 40.0 * (double)(Mn + Rn) + 272.0 * (double)C,
+  const double by_nn = 76.0 * (double)(Mn + Rn) + 272.0 * (double)C, by_mom = 0.0,
                by_app = 68.0 * (double)Mn + 416.0 * (double)C;
   while (it < max_iter) {
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;

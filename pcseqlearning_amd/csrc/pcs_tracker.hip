@@ -1578,8 +1578,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         for (int j = 0; j < chunk; ++j) {
           if (h.it_before + 1 + j > h.icp.iters) break;
           live_j[j] += 1;
-          b3[3 * j] += 36.0 * (Mn + Rn);
-          b3[3 * j + 1] += 40.0 * (Mn + Rn) + 272.0 * C;
+          b3[3 * j] += 76.0 * (Mn + Rn) + 272.0 * C;  // search (36 per query) + moments (40 per query, 272 per component)
           b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
         }
       }

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
+from ....utils import timer
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
@@ -59,6 +60,8 @@ class ClusterProposal(nn.Module):
                     e0_all, e1_all, d2_all = ops.radius_graph(
                         pts, pts, radii[big], g.max_num_neighbors, True, 0, 0,
                         cell_size=-(radii[big] / 2), want_dists=True)
+                    timer.count("proposal graph points", 2 * n_chunk)
+                    timer.count("proposal graph edges", e0_all.shape[0])
             for key, graph, radius in zip(self.component_keys, graphs, radii):
                 with Timer(f"Propose Cluster for {key}"):
                     if shared:
@@ -68,6 +71,8 @@ class ClusterProposal(nn.Module):
                     else:
                         e0, e1, _ = graph(pcframe, pcframe)
                     num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0), n_chunk)
+                    timer.count("proposal cc edges", e0.shape[0])
+                    timer.count("proposal cc nodes", n_chunk)
                     components[key][idx] = comp.to(torch.int64) + totals[key]
                     totals[key] += num
         for key in self.component_keys:

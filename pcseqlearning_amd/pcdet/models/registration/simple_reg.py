@@ -8,7 +8,9 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ...utils import timer
 from ...utils.common_utils import EasyDict, filter_dict, run_deferred
+from ...utils.timer import Timer
 from ..model_utils.grid_sampling import GridSampling3D
 from .registration_module_template import RegistrationTemplate
 
@@ -89,12 +91,16 @@ class SimpleReg(RegistrationTemplate):
                                             seq_dict["point_bxyz"][:, 1:]], dim=-1)
         seq_dict.pop("point_bxyz")
         if self.subsample:
-            seg = self.grid_sampler.segments(seq_dict["point_fxyz"].contiguous())
-            pick = ops.segment_pick(seg, last=True)  # scatter(arange, inv, 'max')
-            for key in ("point_fxyz", "point_feat", "segmentation_label", "instance_label",
-                        "is_foreground", "point_sweep"):
-                if key in seq_dict:
-                    seq_dict[key] = seq_dict[key][pick]
+            with Timer("Subsample (8 cm grid pick)"):
+                n_in = seq_dict["point_fxyz"].shape[0]
+                seg = self.grid_sampler.segments(seq_dict["point_fxyz"].contiguous())
+                pick = ops.segment_pick(seg, last=True)  # scatter(arange, inv, 'max')
+                for key in ("point_fxyz", "point_feat", "segmentation_label", "instance_label",
+                            "is_foreground", "point_sweep"):
+                    if key in seq_dict:
+                        seq_dict[key] = seq_dict[key][pick]
+                timer.count("subsample points in", n_in)
+                timer.count("subsample cells out", pick.shape[0])
         for key in ("gt_box_cls_label", "gt_box_attr", "obj_ids", "frame_id"):
             if key in batch_dict:
                 seq_dict[key] = batch_dict[key][b]

@@ -8,6 +8,12 @@ import torch
 VERBOSE = False
 SYNC = False  # synchronise the device around every span (stage-time tooling)
 RECORDS = {}
+STATS = {}    # sizes the stages log for the roofline report: name -> accumulated count
+
+
+def count(name, value):
+    """Accumulate a size (points, voxels, edges ...) under `name`; host integers only (no device sync)."""
+    STATS[name] = STATS.get(name, 0) + int(value)
 
 
 class Timer:

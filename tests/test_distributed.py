@@ -1,5 +1,6 @@
-"""The N>1 logic of bench.py (sequence s -> rank s mod world, no data-path collective, final
-all-reduce of {max wall time, sequences done}) on a world-size-2 gloo group on CPU."""
+"""The N>1 logic of bench.py (it launches the ranks itself; sequence s -> rank s mod world, no
+data-path collective, final all-reduce of the metric vector) driven through bench.py on a
+world-size-2 gloo group on CPU, and the gradient all-reduce of the backbone's training path."""
 import os
 import socket
 import subprocess
@@ -8,40 +9,51 @@ import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-WORKER = textwrap.dedent("""
-    import os, sys, json, time
-    import torch, torch.distributed as dist
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo")
-    # every rank owns the sequences s with s % world == rank (DistributedSampler striding)
-    mine = [s for s in range(5) if s % world == rank]
-    t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dt = time.perf_counter() - t0
-    dist.barrier()
-    t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    n = torch.tensor([float(len(mine))], dtype=torch.float64); dist.all_reduce(n, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        print(json.dumps({"max_dt": float(t), "own_dt": dt, "total": float(n), "mine": mine}))
-    dist.destroy_process_group()
-""")
+import json
 
 
-def test_two_rank_gloo_reduction(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=120)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs)
-    import json
-    res = json.loads(outs[0].strip().splitlines()[-1])
-    assert res["total"] == 5.0 and res["mine"] == [0, 2, 4]
-    assert res["max_dt"] >= res["own_dt"]  # rank 1 sleeps longer: MAX over ranks is reported
+def _last_json(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError(f"no JSON line in: {text!r}")
+
+
+def test_bench_launches_two_ranks_and_reduces():
+    """`python bench.py --gpus 2 --backend gloo --dry-run`: bench.py itself starts the two ranks
+    (torch.distributed.run as a child process), assigns sequence s to rank s mod 2 and reduces the
+    metric vector (MAX of the wall time, SUM of the rest) -- the code the GPU run uses, on CPU."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--dry-run", "--steps", "3", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = _last_json(p.stdout)
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    assert res["config"]["sequence_seed_sum"] == 1.0       # rank 0 tracks sequence 0, rank 1 sequence 1
+    # 6 sequences in the time of the slower rank (rank 1 sleeps 20 ms per step)
+    assert res["ms_per_step"] >= 19.0
+    assert abs(res["value"] - 6.0 / (res["ms_per_step"] * 3e-3)) / res["value"] < 1e-3
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Started by a launcher with WORLD_SIZE != --gpus the script fails fast (it used to run one rank
+    and print n_gpus: 1)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_sequence_assignment_and_single_rank_reduction():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.sequences_of_rank(1, 4, 3) == [1, 5, 9]
+    owned = sorted(s for r in range(4) for s in bench.sequences_of_rank(r, 4, 2))
+    assert owned == list(range(8))                         # every sequence exactly once
+    assert bench.reduce_metrics(None, None, 0.5, [3, 7]) == (0.5, [3.0, 7.0])
 
 
 GRAD_WORKER = textwrap.dedent("""

@@ -35,6 +35,27 @@ def test_register_to_next_frame_vs_reference(oracle, path):
     np.testing.assert_allclose(moved, g["moved"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "reg_icp_*.npz"))))
+@pytest.mark.parametrize("threads", [1, 3])
+def test_cpp_register_to_next_frame_vs_numpy_oracle(oracle, path, threads):
+    """The C++ restatement that bench.py's cpu_baseline times (oracle/pcs_oracle_icp.cpp, serial and
+    OpenMP) against the numpy oracle: same iteration count, transforms to f64 round-off, and through
+    it within 1e-5 of the reference's own function."""
+    from oracle import reg_oracle as R
+    g = np.load(path)
+    moving = dict(fxyz=g["mov_fxyz"], component=g["mov_comp"], frame=g["mov_frame"], stationary=g["mov_stationary"])
+    ref = dict(fxyz=g["ref_fxyz"], frame=g["ref_frame"], stationary=g["ref_stationary"])
+    C = int(g["C"])
+    want = R.register_to_next_frame(R.Graph(float(g["radius"])), moving, ref, C, 10.0, 80, 0.05)
+    got = R.register_to_next_frame_cpp(float(g["radius"]), moving, ref, C, 10.0, 80, 0.05, threads=threads)
+    assert got[4] == want[4]
+    np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got[2], want[2], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(got[3], want[3])
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[1], g["T"], rtol=0, atol=1e-5)
+
+
 def test_radius_graph_hand_case(oracle):
     """pcdet/ops/torch_hash/torch_hash_modules.py:146-151: three points on a diagonal, r=0.15,
     1-NN sorted: every point pairs with itself at distance 0."""
