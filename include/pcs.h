@@ -205,6 +205,21 @@ int pcs_radius_graph_table_fill(const int64_t* keys, const float* values, const 
                                 const int32_t* degree, const int32_t* offset, int64_t* edges,
                                 float* dists, pcs_stream_t stream);
 
+/* correspondence (pcdet/ops/torch_hash/src/torch_hash.h:20-22, torch_hash_kernel.cu:96-155,444-485)
+ * on the reference's table layout, its argument order: corres_indices [M] int64 = index into the
+ * inserted array of the nearest hashed point among the walked cells (strict `<`, no radius; ties by
+ * the lower index), -1 if none. */
+int pcs_correspondence(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                       const int64_t* dims, int D, const int64_t* query_keys,
+                       const float* query_values, int64_t M, const int32_t* qmin,
+                       const int32_t* qmax, int64_t* corres_indices, pcs_stream_t stream);
+/* points_in_radius_gpu (torch_hash.h:29-32, torch_hash_kernel.cu:160-222,563-605): visited [N] int64,
+ * zeroed by the caller, gets 1 for every hashed point strictly closer than `radius` to a query. */
+int pcs_points_in_radius(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                         const int64_t* dims, int D, const int64_t* query_keys,
+                         const float* query_values, int64_t M, const int32_t* qmin,
+                         const int32_t* qmax, float radius, int64_t* visited, pcs_stream_t stream);
+
 /* ------------------------------------------------------------------ components, medians */
 
 /* connected_components, pcdet/models/model_utils/graph_utils.py:40-53 (scipy csgraph on the

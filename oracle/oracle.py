@@ -232,6 +232,28 @@ def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, qmin=(0, -1, -1
     return e_ref[:E].copy(), e_qry[:E].copy()
 
 
+def correspondence(ref, query, cell, qmin=(0, -1, -1, -1), qmax=(0, 1, 1, 1)):
+    """correspondence_kernel (torch_hash_kernel.cu:96-155): nearest hashed point among the walked
+    cells of size `cell`, -1 if none."""
+    r, q = _c(ref, np.float32), _c(query, np.float32)
+    out = np.empty(q.shape[0], np.int64)
+    lib().orc_table_query(_p(r), ctypes.c_int64(r.shape[0]), _p(q), ctypes.c_int64(q.shape[0]),
+                          ctypes.c_float(cell), _ints(qmin), _ints(qmax), ctypes.c_int(0), ctypes.c_float(0),
+                          _p(out))
+    return out
+
+
+def points_in_radius(ref, query, cell, radius, qmin=(0, -1, -1, -1), qmax=(0, 1, 1, 1)):
+    """points_in_radius_kernel (torch_hash_kernel.cu:160-222): visited[ref] = 1 where some query is
+    closer than `radius` (strict)."""
+    r, q = _c(ref, np.float32), _c(query, np.float32)
+    out = np.zeros(r.shape[0], np.int64)
+    lib().orc_table_query(_p(r), ctypes.c_int64(r.shape[0]), _p(q), ctypes.c_int64(q.shape[0]),
+                          ctypes.c_float(cell), _ints(qmin), _ints(qmax), ctypes.c_int(1), ctypes.c_float(radius),
+                          _p(out))
+    return out
+
+
 def connected_components(e0, e1, n):
     e0 = _c(e0, np.int64)
     e1 = _c(e1, np.int64)

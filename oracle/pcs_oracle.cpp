@@ -416,6 +416,79 @@ int64_t orc_radius_graph(const float* ref, int64_t N, const float* qry, int64_t 
   return E;
 }
 
+// correspondence_kernel / points_in_radius_kernel (torch_hash_kernel.cu:96-155, 160-222) on the
+// same literal table and cell walk as orc_radius_graph (voxel coordinates of graph_utils.py:169-183
+// for cells of `cell` metres, frame cells of 1 - 1e-3). mode 0: corres[q] = the nearest hashed point
+// among the walked cells (strict `<`, no radius; ties -- race-ordered in the reference -- by the lower
+// ref index), -1 if none. mode 1: visited[ref] = 1 for every hashed point with dist2 < radius^2 of
+// some query.
+void orc_table_query(const float* ref, int64_t N, const float* qry, int64_t M, float cell,
+                     const int* qmin, const int* qmax, int mode, float radius, int64_t* out) {
+  if (mode == 0) for (int64_t q = 0; q < M; ++q) out[q] = -1;
+  if (N == 0 || M == 0) return;
+  float vs[4] = {(float)(1 - 1e-3), cell, cell, cell};
+  float lo[4], hi[4];
+  for (int d = 0; d < 4; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
+  for (int64_t i = 0; i < N; ++i)
+    for (int d = 0; d < 4; ++d) { lo[d] = std::fmin(lo[d], ref[i * 4 + d]); hi[d] = std::fmax(hi[d], ref[i * 4 + d]); }
+  for (int64_t i = 0; i < M; ++i)
+    for (int d = 0; d < 4; ++d) { lo[d] = std::fmin(lo[d], qry[i * 4 + d]); hi[d] = std::fmax(hi[d], qry[i * 4 + d]); }
+  int64_t dims[4];
+  for (int d = 0; d < 4; ++d) {
+    lo[d] = lo[d] - vs[d] * 2.f;
+    hi[d] = hi[d] + vs[d] * 2.f;
+    dims[d] = (int64_t)std::nearbyint((hi[d] - lo[d]) / vs[d]) + 3;
+  }
+  auto coord = [&](const float* p, int64_t* c) {
+    for (int d = 0; d < 4; ++d) c[d] = (int64_t)std::nearbyint((p[d] - lo[d]) / vs[d]) + 1;
+  };
+  int64_t H = (int64_t)((double)N / 0.5);
+  std::vector<int64_t> keys(H, -1), rev(H, 0);
+  std::vector<float> vals((size_t)H * 4);
+  for (int64_t i = 0; i < N; ++i) {
+    int64_t c[4];
+    coord(ref + i * 4, c);
+    int64_t key = orc_map2key(c, dims);
+    int64_t slot = orc_hashkey(key, H);
+    while (keys[slot] != -1) slot = (slot + 1) % H;
+    keys[slot] = key;
+    for (int d = 0; d < 4; ++d) vals[slot * 4 + d] = ref[i * 4 + d];
+    rev[slot] = i;
+  }
+  int w[4], ncomb = 1;
+  for (int d = 0; d < 4; ++d) { w[d] = qmax[d] - qmin[d] + 1; ncomb *= w[d]; }
+  const float r2 = radius * radius;
+  for (int64_t q = 0; q < M; ++q) {
+    int64_t qc[4];
+    coord(qry + q * 4, qc);
+    float best = 1e10f;
+    int64_t bi = -1;
+    for (int c = 0; c < ncomb; ++c) {
+      int64_t cc[4];
+      int tmp = c;
+      for (int d = 0; d < 4; ++d) { cc[d] = qc[d] + (tmp % w[d] + qmin[d]); tmp /= w[d]; }
+      int64_t key = orc_map2key(cc, dims);
+      int64_t slot = orc_hashkey(key, H);
+      while (keys[slot] != -1) {
+        if (keys[slot] == key) {
+          float dist2 = 0.f;
+          for (int d = 0; d < 4; ++d) {
+            float di = vals[slot * 4 + d] - qry[q * 4 + d];
+            dist2 = dist2 + di * di;
+          }
+          if (mode == 0) {
+            if (dist2 < best || (dist2 == best && bi >= 0 && rev[slot] < bi)) { best = dist2; bi = rev[slot]; }
+          } else if (dist2 < r2) {
+            out[rev[slot]] = 1;
+          }
+        }
+        slot = (slot + 1) % H;
+      }
+    }
+    if (mode == 0) out[q] = bi;
+  }
+}
+
 // connected_components (graph_utils.py:40-53): weakly connected components, label = order of
 // first appearance scanning nodes 0..n-1 (scipy.sparse.csgraph labelling). Returns the count.
 int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n,

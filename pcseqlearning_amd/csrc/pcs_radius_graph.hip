@@ -324,6 +324,51 @@ table_walk_kernel(const int64_t* __restrict__ keys, const float* __restrict__ va
   if (MODE == 0) degree[q] = cnt;
 }
 
+// correspondence_kernel / points_in_radius_kernel of the reference (torch_hash_kernel.cu:96-155,
+// 160-222) on its own table layout: one thread per query walks the cell combinations (dim 0
+// fastest) and every probe chain. MODE 0: corres[q] = nearest hashed point, strict `<` against
+// 1e10 (no radius); ties -- broken by the atomicCAS race of the reference's insert -- by the lower
+// reference index. MODE 1: visited[ref] = 1 for every hashed point closer than `radius`.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+table_near_kernel(const int64_t* __restrict__ keys, const float* __restrict__ values,
+                  const int64_t* __restrict__ reverse, int64_t H, const int64_t* __restrict__ dims,
+                  int D, const int64_t* __restrict__ qkeys, const float* __restrict__ qvals, int64_t M,
+                  const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax, float radius,
+                  int64_t* __restrict__ out) {
+  int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  int w[8], ncomb = 1;
+  for (int d = 0; d < D; ++d) { w[d] = qmax[d] - qmin[d] + 1; ncomb *= w[d]; }
+  const float r2 = radius * radius;
+  float best = 1e10f;
+  int64_t bi = -1;
+  for (int c = 0; c < ncomb; ++c) {
+    int64_t cc[8];
+    int tmp = c;
+    for (int d = 0; d < D; ++d) { cc[d] = qkeys[q * D + d] + (tmp % w[d] + qmin[d]); tmp /= w[d]; }
+    int64_t key = ref_map2key(cc, dims, D);
+    int64_t slot = ref_hashkey(key, H);
+    while (keys[slot] != -1) {
+      if (keys[slot] == key) {
+        float dist2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+          float di = values[slot * D + d] - qvals[q * D + d];
+          dist2 = dist2 + di * di;
+        }
+        if (MODE == 0) {
+          int64_t ri = reverse[slot];
+          if (dist2 < best || (dist2 == best && bi >= 0 && ri < bi)) { best = dist2; bi = ri; }
+        } else if (dist2 < r2) {
+          out[reverse[slot]] = 1;
+        }
+      }
+      slot = (slot + 1) % H;
+    }
+  }
+  if (MODE == 0) out[q] = bi;
+}
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -477,6 +522,40 @@ int pcs_radius_graph_table_fill(const int64_t* keys, const float* values, const 
   table_walk_kernel<1><<<(int)((M + kBlock - 1) / kBlock), kBlock, 0, s>>>(
       keys, values, reverse, H, dims, D, query_keys, query_values, M, qmin, qmax, radius, 0,
       sort_by_dist, (int32_t*)degree, offset, edges, dists);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// correspondence (torch_hash.h:20-22, torch_hash_kernel.cu:444-485), the reference's argument order:
+// corres_indices [M] int64 = index (into the inserted array) of the nearest hashed point among the
+// walked cells, -1 if there is none. query_keys is read only here (the reference adds the cell
+// offsets in place and takes them back).
+int pcs_correspondence(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                       const int64_t* dims, int D, const int64_t* query_keys, const float* query_values,
+                       int64_t M, const int32_t* qmin, const int32_t* qmax, int64_t* corres_indices,
+                       hipStream_t s) {
+  if (!keys || !values || !reverse || !dims || !qmin || !qmax || D < 1 || D > 8 || M < 0 || H < 1)
+    return PCS_ERR_ARG;
+  if (M == 0) return PCS_OK;
+  if (!query_keys || !query_values || !corres_indices) return PCS_ERR_ARG;
+  table_near_kernel<0><<<(int)((M + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      keys, values, reverse, H, dims, D, query_keys, query_values, M, qmin, qmax, 0.f, corres_indices);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// points_in_radius_gpu (torch_hash.h:29-32, torch_hash_kernel.cu:563-605): visited [N] int64 (the
+// caller zeroes it) gets 1 for every hashed point strictly closer than `radius` to some query.
+int pcs_points_in_radius(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                         const int64_t* dims, int D, const int64_t* query_keys, const float* query_values,
+                         int64_t M, const int32_t* qmin, const int32_t* qmax, float radius, int64_t* visited,
+                         hipStream_t s) {
+  if (!keys || !values || !reverse || !dims || !qmin || !qmax || D < 1 || D > 8 || M < 0 || H < 1)
+    return PCS_ERR_ARG;
+  if (M == 0) return PCS_OK;
+  if (!query_keys || !query_values || !visited) return PCS_ERR_ARG;
+  table_near_kernel<1><<<(int)((M + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+      keys, values, reverse, H, dims, D, query_keys, query_values, M, qmin, qmax, radius, visited);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

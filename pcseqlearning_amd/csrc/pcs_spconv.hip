@@ -306,7 +306,10 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
   // matrix cores where the tile is dense enough to feed them: 4-aligned input channels (the
   // first layer, Cin = 3..5, stays on the FMA path: it is bandwidth-bound); wider
   // inputs (the 128-channel residual stage, the input gradient of 64 -> 128) in slices of CIN_MAX
-  if (cout_ok && g_use_mfma && (cin % 4 == 0) && cin >= 16 && cin <= 8 * CIN_MAX) {
+  // (the matrix-core kernel stages a tile's rows of the neighbour table in LDS, 32 offsets wide:
+  //  wider kernels -- 5x5x5, 3x3x5 ... from an externally built rulebook -- take the tile / generic
+  //  kernels, which read the table from memory)
+  if (cout_ok && g_use_mfma && kv <= 32 && (cin % 4 == 0) && cin >= 16 && cin <= 8 * CIN_MAX) {
 #define PCS_MFMA_LAUNCH(NCV, WIDEV)                                                                   \
   indice_conv_mfma_kernel<NCV, WIDEV><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, \
                                                                  table, num_out, bias, scale, shift, relu, out)

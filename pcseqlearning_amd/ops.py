@@ -377,6 +377,36 @@ def radius_graph_gpu(keys, values, reverse_indices, dims, query_keys, query_valu
     return edges
 
 
+def correspondence(keys, values, reverse_indices, dims, query_keys, query_values, qmin, qmax,
+                   corres_indices):
+    """torch_hash_cuda.correspondence (torch_hash_kernel.cu:444-485), same argument order; fills
+    corres_indices [M] int64 in place (nearest hashed point among the walked cells, -1 if none)."""
+    L.require_gpu(keys, "correspondence")
+    lib = L.load()
+    M, D = query_values.shape
+    assert corres_indices.is_contiguous() and corres_indices.dtype == torch.int64 and corres_indices.shape[0] == M
+    L.check(lib.pcs_correspondence(
+        L.ptr(keys), L.ptr(values), L.ptr(reverse_indices), L.i64(keys.shape[0]), L.ptr(dims.contiguous()),
+        L.i32(D), L.ptr(query_keys.contiguous()), L.ptr(query_values.contiguous()), L.i64(M),
+        L.ptr(qmin.contiguous()), L.ptr(qmax.contiguous()), L.ptr(corres_indices), L.stream()),
+        "pcs_correspondence")
+
+
+def points_in_radius_gpu(keys, values, reverse_indices, dims, query_keys, query_values, qmin, qmax,
+                         radius, visited):
+    """torch_hash_cuda.points_in_radius_gpu (torch_hash_kernel.cu:563-605), same argument order; sets
+    visited [N] int64 to 1 for hashed points strictly closer than `radius` to some query."""
+    L.require_gpu(keys, "points_in_radius_gpu")
+    lib = L.load()
+    M, D = query_values.shape
+    assert visited.is_contiguous() and visited.dtype == torch.int64
+    L.check(lib.pcs_points_in_radius(
+        L.ptr(keys), L.ptr(values), L.ptr(reverse_indices), L.i64(keys.shape[0]), L.ptr(dims.contiguous()),
+        L.i32(D), L.ptr(query_keys.contiguous()), L.ptr(query_values.contiguous()), L.i64(M),
+        L.ptr(qmin.contiguous()), L.ptr(qmax.contiguous()), L.f32(radius), L.ptr(visited), L.stream()),
+        "pcs_points_in_radius")
+
+
 # ---------------------------------------------------------------- components / medians
 def connected_components(e0, e1, num_nodes):
     """graph_utils.connected_components: (num_components, component [N] int64)."""

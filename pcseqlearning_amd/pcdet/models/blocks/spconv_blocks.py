@@ -49,8 +49,10 @@ class SparseBasicBlock(spconv.SparseModule):
         self.downsample, self.stride = downsample, stride
 
     def _folded(self, x):
-        return (not self.training and x.features.is_cuda and not torch.is_grad_enabled()
-                and self.bn1.track_running_stats and self.bn2.track_running_stats)
+        def ok(bn):
+            return (isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.track_running_stats
+                    and bn.running_mean is not None)
+        return x.features.is_cuda and not torch.is_grad_enabled() and ok(self.bn1) and ok(self.bn2)
 
     def forward(self, x):
         skip = x.features

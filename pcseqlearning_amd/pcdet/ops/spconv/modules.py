@@ -56,8 +56,9 @@ class SparseSequential(SparseModule):
                 # eval mode: conv -> BatchNorm1d [-> ReLU] runs as ONE kernel, the normalisation folded
                 # into the conv epilogue (fused_spconv_ops.h:29-132 is the reference's own fused form)
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
-                if (not self.training and hasattr(module, "weight") and hasattr(module, "inverse")
-                        and isinstance(nxt, nn.BatchNorm1d) and nxt.track_running_stats
+                if (hasattr(module, "weight") and hasattr(module, "inverse")
+                        and isinstance(nxt, nn.BatchNorm1d) and not nxt.training and nxt.track_running_stats
+                        and nxt.running_mean is not None
                         and input.features.is_cuda and not torch.is_grad_enabled()):
                     scale, shift = fold_batchnorm(nxt)
                     relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
@@ -75,18 +76,13 @@ class SparseSequential(SparseModule):
 
 
 def fold_batchnorm(bn):
-    """Eval-mode BatchNorm1d as y = x * scale + shift, cached on the module until a parameter or
-    running statistic changes."""
-    key = tuple(t._version if t is not None else -1 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
-    cached = getattr(bn, "_pcs_folded", None)
-    if cached is not None and cached[0] == key and cached[1].device == bn.running_mean.device:
-        return cached[1], cached[2]
+    """Eval-mode BatchNorm1d as y = x * scale + shift. Recomputed on every call (four [C]-sized ops):
+    a cache keyed on tensor versions would miss in-place edits through `.data` and re-assigned
+    buffers, and diverge from the module-by-module path without an error."""
     with torch.no_grad():
         inv = torch.rsqrt(bn.running_var.float() + bn.eps)
         scale = inv * bn.weight.float() if bn.weight is not None else inv
         shift = -bn.running_mean.float() * scale
         if bn.bias is not None:
             shift = shift + bn.bias.float()
-        scale, shift = scale.contiguous(), shift.contiguous()
-    bn._pcs_folded = (key, scale, shift)
-    return scale, shift
+        return scale.contiguous(), shift.contiguous()

@@ -122,6 +122,45 @@ def test_folded_batchnorm_matches_module_by_module():
                                    rtol=1e-4, atol=1e-4)
 
 
+def test_folded_batchnorm_follows_the_modules_state():
+    """Folding is decided per BatchNorm module and recomputed from its current buffers: statistics
+    edited through `.data` are seen, and a BatchNorm left in train mode inside an eval container is
+    NOT folded (it normalises with batch statistics and updates its running ones, as PyTorch does)."""
+    import torch.nn as nn
+    from pcseqlearning_amd.pcdet.ops import spconv
+    torch.manual_seed(3)
+    pts = synthetic.gen_voxel_frame(6, 8000)
+    vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
+    batch = vfe({"points": dev(pts), "batch_size": 1})
+    x = spconv.SparseConvTensor(batch["voxel_features"], batch["voxel_coords"].int(),
+                                synthetic.GRID_SIZE.tolist()[::-1], 1)
+    seq = spconv.SparseSequential(spconv.SubMConv3d(5, 16, 3, padding=1, bias=False, indice_key="k"),
+                                  nn.BatchNorm1d(16), nn.ReLU()).to(DEV).eval()
+    bn = seq[1]
+
+    def module_by_module():
+        y = seq[0](x)
+        return seq[2](bn(y.features))
+
+    with torch.no_grad():
+        bn.running_var.data.copy_(torch.rand(16, device=DEV) + 0.5)   # in-place through .data: no version bump
+        bn.running_mean.data.normal_()
+        a = seq(x).features
+        np.testing.assert_allclose(a.cpu().numpy(), module_by_module().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        bn.running_var.data.mul_(4.0)
+        b = seq(x).features
+        assert not torch.allclose(a, b)
+        np.testing.assert_allclose(b.cpu().numpy(), module_by_module().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        # BatchNorm back in train mode inside the eval container: batch statistics, running stats move
+        bn.train()
+        before = bn.running_mean.clone()
+        c = seq(x).features
+        assert not torch.equal(before, bn.running_mean)
+        y = seq[0](x).features
+        want = torch.relu((y - y.mean(0)) * torch.rsqrt(y.var(0, unbiased=False) + bn.eps) * bn.weight + bn.bias)
+        np.testing.assert_allclose(c.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_sparse_to_dense_vs_scatter():
     rng = np.random.default_rng(0)
     B, D, H, W, C = 2, 3, 17, 23, 20

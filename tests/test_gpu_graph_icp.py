@@ -88,6 +88,19 @@ def test_torch_hash_dropins_vs_oracle(oracle):
         np.testing.assert_array_equal(edges[:, 0].cpu().numpy(), o_ref)
         np.testing.assert_array_equal(edges[:, 1].cpu().numpy(), o_q)
     assert int((keys >= 0).sum()) == rt.shape[0]  # every point owns a slot (duplicates not merged)
+    # the other two functions graph_utils.py / torch_hash_modules.py import: correspondence (nearest
+    # hashed point among the walked cells) and points_in_radius_gpu (hashed points near any query)
+    from pcseqlearning_amd.pcdet.ops.torch_hash import torch_hash_cuda
+    corres = cq.new_zeros(cq.shape[0]) - 7
+    torch_hash_cuda.correspondence(keys, values, rev, dims, cq, qt, qmin, qmax, corres)
+    np.testing.assert_array_equal(corres.cpu().numpy(), oracle.correspondence(ref, qry, r))
+    assert int((corres >= 0).sum()) > 0
+    for rq in (0.3, 0.9):
+        visited = cr.new_zeros(rt.shape[0])
+        torch_hash_cuda.points_in_radius_gpu(keys, values, rev, dims, cq, qt, qmin, qmax, rq, visited)
+        want = oracle.points_in_radius(ref, qry, r, rq)
+        np.testing.assert_array_equal(visited.cpu().numpy(), want)
+        assert 0 < int(want.sum()) < ref.shape[0]
 
 
 def test_connected_components_vs_oracle(oracle):

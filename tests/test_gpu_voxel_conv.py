@@ -141,6 +141,27 @@ def test_conv_channel_configs(oracle, cin, cout):
     assert torch.equal(o, o2)
 
 
+def test_conv_wide_kernel_external_rulebook(oracle):
+    """kv = 45 (a 3x3x5 kernel) from a rulebook built outside pcs_get_indice_pairs (the conv entry
+    points take any kv; the matrix-core kernel stages only 32 offsets in LDS, so wider kernels must
+    be routed to the tile kernels) -- against the oracle, MFMA-shaped channel counts included."""
+    rng = np.random.default_rng(21)
+    V, kv = 3000, 45
+    pairs = np.full((kv, 2, V), -1, np.int32)
+    num = np.zeros(kv, np.int32)
+    for k in range(kv):
+        n = int(rng.integers(0, V // 2))
+        src = rng.choice(V, n, replace=False)
+        dst = rng.choice(V, n, replace=False)      # each output at most once per offset
+        pairs[k, 0, :n], pairs[k, 1, :n], num[k] = src, dst, n
+    for cin, cout in ((32, 64), (16, 16), (5, 16)):
+        feat = rng.normal(0, 1, (V, cin)).astype(np.float32)
+        W = rng.normal(0, 0.05, (kv, cin, cout)).astype(np.float32)
+        o = ops.indice_conv(dev(feat), dev(W), dev(pairs), dev(num), V, False, False)
+        ref = oracle.indice_conv(feat, W, pairs, num, V, False, False)
+        np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=3e-5)
+
+
 def test_conv_epilogue_and_inverse(oracle):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_spconv_s2p1.npz"))
     rng = np.random.default_rng(9)

@@ -86,6 +86,31 @@ def test_radius_graph_vs_sklearn(oracle):
         assert len(got) <= 8 and len(got) >= len(want)
 
 
+def test_correspondence_and_points_in_radius_vs_brute_force(oracle):
+    """The oracle's correspondence / points_in_radius (torch_hash_kernel.cu:96-222) against brute force
+    in the reference's own protocol (torch_hash_utils.py:365-394: hash-table correspondences ==
+    sklearn nearest neighbours when the neighbour lies within one cell)."""
+    from sklearn.neighbors import NearestNeighbors
+    rng = np.random.default_rng(11)
+    ref = rng.uniform(-3, 3, (6000, 4)).astype(np.float32)
+    qry = rng.uniform(-3, 3, (500, 4)).astype(np.float32)
+    ref[:, 0] = 0
+    qry[:, 0] = 0
+    cell = 0.5
+    got = oracle.correspondence(ref, qry, cell)
+    dist, ind = NearestNeighbors(n_neighbors=1).fit(ref.astype(np.float64)).kneighbors(qry.astype(np.float64))
+    near = dist[:, 0] < cell / 2          # then the nearest point is certainly inside the 27 cells
+    assert near.sum() > 300
+    np.testing.assert_array_equal(got[near], ind[near, 0])
+    # points_in_radius: strict `<` on the fp32 squared distance, restricted to the walked cells
+    r = 0.2
+    want = np.zeros(ref.shape[0], np.int64)
+    d2 = ((ref[None, :, :] - qry[:, None, :]) ** 2).astype(np.float32)
+    d2 = ((d2[..., 0] + d2[..., 1]) + d2[..., 2]) + d2[..., 3]
+    want[(d2 < np.float32(r) * np.float32(r)).any(0)] = 1
+    np.testing.assert_array_equal(oracle.points_in_radius(ref, qry, cell, r), want)
+
+
 def test_connected_components_vs_scipy(oracle):
     import scipy.sparse as sp
     rng = np.random.default_rng(2)
