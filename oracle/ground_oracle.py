@@ -1,0 +1,218 @@
+"""numpy restatement of the reference's ground-height estimation.
+
+TEST INFRASTRUCTURE ONLY (see oracle/oracle.py). Follows
+pcdet/models/registration/preprocessors/preprocessor_utils.py: grid_sample (:21-30),
+iterative_reweighted_ransac (:32-80), compute_min_height_from_ransac (:84-272: 30 height ratios of
+IRLS plane fits per 8 m super-pillar, "truncated least squares" pruning of the hypotheses by 8-NN
+curvature over 100 thresholds, propagation by confidence / (distance + 1), heights along the
+plane normal), format_pillars (:274-311), l1_minimization (:313-350: AdamW, MultiStepLR, 3-strike
+stop), ground_plane_removal (:352-419). Pinned by tests/golden/ground_small.npz, produced by running
+the reference's own functions (tests/golden/make_golden_ground.py).
+
+`normal_sign`: the reference takes the plane normal from torch.linalg.eigh, whose SIGN is whatever
+LAPACK returns, and its height formula is sensitive to it (a normal with n_z < 0 flips the sign of
+the height and doubles it, :249-251). "lapack" reproduces that with numpy's eigh (the same LAPACK
+driver family; equal signs on the golden data). "up" is the canonical form of the HIP path: n_z >= 0.
+"""
+import numpy as np
+
+from . import oracle as O
+
+
+def _scatter(vals, idx, n, reduce):
+    out_shape = (n,) + vals.shape[1:]
+    if reduce == "sum":
+        out = np.zeros(out_shape, vals.dtype)
+        np.add.at(out, idx, vals)
+        return out
+    if reduce == "mean":
+        s = np.zeros(out_shape, np.float64)
+        np.add.at(s, idx, vals.astype(np.float64))
+        cnt = np.bincount(idx, minlength=n).astype(np.float64)
+        return (s / np.maximum(cnt, 1).reshape((-1,) + (1,) * (vals.ndim - 1))).astype(vals.dtype)
+    out = np.zeros(out_shape, vals.dtype)
+    touched = np.zeros(n, bool)
+    touched[idx] = True
+    tmp = np.full(out_shape, np.inf if reduce == "min" else -np.inf, vals.dtype)
+    (np.minimum if reduce == "min" else np.maximum).at(tmp, idx, vals)
+    out[touched] = tmp[touched]
+    return out
+
+
+def grid_sample(point_bxyz, grid_size):
+    merged = point_bxyz.copy()
+    merged[:, 0] = 0
+    means, inv, _, _ = O.grid_sample(merged, grid_size)
+    return means, inv
+
+
+def format_pillars(bxyz, pillar_size, pc_range_min):
+    coords = np.round(np.floor((bxyz[:, 1:3] - pc_range_min) / pillar_size)).astype(np.int64)
+    dims = coords.max(0) + 1
+    P = int(dims[0] * dims[1])
+    idx = coords[:, 0] * dims[1] + coords[:, 1]
+    density = _scatter(np.ones(len(bxyz), np.float32), idx, P, "sum").reshape(dims)
+    min_z = _scatter(bxyz[:, -1], idx, P, "min").reshape(dims)
+    xyz = _scatter(bxyz[:, 1:], idx, P, "mean").reshape(-1, 3)
+    weight = (density > 0.5).astype(np.float32).reshape(-1)
+    return dims, P, coords, idx, dict(density=density, min_z=min_z, xyz=xyz, weight=weight)
+
+
+def irls_plane_fit(xyz, pidx, w0, P, sigma2, normal_sign, stopping_delta=1e-2):
+    """iterative_reweighted_ransac (:32-80); fp32 like the reference's tensors, eigh in fp32."""
+    w = w0.astype(np.float32).reshape(-1, 1)
+    center = normal = err = None
+    for _ in range(50):
+        center = _scatter(xyz * w, pidx, P, "sum") / (_scatter(w, pidx, P, "sum") + np.float32(1e-6))
+        d = xyz - center[pidx]
+        ddT = (w[:, :, None] * d[:, :, None]) * d[:, None, :]
+        cov = _scatter(ddT, pidx, P, "mean")
+        _, Q = np.linalg.eigh(cov)
+        normal = Q[:, :, 0].astype(np.float32)
+        if normal_sign == "up":
+            normal = np.where(normal[:, 2:3] < 0, -normal, normal)
+        err = np.abs((d * normal[pidx]).sum(-1))
+        new_w = (np.float32(sigma2) / (err ** 2 + np.float32(sigma2))).reshape(-1)
+        dist_w = np.float32(0.25) / ((d ** 2).sum(-1) + np.float32(0.25))
+        new_w = (new_w * dist_w).reshape(-1, 1).astype(np.float32)
+        if np.abs(new_w - w).max() < stopping_delta:
+            break
+        w = new_w
+    return center, normal, err
+
+
+def knn_self(xyz, k):
+    d = ((xyz[:, None, :] - xyz[None, :, :]) ** 2).sum(-1)
+    nbr = np.argsort(d, axis=1, kind="stable")[:, :k]
+    return np.repeat(np.arange(len(xyz)), nbr.shape[1]), nbr.reshape(-1), nbr.shape[1]
+
+
+def compute_min_height_from_ransac(dims, P, vox, coords, pidx, pillars, cfg, normal_sign, window=4, debug=None):
+    ar = np.arange(P)
+    pc = np.stack([ar // dims[1], ar % dims[1]], -1) // window
+    nd = pc.max(0) + 1
+    NP = int(nd[0] * nd[1])
+    best_conf = np.zeros(P, np.float32)
+    best_normal = np.zeros((P, 3), np.float32)
+    best_center = np.zeros((P, 3), np.float32)
+    ncoords = coords // window
+    nidx = ncoords[:, 0] * nd[1] + ncoords[:, 1]
+    order = np.argsort(nidx, kind="stable")
+    nb, nidx = vox[order], nidx[order]
+    z = nb[:, -1]
+    n_min, n_max = _scatter(z, nidx, NP, "min"), _scatter(z, nidx, NP, "max")
+    n_conf = np.zeros(NP, np.float32)
+    n_normal = np.zeros((NP, 3), np.float32)
+    n_normal[:, -1] = 1
+    n_center = np.zeros((NP, 3), np.float32)
+    sigma2 = np.float32(cfg["SIGMA2"])
+    for ratio in np.linspace(0.3, 1, 30, dtype=np.float32):
+        cur_z = n_min * ratio + n_max * (1 - ratio)
+        zd = cur_z[nidx] - z
+        w0 = sigma2 / (zd ** 2 + sigma2)
+        center, normal, err = irls_plane_fit(nb[:, 1:4], nidx, w0, NP, cfg["SIGMA2"], normal_sign)
+        hit = (err < np.float32(cfg["SIGMA2"] ** 0.5)).astype(np.float32)
+        num_hit = _scatter(hit, nidx, NP, "sum")
+        m = n_conf < num_hit
+        n_normal[m], n_center[m], n_conf[m] = normal[m], center[m], num_hit[m]
+    xyz, normal, conf = n_center, n_normal, n_conf
+    if debug is not None:
+        debug["hyp_xyz_first"] = xyz.copy()
+    for thr in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100):
+        e0, e1, k = knn_self(xyz, cfg["K"])
+        diff = xyz[e1] - xyz[e0]
+        p2p = np.abs((diff * normal[e0]).sum(-1))
+        curv = p2p / (np.linalg.norm(diff, axis=-1) + np.float32(1e-4))
+        mc = curv.reshape(-1, k).mean(-1)
+        if np.float32(thr) > mc.max():
+            continue
+        keep = mc < np.float32(thr)
+        xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+    if debug is not None:
+        debug["hyp_xyz_last"] = xyz.copy()
+    conf = np.ones_like(conf)
+    for i in range(len(conf)):
+        dist = np.linalg.norm(pillars["xyz"][:, :2] - xyz[i, :2], axis=-1)
+        ind = conf[i] / (dist + 1)
+        m = ind > best_conf
+        best_center[m], best_normal[m], best_conf[m] = xyz[i], normal[i], ind[m]
+    vn, vc = best_normal[pidx], best_center[pidx]
+    vd = vox[:, 1:] - vc
+    nz = np.maximum(np.abs(vn[:, -1]), np.float32(0.01)) * ((vn[:, -1] >= 0).astype(np.float32) + 1) / 2
+    vh = (vd * vn).sum(-1) / nz
+    pillars["min_z"] = _scatter(vox[:, -1] - vh, pidx, P, "mean").reshape(dims)
+    pillars["height"] = pillars["min_z"].copy()
+    return pillars
+
+
+def l1_minimization(min_z, weight, cfg):
+    """AdamW (lr cfg.LR, betas .9/.999, eps 1e-8, weight decay 1e-2), MultiStepLR(cfg.DECAY_STEPS),
+    closed-form gradient of mean|(h - min_z) w| + rigid * (4 second-difference terms); stops when 3
+    consecutive improvements are below 1e-4 (:313-350). fp32 state like the reference's tensors."""
+    X, Y = min_z.shape
+    h = np.zeros((X, Y), np.float32)
+    m = np.zeros_like(h)
+    v = np.zeros_like(h)
+    w = weight.reshape(X, Y).astype(np.float32)
+    lr = cfg["LR"]
+    last, countdown = 1e10, 3
+    rigid = np.float32(cfg["RIGID_WEIGHT"])
+
+    def second(hh, a, b, c, wsl):
+        t = (hh[a] - 2 * hh[b] + hh[c]) * (w[wsl] + np.float32(1e-2))
+        return t
+
+    sl = slice
+    terms = (((sl(None, -2), sl(None)), (sl(1, -1), sl(None)), (sl(2, None), sl(None)), (sl(1, -1), sl(None))),
+             ((sl(None), sl(None, -2)), (sl(None), sl(1, -1)), (sl(None), sl(2, None)), (sl(None), sl(1, -1))),
+             ((sl(None, -2), sl(None, -2)), (sl(1, -1), sl(1, -1)), (sl(2, None), sl(2, None)), (sl(1, -1), sl(1, -1))),
+             ((sl(2, None), sl(None, -2)), (sl(1, -1), sl(1, -1)), (sl(None, -2), sl(2, None)), (sl(1, -1), sl(1, -1))))
+    for it in range(cfg["MAX_NUM_ITERS"]):
+        r = (h - min_z) * w
+        loss = np.abs(r).mean(dtype=np.float32)
+        g = np.sign(r) * w / np.float32(r.size)
+        for a, b, c, wsl in terms:
+            t = second(h, a, b, c, wsl)
+            if t.size == 0:
+                continue
+            loss = loss + rigid * np.abs(t).mean(dtype=np.float32)
+            s = np.sign(t) * (w[wsl] + np.float32(1e-2)) * rigid / np.float32(t.size)
+            g[a] += s
+            g[b] -= 2 * s
+            g[c] += s
+        h = h * np.float32(1 - lr * 1e-2)
+        m = m + np.float32(0.1) * (g - m)
+        v = v * np.float32(0.999) + np.float32(0.001) * g * g
+        bc1, bc2 = 1 - 0.9 ** (it + 1), 1 - 0.999 ** (it + 1)
+        h = h - np.float32(lr / bc1) * (m / (np.sqrt(v) / np.float32(np.sqrt(bc2)) + np.float32(1e-8)))
+        if it + 1 in cfg["DECAY_STEPS"]:
+            lr = lr * 0.1
+        if last - float(loss) < 1e-4:
+            countdown -= 1
+        else:
+            countdown = 3
+        if countdown == 0:
+            break
+        last = float(loss)
+    return h
+
+
+def ground_plane_removal(point_bxyz, cfg, normal_sign="lapack", debug=None):
+    """Returns (point_height, point_horizon, point_error, pillar_height, pillar_min_z) like the
+    reference (:352-419)."""
+    pillar_size = np.asarray(cfg["PILLAR_SIZE"], np.float32)
+    pc_min = point_bxyz[:, 1:3].min(0) - np.float32(0.05)
+    vox, inv = grid_sample(point_bxyz, [0.10, 0.10, 0.03])
+    dims, P, coords, pidx, pillars = format_pillars(vox, pillar_size, pc_min)
+    if cfg.get("RANSAC", False):
+        pillars = compute_min_height_from_ransac(dims, P, vox, coords, pidx, pillars, cfg, normal_sign, debug=debug)
+    else:
+        pillars["height"] = pillars["min_z"].copy()
+    if cfg.get("JointOpt", False):
+        pillars["height"] = l1_minimization(pillars["min_z"], pillars["weight"], cfg)
+    ij = (coords[:, 0], coords[:, 1])
+    v_h, v_min = pillars["height"][ij], pillars["min_z"][ij]
+    horizon = vox[:, -1] > v_min
+    v_height = vox[:, -1] - v_h
+    err = v_height - v_min
+    return v_height[inv], horizon[inv], err[inv], pillars["height"], pillars["min_z"]
