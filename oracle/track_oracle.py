@@ -103,9 +103,13 @@ def dist_compensate(deg):
     return out
 
 
-def smooth_velo(v, d, frame_id, next_frame_id, weight0=1.0, weight=10.0, num_itr=300, stopping=1e-3):
+def smooth_velo(v, d, frame_id, next_frame_id, weight0=1.0, weight=10.0, num_itr=300, stopping=1e-3,
+                force_iters=None, iters_out=None):
     """AdamW(lr 1e-2, betas (.9,.999), eps 1e-8, wd 1e-2) + MultiStepLR([100,200,300]) on the whole
-    [C,F,3] tensor, in place; loss and gradients in closed form."""
+    [C,F,3] tensor, in place; loss and gradients in closed form.
+    force_iters (tests only): run exactly that many AdamW steps instead of the reference's stop rule
+    (`last_loss - loss < 1e-3` on an fp32 mean: marginal by one step run to run); iters_out: 1-element
+    list receiving the number of steps taken."""
     if frame_id == next_frame_id:
         return v
     a, b = (frame_id, next_frame_id) if frame_id < next_frame_id else (next_frame_id, frame_id)
@@ -117,7 +121,9 @@ def smooth_velo(v, d, frame_id, next_frame_id, weight0=1.0, weight=10.0, num_itr
     m = np.zeros((C, nf, 2), F32)
     s = np.zeros((C, nf, 2), F32)
     last_loss, countdown = F32(1e10), 3
-    for it in range(num_itr):
+    if iters_out is not None:
+        iters_out[0] = 0
+    for it in range(num_itr if force_iters is None else int(force_iters)):
         lr = 1e-2 * (0.1 ** sum(it >= ms for ms in (100, 200, 300)))
         x = v[:, a:b + 1, :2]
         dd = d[:, a:b + 1, :2]
@@ -139,6 +145,10 @@ def smooth_velo(v, d, frame_id, next_frame_id, weight0=1.0, weight=10.0, num_itr
         new = (vin - step * (m / denom)).astype(F32)
         v *= decay                      # decoupled weight decay reaches every element
         v[:, a:b + 1, :2] = new
+        if iters_out is not None:
+            iters_out[0] = it + 1
+        if force_iters is not None:
+            continue
         if last_loss - loss < stopping:
             countdown -= 1
         else:
@@ -159,123 +169,175 @@ class Tracker:
         self.reg_error_coeff, self.track_interval = reg_error_coeff, track_interval
         self.angle_threshold, self.min_move_frame = angle_threshold, min_move_frame
 
-    def track_frame(self, seq, frame_id):
+    # The loop of cluster_tracking.py:430-787 in three pieces, so that tests can run it one frame step
+    # at a time from a given state (teacher forcing with the reference's own states,
+    # tests/golden/track_steps.npz): init_state -> for each direction: start_dir -> step ... -> finish.
+    def init_state(self, seq, frame_id):
         """seq: dict(fxyz [N,4] f32, frame [N] i64, component [N] i64, stationary [N] bool,
-        extracted [N] bool). Returns the `extracted` dict of the reference."""
+        extracted [N] bool)."""
+        S = {}
         fmask = seq["frame"] == frame_id
-        orig_idx = np.nonzero(fmask)[0]
+        S["fmask"], S["orig_idx"], S["frame_id"] = fmask, np.nonzero(fmask)[0], frame_id
         fr = dict(fxyz=seq["fxyz"][fmask].copy(), component=seq["component"][fmask].copy(),
                   stationary=seq["stationary"][fmask].copy(), frame=seq["frame"][fmask].copy())
         fr["component"] = fr["component"] - fr["component"].min()
         comp = fr["component"]
         C = int(comp.max()) + 1
-        min_f = max(int(seq["frame"].min()), frame_id - self.track_interval)
-        max_f = min(int(seq["frame"].max()), frame_id + self.track_interval)
+        S["fr"], S["comp"], S["C"] = fr, comp, C
+        S["min_f"] = max(int(seq["frame"].min()), frame_id - self.track_interval)
+        S["max_f"] = min(int(seq["frame"].max()), frame_id + self.track_interval)
         sg = Segs(comp, C)
-        comp_deg = np.bincount(comp, minlength=C)
-        comp_diameter = component_diameter(fr["fxyz"], comp, C, sg)
-        Fn = max_f + 1
-        transforms = np.tile(np.eye(4), (C, max_f - min_f + 1, 1, 1))
-        comp_min = np.full(C, frame_id, np.int64)
-        comp_max = np.full(C, frame_id, np.int64)
-        comp_velos = np.zeros((C, Fn, 3), F32)
-        comp_centers = np.zeros((C, Fn, 3), F32)
-        comp_centers[:, frame_id] = component_stats(fr["fxyz"], comp, C, sg)[3]
-        comp_center_diffs = np.zeros((C, Fn, 3), F32)
+        S["sg"] = sg
+        S["comp_deg"] = np.bincount(comp, minlength=C)
+        S["comp_diameter"] = component_diameter(fr["fxyz"], comp, C, sg)
+        Fn = S["max_f"] + 1
+        S["transforms"] = np.tile(np.eye(4), (C, S["max_f"] - S["min_f"] + 1, 1, 1))
+        S["comp_min"] = np.full(C, frame_id, np.int64)
+        S["comp_max"] = np.full(C, frame_id, np.int64)
+        S["comp_velos"] = np.zeros((C, Fn, 3), F32)
+        S["comp_centers"] = np.zeros((C, Fn, 3), F32)
+        S["comp_centers"][:, frame_id] = component_stats(fr["fxyz"], comp, C, sg)[3]
+        S["comp_center_diffs"] = np.zeros((C, Fn, 3), F32)
         _, _, nonempty, _ = component_stats(fr["fxyz"], comp, C, sg)
-        valid_comp = nonempty & (comp_diameter < 12.5)
-        vpm = valid_comp[comp]
-        ex = dict(fxyz=[fr["fxyz"][vpm].copy()], component=[comp[vpm]], frame_indices=[np.nonzero(vpm)[0]],
-                  original_indices=[orig_idx[vpm]])
-        last_velo = None  # (column index) -> live view semantics of the reference
-        moving = None
-        for track_dir in (-1, 1):
-            nf = frame_id + track_dir
-            stopped = ~valid_comp
-            moving = valid_comp.copy()
-            last_xyz = fr["fxyz"][:, 1:].copy()
-            if track_dir == 1 and frame_id > 0:
-                last_velo = frame_id
-            while min_f <= nf <= max_f and (~stopped).any():
-                nmask = seq["frame"] == nf
-                n_orig = np.nonzero(nmask)[0]
-                nxt = dict(fxyz=seq["fxyz"][nmask], component=seq["component"][nmask],
-                           stationary=seq["stationary"][nmask], frame=seq["frame"][nmask])
-                col = nf - min_f
-                transforms[:, col] = transforms[:, col - track_dir]
-                if last_velo is not None:
-                    trans = comp_velos[:, last_velo].copy()
-                    trans[stopped] = 0
-                    fr["fxyz"][:, 1:] += trans[comp] * F32(track_dir)
-                    transforms[:, col, :3, 3] += trans.astype(np.float64) * track_dir
-                for i, radius in enumerate(self.radius_list):
-                    sub = sample_frame(self.voxel_sizes[i], fr)
-                    sub_next = sample_frame(self.voxel_sizes[i], nxt)
-                    graph = R.Graph(radius)
-                    _, T, l1, ratio, _ = R.register_to_next_frame(graph, sub, sub_next, C, self.angle_regularizer,
-                                                                  80, self.stopping_delta[i])
-                    if i == 0:
-                        comp_edge_ratio = ratio
-                    if i == len(self.radius_list) - 1:
-                        l1_reg_error = l1
-                    Tc = T[comp]
-                    rot = np.einsum("nab,nb->na", Tc[:, :3, :3], fr["fxyz"][:, 1:].astype(np.float64))
-                    fr["fxyz"][:, 1:] = rot.astype(F32) + Tc[:, :3, 3].astype(F32)
-                    transforms[:, col] = T @ transforms[:, col]
-                comp_centers[:, nf] = component_stats(fr["fxyz"], comp, C, sg)[3]
-                point_velo = (fr["fxyz"][:, 1:] - last_xyz) * F32(track_dir)
-                comp_velo = seg_sum(point_velo, sg, mean=True)
-                comp_velo[:, 2] = 0
-                comp_velos[:, nf] = comp_velo
-                comp_center_diffs[:, nf] = (comp_centers[:, nf] - comp_centers[:, nf - track_dir]) * F32(track_dir)
-                smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, nf)
-                delta = comp_velos[:, nf] - comp_velo
-                fr["fxyz"][:, 1:] += delta[comp] * F32(track_dir)
-                transforms[:, col, :3, 3] += (delta * F32(track_dir)).astype(np.float64)
-                last_xyz = fr["fxyz"][:, 1:].copy()
-                cv = comp_velos[:, nf]
-                stopped = stopped | (l1_reg_error > (F32(self.reg_error_coeff) * comp_diameter *
-                                                     (F32(1) + dist_compensate(comp_deg))).astype(F32))
-                stopped = stopped | (comp_edge_ratio < 0.5)
-                if (nf - frame_id) * track_dir == self.min_move_frame:
-                    moved = norm3(comp_centers[:, nf] - comp_centers[:, frame_id])
-                    moving = moving & (moved > F32(0.08) * comp_diameter)
-                if last_velo is not None:
-                    lv = comp_velos[:, last_velo]
-                    dev = norm3(cv - lv)
-                    stopped = stopped | (dev > F32(0.24) * comp_diameter)
-                    pv = comp_velos[:, nf - track_dir]
-                    nrm = np.maximum(norm3(cv) * norm3(pv), F32(1e-6))
-                    cosang = np.clip((cv * pv).sum(-1, dtype=F32) / nrm, -1, 1)
-                    angle = np.arccos(cosang).astype(F32) / F32(np.pi) * F32(180.0)
-                    stopped = stopped | ((angle > self.angle_threshold) & (norm3(comp_velos[:, nf, :2]) > F32(0.01)))
-                last_velo = nf
-                if nf == frame_id - 1:
-                    comp_velos[:, frame_id] = cv
-                if track_dir == -1:
-                    comp_min[~stopped] = nf
-                else:
-                    comp_max[~stopped] = nf
-                q = fr["fxyz"].copy()
-                q[:, 0] = nf
-                f_this, f_next = O.radius_graph(q, nxt["fxyz"], self.nn_radius, 1, True)
-                ok = (~stopped)[comp[f_this]]
-                f_this, f_next = f_this[ok], f_next[ok]
-                ex["fxyz"].append(nxt["fxyz"][f_next])
-                ex["component"].append(comp[f_this])
-                ex["frame_indices"].append(f_next)
-                ex["original_indices"].append(n_orig[f_next])
-                nf += track_dir
-            fr["fxyz"] = seq["fxyz"][fmask].copy()
-        out = {k: np.concatenate(v) for k, v in ex.items()}
-        out["moving"] = moving[out["component"]]
-        valid_comp = valid_comp & ((comp_max >= frame_id + self.min_move_frame) |
-                                   (comp_min <= frame_id - self.min_move_frame))
+        S["valid_comp"] = nonempty & (S["comp_diameter"] < 12.5)
+        vpm = S["valid_comp"][comp]
+        S["ex"] = dict(fxyz=[fr["fxyz"][vpm].copy()], component=[comp[vpm]], frame_indices=[np.nonzero(vpm)[0]],
+                       original_indices=[S["orig_idx"][vpm]])
+        S["last_velo"] = None  # (column index) -> live view semantics of the reference
+        S["moving"] = None
+        return S
+
+    def start_dir(self, S, seq, track_dir):
+        S["track_dir"] = track_dir
+        S["nf"] = S["frame_id"] + track_dir
+        S["fr"]["fxyz"] = seq["fxyz"][S["fmask"]].copy()
+        S["stopped"] = ~S["valid_comp"]
+        S["moving"] = S["valid_comp"].copy()
+        S["last_xyz"] = S["fr"]["fxyz"][:, 1:].copy()
+        if track_dir == 1 and S["frame_id"] > 0:
+            S["last_velo"] = S["frame_id"]
+
+    def can_step(self, S):
+        return S["min_f"] <= S["nf"] <= S["max_f"] and bool((~S["stopped"]).any())
+
+    def step(self, S, seq):
+        """One frame step (the body of the reference's while loop). Returns the harvest's edges
+        (f_this, f_next) before the stop filter."""
+        fr, comp, C, sg = S["fr"], S["comp"], S["C"], S["sg"]
+        nf, track_dir, frame_id, min_f = S["nf"], S["track_dir"], S["frame_id"], S["min_f"]
+        transforms, comp_velos, comp_centers = S["transforms"], S["comp_velos"], S["comp_centers"]
+        comp_center_diffs, comp_diameter, comp_deg = S["comp_center_diffs"], S["comp_diameter"], S["comp_deg"]
+        stopped, moving, last_velo = S["stopped"], S["moving"], S["last_velo"]
+        nmask = seq["frame"] == nf
+        n_orig = np.nonzero(nmask)[0]
+        nxt = dict(fxyz=seq["fxyz"][nmask], component=seq["component"][nmask],
+                   stationary=seq["stationary"][nmask], frame=seq["frame"][nmask])
+        col = nf - min_f
+        transforms[:, col] = transforms[:, col - track_dir]
+        if last_velo is not None:
+            trans = comp_velos[:, last_velo].copy()
+            trans[stopped] = 0
+            fr["fxyz"][:, 1:] += trans[comp] * F32(track_dir)
+            transforms[:, col, :3, 3] += trans.astype(np.float64) * track_dir
+        for i, radius in enumerate(self.radius_list):
+            sub = sample_frame(self.voxel_sizes[i], fr)
+            sub_next = sample_frame(self.voxel_sizes[i], nxt)
+            graph = R.Graph(radius)
+            _, T, l1, ratio, _ = R.register_to_next_frame(graph, sub, sub_next, C, self.angle_regularizer,
+                                                          80, self.stopping_delta[i])
+            if i == 0:
+                comp_edge_ratio = ratio
+            if i == len(self.radius_list) - 1:
+                l1_reg_error = l1
+            Tc = T[comp]
+            rot = np.einsum("nab,nb->na", Tc[:, :3, :3], fr["fxyz"][:, 1:].astype(np.float64))
+            fr["fxyz"][:, 1:] = rot.astype(F32) + Tc[:, :3, 3].astype(F32)
+            transforms[:, col] = T @ transforms[:, col]
+        comp_centers[:, nf] = component_stats(fr["fxyz"], comp, C, sg)[3]
+        point_velo = (fr["fxyz"][:, 1:] - S["last_xyz"]) * F32(track_dir)
+        comp_velo = seg_sum(point_velo, sg, mean=True)
+        comp_velo[:, 2] = 0
+        comp_velos[:, nf] = comp_velo
+        comp_center_diffs[:, nf] = (comp_centers[:, nf] - comp_centers[:, nf - track_dir]) * F32(track_dir)
+        iters = [0]
+        smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, nf,
+                    force_iters=S.get("force_smooth_iters"), iters_out=iters)
+        S["smooth_iters"] = iters[0]
+        delta = comp_velos[:, nf] - comp_velo
+        fr["fxyz"][:, 1:] += delta[comp] * F32(track_dir)
+        transforms[:, col, :3, 3] += (delta * F32(track_dir)).astype(np.float64)
+        S["last_xyz"] = fr["fxyz"][:, 1:].copy()
+        cv = comp_velos[:, nf]
+        stopped = stopped | (l1_reg_error > (F32(self.reg_error_coeff) * comp_diameter *
+                                             (F32(1) + dist_compensate(comp_deg))).astype(F32))
+        stopped = stopped | (comp_edge_ratio < 0.5)
+        if (nf - frame_id) * track_dir == self.min_move_frame:
+            moved = norm3(comp_centers[:, nf] - comp_centers[:, frame_id])
+            moving = moving & (moved > F32(0.08) * comp_diameter)
+        if last_velo is not None:
+            lv = comp_velos[:, last_velo]
+            dev = norm3(cv - lv)
+            stopped = stopped | (dev > F32(0.24) * comp_diameter)
+            pv = comp_velos[:, nf - track_dir]
+            nrm = np.maximum(norm3(cv) * norm3(pv), F32(1e-6))
+            cosang = np.clip((cv * pv).sum(-1, dtype=F32) / nrm, -1, 1)
+            angle = np.arccos(cosang).astype(F32) / F32(np.pi) * F32(180.0)
+            stopped = stopped | ((angle > self.angle_threshold) & (norm3(comp_velos[:, nf, :2]) > F32(0.01)))
+        S["last_velo"] = nf
+        if nf == frame_id - 1:
+            comp_velos[:, frame_id] = cv
+        if track_dir == -1:
+            S["comp_min"][~stopped] = nf
+        else:
+            S["comp_max"][~stopped] = nf
+        q = fr["fxyz"].copy()
+        q[:, 0] = nf
+        f_this, f_next = O.radius_graph(q, nxt["fxyz"], self.nn_radius, 1, True)
+        ok = (~stopped)[comp[f_this]]
+        ex = S["ex"]
+        ex["fxyz"].append(nxt["fxyz"][f_next[ok]])
+        ex["component"].append(comp[f_this[ok]])
+        ex["frame_indices"].append(f_next[ok])
+        ex["original_indices"].append(n_orig[f_next[ok]])
+        S["stopped"], S["moving"] = stopped, moving
+        S["l1_reg_error"], S["comp_edge_ratio"] = l1_reg_error, comp_edge_ratio
+        S["nf"] = nf + track_dir
+        return f_this, f_next
+
+    def finish(self, S, seq):
+        frame_id = S["frame_id"]
+        out = {k: np.concatenate(v) for k, v in S["ex"].items()}
+        out["moving"] = S["moving"][out["component"]]
+        valid_comp = S["valid_comp"] & ((S["comp_max"] >= frame_id + self.min_move_frame) |
+                                        (S["comp_min"] <= frame_id - self.min_move_frame))
         keep = valid_comp[out["component"]]
         out = {k: v[keep] for k, v in out.items()}
-        out["transforms"] = transforms
+        out["transforms"] = S["transforms"]
         seq["extracted"][out["original_indices"]] = True
         return out
+
+    def track_frame(self, seq, frame_id):
+        """Returns the `extracted` dict of the reference."""
+        S = self.init_state(seq, frame_id)
+        for track_dir in (-1, 1):
+            self.start_dir(S, seq, track_dir)
+            while self.can_step(S):
+                self.step(S, seq)
+        S["fr"]["fxyz"] = seq["fxyz"][S["fmask"]].copy()
+        return self.finish(S, seq)
+
+    # ---- teacher forcing: overwrite the loop state with the reference's state after its step `s`
+    STATE_MAP = dict(stopped="stopped", moving="moving", transforms="transforms", comp_velos="comp_velos",
+                     comp_centers="comp_centers", comp_center_diffs="comp_center_diffs",
+                     comp_min_frame_id="comp_min", comp_max_frame_id="comp_max", last_xyz="last_xyz")
+
+    def load_reference_state(self, S, g, s):
+        for ref_key, key in self.STATE_MAP.items():
+            S[key] = g[f"s{s}_{ref_key}"].copy()
+        S["fr"]["fxyz"] = g[f"s{s}_frame_fxyz"].copy()
+        S["track_dir"] = int(g[f"s{s}_track_dir"])
+        S["last_velo"] = int(g[f"s{s}_next_frame_id"])
+        S["nf"] = S["last_velo"] + S["track_dir"]
 
 
 def propose_clusters(fxyz, frame, radius, max_nbr=32, chunk=10):

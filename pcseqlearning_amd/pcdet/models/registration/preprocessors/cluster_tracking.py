@@ -341,155 +341,188 @@ class ClusterTracking(nn.Module):
         return self._extracted_from_native(seq_points, frame_id, out, perm, frame.component.dtype)
 
     def track_frame_host(self, seq_points, frame, seq_boxes):
-        """track_frame op by op (one framework call per step of cluster_tracking.py:430-787)."""
-        num_components = int(frame.component.max().long().item()) + 1
-        frame_id = int(frame.frame[0].long().item())
-        frame_mask = (seq_points.frame == frame_id).reshape(-1)
-        min_frame_id = max(int(seq_points.frame.min().long().item()), frame_id - self.track_interval)
-        max_frame_id = min(int(seq_points.frame.max().long().item()), frame_id + self.track_interval)
-        comp_sg = IndexSegments(frame.component, num_components)
-        comp_deg = efficient_robust_sum(torch.ones_like(frame.component), comp_sg, num_components)
-        if self.verbose:
-            print(f"Tracking frame-{frame_id:03d} with {num_components:03d} components")
-        comp_diameter = component_diameter(frame, comp_sg)
-
-        F = max_frame_id + 1
-        transforms = torch.diag_embed(
-            frame.fxyz.new_ones(num_components, max_frame_id - min_frame_id + 1, 4).double())
-        reg_errors = frame.fxyz.new_zeros(num_components, F)
-        comp_edge_ratios = frame.fxyz.new_zeros(num_components, F)
-        comp_min_frame_id = frame.component.new_zeros(num_components) + frame_id
-        comp_max_frame_id = frame.component.new_zeros(num_components) + frame_id
-        comp_velos = frame.fxyz.new_zeros(num_components, F, 3)
-        comp_centers = frame.fxyz.new_zeros(num_components, F, 3)
-        comp_centers[:, frame_id] = component_center(frame, comp_sg)
-        comp_center_diffs = frame.fxyz.new_zeros(num_components, F, 3)
-
-        valid_comp_mask = filter_components(frame, sg=comp_sg)
-        valid_point_mask = valid_comp_mask[frame.component]
-        ex_fxyz = [frame.fxyz[valid_point_mask]]
-        ex_component = [frame.component[valid_point_mask]]
-        ex_seg = [frame.segmentation_label[valid_point_mask]]
-        ex_indices = [valid_point_mask.nonzero().reshape(-1)]
-        ex_original = [frame_mask.nonzero()[valid_point_mask].reshape(-1)]
-
-        last_velo = None
-        moving = None
+        """track_frame op by op (one framework call per step of cluster_tracking.py:430-787): the same
+        loop in four pieces (host_init / host_start_dir / host_step / host_finish) so that a test can
+        run one frame step from a given state (tests/test_gpu_track_steps.py)."""
+        st = self.host_init(seq_points, frame)
         for track_dir in (-1, 1):  # backward, then forward
-            next_frame_id = frame_id + track_dir
-            stopped = ~valid_comp_mask
-            moving = valid_comp_mask.clone()
-            last_xyz = frame.fxyz[:, 1:].clone()
-            if track_dir == 1 and frame_id > 0:
-                last_velo = comp_velos[:, frame_id]
-            while min_frame_id <= next_frame_id <= max_frame_id and bool((~stopped).any()):
-                if self.verbose:
-                    print(f"Tracking {frame_id} --> {next_frame_id}")
-                next_mask = (seq_points.frame == next_frame_id).reshape(-1)
-                next_frame = EasyDict(filter_dict(seq_points, next_mask, ignore_keys=("frame_offsets", "frame_perm")))
-                col = next_frame_id - min_frame_id
-                frame.require_corres = ((~stopped)[frame.component]).reshape(-1)
-                transforms[:, col] = transforms[:, col - track_dir]
-                if last_velo is not None:
-                    # constant-velocity prediction for the components still being tracked
-                    trans = last_velo.clone()
-                    trans[stopped] = 0
-                    frame.fxyz[:, 1:] += trans[frame.component] * track_dir
-                    transforms[:, col, :3, 3] += trans.double() * track_dir
-                for i in range(len(self.radius_list)):
-                    sampler = getattr(self, f"sampler_{i}")
-                    graph = getattr(self, f"registration_graph_{i}")
-                    sub_frame = sample_frame(sampler, frame)
-                    sub_next = sample_frame(sampler, next_frame)
-                    self.num_registration_calls += 1
-                    with Timer(f"REGISTRATION at Level {i}"):
-                        sub_frame, T, _l1, _ratio = register_to_next_frame(
-                            graph, sub_frame, sub_next, num_components,
-                            self.model_cfg["ANGLE_REGULARIZER"], max_iter=80,
-                            stopping_delta=self.stopping_delta[i])
-                    if i == 0:
-                        comp_edge_ratio = _ratio
-                    if i == len(self.radius_list) - 1:
-                        l1_reg_error = _l1
-                    Tc = T[frame.component]
-                    frame.fxyz[:, 1:] = (Tc[:, :3, :3] @ frame.fxyz[:, 1:, None].double()).squeeze(-1).float() \
-                        + Tc[:, :3, 3].float()
-                    transforms[:, col] = T @ transforms[:, col]
+            self.host_start_dir(st, seq_points, track_dir)
+            while self.host_can_step(st):
+                self.host_step(st, seq_points)
+        frame.fxyz = seq_points.fxyz[st.frame_mask]
+        return self.host_finish(st, seq_points)
 
-                comp_centers[:, next_frame_id] = component_center(frame, comp_sg)
-                point_velo = (frame.fxyz[:, 1:] - last_xyz) * track_dir
-                comp_velo = robust_mean(point_velo, comp_sg, num_components)
-                comp_velo[:, 2] = 0
-                comp_velos[:, next_frame_id] = comp_velo
-                comp_center_diffs[:, next_frame_id] = \
-                    (comp_centers[:, next_frame_id] - comp_centers[:, next_frame_id - track_dir]) * track_dir
-                comp_velos = smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, next_frame_id)
-                delta_velo = comp_velos[:, next_frame_id] - comp_velo
-                comp_velo = comp_velos[:, next_frame_id]  # live view, like the reference's
-                frame.fxyz[:, 1:] += delta_velo[frame.component] * track_dir
-                transforms[:, col, :3, 3] += delta_velo * track_dir
-                last_xyz = frame.fxyz[:, 1:].clone()
+    def host_init(self, seq_points, frame):
+        st = EasyDict(frame=frame)
+        C = st.num_components = int(frame.component.max().long().item()) + 1
+        frame_id = st.frame_id = int(frame.frame[0].long().item())
+        st.frame_mask = (seq_points.frame == frame_id).reshape(-1)
+        st.min_frame_id = max(int(seq_points.frame.min().long().item()), frame_id - self.track_interval)
+        st.max_frame_id = min(int(seq_points.frame.max().long().item()), frame_id + self.track_interval)
+        st.comp_sg = IndexSegments(frame.component, C)
+        st.comp_deg = efficient_robust_sum(torch.ones_like(frame.component), st.comp_sg, C)
+        if self.verbose:
+            print(f"Tracking frame-{frame_id:03d} with {C:03d} components")
+        st.comp_diameter = component_diameter(frame, st.comp_sg)
 
-                # ---- stop rules (cluster_tracking.py:676-691)
-                stopped = stopped | (l1_reg_error > self.reg_error_coeff * comp_diameter *
-                                     (1 + dist_compensate(comp_deg)))
-                stopped = stopped | (comp_edge_ratio < 0.5)
-                if (next_frame_id - frame_id) * track_dir == self.min_move_frame:
-                    moved = (comp_centers[:, next_frame_id] - comp_centers[:, frame_id]).norm(p=2, dim=-1)
-                    moving = moving & (moved > 0.08 * comp_diameter)
-                if last_velo is not None:
-                    dev_velo_norm = (comp_velo - last_velo).norm(p=2, dim=-1)
-                    stopped = stopped | (dev_velo_norm > 0.24 * comp_diameter)
-                    prev_velo = comp_velos[:, next_frame_id - track_dir]
-                    norm = (comp_velo.norm(p=2, dim=-1) * prev_velo.norm(p=2, dim=-1)).clamp(min=1e-6)
-                    angle = ((comp_velo * prev_velo).sum(-1) / norm).clamp(min=-1, max=1).arccos() \
-                        / np.pi * 180.0
-                    stopped = stopped | (angle > self.angle_threshold) & \
-                        (comp_velos[:, next_frame_id, :2].norm(p=2, dim=-1) > 0.01)
-                last_velo = comp_velo
-                if next_frame_id == frame_id - 1:
-                    comp_velos[:, frame_id] = comp_velo
-                if track_dir == -1:
-                    comp_min_frame_id[~stopped] = next_frame_id
-                else:
-                    comp_max_frame_id[~stopped] = next_frame_id
+        F = st.max_frame_id + 1
+        st.transforms = torch.diag_embed(
+            frame.fxyz.new_ones(C, st.max_frame_id - st.min_frame_id + 1, 4).double())
+        st.reg_errors = frame.fxyz.new_zeros(C, F)
+        st.comp_edge_ratios = frame.fxyz.new_zeros(C, F)
+        st.comp_min_frame_id = frame.component.new_zeros(C) + frame_id
+        st.comp_max_frame_id = frame.component.new_zeros(C) + frame_id
+        st.comp_velos = frame.fxyz.new_zeros(C, F, 3)
+        st.comp_centers = frame.fxyz.new_zeros(C, F, 3)
+        st.comp_centers[:, frame_id] = component_center(frame, st.comp_sg)
+        st.comp_center_diffs = frame.fxyz.new_zeros(C, F, 3)
 
-                # ---- harvest the target frame's points next to the moved anchor points
-                frame.fxyz[:, 0] = next_frame_id
-                f_this, f_next, _ = self.nn_graph(frame, next_frame)
-                ok = (~stopped)[frame.component[f_this]]
-                f_this, f_next = f_this[ok], f_next[ok]
-                ex_fxyz.append(next_frame.fxyz[f_next])
-                ex_component.append(frame.component[f_this])
-                ex_seg.append(next_frame.segmentation_label[f_next])
-                ex_indices.append(f_next.reshape(-1))
-                ex_original.append(next_mask.nonzero()[f_next].reshape(-1))
-                frame.fxyz[:, 0] = frame_id
+        st.valid_comp_mask = filter_components(frame, sg=st.comp_sg)
+        vpm = st.valid_comp_mask[frame.component]
+        st.ex_fxyz = [frame.fxyz[vpm]]
+        st.ex_component = [frame.component[vpm]]
+        st.ex_seg = [frame.segmentation_label[vpm]]
+        st.ex_indices = [vpm.nonzero().reshape(-1)]
+        st.ex_original = [st.frame_mask.nonzero()[vpm].reshape(-1)]
+        st.last_velo = None
+        st.moving = None
+        st.smooth_iters = None  # tests only: a fixed AdamW step count for smooth_velo
+        return st
 
-                reg_errors[:, next_frame_id] = l1_reg_error
-                comp_edge_ratios[:, next_frame_id] = comp_edge_ratio
-                next_frame_id += track_dir
-            frame.fxyz = seq_points.fxyz[frame_mask]
+    def host_start_dir(self, st, seq_points, track_dir):
+        st.track_dir = track_dir
+        st.next_frame_id = st.frame_id + track_dir
+        st.frame.fxyz = seq_points.fxyz[st.frame_mask]
+        st.stopped = ~st.valid_comp_mask
+        st.moving = st.valid_comp_mask.clone()
+        st.last_xyz = st.frame.fxyz[:, 1:].clone()
+        if track_dir == 1 and st.frame_id > 0:
+            st.last_velo = st.comp_velos[:, st.frame_id]
 
-        ex_component = torch.cat(ex_component, dim=0)
+    def host_can_step(self, st):
+        return st.min_frame_id <= st.next_frame_id <= st.max_frame_id and bool((~st.stopped).any())
+
+    def host_step(self, st, seq_points):
+        """One frame step; returns the harvest's edges (f_this, f_next) before the stop filter."""
+        frame, frame_id, track_dir, next_frame_id = st.frame, st.frame_id, st.track_dir, st.next_frame_id
+        num_components, comp_sg = st.num_components, st.comp_sg
+        transforms, comp_velos, comp_centers = st.transforms, st.comp_velos, st.comp_centers
+        comp_center_diffs, comp_diameter = st.comp_center_diffs, st.comp_diameter
+        stopped, moving, last_velo = st.stopped, st.moving, st.last_velo
+        if self.verbose:
+            print(f"Tracking {frame_id} --> {next_frame_id}")
+        next_mask = (seq_points.frame == next_frame_id).reshape(-1)
+        next_frame = EasyDict(filter_dict(seq_points, next_mask, ignore_keys=("frame_offsets", "frame_perm")))
+        col = next_frame_id - st.min_frame_id
+        frame.require_corres = ((~stopped)[frame.component]).reshape(-1)
+        transforms[:, col] = transforms[:, col - track_dir]
+        if last_velo is not None:
+            # constant-velocity prediction for the components still being tracked
+            trans = last_velo.clone()
+            trans[stopped] = 0
+            frame.fxyz[:, 1:] += trans[frame.component] * track_dir
+            transforms[:, col, :3, 3] += trans.double() * track_dir
+        for i in range(len(self.radius_list)):
+            sampler = getattr(self, f"sampler_{i}")
+            graph = getattr(self, f"registration_graph_{i}")
+            sub_frame = sample_frame(sampler, frame)
+            sub_next = sample_frame(sampler, next_frame)
+            self.num_registration_calls += 1
+            with Timer(f"REGISTRATION at Level {i}"):
+                sub_frame, T, _l1, _ratio = register_to_next_frame(
+                    graph, sub_frame, sub_next, num_components,
+                    self.model_cfg["ANGLE_REGULARIZER"], max_iter=80,
+                    stopping_delta=self.stopping_delta[i])
+            if i == 0:
+                comp_edge_ratio = _ratio
+            if i == len(self.radius_list) - 1:
+                l1_reg_error = _l1
+            Tc = T[frame.component]
+            frame.fxyz[:, 1:] = (Tc[:, :3, :3] @ frame.fxyz[:, 1:, None].double()).squeeze(-1).float() \
+                + Tc[:, :3, 3].float()
+            transforms[:, col] = T @ transforms[:, col]
+
+        comp_centers[:, next_frame_id] = component_center(frame, comp_sg)
+        point_velo = (frame.fxyz[:, 1:] - st.last_xyz) * track_dir
+        comp_velo = robust_mean(point_velo, comp_sg, num_components)
+        comp_velo[:, 2] = 0
+        comp_velos[:, next_frame_id] = comp_velo
+        comp_center_diffs[:, next_frame_id] = \
+            (comp_centers[:, next_frame_id] - comp_centers[:, next_frame_id - track_dir]) * track_dir
+        if st.smooth_iters is None:
+            smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, next_frame_id)
+        else:
+            smooth_velo(comp_velos, comp_center_diffs, frame_id + track_dir, next_frame_id,
+                        num_itr=st.smooth_iters, stopping=-1e30)
+        delta_velo = comp_velos[:, next_frame_id] - comp_velo
+        comp_velo = comp_velos[:, next_frame_id]  # live view, like the reference's
+        frame.fxyz[:, 1:] += delta_velo[frame.component] * track_dir
+        transforms[:, col, :3, 3] += delta_velo * track_dir
+        st.last_xyz = frame.fxyz[:, 1:].clone()
+
+        # ---- stop rules (cluster_tracking.py:676-691)
+        stopped = stopped | (l1_reg_error > self.reg_error_coeff * comp_diameter *
+                             (1 + dist_compensate(st.comp_deg)))
+        stopped = stopped | (comp_edge_ratio < 0.5)
+        if (next_frame_id - frame_id) * track_dir == self.min_move_frame:
+            moved = (comp_centers[:, next_frame_id] - comp_centers[:, frame_id]).norm(p=2, dim=-1)
+            moving = moving & (moved > 0.08 * comp_diameter)
+        if last_velo is not None:
+            dev_velo_norm = (comp_velo - last_velo).norm(p=2, dim=-1)
+            stopped = stopped | (dev_velo_norm > 0.24 * comp_diameter)
+            prev_velo = comp_velos[:, next_frame_id - track_dir]
+            norm = (comp_velo.norm(p=2, dim=-1) * prev_velo.norm(p=2, dim=-1)).clamp(min=1e-6)
+            angle = ((comp_velo * prev_velo).sum(-1) / norm).clamp(min=-1, max=1).arccos() \
+                / np.pi * 180.0
+            stopped = stopped | (angle > self.angle_threshold) & \
+                (comp_velos[:, next_frame_id, :2].norm(p=2, dim=-1) > 0.01)
+        st.last_velo = comp_velo
+        if next_frame_id == frame_id - 1:
+            comp_velos[:, frame_id] = comp_velo
+        if track_dir == -1:
+            st.comp_min_frame_id[~stopped] = next_frame_id
+        else:
+            st.comp_max_frame_id[~stopped] = next_frame_id
+
+        # ---- harvest the target frame's points next to the moved anchor points
+        frame.fxyz[:, 0] = next_frame_id
+        f_this, f_next, _ = self.nn_graph(frame, next_frame)
+        ok = (~stopped)[frame.component[f_this]]
+        st.ex_fxyz.append(next_frame.fxyz[f_next[ok]])
+        st.ex_component.append(frame.component[f_this[ok]])
+        st.ex_seg.append(next_frame.segmentation_label[f_next[ok]])
+        st.ex_indices.append(f_next[ok].reshape(-1))
+        st.ex_original.append(next_mask.nonzero()[f_next[ok]].reshape(-1))
+        frame.fxyz[:, 0] = frame_id
+
+        st.reg_errors[:, next_frame_id] = l1_reg_error
+        st.comp_edge_ratios[:, next_frame_id] = comp_edge_ratio
+        st.l1_reg_error, st.comp_edge_ratio = l1_reg_error, comp_edge_ratio
+        st.stopped, st.moving = stopped, moving
+        st.next_frame_id = next_frame_id + track_dir
+        return f_this, f_next
+
+    def host_finish(self, st, seq_points):
+        frame_id = st.frame_id
+        ex_component = torch.cat(st.ex_component, dim=0)
         extracted = EasyDict(dict(
-            fxyz=torch.cat(ex_fxyz, dim=0),
+            fxyz=torch.cat(st.ex_fxyz, dim=0),
             component=ex_component,
-            segmentation_label=torch.cat(ex_seg, dim=0),
-            frame_indices=torch.cat(ex_indices, dim=0),
-            original_indices=torch.cat(ex_original, dim=0),
-            moving=moving[ex_component],
-            valid_comp_mask=moving[ex_component],
+            segmentation_label=torch.cat(st.ex_seg, dim=0),
+            frame_indices=torch.cat(st.ex_indices, dim=0),
+            original_indices=torch.cat(st.ex_original, dim=0),
+            moving=st.moving[ex_component],
+            valid_comp_mask=st.moving[ex_component],
             gt_box_label=torch.zeros_like(ex_component),
         ))
-        valid_comp_mask = valid_comp_mask & ((comp_max_frame_id >= frame_id + self.min_move_frame) |
-                                             (comp_min_frame_id <= frame_id - self.min_move_frame))
+        valid_comp_mask = st.valid_comp_mask & ((st.comp_max_frame_id >= frame_id + self.min_move_frame) |
+                                                (st.comp_min_frame_id <= frame_id - self.min_move_frame))
         extracted = EasyDict(filter_dict(extracted, valid_comp_mask[extracted.component]))
-        extracted.transforms = transforms
+        extracted.transforms = st.transforms
         seq_points.extracted[extracted.original_indices] = True
-        self.last_track_debug = dict(reg_errors=reg_errors, comp_edge_ratios=comp_edge_ratios,
-                                     comp_velos=comp_velos, comp_min_frame_id=comp_min_frame_id,
-                                     comp_max_frame_id=comp_max_frame_id)
+        self.last_track_debug = dict(reg_errors=st.reg_errors, comp_edge_ratios=st.comp_edge_ratios,
+                                     comp_velos=st.comp_velos, comp_min_frame_id=st.comp_min_frame_id,
+                                     comp_max_frame_id=st.comp_max_frame_id)
         return extracted
 
     def _track_units_native(self, seq_dict, key_points, units, offsets, perm):

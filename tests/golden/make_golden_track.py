@@ -12,6 +12,9 @@ torch.optim.AdamW, the stop rules) is the reference's own code.
   track_small.npz   inputs (subsampled non-ground points of a small synthetic sequence with
                     proposed components) + per-anchor outputs of track_frame
   smooth_velo.npz   inputs + outputs of smooth_velo
+  track_steps.npz   (python tests/golden/make_golden_track.py --steps) the reference's complete loop
+                    state after every frame step of track_frame(anchor 8) on the same sequence, for
+                    teacher-forced step-by-step tests
 Run: python tests/golden/make_golden_track.py
 """
 import importlib.util
@@ -170,5 +173,83 @@ def main():
     np.savez_compressed(os.path.join(HERE, "track_small.npz"), **gold)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--steps" not in sys.argv:
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# Per-step states of the reference's track_frame (teacher forcing): the reference keeps its loop
+# state in locals of one long function; its last call of every step is the harvest graph
+# `self.nn_graph(frame, next_frame)`, so a spy installed there reads the caller's locals and gets the
+# complete state AFTER the step (stop flags, velocities, frame ranges, transforms, moved points ...)
+# together with the harvest's own edges. The state after step s is the state before step s + 1.
+STATE_KEYS = ("stopped", "moving", "transforms", "comp_velos", "comp_centers", "comp_center_diffs",
+              "comp_min_frame_id", "comp_max_frame_id", "last_xyz", "l1_reg_error", "comp_edge_ratio")
+
+
+def main_steps(frame_id=8):
+    import inspect
+    mod, EasyDict = load_reference_tracking()
+    t = torch.from_numpy
+    fxyz, seg_label, comp = small_sequence()
+    cfg = EasyDict({k: (EasyDict(v) if isinstance(v, dict) else v) for k, v in MODEL_CFG.items()})
+    cfg.REGISTRATION = EasyDict(MODEL_CFG["REGISTRATION"])
+    tracker = mod.ClusterTracking(cfg, {"visualize": False})
+    seq_points = EasyDict(fxyz=t(fxyz.copy()), frame=t(fxyz[:, :1].astype(np.int64).copy()),
+                          gt_box_id=t(np.full(len(fxyz), -1, np.int64)),
+                          segmentation_label=t(seg_label.copy()), component=t(comp.copy()))
+    diam = mod.component_diameter(seq_points)
+    seq_points.component_diameter = diam[seq_points.component]
+    seq_points.stationary = seq_points.component_diameter > 12.5
+    seq_points.extracted = torch.zeros_like(seq_points.fxyz[:, 0]).bool()
+    steps = []
+    graph = tracker.nn_graph
+    orig_forward = graph.forward
+
+    def spy(ref, query):
+        out = orig_forward(ref, query)
+        f = inspect.currentframe()
+        while f is not None and f.f_code.co_name != "track_frame":
+            f = f.f_back
+        if f is not None:
+            L = f.f_locals
+            rec = {k: L[k].detach().clone().numpy() for k in STATE_KEYS}
+            rec["frame_fxyz"] = L["frame"].fxyz.detach().clone().numpy()
+            rec["frame_fxyz"][:, 0] = frame_id          # (set to the target frame for the duration of the query)
+            rec["next_frame_id"] = np.int64(L["next_frame_id"])
+            rec["track_dir"] = np.int64(L["track_dir"])
+            rec["f_this"], rec["f_next"] = out[0].numpy().copy(), out[1].numpy().copy()
+            rec["smooth_iters"] = np.int64(adam_steps[0])
+            adam_steps[0] = 0
+            steps.append(rec)
+        return out
+
+    graph.forward = spy
+    # smooth_velo stops on `last_loss - loss < 1e-3` of an fp32 mean over every component: one more or
+    # one fewer AdamW step (lr 1e-2) moves every velocity by ~1e-2, so the step count is recorded too
+    adam_steps = [0]
+    orig_adam_step = torch.optim.AdamW.step
+
+    def counting_step(self, *a, **k):
+        adam_steps[0] += 1
+        return orig_adam_step(self, *a, **k)
+
+    torch.optim.AdamW.step = counting_step
+    mask = (seq_points.fxyz[:, 0] == frame_id).reshape(-1)
+    frame_points = EasyDict({k: v[mask] for k, v in seq_points.items()})
+    frame_points.component = frame_points.component - frame_points.component.min()
+    ex = tracker.track_frame(seq_points, frame_points, None)
+    graph.forward = orig_forward
+    torch.optim.AdamW.step = orig_adam_step
+    gold = dict(anchor=np.int64(frame_id), num_steps=np.int64(len(steps)))
+    for s, rec in enumerate(steps):
+        for k, v in rec.items():
+            gold[f"s{s}_{k}"] = v
+    for k in ("fxyz", "component", "frame_indices", "original_indices", "moving"):
+        gold[f"final_{k}"] = ex[k].numpy()
+    print("anchor", frame_id, "steps", len(steps), [(int(r["track_dir"]), int(r["next_frame_id"]), int(r["smooth_iters"])) for r in steps])
+    np.savez_compressed(os.path.join(HERE, "track_steps.npz"), **gold)
+
+
+if __name__ == "__main__" and "--steps" in sys.argv:
+    main_steps()

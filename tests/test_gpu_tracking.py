@@ -182,3 +182,44 @@ def test_track_frame_with_empty_frames_in_the_window():
         assert not np.isin(b["fxyz"][:, 0].cpu().numpy().astype(np.int64), [3, 10]).any()
         for key in ("original_indices", "frame_indices", "component", "moving"):
             np.testing.assert_array_equal(b[key].cpu().numpy(), outs[1][key].cpu().numpy(), err_msg=key)
+
+
+def test_track_frame_steps_teacher_forced():
+    """Every frame step of the op-by-op loop (the kernels the native tracker runs, bit-identical to it:
+    test_track_frame_native_vs_host) from the REFERENCE's own state before the step
+    (tests/_track_steps.py, golden track_steps.npz): decisions exact, state to fp32 noise."""
+    from pcseqlearning_amd.pcdet.utils.common_utils import filter_dict
+    from tests import _track_steps as TS
+    g, gs = TS.load()
+    tracker, sp = _tracker(), _prepare(gs)
+    anchor = int(g["anchor"])
+    mask = (sp.fxyz[:, 0] == anchor).reshape(-1)
+    fp = EasyDict(filter_dict(sp, mask, ignore_keys=("frame_offsets", "frame_perm")))
+    fp.component = fp.component - fp.component.min()
+    st = tracker.host_init(sp, fp)
+    names = dict(stopped="stopped", moving="moving", transforms="transforms", comp_velos="comp_velos",
+                 comp_centers="comp_centers", comp_center_diffs="comp_center_diffs",
+                 comp_min_frame_id="comp_min_frame_id", comp_max_frame_id="comp_max_frame_id",
+                 last_xyz="last_xyz")
+    prev_dir = None
+    for s in range(int(g["num_steps"])):
+        d, nf = int(g[f"s{s}_track_dir"]), int(g[f"s{s}_next_frame_id"])
+        if s > 0:  # the reference's state after its step s-1
+            for ref_key, key in names.items():
+                st[key] = dev(g[f"s{s - 1}_{ref_key}"].copy())
+            st.frame.fxyz = dev(g[f"s{s - 1}_frame_fxyz"].copy())
+            last = int(g[f"s{s - 1}_next_frame_id"])
+            st.last_velo = st.comp_velos[:, last]
+            st.track_dir = int(g[f"s{s - 1}_track_dir"])
+            st.next_frame_id = last + st.track_dir
+        if d != prev_dir:
+            tracker.host_start_dir(st, sp, d)
+        prev_dir = d
+        assert tracker.host_can_step(st) and st.next_frame_id == nf
+        live = (~st.stopped).cpu().numpy()
+        st.smooth_iters = int(g[f"s{s}_smooth_iters"])
+        f_this, f_next = tracker.host_step(st, sp)
+        got = {k: st[k].cpu().numpy() for k in TS.DECISIONS + TS.CONTINUOUS + ("l1_reg_error", "comp_edge_ratio")}
+        got["frame_fxyz"] = st.frame.fxyz.cpu().numpy()
+        got["component"] = st.frame.component.cpu().numpy()
+        TS.check_step(s, g, got, live, (f_this.cpu().numpy(), f_next.cpu().numpy()))

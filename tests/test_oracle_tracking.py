@@ -6,6 +6,7 @@ scatter sums whose order is unspecified (its own results move by ~1e-5 run to ru
 nearest-neighbour flip can push one component across a stop rule. The oracle is therefore pinned
 (a) exactly on everything upstream of such flips (smooth_velo, diameters, per-call ICP: see
 test_oracle_registration.py) and (b) statistically on the end-to-end extraction. CPU."""
+import copy
 import os
 
 import numpy as np
@@ -62,3 +63,43 @@ def test_track_frame_vs_reference():
         d_near = np.abs(W[:, near] - M[:, near]).max(axis=(1, 2, 3))
         assert np.median(d_near) < 1e-4, np.median(d_near)
         assert np.median(np.abs(W - M).max(axis=(1, 2, 3))) < 0.5
+
+
+def test_track_frame_steps_teacher_forced():
+    """Every frame step of the oracle's loop from the reference's own state before it
+    (tests/_track_steps.py): decisions exact, continuous state to fp32 noise."""
+    from oracle import track_oracle as T
+    from tests import _track_steps as TS
+    g, gs = TS.load()
+    seq, _ = _seq(gs)
+    tracker = T.Tracker()
+    S = tracker.init_state(seq, int(g["anchor"]))
+    n = int(g["num_steps"])
+    assert n >= 8
+    prev_dir = None
+    free_iters = []
+    for s in range(n):
+        d, nf = int(g[f"s{s}_track_dir"]), int(g[f"s{s}_next_frame_id"])
+        if s > 0:
+            tracker.load_reference_state(S, g, s - 1)
+        if d != prev_dir:
+            tracker.start_dir(S, seq, d)
+        prev_dir = d
+        assert tracker.can_step(S) and S["nf"] == nf
+        live = ~S["stopped"]
+        # the same step free-running: smooth_velo's own stop rule lands within a few AdamW steps
+        S2 = copy.deepcopy(S)
+        S2["force_smooth_iters"] = None
+        tracker.step(S2, seq)
+        free_iters.append(abs(S2["smooth_iters"] - int(g[f"s{s}_smooth_iters"])))
+        S["force_smooth_iters"] = int(g[f"s{s}_smooth_iters"])
+        edges = tracker.step(S, seq)
+        got = dict(stopped=S["stopped"], moving=S["moving"], comp_min_frame_id=S["comp_min"],
+                   comp_max_frame_id=S["comp_max"], transforms=S["transforms"], comp_velos=S["comp_velos"],
+                   comp_centers=S["comp_centers"], comp_center_diffs=S["comp_center_diffs"],
+                   frame_fxyz=S["fr"]["fxyz"], component=S["comp"], l1_reg_error=S["l1_reg_error"],
+                   comp_edge_ratio=S["comp_edge_ratio"])
+        TS.check_step(s, g, got, live, edges)
+    assert max(free_iters) <= 4 and np.median(free_iters) == 0, free_iters
+    # the loop ends where the reference's ended: after its last step nothing is left to do forwards
+    assert not tracker.can_step(S) or S["nf"] > int(g[f"s{n - 1}_next_frame_id"])
