@@ -218,6 +218,8 @@ class ClusterTracking(nn.Module):
         keep &= dist < diameter[ekey] + 0.05
         keep &= dz > -0.05
         kidx = keep.nonzero(as_tuple=True)[0]
+        # rows in the reference's order: frame by frame ascending, within a frame by tracked voxel
+        kidx = kidx[torch.argsort(ext_frame[e_ext[kidx]], stable=True)]
         e_ext, e_ref = e_ext[kidx], e_ref[kidx]
         g_ref = e_ref + lo                       # row in the frame-grouped full-resolution arrays
         out_frame = v.frame[g_ref]
