@@ -39,7 +39,7 @@ namespace pcs {
 
 constexpr int kMaxLevels = 4;
 constexpr int kWg = 1024;  // one-workgroup kernels (sort, compaction)
-constexpr int kMaxGroups = 8;  // lock-step groups (streams) one call may drive
+constexpr int kMaxGroups = 16;  // lock-step groups (streams) one call may drive
 
 struct TrkState {
   int32_t active;     // any component still tracked (loop condition of the next step)
@@ -1016,8 +1016,10 @@ static inline int pow2_words(int64_t n) {
 // stream, event and pinned status page from call to call.
 class GroupWorkers {
  public:
+  // one pool per calling thread (several sequences may be tracked at once, each from its own host
+  // thread); never destroyed: the workers outlive main
   static GroupWorkers& get() {
-    static GroupWorkers* inst = new GroupWorkers();  // never destroyed: the threads outlive main
+    static thread_local GroupWorkers* inst = new GroupWorkers();
     return *inst;
   }
   void start(int slot, std::function<void()> job) {
@@ -1248,11 +1250,13 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     int c = e ? atoi(e) : 0;
     return (c >= 1 && c <= kMaxGroups) ? c : 4;
   }();
-  const int chunk = chunk_env;
+  // (G is fixed below; the one-launch form of the ICP loop runs a whole registration per tick)
   // rocprofiler-sdk on this image faults when kernels are launched from several native threads at
   // once: a profiled run takes one group (same kernels, same results)
   static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
   const int G = profiled ? 1 : (groups_env < n_units ? groups_env : n_units);
+  const bool one_launch = icp_one_launch((n_units + G - 1) / G, G);
+  const int chunk = one_launch ? (prm->max_iter > 0 ? prm->max_iter : 1) : chunk_env;
   struct Group {
     int n, base, live;
     int unit[kMaxBatch];
@@ -1361,7 +1365,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           break;
         }
         case PH_ICP: {
-          if (h.icp.err) return PCS_ERR_RANGE;
+          if (h.icp.err) return h.icp.err == 5 ? PCS_ERR_HIP : PCS_ERR_RANGE;
           if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
             s_fin.a[b_fin.n] = step_arg(h);
             h_fin[b_fin.n] = h.hint;
@@ -1535,7 +1539,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
       b_iter.idx[b_iter.n++] = i;
     }
     if (b_iter.n) {
-      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0));
+      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0, G));
       for (int e = 0; e < b_iter.n; ++e) {
         HostUnit& h = hu[b_iter.idx[e]];
         h.it_before = h.it;
@@ -1567,7 +1571,18 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         h.seen[h.lv][2] = (int)h.host.counts[3];
       }
     }
-    if (gr.b_iter.n) {
+    if (gr.b_iter.n && one_launch) {
+      double bytes = 0.0, its = 0.0;
+      for (int e = 0; e < gr.b_iter.n; ++e) {
+        HostUnit& h = hu[gr.b_iter.idx[e]];
+        h.icp = gr.pin_icp[e];
+        const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
+        const double ran = (double)(h.icp.iters - h.it_before);
+        bytes += ran * (76.0 * (Mn + Rn) + 272.0 * C + 68.0 * Mn + 416.0 * C);
+        its = ran > its ? ran : its;
+      }
+      icp_profile_account_launch(bytes, its, 0);
+    } else if (gr.b_iter.n) {
       int live_j[kIcpMaxChunk];
       double b3[3 * kIcpMaxChunk];
       for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
