@@ -166,14 +166,18 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
   int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
   int pos = atomicAdd(&g.fslot[fs].count, 1);
   atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << bit);
-  if (pos < kCellCap) {
-    g.spts[(size_t)fs * kCellCap + pos] = p;
-    g.sidx[(size_t)fs * kCellCap + pos] = i;
-  } else {
-    int o = atomicAdd(g.ovf, 1);
-    g.ovf_pts[o] = p;
-    g.ovf_idx[o] = i;
+  // (destination chosen in registers: written as two branches the stores were merged through a
+  // pointer table in scratch memory)
+  size_t at = (size_t)fs * kCellCap + (size_t)(pos < kCellCap ? pos : 0);
+  float4* dp = g.spts;
+  int32_t* di = g.sidx;
+  if (pos >= kCellCap) {
+    at = (size_t)atomicAdd(g.ovf, 1);
+    dp = g.ovf_pts;
+    di = g.ovf_idx;
   }
+  dp[at] = p;
+  di[at] = i;
 }
 
 static __global__ void __launch_bounds__(kBlock)

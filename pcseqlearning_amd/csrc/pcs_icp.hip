@@ -40,7 +40,6 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.geom = a.take<IcpGeom>(1);
   b.bounds = a.take<float>(24);  // ref, mov, all: 8 floats each
   b.state = a.take<IcpState>(1);
-  b.bar = a.take<IcpBarrier>(1);
   plan_grid2(a, Rn, b.gr);
   plan_grid2(a, Mn, b.gm[0]);
   plan_grid2(a, Mn, b.gm[1]);
@@ -108,7 +107,6 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.corg = b.corg;
   pr.cov = b.cov;
   pr.st = b.state;
-  pr.bar = b.bar;
   pr.geom = b.geom;
   pr.bounds = b.bounds;
   pr.gr = b.gr;
@@ -154,9 +152,6 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->wl_n = 0;
     st->ws_n = 0;
     st->dmax[0] = st->dmax[1] = 0u;
-    pr.bar->arrive = 0u;
-    pr.bar->done = 0u;
-    pr.bar->timeout = 0;
   }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {
     int e = (int)(q & 15);
@@ -266,7 +261,8 @@ icp_insert3_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
 // ONE workgroup from the per-component loss terms of the apply launch, summed in component order by
 // a fixed tree (independent of every launch geometry). It may lower stop_iter to k_done, which still
 // admits every kernel of iteration k_done.
-__device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done, double* red /* LDS [kBlock / 64] */) {
+__device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
+  __shared__ double red[kBlock / 64];
   IcpState* st = pr.st;
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
   double part = 0.0;
@@ -297,8 +293,7 @@ icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase,
   int k_last = kbase.v[blockIdx.x] + n_it;
   if (k_last > pr.max_iter) k_last = pr.max_iter;
   if (k_last > pr.st->iters) k_last = pr.st->iters;  // iterations that did not run have no loss
-  __shared__ double red[kBlock / 64];
-  icp_decide(pr, k_last, red);
+  icp_decide(pr, k_last);
   __syncthreads();
   if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;
 }
@@ -314,6 +309,7 @@ struct MomTable {
   int* skey;                      // LDS [kMomSlots]
   unsigned long long* sacc;       // LDS [kMomSlots * 17]
   unsigned long long* acc;        // global [C, kAcc] of the iteration
+  int C;                          // components (keys outside [0, C) are never flushed)
 };
 __device__ __forceinline__ void mom_init(const MomTable& t) {  // every thread of the workgroup; then a barrier
   for (int q = threadIdx.x; q < kMomSlots; q += kBlock) t.skey[q] = -1;
@@ -412,7 +408,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
   for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
     int sl = q / 17, a = q - sl * 17;
     int key = t.skey[sl];
-    if (key >= 0) atomicAdd(&t.acc[(int64_t)key * kAcc + a], t.sacc[q]);
+    if (key >= 0 && key < t.C) atomicAdd(&t.acc[(int64_t)key * kAcc + a], t.sacc[q]);
   }
 }
 
@@ -430,38 +426,41 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 //                         cell or so; blockIdx.z = 1: the cooperative search (32 lanes per query)
 //                         for the rest -- and for every query in iteration 1.
 // Exact: the same neighbours as a full search, always.
-// The three steps of iteration k are device functions over a (bx of nbx) slice of workgroups, shared by
-// the three-launch form (one kernel each, bx = blockIdx.x) and the one-launch form (icp_iterate_kernel:
-// the steps separated by grid barriers). LDS comes from the caller: the moment table `mt` (initialised
-// before, flushed after) and `red` for the stop rule.
-struct IcpLds {
-  int skey[kMomSlots];
-  unsigned long long sacc[kMomSlots * 17];
-  double red[kBlock / 64];
-};
-__device__ __forceinline__ MomTable icp_mom_table(const IcpProblem& pr, int k, IcpLds& l) {
-  return MomTable{l.skey, l.sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc};
-}
-
-__device__ __forceinline__ void icp_step_nn(const IcpProblem& pr, const int k, const int bx, const int nbx,
-                                         const MomTable mt, double* red) {
+__global__ void __launch_bounds__(kBlock)
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
-  if (k > pr.max_iter || k > st->stop_iter) return;
+  // The gate is read ONCE per workgroup. Workgroup 0 lowers stop_iter during this very launch (below),
+  // and the waves of a workgroup do not start together: with a per-thread gate some waves of a
+  // workgroup could leave while the others go on with a moment table in LDS that is only partly
+  // initialised -- whatever another stream's kernel left there then served as component ids in
+  // mom_flush (an out-of-range atomic: the memory fault seen once in ~50 sequences with two or more
+  // lock-step groups in flight, never with one).
+  __shared__ int s_go;
+  if (threadIdx.x == 0) s_go = (k > pr.max_iter || k > st->stop_iter) ? 0 : 1;
+  __syncthreads();
+  if (!s_go) return;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
   const int nround = (nq + kBlock - 1) / kBlock;
-  if (bx != 0 && bx >= nround) return;
-  // iteration k, first step: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
-  // were written by the previous step). The other workgroups may run before the stop is known:
+  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
+  // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (bx == 0) icp_decide(pr, k - 1, red);
+  if (blockIdx.x == 0) icp_decide(pr, k - 1);
   if (k == 1) {  // no neighbours yet: every query takes the cooperative search
-    for (int q = bx * kBlock + threadIdx.x; q < nq; q += nbx * kBlock) pr.wl[q] = q;
-    if (bx == 0 && threadIdx.x == 0) st->wl_n = nq;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->wl_n = nq;
     return;
   }
+  __shared__ int skey[kMomSlots];
+  __shared__ unsigned long long sacc[kMomSlots * 17];
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
   const double lim2 = icp_limit_sq(nq);
+  mom_init(mt);
+  __syncthreads();
   GridDesc g = pr.geom->g;
   const int lane = threadIdx.x & 63;
   int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
@@ -475,7 +474,7 @@ __device__ __forceinline__ void icp_step_nn(const IcpProblem& pr, const int k, c
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
   // steps of the moving points in iteration k-1, by the place they moved into
   const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
-  for (int r = bx; r < nround; r += nbx) {  // whole waves stay together (ballots below)
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
@@ -557,28 +556,21 @@ __device__ __forceinline__ void icp_step_nn(const IcpProblem& pr, const int k, c
       if (to_coop) pr.wl[base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
     }
   }
-}
-
-__global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
-  if (k > pr.max_iter || k > pr.st->stop_iter) return;
-  __shared__ IcpLds lds;
-  const MomTable mt = icp_mom_table(pr, k, lds);
-  mom_init(mt);
-  __syncthreads();
-  icp_step_nn(pr, k, blockIdx.x, gridDim.x, mt, lds.red);
   __syncthreads();
   mom_flush(mt);
 }
 
-// which: 0 = the list of searches around the old partner (eight lanes per query), 1 = the list of
-// cooperative searches (32 lanes per query), 2 = both, one after the other
-__device__ __forceinline__ void icp_step_search(const IcpProblem& pr, const int k, const int bx, const int nbx,
-                                             const MomTable mt, const int which) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
   if (k > pr.max_iter || k > st->stop_iter) return;
+  const bool coop = blockIdx.z == 1;
+  const int nw = coop ? st->wl_n : st->ws_n;
+  const int per_block = coop ? kBlock / 32 : kBlock / 8;
+  const int nround = (nw + per_block - 1) / per_block;
+  if ((int)blockIdx.x >= nround) return;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   GridDesc g = pr.geom->g;
@@ -587,12 +579,15 @@ __device__ __forceinline__ void icp_step_search(const IcpProblem& pr, const int 
   float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
   float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  __shared__ int skey[kMomSlots];
+  __shared__ unsigned long long sacc[kMomSlots * 17];
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
   const double lim2 = icp_limit_sq(Mn + Rn);
-  if (which != 0) {
-    const int nw = st->wl_n;
-    const int nround = (nw + kBlock / 32 - 1) / (kBlock / 32);
+  mom_init(mt);
+  __syncthreads();
+  if (coop) {
     const int sub = threadIdx.x & 31;
-    for (int r = bx; r < nround; r += nbx) {
+    for (int r = blockIdx.x; r < nround; r += gridDim.x) {
       const int w = r * (kBlock / 32) + (threadIdx.x >> 5);
       const bool valid = w < nw;
       const int qid = valid ? pr.wl[w] : 0;
@@ -623,13 +618,13 @@ __device__ __forceinline__ void icp_step_search(const IcpProblem& pr, const int 
         }
       }
     }
+    __syncthreads();
+    mom_flush(mt);
+    return;
   }
-  if (which == 1) return;
-  const int nw = st->ws_n;
-  const int nround = (nw + kBlock / 8 - 1) / (kBlock / 8);
   const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
   const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
-  for (int r = bx; r < nround; r += nbx) {  // whole waves stay together (shuffles inside)
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles inside)
     const int w = r * (kBlock / 8) + (threadIdx.x >> 3);
     const bool valid = w < nw;
     const int qid = valid ? pr.wls[w] : 0;
@@ -666,24 +661,6 @@ __device__ __forceinline__ void icp_step_search(const IcpProblem& pr, const int 
       }
     }
   }
-}
-
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
-  if (k > pr.max_iter || k > pr.st->stop_iter) return;
-  {
-    const bool coop = blockIdx.z == 1;
-    const int nw = coop ? pr.st->wl_n : pr.st->ws_n;
-    const int per_block = coop ? kBlock / 32 : kBlock / 8;
-    if ((int)blockIdx.x >= (nw + per_block - 1) / per_block) return;
-  }
-  __shared__ IcpLds lds;
-  const MomTable mt = icp_mom_table(pr, k, lds);
-  mom_init(mt);
-  __syncthreads();
-  icp_step_search(pr, k, blockIdx.x, gridDim.x, mt, blockIdx.z == 1 ? 1 : 0);
   __syncthreads();
   mom_flush(mt);
 }
@@ -693,17 +670,20 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
 __device__ __forceinline__ void centres(const long long* __restrict__ a, const double* org,
                                         double* cm, double* cr, double* sp, double* sq) {
   double n = (double)a[0];
+#pragma unroll
   for (int d = 0; d < 3; ++d) {
     sp[d] = (double)a[1 + d] * kFxInv;
     sq[d] = (double)a[4 + d] * kFxInv;
   }
-  if (n > 0.5) {
-    for (int d = 0; d < 3; ++d) {
-      cm[d] = (double)(float)(sp[d] / n + org[d]);
-      cr[d] = (double)(float)(sq[d] / n + org[d]);
-    }
-  } else {
-    for (int d = 0; d < 3; ++d) cm[d] = cr[d] = 0.0;
+  // (selects, not branches around indexed stores: the arrays stay in registers)
+  const bool any = n > 0.5;
+  const double nn = any ? n : 1.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double m = (double)(float)(sp[d] / nn + org[d]);
+    const double r = (double)(float)(sq[d] / nn + org[d]);
+    cm[d] = any ? m : 0.0;
+    cr[d] = any ? r : 0.0;
   }
 }
 
@@ -785,23 +765,27 @@ __device__ inline void svd3(const double M[9], double U[9], double S[3], double 
       }
     if (off < 1e-15) break;
   }
+#pragma unroll
   for (int j = 0; j < 3; ++j)
     S[j] = sqrt(A[0 * 3 + j] * A[0 * 3 + j] + A[1 * 3 + j] * A[1 * 3 + j] + A[2 * 3 + j] * A[2 * 3 + j]);
-  int ord[3] = {0, 1, 2};
-  for (int a = 0; a < 2; ++a)
-    for (int b = a + 1; b < 3; ++b)
-      if (S[ord[b]] > S[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
-  double A2[9], V2[9], S2[3];
-  for (int j = 0; j < 3; ++j) {
-    S2[j] = S[ord[j]];
-    for (int i = 0; i < 3; ++i) { A2[i * 3 + j] = A[i * 3 + ord[j]]; V2[i * 3 + j] = V[i * 3 + ord[j]]; }
+  // columns by descending singular value: three compare-and-swaps of whole columns (no indexed
+  // access: the arrays stay in registers, the kernel needs no scratch memory)
+#define PCS_SVD_SWAP(a, b)                                             \
+  if (S[b] > S[a]) {                                                   \
+    double ts = S[a]; S[a] = S[b]; S[b] = ts;                          \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                    \
+      double ta = A[i * 3 + a]; A[i * 3 + a] = A[i * 3 + b]; A[i * 3 + b] = ta; \
+      double tv = V[i * 3 + a]; V[i * 3 + a] = V[i * 3 + b]; V[i * 3 + b] = tv; \
+    }                                                                  \
   }
+  PCS_SVD_SWAP(0, 1)
+  PCS_SVD_SWAP(0, 2)
+  PCS_SVD_SWAP(1, 2)
+#undef PCS_SVD_SWAP
+#pragma unroll
   for (int j = 0; j < 3; ++j) {
-    S[j] = S2[j];
-    for (int i = 0; i < 3; ++i) {
-      V[i * 3 + j] = V2[i * 3 + j];
-      U[i * 3 + j] = S2[j] > 1e-300 ? A2[i * 3 + j] / S2[j] : 0.0;
-    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) U[i * 3 + j] = S[j] > 1e-300 ? A[i * 3 + j] / S[j] : 0.0;
   }
   // complete U when a singular value vanished (rank-deficient M): orthonormal completion
   if (S[2] <= 1e-300) {
@@ -809,7 +793,7 @@ __device__ inline void svd3(const double M[9], double U[9], double S[3], double 
       if (S[0] <= 1e-300) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
       double u0[3] = {U[0], U[3], U[6]};
       int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
-      double e[3] = {0, 0, 0}; e[k] = 1.0;
+      double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
       double d = e[0] * u0[0] + e[1] * u0[1] + e[2] * u0[2];
       double w[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
       double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
@@ -927,7 +911,10 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
 // buffer k) and the loss term. The previous positions are kept for the l1 passes. The moved points go
 // straight into the grid of the next iteration (the moving grid is double-buffered: no separate
 // build launch), and the grid this iteration searched is reset.
-__device__ __forceinline__ void icp_step_apply(const IcpProblem& pr, const int k, const int bx, const int nbx) {
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
   if (k > pr.max_iter || k > st->stop_iter) return;
   int Mn, Rn, Ra;
@@ -942,11 +929,10 @@ __device__ __forceinline__ void icp_step_apply(const IcpProblem& pr, const int k
   double* __restrict__ Tb = pr.Tb;
   const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
   const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
-  const int64_t tid = bx * (int64_t)kBlock + threadIdx.x;
-  const int64_t nthreads = (int64_t)nbx * kBlock;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
-  g2_clear(gm_done, tid, nthreads);
+  g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
   if (tid == 0) {
     st->iters = k;
     st->wl_n = 0;                 // the work lists of iteration k have been served
@@ -955,13 +941,13 @@ __device__ __forceinline__ void icp_step_apply(const IcpProblem& pr, const int k
   }
   {  // the step table of iteration k+1 (nothing reads it during this launch)
     unsigned int* nxt = pr.sstep + (size_t)((k + 1) & 1) * kStepH;
-    for (int64_t q = tid; q < kStepH; q += nthreads) nxt[q] = 0u;
+    for (int64_t q = tid; q < kStepH; q += (int64_t)gridDim.x * blockDim.x) nxt[q] = 0u;
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   float step = 0.f;  // largest step of this thread's points
   const GridDesc d = pr.geom->g;
   const int nround = (Mn + kBlock - 1) / kBlock;
-  for (int r = bx; r < nround; r += nbx) {  // whole workgroups stay together (shuffles)
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
     const int i = r * kBlock + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < Mn) {
@@ -1003,103 +989,6 @@ __device__ __forceinline__ void icp_step_apply(const IcpProblem& pr, const int k
   }
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
-}
-
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  icp_step_apply(tab[bt.idx[blockIdx.y]], kbase.v[blockIdx.y] + 1 + j, blockIdx.x, gridDim.x);
-}
-
-// ---- iterations in ONE launch. The grid's workgroups are dealt to the batch entries (workgroup b
-// serves entry b % n); the three steps of an iteration are separated by grid barriers (an arrival
-// counter in device memory; every workgroup passes every barrier, whatever its entry still has to do),
-// so an iteration costs three barrier round trips instead of three launches, the table entry, sizes and
-// grid description stay in registers, and the loop ends on the device as soon as every entry has
-// stopped -- the host launches once per registration and reads the state words once.
-// All workgroups must be resident together: the host sizes the grid far below what the device holds
-// (icp_iterate_blocks), and the wait is bounded: on time-out the error word is set and every wave exits.
-__device__ __forceinline__ bool icp_grid_barrier(IcpBarrier* g, unsigned target, int* ok_s) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // release: this workgroup's writes reach the other XCDs' view before the arrival is counted
-    __hip_atomic_fetch_add(&g->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    bool ok = false;
-    // relaxed polls (an acquire per poll would invalidate the caches of the workgroups still at work)
-    for (int spin = 0; spin < (1 << 21); ++spin) {
-      if (__hip_atomic_load(&g->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
-      if (__hip_atomic_load(&g->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!ok) __hip_atomic_store(&g->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *ok_s = ok ? 1 : 0;
-  }
-  __syncthreads();
-  return *ok_s != 0;
-}
-
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 8)))
-icp_iterate_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int n_it,
-                   IcpState* __restrict__ out) {
-  IcpBarrier* bar = tab[bt.idx[0]].bar;  // of the batch's first entry: an entry is in one batch at a time
-  __shared__ IcpLds lds;
-  __shared__ int ok_s;
-  const int n = bt.n, NB = (int)gridDim.x;
-  const int e = (int)blockIdx.x % n, bx = (int)blockIdx.x / n, nbx = (NB - e + n - 1) / n;
-  const IcpProblem& pr = tab[bt.idx[e]];
-  const int k0 = kbase.v[e];
-  unsigned nbar = 0;
-  bool ok = true;
-  for (int j = 0; j < n_it; ++j) {
-    const int k = k0 + 1 + j;
-    const MomTable mt = icp_mom_table(pr, k, lds);
-    mom_init(mt);
-    __syncthreads();
-    icp_step_nn(pr, k, bx, nbx, mt, lds.red);
-    ok = icp_grid_barrier(bar, ++nbar * (unsigned)NB, &ok_s);
-    if (!ok) break;
-    // every stop rule of iteration k-1 has been settled (by workgroup 0 of its entry, before the
-    // barrier) and nothing writes a stop word until the next first step: the same answer everywhere
-    bool alive = false;
-    for (int q = 0; q < n; ++q) {
-      const IcpProblem& pq = tab[bt.idx[q]];
-      const int kq = kbase.v[q] + 1 + j;
-      const int stop = __hip_atomic_load(&pq.st->stop_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      alive = alive || (kq <= pq.max_iter && kq <= stop);
-    }
-    if (!alive) break;
-    icp_step_search(pr, k, bx, nbx, mt, 2);
-    __syncthreads();
-    mom_flush(mt);  // the budget test's pairs and the searches' pairs in one flush
-    ok = icp_grid_barrier(bar, ++nbar * (unsigned)NB, &ok_s);
-    if (!ok) break;
-    icp_step_apply(pr, k, bx, nbx);
-    ok = icp_grid_barrier(bar, ++nbar * (unsigned)NB, &ok_s);
-    if (!ok) break;
-  }
-  if (bx == 0) {
-    // the stop rule of the entry's last iteration (settled already when the loop ended early), and the
-    // state mirrored where the host reads it
-    if (ok) {
-      int k_last = k0 + n_it;
-      if (k_last > pr.max_iter) k_last = pr.max_iter;
-      if (k_last > pr.st->iters) k_last = pr.st->iters;
-      icp_decide(pr, k_last, lds.red);
-    } else if (threadIdx.x == 0) {
-      pr.st->err = 5;  // barrier time-out
-    }
-    __syncthreads();
-    if (out && threadIdx.x == 0) out[e] = *pr.st;
-  }
-  // the last workgroup to leave re-arms the barrier for the stream's next launch
-  if (threadIdx.x == 0) {
-    unsigned d = __hip_atomic_fetch_add(&bar->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == (unsigned)NB - 1u) {
-      __hip_atomic_store(&bar->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&bar->timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&bar->done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
@@ -1186,43 +1075,8 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
   return PCS_OK;
 }
 
-// One-launch form: how many workgroups the loop kernel may take. All of them must be resident at once
-// (they meet at grid barriers), together with those of every other loop kernel in flight: `share` is
-// the number of streams that may run one concurrently, and only half of what the device can hold is
-// ever claimed. 0 = not enough room: the caller takes the three-launch form.
-static int icp_iterate_capacity() {
-  static const int cap = [] {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_iterate_kernel, kBlock, 0) != hipSuccess) return 0;
-    return per_cu * prop.multiProcessorCount;
-  }();
-  return cap;
-}
-// Opt-in (PCS_ICP_ONE_LAUNCH=1). Measured on MI355X (20 x 160 k sequence, tools/stage_times.py): the
-// tracking stage takes 340-400 ms in this form against 190 ms with three launches per iteration. A grid
-// that must stay resident beside the other groups' is a few thousand lanes per tracking unit, and the
-// searches (8 or 32 lanes per query) want hundreds of thousands for a few microseconds; the stream of
-// the three-launch form is 98 % busy as it is (kernel trace, profiles/r02_*), so there is no launch gap
-// to win back. Kept for small problems and as the A/B check of the step functions.
-static bool icp_one_launch_enabled() {
-  static const bool on = [] { const char* e = getenv("PCS_ICP_ONE_LAUNCH"); return e && atoi(e) != 0; }();
-  return on;
-}
-static int icp_blocks_per_entry_env() {
-  static const int v = [] { const char* e = getenv("PCS_ICP_BLOCKS_PER_ENTRY"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
-bool icp_one_launch(int n_entries, int share) {
-  if (!icp_one_launch_enabled() || n_entries < 1) return false;
-  if (share < 1) share = 1;
-  return icp_iterate_capacity() / (2 * share) >= n_entries;
-}
-
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot, int share) {
+                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot) {
   if (bt.n < 1 || n_it < 1) return PCS_OK;
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
@@ -1232,27 +1086,6 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
     int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
     if (qe > q) q = qe;
     if (hints[e].Mn > m) m = hints[e].Mn;
-  }
-  if (icp_one_launch(bt.n, share)) {
-    if (share < 1) share = 1;
-    const int budget = icp_iterate_capacity() / (2 * share);
-    // two rounds of the budget test per workgroup at the expected sizes, within the budget
-    int per_entry = icp_blocks_per_entry_env() > 0 ? icp_blocks_per_entry_env() : gx_for(q, 2 * kBlock, 256);
-    if (per_entry * bt.n > budget) per_entry = budget / bt.n;
-    const int NB = per_entry * bt.n;
-    bool prof = g_prof_on;
-    if (prof && !t_ev.have) {
-      for (int i = 0; i < 6 * kProfChunk; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
-      t_ev.have = true;
-    }
-    t_ev_used = prof ? -1 : 0;  // -1: one launch carried the events
-    if (prof)
-      hipExtLaunchKernelGGL(icp_iterate_kernel, dim3(NB), dim3(kBlock), 0, s, t_ev.ev[0], t_ev.ev[1], 0, tab, bt,
-                            kbase, n_it, out);
-    else
-      icp_iterate_kernel<<<NB, kBlock, 0, s>>>(tab, bt, kbase, n_it, out);
-    PCS_LAUNCH_CHECK();
-    return PCS_OK;
   }
   bool any_first = false;
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
@@ -1288,23 +1121,6 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   icp_decide_kernel<<<bt.n, kBlock, 0, s>>>(tab, bt, kbase, n_it, out);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
-}
-
-// after the stream has been synchronised: the one-launch form's kernel time and the algorithmic bytes
-// of the iterations it ran (all three steps) go to profile slot 0
-void icp_profile_account_launch(double bytes, double iterations, int prof_slot) {
-  if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
-  ProfEvents& t_ev = t_evs[prof_slot];
-  int& t_ev_used = t_ev_useds[prof_slot];
-  if (!g_prof_on || t_ev_used != -1) return;
-  t_ev_used = 0;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, t_ev.ev[0], t_ev.ev[1]) != hipSuccess) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof[0].ms += ms;
-  g_prof[0].launches += 1.0;
-  g_prof[0].bytes += bytes;
-  g_prof[1].launches += iterations;  // (slot 1 is otherwise unused: iterations inside the launches)
 }
 
 // after the stream has been synchronised: add the chunk's launches to the profile. live[j] = number
@@ -1437,8 +1253,6 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   }
   if (chunk < 1) chunk = 8;
   if (chunk > kProfChunk) chunk = kProfChunk;
-  const bool one_launch = icp_one_launch(1, 1);
-  if (one_launch) chunk = max_iter > 0 ? max_iter : 1;  // the loop leaves on the device when it has stopped
   Batch bt;
   bt.n = 1;
   bt.idx[0] = 0;
@@ -1458,15 +1272,12 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
     BatchInts kb;
     kb.v[0] = it;
-    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s, 0, 1);
+    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s, 0);
     if (rc) return rc;
     if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (pin) host = *pin;
-    if (one_launch) {
-      const double ran = (double)(host.iters - it);
-      icp_profile_account_launch(ran * (by_nn + by_app), ran, 0);
-    } else {
+    {
       int live[kProfChunk];
       double b3[3 * kProfChunk];
       for (int j = 0; j < n_it; ++j) {
@@ -1476,7 +1287,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
       icp_profile_account(n_it, live, b3, 0);
     }
     it += n_it;
-    if (host.err) return host.err == 5 ? PCS_ERR_HIP : PCS_ERR_RANGE;
+    if (host.err) return PCS_ERR_RANGE;
     if (host.stop_iter != INT_MAX) break;
   }
   info[0] = host.iters;

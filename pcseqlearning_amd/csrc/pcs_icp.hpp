@@ -64,13 +64,6 @@ __host__ __device__ inline int icp_step_slot(int sx, int sy, int sz) {
 struct IcpGeom {
   GridDesc g;
 };
-// grid barrier of the one-launch form (icp_iterate_kernel): arrivals, workgroups that have left, time-out
-struct IcpBarrier {
-  unsigned int arrive;
-  unsigned int done;
-  int timeout;
-  int pad;
-};
 // largest admissible squared distance of a point from its component origin: ne products of that size
 // stay below 2^62 in fixed point
 __host__ __device__ inline double icp_limit_sq(int ne) {
@@ -97,7 +90,6 @@ struct IcpProblem {
   float4* corg;         // [C] origin of the component's fixed-point moments
   int32_t* cov;         // [C] matched moving points in the final coverage query
   IcpState* st;
-  IcpBarrier* bar;
   IcpGeom* geom;
   float* bounds;        // [24] min/max of ref, mov, all
   Grid2 gr, ga, gm[2];  // reference (non-stationary / all), moving (double-buffered)
@@ -130,7 +122,6 @@ struct IcpBufs {
   IcpGeom* geom;
   float* bounds;
   IcpState* state;
-  IcpBarrier* bar;
   Grid2 gr, ga, gm[2];
   int32_t *nn_f, *nn_b, *wl, *wls;
   unsigned int* sstep;
@@ -178,13 +169,8 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
 // enqueue n_it iterations (entry e runs iterations kbase[e]+1 .. kbase[e]+n_it, gated by its stop
 // word and max_iter), then the stop rule of the last one; the states are mirrored to out[e] (may be
 // pinned host memory, may be nullptr)
-// ONE launch when the device has room (icp_one_launch: the loop kernel's workgroups meet at grid
-// barriers and leave when every entry has stopped), else three launches per iteration. `share` = how
-// many streams may have such a launch in flight at the same time (it bounds the grid).
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot, int share);
-bool icp_one_launch(int n_entries, int share);
-void icp_profile_account_launch(double bytes, double iterations, int prof_slot);
+                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot);
 // enqueue: l1 error of the last iteration, coverage ratio, outputs
 int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
                        hipStream_t s);

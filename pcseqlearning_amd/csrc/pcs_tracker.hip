@@ -39,7 +39,7 @@ namespace pcs {
 
 constexpr int kMaxLevels = 4;
 constexpr int kWg = 1024;  // one-workgroup kernels (sort, compaction)
-constexpr int kMaxGroups = 16;  // lock-step groups (streams) one call may drive
+constexpr int kMaxGroups = 8;  // lock-step groups (streams) one call may drive
 
 struct TrkState {
   int32_t active;     // any component still tracked (loop condition of the next step)
@@ -338,6 +338,11 @@ trk_comp_init_kernel(int C, int F, int W, int frame_id, float max_diam, const fl
 // grid description of the harvest searches (1-NN of the target frame's points among the moved
 // anchor points, radius NN_GRAPH.RADIUS): one for the whole sequence, padded so that tracked points
 // stay inside the cell range
+// one table slot <- a descriptor passed by value
+__global__ void trk_store_icp_kernel(IcpProblem* __restrict__ slot, IcpProblem desc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *slot = desc;
+}
+
 __global__ void trk_hdesc_kernel(const float* __restrict__ b8, float radius, float cell, float pad,
                                  GridDesc* __restrict__ g) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1016,10 +1021,8 @@ static inline int pow2_words(int64_t n) {
 // stream, event and pinned status page from call to call.
 class GroupWorkers {
  public:
-  // one pool per calling thread (several sequences may be tracked at once, each from its own host
-  // thread); never destroyed: the workers outlive main
   static GroupWorkers& get() {
-    static thread_local GroupWorkers* inst = new GroupWorkers();
+    static GroupWorkers* inst = new GroupWorkers();  // never destroyed: the threads outlive main
     return *inst;
   }
   void start(int slot, std::function<void()> job) {
@@ -1077,7 +1080,7 @@ using namespace pcs;
     if (_rc) return _rc;        \
   } while (0)
 
-static_assert(kPinnedStageOff + kMaxBatch * (sizeof(UnitDev) + sizeof(IcpProblem)) <= kPinnedPageBytes,
+static_assert(kPinnedStageOff + kMaxBatch * sizeof(UnitDev) <= kPinnedPageBytes,
               "descriptor staging does not fit the pinned page");
 static_assert(kMaxBatch * sizeof(TrkState) <= kPinnedStageOff - kPinnedTrackerOff, "tracker state mirror");
 static_assert(kMaxBatch * sizeof(IcpState) <= 2048, "ICP state mirrors");
@@ -1105,7 +1108,6 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   IcpState* pin_fin = (IcpState*)(page + 2048);  // states of the registrations that finished this tick
   TrkState* pin_trk = (TrkState*)(page + kPinnedTrackerOff);
   UnitDev* stage_units = (UnitDev*)(page + kPinnedStageOff);
-  IcpProblem* stage_icp = (IcpProblem*)(page + kPinnedStageOff + kMaxBatch * sizeof(UnitDev));
 
   Arena a(ws, ws_bytes);
   EnginePlan eng;
@@ -1250,13 +1252,11 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     int c = e ? atoi(e) : 0;
     return (c >= 1 && c <= kMaxGroups) ? c : 4;
   }();
-  // (G is fixed below; the one-launch form of the ICP loop runs a whole registration per tick)
+  const int chunk = chunk_env;
   // rocprofiler-sdk on this image faults when kernels are launched from several native threads at
   // once: a profiled run takes one group (same kernels, same results)
   static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
   const int G = profiled ? 1 : (groups_env < n_units ? groups_env : n_units);
-  const bool one_launch = icp_one_launch((n_units + G - 1) / G, G);
-  const int chunk = one_launch ? (prm->max_iter > 0 ? prm->max_iter : 1) : chunk_env;
   struct Group {
     int n, base, live;
     int unit[kMaxBatch];
@@ -1268,7 +1268,6 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     hipEvent_t ev;
     IcpState *pin_icp, *pin_fin;
     TrkState* pin_trk;
-    IcpProblem* stage_icp;
     int rc;
   };
   Group grp[kMaxGroups];
@@ -1365,7 +1364,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           break;
         }
         case PH_ICP: {
-          if (h.icp.err) return h.icp.err == 5 ? PCS_ERR_HIP : PCS_ERR_RANGE;
+          if (h.icp.err) return PCS_ERR_RANGE;
           if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
             s_fin.a[b_fin.n] = step_arg(h);
             h_fin[b_fin.n] = h.hint;
@@ -1515,8 +1514,10 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         ia.T = d.Tl;
         ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
         ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
-        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &gr.stage_icp[i]));
-        PCS_CHECK_HIP(hipMemcpyAsync(eng.d_icp + i, &gr.stage_icp[i], sizeof(IcpProblem), hipMemcpyHostToDevice, gs));
+        // the descriptor travels as a kernel argument (no copy engine, no staging buffer to keep alive)
+        IcpProblem desc;
+        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &desc));
+        trk_store_icp_kernel<<<1, 64, 0, gs>>>(eng.d_icp + i, desc);
         // launch sizes: what this level had at the previous step, else a guess
         const int* sn = h.seen[h.lv];
         h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
@@ -1539,7 +1540,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
       b_iter.idx[b_iter.n++] = i;
     }
     if (b_iter.n) {
-      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0, G));
+      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0));
       for (int e = 0; e < b_iter.n; ++e) {
         HostUnit& h = hu[b_iter.idx[e]];
         h.it_before = h.it;
@@ -1571,18 +1572,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         h.seen[h.lv][2] = (int)h.host.counts[3];
       }
     }
-    if (gr.b_iter.n && one_launch) {
-      double bytes = 0.0, its = 0.0;
-      for (int e = 0; e < gr.b_iter.n; ++e) {
-        HostUnit& h = hu[gr.b_iter.idx[e]];
-        h.icp = gr.pin_icp[e];
-        const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
-        const double ran = (double)(h.icp.iters - h.it_before);
-        bytes += ran * (76.0 * (Mn + Rn) + 272.0 * C + 68.0 * Mn + 416.0 * C);
-        its = ran > its ? ran : its;
-      }
-      icp_profile_account_launch(bytes, its, 0);
-    } else if (gr.b_iter.n) {
+    if (gr.b_iter.n) {
       int live_j[kIcpMaxChunk];
       double b3[3 * kIcpMaxChunk];
       for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
@@ -1625,7 +1615,6 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     gr.pin_icp = (IcpState*)pg;
     gr.pin_fin = (IcpState*)(pg + 2048);
     gr.pin_trk = (TrkState*)(pg + kPinnedTrackerOff);
-    gr.stage_icp = (IcpProblem*)(pg + kPinnedStageOff + kMaxBatch * sizeof(UnitDev));
     int rc = enqueue_tick(gi);
     while (rc == PCS_OK && gr.inflight) {
       if (hipEventSynchronize(gr.ev) != hipSuccess) { rc = PCS_ERR_HIP; break; }

@@ -180,75 +180,132 @@ class ClusterTracking(nn.Module):
 
     def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes, views=None):
         """Map tracked voxels back to the full-resolution points of each frame and update the
-        per-box best IoU (cluster_tracking.py:287-428). The reference loops over the frames; here
-        all frames go through one radius-graph call (edges never cross frames), the per-(frame,
-        component) centres / diameters are segment reductions on a combined key, and the GT
-        bookkeeping is the histogram form of eval_utils."""
+        per-box best IoU (cluster_tracking.py:287-428): `extract_traces_of_units` for one unit."""
+        full = self.extract_traces_of_units(all_points, [extracted], seq_boxes, views)[0]
+        return full, seq_boxes
+
+    def extract_traces_of_units(self, all_points, extracted_list, seq_boxes, views=None):
+        """cluster_tracking.py:287-428 for several tracking units at once (the reference runs it per
+        unit and, inside, per frame). The units' tracked voxels are concatenated with their component
+        ids offset, so that a (unit, component) pair is one id: all frames of all units go through ONE
+        radius-graph call (edges never cross frames; a query belongs to one unit), the per-(frame,
+        component) centres / diameters are segment reductions on a combined key, the GT bookkeeping is
+        the histogram form of eval_utils, and best_iou -- a running maximum over units in the
+        reference -- is one scatter-max. Returns the reference's `full_extracted` per unit, rows in the
+        reference's order (frame ascending, then tracked voxel); seq_boxes.best_iou is updated in place.
+        Units without any tracked voxel come back unchanged (the reference skips the call for them)."""
         if views is None:
             views = self.sequence_views(all_points, seq_boxes)
         v = views
-        transforms = extracted.pop("transforms")
-        num_components = int(extracted.component.max().long().item()) + 1
-        comp_sg = IndexSegments(extracted.component, num_components)
-        component_hit = extracted.component.new_zeros(num_components)
-        size_min = segment_min(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
-        size_max = segment_max(extracted.fxyz[:, 0], comp_sg, num_components).round().long()
+        out = list(extracted_list)
+        todo = [i for i, ex in enumerate(extracted_list) if ex.fxyz.shape[0] > 0]
+        if not todo:
+            return out
+        exs = [extracted_list[i] for i in todo]
+        transforms = [ex.pop("transforms") for ex in exs]
+        rows = [ex.fxyz.shape[0] for ex in exs]
+        # one host read for all units: components per unit and the frame range
+        stats = torch.stack([torch.stack([ex.component.max().long(), ex.fxyz[:, 0].min().round().long(),
+                                          ex.fxyz[:, 0].max().round().long()]) for ex in exs]).tolist()
+        ncomp = [s[0] + 1 for s in stats]
+        f_lo, f_hi = min(s[1] for s in stats), max(s[2] for s in stats)
+        coff = [0]
+        for c in ncomp:
+            coff.append(coff[-1] + c)
+        num_components = coff[-1]
+        dev = exs[0].fxyz.device
+        fxyz = torch.cat([ex.fxyz for ex in exs]) if len(exs) > 1 else exs[0].fxyz
+        comp = torch.cat([ex.component.long() + coff[u] for u, ex in enumerate(exs)])
+        moving = torch.cat([ex.moving for ex in exs])
+        unit = torch.repeat_interleave(torch.arange(len(exs), device=dev), torch.tensor(rows, device=dev))
+        comp_sg = IndexSegments(comp, num_components)
+        component_hit = comp.new_zeros(num_components)
+        size_min = segment_min(fxyz[:, 0], comp_sg, num_components).round().long()
+        size_max = segment_max(fxyz[:, 0], comp_sg, num_components).round().long()
         component_size = size_max - size_min + 1
-        ext_frame = extracted.fxyz[:, 0].round().long()
-        f_lo, f_hi = int(ext_frame.min().item()), int(ext_frame.max().item())
-        lo, hi = v.frame_start_host[f_lo], v.frame_start_host[f_hi + 1]
-        ref_fxyz = v.fxyz[lo:hi]
+        ext_frame = fxyz[:, 0].round().long()
+        # 1-NN of every full-resolution point among the tracked voxels OF ONE UNIT (the graph's "ref" set
+        # is the voxels, its queries the full-resolution points of the unit's frame range): the units
+        # are kept apart by shifting the frame coordinate of unit u by u * stride on both sides
+        stride = v.num_frames + 2
+        q_lo = [v.frame_start_host[s[1]] for s in stats]
+        q_hi = [v.frame_start_host[s[2] + 1] for s in stats]
+        q_off = [0]
+        for a, b in zip(q_lo, q_hi):
+            q_off.append(q_off[-1] + (b - a))
+        if len(exs) == 1:
+            vox, queries = fxyz, v.fxyz[q_lo[0]:q_hi[0]]
+        else:
+            vox = fxyz.clone()
+            vox[:, 0] += (unit * stride).to(vox.dtype)
+            queries = torch.cat([v.fxyz[a:b] for a, b in zip(q_lo, q_hi)])
+            q_unit = torch.repeat_interleave(torch.arange(len(exs), device=dev),
+                                             torch.tensor([b - a for a, b in zip(q_lo, q_hi)], device=dev))
+            queries[:, 0] += (q_unit * stride).to(queries.dtype)
 
         self.nn_graph.radius *= 1.732
-        e_ext, e_ref, _ = self.nn_graph(extracted, EasyDict(fxyz=ref_fxyz))
+        e_ext, e_ref, _ = self.nn_graph(EasyDict(fxyz=vox), EasyDict(fxyz=queries))
         self.nn_graph.radius /= 1.732
+        # row in the frame-grouped full-resolution arrays
+        to_row = torch.tensor([a - o for a, o in zip(q_lo, q_off[:-1])], device=dev)
+        g_ref = e_ref + to_row[unit[e_ext]]
 
-        # centre and xy-diameter of every (frame, component) of the tracked voxels
-        comp = extracted.component.long()
+        # centre and xy-diameter of every (frame, unit component) of the tracked voxels
         gkey = (ext_frame - f_lo) * num_components + comp
         num_groups = (f_hi - f_lo + 1) * num_components
         gsg = IndexSegments(gkey, num_groups)
-        center = robust_mean(extracted.fxyz[:, 1:3], gsg, num_groups)
-        spread = (extracted.fxyz[:, 1:3] - center[gkey]).norm(p=2, dim=-1)
+        center = robust_mean(fxyz[:, 1:3], gsg, num_groups)
+        spread = (fxyz[:, 1:3] - center[gkey]).norm(p=2, dim=-1)
         diameter = segment_max(spread, gsg, num_groups)
         ekey = gkey[e_ext]
-        dz = extracted.fxyz[e_ext, -1] - ref_fxyz[e_ref, -1]
+        ref_xyz = v.fxyz[g_ref]
+        dz = fxyz[e_ext, -1] - ref_xyz[:, -1]
         keep = dz < 0.5
-        dist = (ref_fxyz[e_ref, 1:3] - center[ekey]).norm(p=2, dim=-1)
+        dist = (ref_xyz[:, 1:3] - center[ekey]).norm(p=2, dim=-1)
         keep &= dist < diameter[ekey] + 0.05
         keep &= dz > -0.05
         kidx = keep.nonzero(as_tuple=True)[0]
-        # rows in the reference's order: frame by frame ascending, within a frame by tracked voxel
-        kidx = kidx[torch.argsort(ext_frame[e_ext[kidx]], stable=True)]
-        e_ext, e_ref = e_ext[kidx], e_ref[kidx]
-        g_ref = e_ref + lo                       # row in the frame-grouped full-resolution arrays
+        # rows in the reference's order: unit by unit, frame by frame ascending, within a frame by voxel
+        num_f = f_hi - f_lo + 1
+        kidx = kidx[torch.argsort(unit[e_ext[kidx]] * num_f + (ext_frame[e_ext[kidx]] - f_lo), stable=True)]
+        e_ext, g_ref = e_ext[kidx], g_ref[kidx]
         out_frame = v.frame[g_ref]
-        full = EasyDict(dict(
-            fxyz=v.fxyz[g_ref],
-            component=extracted.component[e_ext],
-            segmentation_label=v.full_segmentation_label[g_ref],
-            instance_label=v.full_instance_label[g_ref],
-            original_indices=v.perm[g_ref].reshape(-1, 1),
-            frame_indices=(g_ref - v.frame_start[out_frame]).to(extracted.component),
-            moving=extracted.moving[e_ext],
-        ))
+        out_comp = comp[e_ext]
+        out_unit = unit[e_ext]
+        full_fxyz = ref_xyz[kidx]
         # GT bookkeeping on the frames that have boxes
-        if v.bmax > 0 and full.fxyz.shape[0] > 0:
+        if v.bmax > 0 and full_fxyz.shape[0] > 0:
             sel = (v.box_cnt[out_frame] > 0).nonzero(as_tuple=True)[0]
             if sel.numel():
                 s_fr = out_frame[sel]
-                member, _ = ops.points_in_frame_boxes(full.fxyz[sel, 1:].contiguous(), s_fr, seq_boxes.attr,
+                member, _ = ops.points_in_frame_boxes(full_fxyz[sel, 1:].contiguous(), s_fr, seq_boxes.attr,
                                                       v.box_off32, v.bmax, want_first=False)
                 gframe, gcomp, _, has_box, box, iou = component_box_iou_frames(
-                    full.component[sel], s_fr, member, v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all)
+                    out_comp[sel], s_fr, member, v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all)
                 iou32 = iou.to(seq_boxes.best_iou.dtype)
                 hit = has_box & (iou32 > 0.7)
                 component_hit.index_add_(0, gcomp[hit], torch.ones_like(gcomp[hit]).to(component_hit))
                 scatter_max_(seq_boxes.best_iou, (v.box_off[gframe] + box)[has_box], iou32[has_box])
-        full.component_hit = component_hit
-        full.component_size = component_size
-        full.transforms = transforms
-        return full, seq_boxes
+        counts = torch.bincount(out_unit, minlength=len(exs)).tolist()
+        start = 0
+        for u, ex in enumerate(exs):
+            sl = slice(start, start + counts[u])
+            start += counts[u]
+            rows_ref = g_ref[sl]
+            full = EasyDict(dict(
+                fxyz=full_fxyz[sl],
+                component=(out_comp[sl] - coff[u]).to(ex.component.dtype),
+                segmentation_label=v.full_segmentation_label[rows_ref],
+                instance_label=v.full_instance_label[rows_ref],
+                original_indices=v.perm[rows_ref].reshape(-1, 1),
+                frame_indices=(rows_ref - v.frame_start[out_frame[sl]]).to(ex.component.dtype),
+                moving=moving[e_ext[sl]],
+            ))
+            full.component_hit = component_hit[coff[u]:coff[u + 1]].to(ex.component.dtype)
+            full.component_size = component_size[coff[u]:coff[u + 1]]
+            full.transforms = transforms[u]
+            out[todo[u]] = full
+        return out
 
     # ------------------------------------------------------------------ tracking of one anchor
     def track_frame(self, seq_points, frame, seq_boxes):
@@ -657,24 +714,14 @@ class ClusterTracking(nn.Module):
             sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
             return sp
 
-        def finish_unit(extracted):
-            boxes = EasyDict(dict(seq_boxes))
-            boxes.best_iou = torch.zeros_like(seq_boxes.best_iou)
-            with Timer("Extract Traces from all points"):
-                if extracted.fxyz.shape[0] > 0:
-                    extracted, boxes = self.extract_traces_and_update_boxes(all_points, extracted, boxes, views)
-            return extracted, boxes.best_iou
-
         def run_unit_host(comp_key, frame_id):
             sp = unit_points(comp_key)
             frame_mask = (sp.fxyz[:, 0] == frame_id).reshape(-1)
             frame_points = EasyDict(filter_dict(sp, frame_mask, ignore_keys=("frame_offsets", "frame_perm")))
             frame_points.component = frame_points.component - frame_points.component.min()
             with Timer(f"Tracking Frame {frame_id}"):
-                extracted = self.track_frame_host(sp, frame_points, None)
-            return finish_unit(extracted)
+                return self.track_frame_host(sp, frame_points, None)
 
-        results, best = {}, []
         tracked = None
         self.last_num_workers = 1
         if frame_offsets is not None and seq_points.fxyz.is_cuda:
@@ -686,18 +733,18 @@ class ClusterTracking(nn.Module):
                 if "PCS_ERR_RANGE" not in str(err):
                     raise
         run_deferred(seq_dict)  # (already done beside the native call when that ran)
+        extracted_list = []
         for i, (comp_key, frame_id) in enumerate(units):
             if tracked is not None:
-                sp = unit_points(comp_key)
                 out, comp_dtype = tracked[i]
-                extracted = self._extracted_from_native(sp, frame_id, out, frame_perm, comp_dtype)
-                ex, biou = finish_unit(extracted)
+                extracted_list.append(self._extracted_from_native(unit_points(comp_key), frame_id, out,
+                                                                  frame_perm, comp_dtype))
             else:
-                ex, biou = run_unit_host(comp_key, frame_id)
-            results[(frame_id, comp_key)] = ex
-            best.append(biou)
-        for biou in best:
-            seq_boxes.best_iou = torch.maximum(seq_boxes.best_iou, biou)
+                extracted_list.append(run_unit_host(comp_key, frame_id))
+        # best_iou is a running maximum over the units: one pass over all of them
+        with Timer("Extract Traces from all points"):
+            full_list = self.extract_traces_of_units(all_points, extracted_list, seq_boxes, views)
+        results = {(frame_id, comp_key): ex for (comp_key, frame_id), ex in zip(units, full_list)}
         for (frame_id, comp_key), extracted in results.items():
             if save:
                 torch.save(dict(extracted), f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
