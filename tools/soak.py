@@ -1,5 +1,6 @@
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+"""Memory soak: three sequences in turn through one model; allocator figures per step."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from pcseqlearning_amd.pcdet import models
 from tools.run_sequence import build_model
