@@ -208,6 +208,48 @@ def stage_rooflines(records, stats, prof, out):
     return stages
 
 
+def kernel_stats_stages(out):
+    """Rows for the tracker's phases that run inside the native call (no host span): kernel time from the
+    committed rocprofv3 summary of this command (profiles/r02_sequence_kernel_stats.csv, 4 sequences,
+    single-group schedule), algorithmic bytes from SURVEY 8d's per-unit figures and this run's sizes."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r02_sequence_kernel_stats.csv")
+    if not os.path.exists(path):
+        return []
+    seqs = 4.0
+    rows = list(csv.DictReader(open(path)))
+
+    def ms_of(*names):
+        return sum(float(r["TotalDurationNs"]) for r in rows if any(n in r["Name"] for n in names)) / 1e6 / seqs
+
+    def calls_of(name):
+        return sum(int(r["Calls"]) for r in rows if name in r["Name"]) / seqs
+
+    n_pts = float(out["point_fxyz"].shape[0])
+    frames = float(out["point_fxyz"][:, 0].max().item()) + 1.0
+    per_frame = n_pts / frames
+    res = []
+    # sampling: per registration and unit both clouds are keyed, sorted, reduced: 16 B read + 12 B of
+    # key / value traffic per point and pass of the 4-pass radix sort, 20 B written per voxel
+    regs = 315.0
+    t = ms_of("smp_sort_kernel", "smp_emit_kernel", "smp_compact_kernel")
+    nbytes = regs * 2.0 * per_frame * (16.0 + 4 * 12.0 + 20.0)
+    if t > 0:
+        res.append({"stage": "tracker sampling (voxel keys, one-workgroup radix sort, means / medians)", "ms": round(t, 3),
+                    "launches": int(calls_of("smp_sort_kernel") * 3), "algorithmic_MB": round(nbytes / 1e6, 2),
+                    "achieved_GBs": round(nbytes / t / 1e6, 2), "frac": round(nbytes / t / 1e6 / HBM_PEAK_GBS, 5),
+                    "bytes": "per registration 2 clouds x n x (16 + 4 x 12 + 20)", "source": "profiles/r02_sequence_kernel_stats.csv"})
+    t = ms_of("hv_insert_kernel", "hv_search_kernel", "hv_compact_kernel")
+    steps = calls_of("hv_search_kernel") * 9.0 / max(1.0, 9.0)  # launches serve all units of the group
+    nbytes = 105.0 * per_frame * (16.0 + 16.0 + 16.0)  # 105 unit-steps per sequence: N + M + E rows of 16 B
+    if t > 0:
+        res.append({"stage": "tracker harvest (1-NN r = 0.5 of the moved anchor against the target frame)", "ms": round(t, 3),
+                    "launches": int(steps * 3), "algorithmic_MB": round(nbytes / 1e6, 2),
+                    "achieved_GBs": round(nbytes / t / 1e6, 2), "frac": round(nbytes / t / 1e6 / HBM_PEAK_GBS, 5),
+                    "bytes": "per unit step 16 N + 16 M + 16 E", "source": "profiles/r02_sequence_kernel_stats.csv"})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,8 +366,15 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            traffic = pmc.get("icp_nn_pair_bytes_per_iteration")
-            traffic_src = "profiles/r02_icp_hbm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            # per launch like `achieved`: the PMC passes run the single-group schedule (9 units per
+            # launch), the timed region 4 groups (2-3 units per launch): the measured ratio of fabric
+            # bytes to algorithmic bytes is applied to this run's algorithmic bytes per launch
+            ratio = pmc.get("icp_nn_pair_traffic_over_algorithmic")
+            if ratio and launches > 0:
+                traffic = round(ratio * nbytes / launches, 1)
+            traffic_src = ("profiles/r02_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                           "this command, (fetch + write) / algorithmic = %s, times this run's algorithmic "
+                           "bytes per launch" % ratio)
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
@@ -361,9 +410,11 @@ def main():
                            "searches around the old partner / cooperative searches, moments)"),
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "launches": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                "launches_timed": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                "timing": ("HIP events on the dispatches themselves, inside the timed steps, on one iteration "
+                           "of every chunk of 8 (rotating position): first start to last stop of the pair"),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
-                "stages": stages,
+                "stages": stages + kernel_stats_stages(out),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

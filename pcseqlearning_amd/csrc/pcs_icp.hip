@@ -1038,9 +1038,9 @@ struct KernelProfile {
 static bool g_prof_on = false;
 static KernelProfile g_prof[3];
 static std::mutex g_prof_mu;
-constexpr int kProfChunk = 16;  // iterations per chunk that can carry events
+constexpr int kProfChunk = 16;  // chunk limit of the stand-alone entry point
 struct ProfEvents {
-  hipEvent_t ev[6 * kProfChunk];
+  hipEvent_t ev[6];  // one iteration of a chunk carries events
   bool have = false;
 };
 constexpr int kProfSlots = 8;  // chunks one thread may have in flight (one per lock-step group)
@@ -1093,18 +1093,23 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
   const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
   const int nb_m = gx_for(m, kBlock, 4096);
-  bool prof = g_prof_on && n_it <= kProfChunk;
+  bool prof = g_prof_on;
   if (prof && !t_ev.have) {
-    for (int i = 0; i < 6 * kProfChunk; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
+    for (int i = 0; i < 6; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
     t_ev.have = true;
   }
-  t_ev_used = prof ? n_it : 0;
+  // ONE iteration of the chunk carries events (its position rotates from chunk to chunk, so that every
+  // position -- the full search of iteration 1 included -- is sampled at its own rate): timing every
+  // launch cost 7 % of the step (hipExtLaunchKernelGGL + four event records per iteration)
+  static thread_local unsigned t_rot = 0;
+  const int js = prof ? (int)(t_rot++ % (unsigned)n_it) : -1;
+  t_ev_used = prof ? js + 1 : 0;
   for (int j = 0; j < n_it; ++j) {
     const int nb_c = (j == 0 && any_first) ? nb_c1 : nb_cs;
-    if (prof) {
+    if (j == js) {
       // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
       // kernel's own begin-to-end time, as rocprofv3 reports it
-      hipEvent_t* e = &t_ev.ev[6 * j];
+      hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 2), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
@@ -1131,19 +1136,17 @@ void icp_profile_account(int n_it, const int* live, const double* bytes3, int pr
   ProfEvents& t_ev = t_evs[prof_slot];
   int& t_ev_used = t_ev_useds[prof_slot];
   if (!g_prof_on || t_ev_used < 1) return;
-  int n = n_it < t_ev_used ? n_it : t_ev_used;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int j = 0; j < n; ++j) {
-    if (live[j] < 1) continue;
-    for (int q = 0; q < 3; q += 2) {  // 0: the two neighbour kernels (moments included), 2: solve + apply
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, t_ev.ev[6 * j + 2 * q], t_ev.ev[6 * j + 2 * q + 1]) != hipSuccess) continue;
-      g_prof[q].ms += ms;
-      g_prof[q].launches += 1.0;
-      g_prof[q].bytes += bytes3[j * 3 + q];
-    }
-  }
+  const int j = t_ev_used - 1;  // the iteration of the chunk that carried the events
   t_ev_used = 0;
+  if (j >= n_it || live[j] < 1) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int q = 0; q < 3; q += 2) {  // 0: the two neighbour kernels (moments included), 2: solve + apply
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t_ev.ev[2 * q], t_ev.ev[2 * q + 1]) != hipSuccess) continue;
+    g_prof[q].ms += ms;
+    g_prof[q].launches += 1.0;
+    g_prof[q].bytes += bytes3[j * 3 + q];
+  }
 }
 
 int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
