@@ -2,7 +2,13 @@
 12 sparse convs over 8 rulebooks), eval-mode BN. Times the forward with the MFMA tiles and with
 the FMA tiles (bit-identical outputs are asserted) and prints one JSON line.
 
-  python tools/bench_backbone.py [--points 160000] [--reps 20] [--mfma 0|1|both]
+  python tools/bench_backbone.py [--points 160000] [--batch 1] [--reps 20] [--mfma 0|1|both]
+
+--batch B puts B frames (seeds 0..B-1) into one batch, as the reference's API does (B = 1 is a
+launch-latency benchmark). The line carries a `roofline` block: conv FLOP/s against the f32 MFMA peak
+and the algorithmic HBM bytes of the 12 convs (4 V Cin + 4 V' Cout + 8 sum P_k + 4 KV Cin
+Cout per layer) against the HBM peak; MFMA busy % comes from a separate rocprofv3 --pmc pass
+(tools/summarize_pmc.py -> profiles/*_backbone_mfma_pmc*.json).
 """
 import argparse
 import ctypes
@@ -31,18 +37,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=160000)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--mfma", default="both")
     ap.add_argument("--train", action="store_true", help="also time one forward + backward step")
     args = ap.parse_args()
     dev = "cuda:0"
     lib = L.load()
     torch.manual_seed(0)
-    pts = torch.from_numpy(synthetic.gen_voxel_frame(0, args.points)).to(dev)
+    frames = []
+    for b in range(args.batch):
+        f = synthetic.gen_voxel_frame(b, args.points)
+        f[:, 0] = b
+        frames.append(f)
+    import numpy as np
+    pts = torch.from_numpy(np.concatenate(frames)).to(dev)
     vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
     net = VoxelBackBone8x({}, 5, synthetic.GRID_SIZE.tolist()).to(dev).eval()
 
     def forward():
-        batch = vfe({"points": pts, "batch_size": 1})
+        batch = vfe({"points": pts, "batch_size": args.batch})
         with torch.no_grad():
             return net(batch)
 
@@ -69,13 +82,35 @@ def main():
              "spconv3": [(32, 64)], "subm3": [(64, 64)] * 2, "spconv4": [(64, 64)],
              "subm4": [(64, 64)] * 2, "spconv_down2": [(64, 128)]}
     flops = 0
+    hbm_bytes = 0
     voxels = {}
+    layers_out = []
+    v_in = int(out["multi_scale_3d_features"]["x_conv1"].indices.shape[0])
     for key, layers in chans.items():
         num = int(d[key][3].sum())
-        voxels[key] = int(d[key][0].shape[0])
+        kv = int(d[key][3].numel())
+        v_out = int(d[key][0].shape[0])
+        voxels[key] = v_out
         for cin, cout in layers:
-            flops += 2 * num * cin * cout
-    line = {"workload": "config5: VoxelBackBone8x forward, one synthetic frame", "points": args.points,
+            fl = 2 * num * cin * cout
+            by = 4 * v_in * cin + 4 * v_out * cout + 8 * num + 4 * kv * cin * cout
+            flops += fl
+            hbm_bytes += by
+            layers_out.append({"rulebook": key, "cin": cin, "cout": cout, "pairs": num, "mflop": round(fl / 1e6, 1),
+                               "algorithmic_MB": round(by / 1e6, 2)})
+            v_in = v_out
+    t_best = results.get("mfma", results.get("fma")) * 1e-3
+    line = {"workload": f"config5: VoxelBackBone8x forward, {args.batch} synthetic frame(s) per batch",
+            "points": args.points, "batch": args.batch,
+            "ms_per_frame": round(t_best * 1e3 / args.batch, 3),
+            "roofline": {"bound": "mfma", "achieved": round(flops / t_best / 1e12, 3), "peak": 157.3,
+                         "unit": "TFLOP/s", "frac": round(flops / t_best / 1e12 / 157.3, 4),
+                         "hbm": {"algorithmic_MB": round(hbm_bytes / 1e6, 1),
+                                 "achieved_GBs": round(hbm_bytes / t_best / 1e9, 1),
+                                 "frac_of_8TBs": round(hbm_bytes / t_best / 1e9 / 8000.0, 4)},
+                         "note": ("whole forward (VFE + 8 rulebooks + 12 convs + BN/ReLU epilogues) over the "
+                                  "convs' flops / bytes; f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32)"),
+                         "layers": layers_out},
             "voxels": int(out["multi_scale_3d_features"]["x_conv1"].indices.shape[0]),
             "ms_per_forward": {k: round(v, 3) for k, v in results.items()},
             "conv_gflop": round(flops / 1e9, 3),
