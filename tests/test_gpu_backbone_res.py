@@ -232,3 +232,112 @@ def test_unet_up_block_modules_vs_oracle(oracle):
     np.testing.assert_array_equal(up.indices.cpu().numpy(), idx)   # back on the input's voxels
     assert up.spatial_shape == shape
     np.testing.assert_allclose(up.features.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
+
+
+class _OracleSparseNet:
+    """Walks this package's spconv modules with the CPU oracle's rulebook builder and conv (numpy):
+    rulebooks cached by indice key like SparseConvTensor.indice_dict."""
+
+    def __init__(self, oracle):
+        self.o, self.books = oracle, {}
+
+    def conv(self, m, idx, feat, shape):
+        o = self.o
+        w = m.weight.detach().cpu().numpy()
+        k, st, pd, dl = (list(v) for v in (m.kernel_size, m.stride, m.padding, m.dilation))
+        if m.inverse:
+            in_idx, in_shape, pairs, num = self.books[m.indice_key]
+            return in_idx, o.indice_conv(feat, w, pairs, num, in_idx.shape[0], True, False), in_shape
+        if m.subm:
+            if m.indice_key not in self.books:
+                _, pairs, num = o.get_indice_pairs(idx, shape, k, [1, 1, 1], pd, dl, True)
+                self.books[m.indice_key] = (idx, shape, pairs, num)
+            _, _, pairs, num = self.books[m.indice_key]
+            return idx, o.indice_conv(feat, w, pairs, num, idx.shape[0], False, True), shape
+        oshape = o.conv_out_shape(shape, k, st, pd, dl)
+        oidx, pairs, num = o.get_indice_pairs(idx, oshape, k, st, pd, dl, False)
+        self.books[m.indice_key] = (idx, shape, pairs, num)
+        return oidx, o.indice_conv(feat, w, pairs, num, oidx.shape[0], False, False), oshape
+
+    def block(self, seq, idx, feat, shape):      # post_act_block: conv, BatchNorm1d, ReLU
+        idx, y, shape = self.conv(seq[0], idx, feat, shape)
+        return idx, np.maximum(bn_np(y, seq[1]), 0), shape
+
+    def stage(self, seq, idx, feat, shape):
+        for blk in seq:
+            idx, feat, shape = self.block(blk, idx, feat, shape)
+        return idx, feat, shape
+
+    def basic(self, b, idx, feat, shape):        # SparseBasicBlock
+        _, y, _ = self.conv(b.conv1, idx, feat, shape)
+        y = np.maximum(bn_np(y, b.bn1), 0)
+        _, y, _ = self.conv(b.conv2, idx, y, shape)
+        return np.maximum(bn_np(y, b.bn2) + feat, 0)
+
+
+@pytest.mark.parametrize("deep", [False, True])
+def test_unet_v2_vs_oracle(oracle, deep):
+    """UNetV2 (spconv_unet.py:13-271) end to end on a small voxel set against an oracle walk of the same
+    modules: encoder 4 (or 6) stages, every decoder step back to the input's voxels; indices bit-exact,
+    features 5e-4 (dozens of chained fp32 convs); output keys and centres as the reference computes them."""
+    from pcseqlearning_amd.pcdet.models.backbones_3d import UNetV2
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    grid = [48, 40, 40 if deep else 16]      # x, y, z (the fifth stage needs the reference's 41 z-cells: 41-21-11-5-2)
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    n = 2500
+    lin = rng.choice(int(np.prod(shape[:1]) * shape[1] * shape[2]), n, replace=False)
+    zyx = np.stack(np.unravel_index(lin, shape), 1)
+    b = rng.integers(0, 2, (n, 1))
+    idx = np.concatenate([b, zyx], 1).astype(np.int32)
+    idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    feat = rng.normal(size=(n, 4)).astype(np.float32)
+    rc = dict(grid_size=grid, voxel_size=[0.1, 0.1, 0.15], point_cloud_range=[0, -2, -1, 4.8, 2, 1.4],
+              input_channels=4, scale=0.25)
+    if deep:
+        rc["point_cloud_range"] = [0, -2, -1, 4.8, 2, 5.0]
+    cfg = {"CONV5": True, "CONV6": True} if deep else {}
+    net = UNetV2(cfg, rc).to(DEV).eval()
+    randomise_bn(net)
+    bcoords = dev(idx[:, [0, 3, 2, 1]].astype(np.int64))       # (b, x, y, z) as the reference's voxel_bcoords
+    with torch.no_grad():
+        out = net(dict(voxel_feat=dev(feat), voxel_bcoords=bcoords, batch_size=2))
+    # ---- oracle walk
+    O = _OracleSparseNet(oracle)
+    enc = {}
+    cur = (idx, feat, shape)
+    for s in (1, 2, 3, 4) + ((5, 6) if deep else ()):
+        cur = O.stage(getattr(net, f"conv{s}"), *cur)
+        enc[s] = cur
+
+    def up_step(s, lateral, bottom_feat):
+        l_idx, l_feat, l_shape = lateral
+        t = O.basic(getattr(net, f"conv_up_t{s}"), l_idx, l_feat, l_shape)
+        cat = np.concatenate([bottom_feat, t], axis=1)
+        m_seq = getattr(net, f"conv_up_m{s}")
+        _, m, _ = O.block(m_seq, l_idx, cat, l_shape)
+        mixed = (m + cat.reshape(cat.shape[0], m.shape[1], -1).sum(axis=2)).astype(np.float32)
+        return O.block(getattr(net, f"inv_conv{s}"), l_idx, mixed, l_shape)
+
+    if deep:
+        up = up_step(6, enc[6], enc[6][1])
+        up = up_step(5, enc[5], up[1])
+    else:
+        up = enc[4]
+    for s in (4, 3, 2, 1):
+        up = up_step(s, enc[s], up[1])
+    np.testing.assert_array_equal(up[0], idx)                    # back on the input's voxels
+    np.testing.assert_allclose(out["unet_voxel_feat"].cpu().numpy(), up[1], rtol=5e-4, atol=5e-4)
+    for i in range(5 if deep else 4):
+        e_idx, e_feat, _ = enc[i + 1]
+        np.testing.assert_allclose(out[f"spconv_unet_feat{5 - i}"].cpu().numpy(), e_feat, rtol=5e-4, atol=5e-4)
+        times = np.array([1, 2, 4, 8, [8, 8, 16]][i], np.float32) if i < 4 else np.array([8, 8, 16], np.float32)
+        vs = np.array(rc["voxel_size"], np.float32)
+        want = e_idx[:, [3, 2, 1]].astype(np.float32) * (vs * times) + np.array(rc["point_cloud_range"][:3], np.float32) + vs * 0.5
+        got = out[f"spconv_unet_bcenter{5 - i}"].cpu().numpy()
+        np.testing.assert_array_equal(got[:, 0], e_idx[:, 0].astype(np.float32))
+        np.testing.assert_allclose(got[:, 1:], want, rtol=0, atol=1e-5)
+    centers = (idx[:, [3, 2, 1]].astype(np.float32) + 0.5) * np.array(rc["voxel_size"], np.float32) + \
+        np.array(rc["point_cloud_range"][:3], np.float32)
+    np.testing.assert_allclose(out["unet_voxel_bxyz"].cpu().numpy()[:, 1:], centers, rtol=0, atol=1e-5)
+    assert out["unet_voxel_feat"].shape == (n, 8) and net.num_point_features == 8

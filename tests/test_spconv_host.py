@@ -53,3 +53,26 @@ def test_backbone_module_trees():
     assert a.conv2[0][0].indice_key == "spconv2" and a.conv2[1][0].indice_key == "subm2"
     assert b.conv3[0][0].indice_key == "spconv3" and b.conv3[2].conv1.indice_key == "res3"
     assert a.conv_input[0].indice_key == "subm1" and b.conv_input[0].indice_key == "res1"
+
+
+def test_unet_v2_module_tree():
+    """UNetV2's parameter names and shapes as the reference lays them out (spconv_unet.py:20-124)."""
+    import pytest
+    from pcseqlearning_amd.pcdet.models.backbones_3d import UNetV2
+    rc = dict(grid_size=[1504, 1504, 40], voxel_size=[0.1, 0.1, 0.15], point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4],
+              input_channels=5)
+    net = UNetV2({}, dict(rc))
+    assert net.sparse_shape == [41, 1504, 1504] and net.num_point_features == 32 and net.conv5 is None
+    sd = net.state_dict()
+    assert sd["conv1.0.0.weight"].shape[-2:] == (5, 32) and sd["conv4.0.0.weight"].shape[-2:] == (128, 256)
+    assert sd["conv_up_m4.0.weight"].shape[-2:] == (512, 256) and sd["inv_conv4.0.weight"].shape[-2:] == (256, 128)
+    assert sd["inv_conv2.0.weight"].shape[-2:] == (64, 32) and sd["inv_conv1.0.weight"].shape[-2:] == (32, 32)
+    assert {"conv_up_t1.conv1.weight", "conv_up_t3.bn2.running_var", "conv3.2.1.weight"} <= set(sd)
+    assert not any(k.startswith(("conv5", "conv6", "conv_up_t5", "inv_conv6")) for k in sd)
+    deep = UNetV2({"CONV5": True, "CONV6": True}, dict(rc))
+    assert list(deep.conv5[0][0].stride) == [2, 1, 1] and list(deep.conv5[0][0].padding) == [0, 1, 1]
+    assert {"conv_up_m6.0.weight", "inv_conv5.0.weight", "conv6.2.0.weight"} <= set(deep.state_dict())
+    assert net.conv4[0][0].indice_key == "spconv4" and net.inv_conv4[0].indice_key == "spconv4" and net.inv_conv4[0].inverse
+    assert net.inv_conv1[0].subm and net.inv_conv1[0].indice_key == "subm1"
+    with pytest.raises(NotImplementedError):
+        UNetV2({"GLOBAL": {"x": 1}}, dict(rc))
