@@ -430,6 +430,15 @@ int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int6
                                 float* best_normal, float* best_conf, void* ws, size_t ws_bytes,
                                 pcs_stream_t stream);
 
+/* The "truncated least squares" pruning of the plane hypotheses (preprocessor_utils.py:137-160: for
+ * each of the T shrinking thresholds (host array, T <= 128) above which nothing lies the loop skips;
+ * otherwise the hypotheses whose mean curvature over their K (<= 8) nearest hypotheses, themselves
+ * included, is not below the threshold are dropped and the curvatures are recomputed) as ONE launch.
+ * xyz / normal [H,3] f32 device; keep [H] uint8 device out (1 = survives). PCS_ERR_RANGE when H > 2048
+ * (the caller then uses its own loop). */
+int pcs_prune_plane_hypotheses(const float* xyz, const float* normal, int64_t H, int K,
+                               const float* thresholds, int T, uint8_t* keep, pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

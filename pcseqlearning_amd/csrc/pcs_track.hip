@@ -1176,6 +1176,118 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
   return PCS_OK;
 }
 
+
+// ---- hypothesis pruning of the ground stage ("truncated least squares", preprocessor_utils.py:137-160
+// of the reference: for each of 100 shrinking thresholds, drop the plane hypotheses whose mean 8-NN
+// curvature is at or above it and recompute). The whole loop in ONE workgroup: the hypotheses (a
+// few hundred to a couple of thousand super-pillar planes) live in LDS, every thread owns up to two
+// of them, the k nearest are kept in registers by a fixed insertion network (ties by index), the
+// threshold loop and its "skip while the threshold is above the largest curvature" test run on the
+// device. The reference (and the host form this replaces) launches a k-NN graph and reads a maximum
+// back to the host for each of the ~20-30 pruning events.
+constexpr int kPruneMax = 2048;
+constexpr int kPruneWg = 1024;
+constexpr int kPruneK = 8;
+struct PruneThresholds {
+  float v[128];
+};
+
+__global__ void __launch_bounds__(kPruneWg)
+prune_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ normal, int H, int K,
+                        PruneThresholds thr, int T, uint8_t* __restrict__ keep) {
+  __shared__ float sx[kPruneMax], sy[kPruneMax], sz[kPruneMax];
+  __shared__ float snx[kPruneMax], sny[kPruneMax], snz[kPruneMax];
+  __shared__ uint8_t alive[kPruneMax];
+  __shared__ float red[kPruneWg / 64];
+  __shared__ int redn[kPruneWg / 64];
+  __shared__ float s_max;
+  __shared__ int s_alive;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < H; i += kPruneWg) {
+    sx[i] = xyz[3 * i]; sy[i] = xyz[3 * i + 1]; sz[i] = xyz[3 * i + 2];
+    snx[i] = normal[3 * i]; sny[i] = normal[3 * i + 1]; snz[i] = normal[3 * i + 2];
+    alive[i] = 1;
+  }
+  __syncthreads();
+  float curv[2] = {0.f, 0.f};
+  // mean curvature of the hypotheses this thread owns over their k nearest alive hypotheses (itself
+  // included, like torch_cluster.knn(x, x, k)); returns through s_max / s_alive the maximum and count
+  auto evaluate = [&]() {
+    float mx = -__builtin_inff();
+    int cnt = 0;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int i = tid + o * kPruneWg;
+      curv[o] = 0.f;
+      if (i >= H || !alive[i]) continue;
+      ++cnt;
+      double bd[kPruneK];
+      int bi[kPruneK];
+#pragma unroll
+      for (int q = 0; q < kPruneK; ++q) { bd[q] = 1e300; bi[q] = 0x7fffffff; }
+      const double xi = sx[i], yi = sy[i], zi = sz[i];
+      int n_alive = 0;
+      for (int j = 0; j < H; ++j) {
+        if (!alive[j]) continue;
+        ++n_alive;
+        const double dx = (double)sx[j] - xi, dy = (double)sy[j] - yi, dz = (double)sz[j] - zi;
+        double d = dx * dx + dy * dy + dz * dz;
+        int id = j;
+        if (d > bd[kPruneK - 1]) continue;  // not among the k nearest so far (ties go through the network)
+        // insert (d, id) into the ascending list: fixed network, no indexed access
+#pragma unroll
+        for (int q = 0; q < kPruneK; ++q) {
+          const bool lt = d < bd[q] || (d == bd[q] && id < bi[q]);
+          const double td = lt ? bd[q] : d;
+          const int ti = lt ? bi[q] : id;
+          bd[q] = lt ? d : bd[q];
+          bi[q] = lt ? id : bi[q];
+          d = td;
+          id = ti;
+        }
+      }
+      const int k = n_alive < K ? n_alive : K;
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPruneK; ++q) {
+        if (q < k) {
+          const int j = bi[q];
+          const float dx = sx[j] - sx[i], dy = sy[j] - sy[i], dz = sz[j] - sz[i];
+          const float p2p = fabsf((dx * snx[i] + dy * sny[i]) + dz * snz[i]);
+          sum += p2p / (sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-4f);
+        }
+      }
+      curv[o] = sum / (float)k;
+      mx = fmaxf(mx, curv[o]);
+    }
+    mx = wave_max(mx);
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) { red[w] = mx; redn[w] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0];
+      int c = redn[0];
+      for (int q = 1; q < kPruneWg / 64; ++q) { m = fmaxf(m, red[q]); c += redn[q]; }
+      s_max = m;
+      s_alive = c;
+    }
+    __syncthreads();
+  };
+  evaluate();
+  for (int t = 0; t < T; ++t) {
+    const float th = thr.v[t];
+    if (th > s_max) continue;  // (uniform: s_max is only written inside evaluate(), between barriers)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int i = tid + o * kPruneWg;
+      if (i < H && alive[i] && !(curv[o] < th)) alive[i] = 0;
+    }
+    __syncthreads();
+    evaluate();
+  }
+  for (int i = tid; i < H; i += kPruneWg) keep[i] = alive[i];
+}
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -1388,6 +1500,20 @@ int pcs_irls_plane_fit(const float* xyz, const int64_t* pillar_idx, int64_t n, c
   irls_error_kernel<<<grid_for(n), kBlock, 0, s>>>(xyz, pillar_idx, n, plane, plane_err);
   if (d_rounds)
     PCS_CHECK_HIP(hipMemcpyAsync(d_rounds, &st->rounds, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+
+/* prune_plane_hypotheses: see include/pcs.h */
+int pcs_prune_plane_hypotheses(const float* xyz, const float* normal, int64_t H, int K,
+                               const float* thresholds, int T, uint8_t* keep, hipStream_t s) {
+  if (!xyz || !normal || !thresholds || !keep || H < 1 || K < 1 || K > kPruneK || T < 0 || T > 128)
+    return PCS_ERR_ARG;
+  if (H > kPruneMax) return PCS_ERR_RANGE;  // the caller keeps its host-driven form for that
+  PruneThresholds th;
+  for (int t = 0; t < T; ++t) th.v[t] = thresholds[t];
+  prune_hypotheses_kernel<<<1, kPruneWg, 0, s>>>(xyz, normal, (int)H, K, th, T, keep);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

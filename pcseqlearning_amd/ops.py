@@ -634,6 +634,21 @@ def ransac_plane_hypotheses(xyz, seg_start, min_z, max_z, ratios, origin, sigma2
     return center, normal, conf
 
 
+def prune_plane_hypotheses(xyz, normal, thresholds, k=8):
+    """The 100-threshold pruning loop of compute_min_height_from_ransac in one launch: keep mask [H] bool.
+    Raises PcsError(PCS_ERR_RANGE) for more than 2048 hypotheses."""
+    L.require_gpu(xyz, "prune_plane_hypotheses")
+    lib = L.load()
+    xyz = xyz.float().contiguous()
+    normal = normal.float().contiguous()
+    H = xyz.shape[0]
+    keep = torch.empty(H, dtype=torch.uint8, device=xyz.device)
+    th = [float(t) for t in thresholds]
+    L.check(lib.pcs_prune_plane_hypotheses(L.ptr(xyz), L.ptr(normal), L.i64(H), L.i32(k), L.host_floats(th),
+                                           L.i32(len(th)), L.ptr(keep), L.stream()), "pcs_prune_plane_hypotheses")
+    return keep.bool()
+
+
 # ---------------------------------------------------------------- native tracker
 class TrackParams(__import__("ctypes").Structure):
     """Mirror of PcsTrackParams (include/pcs.h)."""

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from ..... import ops
+from .....lib import PcsError
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils.grid_sampling import GridSampling3D
@@ -130,15 +131,27 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
         mean_curv = curvature.reshape(-1, k).mean(-1)
         return mean_curv, float(mean_curv.max().item())
 
-    # the k-NN curvature only changes when a hypothesis is dropped: evaluated once per pruning
-    # event, not once per threshold (the reference recomputes it for each of the 100 thresholds)
-    mean_curv, max_curv = mean_curvature(xyz, normal)
-    for threshold in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100):
-        if np.float32(threshold) > np.float32(max_curv):  # fp32, like the tensor comparison it replaces
-            continue
-        keep = mean_curv < threshold
-        xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+    thresholds = np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100)
+    pruned = False
+    if cfg.get("PRUNE_KERNEL", True) and xyz.is_cuda and 0 < xyz.shape[0] and cfg["K"] <= 8:
+        # the whole loop in one launch (pcs_prune_plane_hypotheses); more than 2048 hypotheses fall through
+        try:
+            keep = ops.prune_plane_hypotheses(xyz, normal, thresholds, cfg["K"])
+            xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+            pruned = True
+        except PcsError as err:
+            if "PCS_ERR_RANGE" not in str(err):
+                raise
+    if not pruned:
+        # the k-NN curvature only changes when a hypothesis is dropped: evaluated once per pruning
+        # event, not once per threshold (the reference recomputes it for each of the 100 thresholds)
         mean_curv, max_curv = mean_curvature(xyz, normal)
+        for threshold in thresholds:
+            if np.float32(threshold) > np.float32(max_curv):  # fp32, like the tensor comparison it replaces
+                continue
+            keep = mean_curv < threshold
+            xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+            mean_curv, max_curv = mean_curvature(xyz, normal)
     conf[:] = 1
     t_tls.__exit__(None, None, None)
     t_prop = Timer("ground: propagation to pillars")

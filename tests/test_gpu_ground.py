@@ -202,3 +202,53 @@ def test_config0_plumbing_frame():
     # fall on either side: at most 0.1 % of the points, heights 4 mm on average
     assert a["differ"] <= 50 and a["mean"] < 4e-3 and a["max"] < 0.1, a
     assert 10000 < int((h >= 0.5).sum()) < 30000
+
+
+def test_prune_plane_hypotheses_kernel_vs_host_loop():
+    """pcs_prune_plane_hypotheses (the 100-threshold pruning loop in one launch) against the host-driven
+    loop it replaces (torch.cdist + topk + one read-back per pruning event): the same survivors, on
+    random plane sets of several sizes, and on the ground stage as a whole (PRUNE_KERNEL on / off)."""
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors import preprocessor_utils as PU
+    from tests.golden.make_golden_ground import GROUND_CFG
+    thresholds = np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for H in (5, 300, 1500, 2048):
+        xy = (torch.rand(H, 2, generator=g) * 150 - 75)
+        z = 0.02 * xy[:, :1] + torch.randn(H, 1, generator=g) * 0.05
+        z[torch.rand(H, 1, generator=g) < 0.15] += 1.5          # hypotheses sitting on objects
+        xyz = torch.cat([xy, z], 1).to(DEV)
+        n = torch.randn(H, 3, generator=g) * 0.05
+        n[:, 2] = 1.0
+        normal = (n / n.norm(dim=1, keepdim=True)).to(DEV)
+        keep = ops.prune_plane_hypotheses(xyz, normal, thresholds, 8)
+        # the host loop, literally
+        a, b = xyz, normal
+        idx = torch.arange(H, device=DEV)
+
+        def mean_curv(a, b):
+            e0, e1, k = PU._knn_self(a, 8)
+            diff = a[e1] - a[e0]
+            p2p = (diff * b[e0]).sum(dim=-1).abs()
+            c = (p2p / (diff.norm(p=2, dim=-1) + 1e-4)).reshape(-1, k).mean(-1)
+            return c, float(c.max().item())
+
+        mc, mx = mean_curv(a, b)
+        for t in thresholds:
+            if np.float32(t) > np.float32(mx):
+                continue
+            m = mc < t
+            a, b, idx = a[m], b[m], idx[m]
+            if a.shape[0] == 0:
+                break
+            mc, mx = mean_curv(a, b)
+        want = torch.zeros(H, dtype=torch.bool, device=DEV)
+        want[idx] = True
+        differ = int((keep != want).sum().item())
+        assert differ <= max(1, H // 500), (H, differ, int(keep.sum()), int(want.sum()))
+        assert 0 < int(keep.sum()) < H or H <= 5
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ground_small.npz"))
+    hs = []
+    for on in (True, False):
+        h = PU.ground_plane_removal(dev(gold["point_fxyz"]), dict(GROUND_CFG, PRUNE_KERNEL=on))[0]
+        hs.append(h.cpu().numpy())
+    assert int(((hs[0] >= 0.5) != (hs[1] >= 0.5)).sum()) <= 5 and float(np.abs(hs[0] - hs[1]).mean()) < 1e-3
