@@ -265,9 +265,20 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
   __shared__ double red[kBlock / 64];
   IcpState* st = pr.st;
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
-  double part = 0.0;
+  // four independent partial sums per thread (the loads of one chain were the launch's critical path
+  // for the keys with ten thousand components); the order is fixed, so the sum is reproducible
   const int C = (int)pr.C;
-  for (int q = threadIdx.x; q < C; q += kBlock) part += pr.lsc[q];
+  const double* __restrict__ lsc = pr.lsc;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  int q = threadIdx.x;
+  for (; q + 3 * kBlock < C; q += 4 * kBlock) {
+    p0 += lsc[q];
+    p1 += lsc[q + kBlock];
+    p2 += lsc[q + 2 * kBlock];
+    p3 += lsc[q + 3 * kBlock];
+  }
+  for (; q < C; q += kBlock) p0 += lsc[q];
+  double part = (p0 + p1) + (p2 + p3);
   part = wave_sum_f64(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
