@@ -814,12 +814,11 @@ __global__ void irls_seg_init_kernel(IrlsSegState* st) {
 __global__ void __launch_bounds__(kBlock)
 irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
                       const int32_t* __restrict__ seg_start, const float* __restrict__ origin,
-                      float sigma2, float delta, float* __restrict__ w, float* __restrict__ planes,
+                      float sigma2, float delta, const float* __restrict__ w0, float* __restrict__ planes,
                       int64_t P, IrlsSegState* __restrict__ st, int64_t n,
                       const float* __restrict__ ratios, const float* __restrict__ min_z,
                       const float* __restrict__ max_z) {
   st += blockIdx.y;
-  w += (size_t)blockIdx.y * n;
   planes += (size_t)blockIdx.y * P * 12;
   if (r > st->stop_round) return;
   float* plane_prev = planes + (size_t)((r - 1) & 1) * P * 6;  // plane of round r-1
@@ -836,41 +835,54 @@ irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
   const int c = blockIdx.x;
   const int b = seg_start[c], e = seg_start[c + 1];
   const float o0 = origin[c * 3], o1 = origin[c * 3 + 1], o2 = origin[c * 3 + 2];
-  float pl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // The weights are never stored: the weight of round r is a function of the plane of round r-1 (or of
+  // the initial rule), and the previous weight -- needed only for the convergence test -- of the
+  // plane of round r-2, which is still in the other plane buffer. (Stored, they were R x n floats
+  // read and written every round: 600 MB per round for the 30-ratio batch, the launch's whole time.)
+  float pl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pl2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (r > 1) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) pl[q] = plane_prev[(int64_t)c * 6 + q];
+  }
+  if (r > 2) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pl2[q] = plane_cur[(int64_t)c * 6 + q];  // round r-2 (overwritten at the end)
   }
   double v[11];
 #pragma unroll
   for (int q = 0; q < 11; ++q) v[q] = 0.0;
   float dw = 0.f;
   float cur_z = 0.f;
-  const bool from_ratio = ratios != nullptr && r == 1;
-  if (from_ratio) {
+  const bool from_ratio = ratios != nullptr;
+  if (from_ratio && r <= 2) {
     float ratio = ratios[blockIdx.y];
     float omr = (float)(1.0 - (double)ratio);  // Python forms 1 - ratio in double
     cur_z = min_z[c] * ratio + max_z[c] * omr;
   }
+  auto plane_weight = [&](const float* q, float x, float y, float z) {
+    float dx = x - q[0], dy = y - q[1], dz = z - q[2];
+    float er = fabsf(dx * q[3] + dy * q[4] + dz * q[5]);
+    float nw = sigma2 / (er * er + sigma2);
+    float dist_w = 0.25f / (dx * dx + dy * dy + dz * dz + 0.25f);
+    return nw * dist_w;
+  };
   for (int i = b + (int)threadIdx.x; i < e; i += kBlock) {
     float x = xyz[(int64_t)i * 3], y = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
     float wi;
-    if (from_ratio) {
-      float zd = cur_z - z;
-      wi = (1.f / (zd * zd + sigma2)) * sigma2;  // scalar / tensor is reciprocal() * scalar in torch
-      w[i] = wi;
+    if (r <= 2) {  // the initial weight (round 1) / the previous weight of round 2
+      if (from_ratio) {
+        float zd = cur_z - z;
+        wi = (1.f / (zd * zd + sigma2)) * sigma2;  // scalar / tensor is reciprocal() * scalar in torch
+      } else {
+        wi = w0[i];
+      }
     } else {
-      wi = w[i];
+      wi = plane_weight(pl2, x, y, z);
     }
     if (r > 1) {
-      float dx = x - pl[0], dy = y - pl[1], dz = z - pl[2];
-      float er = fabsf(dx * pl[3] + dy * pl[4] + dz * pl[5]);
-      float nw = sigma2 / (er * er + sigma2);
-      float dist_w = 0.25f / (dx * dx + dy * dy + dz * dz + 0.25f);
-      nw = nw * dist_w;
+      float nw = plane_weight(pl, x, y, z);
       dw = fmaxf(dw, fabsf(nw - wi));
       wi = nw;
-      w[i] = nw;
     }
     float ox = x - o0, oy = y - o1, oz = z - o2;
     double W = wi;
@@ -1374,7 +1386,7 @@ size_t pcs_irls_plane_fit_sorted_workspace_bytes(int64_t n, int64_t P) {
   Arena a(nullptr, 0);
   a.take<IrlsSegState>(1);
   a.take<float>((size_t)(P > 0 ? P : 1) * 12);
-  a.take<float>((size_t)(n > 0 ? n : 1));
+  (void)n;
   return a.off;
 }
 
@@ -1391,15 +1403,13 @@ int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_
   Arena a(ws, ws_bytes);
   IrlsSegState* st = a.take<IrlsSegState>(1);
   float* planes = a.take<float>((size_t)P * 12);
-  float* w = a.take<float>((size_t)n);
   if (!a.ok()) return PCS_ERR_WORKSPACE;
-  PCS_CHECK_HIP(hipMemcpyAsync(w, w0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
   irls_seg_init_kernel<<<1, 64, 0, s>>>(st);
   for (int r = 1; r <= max_rounds; ++r)
     irls_seg_round_kernel<<<(int)P, kBlock, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta,
-                                                    w, planes, P, st, n, nullptr, nullptr, nullptr);
+                                                    w0, planes, P, st, n, nullptr, nullptr, nullptr);
   irls_seg_round_kernel<<<1, 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin, sigma2,
-                                         stopping_delta, w, planes, P, st, n, nullptr, nullptr, nullptr);
+                                         stopping_delta, w0, planes, P, st, n, nullptr, nullptr, nullptr);
   irls_seg_finish_kernel<<<(int)P, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, plane, plane_err, 0.f,
                                                    nullptr);
   if (d_rounds)
@@ -1413,7 +1423,7 @@ size_t pcs_ransac_plane_hypotheses_workspace_bytes(int64_t n, int64_t P, int R) 
   if (R < 1) R = 1;
   a.take<IrlsSegState>(R);
   a.take<float>((size_t)R * (P > 0 ? P : 1) * 12);
-  a.take<float>((size_t)R * (n > 0 ? n : 1));
+  (void)n;
   a.take<float>((size_t)R * (P > 0 ? P : 1) * 6);
   a.take<float>((size_t)R * (P > 0 ? P : 1));
   a.take<float>(R);
@@ -1439,7 +1449,7 @@ int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int6
   Arena a(ws, ws_bytes);
   IrlsSegState* st = a.take<IrlsSegState>(R);
   float* planes = a.take<float>((size_t)R * P * 12);
-  float* w = a.take<float>((size_t)R * n);
+  const float* w = nullptr;  // the weights of the ratio fits are never stored
   float* planes_out = a.take<float>((size_t)R * P * 6);
   float* num_hit = a.take<float>((size_t)R * P);
   float* d_ratios = a.take<float>(R);
