@@ -24,10 +24,12 @@ def _bn_relu(x, bn):
     return np.maximum((x - m) / np.sqrt(v + bn.eps) * w + b, 0).astype(np.float32)
 
 
-def test_voxel_backbone_8x_vs_oracle(oracle):
-    """BASELINE config 5 on a reduced frame: dynamic VFE -> 12 sparse convs / 8 rulebooks, eval BN."""
+@pytest.mark.parametrize("n_points", [30000, 160000])
+def test_voxel_backbone_8x_vs_oracle(oracle, n_points):
+    """BASELINE configs[4] (a reduced frame and the full 160k-pt frame): dynamic VFE -> 12 sparse convs /
+    8 rulebooks, eval BN, against the oracle chain: indices bit-exact at every scale, features 1e-4."""
     torch.manual_seed(0)
-    pts = synthetic.gen_voxel_frame(2, 30000)
+    pts = synthetic.gen_voxel_frame(2, n_points)
     vfe = DynamicMeanVFE({}, 5, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE, synthetic.PC_RANGE)
     net = VoxelBackBone8x({}, 5, synthetic.GRID_SIZE.tolist()).to(DEV).eval()
     for m in net.modules():
