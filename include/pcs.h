@@ -303,7 +303,7 @@ typedef struct PcsTrackParams {
   float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
   float max_diameter;      /* filter_components max_diameter (12.5) */
   float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
-  int32_t reserved;        /* 0 */
+  int32_t groups;          /* lock-step groups (streams + host threads) of pcs_track_sequence; 0 = default (PCS_TRACK_GROUPS or 4) */
 } PcsTrackParams;
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames);

@@ -1021,8 +1021,10 @@ static inline int pow2_words(int64_t n) {
 // stream, event and pinned status page from call to call.
 class GroupWorkers {
  public:
+  // one pool per calling thread (several sequences may be tracked at once, each from its own host
+  // thread); never destroyed: the workers outlive main
   static GroupWorkers& get() {
-    static GroupWorkers* inst = new GroupWorkers();  // never destroyed: the threads outlive main
+    static thread_local GroupWorkers* inst = new GroupWorkers();
     return *inst;
   }
   void start(int slot, std::function<void()> job) {
@@ -1256,7 +1258,8 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   // rocprofiler-sdk on this image faults when kernels are launched from several native threads at
   // once: a profiled run takes one group (same kernels, same results)
   static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
-  const int G = profiled ? 1 : (groups_env < n_units ? groups_env : n_units);
+  const int want_groups = (prm->groups >= 1 && prm->groups <= kMaxGroups) ? prm->groups : groups_env;
+  const int G = profiled ? 1 : (want_groups < n_units ? want_groups : n_units);
   struct Group {
     int n, base, live;
     int unit[kMaxBatch];

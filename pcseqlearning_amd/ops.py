@@ -661,15 +661,15 @@ class TrackParams(__import__("ctypes").Structure):
         ("voxel_size", (_c.c_float * 3) * 4),
         ("nn_radius", _c.c_float), ("reg_error_coeff", _c.c_float), ("angle_threshold", _c.c_float),
         ("max_diameter", _c.c_float), ("smooth_weight0", _c.c_float), ("smooth_weight", _c.c_float),
-        ("smooth_stopping", _c.c_float), ("reserved", _c.c_int32),
+        ("smooth_stopping", _c.c_float), ("groups", _c.c_int32),
     ]
 
 
 def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
-                 smooth=(1.0, 10.0, 300, 1e-3)):
+                 smooth=(1.0, 10.0, 300, 1e-3), groups=0):
     prm = TrackParams()
-    prm.reserved = 0
+    prm.groups = int(groups)  # lock-step groups of track_sequence; 0 = the library's default
     L_ = len(radius_list)
     if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
         raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")

@@ -131,6 +131,9 @@ class ClusterTracking(nn.Module):
         self.num_registration_calls = 0
         # NATIVE_TRACKER: run track_frame's loop in pcs_track_frame (default) or op by op
         self.native = bool(model_cfg.get("NATIVE_TRACKER", True))
+        # TRACK_GROUPS: lock-step groups (streams + host threads) inside the native call; 0 = the library's
+        # default (4). SimpleReg sets 1 on the copies that track several sequences of a batch at once.
+        self.track_groups = int(model_cfg.get("TRACK_GROUPS", 0))
         self._track_params = None
 
     # ------------------------------------------------------------------ boxes
@@ -345,7 +348,8 @@ class ClusterTracking(nn.Module):
             self._track_params = ops.track_params(
                 self.radius_list, self.voxel_size_list, self.stopping_delta,
                 self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
-                self.angle_threshold, self.min_move_frame, max_iter=80)
+                self.angle_threshold, self.min_move_frame, max_iter=80, groups=self.track_groups)
+        self._track_params.groups = int(self.track_groups)
         return self._track_params
 
     def _native_window(self, offsets, frame_id):

@@ -37,10 +37,57 @@ class SimpleReg(RegistrationTemplate):
         if self.subsample:
             self.grid_sampler = GridSampling3D(grid_size=[0.08, 0.08, 0.08])
 
-    def process_sequence(self, seq_dict):
-        for module in self.preprocessors or []:
+    def process_sequence(self, seq_dict, preprocessors=None):
+        for module in (self.preprocessors or []) if preprocessors is None else preprocessors:
             seq_dict = module(seq_dict)
         return run_deferred(seq_dict)
+
+    def _process_batch_concurrently(self, batch_dict, todo, inflight):
+        """The sequences of a batch are independent (the reference loops over them, simple_reg.py:105-147):
+        `inflight` of them are processed at once, each on its own host thread, HIP stream and private copy
+        of the preprocessor modules (made per call: they hold no parameters, only small configuration
+        objects; nothing of a worker outlives the call). A sequence's tracking stage is a chain of small,
+        latency-bound launches, so several chains side by side fill the device where one cannot; the
+        tracker copies take ONE lock-step group each (the batch supplies the concurrency). Results do not
+        depend on what runs beside a sequence (tests/test_gpu_backbone_pipeline.py)."""
+        import copy
+        import threading
+        device = batch_dict["point_bxyz"].device
+        main = torch.cuda.current_stream(device)
+        grad = torch.is_grad_enabled()
+        results, errors = {}, []
+        lock = threading.Lock()
+        queue = list(todo)
+
+        def worker():
+            mods = copy.deepcopy(self.preprocessors)
+            for m in mods:
+                if hasattr(m, "track_groups"):
+                    m.track_groups = 1
+                    m._track_params = None
+            stream = torch.cuda.Stream(device=device)
+            stream.wait_stream(main)
+            try:
+                with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
+                    while True:
+                        with lock:
+                            if not queue or errors:
+                                break
+                            b = queue.pop(0)
+                        results[b] = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                    stream.synchronize()
+            except BaseException as e:  # re-raised on the calling thread
+                with lock:
+                    errors.append(e)
+
+        threads = [threading.Thread(target=worker, name=f"pcs-seq-{i}") for i in range(inflight)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
 
     def format_boxes(self, seq_dict):
         """Frame ids of the (frame-major, equally many per frame) GT boxes, track labels from the
@@ -107,12 +154,26 @@ class SimpleReg(RegistrationTemplate):
         return self.format_boxes(seq_dict)
 
     def forward(self, batch_dict):
+        batch_size = batch_dict["batch_size"]
+        save_dir = self.model_cfg.get("SAVE_DIR", None)
+
+        def done_before(b):
+            sequence_id = batch_dict["frame_id"][b][0][:-4]
+            return save_dir is not None and os.path.exists(f"{save_dir}/{sequence_id}/all.pth")
+
+        # SEQUENCES_IN_FLIGHT (default 4): how many sequences of a batch are processed at once
+        inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 4)), batch_size)
+        todo = [b for b in range(batch_size) if not done_before(b)]
+        processed = {}
+        if inflight > 1 and len(todo) > 1 and batch_dict["point_bxyz"].is_cuda:
+            processed = self._process_batch_concurrently(batch_dict, todo, min(inflight, len(todo)))
         outputs = []
-        for b in range(batch_dict["batch_size"]):
+        for b in range(batch_size):
+            if b in processed:
+                outputs.append(processed[b])
+                continue
             seq_dict = self.build_sequence(batch_dict, b)
-            sequence_id = seq_dict["frame_id"][0][:-4]
-            save_dir = self.model_cfg.get("SAVE_DIR", None)
-            if save_dir is None or not os.path.exists(f"{save_dir}/{sequence_id}/all.pth"):
+            if b in todo:
                 seq_dict = self.process_sequence(seq_dict)
             outputs.append(seq_dict)
         self.last_outputs = outputs

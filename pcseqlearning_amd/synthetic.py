@@ -179,6 +179,24 @@ def gen_sequence(seq_seed=0, num_frames=20, n_target=160_000, **scene_kw):
     return batch
 
 
+def collate_sequences(batches):
+    """Several gen_sequence() results as ONE batch (collate_batch of the reference's dataset,
+    dataset.py:252-298, for this sample contract): point arrays concatenated with the batch index in
+    column 0 of point_bxyz, per-sequence entries as lists."""
+    out = dict(batch_size=len(batches), num_frames=batches[0]["num_frames"])
+    pts = []
+    for b, s in enumerate(batches):
+        p = s["point_bxyz"].copy()
+        p[:, 0] = b
+        pts.append(p)
+    out["point_bxyz"] = np.concatenate(pts)
+    for key in ("point_sweep", "point_feat", "segmentation_label", "instance_label"):
+        out[key] = np.concatenate([s[key] for s in batches])
+    for key in ("gt_box_attr", "gt_box_cls_label", "obj_ids", "frame_id"):
+        out[key] = [s[key][0] for s in batches]
+    return out
+
+
 def gen_voxel_frame(seed=0, n_target=160_000):
     """Config 2 input: one 160k-pt frame as `points` [n, 1+3+2] (batch, x, y, z, intensity,
     elongation) -- 5 features after the mean VFE, as with Waymo in OpenPCDet."""

@@ -139,3 +139,34 @@ def test_full_pipeline_lockstep_vs_unit_by_unit():
         assert torch.equal(outs[0]["gt_box_best_iou_tracking"], other["gt_box_best_iou_tracking"])
         for k in ("point_component_rad1x25", "point_component_rad0x25", "point_gt_box_id"):
             assert torch.equal(outs[0][k], other[k])
+
+
+def test_batch_of_sequences_concurrently_vs_one_by_one():
+    """SimpleReg.forward on a batch of three sequences: processed at once (SEQUENCES_IN_FLIGHT 3: one host
+    thread, stream and preprocessor copy per sequence, one lock-step group each) and one after the other
+    (SEQUENCES_IN_FLIGHT 1, four groups) -- every sequence's outputs bit-identical."""
+    from pcseqlearning_amd.pcdet import models
+    from tools.run_sequence import build_model
+    seqs = [synthetic.gen_sequence(s, 10, 9000, n_static=12, n_vehicle=6, n_ped=3) for s in (5, 6, 7)]
+    batch = models.load_data_to_gpu(synthetic.collate_sequences(seqs), DEV)
+    outs = []
+    for inflight in (3, 1):
+        model = build_model(save=False, device=DEV)
+        model.model_cfg["SEQUENCES_IN_FLIGHT"] = inflight
+        with torch.no_grad():
+            model(batch)
+        outs.append(model.last_outputs)
+    assert len(outs[0]) == len(outs[1]) == 3
+    for a, b in zip(*outs):
+        ra, rb = a["cluster_tracking_results"], b["cluster_tracking_results"]
+        assert ra.keys() == rb.keys() and len(ra) == 6
+        assert any(v["fxyz"].shape[0] > 0 for v in ra.values())
+        for key in ra:
+            for field in ("fxyz", "component", "original_indices", "frame_indices", "moving", "component_hit"):
+                if field in ra[key]:
+                    assert torch.equal(ra[key][field], rb[key][field]), (key, field)
+        for k in ("gt_box_best_iou_tracking", "point_component_rad1x25", "point_component_rad0x25", "point_gt_box_id",
+                  "point_height"):
+            assert torch.equal(a[k], b[k]), k
+    # the three sequences differ from each other (the batch index really selects them)
+    assert outs[0][0]["point_fxyz"].shape != outs[0][1]["point_fxyz"].shape
