@@ -89,6 +89,24 @@ def load_sequence(seed, frames, points):
     return batch
 
 
+def load_sequences(seeds, frames, points):
+    """The rank's sequences; the ones not cached yet are generated side by side in child processes
+    (~40 s of numpy ray casting each). Called before this process touches the GPU."""
+    missing = [s for s in seeds if not os.path.exists(f"/tmp/pcs_seq_s{s}_f{frames}_p{points}.pkl")]
+    if len(missing) > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        workers = max(1, min(len(missing), (os.cpu_count() or 2) // 2))
+        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+            list(pool.map(_generate_sequence, [(s, frames, points) for s in missing]))
+    return [load_sequence(s, frames, points) for s in seeds]
+
+
+def _generate_sequence(job):
+    load_sequence(*job)
+    return job[0]
+
+
 def baseline_metric():
     """BASELINE.json's metric string (the file sits next to this script)."""
     try:
@@ -257,6 +275,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
+    ap.add_argument("--batch", type=int, default=6,
+                    help="sequences per step (one batch, as the reference's collate_batch hands them to "
+                         "SimpleReg.forward, which tracks the sequences of a batch concurrently)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank / sequence assignment and reduction only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,6 +294,10 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
 
+    seeds = sequences_of_rank(rank, world, max(1, args.batch))  # every step re-tracks the rank's batch
+    # (before this process initialises the GPU: the generator runs in child processes)
+    host_batches = None if args.dry_run else load_sequences(seeds, args.frames, args.points)
+
     import torch
     dist = None
     if world > 1:
@@ -282,7 +307,6 @@ def main():
         if not args.dry_run and args.backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(args.backend)  # "nccl" is RCCL over xGMI on ROCm
-    seeds = sequences_of_rank(rank, world, 1)  # every step re-tracks the rank's sequence
 
     if args.dry_run:
         # the N > 1 logic without a GPU: a rank "tracks" for 10 ms x (1 + rank) per step
@@ -310,8 +334,12 @@ def main():
     from tools.run_sequence import build_model
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    host_batch = load_sequence(seeds[0], args.frames, args.points)
-    batch = models.load_data_to_gpu(host_batch, device)
+    from pcseqlearning_amd import synthetic
+    host_batch = host_batches[0]
+    batch1 = models.load_data_to_gpu(host_batch, device)  # the first sequence alone (latency / stage report)
+    batch = batch1 if len(host_batches) == 1 else \
+        models.load_data_to_gpu(synthetic.collate_sequences(host_batches), device)
+    n_points_in = int(batch["point_bxyz"].shape[0])
     model = build_model(save=False, device=device)
     lib = L.load()
 
@@ -338,12 +366,23 @@ def main():
     prof = (ctypes.c_double * 9)()
     lib.pcs_profile_icp_read(prof)
     lib.pcs_profile_icp(ctypes.c_int(0))
-    host_spans = {k: round(v / args.steps, 4) for k, v in timer.RECORDS.items()
+    B = len(host_batches)
+    host_spans = {k: round(v / (args.steps * B), 4) for k, v in timer.RECORDS.items()
                   if not k.startswith(("Tracking Frame", "ground:"))}
     tracker = model.preprocessors[2]
-    out = model.last_outputs[0]
     dt, (total_sequences, points_in) = reduce_metrics(
-        dist, device, dt, [float(args.steps), float(args.steps) * float(host_batch["point_bxyz"].shape[0])])
+        dist, device, dt, [float(args.steps * B), float(args.steps) * float(n_points_in)])
+    # one sequence alone through the same model (four lock-step groups, nothing beside it): its latency,
+    # and the outputs / tracker counters the report below quotes (the batch's worker copies are gone)
+    with torch.no_grad():
+        model(batch1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        model(batch1)
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) * 1e3
+    out = model.last_outputs[0]
 
     if rank == 0:
         # one extra, untimed step with device-synchronised stage spans for the per-stage report
@@ -352,7 +391,8 @@ def main():
             timer.RECORDS.clear()
             timer.STATS.clear()
             timer.SYNC = True
-            step()
+            with torch.no_grad():
+                model(batch1)
             torch.cuda.synchronize()
             timer.SYNC = False
             stages = stage_rooflines(dict(timer.RECORDS), dict(timer.STATS), prof, out)
@@ -389,9 +429,18 @@ def main():
             "dtype": "f32 points / f64 solve",
             "data": "synthetic",
             "config": {
-                "workload": ("configs[2]: 20-frame x 160k-pt synthetic sequence, "
+                "workload": ("configs[2]: 20-frame x 160k-pt synthetic sequences, "
                              "cluster_tracking_TLS_multiradius_every8 end to end "
-                             "(subsample + ground removal + 3-radius proposal + tracking)"),
+                             "(subsample + ground removal + 3-radius proposal + tracking); a step is one "
+                             f"batch of {B} independent sequences through SimpleReg.forward, which processes "
+                             "the sequences of a batch concurrently (one host thread, stream and lock-step "
+                             "group per sequence)" if B > 1 else
+                             "configs[2]: one 20-frame x 160k-pt synthetic sequence per step, "
+                             "cluster_tracking_TLS_multiradius_every8 end to end"),
+                "batch_size": B,
+                "sequences_in_flight": min(B, int(model.model_cfg.get("SEQUENCES_IN_FLIGHT", 4))),
+                "one_sequence_alone_ms": round(single_ms, 2),
+                "one_sequence_alone_sequences_per_s": round(1e3 / single_ms, 4),
                 "frames": args.frames, "points_per_frame": args.points,
                 "points_in_per_second": round(points_in / dt, 1),
                 "points_after_subsample": int(out["full_point_fxyz"].shape[0]),
@@ -401,8 +450,9 @@ def main():
                 "tracker_host_ticks": int(getattr(tracker, "last_ticks", 0)),
                 "icp_level_calls_per_sequence": int(tracker.num_registration_calls),
                 "profiler_forced_single_group": bool(os.environ.get("ROCP_TOOL_LIBRARIES")),
-                # host wall spans of the timed steps (not device-synchronised)
-                "stage_seconds_per_step": host_spans,
+                # host wall spans of the timed steps per sequence (not device-synchronised; the sequences of a
+                # batch overlap, so the spans add up to more than the step)
+                "stage_seconds_per_sequence": host_spans,
             },
             "roofline": {
                 "bound": "hbm",
