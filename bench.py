@@ -234,7 +234,7 @@ def kernel_stats_stages(out):
     path = os.path.join(ROOT, "profiles", "r02_sequence_kernel_stats.csv")
     if not os.path.exists(path):
         return []
-    seqs = 4.0
+    seqs = 6.0  # --batch 1: 1 warm-up + 3 timed + 2 single-sequence runs of the profiled command
     rows = list(csv.DictReader(open(path)))
 
     def ms_of(*names):
@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--batch", type=int, default=6,
                     help="sequences per step (one batch, as the reference's collate_batch hands them to "
                          "SimpleReg.forward, which tracks the sequences of a batch concurrently)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="sequences of a batch processed at once (SimpleReg's SEQUENCES_IN_FLIGHT; 0 = its default)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank / sequence assignment and reduction only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -341,6 +343,8 @@ def main():
         models.load_data_to_gpu(synthetic.collate_sequences(host_batches), device)
     n_points_in = int(batch["point_bxyz"].shape[0])
     model = build_model(save=False, device=device)
+    if args.inflight > 0:
+        model.model_cfg["SEQUENCES_IN_FLIGHT"] = args.inflight
     lib = L.load()
 
     def step():

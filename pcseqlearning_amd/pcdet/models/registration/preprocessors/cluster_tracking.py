@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ..... import ops
 from .....lib import PcsError
-from ....utils.common_utils import EasyDict, filter_dict, run_deferred
+from ....utils.common_utils import EasyDict, filter_dict, pooled_stream, run_deferred
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
@@ -615,10 +615,12 @@ class ClusterTracking(nn.Module):
         if perm is not None:
             s_fxyz = s_fxyz[perm].contiguous()
         helper = None
+        side_ctx = None
         if seq_dict.get("_deferred"):
             device = s_fxyz.device
             main = torch.cuda.current_stream(device)
-            side = torch.cuda.Stream(device=device)
+            side_ctx = pooled_stream(device)
+            side = side_ctx.__enter__()
             side.wait_stream(main)
             grad = torch.is_grad_enabled()
             err = []
@@ -644,6 +646,7 @@ class ClusterTracking(nn.Module):
             if helper is not None:
                 helper.join()
                 main.wait_stream(side)
+                side_ctx.__exit__(None, None, None)
                 if err:
                     raise err[0]
         self.num_registration_calls += sum(r[1][1] for r in res)

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .... import ops
 from ...utils import timer
-from ...utils.common_utils import EasyDict, filter_dict, run_deferred
+from ...utils.common_utils import EasyDict, filter_dict, pooled_stream, run_deferred
 from ...utils.timer import Timer
 from ..model_utils.grid_sampling import GridSampling3D
 from .registration_module_template import RegistrationTemplate
@@ -73,17 +73,17 @@ class SimpleReg(RegistrationTemplate):
                 if hasattr(m, "track_groups"):
                     m.track_groups = 1
                     m._track_params = None
-            stream = torch.cuda.Stream(device=device)
-            stream.wait_stream(main)
             try:
-                with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
-                    while True:
-                        with lock:
-                            if not queue or errors:
-                                break
-                            b = queue.pop(0)
-                        results[b] = self.process_sequence(self.build_sequence(batch_dict, b), mods)
-                    stream.synchronize()
+                with pooled_stream(device) as stream:
+                    stream.wait_stream(main)
+                    with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
+                        while True:
+                            with lock:
+                                if not queue or errors:
+                                    break
+                                b = queue.pop(0)
+                            results[b] = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                        stream.synchronize()
             except BaseException as e:  # re-raised on the calling thread
                 with lock:
                     errors.append(e)
@@ -171,6 +171,8 @@ class SimpleReg(RegistrationTemplate):
 
         # SEQUENCES_IN_FLIGHT (default 4): how many sequences of a batch are processed at once
         inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 4)), batch_size)
+        if os.environ.get("ROCP_TOOL_LIBRARIES"):
+            inflight = 1  # rocprofiler-sdk on this image faults when several host threads launch kernels
         todo = [b for b in range(batch_size) if not done_before(b)]
         processed = {}
         if inflight > 1 and len(todo) > 1 and batch_dict["point_bxyz"].is_cuda:
