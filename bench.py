@@ -363,8 +363,13 @@ def main():
     timer.RECORDS.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    trace = os.environ.get("PCS_BENCH_TRACE")
+    for i in range(args.steps):
+        ts = time.perf_counter()
         step()
+        if trace:
+            print(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB",
+                  file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 9)()

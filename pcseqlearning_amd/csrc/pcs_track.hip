@@ -10,8 +10,18 @@
 // loss reduced through LDS; a second elementwise kernel applies the same sequence of decoupled
 // weight-decay factors to the elements that never see a gradient.
 #include "pcs_common.hpp"
+#include <mutex>
 
 namespace pcs {
+
+// Kernels with a grid-wide barrier need every workgroup of the launch resident at once.  Two such
+// launches from different host threads (sequences of a batch in flight) can each take part of the
+// chip and wait for the rest for ever, so they are issued one at a time, process-wide, and the
+// holder waits for its launch before the next may start.
+static std::mutex& sv_grid_mutex() {
+  static std::mutex* mu = new std::mutex();
+  return *mu;
+}
 
 struct SmoothState {
   int iters;
@@ -1090,10 +1100,12 @@ int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C
         comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
         stopping, st);
   } else if (blocks <= SV_MAX_BLOCKS && num_itr <= SV_MAX_ITR) {
+    std::lock_guard<std::mutex> lk(sv_grid_mutex());  // one grid-barrier launch at a time (see smooth_velo_run_batch)
     PCS_CHECK_HIP(hipMemsetAsync(grid, 0, sizeof(SmoothGrid), s));
     smooth_velo_grid_kernel<<<(int)blocks, SV_BLOCK, (size_t)cpb * nf * 2 * sizeof(float), s>>>(
         comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
         stopping, cpb, grid, st, err);
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
   } else {
     smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
                                               frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
@@ -1166,18 +1178,31 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
   if (sb.n == 0) return PCS_OK;
   // the multi-workgroup form spins at a grid barrier: all its workgroups must be resident together
   // (256 CUs x 2 workgroups of 1024 threads); beyond that the problems go one launch at a time
-  if (have[1]) smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
   for (int kind = 0; kind < 3; ++kind) {
     if (!have[kind]) continue;
-    if (kind == 1 && resident > 384) {
-      for (int e = 0; e < sb.n; ++e) {
-        if (sb.j[e].kind != 1) continue;
-        SvBatch one;
-        one.n = 1;
-        one.j[0] = sb.j[e];
-        smooth_velo_batch_kernel<<<dim3(one.j[0].blocks, 1), SV_BLOCK, lds[1], s>>>(one, 1, weight0, weight, num_itr,
-                                                                                    stopping);
+    if (kind == 1) {
+      // The multi-workgroup form meets at a grid barrier, so ALL its workgroups must be resident at once
+      // -- and the chip holds 512 workgroups of 1024 threads. Several host threads (lock-step groups,
+      // sequences of a batch) can arrive here together: two such launches side by side can each get half
+      // their workgroups and wait for the other half until the barrier times out (seen as a 30 s stall
+      // once in ~25 batches with four sequences in flight). One launch of this form at a time, process
+      // wide: the lock is held until the launch has drained.
+      std::lock_guard<std::mutex> lk(sv_grid_mutex());
+      smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
+      if (resident > 384) {
+        for (int e = 0; e < sb.n; ++e) {
+          if (sb.j[e].kind != 1) continue;
+          SvBatch one;
+          one.n = 1;
+          one.j[0] = sb.j[e];
+          smooth_velo_batch_kernel<<<dim3(one.j[0].blocks, 1), SV_BLOCK, lds[1], s>>>(one, 1, weight0, weight,
+                                                                                      num_itr, stopping);
+        }
+      } else {
+        smooth_velo_batch_kernel<<<dim3(nblk[1], sb.n), SV_BLOCK, lds[1], s>>>(sb, 1, weight0, weight, num_itr,
+                                                                              stopping);
       }
+      PCS_CHECK_HIP(hipStreamSynchronize(s));
       continue;
     }
     smooth_velo_batch_kernel<<<dim3(nblk[kind], sb.n), SV_BLOCK, lds[kind], s>>>(sb, kind, weight0, weight, num_itr,

@@ -101,6 +101,18 @@ def smooth_velo(comp_velos, comp_center_diffs, frame_id, next_frame_id, weight0=
                            float(weight), num_itr, stopping)
 
 
+_DEFERRED_POOL = []
+
+
+def _deferred_pool():
+    """Process-wide helper threads for the work parked beside the native tracker (persistent: the ops
+    they call keep per-thread pinned pages)."""
+    if not _DEFERRED_POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _DEFERRED_POOL.append(ThreadPoolExecutor(max_workers=16, thread_name_prefix="pcs-deferred"))
+    return _DEFERRED_POOL[0]
+
+
 class ClusterTracking(nn.Module):
     def __init__(self, model_cfg, runtime_cfg):
         super().__init__()
@@ -632,8 +644,7 @@ class ClusterTracking(nn.Module):
                 except BaseException as e:  # re-raised on the main thread
                     err.append(e)
 
-            helper = threading.Thread(target=side_job, name="pcs-deferred")
-            helper.start()
+            helper = _deferred_pool().submit(side_job)
         # UNITS_PER_CALL (default: all): how many units share a native call; 1 = one unit after the
         # other (same results bit for bit -- a unit never depends on what runs beside it)
         per_call = int(self.model_cfg.get("UNITS_PER_CALL", 0)) or len(descs)
@@ -644,7 +655,7 @@ class ClusterTracking(nn.Module):
                 res += ops.track_sequence(self._native_params(), s_fxyz, offsets, descs[b:b + per_call])
         finally:
             if helper is not None:
-                helper.join()
+                helper.result()
                 main.wait_stream(side)
                 side_ctx.__exit__(None, None, None)
                 if err:
