@@ -366,8 +366,12 @@ def main():
     trace = os.environ.get("PCS_BENCH_TRACE")
     for i in range(args.steps):
         ts = time.perf_counter()
+        if trace:  # a step that hangs shows where: every thread's Python stack after 5 s, then every 5 s
+            import faulthandler
+            faulthandler.dump_traceback_later(5, repeat=True, file=sys.stderr)
         step()
         if trace:
+            faulthandler.cancel_dump_traceback_later()
             print(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB",
                   file=sys.stderr, flush=True)
     barrier()

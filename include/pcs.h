@@ -268,6 +268,14 @@ size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F);
 int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C, int F,
                     int frame_lo, int frame_hi, float weight0, float weight, int num_itr,
                     float stopping, void* ws, size_t ws_bytes, pcs_stream_t stream);
+/* The same for n problems in one call (what the sequence tracker does at every frame step, one problem
+ * per tracking unit; host arrays of n device pointers / sizes; ws[e] sized by
+ * pcs_smooth_velo_workspace_bytes(C[e], F[e])). Results are those of n separate calls. The call
+ * returns after the stream has drained; PCS_ERR_HIP if a multi-workgroup problem's barrier timed out. */
+int pcs_smooth_velo_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
+                          const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
+                          float weight0, float weight, int num_itr, float stopping, void* const* ws,
+                          const size_t* ws_bytes, pcs_stream_t stream);
 
 /* ClusterTracking.track_frame, pcdet/models/registration/preprocessors/cluster_tracking.py:430-787
  * (with sample_frame :39-51, component_center / component_diameter / filter_components :89-160,

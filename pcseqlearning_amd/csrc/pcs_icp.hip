@@ -438,8 +438,11 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 //                         for the rest -- and for every query in iteration 1.
 // Exact: the same neighbours as a full search, always.
 __global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int jf) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int j = jf & 0xffff;
+  const bool own_wg = (jf >> 16) != 0;  // EXPERIMENT: the stop rule has a workgroup of its own (the last)
+  const int gdx = own_wg ? (int)gridDim.x - 1 : (int)gridDim.x;
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
   // The gate is read ONCE per workgroup. Workgroup 0 lowers stop_iter during this very launch (below),
@@ -456,13 +459,19 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
   const int nround = (nq + kBlock - 1) / kBlock;
-  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  if (own_wg) {
+    if ((int)blockIdx.x == gdx) {
+      icp_decide(pr, k - 1);
+      return;
+    }
+    if ((int)blockIdx.x >= nround) return;
+  } else if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
   // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  if (!own_wg && blockIdx.x == 0) icp_decide(pr, k - 1);
   if (k == 1) {  // no neighbours yet: every query takes the cooperative search
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gdx * blockDim.x) pr.wl[q] = q;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->wl_n = nq;
     return;
   }
@@ -485,7 +494,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
   // steps of the moving points in iteration k-1, by the place they moved into
   const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+  for (int r = blockIdx.x; r < nround; r += gdx) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
@@ -1102,7 +1111,9 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
   const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
   const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
-  const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
+  static const int x_cs = getenv("PCS_X_CS") ? atoi(getenv("PCS_X_CS")) : 4;
+  static const int x_own = getenv("PCS_X_OWN") ? atoi(getenv("PCS_X_OWN")) : 0;
+  const int nb_cs = gx_for(q * x_cs, kBlock, 4096);   // later: the work lists (a fraction of the queries)
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -1122,13 +1133,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       // kernel's own begin-to-end time, as rocprofv3 reports it
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
-      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q + x_own, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j | (x_own << 16));
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 2), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
-      icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_nn_kernel<<<dim3(nb_q + x_own, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j | (x_own << 16));
       icp_nn_search_kernel<<<dim3(nb_c, bt.n, 2), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }

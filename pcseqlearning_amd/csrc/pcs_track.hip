@@ -269,8 +269,9 @@ smooth_velo_lds_body(float* __restrict__ sv /* LDS [n_in] current iterate */, fl
 // its slice of v in LDS. The only coupling is the scalar loss of the 3-strike stop rule: one f64
 // partial per workgroup and ONE grid barrier per step (arrival counter that only grows; partials
 // double-buffered by step parity). All workgroups evaluate the same stop rule on the same sum, so
-// they leave together. The grid is at most 64 x 1024 threads, far below what the device keeps
-// resident, and the barrier wait is bounded: on time-out the error word is set and every wave exits.
+// they leave together. The grid is at most 64 x 1024 threads (a quarter of what the device keeps
+// resident: one such workgroup per CU), the host sends one such launch at a time, and the barrier
+// wait is bounded: on time-out the error word is set to 3 and every wave exits.
 constexpr int SV_MAX_BLOCKS = 64;
 struct SmoothGrid {
   unsigned int arrive;
@@ -472,7 +473,7 @@ smooth_velo_batch_kernel(SvBatch sb, int kind, float weight0, float weight, int 
 __global__ void __launch_bounds__(kBlock)
 smooth_velo_batch_reset_kernel(SvBatch sb) {
   const SvJob& j = sb.j[blockIdx.x];
-  if (threadIdx.x == 0 && j.kind == 1) {
+  if (threadIdx.x == 0) {  // (every kind: the time-out word is read back whatever form the problem took)
     j.grid->arrive = 0;
     j.grid->timeout = 0;
   }
@@ -1106,6 +1107,11 @@ int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C
         comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
         stopping, cpb, grid, st, err);
     PCS_CHECK_HIP(hipStreamSynchronize(s));
+    if (!err) {  // nobody else would see a barrier that timed out
+      int timed_out = 0;
+      PCS_CHECK_HIP(hipMemcpy(&timed_out, &grid->timeout, sizeof(int), hipMemcpyDeviceToHost));
+      if (timed_out) return PCS_ERR_HIP;
+    }
   } else {
     smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
                                               frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
@@ -1130,7 +1136,6 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
   size_t lds[3] = {0, 0, 0};
   int nblk[3] = {0, 0, 0}, have[3] = {0, 0, 0};
   int64_t tot_max = 1;
-  int resident = 0;
   for (int e = 0; e < n; ++e) {
     if (!comp_velos[e] || !comp_center_diffs[e] || !ws[e] || C[e] < 1 || F[e] < 1 || frame_lo[e] < 0 ||
         frame_hi[e] >= F[e] || frame_lo[e] > frame_hi[e] || num_itr < 0)
@@ -1164,7 +1169,6 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
       j.kind = 1;
       j.blocks = (int)blocks;
       need = (size_t)j.cpb * nf * 2 * sizeof(float);
-      resident += (int)blocks;
     } else {
       j.kind = 2;
     }
@@ -1176,32 +1180,50 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
     ++sb.n;
   }
   if (sb.n == 0) return PCS_OK;
-  // the multi-workgroup form spins at a grid barrier: all its workgroups must be resident together
-  // (256 CUs x 2 workgroups of 1024 threads); beyond that the problems go one launch at a time
+  smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
   for (int kind = 0; kind < 3; ++kind) {
     if (!have[kind]) continue;
     if (kind == 1) {
-      // The multi-workgroup form meets at a grid barrier, so ALL its workgroups must be resident at once
-      // -- and the chip holds 512 workgroups of 1024 threads. Several host threads (lock-step groups,
-      // sequences of a batch) can arrive here together: two such launches side by side can each get half
-      // their workgroups and wait for the other half until the barrier times out (seen as a 30 s stall
-      // once in ~25 batches with four sequences in flight). One launch of this form at a time, process
-      // wide: the lock is held until the launch has drained.
+      // The multi-workgroup form meets at a grid barrier, so ALL workgroups of a launch must be resident
+      // at once. The kernel takes 87 VGPRs: a 1024-thread workgroup is four waves on each SIMD, and a SIMD
+      // holds five such waves, so a CU holds ONE workgroup (256 on the chip, not the 512 a 64-register
+      // kernel would get). A launch gets at most half of what the occupancy query allows -- the rest of
+      // the chip stays free for the kernels other streams keep sending -- and the problems are packed
+      // into as many launches as that takes. Several host threads (lock-step groups, sequences of a
+      // batch) can arrive here together, and two such launches side by side could each get part of
+      // their workgroups and wait for the rest until the barrier times out: one launch of this form at
+      // a time, process wide, the lock held until it has drained.
       std::lock_guard<std::mutex> lk(sv_grid_mutex());
-      smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
-      if (resident > 384) {
-        for (int e = 0; e < sb.n; ++e) {
-          if (sb.j[e].kind != 1) continue;
-          SvBatch one;
-          one.n = 1;
-          one.j[0] = sb.j[e];
-          smooth_velo_batch_kernel<<<dim3(one.j[0].blocks, 1), SV_BLOCK, lds[1], s>>>(one, 1, weight0, weight,
-                                                                                      num_itr, stopping);
-        }
-      } else {
-        smooth_velo_batch_kernel<<<dim3(nblk[1], sb.n), SV_BLOCK, lds[1], s>>>(sb, 1, weight0, weight, num_itr,
-                                                                              stopping);
+      static int budget = 0;  // (under the lock)
+      if (budget == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        PCS_CHECK_HIP(hipGetDevice(&dev));
+        PCS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        PCS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_velo_batch_kernel, SV_BLOCK,
+                                                               (size_t)SV_BLOCK * SV_ELEMS * sizeof(float)));
+        if (per_cu > 1) per_cu = 1;  // (the query is known to answer one too many near an SGPR boundary)
+        budget = per_cu * prop.multiProcessorCount / 2;
+        if (budget < SV_MAX_BLOCKS) return PCS_ERR_HIP;  // not this device
       }
+      SvBatch part;
+      part.n = 0;
+      int part_blocks = 0, part_max = 0;
+      auto flush = [&]() {
+        if (part.n == 0) return;
+        smooth_velo_batch_kernel<<<dim3(part_max, part.n), SV_BLOCK, lds[1], s>>>(part, 1, weight0, weight, num_itr,
+                                                                               stopping);
+        part.n = 0;
+        part_blocks = part_max = 0;
+      };
+      for (int e = 0; e < sb.n; ++e) {
+        if (sb.j[e].kind != 1) continue;
+        if (part_blocks + sb.j[e].blocks > budget) flush();
+        part.j[part.n++] = sb.j[e];
+        part_blocks += sb.j[e].blocks;
+        if (sb.j[e].blocks > part_max) part_max = sb.j[e].blocks;
+      }
+      flush();
       PCS_CHECK_HIP(hipStreamSynchronize(s));
       continue;
     }
@@ -1347,6 +1369,30 @@ int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C
                     float stopping, void* ws, size_t ws_bytes, hipStream_t s) {
   return pcs::smooth_velo_run(comp_velos, comp_center_diffs, C, F, frame_lo, frame_hi, weight0, weight,
                               num_itr, stopping, ws, ws_bytes, nullptr, s);
+}
+
+// several problems in one call (what the sequence tracker does at every step, one problem per unit)
+int pcs_smooth_velo_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
+                          const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
+                          float weight0, float weight, int num_itr, float stopping, void* const* ws,
+                          const size_t* ws_bytes, hipStream_t s) {
+  if (n < 0 || (n > 0 && (!comp_velos || !comp_center_diffs || !C || !F || !frame_lo || !frame_hi || !ws ||
+                          !ws_bytes)))
+    return PCS_ERR_ARG;
+  int rc = pcs::smooth_velo_run_batch(n, comp_velos, comp_center_diffs, C, F, frame_lo, frame_hi, weight0,
+                                      weight, num_itr, stopping, ws, ws_bytes, nullptr, s);
+  if (rc != PCS_OK) return rc;
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  for (int e = 0; e < n; ++e) {  // a grid barrier that timed out must not pass silently
+    if (frame_lo[e] == frame_hi[e]) continue;
+    pcs::Arena a(ws[e], ws_bytes[e]);
+    (void)a.take<pcs::SmoothState>(1);
+    pcs::SmoothGrid* grid = a.take<pcs::SmoothGrid>(1);
+    int timed_out = 0;
+    PCS_CHECK_HIP(hipMemcpy(&timed_out, &grid->timeout, sizeof(int), hipMemcpyDeviceToHost));
+    if (timed_out) return PCS_ERR_HIP;
+  }
+  return PCS_OK;
 }
 
 // out [B, N] int32 (1 = point inside box)

@@ -1007,6 +1007,9 @@ struct HostUnit {
   IcpState icp;
 };
 
+// a unit's error word: 3 = the grid barrier of smooth_velo timed out (a device-side failure: loud),
+// anything else = a search grid / fixed-point range overflowed (the caller may fall back)
+static inline int unit_error(int err) { return err == 3 ? PCS_ERR_HIP : PCS_ERR_RANGE; }
 static inline int nblk(int64_t n) { return (int)(((n < 1 ? 1 : n) + kBlock - 1) / kBlock); }
 
 static inline int pow2_words(int64_t n) {
@@ -1235,7 +1238,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < n_units; ++i) {
     hu[i].host = pin_trk[i];
-    if (hu[i].host.err) return PCS_ERR_RANGE;
+    if (hu[i].host.err) return unit_error(hu[i].host.err);
     hu[i].any_valid = hu[i].host.active != 0;
   }
 
@@ -1386,7 +1389,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           break;
         }
         case PH_POSTWAIT: {
-          if (h.host.err) return PCS_ERR_RANGE;
+          if (h.host.err) return unit_error(h.host.err);
           h.last_col = h.next;
           h.next += h.dir;
           if (in_range(h, h.next) && h.host.active) {
@@ -1402,7 +1405,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
           break;
         }
         case PH_FINALWAIT: {
-          if (h.host.err) return PCS_ERR_RANGE;
+          if (h.host.err) return unit_error(h.host.err);
           h.io->info[0] = h.host.ex_count;
           h.io->info[1] = h.reg_calls;
           h.io->info[2] = h.steps;

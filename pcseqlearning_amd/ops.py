@@ -495,6 +495,39 @@ def smooth_velo(comp_velos, comp_center_diffs, frame_id, next_frame_id, weight0=
     return comp_velos
 
 
+def smooth_velo_batch(problems, weight0=1.0, weight=10.0, num_itr=300, stopping=1e-3):
+    """smooth_velo for several problems in one call: problems = [(comp_velos [C,F,3] f32 (in place),
+    comp_center_diffs, frame_id, next_frame_id), ...]; what the sequence tracker does at every frame step."""
+    import ctypes
+    lib = L.load()
+    n = len(problems)
+    if n == 0:
+        return []
+    keep, ws_list = [], []
+    vel = (ctypes.c_void_p * n)()
+    dif = (ctypes.c_void_p * n)()
+    wsp = (ctypes.c_void_p * n)()
+    Cs = (ctypes.c_int64 * n)()
+    Fs = (ctypes.c_int * n)()
+    lo = (ctypes.c_int * n)()
+    hi = (ctypes.c_int * n)()
+    wsb = (ctypes.c_size_t * n)()
+    for e, (v, d, a, b) in enumerate(problems):
+        L.require_gpu(v, "smooth_velo_batch")
+        assert v.is_contiguous() and v.dtype == torch.float32
+        d = d.float().contiguous()
+        keep.append(d)
+        C, F, _ = v.shape
+        ws = L.workspace(lib.pcs_smooth_velo_workspace_bytes(L.i64(C), L.i32(F)), v.device)
+        ws_list.append(ws)
+        vel[e], dif[e], wsp[e] = v.data_ptr(), d.data_ptr(), ws.data_ptr()
+        Cs[e], Fs[e], lo[e], hi[e], wsb[e] = C, F, min(a, b), max(a, b), ws.numel()
+    L.check(lib.pcs_smooth_velo_batch(L.i32(n), vel, dif, Cs, Fs, lo, hi, L.f32(weight0), L.f32(weight),
+                                      L.i32(num_itr), L.f32(stopping), wsp, wsb, L.stream()),
+            "pcs_smooth_velo_batch")
+    return [p[0] for p in problems]
+
+
 def points_in_boxes(points, boxes):
     """roiaware_pool3d_utils.points_in_boxes_cpu semantics on the device: [B, N] int32."""
     L.require_gpu(points, "points_in_boxes")

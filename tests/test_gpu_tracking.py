@@ -45,6 +45,25 @@ def test_smooth_velo_many_components_vs_oracle():
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-5)
 
 
+def test_smooth_velo_batch_more_workgroups_than_the_chip_holds():
+    """Seven multi-workgroup problems of ~54 workgroups each in ONE call: 380 workgroups of 1024 threads,
+    and the chip keeps 256 resident (one per CU at the kernel's 87 registers). All at a barrier in one
+    launch would wait for ever (the time-out, then a silent fallback: seen as a 50 s stall once in ~100
+    sequences of a batch); the call packs them under a residency budget. Results = separate calls,
+    bit for bit; two small problems ride along in the other kernel forms."""
+    rng = np.random.default_rng(11)
+    shapes = [(20000, 20, 4, 14)] * 7 + [(300, 20, 9, 2), (5, 20, 0, 19)]
+    probs, want = [], []
+    for C, F, a, b in shapes:
+        diffs = (rng.standard_normal((C, F, 3)) * 0.3).astype(np.float32)
+        velos = (diffs + rng.standard_normal((C, F, 3)) * 0.05).astype(np.float32)
+        want.append(ops.smooth_velo(dev(velos.copy()), dev(diffs), a, b).cpu().numpy())
+        probs.append((dev(velos.copy()), dev(diffs), a, b))
+    got = ops.smooth_velo_batch(probs)
+    for g_, w_ in zip(got, want):
+        np.testing.assert_array_equal(g_.cpu().numpy(), w_)
+
+
 def _seq_points(g):
     sp = EasyDict(fxyz=dev(g["fxyz"].copy()), frame=dev(g["fxyz"][:, :1].astype(np.int64)),
                   gt_box_id=dev(np.full(len(g["fxyz"]), -1, np.int64)),
