@@ -269,6 +269,8 @@ def kernel_stats_stages(out):
 
 
 def main():
+    if os.environ.get("PCS_SWITCH_US"):  # EXPERIMENT: the interpreter's thread switch interval
+        sys.setswitchinterval(float(os.environ["PCS_SWITCH_US"]) * 1e-6)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)

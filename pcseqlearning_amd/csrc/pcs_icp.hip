@@ -149,8 +149,8 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->iters = 0;
     st->err = 0;
     st->decided = 0;
-    st->wl_n = 0;
-    st->ws_n = 0;
+    st->wl_n[0] = st->wl_n[1] = 0;
+    st->ws_n[0] = st->ws_n[1] = 0;
     st->dmax[0] = st->dmax[1] = 0u;
   }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {
@@ -432,10 +432,12 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 // (98 % of the searches of a converging loop return the partner they returned before).
 //   icp_nn_kernel         one LANE per query: the budget test; the queries that must search again
 //                         are compacted into two work lists (one atomic per wave and list)
-//   icp_nn_search_kernel  blockIdx.z = 0: eight lanes per query around the old partner
+//   icp_nn_search_kernel  blockIdx.z & 1 = 0: eight lanes per query around the old partner
 //                         (g2_nearest_seeded8) for the list of queries whose partner is within a
-//                         cell or so; blockIdx.z = 1: the cooperative search (32 lanes per query)
-//                         for the rest -- and for every query in iteration 1.
+//                         cell or so; 1: the cooperative search (32 lanes per query) for the rest --
+//                         and for every query in iteration 1. blockIdx.z >> 1 = the direction: a
+//                         workgroup serves forward OR backward queries (one grid, one copy of the
+//                         search in the code: the two-direction form spilled ~400 scalar registers).
 // Exact: the same neighbours as a full search, always.
 __global__ void __launch_bounds__(kBlock)
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int jf) {
@@ -472,7 +474,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   if (!own_wg && blockIdx.x == 0) icp_decide(pr, k - 1);
   if (k == 1) {  // no neighbours yet: every query takes the cooperative search
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gdx * blockDim.x) pr.wl[q] = q;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->wl_n = nq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
     return;
   }
   __shared__ int skey[kMomSlots];
@@ -562,18 +564,25 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
       }
     }
     mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
-    const unsigned long long ms = __ballot(to_seeded), mc = __ballot(to_coop);
-    if (ms) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&st->ws_n, __popcll(ms));
-      base = __shfl(base, 0, 64);
-      if (to_seeded) pr.wls[base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
-    }
-    if (mc) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&st->wl_n, __popcll(mc));
-      base = __shfl(base, 0, 64);
-      if (to_coop) pr.wl[base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
+    // the work lists, by direction (a wave is all forward or all backward, except the one at Mn)
+    const unsigned long long mf = __ballot(fwd);
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const unsigned long long md = dir ? ~mf : mf;
+      const unsigned long long ms = __ballot(to_seeded) & md, mc = __ballot(to_coop) & md;
+      const int off = dir ? Mn : 0;
+      if (ms) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&st->ws_n[dir], __popcll(ms));
+        base = __shfl(base, 0, 64);
+        if (to_seeded && fwd == (dir == 0)) pr.wls[off + base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
+      }
+      if (mc) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&st->wl_n[dir], __popcll(mc));
+        base = __shfl(base, 0, 64);
+        if (to_coop && fwd == (dir == 0)) pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
+      }
     }
   }
   __syncthreads();
@@ -586,19 +595,24 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
   if (k > pr.max_iter || k > st->stop_iter) return;
-  const bool coop = blockIdx.z == 1;
-  const int nw = coop ? st->wl_n : st->ws_n;
+  const bool coop = (blockIdx.z & 1) != 0;
+  const int dir = blockIdx.z >> 1;  // 0: forward queries (moving -> reference grid), 1: backward
+  const int nw = coop ? st->wl_n[dir] : st->ws_n[dir];
   const int per_block = coop ? kBlock / 32 : kBlock / 8;
   const int nround = (nw + per_block - 1) / per_block;
   if ((int)blockIdx.x >= nround) return;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   GridDesc g = pr.geom->g;
-  int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
-  int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
-  float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
-  float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
-  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  const bool fwd = dir == 0;
+  // everything below is uniform in the workgroup: one direction, one grid, one instance of the search
+  int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
+  float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
+  const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
+  const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
+  const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
+  const int qoff = fwd ? 0 : Mn;
+  const int df = fwd ? pr.df : -pr.df;
   __shared__ int skey[kMomSlots];
   __shared__ unsigned long long sacc[kMomSlots * 17];
   const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
@@ -607,34 +621,21 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
   __syncthreads();
   if (coop) {
     const int sub = threadIdx.x & 31;
+    const int32_t* __restrict__ list = pr.wl + qoff;
     for (int r = blockIdx.x; r < nround; r += gridDim.x) {
       const int w = r * (kBlock / 32) + (threadIdx.x >> 5);
       const bool valid = w < nw;
-      const int qid = valid ? pr.wl[w] : 0;
-      const bool fwd = qid < Mn;
+      const int qi = valid ? list[w] - qoff : 0;  // index in the queries' cloud
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
-      // the two halves of a wave may search different grids
-      const bool any_fwd = __ballot(valid && fwd) != 0;
-      const bool any_bwd = __ballot(valid && !fwd) != 0;
-      int res = -1;
+      if (valid) p = qpts[qi];
       float bud = 0.f;
-      if (any_fwd) {
-        float tb;
-        int rr = g2_nearest_coop<true>(g, g_ref, p, pr.df, valid && fwd, &st->err, nullptr, pr.mu, &tb);
-        if (fwd) { res = rr; bud = tb; }
-      }
-      if (any_bwd) {
-        float tb;
-        int rr = g2_nearest_coop<true>(g, g_mov, p, -pr.df, valid && !fwd, &st->err, nullptr, pr.mu, &tb);
-        if (!fwd) { res = rr; bud = tb; }
-      }
+      const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud);
       if (valid && sub == 0) {
-        if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
-        else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
-        if (res >= 0) {
-          if (fwd) mom_add(pr, mt, p, pr.ref[res], pr.comp[qid], lim2);
-          else mom_add(pr, mt, pr.mov[res], p, pr.comp[res], lim2);
+        nn_o[qi] = res;
+        bud_o[qi] = bud;
+        if (res >= 0) {  // (moving point, reference point, the moving point's component)
+          if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+          else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
         }
       }
     }
@@ -642,42 +643,30 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
     mom_flush(mt);
     return;
   }
-  const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
-  const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+  const int32_t* __restrict__ seed = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
+                                         : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+  const int32_t* __restrict__ list = pr.wls + qoff;
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles inside)
     const int w = r * (kBlock / 8) + (threadIdx.x >> 3);
     const bool valid = w < nw;
-    const int qid = valid ? pr.wls[w] : 0;
-    const bool fwd = qid < Mn;
+    const int qi = valid ? list[w] - qoff : 0;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
     int s = -1;
     if (valid) {
-      p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
-      s = fwd ? seed_f[qid] : seed_b[qid - Mn];
-      sp = fwd ? pr.ref[s] : pr.mov[s];
+      p = qpts[qi];
+      s = seed[qi];
+      sp = hpts[s];
     }
     int res = -1;
     float bud = 0.f;
-    bool ok = true;
-    if (__ballot(valid && fwd) != 0) {
-      int t;
-      float tb;
-      bool o = g2_nearest_seeded8(g, g_ref, p, pr.df, sp, s, valid && fwd, pr.mu, &t, &tb);
-      if (valid && fwd) { res = t; bud = tb; ok = o; }
-    }
-    if (__ballot(valid && !fwd) != 0) {
-      int t;
-      float tb;
-      bool o = g2_nearest_seeded8(g, g_mov, p, -pr.df, sp, s, valid && !fwd, pr.mu, &t, &tb);
-      if (valid && !fwd) { res = t; bud = tb; ok = o; }
-    }
+    const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, s, valid, pr.mu, &res, &bud);
     if (valid && (threadIdx.x & 7) == 0) {
       if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
-      if (fwd) { nn_f[qid] = res; bud_f[qid] = bud; }
-      else { nn_b[qid - Mn] = res; bud_b[qid - Mn] = bud; }
+      nn_o[qi] = res;
+      bud_o[qi] = bud;
       if (res >= 0) {
-        if (fwd) mom_add(pr, mt, p, pr.ref[res], pr.comp[qid], lim2);
-        else mom_add(pr, mt, pr.mov[res], p, pr.comp[res], lim2);
+        if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+        else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
       }
     }
   }
@@ -955,8 +944,8 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
   if (tid == 0) {
     st->iters = k;
-    st->wl_n = 0;                 // the work lists of iteration k have been served
-    st->ws_n = 0;
+    st->wl_n[0] = st->wl_n[1] = 0;  // the work lists of iteration k have been served
+    st->ws_n[0] = st->ws_n[1] = 0;
     st->dmax[(k + 1) & 1] = 0u;   // takes the steps of iteration k+1
   }
   {  // the step table of iteration k+1 (nothing reads it during this launch)
@@ -1134,13 +1123,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q + x_own, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j | (x_own << 16));
-      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 2), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
+      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 4), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
       icp_nn_kernel<<<dim3(nb_q + x_own, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j | (x_own << 16));
-      icp_nn_search_kernel<<<dim3(nb_c, bt.n, 2), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_nn_search_kernel<<<dim3(nb_c, bt.n, 4), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }

@@ -33,9 +33,10 @@ struct IcpState {
   int iters;      // iterations solved so far
   int err;
   int decided;    // last iteration whose stop rule has been evaluated
-  int wl_n;       // queries waiting for the cooperative search of the current iteration
-  int ws_n;       // queries waiting for the search around their old partner
-  int pad;
+  // work lists of the current iteration, one per direction (0: forward queries, moving -> reference,
+  // list entries [0, Mn); 1: backward, entries [Mn, Mn + Rn)): a search workgroup serves ONE direction
+  int wl_n[2];    // queries waiting for the cooperative search
+  int ws_n[2];    // queries waiting for the search around their old partner
   unsigned int dmax[2];  // float bits: largest displacement of a moving point in iteration k (slot k & 1)
 };
 

@@ -34,6 +34,9 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 
 namespace pcs {
 
@@ -259,6 +262,81 @@ __device__ __forceinline__ int wg_radix_sort(uint64_t* k0, int32_t* v0, uint64_t
   return which;
 }
 
+// The same sort on PACKED words (key << ib | original index, ib = bits of n - 1): one 8-byte word per
+// item instead of a key and a value (a third less traffic through the one CU that runs the sort), and
+// the histogram of the NEXT digit is counted while a pass scatters (the destination says which wave
+// slice the item will be in), so a pass reads the data once instead of twice. On entry hist_a holds
+// the per-slice histogram of the first digit (the caller counts it while it writes the words) and the
+// workgroup has passed a barrier. Sorts by bits [ib, ib + nbits); returns 0 / 1 like wg_radix_sort.
+__device__ __forceinline__ int wg_radix_sort_packed(uint64_t* w0, uint64_t* w1, int n, int ib, int nbits,
+                                                    int* hist_a, int* hist_b, int* sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per_wave = ((n + kWg - 1) / kWg) * 64;
+  const int begin = w * per_wave;
+  const int end = begin + per_wave < n ? begin + per_wave : n;
+  uint64_t *win = w0, *wout = w1;
+  int *cur = hist_a, *nxt = hist_b;
+  int which = 0;
+  constexpr int U = 8;  // rounds whose loads are issued together
+  for (int b = 0; b < nbits; b += 8) {
+    const bool more = b + 8 < nbits;
+    const int sh0 = ib + b, sh1 = ib + b + 8;
+    // exclusive scan in (digit, wave) order: thread t owns entries 4t .. 4t+3 of that order
+    int c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int e = 4 * tid + q;
+      c[q] = cur[(e & 15) * 256 + (e >> 4)];
+      sum += c[q];
+    }
+    int tot;
+    int run = wg_excl_scan(sum, &tot, sh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int e = 4 * tid + q;
+      cur[(e & 15) * 256 + (e >> 4)] = run;
+      run += c[q];
+    }
+    for (int q = tid; q < 16 * 256; q += kWg) nxt[q] = 0;
+    __syncthreads();
+    for (int i0 = begin; i0 < end; i0 += 64 * U) {
+      uint64_t kk[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        kk[r] = i < end ? win[i] : ~0ULL;
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        int i = i0 + r * 64 + lane;
+        bool in = i < end;
+        int d = (int)((kk[r] >> sh0) & 255);
+        unsigned long long same = __ballot(in);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          unsigned long long bm = __ballot((d >> bit) & 1);
+          same &= ((d >> bit) & 1) ? bm : ~bm;
+        }
+        int rank = __popcll(same & ((1ULL << lane) - 1ULL));
+        int cnt = __popcll(same);
+        int base = 0;
+        if (in) base = cur[w * 256 + d];
+        if (in && rank == 0) cur[w * 256 + d] = base + cnt;  // after every lane of the group has read
+        if (in) {
+          const int dest = base + rank;
+          wout[dest] = kk[r];
+          if (more) atomicAdd(&nxt[(dest / per_wave) * 256 + (int)((kk[r] >> sh1) & 255)], 1);
+        }
+      }
+    }
+    __syncthreads();
+    uint64_t* tk = win; win = wout; wout = tk;
+    int* th = cur; cur = nxt; nxt = th;
+    which ^= 1;
+  }
+  return which;
+}
+
 // ------------------------------------------------------------------ anchor set-up (per unit)
 __global__ void __launch_bounds__(kBlock)
 trk_load_anchor_kernel(const float4* __restrict__ src, const int64_t* __restrict__ comp_in, int64_t base,
@@ -445,7 +523,7 @@ trk_step_begin_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
 // blockIdx.x = set (0: the anchor's points as moved so far, 1: the target frame).
 __global__ void __launch_bounds__(kWg)
 smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls) {
-  __shared__ int hist[16 * 256];
+  __shared__ int hist[16 * 256], hist2[16 * 256];
   __shared__ int sh[kWg / 64 + 1];
   __shared__ float smn[kWg / 64][4], smx[kWg / 64][4];
   __shared__ float bnd[8];
@@ -507,6 +585,14 @@ smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls
   for (int d = 0; d < 4; ++d) stride[d + 1] = stride[d] * ((int64_t)((en[d] - st[d]) / sz[d]) + 1);
   int nbits = 1;
   while (nbits < 62 && (1LL << nbits) < stride[4]) ++nbits;
+  int ib = 1;
+  while ((1 << ib) < n) ++ib;
+  const bool packed = nbits + ib <= 64;  // (always, for clouds of this size: ~35 + 17 bits)
+  const int per_wave = ((n + kWg - 1) / kWg) * 64;
+  if (packed) {
+    for (int q = tid; q < 16 * 256; q += kWg) hist[q] = 0;
+    __syncthreads();
+  }
   for (int i0 = tid; i0 < n; i0 += kWg * 8) {
     float4 q[8];
 #pragma unroll
@@ -521,28 +607,56 @@ smp_sort_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa, LevelSizes ls
       float4 p = q[r];
       int64_t id = (int64_t)((p.x - st[0]) / sz[0]) * stride[0] + (int64_t)((p.y - st[1]) / sz[1]) * stride[1] +
                    (int64_t)((p.z - st[2]) / sz[2]) * stride[2] + (int64_t)((p.w - st[3]) / sz[3]) * stride[3];
-      S.k0[i] = (uint64_t)id;
-      S.v0[i] = i;
+      if (packed) {
+        S.k0[i] = ((uint64_t)id << ib) | (uint64_t)i;
+        atomicAdd(&hist[(i / per_wave) * 256 + (int)(id & 255)], 1);
+      } else {
+        S.k0[i] = (uint64_t)id;
+        S.v0[i] = i;
+      }
     }
   }
   __syncthreads();
-  int which = wg_radix_sort(S.k0, S.v0, S.k1, S.v1, n, nbits, hist, sh);
-  const uint64_t* __restrict__ sk = which ? S.k1 : S.k0;
-  const int32_t* __restrict__ sv = which ? S.v1 : S.v0;
-  // voxel boundaries + the sorted order in its final place
-  int tot = wg_compact(
-      n, [&](int i) { return i == 0 || sk[i] != sk[i - 1]; }, [&](int i, int pos) { S.seg[pos] = i; }, sh);
-  for (int i0 = tid; i0 < n; i0 += kWg * 8) {
-    int32_t vv[8];
+  int tot;
+  if (packed) {
+    int which = wg_radix_sort_packed(S.k0, S.k1, n, ib, nbits, hist, hist2, sh);
+    const uint64_t* __restrict__ sw = which ? S.k1 : S.k0;
+    // voxel boundaries + the sorted order in its final place
+    tot = wg_compact(
+        n, [&](int i) { return i == 0 || (sw[i] >> ib) != (sw[i - 1] >> ib); },
+        [&](int i, int pos) { S.seg[pos] = i; }, sh);
+    const uint64_t imask = (1ULL << ib) - 1ULL;
+    for (int i0 = tid; i0 < n; i0 += kWg * 8) {
+      uint64_t vv[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int i = i0 + r * kWg;
-      vv[r] = sv[i < n ? i : i0];
+      for (int r = 0; r < 8; ++r) {
+        int i = i0 + r * kWg;
+        vv[r] = sw[i < n ? i : i0];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int i = i0 + r * kWg;
+        if (i < n) S.order[i] = (int32_t)(vv[r] & imask);
+      }
     }
+  } else {
+    int which = wg_radix_sort(S.k0, S.v0, S.k1, S.v1, n, nbits, hist, sh);
+    const uint64_t* __restrict__ sk = which ? S.k1 : S.k0;
+    const int32_t* __restrict__ sv = which ? S.v1 : S.v0;
+    tot = wg_compact(
+        n, [&](int i) { return i == 0 || sk[i] != sk[i - 1]; }, [&](int i, int pos) { S.seg[pos] = i; }, sh);
+    for (int i0 = tid; i0 < n; i0 += kWg * 8) {
+      int32_t vv[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int i = i0 + r * kWg;
-      if (i < n) S.order[i] = vv[r];
+      for (int r = 0; r < 8; ++r) {
+        int i = i0 + r * kWg;
+        vv[r] = sv[i < n ? i : i0];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int i = i0 + r * kWg;
+        if (i < n) S.order[i] = vv[r];
+      }
     }
   }
   if (tid == 0) { S.seg[tot] = n; *S.d_num = tot; }
@@ -1009,6 +1123,22 @@ struct HostUnit {
 
 // a unit's error word: 3 = the grid barrier of smooth_velo timed out (a device-side failure: loud),
 // anything else = a search grid / fixed-point range overflowed (the caller may fall back)
+// EXPERIMENT (PCS_TICK_PROFILE=1): where a driving thread's time goes -- enqueueing a tick's launches,
+// waiting for the tick's event, the rest; printed when the process ends
+struct TickProfile {
+  std::atomic<long long> enq_ns{0}, wait_ns{0}, ticks{0}, calls{0}, total_ns{0};
+  bool on = getenv("PCS_TICK_PROFILE") != nullptr;
+  ~TickProfile() {
+    if (on && ticks.load())
+      fprintf(stderr, "[tick profile] calls %lld ticks %lld: per tick enqueue %.1f us, wait %.1f us; per call total %.2f ms\n",
+              calls.load(), ticks.load(), enq_ns.load() / 1e3 / ticks.load(), wait_ns.load() / 1e3 / ticks.load(),
+              total_ns.load() / 1e6 / (calls.load() ? calls.load() : 1));
+  }
+};
+static TickProfile g_tick_profile;
+static inline long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 static inline int unit_error(int err) { return err == 3 ? PCS_ERR_HIP : PCS_ERR_RANGE; }
 static inline int nblk(int64_t n) { return (int)(((n < 1 ? 1 : n) + kBlock - 1) / kBlock); }
 
@@ -1621,13 +1751,22 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     gr.pin_icp = (IcpState*)pg;
     gr.pin_fin = (IcpState*)(pg + 2048);
     gr.pin_trk = (TrkState*)(pg + kPinnedTrackerOff);
+    const bool tp = g_tick_profile.on;
+    long long t_begin = tp ? now_ns() : 0, t0 = t_begin;
     int rc = enqueue_tick(gi);
+    if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; g_tick_profile.calls += 1; }
     while (rc == PCS_OK && gr.inflight) {
+      if (tp) t0 = now_ns();
       if (hipEventSynchronize(gr.ev) != hipSuccess) { rc = PCS_ERR_HIP; break; }
+      if (tp) { g_tick_profile.wait_ns += now_ns() - t0; t0 = now_ns(); }
       rc = collect_tick(gi);
-      if (rc == PCS_OK && gr.live > 0) rc = enqueue_tick(gi);
+      if (rc == PCS_OK && gr.live > 0) {
+        rc = enqueue_tick(gi);
+        if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; }
+      }
     }
     (void)hipStreamSynchronize(gr.st);  // nothing may still run on the workspace when the call returns
+    if (tp) g_tick_profile.total_ns += now_ns() - t_begin;
     gr.rc = rc;
   };
   for (int g = 1; g < G; ++g) GroupWorkers::get().start(g, [&drive, g] { drive(g); });

@@ -187,7 +187,7 @@ class SimpleReg(RegistrationTemplate):
 
         # SEQUENCES_IN_FLIGHT (default 4): how many sequences of a batch are processed at once
         inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 4)), batch_size)
-        if os.environ.get("ROCP_TOOL_LIBRARIES"):
+        if os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("PCS_PROFILE_CONCURRENT"):
             inflight = 1  # rocprofiler-sdk on this image faults when several host threads launch kernels
         todo = [b for b in range(batch_size) if not done_before(b)]
         processed = {}
