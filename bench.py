@@ -269,15 +269,13 @@ def kernel_stats_stages(out):
 
 
 def main():
-    if os.environ.get("PCS_SWITCH_US"):  # EXPERIMENT: the interpreter's thread switch interval
-        sys.setswitchinterval(float(os.environ["PCS_SWITCH_US"]) * 1e-6)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
-    ap.add_argument("--batch", type=int, default=6,
+    ap.add_argument("--batch", type=int, default=8,
                     help="sequences per step (one batch, as the reference's collate_batch hands them to "
                          "SimpleReg.forward, which tracks the sequences of a batch concurrently)")
     ap.add_argument("--inflight", type=int, default=0,

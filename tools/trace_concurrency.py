@@ -26,6 +26,20 @@ def main():
     print("window ms", span / 1e6, "dispatches", len(rows))
     for q, (c, b) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
         print(f"  queue {q}: {c} dispatches, busy {b / 1e6:.1f} ms ({100 * b / span:.1f} % of the window)")
+    # gaps between consecutive kernels of a queue (end -> next start)
+    by_q = collections.defaultdict(list)
+    for s_, e_, n_, q_, g_, w_ in rows:
+        by_q[q_].append((s_, e_, n_))
+    for q, lst in sorted(by_q.items(), key=lambda kv: -len(kv[1]))[:5]:
+        lst.sort()
+        gaps = sorted(max(0, b[0] - a[1]) for a, b in zip(lst, lst[1:]))
+        small = [g for g in gaps if g < 200000]  # (longer ones: the host is between ticks or in another phase)
+        if not gaps:
+            continue
+        print(f"  queue {q} gaps: median {gaps[len(gaps) // 2] / 1e3:.2f} us, p90 {gaps[int(len(gaps) * 0.9)] / 1e3:.2f} us, "
+              f"sum of gaps < 200 us: {sum(small) / 1e6:.1f} ms, all: {sum(gaps) / 1e6:.1f} ms")
+        hist = collections.Counter(min(int(g / 5000), 12) for g in gaps)
+        print("    gap histogram (5 us bins, last = >= 60 us):", [hist.get(k, 0) for k in range(13)])
     ev = []
     for i, (s, e, *_) in enumerate(rows):
         ev.append((s, 1))
