@@ -54,7 +54,7 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
-  b.lsc = a.take<double>(C);
+  b.lossfx = a.take<long long>(2 * kLossParts);
   b.corg = a.take<float4>(C);
   b.first = a.take<int32_t>(C);
   b.cov = a.take<int32_t>(C);
@@ -103,7 +103,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.sstep = b.sstep;
   pr.acc = b.acc;
   pr.Tb = b.Tb;
-  pr.lsc = b.lsc;
+  pr.lossfx = b.lossfx;
   pr.corg = b.corg;
   pr.cov = b.cov;
   pr.st = b.state;
@@ -159,7 +159,8 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   }
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) pr.acc[q] = 0;
   for (int64_t q = i; q < 2 * kStepH; q += stride) pr.sstep[q] = 0u;
-  for (int64_t q = i; q < C; q += stride) { pr.cov[q] = 0; pr.first[q] = INT_MAX; pr.lsc[q] = 0.0; }
+  for (int64_t q = i; q < C; q += stride) { pr.cov[q] = 0; pr.first[q] = INT_MAX; }
+  if (i < 2 * kLossParts) pr.lossfx[i] = 0;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   g2_clear(g2_view(pr.gr, Rn), i, stride);
@@ -258,33 +259,26 @@ icp_insert3_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
 }
 
 // loss-delta / 3-strike stop rule of iteration k_done (registration_utils.py:186-193), evaluated by
-// ONE workgroup from the per-component loss terms of the apply launch, summed in component order by
-// a fixed tree (independent of every launch geometry). It may lower stop_iter to k_done, which still
-// admits every kernel of iteration k_done.
+// ONE wave from the loss of the apply launch: the components' terms arrive as 64-bit fixed-point
+// partial sums (kLossParts addresses; integer adds commute, so the total does not depend on any
+// launch geometry or arrival order). Summing the [C] terms here instead -- ten dependent rounds of
+// loads for the keys with ten thousand components -- made every budget-test launch of those keys
+// 9 us longer than the others' (20.6 against 11.5 us). It may lower stop_iter to k_done, which
+// still admits every kernel of iteration k_done.
 __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
-  __shared__ double red[kBlock / 64];
   IcpState* st = pr.st;
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
-  // four independent partial sums per thread (the loads of one chain were the launch's critical path
-  // for the keys with ten thousand components); the order is fixed, so the sum is reproducible
-  const int C = (int)pr.C;
-  const double* __restrict__ lsc = pr.lsc;
-  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-  int q = threadIdx.x;
-  for (; q + 3 * kBlock < C; q += 4 * kBlock) {
-    p0 += lsc[q];
-    p1 += lsc[q + kBlock];
-    p2 += lsc[q + 2 * kBlock];
-    p3 += lsc[q + 3 * kBlock];
+  if (threadIdx.x >= 64) return;
+  long long* part = pr.lossfx + (size_t)(k_done & 1) * kLossParts;
+  long long v = 0;
+  if (threadIdx.x < kLossParts) {
+    v = part[threadIdx.x];
+    part[threadIdx.x] = 0;  // (the apply launch of iteration k_done + 2 adds here next)
   }
-  for (; q < C; q += kBlock) p0 += lsc[q];
-  double part = (p0 + p1) + (p2 + p3);
-  part = wave_sum_f64(part);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) {
-    double loss = 0.0;
-    for (int q = 0; q < kBlock / 64; ++q) loss += red[q];
+    const double loss = (double)v * kFxInv;
     st->loss = loss;
     if (st->last_error - loss < pr.delta) st->countdown -= 1;
     else st->countdown = 3;
@@ -327,26 +321,29 @@ __device__ __forceinline__ void mom_init(const MomTable& t) {  // every thread o
   for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) t.sacc[q] = 0ULL;
 }
 // the pair (moving point pf of component c, reference point qf)
-__device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
-                                        double lim2) {
+// the 17 fixed-point terms of one pair relative to the component's origin
+__device__ __forceinline__ void mom_terms(const IcpProblem& pr, float4 pf, float4 qf, int c, double lim2,
+                                          long long v[17]) {
   const float4 og = pr.corg[c];
   double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
   double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
   if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
     pr.st->err = 1;  // a component too large for the fixed-point range
-  unsigned long long v[17];
-  v[0] = 1ULL;
+  v[0] = 1;
   double d2 = 0.0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    v[1 + a] = (unsigned long long)to_fx(p[a]);
-    v[4 + a] = (unsigned long long)to_fx(q[a]);
+    v[1 + a] = to_fx(p[a]);
+    v[4 + a] = to_fx(q[a]);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = (unsigned long long)to_fx(p[a] * q[b]);
+    for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = to_fx(p[a] * q[b]);
     double e = p[a] - q[a];
     d2 += e * e;
   }
-  v[16] = (unsigned long long)to_fx(d2);
+  v[16] = to_fx(d2);
+}
+// 17 sums of component c into the workgroup's table
+__device__ __forceinline__ void mom_put(const MomTable& t, int c, const long long v[17]) {
   // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
   int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
   int found = -1;
@@ -357,11 +354,17 @@ __device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t,
   }
   if (found >= 0) {
 #pragma unroll
-    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.sacc[found * 17 + q2], v[q2]);
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.sacc[found * 17 + q2], (unsigned long long)v[q2]);
   } else {
 #pragma unroll
-    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)c * kAcc + q2], v[q2]);
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)c * kAcc + q2], (unsigned long long)v[q2]);
   }
+}
+__device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
+                                        double lim2) {
+  long long v[17];
+  mom_terms(pr, pf, qf, c, lim2, v);
+  mom_put(t, c, v);
 }
 // The same for a whole wave (every lane calls; `active` lanes hold a pair). Neighbouring queries
 // mostly belong to one component: when all active lanes agree on it their terms are summed by
@@ -374,7 +377,32 @@ __device__ __forceinline__ void mom_add_wave(const IcpProblem& pr, const MomTabl
   const int c0 = __shfl(c, leader, 64);
   const bool uniform = __ballot(active && c != c0) == 0 && __popcll(am) >= 8;
   if (!uniform) {
-    if (active) mom_add(pr, t, pf, qf, c, lim2);
+    // Several components in the wave (the keys with thousands of small clusters: always). The points
+    // come in voxel order, so a component's points sit next to each other row by row: the RUNS of equal
+    // component add up by shuffles first and only a run's first lane goes to the table -- 64 lanes with
+    // 17 LDS adds each on a handful of slots queued up eight deep (the budget-test launch of those keys
+    // took 20.6 us against 11.5 us for the others).
+    const int lane = threadIdx.x & 63;
+    const int c_prev = __shfl_up(c, 1, 64);
+    const bool a_prev = ((am >> (lane > 0 ? lane - 1 : 0)) & 1ULL) != 0 && lane > 0;
+    const bool head = active && (!a_prev || c_prev != c);
+    const unsigned long long hm = __ballot(head);
+    const int rid = active ? __popcll(hm & ((2ULL << lane) - 1ULL)) : -1 - lane;  // run number (inactive: unique)
+    long long v[17];
+#pragma unroll
+    for (int q = 0; q < 17; ++q) v[q] = 0;
+    if (active) mom_terms(pr, pf, qf, c, lim2, v);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int rid_o = __shfl_down(rid, o, 64);
+      const bool take = lane + o < 64 && rid_o == rid;
+#pragma unroll
+      for (int q = 0; q < 17; ++q) {
+        const long long tq = __shfl_down(v[q], o, 64);
+        if (take) v[q] += tq;
+      }
+    }
+    if (head) mom_put(t, c, v);
     return;
   }
   const float4 og = pr.corg[c0];
@@ -440,11 +468,8 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 //                         search in the code: the two-direction form spilled ~400 scalar registers).
 // Exact: the same neighbours as a full search, always.
 __global__ void __launch_bounds__(kBlock)
-icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int jf) {
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int j = jf & 0xffff;
-  const bool own_wg = (jf >> 16) != 0;  // EXPERIMENT: the stop rule has a workgroup of its own (the last)
-  const int gdx = own_wg ? (int)gridDim.x - 1 : (int)gridDim.x;
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
   // The gate is read ONCE per workgroup. Workgroup 0 lowers stop_iter during this very launch (below),
@@ -461,19 +486,13 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
   const int nround = (nq + kBlock - 1) / kBlock;
-  if (own_wg) {
-    if ((int)blockIdx.x == gdx) {
-      icp_decide(pr, k - 1);
-      return;
-    }
-    if ((int)blockIdx.x >= nround) return;
-  } else if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
   // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (!own_wg && blockIdx.x == 0) icp_decide(pr, k - 1);
+  if (blockIdx.x == 0) icp_decide(pr, k - 1);
   if (k == 1) {  // no neighbours yet: every query takes the cooperative search
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gdx * blockDim.x) pr.wl[q] = q;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
     return;
   }
@@ -496,7 +515,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
   // steps of the moving points in iteration k-1, by the place they moved into
   const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
-  for (int r = blockIdx.x; r < nround; r += gdx) {  // whole waves stay together (ballots below)
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
@@ -954,6 +973,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   float step = 0.f;  // largest step of this thread's points
+  long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   const GridDesc d = pr.geom->g;
   const int nround = (Mn + kBlock - 1) / kBlock;
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
@@ -991,13 +1011,21 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
         for (int q = 0; q < 16; ++q) To[q] = Tn[q];
         long long* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
         for (int q = 0; q < kAcc; ++q) an[q] = 0;
-        pr.lsc[c] = ls;
+        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
+        else loss_fx += to_fx(ls);
       }
     }
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
+  // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss_fx += __shfl_xor(loss_fx, o, 64);
+  if ((threadIdx.x & 63) == 0 && loss_fx != 0)
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
+                                             ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
+              (unsigned long long)loss_fx);
 }
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
@@ -1100,9 +1128,7 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
   const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
   const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
-  static const int x_cs = getenv("PCS_X_CS") ? atoi(getenv("PCS_X_CS")) : 4;
-  static const int x_own = getenv("PCS_X_OWN") ? atoi(getenv("PCS_X_OWN")) : 0;
-  const int nb_cs = gx_for(q * x_cs, kBlock, 4096);   // later: the work lists (a fraction of the queries)
+  const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -1122,13 +1148,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       // kernel's own begin-to-end time, as rocprofv3 reports it
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
-      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q + x_own, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j | (x_own << 16));
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 4), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
-      icp_nn_kernel<<<dim3(nb_q + x_own, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j | (x_own << 16));
+      icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_nn_search_kernel<<<dim3(nb_c, bt.n, 4), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }

@@ -49,6 +49,7 @@ struct IcpState {
 // arrive: bit-identical run to run and schedule to schedule by construction. A coordinate too far
 // from its origin for the 64-bit range (limit_sq below) raises the call's error word.
 constexpr int kAcc = 20;
+constexpr int kLossParts = 16;  // addresses the loss terms of one iteration are spread over
 constexpr int kFxBits = 36;
 constexpr double kFx = 68719476736.0;        // 2^36
 constexpr double kFxInv = 1.0 / 68719476736.0;
@@ -87,7 +88,7 @@ struct IcpProblem {
   unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
   long long* acc;       // [2, C, kAcc]
   double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
-  double* lsc;          // [C] loss term of each component, last applied iteration
+  long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity)
   float4* corg;         // [C] origin of the component's fixed-point moments
   int32_t* cov;         // [C] matched moving points in the final coverage query
   IcpState* st;
@@ -129,7 +130,8 @@ struct IcpBufs {
   float *bud_f, *bud_b;
   float* prev;
   long long* acc;
-  double *Tb, *lsc;
+  double* Tb;
+  long long* lossfx;
   float4* corg;
   int32_t *first, *cov;
 };
