@@ -1388,9 +1388,11 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     return (c >= 1 && c <= kMaxGroups) ? c : 4;
   }();
   const int chunk = chunk_env;
-  // rocprofiler-sdk on this image faults when kernels are launched from several native threads at
-  // once: a profiled run takes one group (same kernels, same results)
-  static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+  // a run under rocprofv3 takes ONE group unless PCS_PROFILE_CONCURRENT is set (same kernels, same
+  // results): the per-kernel numbers of profiles/*_sequence_kernel_stats.csv refer to that schedule.
+  // (It began as a work-around -- profiled runs with several launching threads faulted -- but the
+  // fault was the split-workgroup bug of icp_nn_kernel, fixed since.)
+  static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr && getenv("PCS_PROFILE_CONCURRENT") == nullptr;
   const int want_groups = (prm->groups >= 1 && prm->groups <= kMaxGroups) ? prm->groups : groups_env;
   const int G = profiled ? 1 : (want_groups < n_units ? want_groups : n_units);
   struct Group {

@@ -188,7 +188,8 @@ class SimpleReg(RegistrationTemplate):
         # SEQUENCES_IN_FLIGHT (default 4): how many sequences of a batch are processed at once
         inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 4)), batch_size)
         if os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("PCS_PROFILE_CONCURRENT"):
-            inflight = 1  # rocprofiler-sdk on this image faults when several host threads launch kernels
+            inflight = 1  # profiled runs take one sequence at a time (comparable per-kernel numbers);
+            # PCS_PROFILE_CONCURRENT=1 profiles the batch mode as it runs (tools/profile_concurrent.sh)
         todo = [b for b in range(batch_size) if not done_before(b)]
         processed = {}
         if inflight > 1 and len(todo) > 1 and batch_dict["point_bxyz"].is_cuda:
