@@ -124,6 +124,12 @@ int pcs_indice_conv_f32(const float* features, int cin, const float* filters, in
 int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
                              int inverse, int64_t num_out, int32_t* table, pcs_stream_t stream);
 int pcs_conv_use_mfma(int enable); /* 1 (default): MFMA tiles for Cin >= 16; 0: FMA tiles only */
+/* scale / shift [C] f32 of an eval-mode BatchNorm1d for the conv epilogue above (torch.nn.BatchNorm1d in
+ * eval mode after every conv of spconv_backbone.py:6-27) from inv_std = rsqrt(running_var + eps):
+ * scale = inv_std * weight, shift = -mean * scale + bias, each product / sum rounded to fp32 like the
+ * tensor ops they replace; weight / bias may be NULL. */
+int pcs_bn_fold_f32(const float* weight, const float* bias, const float* running_mean,
+                    const float* inv_std, int C, float* scale, float* shift, pcs_stream_t stream);
 int pcs_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv,
                               int cout, int centre, const int32_t* table, int64_t num_out,
                               const float* bias, const float* scale, const float* shift, int relu,

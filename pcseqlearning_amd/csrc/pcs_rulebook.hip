@@ -203,6 +203,80 @@ pair_fill_kernel(const int4* __restrict__ idx, int V, ConvGeom g,
   }
 }
 
+// Everything a rulebook build resets, in ONE launch (they were six to eight hipMemsetAsync / fill /
+// copy calls per geometry: at one frame per batch the backbone's forward is launch-bound and a third
+// of its launches were these).
+struct RulebookInit {
+  int32_t* pairs; int64_t n_pairs;     // <- -1
+  int32_t* num; int kv;                // <- 0
+  uint64_t* keys; int32_t* vals; uint32_t* minseq; int64_t H;  // <- all ones (minseq: strided only)
+  uint32_t* lseq; int64_t cap;         // <- 0xFFFFFFFF (strided only)
+  int32_t* counter;                    // <- 0 (strided only)
+  int32_t* blockcnt_tail;              // <- 0
+  int64_t* d_num_out; int64_t num_out; // <- num_out when >= 0 (subM: the outputs are the inputs)
+};
+__global__ void __launch_bounds__(kBlock) rulebook_init_kernel(RulebookInit a) {
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = tid; q < a.n_pairs; q += nt) a.pairs[q] = -1;
+  for (int64_t q = tid; q < a.H; q += nt) {
+    a.keys[q] = ~0ULL;
+    a.vals[q] = -1;
+    if (a.minseq) a.minseq[q] = 0xFFFFFFFFu;
+  }
+  if (a.lseq)
+    for (int64_t q = tid; q < a.cap; q += nt) a.lseq[q] = 0xFFFFFFFFu;
+  if (tid < a.kv) a.num[tid] = 0;
+  if (tid == 0) {
+    if (a.counter) *a.counter = 0;
+    *a.blockcnt_tail = 0;
+    if (a.num_out >= 0) *a.d_num_out = a.num_out;
+  }
+}
+
+// exclusive scan of n <= kScanOneWg ints by ONE workgroup (the per-(offset, block) pair counts: a few
+// thousand entries; the library scan is three launches)
+constexpr int kScanWg = 1024;
+constexpr size_t kScanOneWg = 1u << 17;
+__global__ void __launch_bounds__(kScanWg) scan_one_wg_kernel(const int32_t* __restrict__ in,
+                                                              int32_t* __restrict__ out, int n) {
+  __shared__ int wsum[kScanWg / 64];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  constexpr int PER = 4;  // consecutive entries per thread and round
+  for (int base = 0; base < n; base += kScanWg * PER) {
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      int i = base + tid * PER + q;
+      v[q] = i < n ? in[i] : 0;
+      sum += v[q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int carry = carry_s;
+    int before = 0;
+    for (int q = 0; q < w; ++q) before += wsum[q];
+    int run = carry + before + incl - sum;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      int i = base + tid * PER + q;
+      if (i < n) out[i] = run;
+      run += v[q];
+    }
+    __syncthreads();
+    if (tid == kScanWg - 1) carry_s = run;
+    __syncthreads();
+  }
+}
+
 __global__ void fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -308,9 +382,11 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
   if (V >= (1LL << 31) / g.kv) return PCS_ERR_RANGE;
   uint64_t vol = (uint64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
   if (vol * (uint64_t)batch >= (1ULL << 62)) return PCS_ERR_RANGE;
-  if (V > 0) PCS_CHECK_HIP(hipMemsetAsync(pairs, 0xFF, (size_t)g.kv * 2 * V * sizeof(int32_t), s));
-  PCS_CHECK_HIP(hipMemsetAsync(num, 0, g.kv * sizeof(int32_t), s));
-  if (V == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s)); return PCS_OK; }
+  if (V == 0) {
+    PCS_CHECK_HIP(hipMemsetAsync(num, 0, g.kv * sizeof(int32_t), s));
+    PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s));
+    return PCS_OK;
+  }
   int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, subm);
   if (!subm && (!out_ids || out_cap < cap)) return PCS_ERR_ARG;
   Arena a(ws, ws_bytes);
@@ -319,16 +395,25 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
   uint32_t hmask = p.H - 1;
   const int4* idx = (const int4*)indices;
   int nb = p.nblocks;
-  PCS_CHECK_HIP(hipMemsetAsync(p.keys, 0xFF, (size_t)p.H * sizeof(uint64_t), s));
-  PCS_CHECK_HIP(hipMemsetAsync(p.vals, 0xFF, (size_t)p.H * sizeof(int32_t), s));
+  size_t nscan = (size_t)g.kv * nb + 1;
+  {
+    RulebookInit in;
+    in.pairs = pairs; in.n_pairs = (int64_t)g.kv * 2 * V;
+    in.num = num; in.kv = g.kv;
+    in.keys = p.keys; in.vals = p.vals; in.minseq = subm ? nullptr : p.minseq; in.H = p.H;
+    in.lseq = subm ? nullptr : p.lseq; in.cap = subm ? 0 : p.cap;
+    in.counter = subm ? nullptr : p.counter;
+    in.blockcnt_tail = p.blockcnt + (nscan - 1);
+    in.d_num_out = d_num_out; in.num_out = subm ? V : -1;
+    int64_t longest = in.n_pairs > in.H ? in.n_pairs : in.H;
+    if (in.cap > longest) longest = in.cap;
+    int gi = grid_for(longest);
+    if (gi > 4096) gi = 4096;
+    rulebook_init_kernel<<<gi, kBlock, 0, s>>>(in);
+  }
   if (subm) {
     insert_inputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask);
-    int64_t v64 = V;
-    PCS_CHECK_HIP(hipMemcpyAsync(d_num_out, &v64, sizeof(int64_t), hipMemcpyHostToDevice, s));
   } else {
-    PCS_CHECK_HIP(hipMemsetAsync(p.minseq, 0xFF, (size_t)p.H * sizeof(uint32_t), s));
-    PCS_CHECK_HIP(hipMemsetAsync(p.counter, 0, sizeof(int32_t), s));
-    fill_u32_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lseq, p.cap, 0xFFFFFFFFu);
     insert_outputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.minseq, hmask, p.lslot,
                                                 p.counter);
     list_outputs_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.minseq, p.lslot, p.counter, p.lseq);
@@ -338,10 +423,12 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
                                                              p.vals, out_ids, d_num_out);
   }
   pair_count_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, hmask, p.masks, p.blockcnt, nb);
-  size_t nscan = (size_t)g.kv * nb + 1;
-  PCS_CHECK_HIP(hipMemsetAsync(p.blockcnt + (nscan - 1), 0, sizeof(int32_t), s));
-  int rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.blockcnt, p.blockoff, nscan, s);
-  if (rc) return rc;
+  if (nscan <= kScanOneWg) {
+    scan_one_wg_kernel<<<1, kScanWg, 0, s>>>(p.blockcnt, p.blockoff, (int)nscan);
+  } else {
+    int rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.blockcnt, p.blockoff, nscan, s);
+    if (rc) return rc;
+  }
   pair_fill_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask, p.masks,
                                          p.blockoff, nb, pairs, num);
   PCS_LAUNCH_CHECK();

@@ -258,6 +258,22 @@ indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float*
 
 static int g_use_mfma = 1;
 
+// eval-mode BatchNorm1d as y = x * scale + shift from inv_std = rsqrt(var + eps) (left to the tensor
+// library: its rsqrt is not the device's rsqrtf bit for bit): the three to five elementwise tensor ops
+// that follow, each rounded to fp32, nothing contracted
+__global__ void bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                               const float* __restrict__ mean, const float* __restrict__ inv_std,
+                               int C, float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float inv = inv_std[c];
+  float sc = weight ? __fmul_rn(inv, weight[c]) : inv;
+  float sh = __fmul_rn(-mean[c], sc);
+  if (bias) sh = __fadd_rn(sh, bias[c]);
+  scale[c] = sc;
+  shift[c] = sh;
+}
+
 }  // namespace pcs
 
 using namespace pcs;
@@ -268,6 +284,16 @@ extern "C" {
 // everywhere (for A/B measurements; both give bit-identical results).
 int pcs_conv_use_mfma(int enable) {
   g_use_mfma = enable != 0;
+  return PCS_OK;
+}
+
+// scale / shift [C] of an eval-mode BatchNorm1d (weight / bias may be null) in one launch
+int pcs_bn_fold_f32(const float* weight, const float* bias, const float* running_mean,
+                    const float* inv_std, int C, float* scale, float* shift, hipStream_t s) {
+  if (!running_mean || !inv_std || !scale || !shift || C < 0) return PCS_ERR_ARG;
+  if (C == 0) return PCS_OK;
+  bn_fold_kernel<<<grid_for(C), kBlock, 0, s>>>(weight, bias, running_mean, inv_std, C, scale, shift);
+  PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
 

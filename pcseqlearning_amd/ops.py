@@ -256,6 +256,20 @@ def build_neighbor_table(pairs, num, num_out, inverse=False):
     return table[:num_out]
 
 
+def bn_fold(weight, bias, running_mean, running_var, eps):
+    """scale / shift [C] f32 of an eval-mode BatchNorm1d (device tensors; weight / bias may be None)."""
+    L.require_gpu(running_mean, "bn_fold")
+    lib = L.load()
+    C = running_mean.numel()
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    weight, bias, mean = f(weight), f(bias), f(running_mean)
+    inv = torch.rsqrt(running_var.detach().float() + eps)
+    out = torch.empty(2, C, dtype=torch.float32, device=mean.device)
+    L.check(lib.pcs_bn_fold_f32(L.ptr(weight), L.ptr(bias), L.ptr(mean), L.ptr(inv), L.i32(C),
+                                L.ptr(out[0]), L.ptr(out[1]), L.stream()), "pcs_bn_fold_f32")
+    return out[0], out[1]
+
+
 def indice_conv_table(features, filters, table, num_out, subm, bias=None, scale=None, shift=None,
                       relu=False):
     """out = epilogue(sum_k feat[table[:,k]] @ W[k]); filters [..., Cin, Cout]."""

@@ -76,10 +76,14 @@ class SparseSequential(SparseModule):
 
 
 def fold_batchnorm(bn):
-    """Eval-mode BatchNorm1d as y = x * scale + shift. Recomputed on every call (four [C]-sized ops):
+    """Eval-mode BatchNorm1d as y = x * scale + shift. Recomputed on every call (rsqrt + one small
+    launch on the device, four [C]-sized tensor ops on the host):
     a cache keyed on tensor versions would miss in-place edits through `.data` and re-assigned
     buffers, and diverge from the module-by-module path without an error."""
     with torch.no_grad():
+        if bn.running_var.is_cuda:  # three launches instead of five to seven (same arithmetic)
+            from .... import ops as _ops
+            return _ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         inv = torch.rsqrt(bn.running_var.float() + bn.eps)
         scale = inv * bn.weight.float() if bn.weight is not None else inv
         shift = -bn.running_mean.float() * scale

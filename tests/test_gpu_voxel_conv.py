@@ -273,3 +273,24 @@ def test_maxpool_vs_reference_golden(oracle, name):
     np.testing.assert_array_equal(y.features.detach().cpu().numpy(), g["out"])
     (y.features * dev(g["out_grad"])).sum().backward()
     np.testing.assert_array_equal(x.grad.cpu().numpy(), g["in_grad"])
+
+
+@pytest.mark.gpu
+def test_bn_fold_kernel_matches_the_tensor_ops():
+    """pcs_bn_fold_f32 (one launch) against the four tensor ops it replaces: bit for bit."""
+    from pcseqlearning_amd import ops
+    torch.manual_seed(5)
+    for C, affine in ((16, True), (64, True), (128, False), (5, True)):
+        bn = torch.nn.BatchNorm1d(C, eps=1e-3, affine=affine).cuda().eval()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.1, 4.0)
+        if affine:
+            bn.weight.data.normal_()
+            bn.bias.data.normal_()
+        inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+        scale = inv * bn.weight.float() if affine else inv
+        shift = -bn.running_mean.float() * scale
+        if affine:
+            shift = shift + bn.bias.float()
+        s2, h2 = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        assert torch.equal(s2, scale) and torch.equal(h2, shift)
