@@ -130,6 +130,32 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
 }
 
 __device__ __forceinline__ long long to_fx(double v) { return __double2ll_rn(v * kFx); }
+#ifdef PCS_WG_TRACE
+__device__ unsigned long long* g_wgt = nullptr;
+__device__ unsigned int g_wgt_n = 0;
+constexpr unsigned kWgtCap = 6u << 20;
+#define WGT_BEGIN() const unsigned long long wgt0 = __builtin_amdgcn_s_memrealtime()
+#define WGT_MARK(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define WGT_END(kid, kk, m1, m2)                                                                       \
+  do {                                                                                                 \
+    __syncthreads();                                                                                   \
+    if (threadIdx.x == 0 && g_wgt) {                                                                   \
+      unsigned i_ = atomicAdd(&g_wgt_n, 1u);                                                           \
+      if (i_ < kWgtCap) {                                                                              \
+        g_wgt[5 * (size_t)i_] = ((unsigned long long)(kid) << 56) | ((unsigned long long)(kk) << 40) | \
+                                ((unsigned long long)blockIdx.y << 32) | ((unsigned long long)blockIdx.z << 28) | blockIdx.x; \
+        g_wgt[5 * (size_t)i_ + 1] = wgt0;                                                              \
+        g_wgt[5 * (size_t)i_ + 2] = __builtin_amdgcn_s_memrealtime();                                  \
+        g_wgt[5 * (size_t)i_ + 3] = (m1);                                                              \
+        g_wgt[5 * (size_t)i_ + 4] = (m2);                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
+#else
+#define WGT_BEGIN()
+#define WGT_MARK(var)
+#define WGT_END(kid, kk, m1, m2)
+#endif
 
 // start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, state <- initial,
 // the four grids <- empty (one launch instead of a dozen memsets)
@@ -469,6 +495,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 // Exact: the same neighbours as a full search, always.
 __global__ void __launch_bounds__(kBlock)
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  WGT_BEGIN();
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
@@ -491,6 +518,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
   if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  WGT_MARK(wg_m1);
   if (k == 1) {  // no neighbours yet: every query takes the cooperative search
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
@@ -605,46 +633,95 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
     }
   }
   __syncthreads();
+  WGT_MARK(wg_m2);
   mom_flush(mt);
+  WGT_END(1, k, wg_m1, wg_m2);
 }
 
+// The searches of one iteration for ALL entries of the batch, as a queue: a work item is one round of
+// one (entry, direction, kind) work list -- 8 cooperative or 32 seeded queries -- and the workgroups
+// take the items w = blockIdx.x, blockIdx.x + gridDim.x, ... of the concatenated lists (cooperative
+// lists first: they are the long ones). Every workgroup first forms the same table of rounds from the
+// list lengths on the device (128 words at most). The form this replaces was a (rounds of the largest
+// list) x entries x 4 grid whose ~10 k workgroups mostly found nothing to do: dealing them out took
+// longer than the searches -- the workgroups with work started up to 26 us apart (58 at the 90th
+// percentile, 187 us at the 99th, the first iteration of a registration, whose seeded slices are all
+// empty), in a launch whose mean workgroup lasts 25 us (tools/wg_trace.py).
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
-  IcpState* st = pr.st;
-  if (k > pr.max_iter || k > st->stop_iter) return;
-  const bool coop = (blockIdx.z & 1) != 0;
-  const int dir = blockIdx.z >> 1;  // 0: forward queries (moving -> reference grid), 1: backward
-  const int nw = coop ? st->wl_n[dir] : st->ws_n[dir];
-  const int per_block = coop ? kBlock / 32 : kBlock / 8;
-  const int nround = (nw + per_block - 1) / per_block;
-  if ((int)blockIdx.x >= nround) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
-  GridDesc g = pr.geom->g;
-  const bool fwd = dir == 0;
-  // everything below is uniform in the workgroup: one direction, one grid, one instance of the search
-  int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
-  float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
-  const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
-  const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
-  const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
-  const int qoff = fwd ? 0 : Mn;
-  const int df = fwd ? pr.df : -pr.df;
+  WGT_BEGIN();
+  __shared__ int s_pref[4 * kMaxBatch + 1];
+  __shared__ int s_wsum[kBlock / 64];
   __shared__ int skey[kMomSlots];
   __shared__ unsigned long long sacc[kMomSlots * 17];
-  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
-  const double lim2 = icp_limit_sq(Mn + Rn);
-  mom_init(mt);
-  __syncthreads();
-  if (coop) {
-    const int sub = threadIdx.x & 31;
-    const int32_t* __restrict__ list = pr.wl + qoff;
-    for (int r = blockIdx.x; r < nround; r += gridDim.x) {
-      const int w = r * (kBlock / 32) + (threadIdx.x >> 5);
-      const bool valid = w < nw;
-      const int qi = valid ? list[w] - qoff : 0;  // index in the queries' cloud
+  const int nlist = 4 * bt.n;  // list t: t < 2n cooperative, else seeded; entry (t mod 2n) / 2, direction t & 1
+  int my_rounds = 0;
+  if ((int)threadIdx.x < nlist) {
+    const int t = threadIdx.x;
+    const bool coop_t = t < 2 * bt.n;
+    const int tt = coop_t ? t : t - 2 * bt.n;
+    const int e = tt >> 1, dir_t = tt & 1;
+    const IcpProblem& pe = tab[bt.idx[e]];
+    const int ke = kbase.v[e] + 1 + j;
+    const IcpState* se = pe.st;
+    if (!(ke > pe.max_iter || ke > se->stop_iter)) {
+      const int nw = coop_t ? se->wl_n[dir_t] : se->ws_n[dir_t];
+      const int per = coop_t ? kBlock / 32 : kBlock / 8;
+      my_rounds = (nw + per - 1) / per;
+    }
+  }
+  {  // exclusive prefix of the rounds (nlist <= 128: the first two waves hold them)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = my_rounds;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    const int before = wv == 0 ? 0 : s_wsum[0];
+    if ((int)threadIdx.x < nlist) s_pref[threadIdx.x] = before + incl - my_rounds;
+    if ((int)threadIdx.x == nlist - 1) s_pref[nlist] = before + incl;
+    __syncthreads();
+  }
+  const int R = s_pref[nlist];
+  for (int w = blockIdx.x; w < R; w += gridDim.x) {
+    int lo = 0, hi = nlist - 1;  // the list of item w: the last t with s_pref[t] <= w
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_pref[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const int r = w - s_pref[lo];
+    const bool coop = lo < 2 * bt.n;
+    const int tt = coop ? lo : lo - 2 * bt.n;
+    const int e = tt >> 1, dir = tt & 1;  // 0: forward queries (moving -> reference grid), 1: backward
+    const IcpProblem& pr = tab[bt.idx[e]];
+    const int k = kbase.v[e] + 1 + j;
+    IcpState* st = pr.st;
+    const int nw = coop ? st->wl_n[dir] : st->ws_n[dir];
+    int Mn, Rn, Ra;
+    icp_sizes(pr, Mn, Rn, Ra);
+    GridDesc g = pr.geom->g;
+    const bool fwd = dir == 0;
+    // everything below is uniform in the workgroup: one direction, one grid, one instance of the search
+    int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
+    float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
+    const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
+    const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
+    const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
+    const int qoff = fwd ? 0 : Mn;
+    const int df = fwd ? pr.df : -pr.df;
+    const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
+    const double lim2 = icp_limit_sq(Mn + Rn);
+    mom_init(mt);
+    __syncthreads();
+    if (coop) {
+      const int sub = threadIdx.x & 31;
+      const int32_t* __restrict__ list = pr.wl + qoff;
+      const int wq = r * (kBlock / 32) + (threadIdx.x >> 5);
+      const bool valid = wq < nw;
+      const int qi = valid ? list[wq] - qoff : 0;  // index in the queries' cloud
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid) p = qpts[qi];
       float bud = 0.f;
@@ -657,40 +734,40 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
           else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
         }
       }
+    } else {
+      const int32_t* __restrict__ seed = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
+                                             : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+      const int32_t* __restrict__ list = pr.wls + qoff;
+      const int wq = r * (kBlock / 8) + (threadIdx.x >> 3);
+      const bool valid = wq < nw;
+      const int qi = valid ? list[wq] - qoff : 0;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
+      int sd = -1;
+      if (valid) {
+        p = qpts[qi];
+        sd = seed[qi];
+        sp = hpts[sd];
+      }
+      int res = -1;
+      float bud = 0.f;
+      const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud);
+      if (valid && (threadIdx.x & 7) == 0) {
+        if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
+        nn_o[qi] = res;
+        bud_o[qi] = bud;
+        if (res >= 0) {
+          if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+          else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
+        }
+      }
     }
     __syncthreads();
     mom_flush(mt);
-    return;
+    __syncthreads();  // (the table is initialised again for the next item)
   }
-  const int32_t* __restrict__ seed = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
-                                         : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
-  const int32_t* __restrict__ list = pr.wls + qoff;
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles inside)
-    const int w = r * (kBlock / 8) + (threadIdx.x >> 3);
-    const bool valid = w < nw;
-    const int qi = valid ? list[w] - qoff : 0;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
-    int s = -1;
-    if (valid) {
-      p = qpts[qi];
-      s = seed[qi];
-      sp = hpts[s];
-    }
-    int res = -1;
-    float bud = 0.f;
-    const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, s, valid, pr.mu, &res, &bud);
-    if (valid && (threadIdx.x & 7) == 0) {
-      if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
-      nn_o[qi] = res;
-      bud_o[qi] = bud;
-      if (res >= 0) {
-        if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
-        else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
-      }
-    }
-  }
-  __syncthreads();
-  mom_flush(mt);
+#ifdef PCS_WG_TRACE
+  if ((int)blockIdx.x < R) WGT_END(2, 0, 0ULL, 0ULL);
+#endif
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151);
@@ -941,6 +1018,7 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
 // build launch), and the grid this iteration searched is reset.
 __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  WGT_BEGIN();
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
@@ -972,6 +1050,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     for (int64_t q = tid; q < kStepH; q += (int64_t)gridDim.x * blockDim.x) nxt[q] = 0u;
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
+  WGT_MARK(wg_m1);
   float step = 0.f;  // largest step of this thread's points
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   const GridDesc d = pr.geom->g;
@@ -1017,6 +1096,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     }
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
+  WGT_MARK(wg_m2);
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
   // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
@@ -1026,7 +1106,25 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
                                              ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
               (unsigned long long)loss_fx);
+  WGT_END(4, k, wg_m1, wg_m2);
 }
+
+#ifdef PCS_WG_TRACE
+extern "C" int pcs_wg_trace_set(unsigned long long* buf) {
+  unsigned z = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgt), &buf, sizeof(buf)) != hipSuccess) return -3;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgt_n), &z, sizeof(z)) != hipSuccess) return -3;
+  return 0;
+}
+extern "C" int pcs_g2_counters(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_g2cnt), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+extern "C" unsigned pcs_wg_trace_count() {
+  unsigned n = 0;
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof(n));
+  return n;
+}
+#endif
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
 __global__ void __launch_bounds__(kBlock)
@@ -1118,17 +1216,20 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
   int& t_ev_used = t_ev_useds[prof_slot];
-  int64_t q = 1, m = 1;
+  int64_t q = 1, m = 1, qsum = 0;
   for (int e = 0; e < bt.n; ++e) {
     int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
     if (qe > q) q = qe;
+    qsum += qe;
     if (hints[e].Mn > m) m = hints[e].Mn;
   }
   bool any_first = false;
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
   const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
-  const int nb_c1 = gx_for(q * 32, kBlock, 8192);  // searches, iteration 1: every query, 32 lanes each
-  const int nb_cs = gx_for(q * 4, kBlock, 4096);   // later: the work lists (a fraction of the queries)
+  // the searches are a queue over the work lists of all entries (items of 8 cooperative / 32 seeded
+  // queries): iteration 1 searches for every query, later ones for ~6 % + ~12 % of them
+  const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8));
+  const int nb_cs = (int)(qsum / 48 < 64 ? 64 : (qsum / 48 > 2048 ? 2048 : qsum / 48));
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -1149,13 +1250,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
-      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c, bt.n, 4), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
+      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
                             j);
     } else {
       icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
-      icp_nn_search_kernel<<<dim3(nb_c, bt.n, 4), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }
