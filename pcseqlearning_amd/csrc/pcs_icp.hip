@@ -979,6 +979,15 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
       }
     }
   }
+#ifdef PCS_WG_TRACE
+  {
+    const unsigned long long need = __ballot(!have_R);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_g2cnt[11], 1ULL);
+      if (need) { atomicAdd(&g_g2cnt[10], 1ULL); atomicAdd(&g_g2cnt[9], (unsigned long long)__popcll(need)); }
+    }
+  }
+#endif
   if (!have_R) {
     double U[9], S[3], V[9];
     svd3(M, U, S, V);
@@ -1055,9 +1064,16 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   const GridDesc d = pr.geom->g;
   const int nround = (Mn + kBlock - 1) / kBlock;
+#ifdef PCS_WG_TRACE
+  int wgt_rounds = 0, wgt_owner = 0;
+#endif
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
     const int i = r * kBlock + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef PCS_WG_TRACE
+    ++wgt_rounds;
+    if (i < Mn && pr.first[pr.comp[i]] == i) ++wgt_owner;
+#endif
     if (i < Mn) {
       int c = comp[i];
       const long long* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
@@ -1106,7 +1122,17 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
                                              ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
               (unsigned long long)loss_fx);
-  WGT_END(4, k, wg_m1, wg_m2);
+#ifdef PCS_WG_TRACE
+  {
+    __shared__ int s_own;
+    if (threadIdx.x == 0) s_own = 0;
+    __syncthreads();
+    atomicAdd(&s_own, wgt_owner);
+    __syncthreads();
+    const unsigned long long info = ((unsigned long long)wgt_rounds << 32) | (unsigned)s_own;
+    WGT_END(4, k, info, wg_m2);
+  }
+#endif
 }
 
 #ifdef PCS_WG_TRACE

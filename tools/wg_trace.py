@@ -78,8 +78,25 @@ for K in (1, 2, 3, 4):
           f" spread 50/90/99: {np.percentile(spread, 50):.1f} {np.percentile(spread, 90):.1f} {np.percentile(spread, 99):.1f}")
     print(f"{'':24s} unit slot of the longest workgroup: {np.bincount(np.array(worst_y), minlength=9).tolist()}")
 
+# apply: what distinguishes the longest workgroup of a launch (rounds it ran, component owners among its threads)
+sel = np.nonzero(kid == 4)[0]
+if len(sel):
+    o = sel[np.argsort(t0[sel], kind="stable")]
+    cuts = np.nonzero(np.diff(t0[o]) > 800)[0] + 1
+    rl, ol, rm, om = [], [], [], []
+    for g in np.split(o, cuts):
+        if len(g) < 4:
+            continue
+        d = t1[g] - t0[g]
+        w = g[np.argmax(d)]
+        rounds = (a[g, 3] >> np.uint64(32)).astype(np.int64)
+        owners = (a[g, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        rl.append(int(a[w, 3] >> np.uint64(32))); ol.append(int(a[w, 3] & np.uint64(0xFFFFFFFF)))
+        rm.append(rounds.mean()); om.append(owners.mean())
+    print(f"apply: longest workgroup ran {np.mean(rl):.2f} rounds with {np.mean(ol):.1f} owners; the mean workgroup {np.mean(rm):.2f} rounds, {np.mean(om):.1f} owners")
 cnt = (ctypes.c_ulonglong * 16)()
 if lib.pcs_g2_counters(cnt) == 0:
     c = list(cnt)
     print(f"cooperative searches {c[0]}: far walk in {c[1]} ({100.0 * c[1] / max(c[0], 1):.1f} %), far rounds per walking query "
           f"{c[2] / max(c[1], 1):.2f}, far cells per walking query {c[3] / max(c[1], 1):.1f}; rounds histogram 1/2/3-4/5-8/9+: {c[4:9]}")
+    print(f"apply: waves {c[11]}, with at least one lane on the Jacobi SVD path {c[10]} ({100.0 * c[10] / max(c[11], 1):.1f} %), such lanes {c[9]}")
