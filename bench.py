@@ -275,7 +275,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=160000)
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=12,
                     help="sequences per step (one batch, as the reference's collate_batch hands them to "
                          "SimpleReg.forward, which tracks the sequences of a batch concurrently)")
     ap.add_argument("--inflight", type=int, default=0,

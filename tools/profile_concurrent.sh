@@ -8,6 +8,6 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_c
 export PCS_PROFILE_CONCURRENT=1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -o ks -- python3 $ROOT/bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --no-stages > $O/${TAG}_concurrent_bench.json 2> $O/conc.err || { echo "failed"; tail -5 $O/conc.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -o ks -- python3 $ROOT/bench.py --batch 12 --steps 2 --warmup 1 --no-cpu-baseline --no-stages > $O/${TAG}_concurrent_bench.json 2> $O/conc.err || { echo "failed"; tail -5 $O/conc.err; exit 1; }
 cp /tmp/prof_c/ks_kernel_stats.csv $O/${TAG}_concurrent_kernel_stats.csv
 python3 $ROOT/tools/trace_concurrency.py /tmp/prof_c/ks_kernel_trace.csv | tee $O/${TAG}_concurrency.txt
