@@ -372,8 +372,10 @@ def main():
         step()
         if trace:
             faulthandler.cancel_dump_traceback_later()
-            print(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB",
-                  file=sys.stderr, flush=True)
+            ms_ = torch.cuda.memory_stats()
+            print(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB"
+                  f" alloc_retries {ms_.get('num_alloc_retries', 0)} device_alloc {ms_.get('num_device_alloc', 0)}"
+                  f" device_free {ms_.get('num_device_free', 0)}", file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 9)()

@@ -11,6 +11,8 @@
 // weight-decay factors to the elements that never see a gradient.
 #include "pcs_common.hpp"
 #include <mutex>
+#include <chrono>
+#include <cstdio>
 
 namespace pcs {
 
@@ -21,6 +23,14 @@ namespace pcs {
 static std::mutex& sv_grid_mutex() {
   static std::mutex* mu = new std::mutex();
   return *mu;
+}
+// Every tracker tick passes this gate before it enqueues anything: while a grid-barrier launch is in
+// flight the other lock-step groups / sequences hold back their next tick, so the launch meets an
+// emptying chip. Without it the 1024-thread workgroups of the barrier kernel could wait for a whole
+// free CU for tens of seconds while the 256-thread workgroups of the other chains kept slipping into
+// every gap (seen as 25-70 s steps, "[pcs] smooth_velo multi-workgroup launch drained after 42.5 s").
+void sv_grid_gate() {
+  std::lock_guard<std::mutex> lk(sv_grid_mutex());
 }
 
 struct SmoothState {
@@ -1224,7 +1234,13 @@ int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* c
         if (sb.j[e].blocks > part_max) part_max = sb.j[e].blocks;
       }
       flush();
-      PCS_CHECK_HIP(hipStreamSynchronize(s));
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        PCS_CHECK_HIP(hipStreamSynchronize(s));
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (sec > 2.0)  // diagnostic: a grid-barrier launch that took this long was waiting for residency
+          fprintf(stderr, "[pcs] smooth_velo multi-workgroup launch drained after %.1f s (%d problems)\n", sec, sb.n);
+      }
       continue;
     }
     smooth_velo_batch_kernel<<<dim3(nblk[kind], sb.n), SV_BLOCK, lds[kind], s>>>(sb, kind, weight0, weight, num_itr,

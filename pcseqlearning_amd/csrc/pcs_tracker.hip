@@ -1013,6 +1013,7 @@ hv_compact_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
   if (threadIdx.x == 0) u.st->ex_count = base + tot;
 }
 
+void sv_grid_gate();  // pcs_track.hip: waits while a grid-barrier launch is in flight
 int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
                           const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
                           float weight0, float weight, int num_itr, float stopping, void* const* ws,
@@ -1456,6 +1457,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   auto enqueue_tick = [&](int gi) -> int {
     Group& gr = grp[gi];
     hipStream_t gs = gr.st;
+    sv_grid_gate();
     ++gr.ticks;
     Batch b_fin, b_post, b_dir, b_step, b_smp, b_begin, b_iter;
     Steps s_fin, s_post, s_step, s_smp;
@@ -1759,7 +1761,11 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; g_tick_profile.calls += 1; }
     while (rc == PCS_OK && gr.inflight) {
       if (tp) t0 = now_ns();
+      const long long w0 = now_ns();
       if (hipEventSynchronize(gr.ev) != hipSuccess) { rc = PCS_ERR_HIP; break; }
+      if (now_ns() - w0 > 2000000000LL)  // diagnostic: a tick that took seconds
+        fprintf(stderr, "[pcs] tracker tick %lld of group %d completed after %.1f s (iterating units %d, finishing %d)\n",
+                (long long)gr.ticks, gi, (now_ns() - w0) / 1e9, gr.b_iter.n, gr.b_fin.n);
       if (tp) { g_tick_profile.wait_ns += now_ns() - t0; t0 = now_ns(); }
       rc = collect_tick(gi);
       if (rc == PCS_OK && gr.live > 0) {
