@@ -277,12 +277,6 @@ __global__ void __launch_bounds__(kScanWg) scan_one_wg_kernel(const int32_t* __r
   }
 }
 
-__global__ void fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = v;
-}
-
 static inline uint32_t pow2_at_least(uint64_t x) {
   uint32_t h = 64;
   while (h < x) h <<= 1;
