@@ -277,7 +277,9 @@ int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C
 /* The same for n problems in one call (what the sequence tracker does at every frame step, one problem
  * per tracking unit; host arrays of n device pointers / sizes; ws[e] sized by
  * pcs_smooth_velo_workspace_bytes(C[e], F[e])). Results are those of n separate calls. The call
- * returns after the stream has drained; PCS_ERR_HIP if a multi-workgroup problem's barrier timed out. */
+ * returns after the stream has drained. (A many-component problem whose multi-workgroup form could
+ * not get its workgroups resident within ~0.2 s is run again in the single-workgroup form; stderr
+ * says so.) */
 int pcs_smooth_velo_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
                           const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
                           float weight0, float weight, int num_itr, float stopping, void* const* ws,
