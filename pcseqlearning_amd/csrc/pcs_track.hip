@@ -281,7 +281,8 @@ smooth_velo_lds_body(float* __restrict__ sv /* LDS [n_in] current iterate */, fl
 // double-buffered by step parity). All workgroups evaluate the same stop rule on the same sum, so
 // they leave together. The grid is at most 64 x 1024 threads (a quarter of what the device keeps
 // resident: one such workgroup per CU), the host sends one such launch at a time, and the barrier
-// wait is bounded: on time-out the error word is set to 3 and every wave exits.
+// wait is bounded: on time-out the problem's time-out word is set, every wave exits without writing
+// anything back, and the host runs the problem again in the generic single-workgroup form.
 constexpr int SV_MAX_BLOCKS = 64;
 // polls of the barrier before a workgroup gives up (1-3 us each: two agent-scope loads and a sleep,
 // so 0.13-0.4 s; a barrier that all workgroups reach takes microseconds). 1 << 24 let a launch that
