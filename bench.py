@@ -107,6 +107,15 @@ def _generate_sequence(job):
     return job[0]
 
 
+def step_stats(ms):
+    """min / median / p95 / max of the timed steps (rank 0's clock), so that a stalled step shows."""
+    v = sorted(ms)
+    if not v:
+        return None
+    pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
+    return {"min": round(v[0], 2), "median": round(pick(0.5), 2), "p95": round(pick(0.95), 2), "max": round(v[-1], 2)}
+
+
 def baseline_metric():
     """BASELINE.json's metric string (the file sits next to this script)."""
     try:
@@ -226,48 +235,6 @@ def stage_rooflines(records, stats, prof, out):
     return stages
 
 
-def kernel_stats_stages(out):
-    """Rows for the tracker's phases that run inside the native call (no host span): kernel time from the
-    committed rocprofv3 summary of this command (profiles/r02_sequence_kernel_stats.csv, 4 sequences,
-    single-group schedule), algorithmic bytes from SURVEY 8d's per-unit figures and this run's sizes."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r02_sequence_kernel_stats.csv")
-    if not os.path.exists(path):
-        return []
-    seqs = 6.0  # --batch 1: 1 warm-up + 3 timed + 2 single-sequence runs of the profiled command
-    rows = list(csv.DictReader(open(path)))
-
-    def ms_of(*names):
-        return sum(float(r["TotalDurationNs"]) for r in rows if any(n in r["Name"] for n in names)) / 1e6 / seqs
-
-    def calls_of(name):
-        return sum(int(r["Calls"]) for r in rows if name in r["Name"]) / seqs
-
-    n_pts = float(out["point_fxyz"].shape[0])
-    frames = float(out["point_fxyz"][:, 0].max().item()) + 1.0
-    per_frame = n_pts / frames
-    res = []
-    # sampling: per registration and unit both clouds are keyed, sorted, reduced: 16 B read + 12 B of
-    # key / value traffic per point and pass of the 4-pass radix sort, 20 B written per voxel
-    regs = 315.0
-    t = ms_of("smp_sort_kernel", "smp_emit_kernel", "smp_compact_kernel")
-    nbytes = regs * 2.0 * per_frame * (16.0 + 4 * 12.0 + 20.0)
-    if t > 0:
-        res.append({"stage": "tracker sampling (voxel keys, one-workgroup radix sort, means / medians)", "ms": round(t, 3),
-                    "launches": int(calls_of("smp_sort_kernel") * 3), "algorithmic_MB": round(nbytes / 1e6, 2),
-                    "achieved_GBs": round(nbytes / t / 1e6, 2), "frac": round(nbytes / t / 1e6 / HBM_PEAK_GBS, 5),
-                    "bytes": "per registration 2 clouds x n x (16 + 4 x 12 + 20)", "source": "profiles/r02_sequence_kernel_stats.csv"})
-    t = ms_of("hv_insert_kernel", "hv_search_kernel", "hv_compact_kernel")
-    steps = calls_of("hv_search_kernel") * 9.0 / max(1.0, 9.0)  # launches serve all units of the group
-    nbytes = 105.0 * per_frame * (16.0 + 16.0 + 16.0)  # 105 unit-steps per sequence: N + M + E rows of 16 B
-    if t > 0:
-        res.append({"stage": "tracker harvest (1-NN r = 0.5 of the moved anchor against the target frame)", "ms": round(t, 3),
-                    "launches": int(steps * 3), "algorithmic_MB": round(nbytes / 1e6, 2),
-                    "achieved_GBs": round(nbytes / t / 1e6, 2), "frac": round(nbytes / t / 1e6 / HBM_PEAK_GBS, 5),
-                    "bytes": "per unit step 16 N + 16 M + 16 E", "source": "profiles/r02_sequence_kernel_stats.csv"})
-    return res
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,12 +331,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     trace = os.environ.get("PCS_BENCH_TRACE")
+    step_ms = []
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
+    fallbacks0 = CT.HOST_FALLBACKS
     for i in range(args.steps):
         ts = time.perf_counter()
         if trace:  # a step that hangs shows where: every thread's Python stack after 5 s, then every 5 s
             import faulthandler
             faulthandler.dump_traceback_later(5, repeat=True, file=sys.stderr)
         step()
+        torch.cuda.current_stream().synchronize()  # (a step's outputs are complete when forward returns; this only orders the clock)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         if trace:
             faulthandler.cancel_dump_traceback_later()
             ms_ = torch.cuda.memory_stats()
@@ -378,6 +350,7 @@ def main():
                   f" device_free {ms_.get('num_device_free', 0)}", file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
+    host_fallbacks = CT.HOST_FALLBACKS - fallbacks0
     prof = (ctypes.c_double * 9)()
     lib.pcs_profile_icp_read(prof)
     lib.pcs_profile_icp(ctypes.c_int(0))
@@ -387,7 +360,7 @@ def main():
     tracker = model.preprocessors[2]
     dt, (total_sequences, points_in) = reduce_metrics(
         dist, device, dt, [float(args.steps * B), float(args.steps) * float(n_points_in)])
-    # one sequence alone through the same model (four lock-step groups, nothing beside it): its latency,
+    # one sequence alone through the same model (its 9 units in the engine, nothing beside it): its latency,
     # and the outputs / tracker counters the report below quotes (the batch's worker copies are gone)
     with torch.no_grad():
         model(batch1)
@@ -416,20 +389,20 @@ def main():
         # start to last stop of the pair, the quantity rocprofv3 reports as kernel durations
         ms, launches, nbytes = prof[0], prof[1], prof[2] + prof[5]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        # HBM traffic of the pair per launch from the PMC passes of THIS schedule (tools/pmc_pass.sh ->
+        # profiles/r03_icp_hbm_pmc.json, written by tools/summarize_pmc.py); null when no such file exists
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_icp_hbm_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_icp_hbm_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            # per launch like `achieved`: the PMC passes run the single-group schedule (9 units per
-            # launch), the timed region 4 groups (2-3 units per launch): the measured ratio of fabric
-            # bytes to algorithmic bytes is applied to this run's algorithmic bytes per launch
             ratio = pmc.get("icp_nn_pair_traffic_over_algorithmic")
             if ratio and launches > 0:
                 traffic = round(ratio * nbytes / launches, 1)
-            traffic_src = ("profiles/r02_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                           "this command, (fetch + write) / algorithmic = %s, times this run's algorithmic "
-                           "bytes per launch" % ratio)
+            traffic_src = ("profiles/r03_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                           "this command (same schedule), (fetch + write) / algorithmic = %s (raw FETCH_SIZE; "
+                           "%s with the guide's x2 correction for gfx950), times this run's algorithmic bytes "
+                           "per launch" % (ratio, pmc.get("icp_nn_pair_traffic_over_algorithmic_fetch_x2")))
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
@@ -438,6 +411,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "step_ms": step_stats(step_ms),
+            "host_fallbacks": int(host_fallbacks),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -448,23 +423,24 @@ def main():
                              "cluster_tracking_TLS_multiradius_every8 end to end "
                              "(subsample + ground removal + 3-radius proposal + tracking); a step is one "
                              f"batch of {B} independent sequences through SimpleReg.forward, which processes "
-                             "the sequences of a batch concurrently (one host thread, stream and lock-step "
-                             "group per sequence)" if B > 1 else
+                             "the sequences of a batch concurrently (one host thread and stream per sequence "
+                             "for the ground / proposal / extraction stages; the tracking units of all "
+                             "sequences in flight share the launches of one lock-step engine)" if B > 1 else
                              "configs[2]: one 20-frame x 160k-pt synthetic sequence per step, "
                              "cluster_tracking_TLS_multiradius_every8 end to end"),
                 "batch_size": B,
-                "sequences_in_flight": min(B, int(model.model_cfg.get("SEQUENCES_IN_FLIGHT", 4))),
+                "sequences_in_flight": min(B, int(model.model_cfg.get("SEQUENCES_IN_FLIGHT", 12))),
                 "one_sequence_alone_ms": round(single_ms, 2),
                 "one_sequence_alone_sequences_per_s": round(1e3 / single_ms, 4),
                 "frames": args.frames, "points_per_frame": args.points,
                 "points_in_per_second": round(points_in / dt, 1),
                 "points_after_subsample": int(out["full_point_fxyz"].shape[0]),
                 "points_after_ground_removal": int(out["point_fxyz"].shape[0]),
-                "parallelism": f"one sequence per GPU x{world}",
-                "tracking_units_in_lock_step": int(getattr(tracker, "last_num_workers", 0)),
+                "parallelism": (f"sequences sharded over {world} GPU(s), sequence s -> rank s mod {world}; per GPU a "
+                                f"batch of {B} per step"),
+                "tracking_units_per_sequence": int(getattr(tracker, "last_num_workers", 0)),
                 "tracker_host_ticks": int(getattr(tracker, "last_ticks", 0)),
                 "icp_level_calls_per_sequence": int(tracker.num_registration_calls),
-                "profiler_forced_single_group": bool(os.environ.get("ROCP_TOOL_LIBRARIES")),
                 # host wall spans of the timed steps per sequence (not device-synchronised; the sequences of a
                 # batch overlap, so the spans add up to more than the step)
                 "stage_seconds_per_sequence": host_spans,
@@ -479,7 +455,7 @@ def main():
                 "timing": ("HIP events on the dispatches themselves, inside the timed steps, on one iteration "
                            "of every chunk of 8 (rotating position): first start to last stop of the pair"),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
-                "stages": stages + kernel_stats_stages(out),
+                "stages": stages,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

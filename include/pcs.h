@@ -98,7 +98,10 @@ int pcs_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6
  * pairs [KV,2,V] int32 (filled with -1 then written), num [KV]; strided conv also writes
  * out_ids [out_cap,4] with out_cap >= pcs_indice_pairs_out_capacity() and *d_num_out.
  * Pair order per offset = ascending input index; output voxel order = first encounter
- * (the reference CPU functor order, geometry.h:145-194). transpose (deconv) is rejected.
+ * (the reference CPU functor order, geometry.h:145-194). transpose != 0 (with subm == 0): the
+ * rulebook of a transposed conv (getIndicePairsDeConv, geometry.h:197-245: out = in * stride - pad
+ * + k * dilation, out_shape3 = get_deconv_output_size), same orders. The capacity / workspace
+ * queries take `subm` = 0 strided, 1 submanifold, 2 transposed.
  * All *3 arrays are host int[3] in (z,y,x) order. KV <= 32. */
 int64_t pcs_indice_pairs_out_capacity(int64_t V, const int* ksize3, const int* stride3, int subm);
 size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const int* stride3,
@@ -302,8 +305,8 @@ int pcs_smooth_velo_batch(int n, float* const* comp_velos, const float* const* c
  *     reg_errors, comp_edge_ratios [C, F] f32 and comp_velos [C, F, 3] f32 with F = max_frame_id + 1;
  *     comp_min_frame_id / comp_max_frame_id [C] int64; moving, valid_comp [C] uint8 (valid_comp =
  *     filter_components of the anchor). info: HOST int64[4] = {rows extracted, registration calls,
- *     frame steps, host ticks}. Returns PCS_ERR_RANGE when a search grid overflowed (caller falls
- *     back to the op-by-op host path). */
+ *     frame steps, host ticks}. Returns PCS_ERR_RANGE when a search grid overflowed (the caller may
+ *     fall back to the op-by-op host path, and must say so). */
 #define PCS_TRACK_MAX_LEVELS 4
 typedef struct PcsTrackParams {
   int32_t num_levels;      /* REGISTRATION.GRAPH.RADIUS / VOXEL_SIZE / STOPPING_DELTA entries */
@@ -319,7 +322,7 @@ typedef struct PcsTrackParams {
   float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
   float max_diameter;      /* filter_components max_diameter (12.5) */
   float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
-  int32_t groups;          /* lock-step groups (streams + host threads) of pcs_track_sequence; 0 = default (PCS_TRACK_GROUPS or 4) */
+  int32_t groups;          /* ignored (round 2: lock-step groups per call); units of all calls now share the device's one lock-step engine */
 } PcsTrackParams;
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames);
@@ -333,15 +336,24 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
                     pcs_stream_t stream);
 
 /* The tracking loop of ClusterTracking.forward (cluster_tracking.py:853-884: for every component
- * key, for every anchor frame, track_frame) for ALL units of a sequence in one call: the units are
- * independent, and each is a chain of small latency-bound launches, so one host thread advances
- * them in lock-step -- every launch serves all units that are in the same phase, the ICP iterations
- * of all units share their three launches -- on ONE stream. A unit's results are those of
- * pcs_track_frame on the same inputs, bit for bit, whatever other units run beside it.
+ * key, for every anchor frame, track_frame) for ALL units of a sequence in one call. The units are
+ * independent, and each is a chain of small latency-bound launches, so they advance in lock-step:
+ * every launch serves all units that are in the same phase, the ICP iterations of all units share
+ * their three launches. The lock-step loop belongs to the DEVICE, not to the call: one driver thread
+ * and one stream per device advance every unit that any call (any host thread, any sequence of a
+ * batch: SimpleReg.forward loops over independent sequences, simple_reg.py:105-147) has handed
+ * over; units join and leave at tick boundaries. The call prepares its units on `stream`, hands them
+ * over and BLOCKS until they are done. A unit's results are those of pcs_track_frame on the same
+ * inputs, bit for bit, whatever other units share its launches. Calls whose PcsTrackParams differ
+ * from those of the units in flight wait until the engine is empty.
  *   seq_fxyz / frame_offsets / num_frames: as for pcs_track_frame (shared by all units);
  *   units[n_units] (HOST array, n_units <= 32): per unit its key's component ids and stationary
  *     flags, the anchor and window, comp_base / C, and the output pointers of pcs_track_frame;
- *     info is written by the call. */
+ *     info is written by the call.
+ * pcs_track_batch: the same for the sequences of a batch from ONE host thread (sequence q's units are
+ * handed over as soon as they are prepared; at most 128 units are in flight on a device, further
+ * ones wait for free table slots); arrays of n_seqs HOST pointers / counts; `ws` is one workspace of
+ * pcs_track_batch_workspace_bytes for all of them. */
 typedef struct PcsTrackUnit {
   const int64_t* seq_component;   /* [N] int64 */
   const uint8_t* seq_stationary;  /* [N] uint8 */
@@ -360,6 +372,11 @@ size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_
 int pcs_track_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
                        int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
                        pcs_stream_t stream);
+size_t pcs_track_batch_workspace_bytes(int n_seqs, const int64_t* const* frame_offsets, const int* num_frames,
+                                       const PcsTrackUnit* const* units, const int* n_units);
+int pcs_track_batch(const PcsTrackParams* prm, int n_seqs, const float* const* seq_fxyz,
+                    const int64_t* const* frame_offsets, const int* num_frames, PcsTrackUnit* const* units,
+                    const int* n_units, void* ws, size_t ws_bytes, pcs_stream_t stream);
 
 /* points_in_boxes_cpu, pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168 (evaluation
  * side-channel of ClusterProposal / ClusterTracking): points [N,3], boxes [B,7]

@@ -102,6 +102,65 @@ def dynamic_voxelize(points, pc_range, voxel_size, grid_size):
     return feat[:v].copy(), coords[:v].copy(), inv
 
 
+def voxel_aggregation(point_bxyz, mean_attrs, median_attrs, voxel_size3, pc_range6=None):
+    """VoxelAggregation.forward, pcdet/ops/voxel/voxel_modules.py:25-126, in numpy (fp32 quantisation like
+    the reference's tensors; means accumulated in f64 and rounded once -- torch_scatter's fp32 sums are
+    unordered). mean_attrs / median_attrs: dicts of per-point arrays (point_bxyz itself is averaged as
+    'bxyz'). Returns (voxel dict, voxel_index [n'], point coords [n',4], num_voxels, out_of_boundary [n]).
+    Pinned by tests/golden/voxel_agg_*.npz (the reference's own module run on CPU)."""
+    bxyz = np.asarray(point_bxyz, np.float32)
+    vs = np.asarray([1.0] + list(voxel_size3), np.float32)
+    batch_size = int(bxyz[:, 0].max()) + 1
+    if pc_range6 is None:
+        mn = bxyz.min(0)
+        vc = np.floor((bxyz - mn) / vs).astype(np.int64)
+        vc = vc - vc.min(0)
+        dims = vc.max(0) + 1
+        oob = np.zeros(len(bxyz), bool)
+    else:
+        r = np.asarray([0] + list(pc_range6[:3]) + [1] + list(pc_range6[3:]), np.float32)
+        mn, mx = r[:4].copy(), r[4:].copy()
+        mn[0] = 0
+        mx[0] = np.float32(batch_size - 1e-5)
+        vc = np.floor((bxyz - mn) / vs).astype(np.int64)
+        dims = np.ceil((mx - mn) / vs).astype(np.int64) + 1
+        oob = (vc >= dims)[:, 1:4].any(-1) | (vc < 0)[:, 1:4].any(-1)
+        vc, bxyz = vc[~oob], bxyz[~oob]
+    merge = np.zeros(len(vc), np.int64)
+    for i in range(4):
+        merge = merge * dims[i] + vc[:, i]
+    uniq, vidx = np.unique(merge, return_inverse=True)
+    V = len(uniq)
+    ucoords = np.zeros((V, 4), np.int64)
+    u = uniq.copy()
+    for i in range(3, -1, -1):
+        ucoords[:, i] = u % dims[i]
+        u = u // dims[i]
+    center = (ucoords.astype(np.float32) * vs + mn)[:, 1:4]
+    center = center + vs[1:4] / np.float32(2)
+    cnt = np.bincount(vidx, minlength=V).astype(np.float64)
+    out = {}
+    attrs = dict(bxyz=bxyz)
+    attrs.update({k: np.asarray(v)[~oob] for k, v in mean_attrs.items()})
+    for key, val in attrs.items():
+        v2 = val.reshape(len(val), -1).astype(np.float64)
+        ssum = np.zeros((V, v2.shape[1]))
+        np.add.at(ssum, vidx, v2)
+        out["voxel_" + key] = (ssum / cnt[:, None]).astype(np.float32).reshape((V,) + val.shape[1:])
+    deg = cnt.astype(np.int64)
+    off = np.cumsum(deg) - deg
+    for key, val in (median_attrs or {}).items():
+        val = np.asarray(val)[~oob].astype(np.int64)
+        tval = (val - val.min()) + vidx * val.max()
+        out["voxel_" + key] = np.sort(tval)[off + deg // 2] - np.arange(V) * val.max()
+    out["voxel_batch_index"] = np.round(out["voxel_bxyz"][:, 0]).astype(np.int64)
+    out["voxel_xyz"] = out["voxel_bxyz"][:, 1:4]
+    out["voxel_center"] = center
+    out["voxel_bcenter"] = np.concatenate([out["voxel_bxyz"][:, :1], center], -1)
+    out["voxel_bcoords"] = ucoords
+    return out, vidx, vc, V, oob
+
+
 def hard_voxelize(points, pc_range, voxel_size, max_points, max_voxels):
     pts = _c(points, np.float32)
     n, ncol = pts.shape
@@ -120,7 +179,13 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
             for i in range(3)]
 
 
-def get_indice_pairs(indices, out_shape, ksize, stride, padding, dilation, subm):
+def deconv_out_shape(spatial_shape, ksize, stride, padding, dilation, output_padding):
+    """get_deconv_output_size, pcdet/ops/spconv/ops.py:33-44."""
+    return [(spatial_shape[i] - 1) * stride[i] - 2 * padding[i] + ksize[i] + output_padding[i] for i in range(3)]
+
+
+def get_indice_pairs(indices, out_shape, ksize, stride, padding, dilation, subm, transpose=False):
+    """subM / strided / transposed (getIndicePairsDeConv, geometry.h:197-245) rulebook."""
     idx = _c(indices, np.int32)
     V = idx.shape[0]
     kv = int(np.prod(ksize))
@@ -129,7 +194,7 @@ def get_indice_pairs(indices, out_shape, ksize, stride, padding, dilation, subm)
     out_ids = np.zeros((max(V * kv, 1), 4), np.int32)
     n = lib().orc_get_indice_pairs(_p(idx), ctypes.c_int64(V), _ints(out_shape), _ints(ksize),
                                    _ints(stride), _ints(padding), _ints(dilation),
-                                   ctypes.c_int(int(subm)), _p(out_ids), _p(pairs), _p(num))
+                                   ctypes.c_int(2 if transpose else int(subm)), _p(out_ids), _p(pairs), _p(num))
     return (idx if subm else out_ids[:n].copy()), pairs, num
 
 
@@ -311,6 +376,23 @@ def ref_get_indice_pairs(indices, batch, out_shape, ksize, stride, padding, dila
                                          _ints(padding), _ints(dilation), ctypes.c_int(int(subm)),
                                          _p(out_ids), _p(pairs), _p(num))
     return (idx if subm else out_ids[:n].copy()), pairs, num
+
+
+def ref_get_indice_pairs_deconv(indices, batch, out_shape, ksize, stride, padding, dilation):
+    """The reference's own getIndicePairsDeConv (compiled in place, oracle/_ref/libref_spconv.so)."""
+    global _REF_SPCONV
+    if _REF_SPCONV is None:
+        _REF_SPCONV = ctypes.CDLL(os.path.join(HERE, "_ref", "libref_spconv.so"))
+    idx = _c(indices, np.int32)
+    V = idx.shape[0]
+    kv = int(np.prod(ksize))
+    pairs = np.empty((kv, 2, V), np.int32)
+    num = np.empty(kv, np.int32)
+    out_ids = np.zeros((max(V * kv, 1), 4), np.int32)
+    n = _REF_SPCONV.ref_get_indice_pairs_deconv(_p(idx), ctypes.c_int(V), ctypes.c_int(batch), _ints(out_shape),
+                                                _ints(ksize), _ints(stride), _ints(padding), _ints(dilation),
+                                                _p(out_ids), _p(pairs), _p(num))
+    return out_ids[:n].copy(), pairs, num
 
 
 def ref_hard_voxelize(points, pc_range, voxel_size, max_points, max_voxels):

@@ -212,9 +212,44 @@ static int valid_out_pos(const int* in, const int* ks, const int* st, const int*
   return cnt;
 }
 
+// getValidOutPosTranspose (geometry.h:87-142) restated: the kernel footprint of one input position of a
+// transposed conv, enumerated from `uppers` downward, last dim fastest; offset = kernel offset id.
+static int valid_out_pos_transpose(const int* in, const int* ks, const int* st, const int* pd, const int* dl,
+                                   const int* oshape, int* out /* [kv][4] */) {
+  int lowers[3], uppers[3], counter[3], csize[3];
+  int npts = 1, cnt = 0;
+  for (int i = 0; i < 3; ++i) {
+    lowers[i] = in[i] * st[i] - pd[i];
+    uppers[i] = lowers[i] + (ks[i] - 1) * dl[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    csize[i] = (uppers[i] - lowers[i]) / dl[i] + 1;
+    npts *= csize[i];
+    counter[i] = 0;
+  }
+  for (int i = 0; i < npts; ++i) {
+    bool valid = true;
+    int m = 1, offset = 0;
+    for (int j = 2; j >= 0; --j) {
+      int val = uppers[j] - counter[j] * dl[j];
+      out[cnt * 4 + j] = val;
+      if (val < 0 || val > oshape[j] - 1) valid = false;
+      offset += m * (val - lowers[j]) / dl[j];
+      m *= ks[j];
+    }
+    out[cnt * 4 + 3] = offset;
+    if (valid) ++cnt;
+    counter[2] += 1;
+    for (int c = 2; c >= 0; --c)
+      if (counter[c] == csize[c] && c > 0) { counter[c - 1] += 1; counter[c] = 0; }
+  }
+  return cnt;
+}
+
 // getIndicePairsSubM (geometry.h:248-297) / getIndicePairsConv (geometry.h:145-194) with the
 // parameter handling of getIndicePair (spconv_ops.h:73-85). pairs [KV,2,V] pre-filled with -1,
-// num [KV] zeroed here. Returns the number of output voxels; out_ids [*,4] for conv.
+// num [KV] zeroed here. Returns the number of output voxels; out_ids [*,4] for conv. subm: 0 strided conv,
+// 1 submanifold, 2 transposed conv (getIndicePairsDeConv, geometry.h:197-245).
 int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_shape3,
                              const int* ksize3, const int* stride3, const int* pad3,
                              const int* dil3, int subm, int32_t* out_ids, int32_t* pairs,
@@ -224,8 +259,8 @@ int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_s
   for (int d = 0; d < 3; ++d) {
     ks[d] = ksize3[d];
     dl[d] = dil3[d];
-    st[d] = subm ? 1 : stride3[d];
-    pd[d] = subm ? ksize3[d] / 2 : pad3[d];
+    st[d] = subm == 1 ? 1 : stride3[d];
+    pd[d] = subm == 1 ? ksize3[d] / 2 : pad3[d];
     kv *= ks[d];
   }
   for (int64_t i = 0; i < (int64_t)kv * 2 * V; ++i) pairs[i] = -1;
@@ -237,7 +272,7 @@ int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_s
   auto flat = [&](const int* p, int b) {
     return ((int64_t)p[0] * out_shape3[1] + p[1]) * out_shape3[2] + p[2] + vol * b;
   };
-  if (subm) {
+  if (subm == 1) {
     for (int64_t j = 0; j < V; ++j) grid[flat(indices + j * 4 + 1, indices[j * 4])] = (int32_t)j;
     for (int64_t j = 0; j < V; ++j) {
       int cnt = valid_out_pos(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data());
@@ -253,10 +288,12 @@ int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_s
     }
     return V;
   }
+  const bool transpose = subm == 2;  // getIndicePairsDeConv (geometry.h:197-245)
   int32_t num_act = 0;
   for (int64_t j = 0; j < V; ++j) {
     int b = indices[j * 4];
-    int cnt = valid_out_pos(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data());
+    int cnt = transpose ? valid_out_pos_transpose(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data())
+                        : valid_out_pos(indices + j * 4 + 1, ks, st, pd, dl, out_shape3, vp.data());
     for (int i = 0; i < cnt; ++i) {
       const int* p = vp.data() + i * 4;
       int off = p[3];

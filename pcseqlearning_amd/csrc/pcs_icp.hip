@@ -642,7 +642,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
 // one (entry, direction, kind) work list -- 8 cooperative or 32 seeded queries -- and the workgroups
 // take the items w = blockIdx.x, blockIdx.x + gridDim.x, ... of the concatenated lists (cooperative
 // lists first: they are the long ones). Every workgroup first forms the same table of rounds from the
-// list lengths on the device (128 words at most). The form this replaces was a (rounds of the largest
+// list lengths on the device (4 words per entry). The form this replaces was a (rounds of the largest
 // list) x entries x 4 grid whose ~10 k workgroups mostly found nothing to do: dealing them out took
 // longer than the searches -- the workgroups with work started up to 26 us apart (58 at the 90th
 // percentile, 187 us at the 99th, the first iteration of a registration, whose seeded slices are all
@@ -650,29 +650,35 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   WGT_BEGIN();
+  static_assert(4 * kMaxBatch <= 2 * kBlock, "two lists per thread");
   __shared__ int s_pref[4 * kMaxBatch + 1];
   __shared__ int s_wsum[kBlock / 64];
   __shared__ int skey[kMomSlots];
   __shared__ unsigned long long sacc[kMomSlots * 17];
   const int nlist = 4 * bt.n;  // list t: t < 2n cooperative, else seeded; entry (t mod 2n) / 2, direction t & 1
-  int my_rounds = 0;
-  if ((int)threadIdx.x < nlist) {
-    const int t = threadIdx.x;
-    const bool coop_t = t < 2 * bt.n;
-    const int tt = coop_t ? t : t - 2 * bt.n;
-    const int e = tt >> 1, dir_t = tt & 1;
-    const IcpProblem& pe = tab[bt.idx[e]];
-    const int ke = kbase.v[e] + 1 + j;
-    const IcpState* se = pe.st;
-    if (!(ke > pe.max_iter || ke > se->stop_iter)) {
-      const int nw = coop_t ? se->wl_n[dir_t] : se->ws_n[dir_t];
-      const int per = coop_t ? kBlock / 32 : kBlock / 8;
-      my_rounds = (nw + per - 1) / per;
+  // thread x holds the rounds of lists 2x and 2x + 1 (nlist <= 2 * kBlock)
+  int my_rounds[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int t = 2 * (int)threadIdx.x + h;
+    if (t < nlist) {
+      const bool coop_t = t < 2 * bt.n;
+      const int tt = coop_t ? t : t - 2 * bt.n;
+      const int e = tt >> 1, dir_t = tt & 1;
+      const IcpProblem& pe = tab[bt.idx[e]];
+      const int ke = kbase.v[e] + 1 + j;
+      const IcpState* se = pe.st;
+      if (!(ke > pe.max_iter || ke > se->stop_iter)) {
+        const int nw = coop_t ? se->wl_n[dir_t] : se->ws_n[dir_t];
+        const int per = coop_t ? kBlock / 32 : kBlock / 8;
+        my_rounds[h] = (nw + per - 1) / per;
+      }
     }
   }
-  {  // exclusive prefix of the rounds (nlist <= 128: the first two waves hold them)
+  {  // exclusive prefix of the rounds
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int incl = my_rounds;
+    const int mine = my_rounds[0] + my_rounds[1];
+    int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       int t = __shfl_up(incl, o, 64);
@@ -680,9 +686,13 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
     }
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
-    const int before = wv == 0 ? 0 : s_wsum[0];
-    if ((int)threadIdx.x < nlist) s_pref[threadIdx.x] = before + incl - my_rounds;
-    if ((int)threadIdx.x == nlist - 1) s_pref[nlist] = before + incl;
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += s_wsum[q];
+    const int ex = before + incl - mine;
+    const int t0 = 2 * (int)threadIdx.x;
+    if (t0 < nlist) s_pref[t0] = ex;
+    if (t0 + 1 < nlist) s_pref[t0 + 1] = ex + my_rounds[0];
+    if (t0 == nlist - 2) s_pref[nlist] = ex + mine;  // (nlist = 4 n is even)
     __syncthreads();
   }
   const int R = s_pref[nlist];

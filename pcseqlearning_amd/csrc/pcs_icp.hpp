@@ -15,7 +15,7 @@
 
 namespace pcs {
 
-constexpr int kMaxBatch = 32;  // table slots one launch can address
+constexpr int kMaxBatch = 128;  // table slots one launch can address (the lists travel by value: 4 B per slot)
 
 struct Batch {
   int n;

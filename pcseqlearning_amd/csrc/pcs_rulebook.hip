@@ -3,6 +3,7 @@
 // Restates the semantics of the reference CPU builders
 //   pcdet/ops/spconv/include/spconv/geometry.h:25-85   (getValidOutPos: kernel-offset numbering)
 //   pcdet/ops/spconv/include/spconv/geometry.h:145-194 (getIndicePairsConv: first-encounter out ids)
+//   pcdet/ops/spconv/include/spconv/geometry.h:87-142, 197-245 (getValidOutPosTranspose, getIndicePairsDeConv)
 //   pcdet/ops/spconv/include/spconv/geometry.h:248-297 (getIndicePairsSubM)
 //   pcdet/ops/spconv/include/spconv/spconv_ops.h:27-141 (getIndicePair: shapes, subM forces s=1,p=k/2)
 // with a different data structure: instead of the dense `gridOut[batch*volume]` (371 MB memset at
@@ -14,7 +15,9 @@
 // Pair (j, k): out position o_d = (in_d + pad_d - k_d*dil_d) / stride_d when divisible and in
 // range; kernel offset id k = (kz*KY + ky)*KX + kx. For a fixed input the reference enumerates
 // valid outputs in ascending k, so the first-encounter order of output voxels is the order of
-// min(j*KV + k) over the emissions that hit them.
+// min(j*KV + k) over the emissions that hit them. Transposed conv: o_d = in_d*stride_d - pad_d + k_d*dil_d
+// when in range; the reference walks a fixed input's footprint from `uppers` downward, i.e. in
+// DESCENDING k, so there the first-encounter order is the order of min(j*KV + (KV - 1 - k)).
 #include "pcs_common.hpp"
 
 namespace pcs {
@@ -25,6 +28,7 @@ struct ConvGeom {
   int ks[3], st[3], pd[3], dl[3];
   int in_shape[3], out_shape[3];
   int kv;
+  int transpose;
 };
 
 __device__ __forceinline__ uint32_t table_find(const uint64_t* __restrict__ keys, uint32_t hmask,
@@ -63,10 +67,16 @@ __device__ __forceinline__ uint64_t out_key(const ConvGeom& g, int4 c, int k) {
   int o[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    int num = in[d] + g.pd[d] - kk[d] * g.dl[d];
-    if (num < 0) return kEmptyKey;
-    int q = num / g.st[d];
-    if (q * g.st[d] != num) return kEmptyKey;
+    int q;
+    if (g.transpose) {
+      q = in[d] * g.st[d] - g.pd[d] + kk[d] * g.dl[d];
+      if (q < 0) return kEmptyKey;
+    } else {
+      int num = in[d] + g.pd[d] - kk[d] * g.dl[d];
+      if (num < 0) return kEmptyKey;
+      q = num / g.st[d];
+      if (q * g.st[d] != num) return kEmptyKey;
+    }
     if (q >= g.out_shape[d]) return kEmptyKey;
     o[d] = q;
   }
@@ -100,7 +110,7 @@ insert_outputs_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t*
     if (key == kEmptyKey) continue;
     bool claimed = false;
     uint32_t slot = table_insert(keys, hmask, key, &claimed);
-    atomicMin(&minseq[slot], (uint32_t)j * (uint32_t)g.kv + (uint32_t)k);
+    atomicMin(&minseq[slot], (uint32_t)j * (uint32_t)g.kv + (uint32_t)(g.transpose ? g.kv - 1 - k : k));
     // the claimer lists the slot (order irrelevant: sorted by minseq afterwards), so the 16 V-slot
     // table never has to be scanned for its occupied entries
     if (claimed) lslot[atomicAdd(counter, 1)] = (int32_t)slot;
@@ -295,9 +305,9 @@ struct RulebookPlan {
   int nblocks;
 };
 
-static int64_t emissions_per_input(const int* ks, const int* st) {
+static int64_t emissions_per_input(const int* ks, const int* st, int transpose = 0) {
   int64_t e = 1;
-  for (int d = 0; d < 3; ++d) e *= (ks[d] + st[d] - 1) / st[d];
+  for (int d = 0; d < 3; ++d) e *= transpose ? ks[d] : (ks[d] + st[d] - 1) / st[d];
   return e;
 }
 
@@ -335,10 +345,11 @@ using namespace pcs;
 extern "C" {
 
 // upper bound on the number of output voxels of a strided conv over V inputs (rows to allocate
-// for out_ids); for subM the outputs are the inputs.
+// for out_ids); for subM the outputs are the inputs. `subm`: 0 strided, 1 submanifold, 2 TRANSPOSED
+// conv (every input emits its whole kernel footprint).
 int64_t pcs_indice_pairs_out_capacity(int64_t V, const int* ksize3, const int* stride3, int subm) {
-  if (subm) return V;
-  return V * emissions_per_input(ksize3, stride3);
+  if (subm == 1) return V;
+  return V * emissions_per_input(ksize3, stride3, subm == 2);
 }
 
 size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const int* stride3,
@@ -346,7 +357,7 @@ size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const 
   Arena a(nullptr, 0);
   RulebookPlan p;
   int kv = ksize3[0] * ksize3[1] * ksize3[2];
-  plan_rulebook(a, V, kv, subm, pcs_indice_pairs_out_capacity(V > 0 ? V : 1, ksize3, stride3, subm), p);
+  plan_rulebook(a, V, kv, subm == 1, pcs_indice_pairs_out_capacity(V > 0 ? V : 1, ksize3, stride3, subm), p);
   return a.off;
 }
 
@@ -358,9 +369,10 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
   if (!out_shape3 || !spatial_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 || !num ||
       !d_num_out || !ws || V < 0 || batch < 1 || (V > 0 && (!indices || !pairs)))
     return PCS_ERR_ARG;
-  if (transpose) return PCS_ERR_ARG;  // deconv rulebooks: SURVEY 8(f) "next", not built yet
+  if (transpose && subm) return PCS_ERR_ARG;
   ConvGeom g;
   g.kv = 1;
+  g.transpose = transpose ? 1 : 0;
   for (int d = 0; d < 3; ++d) {
     g.ks[d] = ksize3[d];
     g.dl[d] = dil3[d];
@@ -381,7 +393,7 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
     PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s));
     return PCS_OK;
   }
-  int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, subm);
+  int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, transpose ? 2 : (subm ? 1 : 0));
   if (!subm && (!out_ids || out_cap < cap)) return PCS_ERR_ARG;
   Arena a(ws, ws_bytes);
   RulebookPlan p;

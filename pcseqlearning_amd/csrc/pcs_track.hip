@@ -10,49 +10,47 @@
 // loss reduced through LDS; a second elementwise kernel applies the same sequence of decoupled
 // weight-decay factors to the elements that never see a gradient.
 #include "pcs_common.hpp"
-#include <mutex>
-#include <chrono>
-#include <cstdio>
 
 namespace pcs {
-
-// Kernels with a grid-wide barrier need every workgroup of the launch resident at once.  Two such
-// launches from different host threads (sequences of a batch in flight) can each take part of the
-// chip and wait for the rest for ever, so they are issued one at a time, process-wide, and the
-// holder waits for its launch before the next may start.
-static std::mutex& sv_grid_mutex() {
-  static std::mutex* mu = new std::mutex();
-  return *mu;
-}
-// Every tracker tick passes this gate before it enqueues anything: while a grid-barrier launch is in
-// flight the other lock-step groups / sequences hold back their next tick, so the launch meets an
-// emptying chip. Without it the 1024-thread workgroups of the barrier kernel could wait for a whole
-// free CU for tens of seconds while the 256-thread workgroups of the other chains kept slipping into
-// every gap (seen as 25-70 s steps, "[pcs] smooth_velo multi-workgroup launch drained after 42.5 s").
-void sv_grid_gate() {
-  std::lock_guard<std::mutex> lk(sv_grid_mutex());
-}
 
 struct SmoothState {
   int iters;
   float last_loss;
 };
-struct SmoothGrid;
+
+// ---- geometry of the multi-workgroup form (see sv2_body)
+constexpr int SV2_BLOCK = 256;     // threads per workgroup
+constexpr int SV2_ELEMS = 4;       // in-range elements per thread
+constexpr int SV2_WINDOW = 64;     // AdamW steps per launch of the window pass
+constexpr int SV2_MAX_BLOCKS = 4096;
+constexpr int SV_MAX_ITR = 512;
+constexpr int SV2_MAX_WINDOWS = SV_MAX_ITR / SV2_WINDOW;
+
+// stop-rule state of one multi-workgroup problem, carried from window to window
+struct SmoothWin {
+  unsigned int arrive[SV2_MAX_WINDOWS];  // workgroups that have finished window w
+  int decided;      // the stop rule has fired, or num_itr steps are done: iters is final
+  int stop_window;  // the window in which that happened
+  int countdown;
+  float last_loss;
+};
+
 // one smooth_velo problem of a batched launch (the sequence tracker, pcs_tracker.hip)
 struct SvJob {
   float* v;
   const float* d;
   SmoothState* st;
-  SmoothGrid* grid;
-  float *m, *sq;
-  int* err;
-  int C, F, a, b, cpb, blocks, kind;  // kind 0: LDS-resident, 1: multi-workgroup, 2: generic
+  SmoothWin* win;
+  double* partial;  // [SV2_WINDOW, blocks] per-workgroup loss terms of the current window
+  float* buf;       // kind 1: checkpoints [2][3][C * nf * 2]; kind 2: Adam moments m, sq [C * F * 2] each
+  int C, F, a, b, cpb, blocks, kind;  // kind 0: one workgroup, LDS-resident, 1: multi-workgroup, 2: generic
 };
-constexpr int kSvMaxBatch = 32;
+constexpr int kSvMaxBatch = 48;  // jobs per launch (the list travels by value: 80 B each, < 4 KB of kernarg)
 struct SvBatch {
   int n;
   SvJob j[kSvMaxBatch];
 };
+static_assert(sizeof(SvBatch) <= 3900, "smooth_velo job list must fit the kernel-argument segment");
 
 // MultiStepLR([100, 200, 300], gamma 0.1); the optimiser forms its scalars in double (Python
 // floats) and hands them to fp32 tensor ops
@@ -167,7 +165,6 @@ smooth_velo_body(float* __restrict__ v, const float* __restrict__ d, int C, int 
 // elements per thread), the per-step scalars tabulated once. Identical arithmetic and the same
 // element -> thread map / reduction tree as smooth_velo_kernel; used when the in-range elements fit.
 constexpr int SV_ELEMS = 8;
-constexpr int SV_MAX_ITR = 512;
 
 __device__ __forceinline__ void
 smooth_velo_lds_body(float* __restrict__ sv /* LDS [n_in] current iterate */, float* __restrict__ v,
@@ -274,154 +271,193 @@ smooth_velo_lds_body(float* __restrict__ sv /* LDS [n_in] current iterate */, fl
   if (tid == 0) { st->iters = it; st->last_loss = last_loss; }
 }
 
-// Many components (thousands of small clusters): the same loop spread over up to SV_MAX_BLOCKS
+// Many components (thousands of small clusters): the same loop spread over many 256-thread
 // workgroups, each owning a contiguous range of components (so the t +- 1 neighbours stay local) with
-// its slice of v in LDS. The only coupling is the scalar loss of the 3-strike stop rule: one f64
-// partial per workgroup and ONE grid barrier per step (arrival counter that only grows; partials
-// double-buffered by step parity). All workgroups evaluate the same stop rule on the same sum, so
-// they leave together. The grid is at most 64 x 1024 threads (a quarter of what the device keeps
-// resident: one such workgroup per CU), the host sends one such launch at a time, and the barrier
-// wait is bounded: on time-out the problem's time-out word is set, every wave exits without writing
-// anything back, and the host runs the problem again in the generic single-workgroup form.
-constexpr int SV_MAX_BLOCKS = 64;
-// polls of the barrier before a workgroup gives up (1-3 us each: two agent-scope loads and a sleep,
-// so 0.13-0.4 s; a barrier that all workgroups reach takes microseconds). 1 << 24 let a launch that
-// could not get its workgroups resident hold the whole process for 40-70 s.
-constexpr int kSvSpinMax = 1 << 17;
-struct SmoothGrid {
-  unsigned int arrive;
-  int timeout;
-  double partial[2][SV_MAX_BLOCKS];
-};
-
+// its slice of the iterate in LDS. The ONLY coupling between workgroups is the scalar loss of the
+// 3-strike stop rule, and the trajectory of the iterate does not depend on when the rule fires. So
+// no workgroup ever waits for another one:
+//   window pass (sv2_body<false>, one launch per window of SV2_WINDOW steps): every workgroup runs the
+//     window's steps on its slice, stores its loss term of each step (f64) in partial[step][workgroup]
+//     and leaves its state (iterate + Adam moments) in a checkpoint, double-buffered by window parity.
+//     The workgroup that arrives LAST (arrival counter; nobody polls it) sums the terms of every step
+//     in workgroup order and walks the stop rule through the window; when it fires (or num_itr is
+//     reached) it stores the final step count. The launches of later windows find `decided` and return.
+//   replay (sv2_body<true>, one launch): every workgroup restarts from the checkpoint BEFORE the window
+//     in which the rule fired, repeats exactly the steps up to the stop, and writes its slice back.
+// Same arithmetic per element as the one-workgroup forms; the loss of a step is the sum of the
+// workgroups' terms in workgroup order whichever workgroup happens to add them up.
+template <bool REPLAY>
 __device__ __forceinline__ void
-smooth_velo_grid_body(float* __restrict__ sv /* LDS: this workgroup's slice of the iterate */, int bx, int B,
-                      float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                      float weight0, float weight, int num_itr, float stopping, int cpb,
-                      SmoothGrid* __restrict__ g, SmoothState* __restrict__ st, int* __restrict__ err) {
-  __shared__ double red[SV_BLOCK / 64];
-  __shared__ float t_step[SV_MAX_ITR], t_bc2[SV_MAX_ITR], t_decay[SV_MAX_ITR];
-  __shared__ int stop_flag;
-  const int nf = b - a + 1;
-  const int c0 = bx * cpb;
-  const int c1 = min(C, c0 + cpb);
+sv2_body(float* __restrict__ sv /* LDS [SV2_BLOCK * SV2_ELEMS] */, const SvJob& j, int bx, int w, float weight0,
+         float weight, int num_itr, float stopping) {
+  __shared__ double red[SV2_BLOCK / 64];
+  __shared__ double losses[SV2_WINDOW];
+  __shared__ float t_step[SV2_WINDOW], t_bc2[SV2_WINDOW], t_decay[SV2_WINDOW];
+  __shared__ int is_last;
+  SmoothWin* __restrict__ win = j.win;
+  int it0, it1;
+  if (REPLAY) {
+    w = win->stop_window;
+    it0 = w * SV2_WINDOW;
+    it1 = j.st->iters;
+  } else {
+    if (win->decided) return;  // (written by an earlier launch: the same for every workgroup)
+    it0 = w * SV2_WINDOW;
+    it1 = min(num_itr, it0 + SV2_WINDOW);
+  }
+  const int B = j.blocks;
+  const int nf = j.b - j.a + 1;
+  const int c0 = bx * j.cpb;
+  const int c1 = min(j.C, c0 + j.cpb);
   const int n_loc = (c1 - c0) * nf * 2;
-  const float inv_fit = 1.0f / (float)(C * nf * 2);
-  const float inv_sm = 1.0f / (float)(C * (nf - 1) * 2);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  float last_loss = 1e10f;
-  int countdown = 3;
-  float de[SV_ELEMS], me[SV_ELEMS], se[SV_ELEMS];
-  int tpos[SV_ELEMS];
+  const int64_t n_tot = (int64_t)j.C * nf * 2;
+  const int64_t g0 = (int64_t)c0 * nf * 2;
+  const float inv_fit = 1.0f / (float)(j.C * nf * 2);
+  const float inv_sm = 1.0f / (float)(j.C * (nf - 1) * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* __restrict__ ck_in = j.buf + (size_t)((w + 1) & 1) * 3 * n_tot;  // what window w - 1 left
+  float* __restrict__ ck_out = j.buf + (size_t)(w & 1) * 3 * n_tot;
+  float de[SV2_ELEMS], me[SV2_ELEMS], se[SV2_ELEMS];
+  int tpos[SV2_ELEMS];  // 0: interior, bit0: first frame of the range, bit1: last frame
 #pragma unroll
-  for (int j = 0; j < SV_ELEMS; ++j) {
-    int e = tid + j * SV_BLOCK;
-    de[j] = 0.f; me[j] = 0.f; se[j] = 0.f; tpos[j] = 0;
+  for (int q = 0; q < SV2_ELEMS; ++q) {
+    int e = tid + q * SV2_BLOCK;
+    de[q] = 0.f; me[q] = 0.f; se[q] = 0.f; tpos[q] = 0;
     if (e < n_loc) {
       int k = e & 1;
       int t = (e >> 1) % nf;
       int c = c0 + (e >> 1) / nf;
-      int64_t at = ((int64_t)c * F + (a + t)) * 3 + k;
-      sv[e] = v[at];
-      de[j] = d[at];
-      tpos[j] = (t == 0 ? 1 : 0) | (t == nf - 1 ? 2 : 0);
+      int64_t at = ((int64_t)c * j.F + (j.a + t)) * 3 + k;
+      de[q] = j.d[at];
+      tpos[q] = (t == 0 ? 1 : 0) | (t == nf - 1 ? 2 : 0);
+      if (w == 0) {
+        sv[e] = j.v[at];
+      } else {
+        sv[e] = ck_in[g0 + e];
+        me[q] = ck_in[n_tot + g0 + e];
+        se[q] = ck_in[2 * n_tot + g0 + e];
+      }
     }
   }
-  for (int it = tid; it < num_itr; it += SV_BLOCK) {
+  for (int q = tid; q < it1 - it0; q += SV2_BLOCK) {
+    const int it = it0 + q;
     double lr = lr_at(it);
     double bc1 = 1.0 - pow(0.9, (double)(it + 1));
     double bc2 = 1.0 - pow(0.999, (double)(it + 1));
-    t_step[it] = (float)(lr / bc1);
-    t_bc2[it] = (float)sqrt(bc2);
-    t_decay[it] = (float)(1.0 - lr * 1e-2);
+    t_step[q] = (float)(lr / bc1);
+    t_bc2[q] = (float)sqrt(bc2);
+    t_decay[q] = (float)(1.0 - lr * 1e-2);
   }
-  if (tid == 0) stop_flag = 0;
   __syncthreads();
-  int it = 0;
-  for (; it < num_itr; ++it) {
+  for (int it = it0; it < it1; ++it) {
     double part = 0.0;
-    float gr[SV_ELEMS];
+    float gr[SV2_ELEMS];
 #pragma unroll
-    for (int j = 0; j < SV_ELEMS; ++j) {
-      int e = tid + j * SV_BLOCK;
-      gr[j] = 0.f;
+    for (int q = 0; q < SV2_ELEMS; ++q) {
+      int e = tid + q * SV2_BLOCK;
+      gr[q] = 0.f;
       if (e < n_loc) {
         float x = sv[e];
-        float r = x - de[j];
-        part += (double)(r * r) * inv_fit * weight0;
+        float r = x - de[q];
+        if (!REPLAY) part += (double)(r * r) * inv_fit * weight0;
         float gj = r * 2.f * (inv_fit * weight0);
-        if (!(tpos[j] & 2)) {
+        if (!(tpos[q] & 2)) {
           float y = x - sv[e + 2];
-          part += (double)fabsf(y) * inv_sm * weight;
+          if (!REPLAY) part += (double)fabsf(y) * inv_sm * weight;
           gj += (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
         }
-        if (!(tpos[j] & 1)) {
+        if (!(tpos[q] & 1)) {
           float y = sv[e - 2] - x;
           gj -= (y > 0.f ? 1.f : (y < 0.f ? -1.f : 0.f)) * (inv_sm * weight);
         }
-        gr[j] = gj;
+        gr[q] = gj;
       }
     }
-    part = wave_sum_f64(part);
-    if (lane == 0) red[w] = part;
+    if (!REPLAY) {
+      part = wave_sum_f64(part);
+      if (lane == 0) red[wv] = part;
+    }
     __syncthreads();  // partial sums visible; every read of the old iterate is done
-    if (tid == 0) {
+    if (!REPLAY && tid == 0) {
       double tot = 0.0;
-      for (int q = 0; q < SV_BLOCK / 64; ++q) tot += red[q];
-      __hip_atomic_store(&g->partial[it & 1][bx], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&g->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < SV2_BLOCK / 64; ++q) tot += red[q];
+      __hip_atomic_store(&j.partial[(size_t)(it - it0) * B + bx], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const float step_size = t_step[it], bc2_sqrt = t_bc2[it], decay = t_decay[it];
+    const float step_size = t_step[it - it0], bc2_sqrt = t_bc2[it - it0], decay = t_decay[it - it0];
 #pragma unroll
-    for (int j = 0; j < SV_ELEMS; ++j) {
-      int e = tid + j * SV_BLOCK;
+    for (int q = 0; q < SV2_ELEMS; ++q) {
+      int e = tid + q * SV2_BLOCK;
       if (e < n_loc) {
-        me[j] = me[j] + 0.1f * (gr[j] - me[j]);
-        se[j] = se[j] * 0.999f + 0.001f * gr[j] * gr[j];
+        me[q] = me[q] + 0.1f * (gr[q] - me[q]);
+        se[q] = se[q] * 0.999f + 0.001f * gr[q] * gr[q];
         float x = sv[e] * decay;
-        float denom = sqrtf(se[j]) / bc2_sqrt + 1e-8f;
-        sv[e] = x - step_size * (me[j] / denom);
-      }
-    }
-    if (tid == 0) {
-      const unsigned target = (unsigned)(it + 1) * (unsigned)B;
-      bool ok = false;
-      for (int spin = 0; spin < kSvSpinMax; ++spin) {
-        if (__hip_atomic_load(&g->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
-        if (__hip_atomic_load(&g->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!ok) {
-        // the host sees the word after the launch has drained and runs the problem again in the
-        // single-workgroup form (nothing of this attempt is written back)
-        __hip_atomic_store(&g->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stop_flag = 2;
-      } else {
-        double tot = 0.0;
-        for (int q = 0; q < B; ++q)
-          tot += __hip_atomic_load(&g->partial[it & 1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float loss = (float)tot;
-        if (last_loss - loss < stopping) countdown -= 1;
-        else countdown = 3;
-        if (countdown <= 0) stop_flag = 1;
-        else last_loss = loss;
+        float denom = sqrtf(se[q]) / bc2_sqrt + 1e-8f;
+        sv[e] = x - step_size * (me[q] / denom);
       }
     }
     __syncthreads();
-    if (stop_flag) { ++it; break; }
   }
-  if (stop_flag == 2) return;  // barrier time-out: v keeps the input
+  if (REPLAY) {
 #pragma unroll
-  for (int j = 0; j < SV_ELEMS; ++j) {
-    int e = tid + j * SV_BLOCK;
+    for (int q = 0; q < SV2_ELEMS; ++q) {
+      int e = tid + q * SV2_BLOCK;
+      if (e < n_loc) {
+        int k = e & 1;
+        int t = (e >> 1) % nf;
+        int c = c0 + (e >> 1) / nf;
+        j.v[((int64_t)c * j.F + (j.a + t)) * 3 + k] = sv[e];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < SV2_ELEMS; ++q) {
+    int e = tid + q * SV2_BLOCK;
     if (e < n_loc) {
-      int k = e & 1;
-      int t = (e >> 1) % nf;
-      int c = c0 + (e >> 1) / nf;
-      v[((int64_t)c * F + (a + t)) * 3 + k] = sv[e];
+      ck_out[g0 + e] = sv[e];
+      ck_out[n_tot + g0 + e] = me[q];
+      ck_out[2 * n_tot + g0 + e] = se[q];
     }
   }
-  if (bx == 0 && tid == 0) { st->iters = it; st->last_loss = last_loss; }
+  // the workgroup that arrives last walks the stop rule through the window (thread 0 wrote this
+  // workgroup's terms itself, so its release covers them; nobody waits for anybody)
+  if (tid == 0) {
+    unsigned old = __hip_atomic_fetch_add(&win->arrive[w], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (old == (unsigned)(B - 1));
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int n = it1 - it0;
+  for (int q = tid; q < n; q += SV2_BLOCK) {
+    double tot = 0.0;
+    for (int p = 0; p < B; ++p)
+      tot += __hip_atomic_load(&j.partial[(size_t)q * B + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    losses[q] = tot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float last_loss = w == 0 ? 1e10f : win->last_loss;
+    int countdown = w == 0 ? 3 : win->countdown;
+    int stop_at = -1;
+    for (int q = 0; q < n; ++q) {
+      float loss = (float)losses[q];
+      if (last_loss - loss < stopping) countdown -= 1;
+      else countdown = 3;
+      if (countdown <= 0) { stop_at = it0 + q + 1; break; }
+      last_loss = loss;
+    }
+    if (stop_at < 0 && it1 == num_itr) stop_at = num_itr;
+    if (stop_at >= 0) {
+      j.st->iters = stop_at;
+      j.st->last_loss = last_loss;
+      win->stop_window = w;
+      win->decided = 1;
+    } else {
+      win->last_loss = last_loss;
+      win->countdown = countdown;
+    }
+  }
 }
 
 // elements outside (c, [a,b], {0,1}) only see the decoupled weight decay of every executed step
@@ -440,59 +476,40 @@ smooth_velo_decay_body(float* __restrict__ v, int64_t total, int F, int a, int b
   }
 }
 
-// ---- single-problem launches (pcs_smooth_velo) and batched launches (the sequence tracker: one
-//      entry per tracking unit, blockIdx.y = entry) of the same bodies
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                   float weight0, float weight, int num_itr, float stopping,
-                   float* __restrict__ m, float* __restrict__ s, SmoothState* __restrict__ st) {
-  smooth_velo_body(v, d, C, F, a, b, weight0, weight, num_itr, stopping, m, s, st);
-}
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_lds_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                       float weight0, float weight, int num_itr, float stopping,
-                       SmoothState* __restrict__ st) {
-  extern __shared__ float sv_dyn[];
-  smooth_velo_lds_body(sv_dyn, v, d, C, F, a, b, weight0, weight, num_itr, stopping, st);
-}
-__global__ void __launch_bounds__(SV_BLOCK)
-smooth_velo_grid_kernel(float* __restrict__ v, const float* __restrict__ d, int C, int F, int a, int b,
-                        float weight0, float weight, int num_itr, float stopping, int cpb,
-                        SmoothGrid* __restrict__ g, SmoothState* __restrict__ st,
-                        int* __restrict__ err) {
-  extern __shared__ float sv_dyn[];
-  smooth_velo_grid_body(sv_dyn, blockIdx.x, gridDim.x, v, d, C, F, a, b, weight0, weight, num_itr, stopping,
-                        cpb, g, st, err);
-}
-__global__ void __launch_bounds__(kBlock)
-smooth_velo_decay_kernel(float* __restrict__ v, int64_t total, int F, int a, int b,
-                         const SmoothState* __restrict__ st) {
-  smooth_velo_decay_body(v, total, F, a, b, st);
-}
-
+// ---- batched launches (blockIdx.y = problem; pcs_smooth_velo is a batch of one)
 __global__ void __launch_bounds__(SV_BLOCK)
 smooth_velo_batch_kernel(SvBatch sb, int kind, float weight0, float weight, int num_itr, float stopping) {
   extern __shared__ float sv_dyn[];
   const SvJob& j = sb.j[blockIdx.y];
   if (j.kind != kind) return;
-  if (kind == 0) {
-    if (blockIdx.x == 0)
-      smooth_velo_lds_body(sv_dyn, j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.st);
-  } else if (kind == 1) {
-    if ((int)blockIdx.x < j.blocks)
-      smooth_velo_grid_body(sv_dyn, blockIdx.x, j.blocks, j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr,
-                            stopping, j.cpb, j.grid, j.st, j.err);
-  } else {
-    if (blockIdx.x == 0)
-      smooth_velo_body(j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.m, j.sq, j.st);
-  }
+  if (kind == 0)
+    smooth_velo_lds_body(sv_dyn, j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.st);
+  else
+    smooth_velo_body(j.v, j.d, j.C, j.F, j.a, j.b, weight0, weight, num_itr, stopping, j.buf,
+                     j.buf + (size_t)j.C * j.F * 2, j.st);
 }
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(SV2_BLOCK)
+smooth_velo_window_kernel(SvBatch sb, int w, float weight0, float weight, int num_itr, float stopping) {
+  __shared__ float sv[SV2_BLOCK * SV2_ELEMS];
+  const SvJob& j = sb.j[blockIdx.y];
+  if (j.kind != 1 || (int)blockIdx.x >= j.blocks) return;
+  sv2_body<false>(sv, j, blockIdx.x, w, weight0, weight, num_itr, stopping);
+}
+__global__ void __launch_bounds__(SV2_BLOCK)
+smooth_velo_replay_kernel(SvBatch sb, float weight0, float weight, int num_itr, float stopping) {
+  __shared__ float sv[SV2_BLOCK * SV2_ELEMS];
+  const SvJob& j = sb.j[blockIdx.y];
+  if (j.kind != 1 || (int)blockIdx.x >= j.blocks) return;
+  sv2_body<true>(sv, j, blockIdx.x, 0, weight0, weight, num_itr, stopping);
+}
+__global__ void __launch_bounds__(64)
 smooth_velo_batch_reset_kernel(SvBatch sb) {
   const SvJob& j = sb.j[blockIdx.x];
-  if (threadIdx.x == 0) {  // (every kind: the time-out word is read back whatever form the problem took)
-    j.grid->arrive = 0;
-    j.grid->timeout = 0;
+  if (threadIdx.x < SV2_MAX_WINDOWS) j.win->arrive[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) {
+    j.win->decided = 0;
+    j.win->stop_window = 0;
+    j.st->iters = 0;
   }
 }
 __global__ void __launch_bounds__(kBlock)
@@ -1092,188 +1109,101 @@ points_in_frame_boxes_kernel(const float* __restrict__ pts, const int64_t* __res
   }
 }
 
-// comp_velos [C,F,3] f32 updated in place; comp_center_diffs [C,F,3]. frame_lo <= frame_hi are the
-// ordered ends of the optimised range (the reference swaps them itself when tracking backwards).
-// `err` (optional device word) is set to 3 if the multi-workgroup form timed out at its barrier.
-int smooth_velo_run(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo,
-                    int frame_hi, float weight0, float weight, int num_itr, float stopping, void* ws,
-                    size_t ws_bytes, int* err, hipStream_t s) {
-  if (!comp_velos || !comp_center_diffs || !ws || C < 1 || F < 1 || frame_lo < 0 ||
-      frame_hi >= F || frame_lo > frame_hi || num_itr < 0)
-    return PCS_ERR_ARG;
-  if (frame_lo == frame_hi) return PCS_OK;  // cluster_tracking.py:166-167
-  if (C * (int64_t)F * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
-  Arena a(ws, ws_bytes);
-  SmoothState* st = a.take<SmoothState>(1);
-  SmoothGrid* grid = a.take<SmoothGrid>(1);
-  float* m = a.take<float>((size_t)C * F * 2);
-  float* sq = a.take<float>((size_t)C * F * 2);
-  if (!a.ok()) return PCS_ERR_WORKSPACE;
-  const int nf = frame_hi - frame_lo + 1;
-  int64_t n_in = C * (int64_t)nf * 2;
-  const int cpb = (SV_BLOCK * SV_ELEMS) / (nf * 2);  // components per workgroup
-  const int64_t blocks = cpb > 0 ? (C + cpb - 1) / cpb : (int64_t)SV_MAX_BLOCKS + 1;
-  if (n_in <= (int64_t)SV_BLOCK * SV_ELEMS && num_itr <= SV_MAX_ITR) {
-    smooth_velo_lds_kernel<<<1, SV_BLOCK, (size_t)n_in * sizeof(float), s>>>(
-        comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
-        stopping, st);
-  } else if (blocks <= SV_MAX_BLOCKS && num_itr <= SV_MAX_ITR) {
-    std::lock_guard<std::mutex> lk(sv_grid_mutex());  // one grid-barrier launch at a time (see smooth_velo_run_batch)
-    PCS_CHECK_HIP(hipMemsetAsync(grid, 0, sizeof(SmoothGrid), s));
-    smooth_velo_grid_kernel<<<(int)blocks, SV_BLOCK, (size_t)cpb * nf * 2 * sizeof(float), s>>>(
-        comp_velos, comp_center_diffs, (int)C, F, frame_lo, frame_hi, weight0, weight, num_itr,
-        stopping, cpb, grid, st, err);
-    PCS_CHECK_HIP(hipStreamSynchronize(s));
-    int timed_out = 0;
-    PCS_CHECK_HIP(hipMemcpy(&timed_out, &grid->timeout, sizeof(int), hipMemcpyDeviceToHost));
-    if (timed_out) {  // nothing was written back: the generic single-workgroup form instead
-      fprintf(stderr, "[pcs] smooth_velo: the grid barrier timed out; single-workgroup form instead\n");
-      smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
-                                                frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
-    }
-  } else {
-    smooth_velo_kernel<<<1, SV_BLOCK, 0, s>>>(comp_velos, comp_center_diffs, (int)C, F, frame_lo,
-                                              frame_hi, weight0, weight, num_itr, stopping, m, sq, st);
-  }
-  smooth_velo_decay_kernel<<<grid_for(C * (int64_t)F * 3), kBlock, 0, s>>>(
-      comp_velos, C * (int64_t)F * 3, F, frame_lo, frame_hi, st);
-  PCS_LAUNCH_CHECK();
-  return PCS_OK;
+// workspace of one problem
+struct SvWs {
+  SmoothState* st;
+  SmoothWin* win;
+  double* partial;
+  float* buf;
+};
+static inline int64_t sv2_max_blocks(int64_t C, int F) {
+  const int per = SV2_BLOCK * SV2_ELEMS / (2 * (F < 2 ? 2 : F));  // components per workgroup at the longest range
+  if (per < 1) return 1;
+  int64_t b = (C + per - 1) / per;
+  return b > SV2_MAX_BLOCKS ? 1 : b;
+}
+static bool sv_plan(Arena& a, int64_t C, int F, SvWs& w) {
+  w.st = a.take<SmoothState>(1);
+  w.win = a.take<SmoothWin>(1);
+  w.partial = a.take<double>((size_t)SV2_WINDOW * sv2_max_blocks(C, F));
+  w.buf = a.take<float>((size_t)C * F * 2 * 6);  // two checkpoints of (iterate, m, sq), or the generic form's moments
+  return a.ok();
 }
 
 // The same for several problems at once (one per tracking unit; every problem takes the kernel form
 // and geometry pcs_smooth_velo would give it, so the results are those of separate calls).
+// comp_velos[e] [C,F,3] f32 updated in place; comp_center_diffs[e] [C,F,3]. frame_lo <= frame_hi are the
+// ordered ends of the optimised range (the reference swaps them itself when tracking backwards).
 // ws[e] / ws_bytes[e]: each problem's own workspace (pcs_smooth_velo_workspace_bytes).
+// Nothing here waits for the device or for another host thread.
 int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
                           const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
                           float weight0, float weight, int num_itr, float stopping, void* const* ws,
-                          const size_t* ws_bytes, int* const* err, hipStream_t s) {
+                          const size_t* ws_bytes, hipStream_t s) {
   if (n < 1) return PCS_OK;
-  if (n > kSvMaxBatch) return PCS_ERR_ARG;
-  SvBatch sb;
-  sb.n = 0;
-  size_t lds[3] = {0, 0, 0};
-  int nblk[3] = {0, 0, 0}, have[3] = {0, 0, 0};
-  int64_t tot_max = 1;
-  for (int e = 0; e < n; ++e) {
-    if (!comp_velos[e] || !comp_center_diffs[e] || !ws[e] || C[e] < 1 || F[e] < 1 || frame_lo[e] < 0 ||
-        frame_hi[e] >= F[e] || frame_lo[e] > frame_hi[e] || num_itr < 0)
-      return PCS_ERR_ARG;
-    if (frame_lo[e] == frame_hi[e]) continue;  // cluster_tracking.py:166-167
-    if (C[e] * (int64_t)F[e] * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
-    Arena a(ws[e], ws_bytes[e]);
-    SvJob& j = sb.j[sb.n];
-    j.st = a.take<SmoothState>(1);
-    j.grid = a.take<SmoothGrid>(1);
-    j.m = a.take<float>((size_t)C[e] * F[e] * 2);
-    j.sq = a.take<float>((size_t)C[e] * F[e] * 2);
-    if (!a.ok()) return PCS_ERR_WORKSPACE;
-    j.v = comp_velos[e];
-    j.d = comp_center_diffs[e];
-    j.err = err ? err[e] : nullptr;
-    j.C = (int)C[e];
-    j.F = F[e];
-    j.a = frame_lo[e];
-    j.b = frame_hi[e];
-    const int nf = frame_hi[e] - frame_lo[e] + 1;
-    int64_t n_in = C[e] * (int64_t)nf * 2;
-    j.cpb = (SV_BLOCK * SV_ELEMS) / (nf * 2);
-    const int64_t blocks = j.cpb > 0 ? (C[e] + j.cpb - 1) / j.cpb : (int64_t)SV_MAX_BLOCKS + 1;
-    j.blocks = 1;
-    size_t need = 0;
-    if (n_in <= (int64_t)SV_BLOCK * SV_ELEMS && num_itr <= SV_MAX_ITR) {
-      j.kind = 0;
-      need = (size_t)n_in * sizeof(float);
-    } else if (blocks <= SV_MAX_BLOCKS && num_itr <= SV_MAX_ITR) {
-      j.kind = 1;
-      j.blocks = (int)blocks;
-      need = (size_t)j.cpb * nf * 2 * sizeof(float);
-    } else {
-      j.kind = 2;
+  if (num_itr < 0) return PCS_ERR_ARG;
+  for (int e0 = 0; e0 < n; e0 += kSvMaxBatch) {
+    const int e1 = e0 + kSvMaxBatch < n ? e0 + kSvMaxBatch : n;
+    SvBatch sb;
+    sb.n = 0;
+    size_t lds0 = 0;
+    int have[3] = {0, 0, 0}, blocks1 = 1;
+    int64_t tot_max = 1;
+    for (int e = e0; e < e1; ++e) {
+      if (!comp_velos[e] || !comp_center_diffs[e] || !ws[e] || C[e] < 1 || F[e] < 1 || frame_lo[e] < 0 ||
+          frame_hi[e] >= F[e] || frame_lo[e] > frame_hi[e])
+        return PCS_ERR_ARG;
+      if (frame_lo[e] == frame_hi[e] || num_itr == 0) continue;  // cluster_tracking.py:166-167
+      if (C[e] * (int64_t)F[e] * 3 >= (1LL << 31)) return PCS_ERR_RANGE;
+      Arena a(ws[e], ws_bytes[e]);
+      SvWs w;
+      if (!sv_plan(a, C[e], F[e], w)) return PCS_ERR_WORKSPACE;
+      SvJob& j = sb.j[sb.n];
+      j.st = w.st;
+      j.win = w.win;
+      j.partial = w.partial;
+      j.buf = w.buf;
+      j.v = comp_velos[e];
+      j.d = comp_center_diffs[e];
+      j.C = (int)C[e];
+      j.F = F[e];
+      j.a = frame_lo[e];
+      j.b = frame_hi[e];
+      const int nf = frame_hi[e] - frame_lo[e] + 1;
+      const int64_t n_in = C[e] * (int64_t)nf * 2;
+      j.cpb = (SV2_BLOCK * SV2_ELEMS) / (nf * 2);
+      const int64_t blocks = j.cpb > 0 ? (C[e] + j.cpb - 1) / j.cpb : (int64_t)SV2_MAX_BLOCKS + 1;
+      j.blocks = 1;
+      if (n_in <= (int64_t)SV_BLOCK * SV_ELEMS && num_itr <= SV_MAX_ITR) {
+        j.kind = 0;
+        if ((size_t)n_in * sizeof(float) > lds0) lds0 = (size_t)n_in * sizeof(float);
+      } else if (blocks <= SV2_MAX_BLOCKS && blocks <= sv2_max_blocks(C[e], F[e]) && num_itr <= SV_MAX_ITR) {
+        j.kind = 1;
+        j.blocks = (int)blocks;
+        if (j.blocks > blocks1) blocks1 = j.blocks;
+      } else {
+        j.kind = 2;
+      }
+      have[j.kind] = 1;
+      const int64_t tot = C[e] * (int64_t)F[e] * 3;
+      if (tot > tot_max) tot_max = tot;
+      ++sb.n;
     }
-    if (need > lds[j.kind]) lds[j.kind] = need;
-    if (j.blocks > nblk[j.kind]) nblk[j.kind] = j.blocks;
-    have[j.kind] = 1;
-    int64_t tot = C[e] * (int64_t)F[e] * 3;
-    if (tot > tot_max) tot_max = tot;
-    ++sb.n;
-  }
-  if (sb.n == 0) return PCS_OK;
-  smooth_velo_batch_reset_kernel<<<sb.n, kBlock, 0, s>>>(sb);
-  for (int kind = 0; kind < 3; ++kind) {
-    if (!have[kind]) continue;
-    if (kind == 1) {
-      // The multi-workgroup form meets at a grid barrier, so ALL workgroups of a launch must be resident
-      // at once. The kernel takes 87 VGPRs: a 1024-thread workgroup is four waves on each SIMD, and a SIMD
-      // holds five such waves, so a CU holds ONE workgroup (256 on the chip, not the 512 a 64-register
-      // kernel would get). A launch gets at most half of what the occupancy query allows -- the rest of
-      // the chip stays free for the kernels other streams keep sending -- and the problems are packed
-      // into as many launches as that takes. Several host threads (lock-step groups, sequences of a
-      // batch) can arrive here together, and two such launches side by side could each get part of
-      // their workgroups and wait for the rest until the barrier times out: one launch of this form at
-      // a time, process wide, the lock held until it has drained.
-      std::lock_guard<std::mutex> lk(sv_grid_mutex());
-      static int budget = 0;  // (under the lock)
-      if (budget == 0) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        PCS_CHECK_HIP(hipGetDevice(&dev));
-        PCS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        PCS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smooth_velo_batch_kernel, SV_BLOCK,
-                                                               (size_t)SV_BLOCK * SV_ELEMS * sizeof(float)));
-        if (per_cu > 1) per_cu = 1;  // (the query is known to answer one too many near an SGPR boundary)
-        budget = per_cu * prop.multiProcessorCount / 2;
-        if (budget < SV_MAX_BLOCKS) return PCS_ERR_HIP;  // not this device
-      }
-      SvBatch part;
-      part.n = 0;
-      int part_blocks = 0, part_max = 0;
-      auto flush = [&]() {
-        if (part.n == 0) return;
-        smooth_velo_batch_kernel<<<dim3(part_max, part.n), SV_BLOCK, lds[1], s>>>(part, 1, weight0, weight, num_itr,
-                                                                               stopping);
-        part.n = 0;
-        part_blocks = part_max = 0;
-      };
-      for (int e = 0; e < sb.n; ++e) {
-        if (sb.j[e].kind != 1) continue;
-        if (part_blocks + sb.j[e].blocks > budget) flush();
-        part.j[part.n++] = sb.j[e];
-        part_blocks += sb.j[e].blocks;
-        if (sb.j[e].blocks > part_max) part_max = sb.j[e].blocks;
-      }
-      flush();
-      const auto t0 = std::chrono::steady_clock::now();
-      PCS_CHECK_HIP(hipStreamSynchronize(s));
-      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (sec > 2.0)  // diagnostic: a grid-barrier launch that took this long was waiting for residency
-        fprintf(stderr, "[pcs] smooth_velo multi-workgroup launch drained after %.1f s (%d problems)\n", sec, sb.n);
-      // a problem whose barrier timed out wrote nothing back: it runs again in the generic
-      // single-workgroup form (slower by two orders of magnitude, correct, and rare). A time-out takes
-      // kSvSpinMax polls (>= 0.13 s); launches that drained within 20 ms are not asked.
-      SvBatch again;
-      again.n = 0;
-      for (int e = 0; e < sb.n && sec > 0.02; ++e) {
-        if (sb.j[e].kind != 1) continue;
-        int timed_out = 0;
-        PCS_CHECK_HIP(hipMemcpy(&timed_out, &sb.j[e].grid->timeout, sizeof(int), hipMemcpyDeviceToHost));
-        if (!timed_out) continue;
-        again.j[again.n] = sb.j[e];
-        again.j[again.n].kind = 2;
-        again.j[again.n].blocks = 1;
-        ++again.n;
-      }
-      if (again.n) {
-        fprintf(stderr, "[pcs] smooth_velo: the grid barrier of %d problem(s) timed out; single-workgroup form instead\n",
-                again.n);
-        smooth_velo_batch_kernel<<<dim3(1, again.n), SV_BLOCK, 0, s>>>(again, 2, weight0, weight, num_itr, stopping);
-      }
-      continue;
+    if (sb.n == 0) continue;
+    smooth_velo_batch_reset_kernel<<<sb.n, 64, 0, s>>>(sb);
+    if (have[0])
+      smooth_velo_batch_kernel<<<dim3(1, sb.n), SV_BLOCK, lds0, s>>>(sb, 0, weight0, weight, num_itr, stopping);
+    if (have[1]) {
+      const int windows = (num_itr + SV2_WINDOW - 1) / SV2_WINDOW;
+      for (int w = 0; w < windows; ++w)
+        smooth_velo_window_kernel<<<dim3(blocks1, sb.n), SV2_BLOCK, 0, s>>>(sb, w, weight0, weight, num_itr,
+                                                                           stopping);
+      smooth_velo_replay_kernel<<<dim3(blocks1, sb.n), SV2_BLOCK, 0, s>>>(sb, weight0, weight, num_itr, stopping);
     }
-    smooth_velo_batch_kernel<<<dim3(nblk[kind], sb.n), SV_BLOCK, lds[kind], s>>>(sb, kind, weight0, weight, num_itr,
-                                                                                stopping);
+    if (have[2])
+      smooth_velo_batch_kernel<<<dim3(1, sb.n), SV_BLOCK, 0, s>>>(sb, 2, weight0, weight, num_itr, stopping);
+    smooth_velo_batch_decay_kernel<<<dim3(grid_for(tot_max), sb.n), kBlock, 0, s>>>(sb);
   }
-  smooth_velo_batch_decay_kernel<<<dim3(grid_for(tot_max), sb.n), kBlock, 0, s>>>(sb);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
@@ -1397,11 +1327,10 @@ using namespace pcs;
 extern "C" {
 
 size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F) {
+  if (C < 1 || F < 1) return 0;
   Arena a(nullptr, 0);
-  a.take<SmoothState>(1);
-  a.take<SmoothGrid>(1);
-  a.take<float>((size_t)C * F * 2);
-  a.take<float>((size_t)C * F * 2);
+  SvWs w;
+  sv_plan(a, C, F, w);
   return a.off;
 }
 
@@ -1410,8 +1339,9 @@ size_t pcs_smooth_velo_workspace_bytes(int64_t C, int F) {
 int pcs_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C, int F,
                     int frame_lo, int frame_hi, float weight0, float weight, int num_itr,
                     float stopping, void* ws, size_t ws_bytes, hipStream_t s) {
-  return pcs::smooth_velo_run(comp_velos, comp_center_diffs, C, F, frame_lo, frame_hi, weight0, weight,
-                              num_itr, stopping, ws, ws_bytes, nullptr, s);
+  if (!comp_velos || !comp_center_diffs || !ws) return PCS_ERR_ARG;
+  return pcs::smooth_velo_run_batch(1, &comp_velos, &comp_center_diffs, &C, &F, &frame_lo, &frame_hi, weight0,
+                                    weight, num_itr, stopping, &ws, &ws_bytes, s);
 }
 
 // several problems in one call (what the sequence tracker does at every step, one problem per unit)
@@ -1423,7 +1353,7 @@ int pcs_smooth_velo_batch(int n, float* const* comp_velos, const float* const* c
                           !ws_bytes)))
     return PCS_ERR_ARG;
   int rc = pcs::smooth_velo_run_batch(n, comp_velos, comp_center_diffs, C, F, frame_lo, frame_hi, weight0,
-                                      weight, num_itr, stopping, ws, ws_bytes, nullptr, s);
+                                      weight, num_itr, stopping, ws, ws_bytes, s);
   if (rc != PCS_OK) return rc;
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   return PCS_OK;

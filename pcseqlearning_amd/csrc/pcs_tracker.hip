@@ -31,7 +31,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <condition_variable>
-#include <functional>
+#include <vector>
 #include <mutex>
 #include <thread>
 #include <atomic>
@@ -42,7 +42,6 @@ namespace pcs {
 
 constexpr int kMaxLevels = 4;
 constexpr int kWg = 1024;  // one-workgroup kernels (sort, compaction)
-constexpr int kMaxGroups = 8;  // lock-step groups (streams) one call may drive
 
 struct TrkState {
   int32_t active;     // any component still tracked (loop condition of the next step)
@@ -92,9 +91,12 @@ struct UnitDev {
   int64_t *ex_index, *ex_local, *ex_comp;
 };
 
+// per (unit, tick) arguments, 16 bytes so that kMaxBatch of them travel by value
 struct StepArg {
-  int dir, next, col, last_col, lv, nn;
-  long long off_n;
+  short next, col, last_col;
+  signed char dir, lv;
+  int nn;     // rows of the target frame
+  int off_n;  // its first row in the sequence (sequences have < 2^31 rows)
 };
 struct Steps {
   StepArg a[kMaxBatch];
@@ -439,7 +441,7 @@ __global__ void trk_hdesc_kernel(const float* __restrict__ b8, float radius, flo
 // synchronisation only)
 __global__ void trk_publish_kernel(const UnitDev* __restrict__ U, Batch bt, TrkState* __restrict__ out) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < bt.n) out[bt.idx[e]] = *U[bt.idx[e]].st;  // slot = unit index
+  if (e < bt.n) out[e] = *U[bt.idx[e]].st;  // slot = position in the list
 }
 
 // the anchor's own points: kept when their component passed filter_components (one workgroup per unit)
@@ -1013,11 +1015,10 @@ hv_compact_kernel(const UnitDev* __restrict__ U, Batch bt, Steps sa) {
   if (threadIdx.x == 0) u.st->ex_count = base + tot;
 }
 
-void sv_grid_gate();  // pcs_track.hip: waits while a grid-barrier launch is in flight
 int smooth_velo_run_batch(int n, float* const* comp_velos, const float* const* comp_center_diffs,
                           const int64_t* C, const int* F, const int* frame_lo, const int* frame_hi,
                           float weight0, float weight, int num_itr, float stopping, void* const* ws,
-                          const size_t* ws_bytes, int* const* err, hipStream_t s);
+                          const size_t* ws_bytes, hipStream_t s);
 
 // ------------------------------------------------------------------ host side
 struct UnitPlan {
@@ -1088,59 +1089,66 @@ static bool plan_unit(Arena& a, int64_t na, int64_t nm, int64_t C, int F, UnitPl
   return a.ok();
 }
 
-struct EnginePlan {
-  UnitDev* d_units;
-  IcpProblem* d_icp;
+// what the units of one sequence share
+struct SeqPlan {
   float* seq_b8;
   GridDesc* hdesc;
 };
 
-static bool plan_engine(Arena& a, EnginePlan& e) {
-  e.d_units = a.take<UnitDev>(kMaxBatch);
-  e.d_icp = a.take<IcpProblem>(kMaxBatch);
+static bool plan_seq(Arena& a, SeqPlan& e) {
   e.seq_b8 = a.take<float>(8);
   e.hdesc = a.take<GridDesc>(1);
   return a.ok();
 }
 
-enum Phase { PH_START, PH_ICP, PH_POSTWAIT, PH_FINALWAIT, PH_DONE };
+constexpr int kMaxCallUnits = 32;  // units one sequence may hand over (their descriptors are staged in one pinned page)
+
+enum Phase { PH_FREE, PH_RESERVED, PH_START, PH_ICP, PH_POSTWAIT, PH_FINALWAIT, PH_DONE };
+
+// one blocking call into the engine (lives on the caller's stack)
+struct Call {
+  std::mutex mu;
+  std::condition_variable cv;
+  int remaining = 0;  // units handed to the engine that have not finished
+  int rc = PCS_OK;
+};
 
 struct HostUnit {
   PcsTrackUnit* io;
+  Call* call;
+  const int64_t* frame_offsets;  // the caller's host array (the caller blocks until the unit is done)
   UnitPlan p;
   int na, nm, C, F, W, anchor, min_f, max_f;
   int64_t off_a;
   int phase, dir, next, last_col, lv;
   int it;         // ICP iterations enqueued for the current registration
   int it_before;  // iterations enqueued before the last chunk
+  int fail;       // error found while collecting a tick (PCS_ERR_*)
   bool any_valid;
   int Cu;
-  int64_t steps, reg_calls;
+  int64_t steps, reg_calls, tick0;
   int seen[kMaxLevels][3];  // {Mn, Ra, Rn} of the last sampling at each level (launch-size estimates)
   IcpHint hint;
   TrkState host;
   IcpState icp;
 };
 
-// a unit's error word: 3 = the grid barrier of smooth_velo timed out (a device-side failure: loud),
-// anything else = a search grid / fixed-point range overflowed (the caller may fall back)
-// EXPERIMENT (PCS_TICK_PROFILE=1): where a driving thread's time goes -- enqueueing a tick's launches,
-// waiting for the tick's event, the rest; printed when the process ends
+// EXPERIMENT (PCS_TICK_PROFILE=1): where the driving thread's time goes -- enqueueing a tick's launches,
+// waiting for the tick's event; printed when the process ends
 struct TickProfile {
-  std::atomic<long long> enq_ns{0}, wait_ns{0}, ticks{0}, calls{0}, total_ns{0};
+  std::atomic<long long> enq_ns{0}, wait_ns{0}, ticks{0}, units{0}, iter_units{0};
   bool on = getenv("PCS_TICK_PROFILE") != nullptr;
   ~TickProfile() {
     if (on && ticks.load())
-      fprintf(stderr, "[tick profile] calls %lld ticks %lld: per tick enqueue %.1f us, wait %.1f us; per call total %.2f ms\n",
-              calls.load(), ticks.load(), enq_ns.load() / 1e3 / ticks.load(), wait_ns.load() / 1e3 / ticks.load(),
-              total_ns.load() / 1e6 / (calls.load() ? calls.load() : 1));
+      fprintf(stderr, "[tick profile] ticks %lld: per tick enqueue %.1f us, wait %.1f us, units %.1f (iterating %.1f)\n",
+              ticks.load(), enq_ns.load() / 1e3 / ticks.load(), wait_ns.load() / 1e3 / ticks.load(),
+              (double)units.load() / ticks.load(), (double)iter_units.load() / ticks.load());
   }
 };
 static TickProfile g_tick_profile;
 static inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static inline int unit_error(int err) { return err == 3 ? PCS_ERR_HIP : PCS_ERR_RANGE; }
 static inline int nblk(int64_t n) { return (int)(((n < 1 ? 1 : n) + kBlock - 1) / kBlock); }
 
 static inline int pow2_words(int64_t n) {
@@ -1149,61 +1157,155 @@ static inline int pow2_words(int64_t n) {
   return (int)h;
 }
 
-// Helper threads of a call: group 0 is driven by the caller, every further lock-step group by one of
-// these (kernels of different streams overlap on the device, but one host thread cannot issue the
-// launches of several groups fast enough). The threads live as long as the process: they keep their
-// stream, event and pinned status page from call to call.
-class GroupWorkers {
+static bool same_params(const PcsTrackParams& a, const PcsTrackParams& b) {
+  if (a.num_levels != b.num_levels || a.max_iter != b.max_iter || a.min_move_frame != b.min_move_frame ||
+      a.smooth_num_itr != b.smooth_num_itr || a.angle_regularizer != b.angle_regularizer ||
+      a.nn_radius != b.nn_radius || a.reg_error_coeff != b.reg_error_coeff ||
+      a.angle_threshold != b.angle_threshold || a.max_diameter != b.max_diameter ||
+      a.smooth_weight0 != b.smooth_weight0 || a.smooth_weight != b.smooth_weight ||
+      a.smooth_stopping != b.smooth_stopping)
+    return false;
+  for (int l = 0; l < a.num_levels && l < PCS_TRACK_MAX_LEVELS; ++l) {
+    if (a.radius[l] != b.radius[l] || a.stopping_delta[l] != b.stopping_delta[l]) return false;
+    for (int k = 0; k < 3; ++k)
+      if (a.voxel_size[l][k] != b.voxel_size[l][k]) return false;
+  }
+  return true;
+}
+
+// The lock-step engine of a device. Tracking units are independent chains of small, latency-bound
+// launches whose duration hardly depends on their width, so ALL units that are being tracked on the
+// device -- whichever call, host thread or sequence they come from -- advance together: one driver
+// thread, one stream, one table of unit / ICP descriptors, and every launch of a tick serves every
+// unit that is in that phase. A call prepares its units on its own stream (workspace layout, anchor
+// set-up), hands them over and blocks until they are done; units join and leave at tick boundaries
+// ("continuous batching"), so several sequences in flight give launches several sequences wide
+// without any of them waiting for the others. A unit's results never depend on what shares its
+// launches (integer moments, exact neighbours, fixed-order sums).
+class Engine {
  public:
-  // one pool per calling thread (several sequences may be tracked at once, each from its own host
-  // thread); never destroyed: the workers outlive main
-  static GroupWorkers& get() {
-    static thread_local GroupWorkers* inst = new GroupWorkers();
-    return *inst;
-  }
-  void start(int slot, std::function<void()> job) {
-    W& w = w_[slot];
-    std::unique_lock<std::mutex> lk(w.mu);
-    if (!w.started) {
-      w.started = true;
-      std::thread([&w] {
-        for (;;) {
-          std::function<void()> f;
-          {
-            std::unique_lock<std::mutex> lk2(w.mu);
-            w.cv.wait(lk2, [&] { return w.has_job; });
-            f = std::move(w.job);
-            w.has_job = false;
-          }
-          f();
-          {
-            std::lock_guard<std::mutex> lk2(w.mu);
-            w.done = true;
-          }
-          w.cv_done.notify_all();
-        }
-      }).detach();
+  static Engine* get(int device) {
+    static std::mutex mu;
+    static Engine* inst[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!inst[device]) {
+      Engine* e = new Engine(device);  // never destroyed: the driver thread outlives main
+      if (!e->start()) return nullptr;
+      inst[device] = e;
     }
-    w.job = std::move(job);
-    w.has_job = true;
-    w.done = false;
-    lk.unlock();
-    w.cv.notify_all();
-  }
-  void wait(int slot) {
-    W& w = w_[slot];
-    std::unique_lock<std::mutex> lk(w.mu);
-    w.cv_done.wait(lk, [&] { return w.done; });
+    return inst[device];
   }
 
+  // n free slots for units with these parameters; blocks while the table is full or units with other
+  // parameters are in flight
+  int reserve(const PcsTrackParams& prm, int n, int* slots) {
+    if (n < 1 || n > kMaxBatch) return PCS_ERR_ARG;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_slots_.wait(lk, [&] { return broken_ || (free_ >= n && (users_ == 0 || same_params(prm, prm_))); });
+    if (broken_) return PCS_ERR_HIP;
+    if (users_ == 0) prm_ = prm;
+    int got = 0;
+    for (int i = 0; i < kMaxBatch && got < n; ++i)
+      if (hu_[i].phase == PH_FREE) {
+        hu_[i].phase = PH_RESERVED;
+        slots[got++] = i;
+      }
+    free_ -= n;
+    users_ += n;
+    return PCS_OK;
+  }
+  void release(const int* slots, int n) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int e = 0; e < n; ++e) hu_[slots[e]].phase = PH_FREE;
+      free_ += n;
+      users_ -= n;
+    }
+    cv_slots_.notify_all();
+  }
+  void submit(Call* call, const int* slots, int n) {
+    {
+      std::lock_guard<std::mutex> lk(call->mu);
+      call->remaining += n;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int e = 0; e < n; ++e) {
+        hu_[slots[e]].call = call;
+        pending_[n_pending_++] = slots[e];
+      }
+    }
+    cv_work_.notify_all();
+  }
+  HostUnit& unit(int slot) { return hu_[slot]; }
+  UnitDev* d_units() { return d_units_; }
+  IcpProblem* d_icp() { return d_icp_; }
+
  private:
-  struct W {
-    std::mutex mu;
-    std::condition_variable cv, cv_done;
-    std::function<void()> job;
-    bool started = false, has_job = false, done = true;
-  };
-  W w_[kMaxGroups];
+  explicit Engine(int device) : device_(device) {
+    for (int i = 0; i < kMaxBatch; ++i) hu_[i].phase = PH_FREE;
+  }
+  bool start() {
+    if (hipSetDevice(device_) != hipSuccess) return false;
+    // the descriptor tables and the pinned mirrors live as long as the process (the one allocation of
+    // this library that is not the caller's workspace: the tables are shared by all calls)
+    if (hipMalloc((void**)&d_units_, kMaxBatch * sizeof(UnitDev)) != hipSuccess) return false;
+    if (hipMalloc((void**)&d_icp_, kMaxBatch * sizeof(IcpProblem)) != hipSuccess) return false;
+    char* pg = nullptr;
+    const size_t pin_bytes = kMaxBatch * (2 * sizeof(IcpState) + sizeof(TrkState));
+    if (hipHostMalloc((void**)&pg, pin_bytes, hipHostMallocDefault) != hipSuccess) return false;
+    pin_icp_ = (IcpState*)pg;
+    pin_fin_ = pin_icp_ + kMaxBatch;
+    pin_trk_ = (TrkState*)(pin_fin_ + kMaxBatch);
+    std::thread([this] { run(); }).detach();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_slots_.wait(lk, [&] { return ready_ || broken_; });
+    return ready_;
+  }
+
+  void finish_unit(int i, int rc) {  // driver thread; the unit's kernels have all completed
+    HostUnit& h = hu_[i];
+    Call* call = h.call;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      h.phase = PH_FREE;
+      ++free_;
+      --users_;
+    }
+    cv_slots_.notify_all();
+    bool last;
+    {
+      std::lock_guard<std::mutex> lk(call->mu);
+      if (rc != PCS_OK && call->rc == PCS_OK) call->rc = rc;
+      last = --call->remaining == 0;
+      if (last) call->cv.notify_all();  // (under the lock: the Call may vanish as soon as it is released)
+    }
+  }
+
+  int enqueue_tick();
+  void collect_tick();
+  void run();
+
+  const int device_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_slots_;
+  bool ready_ = false, broken_ = false;
+  int free_ = kMaxBatch, users_ = 0;
+  int pending_[kMaxBatch], n_pending_ = 0;
+  PcsTrackParams prm_;
+  HostUnit hu_[kMaxBatch];
+  UnitDev* d_units_ = nullptr;
+  IcpProblem* d_icp_ = nullptr;
+  // driver thread only
+  hipStream_t st_ = nullptr;
+  hipEvent_t ev_ = nullptr;
+  IcpState *pin_icp_ = nullptr, *pin_fin_ = nullptr;
+  TrkState* pin_trk_ = nullptr;
+  int live_[kMaxBatch], n_live_ = 0;
+  Batch b_all_, b_iter_, b_fin_;
+  int64_t ticks_ = 0;
+  int chunk_ = 8;
 };
 
 }  // namespace pcs
@@ -1216,10 +1318,11 @@ using namespace pcs;
     if (_rc) return _rc;        \
   } while (0)
 
-static_assert(kPinnedStageOff + kMaxBatch * sizeof(UnitDev) <= kPinnedPageBytes,
+static_assert(kPinnedStageOff + kMaxCallUnits * sizeof(UnitDev) <= kPinnedPageBytes,
               "descriptor staging does not fit the pinned page");
-static_assert(kMaxBatch * sizeof(TrkState) <= kPinnedStageOff - kPinnedTrackerOff, "tracker state mirror");
-static_assert(kMaxBatch * sizeof(IcpState) <= 2048, "ICP state mirrors");
+static_assert(kMaxCallUnits * sizeof(TrkState) <= kPinnedStageOff - kPinnedTrackerOff, "tracker state mirror");
+static_assert(sizeof(Batch) + sizeof(Steps) + sizeof(LevelSizes) + 64 <= 4096,
+              "the by-value unit lists must fit the kernel-argument segment");
 
 static int64_t unit_frame_max(const int64_t* frame_offsets, int anchor, int min_f, int max_f) {
   int64_t nm = 1;
@@ -1230,30 +1333,405 @@ static int64_t unit_frame_max(const int64_t* frame_offsets, int anchor, int min_
   return nm;
 }
 
-static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
-                        int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
-  if (!prm || !seq_fxyz || !frame_offsets || !units || !ws) return PCS_ERR_ARG;
-  if (n_units < 1 || n_units > kMaxBatch || num_frames < 1 || prm->num_levels < 1 ||
-      prm->num_levels > kMaxLevels || prm->max_iter < 0)
-    return PCS_ERR_ARG;
+// Decide every live unit's next phase from the state words read last and enqueue the next tick.
+// Returns PCS_OK or an engine-fatal error (a failed launch); errors of single units fail their call only.
+int Engine::enqueue_tick() {
+  const PcsTrackParams* prm = &prm_;
   const int L = prm->num_levels;
+  const int chunk = chunk_;
+  hipStream_t gs = st_;
+  UnitDev* const d_units = d_units_;
+  IcpProblem* const d_icp = d_icp_;
+  HostUnit* const hu = hu_;
+  auto in_range = [](const HostUnit& h, int f) { return f >= h.min_f && f <= h.max_f; };
+  auto step_arg = [&](const HostUnit& h) {
+    StepArg a;
+    a.dir = (signed char)h.dir;
+    a.next = (short)h.next;
+    a.col = (short)(h.next - h.min_f);
+    a.last_col = (short)h.last_col;
+    a.lv = (signed char)h.lv;
+    a.off_n = in_range(h, h.next) ? (int)h.frame_offsets[h.next] : 0;
+    a.nn = in_range(h, h.next) ? (int)(h.frame_offsets[h.next + 1] - h.frame_offsets[h.next]) : 0;
+    return a;
+  };
+  // ---- 0. units whose last tick raised an error take their whole call with them
+  {
+    bool any = false;
+    for (int e = 0; e < n_live_; ++e) {
+      HostUnit& h = hu[live_[e]];
+      int rc = h.fail;
+      if (!rc && h.phase == PH_ICP && h.icp.err) rc = PCS_ERR_RANGE;
+      if (!rc && (h.phase == PH_POSTWAIT || h.phase == PH_FINALWAIT) && h.host.err) rc = PCS_ERR_RANGE;
+      if (rc) {
+        std::lock_guard<std::mutex> lk(h.call->mu);
+        if (h.call->rc == PCS_OK) h.call->rc = rc;
+        any = true;
+      }
+    }
+    if (any) {
+      int keep = 0;
+      for (int e = 0; e < n_live_; ++e) {
+        const int i = live_[e];
+        int rc;
+        {
+          std::lock_guard<std::mutex> lk(hu[i].call->mu);
+          rc = hu[i].call->rc;
+        }
+        if (rc != PCS_OK) finish_unit(i, rc);
+        else live_[keep++] = i;
+      }
+      n_live_ = keep;
+    }
+  }
+  ++ticks_;
+  Batch b_fin, b_post, b_dir, b_step, b_smp, b_begin, b_iter;
+  Steps s_fin, s_post, s_step, s_smp;
+  b_fin.n = b_post.n = b_dir.n = b_step.n = b_smp.n = b_begin.n = b_iter.n = 0;
+  static thread_local IcpHint h_fin[kMaxBatch], h_begin[kMaxBatch], h_iter[kMaxBatch];
+  BatchInts kb;
+  auto start_level = [&](int i) {  // sampling + start of the registration at hu[i].lv
+    HostUnit& h = hu[i];
+    s_smp.a[b_smp.n] = step_arg(h);
+    b_smp.idx[b_smp.n++] = i;
+    b_begin.idx[b_begin.n++] = i;
+    h.it = h.it_before = 0;
+    h.icp.iters = 0;
+    h.icp.stop_iter = INT_MAX;
+    h.icp.err = 0;
+    h.phase = PH_ICP;
+  };
+  auto start_step = [&](int i) {
+    HostUnit& h = hu[i];
+    h.lv = 0;
+    ++h.steps;
+    s_step.a[b_step.n] = step_arg(h);
+    b_step.idx[b_step.n++] = i;
+    start_level(i);
+  };
+  auto start_dir = [&](int i, int dir) -> bool {  // true if the direction has a first step
+    HostUnit& h = hu[i];
+    h.dir = dir;
+    h.next = h.anchor + dir;
+    h.last_col = (dir == 1 && h.anchor > 0) ? h.anchor : -1;
+    return in_range(h, h.next) && h.any_valid;
+  };
+  int done[kMaxBatch], n_done = 0;
+  for (int e = 0; e < n_live_; ++e) {
+    const int i = live_[e];
+    HostUnit& h = hu[i];
+    switch (h.phase) {
+      case PH_START: {
+        // a backward pass without a step leaves nothing behind that the forward set-up does not redo
+        bool go = start_dir(i, -1);
+        if (!go) go = start_dir(i, 1);
+        b_dir.idx[b_dir.n++] = i;
+        if (go) start_step(i);
+        else h.phase = PH_FINALWAIT;
+        break;
+      }
+      case PH_ICP: {
+        if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
+          s_fin.a[b_fin.n] = step_arg(h);
+          h_fin[b_fin.n] = h.hint;
+          b_fin.idx[b_fin.n++] = i;
+          ++h.reg_calls;
+          ++h.lv;
+          if (h.lv < L) {
+            start_level(i);
+          } else {
+            h.lv = L - 1;
+            s_post.a[b_post.n] = step_arg(h);
+            b_post.idx[b_post.n++] = i;
+            h.phase = PH_POSTWAIT;
+          }
+        }
+        break;
+      }
+      case PH_POSTWAIT: {
+        h.last_col = h.next;
+        h.next += h.dir;
+        if (in_range(h, h.next) && h.host.active) {
+          start_step(i);
+        } else if (h.dir == -1) {
+          bool go = start_dir(i, 1);
+          b_dir.idx[b_dir.n++] = i;
+          if (go) start_step(i);
+          else h.phase = PH_FINALWAIT;
+        } else {
+          h.phase = PH_FINALWAIT;
+        }
+        break;
+      }
+      case PH_FINALWAIT: {
+        h.io->info[0] = h.host.ex_count;
+        h.io->info[1] = h.reg_calls;
+        h.io->info[2] = h.steps;
+        h.io->info[3] = ticks_ - h.tick0;
+        h.phase = PH_DONE;
+        done[n_done++] = i;
+        break;
+      }
+      default:
+        break;
+    }
+  }
+  if (n_done) {
+    int keep = 0;
+    for (int e = 0; e < n_live_; ++e)
+      if (hu[live_[e]].phase != PH_DONE) live_[keep++] = live_[e];
+    n_live_ = keep;
+    for (int e = 0; e < n_done; ++e) finish_unit(done[e], PCS_OK);
+  }
+  b_fin_ = b_fin;
+  b_iter_.n = 0;
+  b_all_.n = n_live_;
+  for (int e = 0; e < n_live_; ++e) b_all_.idx[e] = live_[e];
+  if (n_live_ == 0) return PCS_OK;
+  // ---- 1. registrations that stopped: l1 error, coverage, outputs; then frame <- T frame
+  if (b_fin.n) {
+    TRK_RC(icp_enqueue_finish(d_icp, b_fin, h_fin, pin_fin_, gs));
+    int g = 1;
+    for (int e = 0; e < b_fin.n; ++e) g = max(g, nblk(max(hu[b_fin.idx[e]].na, hu[b_fin.idx[e]].C)));
+    trk_apply_T_kernel<<<dim3(g, b_fin.n), kBlock, 0, gs>>>(d_units, b_fin, s_fin);
+  }
+  // ---- 2. after the last level: component motion, velocity smoothing, stop rules, harvest
+  if (b_post.n) {
+    int gc = 1, gp = 1, gq = 1;
+    static thread_local float* sv_v[kMaxBatch];
+    static thread_local const float* sv_d[kMaxBatch];
+    static thread_local int64_t sv_C[kMaxBatch];
+    static thread_local int sv_F[kMaxBatch], sv_lo[kMaxBatch], sv_hi[kMaxBatch];
+    static thread_local void* sv_ws[kMaxBatch];
+    static thread_local size_t sv_wsb[kMaxBatch];
+    int nsv = 0;
+    for (int e = 0; e < b_post.n; ++e) {
+      HostUnit& h = hu[b_post.idx[e]];
+      gc = max(gc, nblk((int64_t)h.Cu * 64));
+      gp = max(gp, nblk(max(h.na, h.C)));
+      gq = max(gq, nblk((int64_t)s_post.a[e].nn * 32));
+      int a0 = h.anchor + h.dir, b0 = h.next;
+      if (a0 != b0) {
+        sv_v[nsv] = h.p.d.velos;
+        sv_d[nsv] = h.p.d.diffs;
+        sv_C[nsv] = h.C;
+        sv_F[nsv] = h.F;
+        sv_lo[nsv] = a0 < b0 ? a0 : b0;
+        sv_hi[nsv] = a0 < b0 ? b0 : a0;
+        sv_ws[nsv] = h.p.ws_sv;
+        sv_wsb[nsv] = h.p.sv_bytes;
+        ++nsv;
+      }
+    }
+    if (gc > 2048) gc = 2048;
+    if (gq > 8192) gq = 8192;
+    trk_motion_kernel<<<dim3(gc, b_post.n), kBlock, 0, gs>>>(d_units, b_post, s_post);
+    TRK_RC(smooth_velo_run_batch(nsv, sv_v, sv_d, sv_C, sv_F, sv_lo, sv_hi, prm->smooth_weight0,
+                                 prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping, sv_ws,
+                                 sv_wsb, gs));
+    trk_after_smooth_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(d_units, b_post, s_post,
+                                                                   prm->min_move_frame, prm->reg_error_coeff,
+                                                                   prm->angle_threshold);
+    hv_insert_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(d_units, b_post, s_post);
+    hv_search_kernel<<<dim3(gq, b_post.n), kBlock, 0, gs>>>(d_units, b_post, s_post);
+    hv_compact_kernel<<<b_post.n, kWg, 0, gs>>>(d_units, b_post, s_post);
+  }
+  // ---- 3. direction / step set-up
+  if (b_dir.n) {
+    int g = 1;
+    for (int e = 0; e < b_dir.n; ++e) g = max(g, nblk(max(hu[b_dir.idx[e]].na, hu[b_dir.idx[e]].C)));
+    trk_dir_init_kernel<<<dim3(g, b_dir.n), kBlock, 0, gs>>>(d_units, b_dir);
+  }
+  if (b_step.n) {
+    int g = 1;
+    for (int e = 0; e < b_step.n; ++e) g = max(g, nblk(max(hu[b_step.idx[e]].na, hu[b_step.idx[e]].C)));
+    trk_step_begin_kernel<<<dim3(g, b_step.n), kBlock, 0, gs>>>(d_units, b_step, s_step);
+  }
+  // ---- 4. sampling of the anchor (as moved so far) and of the target frame
+  if (b_smp.n) {
+    LevelSizes ls;
+    for (int l = 0; l < kMaxLevels; ++l)
+      for (int k = 0; k < 3; ++k) ls.v[l][k] = l < L ? prm->voxel_size[l][k] : 1.f;
+    int gv = 1;
+    for (int e = 0; e < b_smp.n; ++e) {
+      HostUnit& h = hu[b_smp.idx[e]];
+      int est = h.seen[h.lv][1] > 0 ? (int)(h.seen[h.lv][1] * 1.25) : max(h.na, h.nm) / 2;
+      gv = max(gv, nblk(est));
+    }
+    smp_sort_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(d_units, b_smp, s_smp, ls);
+    smp_emit_kernel<<<dim3(gv, b_smp.n, 2), kBlock, 0, gs>>>(d_units, b_smp, s_smp);
+    smp_compact_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(d_units, b_smp);
+  }
+  // ---- 5. registrations that start: descriptor, reset, grids
+  if (b_begin.n) {
+    for (int e = 0; e < b_begin.n; ++e) {
+      const int i = b_begin.idx[e];
+      HostUnit& h = hu[i];
+      UnitDev& d = h.p.d;
+      IcpArgs ia;
+      ia.mov = (float*)d.sa.out;
+      ia.comp = d.sa.out_comp;
+      ia.ref = (const float*)d.sb.out;
+      ia.all = (const float*)d.sb.sub;
+      ia.comp_deg = (const int64_t*)d.sub_deg;
+      ia.cnt3 = &d.st->counts[1];
+      ia.Mn = h.na;
+      ia.Rn = h.nm;
+      ia.Ra = h.nm;
+      ia.C = h.C;
+      ia.radius = prm->radius[h.lv];
+      ia.frame_offset = h.next - h.anchor;
+      ia.reg = prm->angle_regularizer;
+      ia.delta = prm->stopping_delta[h.lv];
+      ia.max_iter = prm->max_iter;
+      ia.cell_size = 0.f;
+      ia.T = d.Tl;
+      ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
+      ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
+      // the descriptor travels as a kernel argument (no copy engine, no staging buffer to keep alive)
+      IcpProblem desc;
+      TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &desc));
+      trk_store_icp_kernel<<<1, 64, 0, gs>>>(d_icp + i, desc);
+      // launch sizes: what this level had at the previous step, else a guess
+      const int* sn = h.seen[h.lv];
+      h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
+      h.hint.Ra = sn[1] >= 0 ? (int)(sn[1] * 1.25) + 256 : h.nm / 2 + 256;
+      h.hint.Rn = sn[2] >= 0 ? (int)(sn[2] * 1.25) + 256 : h.nm / 4 + 256;
+      h.hint.C = h.C;
+      h.hint.clear_words = 4 * (size_t)pow2_words(h.hint.Mn) + 2 * (size_t)pow2_words(h.hint.Rn) +
+                           2 * (size_t)pow2_words(h.hint.Ra);
+      h_begin[e] = h.hint;
+    }
+    TRK_RC(icp_enqueue_begin(d_icp, b_begin, h_begin, gs));
+  }
+  // ---- 6. one chunk of iterations for every unit that is registering
+  for (int e = 0; e < n_live_; ++e) {
+    const int i = live_[e];
+    HostUnit& h = hu[i];
+    if (h.phase != PH_ICP) continue;
+    kb.v[b_iter.n] = h.it;
+    h_iter[b_iter.n] = h.hint;
+    b_iter.idx[b_iter.n++] = i;
+  }
+  if (b_iter.n) {
+    TRK_RC(icp_enqueue_chunk(d_icp, b_iter, kb, chunk, h_iter, pin_icp_, gs, 0));
+    for (int e = 0; e < b_iter.n; ++e) {
+      HostUnit& h = hu[b_iter.idx[e]];
+      h.it_before = h.it;
+      h.it = min(h.it + chunk, prm->max_iter);
+    }
+  }
+  b_iter_ = b_iter;
+  if (g_tick_profile.on) { g_tick_profile.units += n_live_; g_tick_profile.iter_units += b_iter.n; }
+  // ---- 7. state mirror; the event tells the host when the tick's words can be read
+  trk_publish_kernel<<<(b_all_.n + 63) / 64, 64, 0, gs>>>(d_units, b_all_, pin_trk_);
+  PCS_LAUNCH_CHECK();
+  PCS_CHECK_HIP(hipEventRecord(ev_, gs));
+  return PCS_OK;
+}
+
+// the tick has completed: take its state words
+void Engine::collect_tick() {
+  HostUnit* const hu = hu_;
+  const int chunk = chunk_;
+  for (int e = 0; e < b_fin_.n; ++e)
+    if (pin_fin_[e].err) hu[b_fin_.idx[e]].fail = PCS_ERR_RANGE;  // the coverage query can still overflow a grid
+  for (int e = 0; e < b_all_.n; ++e) {
+    HostUnit& h = hu[b_all_.idx[e]];
+    h.host = pin_trk_[e];
+    if (h.phase == PH_ICP) {
+      h.seen[h.lv][0] = (int)h.host.counts[1];
+      h.seen[h.lv][1] = (int)h.host.counts[2];
+      h.seen[h.lv][2] = (int)h.host.counts[3];
+    }
+  }
+  if (b_iter_.n) {
+    int live_j[kIcpMaxChunk];
+    double b3[3 * kIcpMaxChunk];
+    for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
+    for (int e = 0; e < b_iter_.n; ++e) {
+      HostUnit& h = hu[b_iter_.idx[e]];
+      h.icp = pin_icp_[e];
+      const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
+      for (int j = 0; j < chunk; ++j) {
+        if (h.it_before + 1 + j > h.icp.iters) break;
+        live_j[j] += 1;
+        b3[3 * j] += 76.0 * (Mn + Rn) + 272.0 * C;  // search (36 per query) + moments (40 per query, 272 per component)
+        b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
+      }
+    }
+    icp_profile_account(chunk, live_j, b3, 0);
+  }
+}
+
+void Engine::run() {
+  bool ok = hipSetDevice(device_) == hipSuccess &&
+            hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ev_, hipEventDisableTiming) == hipSuccess;
+  {
+    const char* e = getenv("PCS_TRACK_CHUNK");
+    int c = e ? atoi(e) : 0;
+    chunk_ = (c >= 1 && c <= kIcpMaxChunk) ? c : 8;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    ready_ = ok;
+    broken_ = !ok;
+  }
+  cv_slots_.notify_all();
+  if (!ok) return;
+  const bool tp = g_tick_profile.on;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_work_.wait(lk, [&] { return n_pending_ > 0 || n_live_ > 0; });
+      for (int e = 0; e < n_pending_; ++e) {  // units join at tick boundaries
+        HostUnit& h = hu_[pending_[e]];
+        h.phase = PH_START;
+        h.tick0 = ticks_;
+        live_[n_live_++] = pending_[e];
+      }
+      n_pending_ = 0;
+    }
+    long long t0 = tp ? now_ns() : 0;
+    int rc = enqueue_tick();
+    if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; t0 = now_ns(); }
+    if (rc == PCS_OK && n_live_ > 0) {
+      const long long w0 = now_ns();
+      if (hipEventSynchronize(ev_) != hipSuccess) rc = PCS_ERR_HIP;
+      const long long w1 = now_ns();
+      if (w1 - w0 > 2000000000LL)  // diagnostic: a tick that took seconds
+        fprintf(stderr, "[pcs] tracker tick %lld completed after %.1f s (%d units, %d iterating, %d finishing)\n",
+                (long long)ticks_, (w1 - w0) / 1e9, n_live_, b_iter_.n, b_fin_.n);
+      if (tp) g_tick_profile.wait_ns += w1 - t0;
+      if (rc == PCS_OK) collect_tick();
+    }
+    if (rc != PCS_OK) {
+      // a launch or the event wait failed: nothing of this engine can be trusted any more
+      (void)hipStreamSynchronize(st_);
+      for (int e = 0; e < n_live_; ++e) finish_unit(live_[e], rc);
+      n_live_ = 0;
+      fprintf(stderr, "[pcs] tracker engine of device %d: HIP failure, calls in flight fail with %d\n", device_, rc);
+    }
+  }
+}
+
+// Workspace layout, descriptors and anchor set-up of the units of ONE sequence on the caller's stream;
+// the units are then in the engine's table (slots[]) and ready to be submitted.
+static int prepare_sequence(Engine* eng, const PcsTrackParams* prm, const float* seq_fxyz,
+                            const int64_t* frame_offsets, int num_frames, PcsTrackUnit* units, int n_units,
+                            Arena& a, void* ws, int* slots, hipStream_t s) {
   char* page = (char*)thread_pinned_page();
   if (!page) return PCS_ERR_HIP;
-  IcpState* pin_icp = (IcpState*)page;
-  IcpState* pin_fin = (IcpState*)(page + 2048);  // states of the registrations that finished this tick
   TrkState* pin_trk = (TrkState*)(page + kPinnedTrackerOff);
   UnitDev* stage_units = (UnitDev*)(page + kPinnedStageOff);
-
-  Arena a(ws, ws_bytes);
-  EnginePlan eng;
-  if (!plan_engine(a, eng)) return PCS_ERR_WORKSPACE;
-  static thread_local HostUnit hu_store[kMaxBatch];
-  HostUnit* const hu = hu_store;  // (the helper threads must see the CALLER's array, not their own)
+  SeqPlan sq;
+  if (!plan_seq(a, sq)) return PCS_ERR_WORKSPACE;
   const int64_t n_seq = frame_offsets[num_frames];
+  if (n_seq >= (1LL << 31) || num_frames >= 32767) return PCS_ERR_RANGE;
   for (int i = 0; i < n_units; ++i) {
     PcsTrackUnit& io = units[i];
-    HostUnit& h = hu[i];
+    HostUnit& h = eng->unit(slots[i]);
     if (!io.seq_component || !io.seq_stationary || !io.ex_index || !io.ex_local || !io.ex_component ||
         !io.transforms || !io.reg_errors || !io.comp_edge_ratios || !io.comp_velos ||
         !io.comp_min_frame_id || !io.comp_max_frame_id || !io.moving || !io.valid_comp)
@@ -1263,6 +1741,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
         io.max_frame_id < io.anchor_frame)
       return PCS_ERR_ARG;
     h.io = &io;
+    h.frame_offsets = frame_offsets;
     h.anchor = io.anchor_frame;
     h.min_f = io.min_frame_id;
     h.max_f = io.max_frame_id;
@@ -1292,7 +1771,7 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     d.W = h.W;
     d.anchor = h.anchor;
     d.min_f = h.min_f;
-    d.hdesc = eng.hdesc;
+    d.hdesc = sq.hdesc;
     d.transforms = io.transforms;
     d.reg_errors = io.reg_errors;
     d.edge_ratios = io.comp_edge_ratios;
@@ -1304,26 +1783,29 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
     d.ex_index = io.ex_index;
     d.ex_local = io.ex_local;
     d.ex_comp = io.ex_component;
-    h.phase = PH_START;
     h.steps = h.reg_calls = 0;
     h.it = h.it_before = 0;
+    h.fail = 0;
+    h.icp.err = 0;
+    h.host.err = 0;
     for (int l = 0; l < kMaxLevels; ++l) h.seen[l][0] = h.seen[l][1] = h.seen[l][2] = -1;
     io.info[0] = io.info[1] = io.info[2] = io.info[3] = 0;
     stage_units[i] = d;
+    PCS_CHECK_HIP(hipMemcpyAsync(eng->d_units() + slots[i], stage_units + i, sizeof(UnitDev),
+                                 hipMemcpyHostToDevice, s));
   }
-  PCS_CHECK_HIP(hipMemcpyAsync(eng.d_units, stage_units, (size_t)n_units * sizeof(UnitDev),
-                               hipMemcpyHostToDevice, s));
+  UnitDev* const d_units = eng->d_units();
 
   // ---- set-up, pass 1: the anchors' components (sorted unique), everything zeroed
   const float nn_radius = prm->nn_radius;
   {
     const double nn_r = (double)nn_radius;
     const float nn_cell = (float)(sqrt(nn_r * nn_r + 3e-5 * nn_r * nn_r + 3e-6) / 4 * 1.0005);
-    TRK_RC(pcs_minmax4_f32(seq_fxyz, n_seq, eng.seq_b8, s));
-    trk_hdesc_kernel<<<1, 64, 0, s>>>(eng.seq_b8, nn_radius, nn_cell, 64.f + 4.f * nn_radius, eng.hdesc);
+    TRK_RC(pcs_minmax4_f32(seq_fxyz, n_seq, sq.seq_b8, s));
+    trk_hdesc_kernel<<<1, 64, 0, s>>>(sq.seq_b8, nn_radius, nn_cell, 64.f + 4.f * nn_radius, sq.hdesc);
   }
   for (int i = 0; i < n_units; ++i) {
-    HostUnit& h = hu[i];
+    HostUnit& h = eng->unit(slots[i]);
     UnitDev& d = h.p.d;
     PcsTrackUnit& io = *h.io;
     PCS_CHECK_HIP(hipMemsetAsync(d.st, 0, sizeof(TrkState), s));
@@ -1342,13 +1824,13 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
   }
   Batch all;
   all.n = n_units;
-  for (int i = 0; i < n_units; ++i) all.idx[i] = i;
-  trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+  for (int i = 0; i < n_units; ++i) all.idx[i] = slots[i];
+  trk_publish_kernel<<<1, 64, 0, s>>>(d_units, all, pin_trk);
   PCS_LAUNCH_CHECK();
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   // ---- set-up, pass 2: component size, centre, diameter and validity; the anchors' own points
   for (int i = 0; i < n_units; ++i) {
-    HostUnit& h = hu[i];
+    HostUnit& h = eng->unit(slots[i]);
     UnitDev& d = h.p.d;
     h.Cu = (int)pin_trk[i].counts[0];
     if (h.Cu < 1 || h.Cu > h.C) return PCS_ERR_ARG;
@@ -1363,436 +1845,69 @@ static int run_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const 
                                                       d.diam, d.ctr, d.vcm, d.transforms, d.cmin, d.cmax,
                                                       d.centers, d.st);
   }
-  trk_anchor_emit_kernel<<<n_units, kWg, 0, s>>>(eng.d_units, all);
-  trk_publish_kernel<<<1, 64, 0, s>>>(eng.d_units, all, pin_trk);
+  trk_anchor_emit_kernel<<<n_units, kWg, 0, s>>>(d_units, all);
+  trk_publish_kernel<<<1, 64, 0, s>>>(d_units, all, pin_trk);
   PCS_LAUNCH_CHECK();
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < n_units; ++i) {
-    hu[i].host = pin_trk[i];
-    if (hu[i].host.err) return unit_error(hu[i].host.err);
-    hu[i].any_valid = hu[i].host.active != 0;
+    HostUnit& h = eng->unit(slots[i]);
+    h.host = pin_trk[i];
+    if (h.host.err) return PCS_ERR_RANGE;
+    h.any_valid = h.host.active != 0;
   }
-
-  // ---- the lock-step loop. The units are cut into a few GROUPS; a group advances in lock-step on
-  // its own stream (every launch serves all its units), and the one host thread keeps every group's
-  // next tick enqueued: while it waits for group A's state words, the ticks of groups B, C, ... run,
-  // so the single-workgroup phases of one group (sort, smooth_velo, compaction) hide behind the ICP
-  // iterations of the others.
-  static const int chunk_env = [] {
-    const char* e = getenv("PCS_TRACK_CHUNK");
-    int c = e ? atoi(e) : 0;
-    return (c >= 1 && c <= kIcpMaxChunk) ? c : 8;
-  }();
-  static const int groups_env = [] {
-    const char* e = getenv("PCS_TRACK_GROUPS");
-    int c = e ? atoi(e) : 0;
-    return (c >= 1 && c <= kMaxGroups) ? c : 4;
-  }();
-  const int chunk = chunk_env;
-  // a run under rocprofv3 takes ONE group unless PCS_PROFILE_CONCURRENT is set (same kernels, same
-  // results): the per-kernel numbers of profiles/*_sequence_kernel_stats.csv refer to that schedule.
-  // (It began as a work-around -- profiled runs with several launching threads faulted -- but the
-  // fault was the split-workgroup bug of icp_nn_kernel, fixed since.)
-  static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr && getenv("PCS_PROFILE_CONCURRENT") == nullptr;
-  const int want_groups = (prm->groups >= 1 && prm->groups <= kMaxGroups) ? prm->groups : groups_env;
-  const int G = profiled ? 1 : (want_groups < n_units ? want_groups : n_units);
-  struct Group {
-    int n, base, live;
-    int unit[kMaxBatch];
-    bool inflight;
-    Batch all, b_iter, b_fin;
-    int64_t ticks;
-    // owned by the thread that drives the group
-    hipStream_t st;
-    hipEvent_t ev;
-    IcpState *pin_icp, *pin_fin;
-    TrkState* pin_trk;
-    int rc;
-  };
-  Group grp[kMaxGroups];
-  for (int g = 0; g < G; ++g) {
-    grp[g].n = 0;
-    grp[g].inflight = false;
-    grp[g].ticks = 0;
-    grp[g].b_iter.n = grp[g].b_fin.n = 0;
-  }
-  {
-    // groups = runs of the caller's unit order (keys outermost: a group then holds units of like
-    // size); PCS_TRACK_GROUP_BY_SPAN=1 orders by window length first (measured: 216 ms against 192)
-    int order[kMaxBatch];
-    for (int i = 0; i < n_units; ++i) order[i] = i;
-    static const bool by_span = [] { const char* e = getenv("PCS_TRACK_GROUP_BY_SPAN"); return e && atoi(e) != 0; }();
-    if (by_span)
-      std::stable_sort(order, order + n_units, [&](int a, int b) {
-        return hu[a].max_f - hu[a].min_f > hu[b].max_f - hu[b].min_f;
-      });
-    for (int q = 0; q < n_units; ++q) {
-      Group& g = grp[(int64_t)q * G / n_units];
-      if (g.n == 0) g.base = order[q];
-      g.unit[g.n++] = order[q];
-    }
-  }
-  for (int g = 0; g < G; ++g) {
-    grp[g].live = grp[g].n;
-    grp[g].all.n = grp[g].n;
-    for (int e = 0; e < grp[g].n; ++e) grp[g].all.idx[e] = grp[g].unit[e];
-  }
-  LevelSizes ls;
-  for (int l = 0; l < kMaxLevels; ++l)
-    for (int k = 0; k < 3; ++k) ls.v[l][k] = l < L ? prm->voxel_size[l][k] : 1.f;
-  auto in_range = [](const HostUnit& h, int f) { return f >= h.min_f && f <= h.max_f; };
-  auto step_arg = [&](const HostUnit& h) {
-    StepArg a;
-    a.dir = h.dir;
-    a.next = h.next;
-    a.col = h.next - h.min_f;
-    a.last_col = h.last_col;
-    a.lv = h.lv;
-    a.off_n = in_range(h, h.next) ? frame_offsets[h.next] : 0;
-    a.nn = in_range(h, h.next) ? (int)(frame_offsets[h.next + 1] - frame_offsets[h.next]) : 0;
-    return a;
-  };
-
-  // decide every unit's next phase from the state words read last, enqueue the group's next tick
-  auto enqueue_tick = [&](int gi) -> int {
-    Group& gr = grp[gi];
-    hipStream_t gs = gr.st;
-    sv_grid_gate();
-    ++gr.ticks;
-    Batch b_fin, b_post, b_dir, b_step, b_smp, b_begin, b_iter;
-    Steps s_fin, s_post, s_step, s_smp;
-    b_fin.n = b_post.n = b_dir.n = b_step.n = b_smp.n = b_begin.n = b_iter.n = 0;
-    IcpHint h_fin[kMaxBatch], h_begin[kMaxBatch], h_iter[kMaxBatch];
-    BatchInts kb;
-    auto start_level = [&](int i) {  // sampling + start of the registration at hu[i].lv
-      HostUnit& h = hu[i];
-      s_smp.a[b_smp.n] = step_arg(h);
-      b_smp.idx[b_smp.n++] = i;
-      b_begin.idx[b_begin.n++] = i;
-      h.it = h.it_before = 0;
-      h.icp.iters = 0;
-      h.icp.stop_iter = INT_MAX;
-      h.icp.err = 0;
-      h.phase = PH_ICP;
-    };
-    auto start_step = [&](int i) {
-      HostUnit& h = hu[i];
-      h.lv = 0;
-      ++h.steps;
-      s_step.a[b_step.n] = step_arg(h);
-      b_step.idx[b_step.n++] = i;
-      start_level(i);
-    };
-    auto start_dir = [&](int i, int dir) -> bool {  // true if the direction has a first step
-      HostUnit& h = hu[i];
-      h.dir = dir;
-      h.next = h.anchor + dir;
-      h.last_col = (dir == 1 && h.anchor > 0) ? h.anchor : -1;
-      return in_range(h, h.next) && h.any_valid;
-    };
-    for (int e = 0; e < gr.n; ++e) {
-      const int i = gr.unit[e];
-      HostUnit& h = hu[i];
-      switch (h.phase) {
-        case PH_START: {
-          // a backward pass without a step leaves nothing behind that the forward set-up does not redo
-          bool go = start_dir(i, -1);
-          if (!go) go = start_dir(i, 1);
-          b_dir.idx[b_dir.n++] = i;
-          if (go) start_step(i);
-          else h.phase = PH_FINALWAIT;
-          break;
-        }
-        case PH_ICP: {
-          if (h.icp.err) return PCS_ERR_RANGE;
-          if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
-            s_fin.a[b_fin.n] = step_arg(h);
-            h_fin[b_fin.n] = h.hint;
-            b_fin.idx[b_fin.n++] = i;
-            ++h.reg_calls;
-            ++h.lv;
-            if (h.lv < L) {
-              start_level(i);
-            } else {
-              h.lv = L - 1;
-              s_post.a[b_post.n] = step_arg(h);
-              b_post.idx[b_post.n++] = i;
-              h.phase = PH_POSTWAIT;
-            }
-          }
-          break;
-        }
-        case PH_POSTWAIT: {
-          if (h.host.err) return unit_error(h.host.err);
-          h.last_col = h.next;
-          h.next += h.dir;
-          if (in_range(h, h.next) && h.host.active) {
-            start_step(i);
-          } else if (h.dir == -1) {
-            bool go = start_dir(i, 1);
-            b_dir.idx[b_dir.n++] = i;
-            if (go) start_step(i);
-            else h.phase = PH_FINALWAIT;
-          } else {
-            h.phase = PH_FINALWAIT;
-          }
-          break;
-        }
-        case PH_FINALWAIT: {
-          if (h.host.err) return unit_error(h.host.err);
-          h.io->info[0] = h.host.ex_count;
-          h.io->info[1] = h.reg_calls;
-          h.io->info[2] = h.steps;
-          h.io->info[3] = gr.ticks;
-          h.phase = PH_DONE;
-          --gr.live;
-          break;
-        }
-        default:
-          break;
-      }
-    }
-    gr.b_fin = b_fin;
-    gr.b_iter.n = 0;
-    if (gr.live == 0) return PCS_OK;
-    // ---- 1. registrations that stopped: l1 error, coverage, outputs; then frame <- T frame
-    if (b_fin.n) {
-      TRK_RC(icp_enqueue_finish(eng.d_icp, b_fin, h_fin, gr.pin_fin, gs));
-      int g = 1;
-      for (int e = 0; e < b_fin.n; ++e) g = max(g, nblk(max(hu[b_fin.idx[e]].na, hu[b_fin.idx[e]].C)));
-      trk_apply_T_kernel<<<dim3(g, b_fin.n), kBlock, 0, gs>>>(eng.d_units, b_fin, s_fin);
-    }
-    // ---- 2. after the last level: component motion, velocity smoothing, stop rules, harvest
-    if (b_post.n) {
-      int gc = 1, gp = 1, gq = 1;
-      float* sv_v[kMaxBatch];
-      const float* sv_d[kMaxBatch];
-      int64_t sv_C[kMaxBatch];
-      int sv_F[kMaxBatch], sv_lo[kMaxBatch], sv_hi[kMaxBatch];
-      void* sv_ws[kMaxBatch];
-      size_t sv_wsb[kMaxBatch];
-      int* sv_err[kMaxBatch];
-      int nsv = 0;
-      for (int e = 0; e < b_post.n; ++e) {
-        HostUnit& h = hu[b_post.idx[e]];
-        gc = max(gc, nblk((int64_t)h.Cu * 64));
-        gp = max(gp, nblk(max(h.na, h.C)));
-        gq = max(gq, nblk((int64_t)s_post.a[e].nn * 32));
-        int a0 = h.anchor + h.dir, b0 = h.next;
-        if (a0 != b0) {
-          sv_v[nsv] = h.p.d.velos;
-          sv_d[nsv] = h.p.d.diffs;
-          sv_C[nsv] = h.C;
-          sv_F[nsv] = h.F;
-          sv_lo[nsv] = a0 < b0 ? a0 : b0;
-          sv_hi[nsv] = a0 < b0 ? b0 : a0;
-          sv_ws[nsv] = h.p.ws_sv;
-          sv_wsb[nsv] = h.p.sv_bytes;
-          sv_err[nsv] = &h.p.d.st->err;
-          ++nsv;
-        }
-      }
-      if (gc > 2048) gc = 2048;
-      if (gq > 8192) gq = 8192;
-      trk_motion_kernel<<<dim3(gc, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
-      TRK_RC(smooth_velo_run_batch(nsv, sv_v, sv_d, sv_C, sv_F, sv_lo, sv_hi, prm->smooth_weight0,
-                                   prm->smooth_weight, prm->smooth_num_itr, prm->smooth_stopping, sv_ws,
-                                   sv_wsb, sv_err, gs));
-      trk_after_smooth_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post,
-                                                                     prm->min_move_frame, prm->reg_error_coeff,
-                                                                     prm->angle_threshold);
-      hv_insert_kernel<<<dim3(gp, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
-      hv_search_kernel<<<dim3(gq, b_post.n), kBlock, 0, gs>>>(eng.d_units, b_post, s_post);
-      hv_compact_kernel<<<b_post.n, kWg, 0, gs>>>(eng.d_units, b_post, s_post);
-    }
-    // ---- 3. direction / step set-up
-    if (b_dir.n) {
-      int g = 1;
-      for (int e = 0; e < b_dir.n; ++e) g = max(g, nblk(max(hu[b_dir.idx[e]].na, hu[b_dir.idx[e]].C)));
-      trk_dir_init_kernel<<<dim3(g, b_dir.n), kBlock, 0, gs>>>(eng.d_units, b_dir);
-    }
-    if (b_step.n) {
-      int g = 1;
-      for (int e = 0; e < b_step.n; ++e) g = max(g, nblk(max(hu[b_step.idx[e]].na, hu[b_step.idx[e]].C)));
-      trk_step_begin_kernel<<<dim3(g, b_step.n), kBlock, 0, gs>>>(eng.d_units, b_step, s_step);
-    }
-    // ---- 4. sampling of the anchor (as moved so far) and of the target frame
-    if (b_smp.n) {
-      int gv = 1;
-      for (int e = 0; e < b_smp.n; ++e) {
-        HostUnit& h = hu[b_smp.idx[e]];
-        int est = h.seen[h.lv][1] > 0 ? (int)(h.seen[h.lv][1] * 1.25) : max(h.na, h.nm) / 2;
-        gv = max(gv, nblk(est));
-      }
-      smp_sort_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(eng.d_units, b_smp, s_smp, ls);
-      smp_emit_kernel<<<dim3(gv, b_smp.n, 2), kBlock, 0, gs>>>(eng.d_units, b_smp, s_smp);
-      smp_compact_kernel<<<dim3(2, b_smp.n), kWg, 0, gs>>>(eng.d_units, b_smp);
-    }
-    // ---- 5. registrations that start: descriptor, reset, grids
-    if (b_begin.n) {
-      for (int e = 0; e < b_begin.n; ++e) {
-        const int i = b_begin.idx[e];
-        HostUnit& h = hu[i];
-        UnitDev& d = h.p.d;
-        IcpArgs ia;
-        ia.mov = (float*)d.sa.out;
-        ia.comp = d.sa.out_comp;
-        ia.ref = (const float*)d.sb.out;
-        ia.all = (const float*)d.sb.sub;
-        ia.comp_deg = (const int64_t*)d.sub_deg;
-        ia.cnt3 = &d.st->counts[1];
-        ia.Mn = h.na;
-        ia.Rn = h.nm;
-        ia.Ra = h.nm;
-        ia.C = h.C;
-        ia.radius = prm->radius[h.lv];
-        ia.frame_offset = h.next - h.anchor;
-        ia.reg = prm->angle_regularizer;
-        ia.delta = prm->stopping_delta[h.lv];
-        ia.max_iter = prm->max_iter;
-        ia.cell_size = 0.f;
-        ia.T = d.Tl;
-        ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
-        ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
-        // the descriptor travels as a kernel argument (no copy engine, no staging buffer to keep alive)
-        IcpProblem desc;
-        TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &desc));
-        trk_store_icp_kernel<<<1, 64, 0, gs>>>(eng.d_icp + i, desc);
-        // launch sizes: what this level had at the previous step, else a guess
-        const int* sn = h.seen[h.lv];
-        h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
-        h.hint.Ra = sn[1] >= 0 ? (int)(sn[1] * 1.25) + 256 : h.nm / 2 + 256;
-        h.hint.Rn = sn[2] >= 0 ? (int)(sn[2] * 1.25) + 256 : h.nm / 4 + 256;
-        h.hint.C = h.C;
-        h.hint.clear_words = 4 * (size_t)pow2_words(h.hint.Mn) + 2 * (size_t)pow2_words(h.hint.Rn) +
-                             2 * (size_t)pow2_words(h.hint.Ra);
-        h_begin[e] = h.hint;
-      }
-      TRK_RC(icp_enqueue_begin(eng.d_icp, b_begin, h_begin, gs));
-    }
-    // ---- 6. one chunk of iterations for every unit of the group that is registering
-    for (int e = 0; e < gr.n; ++e) {
-      const int i = gr.unit[e];
-      HostUnit& h = hu[i];
-      if (h.phase != PH_ICP) continue;
-      kb.v[b_iter.n] = h.it;
-      h_iter[b_iter.n] = h.hint;
-      b_iter.idx[b_iter.n++] = i;
-    }
-    if (b_iter.n) {
-      TRK_RC(icp_enqueue_chunk(eng.d_icp, b_iter, kb, chunk, h_iter, gr.pin_icp, gs, 0));
-      for (int e = 0; e < b_iter.n; ++e) {
-        HostUnit& h = hu[b_iter.idx[e]];
-        h.it_before = h.it;
-        h.it = min(h.it + chunk, prm->max_iter);
-      }
-    }
-    gr.b_iter = b_iter;
-    // ---- 7. state mirror; the event tells the host when the tick's words can be read
-    trk_publish_kernel<<<1, 64, 0, gs>>>(eng.d_units, gr.all, gr.pin_trk);
-    PCS_LAUNCH_CHECK();
-    PCS_CHECK_HIP(hipEventRecord(gr.ev, gs));
-    gr.inflight = true;
-    return PCS_OK;
-  };
-
-  // the group's tick has completed: take its state words
-  auto collect_tick = [&](int gi) -> int {
-    Group& gr = grp[gi];
-    gr.inflight = false;
-    for (int e = 0; e < gr.b_fin.n; ++e)
-      if (gr.pin_fin[e].err) return PCS_ERR_RANGE;  // the coverage query can still overflow a grid
-    for (int e = 0; e < gr.n; ++e) {
-      HostUnit& h = hu[gr.unit[e]];
-      if (h.phase == PH_DONE) continue;
-      h.host = gr.pin_trk[gr.unit[e]];
-      if (h.phase == PH_ICP) {
-        h.seen[h.lv][0] = (int)h.host.counts[1];
-        h.seen[h.lv][1] = (int)h.host.counts[2];
-        h.seen[h.lv][2] = (int)h.host.counts[3];
-      }
-    }
-    if (gr.b_iter.n) {
-      int live_j[kIcpMaxChunk];
-      double b3[3 * kIcpMaxChunk];
-      for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
-      for (int e = 0; e < gr.b_iter.n; ++e) {
-        HostUnit& h = hu[gr.b_iter.idx[e]];
-        h.icp = gr.pin_icp[e];
-        const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
-        for (int j = 0; j < chunk; ++j) {
-          if (h.it_before + 1 + j > h.icp.iters) break;
-          live_j[j] += 1;
-          b3[3 * j] += 76.0 * (Mn + Rn) + 272.0 * C;  // search (36 per query) + moments (40 per query, 272 per component)
-          b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
-        }
-      }
-      icp_profile_account(chunk, live_j, b3, 0);
-    }
-    return PCS_OK;
-  };
-
-  // one thread per group: the group's own stream, event and pinned status page
-  int device = 0;
-  PCS_CHECK_HIP(hipGetDevice(&device));
-  auto drive = [&](int gi) {
-    Group& gr = grp[gi];
-    gr.rc = PCS_OK;
-    static thread_local hipStream_t t_stream = nullptr;
-    static thread_local hipEvent_t t_event = nullptr;
-    if (hipSetDevice(device) != hipSuccess) { gr.rc = PCS_ERR_HIP; return; }
-    if (!t_stream) {
-      if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&t_event, hipEventDisableTiming) != hipSuccess) {
-        gr.rc = PCS_ERR_HIP;
-        return;
-      }
-    }
-    char* pg = (char*)thread_pinned_page();
-    if (!pg) { gr.rc = PCS_ERR_HIP; return; }
-    gr.st = t_stream;
-    gr.ev = t_event;
-    gr.pin_icp = (IcpState*)pg;
-    gr.pin_fin = (IcpState*)(pg + 2048);
-    gr.pin_trk = (TrkState*)(pg + kPinnedTrackerOff);
-    const bool tp = g_tick_profile.on;
-    long long t_begin = tp ? now_ns() : 0, t0 = t_begin;
-    int rc = enqueue_tick(gi);
-    if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; g_tick_profile.calls += 1; }
-    while (rc == PCS_OK && gr.inflight) {
-      if (tp) t0 = now_ns();
-      const long long w0 = now_ns();
-      if (hipEventSynchronize(gr.ev) != hipSuccess) { rc = PCS_ERR_HIP; break; }
-      if (now_ns() - w0 > 2000000000LL)  // diagnostic: a tick that took seconds
-        fprintf(stderr, "[pcs] tracker tick %lld of group %d completed after %.1f s (iterating units %d, finishing %d)\n",
-                (long long)gr.ticks, gi, (now_ns() - w0) / 1e9, gr.b_iter.n, gr.b_fin.n);
-      if (tp) { g_tick_profile.wait_ns += now_ns() - t0; t0 = now_ns(); }
-      rc = collect_tick(gi);
-      if (rc == PCS_OK && gr.live > 0) {
-        rc = enqueue_tick(gi);
-        if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; }
-      }
-    }
-    (void)hipStreamSynchronize(gr.st);  // nothing may still run on the workspace when the call returns
-    if (tp) g_tick_profile.total_ns += now_ns() - t_begin;
-    gr.rc = rc;
-  };
-  for (int g = 1; g < G; ++g) GroupWorkers::get().start(g, [&drive, g] { drive(g); });
-  drive(0);
-  for (int g = 1; g < G; ++g) GroupWorkers::get().wait(g);
-  for (int g = 0; g < G; ++g)
-    if (grp[g].rc) return grp[g].rc;
   return PCS_OK;
 }
 
-extern "C" {
+struct SeqIn {
+  const float* seq_fxyz;
+  const int64_t* frame_offsets;
+  int num_frames;
+  PcsTrackUnit* units;
+  int n_units;
+};
 
-size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_frames,
-                                          const PcsTrackUnit* units, int n_units) {
-  if (!frame_offsets || !units || n_units < 1 || num_frames < 1) return 0;
-  Arena a(nullptr, 0);
-  EnginePlan eng;
-  plan_engine(a, eng);
+// every sequence is prepared on the caller's stream and handed to the device's engine as soon as it
+// is ready (its units run while the next sequence is prepared); returns when all units are done
+static int run_sequences(const PcsTrackParams* prm, const SeqIn* seqs, int n_seqs, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+  if (!prm || !seqs || !ws || n_seqs < 1) return PCS_ERR_ARG;
+  if (prm->num_levels < 1 || prm->num_levels > kMaxLevels || prm->max_iter < 0) return PCS_ERR_ARG;
+  for (int q = 0; q < n_seqs; ++q) {
+    if (!seqs[q].seq_fxyz || !seqs[q].frame_offsets || !seqs[q].units) return PCS_ERR_ARG;
+    if (seqs[q].n_units < 1 || seqs[q].n_units > kMaxCallUnits || seqs[q].num_frames < 1) return PCS_ERR_ARG;
+  }
+  int device = 0;
+  PCS_CHECK_HIP(hipGetDevice(&device));
+  Engine* eng = Engine::get(device);
+  if (!eng) return PCS_ERR_HIP;
+  Call call;
+  Arena a(ws, ws_bytes);
+  int rc = PCS_OK;
+  for (int q = 0; q < n_seqs && rc == PCS_OK; ++q) {
+    int slots[kMaxCallUnits];
+    rc = eng->reserve(*prm, seqs[q].n_units, slots);
+    if (rc != PCS_OK) break;
+    rc = prepare_sequence(eng, prm, seqs[q].seq_fxyz, seqs[q].frame_offsets, seqs[q].num_frames, seqs[q].units,
+                          seqs[q].n_units, a, ws, slots, s);
+    if (rc != PCS_OK) {
+      (void)hipStreamSynchronize(s);  // nothing of the set-up may still run on the slots / the workspace
+      eng->release(slots, seqs[q].n_units);
+      break;
+    }
+    eng->submit(&call, slots, seqs[q].n_units);
+  }
+  {
+    std::unique_lock<std::mutex> lk(call.mu);
+    call.cv.wait(lk, [&] { return call.remaining == 0; });
+    if (rc == PCS_OK) rc = call.rc;
+  }
+  return rc;
+}
+
+static size_t sequence_workspace_bytes(Arena& a, const int64_t* frame_offsets, int num_frames,
+                                       const PcsTrackUnit* units, int n_units) {
+  SeqPlan sq;
+  plan_seq(a, sq);
   for (int i = 0; i < n_units; ++i) {
     const PcsTrackUnit& io = units[i];
     if (io.anchor_frame < 0 || io.anchor_frame >= num_frames || io.min_frame_id < 0 ||
@@ -1806,17 +1921,48 @@ size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_
   return a.off;
 }
 
+extern "C" {
+
+size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_frames,
+                                          const PcsTrackUnit* units, int n_units) {
+  if (!frame_offsets || !units || n_units < 1 || num_frames < 1) return 0;
+  Arena a(nullptr, 0);
+  return sequence_workspace_bytes(a, frame_offsets, num_frames, units, n_units);
+}
+
 int pcs_track_sequence(const PcsTrackParams* prm, const float* seq_fxyz, const int64_t* frame_offsets,
                        int num_frames, PcsTrackUnit* units, int n_units, void* ws, size_t ws_bytes,
                        hipStream_t s) {
-  return run_sequence(prm, seq_fxyz, frame_offsets, num_frames, units, n_units, ws, ws_bytes, s);
+  SeqIn in = {seq_fxyz, frame_offsets, num_frames, units, n_units};
+  return run_sequences(prm, &in, 1, ws, ws_bytes, s);
+}
+
+size_t pcs_track_batch_workspace_bytes(int n_seqs, const int64_t* const* frame_offsets, const int* num_frames,
+                                       const PcsTrackUnit* const* units, const int* n_units) {
+  if (n_seqs < 1 || !frame_offsets || !num_frames || !units || !n_units) return 0;
+  Arena a(nullptr, 0);
+  for (int q = 0; q < n_seqs; ++q) {
+    if (!frame_offsets[q] || !units[q] || n_units[q] < 1 || num_frames[q] < 1) return 0;
+    if (!sequence_workspace_bytes(a, frame_offsets[q], num_frames[q], units[q], n_units[q])) return 0;
+  }
+  return a.off;
+}
+
+int pcs_track_batch(const PcsTrackParams* prm, int n_seqs, const float* const* seq_fxyz,
+                    const int64_t* const* frame_offsets, const int* num_frames, PcsTrackUnit* const* units,
+                    const int* n_units, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (n_seqs < 1 || n_seqs > 1024 || !seq_fxyz || !frame_offsets || !num_frames || !units || !n_units)
+    return PCS_ERR_ARG;
+  std::vector<SeqIn> in((size_t)n_seqs);
+  for (int q = 0; q < n_seqs; ++q) in[q] = {seq_fxyz[q], frame_offsets[q], num_frames[q], units[q], n_units[q]};
+  return run_sequences(prm, in.data(), n_seqs, ws, ws_bytes, s);
 }
 
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames) {
   Arena a(nullptr, 0);
-  EnginePlan eng;
-  plan_engine(a, eng);
+  SeqPlan sq;
+  plan_seq(a, sq);
   UnitPlan p;
   plan_unit(a, n_anchor, n_frame_max, C < 1 ? 1 : C, num_frames < 1 ? 1 : num_frames, p);
   return a.off;
@@ -1851,7 +1997,8 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
   u.comp_max_frame_id = comp_max_frame_id;
   u.moving = moving;
   u.valid_comp = valid_comp;
-  int rc = run_sequence(prm, seq_fxyz, frame_offsets, num_frames, &u, 1, ws, ws_bytes, s);
+  SeqIn in = {seq_fxyz, frame_offsets, num_frames, &u, 1};
+  int rc = run_sequences(prm, &in, 1, ws, ws_bytes, s);
   for (int k = 0; k < 4; ++k) info[k] = u.info[k];
   return rc;
 }

@@ -155,12 +155,13 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
     dev = indices.device
     kv = int(ksize[0] * ksize[1] * ksize[2])
     ks, st = L.host_ints(ksize), L.host_ints(stride)
-    cap = int(lib.pcs_indice_pairs_out_capacity(L.i64(V), ks, st, L.i32(int(subm))))
+    kind = 2 if transpose else int(bool(subm))  # capacity / workspace: 0 strided, 1 submanifold, 2 transposed
+    cap = int(lib.pcs_indice_pairs_out_capacity(L.i64(V), ks, st, L.i32(kind)))
     pairs = torch.empty(kv, 2, V, dtype=torch.int32, device=dev)
     num = torch.empty(kv, dtype=torch.int32, device=dev)
     out_ids = None if subm else torch.empty(max(cap, 1), 4, dtype=torch.int32, device=dev)
     d_num = _dev_scalar(dev)
-    ws = L.workspace(lib.pcs_get_indice_pairs_workspace_bytes(L.i64(V), ks, st, L.i32(int(subm))), dev)
+    ws = L.workspace(lib.pcs_get_indice_pairs_workspace_bytes(L.i64(V), ks, st, L.i32(kind)), dev)
     L.check(lib.pcs_get_indice_pairs(L.ptr(indices), L.i64(V), L.i32(batch_size),
                                      L.host_ints(out_shape), L.host_ints(spatial_shape), ks, st,
                                      L.host_ints(padding), L.host_ints(dilation), L.i32(int(subm)),
@@ -714,9 +715,9 @@ class TrackParams(__import__("ctypes").Structure):
 
 def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
-                 smooth=(1.0, 10.0, 300, 1e-3), groups=0):
+                 smooth=(1.0, 10.0, 300, 1e-3)):
     prm = TrackParams()
-    prm.groups = int(groups)  # lock-step groups of track_sequence; 0 = the library's default
+    prm.groups = 0  # (ignored by the library: the units of all calls share the device's lock-step engine)
     L_ = len(radius_list)
     if not (1 <= L_ <= 4 and len(voxel_size_list) == L_ and len(stopping_delta) == L_):
         raise L.PcsError("track_params: 1..4 registration levels with matching voxel sizes / deltas")
@@ -756,24 +757,11 @@ class TrackUnit(__import__("ctypes").Structure):
     ]
 
 
-MAX_TRACK_UNITS = 32  # kMaxBatch of the native tracker
+MAX_TRACK_UNITS = 32  # units one sequence may hand over (kMaxCallUnits of the native tracker)
 
 
-def track_sequence(prm, seq_fxyz, frame_offsets, units):
-    """All tracking units of a sequence in ONE native call (pcs_track_sequence): one host thread
-    advances them in lock-step on the current stream, every launch serves all units in the same
-    phase. `units`: list of dicts with keys component (int64 [N]), stationary (bool/uint8 [N]),
-    anchor_frame, min_frame_id, max_frame_id, comp_base, num_components. Returns one
-    (out dict, (rows, registration calls, frame steps)) per unit, as ops.track_frame would."""
-    import ctypes
-    L.require_gpu(seq_fxyz, "track_sequence")
-    lib = L.load()
-    dev = seq_fxyz.device
-    assert seq_fxyz.is_contiguous() and seq_fxyz.dtype == torch.float32 and seq_fxyz.shape[1] == 4
-    if not (1 <= len(units) <= MAX_TRACK_UNITS):
-        raise L.PcsError(f"track_sequence: 1..{MAX_TRACK_UNITS} units per call")
-    nf = len(frame_offsets) - 1
-    offs = (ctypes.c_int64 * (nf + 1))(*[int(v) for v in frame_offsets])
+def _track_unit_array(dev, frame_offsets, units):
+    """ctypes TrackUnit array + output tensors + the tensors that must outlive the call."""
     arr = (TrackUnit * len(units))()
     outs, keep = [], []
     for i, u in enumerate(units):
@@ -804,13 +792,10 @@ def track_sequence(prm, seq_fxyz, frame_offsets, units):
                   "comp_velos", "comp_min_frame_id", "comp_max_frame_id", "moving", "valid_comp"):
             setattr(t, k, out[k].data_ptr())
         outs.append(out)
-    nbytes = lib.pcs_track_sequence_workspace_bytes(offs, L.i32(nf), arr, L.i32(len(units)))
-    if nbytes == 0:
-        raise L.PcsError("pcs_track_sequence_workspace_bytes: bad unit description")
-    ws = L.workspace(nbytes, dev)
-    L.check(lib.pcs_track_sequence(ctypes.byref(prm), L.ptr(seq_fxyz), offs, L.i32(nf), arr,
-                                   L.i32(len(units)), L.ptr(ws), L.i64(ws.numel()), L.stream()),
-            "pcs_track_sequence")
+    return arr, outs, keep
+
+
+def _track_results(arr, outs):
     res = []
     for i, out in enumerate(outs):
         info = arr[i].info
@@ -822,6 +807,71 @@ def track_sequence(prm, seq_fxyz, frame_offsets, units):
         out["_ticks"] = int(info[3])
         res.append((out, (n_ex, int(info[1]), int(info[2]))))
     return res
+
+
+def track_sequence(prm, seq_fxyz, frame_offsets, units):
+    """All tracking units of a sequence in ONE native call (pcs_track_sequence): they join the
+    device's lock-step engine (one driver thread and stream per device: every launch serves all units of
+    all calls that are in the same phase) and the call returns when they are done.
+    `units`: list of dicts with keys component (int64 [N]), stationary (bool/uint8 [N]),
+    anchor_frame, min_frame_id, max_frame_id, comp_base, num_components. Returns one
+    (out dict, (rows, registration calls, frame steps)) per unit, as ops.track_frame would."""
+    import ctypes
+    L.require_gpu(seq_fxyz, "track_sequence")
+    lib = L.load()
+    dev = seq_fxyz.device
+    assert seq_fxyz.is_contiguous() and seq_fxyz.dtype == torch.float32 and seq_fxyz.shape[1] == 4
+    if not (1 <= len(units) <= MAX_TRACK_UNITS):
+        raise L.PcsError(f"track_sequence: 1..{MAX_TRACK_UNITS} units per call")
+    nf = len(frame_offsets) - 1
+    offs = (ctypes.c_int64 * (nf + 1))(*[int(v) for v in frame_offsets])
+    arr, outs, keep = _track_unit_array(dev, frame_offsets, units)
+    nbytes = lib.pcs_track_sequence_workspace_bytes(offs, L.i32(nf), arr, L.i32(len(units)))
+    if nbytes == 0:
+        raise L.PcsError("pcs_track_sequence_workspace_bytes: bad unit description")
+    ws = L.workspace(nbytes, dev)
+    L.check(lib.pcs_track_sequence(ctypes.byref(prm), L.ptr(seq_fxyz), offs, L.i32(nf), arr,
+                                   L.i32(len(units)), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_track_sequence")
+    del keep
+    return _track_results(arr, outs)
+
+
+def track_batch(prm, sequences):
+    """The tracking units of SEVERAL sequences in one native call (pcs_track_batch), from one host
+    thread. `sequences`: list of (seq_fxyz, frame_offsets, units) as for track_sequence. Returns one
+    result list per sequence; each unit's results are those of track_sequence / track_frame, bit for bit."""
+    import ctypes
+    lib = L.load()
+    n = len(sequences)
+    if n < 1:
+        return []
+    dev = sequences[0][0].device
+    p_fxyz = (ctypes.c_void_p * n)()
+    p_offs = (ctypes.POINTER(ctypes.c_int64) * n)()
+    p_units = (ctypes.POINTER(TrackUnit) * n)()
+    nfs, nus = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    held = []
+    for q, (seq_fxyz, frame_offsets, units) in enumerate(sequences):
+        L.require_gpu(seq_fxyz, "track_batch")
+        assert seq_fxyz.is_contiguous() and seq_fxyz.dtype == torch.float32 and seq_fxyz.shape[1] == 4
+        if not (1 <= len(units) <= MAX_TRACK_UNITS):
+            raise L.PcsError(f"track_batch: 1..{MAX_TRACK_UNITS} units per sequence")
+        nf = len(frame_offsets) - 1
+        offs = (ctypes.c_int64 * (nf + 1))(*[int(v) for v in frame_offsets])
+        arr, outs, keep = _track_unit_array(dev, frame_offsets, units)
+        held.append((offs, arr, outs, keep))
+        p_fxyz[q] = seq_fxyz.data_ptr()
+        p_offs[q] = ctypes.cast(offs, ctypes.POINTER(ctypes.c_int64))
+        p_units[q] = ctypes.cast(arr, ctypes.POINTER(TrackUnit))
+        nfs[q], nus[q] = nf, len(units)
+    nbytes = lib.pcs_track_batch_workspace_bytes(L.i32(n), p_offs, nfs, p_units, nus)
+    if nbytes == 0:
+        raise L.PcsError("pcs_track_batch_workspace_bytes: bad unit description")
+    ws = L.workspace(nbytes, dev)
+    L.check(lib.pcs_track_batch(ctypes.byref(prm), L.i32(n), p_fxyz, p_offs, nfs, p_units, nus, L.ptr(ws),
+                                L.i64(ws.numel()), L.stream()), "pcs_track_batch")
+    return [_track_results(arr, outs) for _, arr, outs, _ in held]
 
 
 def track_frame(prm, seq_fxyz, seq_component, seq_stationary, frame_offsets, anchor_frame,

@@ -24,6 +24,19 @@ from .registration_utils import (IndexSegments, efficient_robust_sum, register_t
                                  robust_mean, robust_median, segment_max, segment_min)
 
 
+HOST_FALLBACKS = 0  # sequences that left the native tracker for the op-by-op host loop (bench.py reports it)
+_FALLBACK_LOCK = __import__("threading").Lock()
+
+
+def note_host_fallback(sequence_id, err):
+    global HOST_FALLBACKS
+    import sys
+    with _FALLBACK_LOCK:
+        HOST_FALLBACKS += 1
+    print(f"[pcs] ClusterTracking: sequence {sequence_id}: native tracker returned {err}; "
+          f"tracking this sequence through the op-by-op host loop (slow path)", file=sys.stderr, flush=True)
+
+
 def sample_frame(grid_sampler, frame):
     """Voxel-subsample a frame: mean of fxyz / stationary, median of component / frame ids
     (cluster_tracking.py:39-51)."""
@@ -143,9 +156,6 @@ class ClusterTracking(nn.Module):
         self.num_registration_calls = 0
         # NATIVE_TRACKER: run track_frame's loop in pcs_track_frame (default) or op by op
         self.native = bool(model_cfg.get("NATIVE_TRACKER", True))
-        # TRACK_GROUPS: lock-step groups (streams + host threads) inside the native call; 0 = the library's
-        # default (4). SimpleReg sets 1 on the copies that track several sequences of a batch at once.
-        self.track_groups = int(model_cfg.get("TRACK_GROUPS", 0))
         self._track_params = None
 
     # ------------------------------------------------------------------ boxes
@@ -360,8 +370,7 @@ class ClusterTracking(nn.Module):
             self._track_params = ops.track_params(
                 self.radius_list, self.voxel_size_list, self.stopping_delta,
                 self.model_cfg["ANGLE_REGULARIZER"], self.nn_graph.radius, self.reg_error_coeff,
-                self.angle_threshold, self.min_move_frame, max_iter=80, groups=self.track_groups)
-        self._track_params.groups = int(self.track_groups)
+                self.angle_threshold, self.min_move_frame, max_iter=80)
         return self._track_params
 
     def _native_window(self, offsets, frame_id):
@@ -750,6 +759,9 @@ class ClusterTracking(nn.Module):
             except PcsError as err:
                 if "PCS_ERR_RANGE" not in str(err):
                     raise
+                # a search grid / fixed-point range overflowed inside the native tracker: the op-by-op
+                # host loop gives the same results, two orders of magnitude slower -- never silently
+                note_host_fallback(sequence_id, err)
         run_deferred(seq_dict)  # (already done beside the native call when that ran)
         extracted_list = []
         for i, (comp_key, frame_id) in enumerate(units):

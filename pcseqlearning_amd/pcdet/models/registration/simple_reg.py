@@ -62,9 +62,10 @@ class SimpleReg(RegistrationTemplate):
         `inflight` of them are processed at once, each on its own host thread, HIP stream and private copy
         of the preprocessor modules (made per call: they hold no parameters, only small configuration
         objects; nothing of a worker outlives the call). A sequence's tracking stage is a chain of small,
-        latency-bound launches, so several chains side by side fill the device where one cannot; the
-        tracker copies take ONE lock-step group each (the batch supplies the concurrency). Results do not
-        depend on what runs beside a sequence (tests/test_gpu_backbone_pipeline.py)."""
+        latency-bound launches whose duration hardly depends on their width: the native tracker merges the
+        units of ALL sequences in flight into the launches of one lock-step engine (pcs_track_sequence),
+        while the ground / proposal / extraction stages of the other sequences run on their own streams.
+        Results do not depend on what runs beside a sequence (tests/test_gpu_backbone_pipeline.py)."""
         import copy
         import threading
         device = batch_dict["point_bxyz"].device
@@ -84,10 +85,6 @@ class SimpleReg(RegistrationTemplate):
                 import time
                 time.sleep(stagger * i)
             mods = copy.deepcopy(self.preprocessors)
-            for m in mods:
-                if hasattr(m, "track_groups"):
-                    m.track_groups = 1
-                    m._track_params = None
             try:
                 with pooled_stream(device) as stream:
                     stream.wait_stream(main)
@@ -97,7 +94,11 @@ class SimpleReg(RegistrationTemplate):
                                 if not queue or errors:
                                     break
                                 b = queue.pop(0)
-                            results[b] = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                            out = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                            for v in out.values():  # the caller's stream consumes what this stream allocated
+                                if isinstance(v, torch.Tensor) and v.is_cuda:
+                                    v.record_stream(main)
+                            results[b] = out
                         stream.synchronize()
             except BaseException as e:  # re-raised on the calling thread
                 with lock:
@@ -185,11 +186,9 @@ class SimpleReg(RegistrationTemplate):
             sequence_id = batch_dict["frame_id"][b][0][:-4]
             return save_dir is not None and os.path.exists(f"{save_dir}/{sequence_id}/all.pth")
 
-        # SEQUENCES_IN_FLIGHT (default 4): how many sequences of a batch are processed at once
-        inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 4)), batch_size)
-        if os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("PCS_PROFILE_CONCURRENT"):
-            inflight = 1  # profiled runs take one sequence at a time (comparable per-kernel numbers);
-            # PCS_PROFILE_CONCURRENT=1 profiles the batch mode as it runs (tools/profile_concurrent.sh)
+        # SEQUENCES_IN_FLIGHT (default 12): how many sequences of a batch are processed at once (their
+        # tracking units share the launches of the device's lock-step engine)
+        inflight = min(int(self.model_cfg.get("SEQUENCES_IN_FLIGHT", 12)), batch_size)
         todo = [b for b in range(batch_size) if not done_before(b)]
         processed = {}
         if inflight > 1 and len(todo) > 1 and batch_dict["point_bxyz"].is_cuda:

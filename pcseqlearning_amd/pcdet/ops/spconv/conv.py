@@ -132,6 +132,16 @@ class SubMConv3d(SparseConvolution):
                          bias, True, indice_key=indice_key)
 
 
+class SparseConvTranspose3d(SparseConvolution):
+    """Transposed sparse conv (conv.py:308-331): every input emits its whole kernel footprint
+    (getIndicePairsDeConv, geometry.h:197-245); output shape = get_deconv_output_size."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, transposed=True, indice_key=indice_key)
+
+
 class SparseInverseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
         super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,

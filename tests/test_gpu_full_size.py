@@ -121,8 +121,8 @@ def test_full_size_transforms_are_rigid():
         assert len(glob.glob(f"{tmp}/ClusterTracking/*/all.pth")) == 1
 
 
-def test_tracker_soak_four_groups():
-    """The lock-step tracker 60 times over on the full-size sequence with its four groups in flight.
+def test_tracker_soak():
+    """The lock-step tracker 60 times over on the full-size sequence (9 units in the device's engine).
     Before the stop gate of icp_nn_kernel was made uniform per workgroup, one such run in ~50 ended in
     a GPU memory fault ("The split-workgroup fault"); identical outputs every time
     are checked as well (integer moments, exact neighbours: nothing depends on the schedule)."""
@@ -153,3 +153,39 @@ def test_tracker_soak_four_groups():
         model(batch)
     torch.cuda.synchronize()
     assert len(seen) == 60 and all(s == seen[0] for s in seen)
+
+
+def test_tracker_soak_batch_of_four_sequences():
+    """Batches of four full-size sequences, all in flight (36 units sharing the launches of the engine,
+    joining and leaving at different ticks), 12 times over: every repetition gives every sequence the
+    same outputs, no step takes more than 1.5 x the median (the round-2 schedule froze for 20-70 s a few
+    times per 40 steps: a software grid barrier inside smooth_velo), no sequence leaves the native path."""
+    import time
+    import bench
+    from pcseqlearning_amd import synthetic
+    from pcseqlearning_amd.pcdet import models
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
+    from tools.run_sequence import build_model
+    hosts = [bench.load_sequence(s, 20, 160000) for s in range(4)]
+    batch = models.load_data_to_gpu(synthetic.collate_sequences(hosts))
+    model = build_model(save=False, device=DEV)
+    model.model_cfg["SEQUENCES_IN_FLIGHT"] = 4
+    fallbacks0 = CT.HOST_FALLBACKS
+    sigs, times = [], []
+    for rep in range(13):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model(batch)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        sig = []
+        for out in model.last_outputs:
+            res = out["cluster_tracking_results"]
+            sig.append([(k, int(v["fxyz"].shape[0]), int(v["original_indices"].sum().item()))
+                        for k, v in sorted(res.items())])
+        sigs.append(sig)
+    assert all(s == sigs[0] for s in sigs)
+    assert CT.HOST_FALLBACKS == fallbacks0
+    steady = sorted(times[1:])
+    assert steady[-1] < 1.5 * steady[len(steady) // 2], times

@@ -45,23 +45,38 @@ def test_smooth_velo_many_components_vs_oracle():
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-5)
 
 
-def test_smooth_velo_batch_more_workgroups_than_the_chip_holds():
-    """Seven multi-workgroup problems of ~54 workgroups each in ONE call: 380 workgroups of 1024 threads,
-    and the chip keeps 256 resident (one per CU at the kernel's 87 registers). All at a barrier in one
-    launch would wait for ever (the time-out, then a silent fallback: seen as a 50 s stall once in ~100
-    sequences of a batch); the call packs them under a residency budget. Results = separate calls,
-    bit for bit; two small problems ride along in the other kernel forms."""
+def test_smooth_velo_batch_many_multi_workgroup_problems():
+    """Fifty-two problems in ONE call -- more than one job list holds (48), so the call spans two sets of
+    launches; seven of them run on ~400 workgroups each (2800 workgroups of 256 threads: far more than the
+    chip keeps resident, which is why the multi-workgroup form has no barrier: window pass, last-arrival
+    decision, replay), some stop in the first window, some need several, some run to num_itr; small
+    problems ride along in the one-workgroup form. Results = separate calls, bit for bit."""
     rng = np.random.default_rng(11)
-    shapes = [(20000, 20, 4, 14)] * 7 + [(300, 20, 9, 2), (5, 20, 0, 19)]
-    probs, want = [], []
-    for C, F, a, b in shapes:
-        diffs = (rng.standard_normal((C, F, 3)) * 0.3).astype(np.float32)
-        velos = (diffs + rng.standard_normal((C, F, 3)) * 0.05).astype(np.float32)
+    shapes = [(20000, 20, 4, 14)] * 7 + [(300, 20, 9, 2), (5, 20, 0, 19)] + [(1500 + 37 * i, 17, 8, 8 + 1 + i % 8)
+                                                                               for i in range(43)]
+    probs, want, iters = [], [], []
+    for q, (C, F, a, b) in enumerate(shapes):
+        diffs = (rng.standard_normal((C, F, 3)) * (0.3 if q % 3 else 0.01)).astype(np.float32)
+        velos = (diffs + rng.standard_normal((C, F, 3)) * (0.05 if q % 3 else 0.002)).astype(np.float32)
         want.append(ops.smooth_velo(dev(velos.copy()), dev(diffs), a, b).cpu().numpy())
         probs.append((dev(velos.copy()), dev(diffs), a, b))
     got = ops.smooth_velo_batch(probs)
     for g_, w_ in zip(got, want):
         np.testing.assert_array_equal(g_.cpu().numpy(), w_)
+
+
+def test_smooth_velo_multi_workgroup_vs_oracle_step_counts():
+    """The multi-workgroup form against the oracle where the stop rule fires in the first window, in a
+    later window, and never (num_itr reached): same iterate to 2e-5 means the same number of steps."""
+    from oracle import track_oracle as T
+    rng = np.random.default_rng(23)
+    for scale, noise in ((0.004, 0.001), (0.05, 0.02), (0.3, 0.05)):
+        C, F, a, b = 2500, 17, 8, 15
+        diffs = (rng.standard_normal((C, F, 3)) * scale).astype(np.float32)
+        velos = (diffs + rng.standard_normal((C, F, 3)) * noise).astype(np.float32)
+        want = T.smooth_velo(velos.copy(), diffs, a, b)
+        got = ops.smooth_velo(dev(velos.copy()), dev(diffs), a, b)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-5)
 
 
 def _seq_points(g):
@@ -173,6 +188,59 @@ def test_track_frame_native_vs_host():
             np.testing.assert_allclose(host.last_track_debug[key].cpu().numpy(),
                                        nat.last_track_debug[key].cpu().numpy(), rtol=0, atol=1e-6,
                                        err_msg=key)
+
+
+def _units_of(tracker, sp, anchors):
+    offsets = sp.frame_offsets
+    comp, stat = sp.component.long().contiguous(), sp.stationary.to(torch.uint8).contiguous()
+    units = []
+    for frame_id in anchors:
+        lo, hi = offsets[frame_id], offsets[frame_id + 1]
+        cmin, cmax = int(comp[lo:hi].min()), int(comp[lo:hi].max())
+        w0, w1 = tracker._native_window(offsets, frame_id)
+        units.append(dict(component=comp, stationary=stat, anchor_frame=frame_id, min_frame_id=w0,
+                          max_frame_id=w1, comp_base=cmin, num_components=cmax - cmin + 1))
+    return units
+
+
+def test_track_batch_vs_track_sequence_vs_track_frame():
+    """pcs_track_batch (several sequences handed to the device's lock-step engine by one call),
+    pcs_track_sequence (one sequence per call; here also from three host threads at once, so that units
+    of different calls share launches and join / leave at different ticks) and pcs_track_frame (one
+    unit): every unit's outputs identical, bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = np.load(os.path.join(G, "track_small.npz"))
+    tracker, sp = _tracker(), _prepare(g, native=True)
+    if sp.frame_perm is not None:  # rows grouped by ascending frame, as the native entries take them
+        for k in ("fxyz", "component", "stationary"):
+            sp[k] = sp[k][sp.frame_perm].contiguous()
+    prm = tracker._native_params()
+    anchors = [f for f in (0, 8, 16) if (g["fxyz"][:, 0] == f).any()]
+    fxyz = sp.fxyz.contiguous()
+    seqs = [(fxyz, sp.frame_offsets, _units_of(tracker, sp, anchors)),
+            (fxyz, sp.frame_offsets, _units_of(tracker, sp, anchors[:1])),
+            (fxyz, sp.frame_offsets, _units_of(tracker, sp, anchors[::-1]))]
+    batch = ops.track_batch(prm, seqs)
+    one_by_one = [ops.track_sequence(prm, *q) for q in seqs]
+
+    def worker(q):
+        with torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+            return ops.track_sequence(prm, *q)
+
+    torch.cuda.synchronize()
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        threaded = list(pool.map(worker, seqs))
+    keys = ("ex_index", "ex_local", "ex_component", "transforms", "reg_errors", "comp_edge_ratios", "comp_velos",
+            "comp_min_frame_id", "comp_max_frame_id", "moving", "valid_comp")
+    for q, (fx, offs, units) in enumerate(seqs):
+        for i, u in enumerate(units):
+            single, info = ops.track_frame(prm, fx, u["component"], u["stationary"], offs, u["anchor_frame"],
+                                           u["min_frame_id"], u["max_frame_id"], u["comp_base"], u["num_components"])
+            for other in (batch, one_by_one, threaded):
+                out, info2 = other[q][i]
+                assert info2 == info
+                for k in keys:
+                    assert torch.equal(out[k], single[k]), (q, i, k)
 
 
 def test_track_frame_with_empty_frames_in_the_window():

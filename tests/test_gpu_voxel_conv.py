@@ -294,3 +294,41 @@ def test_bn_fold_kernel_matches_the_tensor_ops():
             shift = shift + bn.bias.float()
         s2, h2 = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         assert torch.equal(s2, scale) and torch.equal(h2, shift)
+
+
+def test_deconv_rulebook_and_transposed_conv(oracle):
+    """Transposed conv (getIndicePairsDeConv, geometry.h:197-245; SparseConvTranspose3d, conv.py:308-331):
+    the HIP rulebook bit-exact against the reference's own outputs (tests/golden/deconvbook_*.npz) and
+    against the oracle on larger random inputs; the module's features against the oracle's
+    gather-GEMM-scatter over the same rulebook."""
+    from pcseqlearning_amd.pcdet.ops import spconv
+    from tests.golden.make_golden import random_indices
+    from tests.golden.make_golden_deconv import DECONV_CASES
+    for name, shape, ks, st, pd, dl, opad in DECONV_CASES:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"deconvbook_{name}.npz"))
+        out_ids, pairs, num = ops.get_indice_pairs(dev(g["indices"]), 2, list(g["out_shape"]), list(g["spatial_shape"]),
+                                                   list(ks), list(st), list(pd), list(dl), False, transpose=True)
+        np.testing.assert_array_equal(num.cpu().numpy(), g["num"])
+        np.testing.assert_array_equal(out_ids.cpu().numpy(), g["out_ids"])
+        np.testing.assert_array_equal(pairs.cpu().numpy(), g["pairs"])
+    rng = np.random.default_rng(31)
+    shape, ks, st, pd, dl, opad = [21, 80, 72], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], [1, 1, 1]
+    idx = random_indices(rng, shape, 20000, batch=2)
+    out_shape = oracle.deconv_out_shape(shape, ks, st, pd, dl, opad)
+    want = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, dl, False, transpose=True)
+    out_ids, pairs, num = ops.get_indice_pairs(dev(idx), 2, out_shape, shape, ks, st, pd, dl, False, transpose=True)
+    np.testing.assert_array_equal(num.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(out_ids.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(pairs.cpu().numpy(), want[1])
+    # the module: 16 -> 32 channels
+    feat = rng.normal(0, 1, (idx.shape[0], 16)).astype(np.float32)
+    conv = spconv.SparseConvTranspose3d(16, 32, 3, stride=2, padding=1, bias=True, indice_key="up").to(DEV)
+    conv.output_padding = [1, 1, 1]
+    x = spconv.SparseConvTensor(dev(feat), dev(idx), shape, 2)
+    with torch.no_grad():
+        y = conv(x)
+    assert list(y.spatial_shape) == out_shape
+    np.testing.assert_array_equal(y.indices.cpu().numpy(), want[0])
+    W = conv.weight.detach().cpu().numpy()
+    ref = oracle.indice_conv(feat, W, want[1], want[2], want[0].shape[0], False, False) + conv.bias.detach().cpu().numpy()
+    np.testing.assert_allclose(y.features.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)

@@ -179,3 +179,26 @@ def test_maxpool_oracle_vs_reference(oracle, name):
     got = oracle.indice_maxpool(c["features"], c["pairs"], c["num"], c["out_ids"].shape[0])
     np.testing.assert_array_equal(got, want_out)
     np.testing.assert_array_equal(oracle.indice_maxpool_backward(c["features"], got, c["out_grad"], c["pairs"], c["num"]), want_din)
+
+
+from tests.golden.make_golden_deconv import DECONV_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv_rulebook_vs_compiled_reference_and_golden(oracle, case):
+    """Transposed-conv rulebook: the oracle against the reference's own getIndicePairsDeConv compiled in
+    place (where oracle/_ref exists; that run also (re)writes nothing) and against the committed golden
+    vectors it produced (tests/golden/deconvbook_*.npz)."""
+    name, shape, ks, st, pd, dl, opad = case
+    out_shape = oracle.deconv_out_shape(shape, ks, st, pd, dl, opad)
+    rng = np.random.default_rng(abs(hash(name)) % 2**31)
+    if oracle.ref_available():
+        for n in (1, 40, 1500):
+            idx = random_indices(rng, shape, n, batch=3)
+            want = oracle.ref_get_indice_pairs_deconv(idx, 3, out_shape, ks, st, pd, dl)
+            got = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, dl, False, transpose=True)
+            _check_rulebook(got, want)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"deconvbook_{name}.npz"))
+    got = oracle.get_indice_pairs(g["indices"], g["out_shape"], g["ksize"], g["stride"], g["padding"],
+                                  g["dilation"], False, transpose=True)
+    _check_rulebook(got, (g["out_ids"], g["pairs"], g["num"]))

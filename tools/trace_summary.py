@@ -1,0 +1,77 @@
+"""Per-kernel and per-queue summary of a rocprofv3 --kernel-trace run (second half = steady state):
+  python tools/trace_summary.py <..._kernel_trace.csv> [top]
+Per kernel: launches, total ms, mean / median us, mean grid size (workgroups), and the share of the
+window; per queue: launches, busy ms; overall: time-weighted mean number of kernels running. For the
+three ICP iteration kernels: mean duration by number of batch entries (gridDim.y where it is the
+entry count) and by how many other kernels ran beside them."""
+import bisect
+import collections
+import csv
+import sys
+
+
+def main():
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    rows = []
+    for r in csv.DictReader(open(sys.argv[1])):
+        wg = int(r.get("Workgroup_Size", 0) or 0)
+        gs = int(r.get("Grid_Size", 0) or 0)
+        gy = int(r.get("Grid_Size_Y", 0) or 0)
+        wy = int(r.get("Workgroup_Size_Y", 1) or 1)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0],
+                     r.get("Queue_Id", "?"), gs // max(wg, 1), gy // max(wy, 1)))
+    rows.sort()
+    t0 = rows[0][0]
+    tmid = t0 + (max(r[1] for r in rows) - t0) // 2
+    rows = [r for r in rows if r[0] >= tmid]
+    span = max(r[1] for r in rows) - rows[0][0]
+    print(f"window {span / 1e6:.1f} ms, {len(rows)} dispatches")
+    per_k = collections.defaultdict(list)
+    per_q = collections.defaultdict(lambda: [0, 0])
+    grid = collections.defaultdict(int)
+    for s, e, n, q, g, gy in rows:
+        per_k[n].append(e - s)
+        grid[n] += g
+        per_q[q][0] += 1
+        per_q[q][1] += e - s
+    tot = sum(sum(v) for v in per_k.values())
+    print(f"sum of kernel durations {tot / 1e6:.1f} ms = {tot / span:.2f} x the window")
+    print(f"{'kernel':58s} {'calls':>8s} {'total ms':>9s} {'mean us':>8s} {'med us':>7s} {'mean WGs':>9s} {'% sum':>6s}")
+    for n, v in sorted(per_k.items(), key=lambda kv: -sum(kv[1]))[:top]:
+        v2 = sorted(v)
+        print(f"{n[-58:]:58s} {len(v):8d} {sum(v) / 1e6:9.2f} {sum(v) / len(v) / 1e3:8.1f} {v2[len(v2) // 2] / 1e3:7.1f} "
+              f"{grid[n] / len(v):9.0f} {100 * sum(v) / tot:6.1f}")
+    for q, (c, b) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
+        print(f"  queue {q}: {c} dispatches, busy {b / 1e6:.1f} ms ({100 * b / span:.1f} % of the window)")
+    ev = []
+    for s, e, *_ in rows:
+        ev.append((s, 1))
+        ev.append((e, -1))
+    ev.sort()
+    level, last, hist = 0, ev[0][0], collections.Counter()
+    for t, d in ev:
+        hist[level] += t - last
+        last = t
+        level += d
+    tt = sum(hist.values())
+    print("time at concurrency level (%):", {k: round(100 * v / tt, 1) for k, v in sorted(hist.items())})
+    print("mean kernels running:", round(sum(k * v for k, v in hist.items()) / tt, 2))
+    starts = sorted((s, e) for s, e, *_ in rows)
+    ss = [s for s, _ in starts]
+    for name in ("pcs::icp_nn_kernel", "pcs::icp_nn_search_kernel", "pcs::icp_apply_kernel", "pcs::smp_sort_kernel"):
+        by_n, by_c = collections.defaultdict(list), collections.defaultdict(list)
+        for s, e, n, q, g, gy in rows:
+            if n != name:
+                continue
+            by_n[min(gy // 16 * 16, 128)].append(e - s)
+            mid = (s + e) // 2
+            hi = bisect.bisect_right(ss, mid)
+            lo = max(0, hi - 64)
+            c = sum(1 for a, b in starts[lo:hi] if b > mid) - 1
+            by_c[min(c, 8)].append(e - s)
+        print(name, "by entries (gridDim.y, bins of 16):", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_n.items())})
+        print(name, "by kernels beside it:", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_c.items())})
+
+
+if __name__ == "__main__":
+    main()
