@@ -89,14 +89,16 @@ def load_sequence(seed, frames, points):
     return batch
 
 
-def load_sequences(seeds, frames, points):
+def load_sequences(seeds, frames, points, world=1):
     """The rank's sequences; the ones not cached yet are generated side by side in child processes
-    (~40 s of numpy ray casting each). Called before this process touches the GPU."""
+    (~40 s of numpy ray casting each; the /tmp cache is keyed by seed, so ranks never generate the same
+    sequence twice and a later run finds them all). Called before this process touches the GPU. With
+    `world` ranks on the host each rank takes its share of the cores (all ranks generate at once)."""
     missing = [s for s in seeds if not os.path.exists(f"/tmp/pcs_seq_s{s}_f{frames}_p{points}.pkl")]
     if len(missing) > 1:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
-        workers = max(1, min(len(missing), (os.cpu_count() or 2) // 2))
+        workers = max(1, min(len(missing), (os.cpu_count() or 2) // (2 * max(1, world))))
         with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
             list(pool.map(_generate_sequence, [(s, frames, points) for s in missing]))
     return [load_sequence(s, frames, points) for s in seeds]
@@ -265,7 +267,7 @@ def main():
 
     seeds = sequences_of_rank(rank, world, max(1, args.batch))  # every step re-tracks the rank's batch
     # (before this process initialises the GPU: the generator runs in child processes)
-    host_batches = None if args.dry_run else load_sequences(seeds, args.frames, args.points)
+    host_batches = None if args.dry_run else load_sequences(seeds, args.frames, args.points, world)
 
     import torch
     dist = None

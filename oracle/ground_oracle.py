@@ -216,3 +216,121 @@ def ground_plane_removal(point_bxyz, cfg, normal_sign="lapack", debug=None):
     v_height = vox[:, -1] - v_h
     err = v_height - v_min
     return v_height[inv], horizon[inv], err[inv], pillars["height"], pillars["min_z"]
+
+
+# ------------------------------------------------------------------------------------------------
+# Canonical form: the same stage with every floating-point operation in the order of the HIP path
+# (oracle/pcs_oracle_ground.cpp restates the kernels; the elementwise steps between them are written
+# here op for op like pcseqlearning_amd/pcdet/.../preprocessor_utils.py). The numpy form above says
+# WHAT the reference computes and is pinned to the reference's own outputs; this form is pinned to
+# the numpy form by tolerance (tests/test_oracle_ground.py) and demands bit equality from the HIP path
+# (tests/test_gpu_ground.py: identical kept-point masks, identical heights).
+def _seg_of(index, n):
+    """sorted-unique segment structure of an index array: (ids, order, seg_start) like pcs_unique_i64"""
+    order = np.argsort(index, kind="stable").astype(np.int32)
+    sidx = index[order]
+    ids, first = np.unique(sidx, return_index=True)
+    seg_start = np.concatenate([first, [len(index)]]).astype(np.int32)
+    return ids, order, seg_start
+
+
+def _reduce_mode(data, index, n, mean, mode):
+    """efficient_robust_sum / robust_mean of the HIP path: ordered sums in the kernel's tree (mode 1: one
+    wave per segment, 2: one workgroup per segment), dense [n, ...] with zeros for empty segments."""
+    import ctypes
+    L = O.lib()
+    ids, order, seg_start = _seg_of(index, n)
+    d2 = np.ascontiguousarray(data.reshape(len(data), -1), np.float32)
+    out = np.zeros((len(ids), d2.shape[1]), np.float32)
+    L.orc_segment_reduce_f32_mode(O._p(d2), ctypes.c_int(d2.shape[1]), O._p(order), O._p(seg_start),
+                                  ctypes.c_int64(len(ids)), ctypes.c_int(int(mean)), ctypes.c_int(mode), O._p(out))
+    dense = np.zeros((n, d2.shape[1]), np.float32)
+    dense[ids] = out
+    return dense.reshape((n,) + data.shape[1:])
+
+
+def ground_plane_removal_canonical(point_bxyz, cfg, debug=None):
+    """(point_height, point_horizon, point_error, pillar_height, pillar_min_z) with the HIP path's
+    arithmetic (RANSAC + JointOpt configuration, plane normals canonical n_z >= 0, <= 2048 hypotheses)."""
+    import ctypes
+    import torch
+    L = O.lib()
+    f32 = np.float32
+    point_bxyz = np.ascontiguousarray(point_bxyz, f32)
+    pillar_size = np.asarray(cfg["PILLAR_SIZE"], f32)
+    pc_min = point_bxyz[:, 1:3].min(0) - f32(0.05)
+    vox, inv = grid_sample(point_bxyz, [0.10, 0.10, 0.03])
+    # format_pillars (torch.div(..., rounding_mode="floor") is Python's float floor division, as numpy's)
+    coords = np.round(np.floor_divide(vox[:, 1:3] - pc_min, pillar_size)).astype(np.int64)
+    dims = coords.max(0) + 1
+    X, Y = int(dims[0]), int(dims[1])
+    P = X * Y
+    pidx = coords[:, 0] * Y + coords[:, 1]
+    density = np.bincount(pidx, minlength=P).astype(f32)
+    p_xyz = _reduce_mode(vox[:, 1:], pidx, P, True, 1)
+    weight = (density > 0.5).astype(f32)
+    # compute_min_height_from_ransac
+    window = 4
+    ar = np.arange(P)
+    pc = np.stack([ar // Y, ar % Y], -1) // window
+    nd = pc.max(0) + 1
+    NP = int(nd[0] * nd[1])
+    ncoords = coords // window
+    nidx = ncoords[:, 0] * nd[1] + ncoords[:, 1]
+    order = np.argsort(nidx, kind="stable")
+    nb, nidx_s = vox[order], nidx[order]
+    z = nb[:, -1]
+    n_min, n_max = _scatter(z, nidx_s, NP, "min"), _scatter(z, nidx_s, NP, "max")
+    origin = _reduce_mode(nb[:, 1:4], nidx_s, NP, True, 1)
+    seg_start = np.searchsorted(nidx_s, np.arange(NP + 1)).astype(np.int32)
+    ratios = np.asarray(torch.linspace(0.3, 1, 30).tolist(), f32)
+    xyz3 = np.ascontiguousarray(nb[:, 1:4], f32)
+    bc, bn, bconf = np.zeros((NP, 3), f32), np.zeros((NP, 3), f32), np.zeros(NP, f32)
+    sigma2 = float(cfg["SIGMA2"])
+    L.orc_ransac_plane_hypotheses(O._p(xyz3), O._p(seg_start), ctypes.c_int64(len(xyz3)), O._p(n_min.astype(f32)),
+                                  O._p(n_max.astype(f32)), O._p(ratios), ctypes.c_int(len(ratios)), O._p(origin),
+                                  ctypes.c_int64(NP), ctypes.c_float(sigma2), ctypes.c_float(1e-2), ctypes.c_int(50),
+                                  ctypes.c_float(sigma2 ** 0.5), O._p(bc), O._p(bn), O._p(bconf))
+    if debug is not None:
+        debug.update(hyp_center=bc.copy(), hyp_normal=bn.copy(), hyp_conf=bconf.copy())
+    thresholds = np.asarray([float(t) for t in np.logspace(np.log(5) / np.log(10), np.log(0.01) / np.log(10), 100)], f32)
+    assert 0 < NP <= 2048 and cfg["K"] <= 8
+    keep = np.zeros(NP, np.uint8)
+    L.orc_prune_plane_hypotheses(O._p(bc), O._p(bn), ctypes.c_int(NP), ctypes.c_int(int(cfg["K"])), O._p(thresholds),
+                                 ctypes.c_int(len(thresholds)), O._p(keep))
+    keep = keep.astype(bool)
+    hx, hn = bc[keep], bn[keep]
+    if debug is not None:
+        debug.update(hyp_keep=keep.copy())
+    # propagation: first hypothesis with the largest 1 / (distance + 1)
+    best_c, best_n = np.zeros((P, 3), f32), np.zeros((P, 3), f32)
+    if len(hx):
+        dx = p_xyz[:, None, 0] - hx[None, :, 0]
+        dy = p_xyz[:, None, 1] - hx[None, :, 1]
+        dist = np.sqrt(dx * dx + dy * dy)
+        ind = f32(1) / (dist + f32(1))
+        bi = ind.argmax(1)  # first occurrence
+        m = ind[np.arange(P), bi] > 0
+        best_c[m], best_n[m] = hx[bi[m]], hn[bi[m]]
+    vn, vc = best_n[pidx], best_c[pidx]
+    vd = vox[:, 1:] - vc
+    nz = np.maximum(np.abs(vn[:, -1]), f32(0.01)) * ((vn[:, -1] >= 0).astype(f32) + f32(1)) / f32(2)
+    vh = ((vd[:, 0] * vn[:, 0] + vd[:, 1] * vn[:, 1]) + vd[:, 2] * vn[:, 2]) / nz
+    min_z = _reduce_mode(vox[:, -1] - vh, pidx, P, True, 1).reshape(X, Y)
+    height = min_z.copy()
+    if cfg.get("JointOpt", False):
+        height = np.zeros((X, Y), f32)
+        steps = np.asarray(list(cfg["DECAY_STEPS"]), np.int32)
+        L.orc_l1_minimization.restype = ctypes.c_int
+        it = L.orc_l1_minimization(O._p(np.ascontiguousarray(min_z, f32)), O._p(weight), ctypes.c_int(X), ctypes.c_int(Y),
+                                   ctypes.c_double(float(cfg["LR"])), O._p(steps), ctypes.c_int(len(steps)),
+                                   ctypes.c_float(float(cfg["RIGID_WEIGHT"])), ctypes.c_int(int(cfg["MAX_NUM_ITERS"])),
+                                   O._p(height))
+        if debug is not None:
+            debug["l1_steps"] = it
+    ij = (coords[:, 0], coords[:, 1])
+    v_h, v_min = height[ij], min_z[ij]
+    horizon = vox[:, -1] > v_min
+    v_height = vox[:, -1] - v_h
+    err = v_height - v_min
+    return v_height[inv], horizon[inv], err[inv], height, min_z

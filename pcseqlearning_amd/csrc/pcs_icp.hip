@@ -54,6 +54,7 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
+  b.Rt = a.take<double>(C * 12);
   b.lossfx = a.take<long long>(2 * kLossParts);
   b.corg = a.take<float4>(C);
   b.first = a.take<int32_t>(C);
@@ -103,6 +104,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.sstep = b.sstep;
   pr.acc = b.acc;
   pr.Tb = b.Tb;
+  pr.Rt = b.Rt;
   pr.lossfx = b.lossfx;
   pr.corg = b.corg;
   pr.cov = b.cov;
@@ -493,7 +495,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 //                         workgroup serves forward OR backward queries (one grid, one copy of the
 //                         search in the code: the two-direction form spilled ~400 scalar registers).
 // Exact: the same neighbours as a full search, always.
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   WGT_BEGIN();
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
@@ -1029,12 +1031,59 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
   *ls_out = ls;
 }
 
-// iteration k, last launch: every moving point solves its own component's step from the completed
-// moments (redundantly across the points of a component: a 3x3 SVD is cheaper than another launch)
-// and moves; the component's first point also stores the updated transform (read buffer k-1, write
-// buffer k) and the loss term. The previous positions are kept for the l1 passes. The moved points go
-// straight into the grid of the next iteration (the moving grid is double-buffered: no separate
-// build launch), and the grid this iteration searched is reset.
+// iteration k, third launch: one THREAD per component solves the regularised Kabsch step from the
+// completed moments: rotation and translation of the step (Rt, read by every point of the component
+// in the next launch), the updated transform (read buffer k-1, write buffer k), the loss term; the
+// other moment buffer is zeroed for the next iteration. (Until round 3 every moving POINT solved its
+// own component's step inside the apply launch -- one launch fewer, fine for a handful of units per
+// launch, but ~50 redundant 3x3 solves per component and 182 registers per lane once a launch carries
+// a hundred units.)
+__global__ void __launch_bounds__(kBlock)
+icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  IcpState* st = pr.st;
+  if (k > pr.max_iter || k > st->stop_iter) return;
+  const int64_t C = pr.C;
+  const double reg = pr.reg;
+  long long* __restrict__ acc2 = pr.acc;
+  double* __restrict__ Tb = pr.Tb;
+  long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
+  const int nround = (int)((C + kBlock - 1) / kBlock);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles below)
+    const int64_t c = (int64_t)r * kBlock + threadIdx.x;
+    if (c < C && pr.first[c] != INT_MAX) {  // components with a moving point
+      const long long* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
+      const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
+      const float4 og = pr.corg[c];
+      const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
+      double R[9], t[3], Tn[16], ls;
+      icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
+      double* rt = pr.Rt + c * 12;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) rt[q] = R[q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rt[9 + q] = t[q];
+      double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
+      for (int q = 0; q < 16; ++q) To[q] = Tn[q];
+      long long* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
+      for (int q = 0; q < kAcc; ++q) an[q] = 0;
+      if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
+      else loss_fx += to_fx(ls);
+    }
+  }
+  // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss_fx += __shfl_xor(loss_fx, o, 64);
+  if ((threadIdx.x & 63) == 0 && loss_fx != 0)
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
+                                             ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
+              (unsigned long long)loss_fx);
+}
+
+// iteration k, last launch: every moving point moves by its component's step. The previous positions are
+// kept for the l1 passes. The moved points go straight into the grid of the next iteration (the moving
+// grid is double-buffered: no separate build launch), and the grid this iteration searched is reset.
 __global__ void __launch_bounds__(kBlock)
 icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   WGT_BEGIN();
@@ -1044,14 +1093,10 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   if (k > pr.max_iter || k > st->stop_iter) return;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
-  const int64_t C = pr.C;
-  const double reg = pr.reg;
   float4* __restrict__ mov = pr.mov;
   float4* __restrict__ prev = pr.prev;
   const int32_t* __restrict__ comp = pr.comp;
-  const int32_t* __restrict__ first = pr.first;
-  long long* __restrict__ acc2 = pr.acc;
-  double* __restrict__ Tb = pr.Tb;
+  const double* __restrict__ Rt = pr.Rt;
   const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
   const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1071,7 +1116,6 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   WGT_MARK(wg_m1);
   float step = 0.f;  // largest step of this thread's points
-  long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   const GridDesc d = pr.geom->g;
   const int nround = (Mn + kBlock - 1) / kBlock;
 #ifdef PCS_WG_TRACE
@@ -1085,13 +1129,8 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     if (i < Mn && pr.first[pr.comp[i]] == i) ++wgt_owner;
 #endif
     if (i < Mn) {
-      int c = comp[i];
-      const long long* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
-      const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
-      const float4 og = pr.corg[c];
-      const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
-      double R[9], t[3], Tn[16], ls;
-      icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
+      const double* __restrict__ R = Rt + (int64_t)comp[i] * 12;
+      const double* __restrict__ t = R + 9;
       float4 p = mov[i];
       prev[i] = p;
       double x = p.y, y = p.z, z = p.w;
@@ -1109,29 +1148,12 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
                   fz = (int)floorf((nz - d.lo[2]) / d.h);
         atomicMax(&sstep[icp_step_slot(fx >> 3, fy >> 3, fz >> 3)], __float_as_uint(st1));
       }
-      if (first[c] == i) {
-        // the component's owner: transform, loss term, and the other moment buffer zeroed for the
-        // next iteration (nothing reads it during this launch)
-        double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
-        for (int q = 0; q < 16; ++q) To[q] = Tn[q];
-        long long* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
-        for (int q = 0; q < kAcc; ++q) an[q] = 0;
-        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
-        else loss_fx += to_fx(ls);
-      }
     }
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
   WGT_MARK(wg_m2);
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
-  // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) loss_fx += __shfl_xor(loss_fx, o, 64);
-  if ((threadIdx.x & 63) == 0 && loss_fx != 0)
-    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
-                                             ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
-              (unsigned long long)loss_fx);
 #ifdef PCS_WG_TRACE
   {
     __shared__ int s_own;
@@ -1252,13 +1274,15 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
   int& t_ev_used = t_ev_useds[prof_slot];
-  int64_t q = 1, m = 1, qsum = 0;
+  int64_t q = 1, m = 1, qsum = 0, cmax = 1;
   for (int e = 0; e < bt.n; ++e) {
     int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
     if (qe > q) q = qe;
     qsum += qe;
     if (hints[e].Mn > m) m = hints[e].Mn;
+    if (hints[e].C > cmax) cmax = hints[e].C;
   }
+  const int nb_s = gx_for(cmax, kBlock, 256);      // solve: one thread per component
   bool any_first = false;
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
   const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
@@ -1288,11 +1312,14 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
-      hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, e[4], e[5], 0, tab, bt, kbase,
-                            j);
+      hipExtLaunchKernelGGL(icp_solve_kernel, dim3(nb_s, bt.n), dim3(kBlock), 0, s, e[4], nullptr, 0, tab, bt,
+                            kbase, j);
+      hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
+                            kbase, j);
     } else {
       icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_solve_kernel<<<dim3(nb_s, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }

@@ -88,6 +88,7 @@ struct IcpProblem {
   unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
   long long* acc;       // [2, C, kAcc]
   double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
+  double* Rt;           // [C, 12] rotation (9) and translation (3) of the current iteration's step
   long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity)
   float4* corg;         // [C] origin of the component's fixed-point moments
   int32_t* cov;         // [C] matched moving points in the final coverage query
@@ -131,6 +132,7 @@ struct IcpBufs {
   float* prev;
   long long* acc;
   double* Tb;
+  double* Rt;
   long long* lossfx;
   float4* corg;
   int32_t *first, *cov;

@@ -548,6 +548,9 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
         iT = 1.f / (float)((X - 2) * (Y - 2));
   float last_loss = 1e10f;
   int countdown = 3, it = 0;
+  // beta^(it + 1) as running products: only IEEE multiplications, so the CPU restatement
+  // (oracle/pcs_oracle_ground.cpp) forms the same bits (pow() is not the same function everywhere)
+  double b1p = 1.0, b2p = 1.0;
   auto H = [&](int i, int j) { return h[i * Y + j]; };
   auto W = [&](int i, int j) { return weight[i * Y + j] + 1e-2f; };
   for (; it < max_iters; ++it) {
@@ -601,8 +604,10 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
     part = wave_sum_f64(part);
     if (lane == 0) red[w] = part;
     __syncthreads();
-    double bc1 = 1.0 - pow(0.9, (double)(it + 1));
-    double bc2 = 1.0 - pow(0.999, (double)(it + 1));
+    b1p *= 0.9;
+    b2p *= 0.999;
+    double bc1 = 1.0 - b1p;
+    double bc2 = 1.0 - b2p;
     float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
     float decay = (float)(1.0 - lr * 1e-2);

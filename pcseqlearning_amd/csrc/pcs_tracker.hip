@@ -1184,17 +1184,34 @@ static bool same_params(const PcsTrackParams& a, const PcsTrackParams& b) {
 // launches (integer moments, exact neighbours, fixed-order sums).
 class Engine {
  public:
+  // A device has a few engines (PCS_TRACK_ENGINES, default 2: while one chain is in its single-workgroup
+  // phases -- sampling sort, smooth_velo, compactions -- the other's iteration launches fill the chip);
+  // a call's units all join the engine that has the fewest units at that moment.
+  static constexpr int kMaxEngines = 4;
   static Engine* get(int device) {
     static std::mutex mu;
-    static Engine* inst[64] = {};
+    static Engine* inst[64][kMaxEngines] = {};
+    static const int n_engines = [] {
+      const char* e = getenv("PCS_TRACK_ENGINES");
+      int c = e ? atoi(e) : 0;
+      return (c >= 1 && c <= kMaxEngines) ? c : 2;
+    }();
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!inst[device]) {
-      Engine* e = new Engine(device);  // never destroyed: the driver thread outlives main
-      if (!e->start()) return nullptr;
-      inst[device] = e;
+    Engine* best = nullptr;
+    for (int g = 0; g < n_engines; ++g) {
+      if (!inst[device][g]) {
+        Engine* e = new Engine(device);  // never destroyed: the driver thread outlives main
+        if (!e->start()) return nullptr;
+        inst[device][g] = e;
+      }
+      if (!best || inst[device][g]->load() < best->load()) best = inst[device][g];
     }
-    return inst[device];
+    return best;
+  }
+  int load() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return users_;
   }
 
   // n free slots for units with these parameters; blocks while the table is full or units with other
@@ -1878,12 +1895,12 @@ static int run_sequences(const PcsTrackParams* prm, const SeqIn* seqs, int n_seq
   }
   int device = 0;
   PCS_CHECK_HIP(hipGetDevice(&device));
-  Engine* eng = Engine::get(device);
-  if (!eng) return PCS_ERR_HIP;
   Call call;
   Arena a(ws, ws_bytes);
   int rc = PCS_OK;
   for (int q = 0; q < n_seqs && rc == PCS_OK; ++q) {
+    Engine* eng = Engine::get(device);  // (the least loaded of the device's engines)
+    if (!eng) { rc = PCS_ERR_HIP; break; }
     int slots[kMaxCallUnits];
     rc = eng->reserve(*prm, seqs[q].n_units, slots);
     if (rc != PCS_OK) break;

@@ -161,9 +161,13 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     # scans the hypotheses in list order with a strict '>' update, i.e. the FIRST maximum wins:
     # one [pillars, hypotheses] table and a first-occurrence max
     if conf.shape[0] > 0:
-        dist = (pillars.xyz[:, None, :2] - xyz[None, :, :2]).norm(p=2, dim=-1)
+        # (elementwise products and sums, not library norm / sum reductions: their internal order and
+        # contraction are not ours to fix, and oracle/pcs_oracle_ground.cpp restates this arithmetic)
+        dx = pillars.xyz[:, None, 0] - xyz[None, :, 0]
+        dy = pillars.xyz[:, None, 1] - xyz[None, :, 1]
+        dist = (dx * dx + dy * dy).sqrt()
         ind = conf[None, :] / (dist + 1)
-        best_val, best_idx = ind.max(dim=1)
+        best_val, best_idx = ind.max(dim=1)  # (documented: the first maximal value's index)
         mask = best_val > pillars.best_confidence
         pillars.best_center[mask] = xyz[best_idx[mask]]
         pillars.best_normal[mask] = normal[best_idx[mask]]
@@ -173,7 +177,7 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     vc = pillars.best_center[voxels.pillar_idx]
     vd = voxels.bxyz[:, 1:] - vc
     nz = vn[:, -1].abs().clamp(min=0.01) * ((vn[:, -1] >= 0).float() + 1) / 2
-    vh = (vd * vn).sum(-1) / nz
+    vh = ((vd[:, 0] * vn[:, 0] + vd[:, 1] * vn[:, 1]) + vd[:, 2] * vn[:, 2]) / nz
     pillars.min_z = robust_mean(voxels.bxyz[:, -1] - vh, voxels.pillar_idx, num_pillars).reshape(
         int(pillar_dims[0]), int(pillar_dims[1]))
     pillars.height = pillars.min_z.clone()

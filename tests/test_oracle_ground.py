@@ -43,3 +43,23 @@ def test_ground_oracle_vs_reference():
     # formula turns into a sign flip and a factor of two; the winning hypotheses point up, so the
     # canonical n_z >= 0 form agrees with its outputs as closely as the bounds above say
     assert 0.0 < float(g["neg_normal_share"].max()) < 0.2
+
+
+def test_canonical_ground_oracle_vs_numpy_oracle_and_reference():
+    """oracle.ground_plane_removal_canonical (every floating-point operation in the HIP kernels' order,
+    oracle/pcs_oracle_ground.cpp) is the same algorithm as the numpy form: against the reference's own
+    outputs it meets the bounds the numpy form meets, and the two agree with each other as closely."""
+    from oracle import ground_oracle as GO
+    from tests.golden.make_golden_ground import GROUND_CFG
+    g = np.load(os.path.join(G, "ground_small.npz"))
+    dbg = {}
+    h, horizon, err, p_height, p_min_z = GO.ground_plane_removal_canonical(g["point_fxyz"], GROUND_CFG, debug=dbg)
+    a = ground_agreement(h, g)
+    assert a["differ"] <= 12 and a["mean"] < 4e-3 and a["p99"] < 6e-2, a
+    assert p_height.shape == g["pillar_height"].shape
+    assert float(np.abs(p_height - g["pillar_height"]).mean()) < 2e-2
+    assert float((horizon == g["point_horizon"]).mean()) > 0.995
+    o_h = GO.ground_plane_removal(g["point_fxyz"], GROUND_CFG, normal_sign="up")[0]
+    b = ground_agreement(h, dict(point_height=o_h))
+    assert b["differ"] <= 12 and b["mean"] < 4e-3, b
+    assert 0 < dbg["l1_steps"] <= GROUND_CFG["MAX_NUM_ITERS"] and dbg["hyp_keep"].sum() > 10
