@@ -328,12 +328,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    lib.pcs_profile_icp(ctypes.c_int(1))
+    icp_events = not os.environ.get("PCS_BENCH_NO_ICP_EVENTS")  # (experiment switch: the roofline row is then empty)
+    if icp_events:
+        lib.pcs_profile_icp(ctypes.c_int(1))
+    if os.environ.get("PCS_BENCH_NO_DEFER"):  # (experiment switch: ClusterProposal's evaluation inline, no side stream)
+        model.model_cfg.PREPROCESSORS[1]["DEFER_EVALUATION"] = False
+        model.preprocessors[1].model_cfg["DEFER_EVALUATION"] = False
     timer.RECORDS.clear()
     barrier()
     t0 = time.perf_counter()
     trace = os.environ.get("PCS_BENCH_TRACE")
     step_ms = []
+    alloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
     fallbacks0 = CT.HOST_FALLBACKS
     for i in range(args.steps):
@@ -353,6 +359,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     host_fallbacks = CT.HOST_FALLBACKS - fallbacks0
+    device_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0
     prof = (ctypes.c_double * 9)()
     lib.pcs_profile_icp_read(prof)
     lib.pcs_profile_icp(ctypes.c_int(0))
@@ -415,6 +422,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "step_ms": step_stats(step_ms),
             "host_fallbacks": int(host_fallbacks),
+            "device_allocations_in_timed_steps": int(device_allocs),
+            "reserved_GiB": round(torch.cuda.memory_reserved() / 2**30, 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

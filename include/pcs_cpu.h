@@ -1,0 +1,62 @@
+/* CPU twins of the hot-path entries of pcs.h ("plus a CPU twin of every symbol
+ * (pcs_cpu_<op>) for the oracle / CPU baseline").
+ *
+ * Same names with the prefix pcs_cpu_, the SAME argument lists as their pcs_* counterparts -- every
+ * pointer is a HOST pointer, `ws` / `ws_bytes` / `stream` are accepted and ignored (pass NULL / 0) --
+ * same return codes. They are exported by oracle/libpcs_oracle.so and oracle/libpcs_oracle_icp.so:
+ * TEST INFRASTRUCTURE and CPU baseline only. The product library (libpcs_hip.so) contains no CPU
+ * path and never calls these; a maintainer who wants the CPU baseline behind the same header links
+ * the oracle libraries instead of libpcs_hip.so and renames the prefix.
+ * The arithmetic is the oracle's (oracle/pcs_oracle.cpp: each function cites the reference lines it
+ * restates); tests/test_cpu_twins.py checks the twins against the oracle's own entry points. */
+#ifndef PCS_CPU_H
+#define PCS_CPU_H
+#include "pcs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pcs_cpu_minmax4_f32(const float* pts, int64_t n, float* out8, pcs_stream_t stream);
+int pcs_cpu_grid_cluster_ids(const float* pts, int64_t n, const float* bounds8, const float* size4,
+                             float margin0, int64_t* ids, pcs_stream_t stream);
+int pcs_cpu_unique_i64(const int64_t* ids, int64_t n, int key_bits, int64_t* uniq, int64_t* inv,
+                       int32_t* order, int32_t* seg_start, int64_t* d_num, void* ws, size_t ws_bytes,
+                       pcs_stream_t stream);
+int pcs_cpu_segment_reduce_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start,
+                               int64_t v, int mean, float* out, pcs_stream_t stream);
+int pcs_cpu_dynamic_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                             const float* voxel3, const int32_t* grid3, float* voxel_feat,
+                             int32_t* voxel_coords, int64_t* inv, int64_t* d_num, void* ws,
+                             size_t ws_bytes, pcs_stream_t stream);
+int pcs_cpu_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6,
+                          const float* voxel3, int max_points, int max_voxels, float* voxels,
+                          int32_t* coords, int32_t* num, int64_t* d_num, void* ws, size_t ws_bytes,
+                          pcs_stream_t stream);
+int pcs_cpu_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
+                             const int* spatial_shape3, const int* ksize3, const int* stride3,
+                             const int* pad3, const int* dil3, int subm, int transpose,
+                             int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
+                             int64_t* d_num_out, void* ws, size_t ws_bytes, pcs_stream_t stream);
+int pcs_cpu_indice_conv_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                            const int32_t* pairs, int64_t pair_stride, const int32_t* num,
+                            int64_t num_out, int inverse, int subm, float* out, void* ws,
+                            size_t ws_bytes, pcs_stream_t stream);
+int pcs_cpu_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n,
+                                 int64_t* component, int64_t* d_num, void* ws, size_t ws_bytes,
+                                 pcs_stream_t stream);
+int pcs_cpu_points_in_boxes(const float* points, int64_t N, const float* boxes, int B, int32_t* out,
+                            pcs_stream_t stream);
+/* (exported by oracle/libpcs_oracle_icp.so; `cell_size` and `chunk` do not change any result) */
+int pcs_cpu_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
+                                   const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
+                                   const int64_t* comp_deg, int64_t C, double radius, int frame_offset,
+                                   double angle_regularizer, int max_iter, double stopping_delta,
+                                   float cell_size, int chunk, double* T, double* l1_err,
+                                   float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
+                                   pcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+// pcs_cpu_<op>: the oracle's entry points behind the argument lists of include/pcs.h (see
+// include/pcs_cpu.h). TEST INFRASTRUCTURE / CPU baseline only: thin adapters, no arithmetic of their own.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/pcs_cpu.h"
+
+extern "C" {
+// oracle/pcs_oracle.cpp
+void orc_grid_cluster_ids(const float* pts, int64_t n, const float* size4, float margin0, int64_t* ids,
+                          float* bounds8_out);
+int64_t orc_unique_i64(const int64_t* ids, int64_t n, int64_t* uniq, int64_t* inv, int32_t* order,
+                       int32_t* seg_start);
+void orc_segment_reduce_f32_mode(const float* data, int d, const int32_t* order, const int32_t* seg_start,
+                                 int64_t v, int mean, int mode, float* out);
+int64_t orc_dynamic_voxelize(const float* pts, int64_t n, int ncol, const float* range6, const float* voxel3,
+                             const int32_t* grid3, float* feat, int32_t* coords, int64_t* inv);
+int64_t orc_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6, const float* voxel3,
+                          int max_points, int max_voxels, float* voxels, int32_t* coords, int32_t* num);
+int64_t orc_get_indice_pairs(const int32_t* indices, int64_t V, const int* out_shape3, const int* ksize3,
+                             const int* stride3, const int* pad3, const int* dil3, int subm, int32_t* out_ids,
+                             int32_t* pairs, int32_t* num);
+void orc_indice_conv_f32(const float* feat, int64_t num_in, int cin, const float* W, int kv, int cout,
+                         const int32_t* pairs, int64_t pair_stride, const int32_t* num, int64_t num_out,
+                         int inverse, int subm, float* out);
+int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n, int64_t* component);
+void orc_points_in_boxes(const float* pts, int64_t N, const float* boxes, int B, int32_t* out);
+
+#define CPU_OK 0
+#define CPU_ERR_ARG (-1)
+#define CPU_ERR_RANGE (-4)
+
+int pcs_cpu_minmax4_f32(const float* pts, int64_t n, float* out8, pcs_stream_t) {
+  if (!pts || !out8 || n < 1) return CPU_ERR_ARG;
+  for (int d = 0; d < 4; ++d) { out8[d] = INFINITY; out8[4 + d] = -INFINITY; }
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 4; ++d) {
+      out8[d] = std::fmin(out8[d], pts[i * 4 + d]);
+      out8[4 + d] = std::fmax(out8[4 + d], pts[i * 4 + d]);
+    }
+  return CPU_OK;
+}
+
+int pcs_cpu_grid_cluster_ids(const float* pts, int64_t n, const float* bounds8, const float* size4, float margin0,
+                             int64_t* ids, pcs_stream_t) {
+  if (!pts || !size4 || !ids || n < 0) return CPU_ERR_ARG;
+  (void)bounds8;  // (the oracle recomputes the bounds: bounds8 is pcs_minmax4_f32 of the same points)
+  orc_grid_cluster_ids(pts, n, size4, margin0, ids, nullptr);
+  return CPU_OK;
+}
+
+int pcs_cpu_unique_i64(const int64_t* ids, int64_t n, int key_bits, int64_t* uniq, int64_t* inv, int32_t* order,
+                       int32_t* seg_start, int64_t* d_num, void*, size_t, pcs_stream_t) {
+  (void)key_bits;
+  if (!ids || !seg_start || !d_num || n < 0) return CPU_ERR_ARG;
+  std::vector<int64_t> u(uniq ? 0 : (size_t)n), iv(inv ? 0 : (size_t)n);
+  std::vector<int32_t> od(order ? 0 : (size_t)n);
+  *d_num = orc_unique_i64(ids, n, uniq ? uniq : u.data(), inv ? inv : iv.data(), order ? order : od.data(), seg_start);
+  return CPU_OK;
+}
+
+int pcs_cpu_segment_reduce_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start, int64_t v,
+                               int mean, float* out, pcs_stream_t) {
+  if (!data || !order || !seg_start || !out || d < 1 || v < 0) return CPU_ERR_ARG;
+  const int mode = ((mean & 4) && d <= 16) ? 2 : (((mean & 2) && d <= 16) ? 1 : 0);
+  orc_segment_reduce_f32_mode(data, d, order, seg_start, v, mean & 1, mode, out);
+  return CPU_OK;
+}
+
+int pcs_cpu_dynamic_voxelize(const float* pts, int64_t n, int ncol, const float* range6, const float* voxel3,
+                             const int32_t* grid3, float* voxel_feat, int32_t* voxel_coords, int64_t* inv,
+                             int64_t* d_num, void*, size_t, pcs_stream_t) {
+  if (!pts || !range6 || !voxel3 || !grid3 || !voxel_feat || !voxel_coords || !d_num || ncol < 4 || n < 0)
+    return CPU_ERR_ARG;
+  *d_num = orc_dynamic_voxelize(pts, n, ncol, range6, voxel3, grid3, voxel_feat, voxel_coords, inv);
+  return CPU_OK;
+}
+
+int pcs_cpu_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6, const float* voxel3,
+                          int max_points, int max_voxels, float* voxels, int32_t* coords, int32_t* num,
+                          int64_t* d_num, void*, size_t, pcs_stream_t) {
+  if (!pts || !range6 || !voxel3 || !voxels || !coords || !num || !d_num || ncol < 3 || n < 0) return CPU_ERR_ARG;
+  std::memset(voxels, 0, sizeof(float) * (size_t)max_voxels * max_points * ncol);
+  std::memset(coords, 0, sizeof(int32_t) * (size_t)max_voxels * 3);
+  std::memset(num, 0, sizeof(int32_t) * (size_t)max_voxels);
+  *d_num = orc_hard_voxelize(pts, n, ncol, range6, voxel3, max_points, max_voxels, voxels, coords, num);
+  return CPU_OK;
+}
+
+int pcs_cpu_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
+                             const int* spatial_shape3, const int* ksize3, const int* stride3, const int* pad3,
+                             const int* dil3, int subm, int transpose, int32_t* out_ids, int64_t out_cap,
+                             int32_t* pairs, int32_t* num, int64_t* d_num_out, void*, size_t, pcs_stream_t) {
+  (void)batch; (void)spatial_shape3; (void)out_cap;
+  if (!out_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 || !num || !d_num_out || V < 0 ||
+      (V > 0 && (!indices || !pairs)) || (transpose && subm))
+    return CPU_ERR_ARG;
+  std::vector<int32_t> tmp;
+  if (!out_ids) { tmp.resize((size_t)(V > 0 ? V : 1) * 27 * 4); out_ids = tmp.data(); }
+  *d_num_out = orc_get_indice_pairs(indices, V, out_shape3, ksize3, stride3, pad3, dil3,
+                                    transpose ? 2 : (subm ? 1 : 0), out_ids, pairs, num);
+  return CPU_OK;
+}
+
+int pcs_cpu_indice_conv_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                            const int32_t* pairs, int64_t pair_stride, const int32_t* num, int64_t num_out,
+                            int inverse, int subm, float* out, void*, size_t, pcs_stream_t) {
+  if (!features || !filters || !pairs || !num || !out) return CPU_ERR_ARG;
+  orc_indice_conv_f32(features, 0, cin, filters, kv, cout, pairs, pair_stride, num, num_out, inverse, subm, out);
+  return CPU_OK;
+}
+
+int pcs_cpu_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n, int64_t* component,
+                                 int64_t* d_num, void*, size_t, pcs_stream_t) {
+  if (!component || !d_num || n < 0 || E < 0 || (E > 0 && (!e0 || !e1))) return CPU_ERR_ARG;
+  *d_num = orc_connected_components(e0, e1, E, n, component);
+  return CPU_OK;
+}
+
+int pcs_cpu_points_in_boxes(const float* points, int64_t N, const float* boxes, int B, int32_t* out, pcs_stream_t) {
+  if (!points || !boxes || !out || N < 0 || B < 0) return CPU_ERR_ARG;
+  orc_points_in_boxes(points, N, boxes, B, out);
+  return CPU_OK;
+}
+
+}  // extern "C"

@@ -294,3 +294,24 @@ int orc_register_to_next_frame(float* mov, const int64_t* comp, int64_t Mn, cons
 int orc_max_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"
+
+// ---- CPU twin of pcs_register_to_next_frame (include/pcs_cpu.h): the same argument list, host pointers
+extern "C" int pcs_cpu_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
+                                              const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
+                                              const int64_t* comp_deg, int64_t C, double radius, int frame_offset,
+                                              double angle_regularizer, int max_iter, double stopping_delta,
+                                              float cell_size, int chunk, double* T, double* l1_err,
+                                              float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
+                                              void* stream) {
+  (void)cell_size; (void)chunk; (void)ws; (void)ws_bytes; (void)stream;
+  if (!mov_fxyz || !mov_comp || !comp_deg || !T || !l1_err || !edge_ratio || !info || C < 1) return -1;
+  std::vector<int64_t> comp64((size_t)Mn);
+  for (int64_t i = 0; i < Mn; ++i) comp64[i] = mov_comp[i];
+  int iters = orc_register_to_next_frame(mov_fxyz, comp64.data(), Mn, ref_fxyz, Rn, ref_all, Ra, comp_deg, C, radius,
+                                         frame_offset, angle_regularizer, max_iter, stopping_delta, T, l1_err,
+                                         edge_ratio, 1);
+  info[0] = iters;
+  info[1] = iters < max_iter ? 1 : 0;
+  info[2] = info[3] = 0;
+  return 0;
+}

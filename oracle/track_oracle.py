@@ -163,7 +163,10 @@ def smooth_velo(v, d, frame_id, next_frame_id, weight0=1.0, weight=10.0, num_itr
 class Tracker:
     def __init__(self, radius_list=(2.5, 1.25, 1.0), voxel_sizes=((0.4, 0.4, 0.6), (0.2, 0.2, 0.3), (0.1, 0.1, 0.15)),
                  stopping_delta=(0.05, 0.05, 0.05), nn_radius=0.5, angle_regularizer=10.0,
-                 reg_error_coeff=0.13, track_interval=8, angle_threshold=45, min_move_frame=6):
+                 reg_error_coeff=0.13, track_interval=8, angle_threshold=45, min_move_frame=6, icp_threads=None):
+        # icp_threads: None = the numpy ICP (reg_oracle.register_to_next_frame); an int = the C++ form of
+        # the same function (pcs_oracle_icp.cpp, bit-compatible; 0 = all cores) for full-size inputs
+        self.icp_threads = icp_threads
         self.radius_list, self.voxel_sizes, self.stopping_delta = radius_list, voxel_sizes, stopping_delta
         self.nn_radius, self.angle_regularizer = nn_radius, angle_regularizer
         self.reg_error_coeff, self.track_interval = reg_error_coeff, track_interval
@@ -242,9 +245,13 @@ class Tracker:
         for i, radius in enumerate(self.radius_list):
             sub = sample_frame(self.voxel_sizes[i], fr)
             sub_next = sample_frame(self.voxel_sizes[i], nxt)
-            graph = R.Graph(radius)
-            _, T, l1, ratio, _ = R.register_to_next_frame(graph, sub, sub_next, C, self.angle_regularizer,
-                                                          80, self.stopping_delta[i])
+            if self.icp_threads is None:
+                graph = R.Graph(radius)
+                _, T, l1, ratio, _ = R.register_to_next_frame(graph, sub, sub_next, C, self.angle_regularizer,
+                                                              80, self.stopping_delta[i])
+            else:
+                _, T, l1, ratio, _ = R.register_to_next_frame_cpp(radius, sub, sub_next, C, self.angle_regularizer,
+                                                                  80, self.stopping_delta[i], threads=self.icp_threads)
             if i == 0:
                 comp_edge_ratio = ratio
             if i == len(self.radius_list) - 1:

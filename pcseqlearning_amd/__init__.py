@@ -1,9 +1,6 @@
 """MI355X-native hot path of PCSeqLearning (see README.md / DESIGN.md)."""
-import os
-
-# The sequence tracker drives a few lock-step groups of tracking units, one HIP stream each. ROCm
-# maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); measured on MI355X
-# (tools/stage_times.py) four groups on 8 queues track a sequence in 232 ms where 4 queues need
-# 316 ms. The variable is read when the HIP runtime initialises, i.e. at the first device call after
-# this import; an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# NB: this package does NOT touch GPU_MAX_HW_QUEUES. Round 2 exported 8 at import (its four lock-step groups
+# per sequence overlapped better on 8 hardware queues than on HIP's default 4). With 8, batches of sequences
+# in flight froze for 3-110 s once in ~10 steps -- every queue of the process standing still at once, no
+# error -- while 30-step soaks with 4 (the default) and with 24 showed none (gpurun_out/r3f, DESIGN.md
+# section 4 "The freeze"); throughput is the same. The default is what the vendor tests.

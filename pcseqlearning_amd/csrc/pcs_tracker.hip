@@ -422,6 +422,18 @@ trk_comp_init_kernel(int C, int F, int W, int frame_id, float max_diam, const fl
 __global__ void trk_store_icp_kernel(IcpProblem* __restrict__ slot, IcpProblem desc) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *slot = desc;
 }
+// table slots bt.idx[e] <- staged[e] for all registrations that start in a tick, in ONE launch (`staged`
+// is pinned host memory the kernel reads directly: a few hundred bytes per entry; it was one launch per
+// unit, 10-30 launches at the head of a tick once a tick serves a hundred units)
+__global__ void __launch_bounds__(64)
+trk_store_icp_batch_kernel(IcpProblem* __restrict__ tab, const IcpProblem* __restrict__ staged, Batch bt) {
+  const int e = blockIdx.x;
+  if (e >= bt.n) return;
+  const unsigned long long* src = (const unsigned long long*)(staged + e);
+  unsigned long long* dst = (unsigned long long*)(tab + bt.idx[e]);
+  static_assert(sizeof(IcpProblem) % 8 == 0, "descriptor copied in 8-byte words");
+  for (int q = threadIdx.x; q < (int)(sizeof(IcpProblem) / 8); q += 64) dst[q] = src[q];
+}
 
 __global__ void trk_hdesc_kernel(const float* __restrict__ b8, float radius, float cell, float pad,
                                  GridDesc* __restrict__ g) {
@@ -1270,11 +1282,12 @@ class Engine {
     if (hipMalloc((void**)&d_units_, kMaxBatch * sizeof(UnitDev)) != hipSuccess) return false;
     if (hipMalloc((void**)&d_icp_, kMaxBatch * sizeof(IcpProblem)) != hipSuccess) return false;
     char* pg = nullptr;
-    const size_t pin_bytes = kMaxBatch * (2 * sizeof(IcpState) + sizeof(TrkState));
+    const size_t pin_bytes = kMaxBatch * (2 * sizeof(IcpState) + sizeof(TrkState) + 2 * sizeof(IcpProblem));
     if (hipHostMalloc((void**)&pg, pin_bytes, hipHostMallocDefault) != hipSuccess) return false;
     pin_icp_ = (IcpState*)pg;
     pin_fin_ = pin_icp_ + kMaxBatch;
     pin_trk_ = (TrkState*)(pin_fin_ + kMaxBatch);
+    pin_desc_ = (IcpProblem*)(pin_trk_ + kMaxBatch);  // [2][kMaxBatch] descriptor staging, by tick parity
     std::thread([this] { run(); }).detach();
     std::unique_lock<std::mutex> lk(mu_);
     cv_slots_.wait(lk, [&] { return ready_ || broken_; });
@@ -1319,6 +1332,7 @@ class Engine {
   hipEvent_t ev_ = nullptr;
   IcpState *pin_icp_ = nullptr, *pin_fin_ = nullptr;
   TrkState* pin_trk_ = nullptr;
+  IcpProblem* pin_desc_ = nullptr;
   int live_[kMaxBatch], n_live_ = 0;
   Batch b_all_, b_iter_, b_fin_;
   int64_t ticks_ = 0;
@@ -1605,10 +1619,9 @@ int Engine::enqueue_tick() {
       ia.T = d.Tl;
       ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
       ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
-      // the descriptor travels as a kernel argument (no copy engine, no staging buffer to keep alive)
-      IcpProblem desc;
-      TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, &desc));
-      trk_store_icp_kernel<<<1, 64, 0, gs>>>(d_icp + i, desc);
+      // the descriptors of a tick go up together: staged in pinned memory (one half per tick parity: the
+      // previous tick's launch has completed before this half is written again), read by one launch
+      TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, pin_desc_ + (size_t)(ticks_ & 1) * kMaxBatch + e));
       // launch sizes: what this level had at the previous step, else a guess
       const int* sn = h.seen[h.lv];
       h.hint.Mn = sn[0] >= 0 ? (int)(sn[0] * 1.25) + 256 : h.na / 4 + 256;
@@ -1619,6 +1632,7 @@ int Engine::enqueue_tick() {
                            2 * (size_t)pow2_words(h.hint.Ra);
       h_begin[e] = h.hint;
     }
+    trk_store_icp_batch_kernel<<<b_begin.n, 64, 0, gs>>>(d_icp, pin_desc_ + (size_t)(ticks_ & 1) * kMaxBatch, b_begin);
     TRK_RC(icp_enqueue_begin(d_icp, b_begin, h_begin, gs));
   }
   // ---- 6. one chunk of iterations for every unit that is registering

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ..... import ops
 from .....lib import PcsError
-from ....utils.common_utils import EasyDict, filter_dict, pooled_stream, run_deferred
+from ....utils.common_utils import EasyDict, filter_dict, run_deferred, thread_stream
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
@@ -636,12 +636,10 @@ class ClusterTracking(nn.Module):
         if perm is not None:
             s_fxyz = s_fxyz[perm].contiguous()
         helper = None
-        side_ctx = None
         if seq_dict.get("_deferred"):
             device = s_fxyz.device
             main = torch.cuda.current_stream(device)
-            side_ctx = pooled_stream(device)
-            side = side_ctx.__enter__()
+            side = thread_stream(device, 1)  # the calling thread's second stream, the same at every call
             side.wait_stream(main)
             grad = torch.is_grad_enabled()
             err = []
@@ -666,7 +664,6 @@ class ClusterTracking(nn.Module):
             if helper is not None:
                 helper.result()
                 main.wait_stream(side)
-                side_ctx.__exit__(None, None, None)
                 if err:
                     raise err[0]
         self.num_registration_calls += sum(r[1][1] for r in res)

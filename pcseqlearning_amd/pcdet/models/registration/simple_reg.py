@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .... import ops
 from ...utils import timer
-from ...utils.common_utils import EasyDict, filter_dict, pooled_stream, run_deferred
+from ...utils.common_utils import EasyDict, filter_dict, run_deferred, thread_stream
 from ...utils.timer import Timer
 from ..model_utils.grid_sampling import GridSampling3D
 from .registration_module_template import RegistrationTemplate
@@ -25,6 +25,19 @@ def boxes_to_corners_3d(boxes):
                        torch.stack([-s, c, torch.zeros_like(c)], -1),
                        torch.stack([torch.zeros_like(c), torch.zeros_like(c), torch.ones_like(c)], -1)], 1)
     return corners @ rot + boxes[:, None, 0:3]
+
+
+def _record_stream(obj, stream):
+    """record_stream on every device tensor of a (nested) result dictionary"""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
 
 
 _SEQUENCE_POOLS = {}
@@ -86,20 +99,18 @@ class SimpleReg(RegistrationTemplate):
                 time.sleep(stagger * i)
             mods = copy.deepcopy(self.preprocessors)
             try:
-                with pooled_stream(device) as stream:
-                    stream.wait_stream(main)
-                    with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
-                        while True:
-                            with lock:
-                                if not queue or errors:
-                                    break
-                                b = queue.pop(0)
-                            out = self.process_sequence(self.build_sequence(batch_dict, b), mods)
-                            for v in out.values():  # the caller's stream consumes what this stream allocated
-                                if isinstance(v, torch.Tensor) and v.is_cuda:
-                                    v.record_stream(main)
-                            results[b] = out
-                        stream.synchronize()
+                stream = thread_stream(device)  # this worker's own stream, the same at every call
+                stream.wait_stream(main)
+                with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
+                    while True:
+                        with lock:
+                            if not queue or errors:
+                                break
+                            b = queue.pop(0)
+                        out = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                        _record_stream(out, main)  # the caller's stream consumes what this stream allocated
+                        results[b] = out
+                    stream.synchronize()
             except BaseException as e:  # re-raised on the calling thread
                 with lock:
                     errors.append(e)

@@ -85,3 +85,25 @@ def pooled_stream(device):
         with _STREAMS_LOCK:
             _STREAMS[index].append(stream)
 
+
+
+_THREAD_STREAMS = threading.local()
+
+
+def thread_stream(device, which=0):
+    """The calling thread's own side stream number `which` of `device`, created once and kept for the
+    thread's life. torch's caching allocator keeps its free blocks per stream, so a worker that takes the
+    SAME stream every time finds the blocks it freed last time; with streams handed out from a shared pool
+    a worker met a different pool of blocks at every call and kept going back to hipMalloc (~60-100 device
+    allocations per batch, the reserved size growing by 10 GiB per batch)."""
+    import torch
+    index = torch.device(device).index
+    if index is None:
+        index = torch.cuda.current_device()
+    table = getattr(_THREAD_STREAMS, "table", None)
+    if table is None:
+        table = _THREAD_STREAMS.table = {}
+    stream = table.get((index, which))
+    if stream is None:
+        stream = table[(index, which)] = torch.cuda.Stream(device=index)
+    return stream

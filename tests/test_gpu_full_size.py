@@ -189,3 +189,59 @@ def test_tracker_soak_batch_of_four_sequences():
     assert CT.HOST_FALLBACKS == fallbacks0
     steady = sorted(times[1:])
     assert steady[-1] < 1.5 * steady[len(steady) // 2], times
+
+
+def test_full_size_first_frame_step_vs_oracle(full_runs):
+    """configs[2] size against the ORACLE (not only HIP against HIP): the first frame step of one tracking
+    unit -- anchor frame 8 of the 1.25 m components tracked backwards into frame 7: constant-velocity
+    set-up, sampling and registration at the three levels (~20 k points each side), component motion,
+    smooth_velo, stop rules, harvest -- from the same state on both sides: the op-by-op loop of the HIP
+    path (bit-identical to the native tracker, test_track_frame_native_vs_host) against oracle.track_oracle
+    with the C++ ICP (bit-compatible with its numpy form, tests/test_oracle_registration.py). Stop /
+    moving flags and the harvest's edges exact, transforms within 1e-5, moved points to fp32 noise."""
+    from oracle import track_oracle as T
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
+    from pcseqlearning_amd.pcdet.utils.common_utils import EasyDict, filter_dict
+    from tools.run_sequence import build_model
+    out = full_runs[0]
+    key, anchor = "rad1x25", 8
+    fxyz = out["point_fxyz"].contiguous()
+    comp = out[f"point_component_{key}"].long()
+    model = build_model(save=False, device=DEV)
+    tracker = model.preprocessors[2]
+    sp = EasyDict(fxyz=fxyz.clone(), frame=out["point_sweep"].reshape(-1).clone(), component=comp.clone())
+    diam = CT.component_diameter(sp)
+    sp.component_diameter = diam[sp.component]
+    sp.stationary = sp.component_diameter > 12.5
+    sp.segmentation_label = torch.zeros_like(comp)
+    sp.extracted = torch.zeros_like(sp.fxyz[:, 0]).bool()
+    mask = (sp.fxyz[:, 0] == anchor).reshape(-1)
+    fp = EasyDict(filter_dict(sp, mask))
+    fp.component = fp.component - fp.component.min()
+    st = tracker.host_init(sp, fp)
+    tracker.host_start_dir(st, sp, -1)
+    assert tracker.host_can_step(st) and st.next_frame_id == anchor - 1
+    f_this, f_next = tracker.host_step(st, sp)
+    # the oracle from the same inputs
+    h_fxyz, h_comp = fxyz.cpu().numpy(), comp.cpu().numpy()
+    frame = np.round(h_fxyz[:, 0]).astype(np.int64)
+    o_diam = T.component_diameter(h_fxyz, h_comp, int(h_comp.max()) + 1)
+    seq = dict(fxyz=h_fxyz.copy(), frame=frame, component=h_comp, stationary=o_diam[h_comp] > 12.5,
+               extracted=np.zeros(len(h_comp), bool))
+    np.testing.assert_array_equal(sp.stationary.cpu().numpy(), seq["stationary"])
+    oracle = T.Tracker(icp_threads=0)
+    S = oracle.init_state(seq, anchor)
+    oracle.start_dir(S, seq, -1)
+    assert oracle.can_step(S)
+    o_this, o_next = oracle.step(S, seq)
+    assert S["C"] == st.num_components and S["C"] > 100
+    np.testing.assert_array_equal(st.stopped.cpu().numpy(), S["stopped"])
+    np.testing.assert_array_equal(st.moving.cpu().numpy(), S["moving"])
+    np.testing.assert_array_equal(st.comp_min_frame_id.cpu().numpy(), S["comp_min"])
+    np.testing.assert_array_equal(f_this.cpu().numpy(), o_this)
+    np.testing.assert_array_equal(f_next.cpu().numpy(), o_next)
+    col = anchor - 1 - st.min_frame_id
+    np.testing.assert_allclose(st.transforms[:, col].cpu().numpy(), S["transforms"][:, col], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st.frame.fxyz.cpu().numpy(), S["fr"]["fxyz"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(st.comp_velos.cpu().numpy(), S["comp_velos"], rtol=0, atol=2e-5)
+    assert int((~S["stopped"]).sum()) > 10 and len(o_this) > 1000
