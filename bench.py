@@ -249,6 +249,9 @@ def main():
                          "SimpleReg.forward, which tracks the sequences of a batch concurrently)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="sequences of a batch processed at once (SimpleReg's SEQUENCES_IN_FLIGHT; 0 = its default)")
+    ap.add_argument("--stagger-ms", type=float, default=-1.0,
+                    help="SimpleReg's SEQUENCE_START_STAGGER_MS (delay between the starts of the sequences of a batch); "
+                         "< 0 = its default")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank / sequence assignment and reduction only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,6 +317,8 @@ def main():
     model = build_model(save=False, device=device)
     if args.inflight > 0:
         model.model_cfg["SEQUENCES_IN_FLIGHT"] = args.inflight
+    if args.stagger_ms >= 0:
+        model.model_cfg["SEQUENCE_START_STAGGER_MS"] = args.stagger_ms
     lib = L.load()
 
     def step():

@@ -338,15 +338,17 @@ icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase,
 // component), then flushes one global integer atomic per (component, accumulator). Integer sums:
 // the result does not depend on any arrival order.
 constexpr int kMomSlots = 64;
+constexpr int kMomSlotsSearch = 16;  // a search item settles 8 or 32 pairs: a small table keeps its reset and drain short
 struct MomTable {
-  int* skey;                      // LDS [kMomSlots]
-  unsigned long long* sacc;       // LDS [kMomSlots * 17]
+  int* skey;                      // LDS [nslots]
+  unsigned long long* sacc;       // LDS [nslots * 17]
   unsigned long long* acc;        // global [C, kAcc] of the iteration
   int C;                          // components (keys outside [0, C) are never flushed)
+  int nslots;                     // power of two <= kMomSlots
 };
 __device__ __forceinline__ void mom_init(const MomTable& t) {  // every thread of the workgroup; then a barrier
-  for (int q = threadIdx.x; q < kMomSlots; q += kBlock) t.skey[q] = -1;
-  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) t.sacc[q] = 0ULL;
+  for (int q = threadIdx.x; q < t.nslots; q += kBlock) t.skey[q] = -1;
+  for (int q = threadIdx.x; q < t.nslots * 17; q += kBlock) t.sacc[q] = 0ULL;
 }
 // the pair (moving point pf of component c, reference point qf)
 // the 17 fixed-point terms of one pair relative to the component's origin
@@ -373,12 +375,12 @@ __device__ __forceinline__ void mom_terms(const IcpProblem& pr, float4 pf, float
 // 17 sums of component c into the workgroup's table
 __device__ __forceinline__ void mom_put(const MomTable& t, int c, const long long v[17]) {
   // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
-  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (kMomSlots - 1);
+  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (t.nslots - 1);
   int found = -1;
-  for (int i = 0; i < kMomSlots; ++i) {
+  for (int i = 0; i < t.nslots; ++i) {
     int old = atomicCAS(&t.skey[slot], -1, c);
     if (old == -1 || old == c) { found = slot; break; }
-    slot = (slot + 1) & (kMomSlots - 1);
+    slot = (slot + 1) & (t.nslots - 1);
   }
   if (found >= 0) {
 #pragma unroll
@@ -472,7 +474,7 @@ __device__ __forceinline__ void mom_add_wave(const IcpProblem& pr, const MomTabl
 }
 
 __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barrier; every thread
-  for (int q = threadIdx.x; q < kMomSlots * 17; q += kBlock) {
+  for (int q = threadIdx.x; q < t.nslots * 17; q += kBlock) {
     int sl = q / 17, a = q - sl * 17;
     int key = t.skey[sl];
     if (key >= 0 && key < t.C) atomicAdd(&t.acc[(int64_t)key * kAcc + a], t.sacc[q]);
@@ -528,7 +530,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   }
   __shared__ int skey[kMomSlots];
   __shared__ unsigned long long sacc[kMomSlots * 17];
-  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C, kMomSlots};
   const double lim2 = icp_limit_sq(nq);
   mom_init(mt);
   __syncthreads();
@@ -655,8 +657,8 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
   static_assert(4 * kMaxBatch <= 2 * kBlock, "two lists per thread");
   __shared__ int s_pref[4 * kMaxBatch + 1];
   __shared__ int s_wsum[kBlock / 64];
-  __shared__ int skey[kMomSlots];
-  __shared__ unsigned long long sacc[kMomSlots * 17];
+  __shared__ int skey[kMomSlotsSearch];
+  __shared__ unsigned long long sacc[kMomSlotsSearch * 17];
   const int nlist = 4 * bt.n;  // list t: t < 2n cooperative, else seeded; entry (t mod 2n) / 2, direction t & 1
   // thread x holds the rounds of lists 2x and 2x + 1 (nlist <= 2 * kBlock)
   int my_rounds[2] = {0, 0};
@@ -724,7 +726,8 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
     const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
     const int qoff = fwd ? 0 : Mn;
     const int df = fwd ? pr.df : -pr.df;
-    const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C};
+    const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C,
+                         kMomSlotsSearch};
     const double lim2 = icp_limit_sq(Mn + Rn);
     mom_init(mt);
     __syncthreads();
@@ -1038,46 +1041,89 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
 // own component's step inside the apply launch -- one launch fewer, fine for a handful of units per
 // launch, but ~50 redundant 3x3 solves per component and 182 registers per lane once a launch carries
 // a hundred units.)
-__global__ void __launch_bounds__(kBlock)
+constexpr int kSolveBlock = 64;  // one wave per workgroup: 24 KB of LDS, six workgroups per CU beside the other kernels
+template <bool STAGED>
+__global__ void __launch_bounds__(kSolveBlock)
 icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  // The per-component records (20 moment words, 16 transform words in, 12 + 16 out) are read and written
+  // by one thread each: straight from memory that is 64 cache lines per wave and load instruction
+  // (38 us per launch at 24 units, as long as the budget test). STAGED: they pass through LDS -- the
+  // records of a workgroup's 64 consecutive components are contiguous, so the copies are coalesced.
+  __shared__ long long s_acc[STAGED ? kSolveBlock * kAcc : 1];
+  __shared__ double s_T[STAGED ? kSolveBlock * 16 : 1];    // transform in, then transform out
+  __shared__ double s_rt[STAGED ? kSolveBlock * 12 : 1];
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   const int k = kbase.v[blockIdx.y] + 1 + j;
   IcpState* st = pr.st;
-  if (k > pr.max_iter || k > st->stop_iter) return;
+  if (k > pr.max_iter || k > st->stop_iter) return;  // (one wave per workgroup: uniform)
   const int64_t C = pr.C;
   const double reg = pr.reg;
-  long long* __restrict__ acc2 = pr.acc;
-  double* __restrict__ Tb = pr.Tb;
+  long long* __restrict__ acc_k = pr.acc + (size_t)(k & 1) * C * kAcc;
+  long long* __restrict__ acc_n = pr.acc + (size_t)((k + 1) & 1) * C * kAcc;
+  const double* __restrict__ T_in = pr.Tb + (size_t)((k - 1) & 1) * C * 16;
+  double* __restrict__ T_out = pr.Tb + (size_t)(k & 1) * C * 16;
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
-  const int nround = (int)((C + kBlock - 1) / kBlock);
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles below)
-    const int64_t c = (int64_t)r * kBlock + threadIdx.x;
-    if (c < C && pr.first[c] != INT_MAX) {  // components with a moving point
-      const long long* a = acc2 + ((size_t)(k & 1) * C + c) * kAcc;
-      const double* Tc = Tb + ((size_t)((k - 1) & 1) * C + c) * 16;
-      const float4 og = pr.corg[c];
-      const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
-      double R[9], t[3], Tn[16], ls;
-      icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
-      double* rt = pr.Rt + c * 12;
+  const int nround = (int)((C + kSolveBlock - 1) / kSolveBlock);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
+    const int64_t c0 = (int64_t)r * kSolveBlock;
+    const int nc = (int)(C - c0 < kSolveBlock ? C - c0 : kSolveBlock);
+    const int64_t c = c0 + threadIdx.x;
+    if (STAGED) {
+      for (int q = threadIdx.x; q < nc * kAcc; q += kSolveBlock) {
+        s_acc[q] = acc_k[c0 * kAcc + q];
+        acc_n[c0 * kAcc + q] = 0;  // the other moment buffer, for the next iteration (nothing reads it now)
+      }
+      for (int q = threadIdx.x; q < nc * 16; q += kSolveBlock) s_T[q] = T_in[c0 * 16 + q];
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < nc) {
+      const long long* a = STAGED ? s_acc + threadIdx.x * kAcc : acc_k + c * kAcc;
+      const double* Tc = STAGED ? s_T + threadIdx.x * 16 : T_in + c * 16;
+      double R[9], t[3], Tn[16];
+      const bool has = pr.first[c] != INT_MAX;  // components with a moving point
+      if (has) {
+        const float4 og = pr.corg[c];
+        const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
+        double ls;
+        icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
+        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
+        else loss_fx += to_fx(ls);
+      } else {  // nothing moves: the transform stays what it is (the identity the reset wrote)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) rt[q] = R[q];
+        for (int q = 0; q < 16; ++q) Tn[q] = Tc[q];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) rt[9 + q] = t[q];
-      double* To = Tb + ((size_t)(k & 1) * C + c) * 16;
-      for (int q = 0; q < 16; ++q) To[q] = Tn[q];
-      long long* an = acc2 + ((size_t)((k + 1) & 1) * C + c) * kAcc;
-      for (int q = 0; q < kAcc; ++q) an[q] = 0;
-      if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
-      else loss_fx += to_fx(ls);
+        for (int q = 0; q < 9; ++q) R[q] = (q % 4 == 0) ? 1.0 : 0.0;
+        t[0] = t[1] = t[2] = 0.0;
+      }
+      if (STAGED) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_T[threadIdx.x * 16 + q] = Tn[q];  // (a thread's own record: read above)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s_rt[threadIdx.x * 12 + q] = R[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s_rt[threadIdx.x * 12 + 9 + q] = t[q];
+      } else if (has) {
+        double* rt = pr.Rt + c * 12;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) rt[q] = R[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rt[9 + q] = t[q];
+        for (int q = 0; q < 16; ++q) T_out[c * 16 + q] = Tn[q];
+        for (int q = 0; q < kAcc; ++q) acc_n[c * kAcc + q] = 0;
+      }
+    }
+    if (STAGED) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < nc * 16; q += kSolveBlock) T_out[c0 * 16 + q] = s_T[q];
+      for (int q = threadIdx.x; q < nc * 12; q += kSolveBlock) pr.Rt[c0 * 12 + q] = s_rt[q];
+      __syncthreads();  // (the buffers are filled again by the next round)
     }
   }
   // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) loss_fx += __shfl_xor(loss_fx, o, 64);
   if ((threadIdx.x & 63) == 0 && loss_fx != 0)
-    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts +
-                                             ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kLossParts - 1))],
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts + (blockIdx.x & (kLossParts - 1))],
               (unsigned long long)loss_fx);
 }
 
@@ -1282,10 +1328,16 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
     if (hints[e].Mn > m) m = hints[e].Mn;
     if (hints[e].C > cmax) cmax = hints[e].C;
   }
-  const int nb_s = gx_for(cmax, kBlock, 256);      // solve: one thread per component
+  const int nb_s = gx_for(cmax, kSolveBlock, 1024);  // solve: one thread per component
+  static const bool solve_staged = [] { const char* e = getenv("PCS_ICP_SOLVE_STAGED"); return !(e && atoi(e) == 0); }();
   bool any_first = false;
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
-  const int nb_q = gx_for(q, kBlock, 1024);        // budget test: one lane per query
+  // budget test: one lane per query. A workgroup resets and drains its moment table once whatever the
+  // number of rounds it serves (a third of a one-round workgroup's time, profiles/r02_wg_trace.txt):
+  // once the launch is several generations of workgroups wide, each takes 2-4 rounds
+  const int64_t wg_total = (qsum + kBlock - 1) / kBlock;
+  const int rounds_per_wg = wg_total > 7168 ? 4 : (wg_total > 5120 ? 3 : (wg_total > 3072 ? 2 : 1));
+  const int nb_q = gx_for((q + rounds_per_wg - 1) / rounds_per_wg, kBlock, 1024);
   // the searches are a queue over the work lists of all entries (items of 8 cooperative / 32 seeded
   // queries): iteration 1 searches for every query, later ones for ~6 % + ~12 % of them
   const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8));
@@ -1312,14 +1364,19 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
-      hipExtLaunchKernelGGL(icp_solve_kernel, dim3(nb_s, bt.n), dim3(kBlock), 0, s, e[4], nullptr, 0, tab, bt,
-                            kbase, j);
+      if (solve_staged)
+        hipExtLaunchKernelGGL(icp_solve_kernel<true>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
+                              bt, kbase, j);
+      else
+        hipExtLaunchKernelGGL(icp_solve_kernel<false>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
+                              bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
                             kbase, j);
     } else {
       icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
-      icp_solve_kernel<<<dim3(nb_s, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      if (solve_staged) icp_solve_kernel<true><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
+      else icp_solve_kernel<false><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
       icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     }
   }

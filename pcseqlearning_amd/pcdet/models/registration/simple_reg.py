@@ -88,10 +88,11 @@ class SimpleReg(RegistrationTemplate):
         lock = threading.Lock()
         queue = list(todo)
 
-        # workers start 25 ms apart (SEQUENCE_START_STAGGER_MS): sequences that enter the ground / proposal /
-        # tracking stages together compete for the same resources at the same moments (measured: 6.2
-        # against 5.6-6.0 sequences/s for batches of six)
-        stagger = float(self.model_cfg.get("SEQUENCE_START_STAGGER_MS", 25)) * 1e-3
+        # workers start 5 ms apart (SEQUENCE_START_STAGGER_MS): sequences that enter the ground / proposal
+        # stages at the same instant compete for the same resources at the same moments (measured with 12
+        # in flight: 0 / 5 / 25 ms -> 1.78 / 1.75 / 1.83 s per batch; 25 ms was round 2's value for 4 in
+        # flight and leaves the twelfth worker idle for 275 ms)
+        stagger = float(self.model_cfg.get("SEQUENCE_START_STAGGER_MS", 5)) * 1e-3
 
         def worker(i=0):
             if stagger > 0 and i > 0:
