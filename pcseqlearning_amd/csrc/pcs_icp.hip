@@ -396,6 +396,42 @@ __device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t,
   mom_terms(pr, pf, qf, c, lim2, v);
   mom_put(t, c, v);
 }
+// Register-lean form: the component's slot first, then every term is formed and added at once (no array
+// of 17 64-bit terms kept alive across shuffles). Lanes of one component meet at the same 17 LDS words;
+// the adds are fire-and-forget.
+__device__ __forceinline__ void mom_add_stream(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
+                                               double lim2) {
+  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (t.nslots - 1);
+  int found = -1;
+  for (int i = 0; i < t.nslots; ++i) {
+    int old = atomicCAS(&t.skey[slot], -1, c);
+    if (old == -1 || old == c) { found = slot; break; }
+    slot = (slot + 1) & (t.nslots - 1);
+  }
+  unsigned long long* base = found >= 0 ? t.sacc + found * 17 : t.acc + (int64_t)c * kAcc;
+  const float4 og = pr.corg[c];
+  const double p0 = (double)pf.y - (double)og.y, p1 = (double)pf.z - (double)og.z, p2 = (double)pf.w - (double)og.w;
+  const double q0 = (double)qf.y - (double)og.y, q1 = (double)qf.z - (double)og.z, q2 = (double)qf.w - (double)og.w;
+  if (p0 * p0 + p1 * p1 + p2 * p2 > lim2 || q0 * q0 + q1 * q1 + q2 * q2 > lim2) pr.st->err = 1;
+  atomicAdd(base + 0, 1ULL);
+  atomicAdd(base + 1, (unsigned long long)to_fx(p0));
+  atomicAdd(base + 2, (unsigned long long)to_fx(p1));
+  atomicAdd(base + 3, (unsigned long long)to_fx(p2));
+  atomicAdd(base + 4, (unsigned long long)to_fx(q0));
+  atomicAdd(base + 5, (unsigned long long)to_fx(q1));
+  atomicAdd(base + 6, (unsigned long long)to_fx(q2));
+  atomicAdd(base + 7, (unsigned long long)to_fx(p0 * q0));
+  atomicAdd(base + 8, (unsigned long long)to_fx(p0 * q1));
+  atomicAdd(base + 9, (unsigned long long)to_fx(p0 * q2));
+  atomicAdd(base + 10, (unsigned long long)to_fx(p1 * q0));
+  atomicAdd(base + 11, (unsigned long long)to_fx(p1 * q1));
+  atomicAdd(base + 12, (unsigned long long)to_fx(p1 * q2));
+  atomicAdd(base + 13, (unsigned long long)to_fx(p2 * q0));
+  atomicAdd(base + 14, (unsigned long long)to_fx(p2 * q1));
+  atomicAdd(base + 15, (unsigned long long)to_fx(p2 * q2));
+  const double e0 = p0 - q0, e1 = p1 - q1, e2 = p2 - q2;
+  atomicAdd(base + 16, (unsigned long long)to_fx(e0 * e0 + e1 * e1 + e2 * e2));
+}
 // The same for a whole wave (every lane calls; `active` lanes hold a pair). Neighbouring queries
 // mostly belong to one component: when all active lanes agree on it their terms are summed by
 // shuffles first and ONE lane adds the 17 totals (otherwise 64 lanes queue up on the same 17 words).
@@ -497,6 +533,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 //                         workgroup serves forward OR backward queries (one grid, one copy of the
 //                         search in the code: the two-direction form spilled ~400 scalar registers).
 // Exact: the same neighbours as a full search, always.
+template <bool STREAM>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   WGT_BEGIN();
@@ -614,7 +651,11 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
         to_coop = true;
       }
     }
-    mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
+    if (STREAM) {
+      if (m_act) mom_add_stream(pr, mt, m_p, m_q, m_c, lim2);
+    } else {
+      mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
+    }
     // the work lists, by direction (a wave is all forward or all backward, except the one at Mn)
     const unsigned long long mf = __ballot(fwd);
 #pragma unroll
@@ -745,8 +786,8 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
         nn_o[qi] = res;
         bud_o[qi] = bud;
         if (res >= 0) {  // (moving point, reference point, the moving point's component)
-          if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
-          else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
+          if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+          else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
         }
       }
     } else {
@@ -771,8 +812,8 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
         nn_o[qi] = res;
         bud_o[qi] = bud;
         if (res >= 0) {
-          if (fwd) mom_add(pr, mt, p, hpts[res], pr.comp[qi], lim2);
-          else mom_add(pr, mt, hpts[res], p, pr.comp[res], lim2);
+          if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+          else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
         }
       }
     }
@@ -1046,9 +1087,11 @@ template <bool STAGED>
 __global__ void __launch_bounds__(kSolveBlock)
 icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
   // The per-component records (20 moment words, 16 transform words in, 12 + 16 out) are read and written
-  // by one thread each: straight from memory that is 64 cache lines per wave and load instruction
-  // (38 us per launch at 24 units, as long as the budget test). STAGED: they pass through LDS -- the
-  // records of a workgroup's 64 consecutive components are contiguous, so the copies are coalesced.
+  // by one thread each: 64 cache lines per wave and load instruction. With 256-thread workgroups that
+  // made the launch as long as the budget test (38 us at 24 units); one-wave workgroups spread the same
+  // gathers over four times as many workgroups. STAGED (off by default, see icp_enqueue_chunk): the
+  // records pass through LDS -- those of a workgroup's 64 consecutive components are contiguous, so the
+  // copies are coalesced.
   __shared__ long long s_acc[STAGED ? kSolveBlock * kAcc : 1];
   __shared__ double s_T[STAGED ? kSolveBlock * 16 : 1];    // transform in, then transform out
   __shared__ double s_rt[STAGED ? kSolveBlock * 12 : 1];
@@ -1329,7 +1372,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
     if (hints[e].C > cmax) cmax = hints[e].C;
   }
   const int nb_s = gx_for(cmax, kSolveBlock, 1024);  // solve: one thread per component
-  static const bool solve_staged = [] { const char* e = getenv("PCS_ICP_SOLVE_STAGED"); return !(e && atoi(e) == 0); }();
+  // PCS_ICP_MOM_STREAM: the budget test's moments as immediate LDS adds per lane (58 VGPRs, 7 waves per SIMD)
+  // instead of the shuffle pre-reduction of runs (123 VGPRs, 4 waves per SIMD)
+  static const bool mom_stream = [] { const char* e = getenv("PCS_ICP_MOM_STREAM"); return !(e && atoi(e) == 0); }();
+  // PCS_ICP_SOLVE_STAGED=1: the records through LDS (measured A/B on one box, batches of 12: 1.57 s staged
+  // against 1.49 s direct -- the coalesced copies cost more than the 64-line gathers of a one-wave
+  // workgroup, which overlap with other waves' arithmetic); default: direct
+  static const bool solve_staged = [] { const char* e = getenv("PCS_ICP_SOLVE_STAGED"); return e && atoi(e) != 0; }();
   bool any_first = false;
   for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
   // budget test: one lane per query. A workgroup resets and drains its moment table once whatever the
@@ -1361,7 +1410,10 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       // kernel's own begin-to-end time, as rocprofv3 reports it
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
-      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+      if (mom_stream)
+        hipExtLaunchKernelGGL(icp_nn_kernel<true>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+      else
+        hipExtLaunchKernelGGL(icp_nn_kernel<false>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       if (solve_staged)
@@ -1373,7 +1425,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
                             kbase, j);
     } else {
-      icp_nn_kernel<<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      if (mom_stream) icp_nn_kernel<true><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      else icp_nn_kernel<false><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
       icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
       if (solve_staged) icp_solve_kernel<true><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
       else icp_solve_kernel<false><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);

@@ -1696,13 +1696,16 @@ void Engine::collect_tick() {
 }
 
 void Engine::run() {
-  // The engine's stream has the highest priority (PCS_TRACK_PRIORITY=0: default priority): its launches are
-  // one long dependent chain, the other streams carry the wide, throughput-bound kernels of the other
-  // stages (measured: 1.72 against 1.75 s per batch of 12)
+  // PCS_TRACK_PRIORITY=1 (experiment, off by default): the engine's stream at the highest priority -- its
+  // launches are one long dependent chain, the other streams carry the wide, throughput-bound kernels of
+  // the other stages. Measured 1.72 against 1.75 s per batch of 12, BUT priority streams get hardware
+  // queues of their own, and with 4 normal + 4 high-priority queues (four engines), or 18 sequences in
+  // flight beside three, the process-wide freezes of DESIGN.md section 4 "The freeze" came back (10-60 s
+  // steps, gpurun_out/r3i). Default priority keeps the process on HIP's four queues.
   bool ok = hipSetDevice(device_) == hipSuccess;
   if (ok) {
     const char* pe = getenv("PCS_TRACK_PRIORITY");
-    if (!(pe && atoi(pe) == 0)) {
+    if (pe && atoi(pe) != 0) {
       int lo = 0, hi = 0;
       ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
            hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, hi) == hipSuccess;

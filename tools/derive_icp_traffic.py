@@ -1,0 +1,49 @@
+"""(fetch + write) / algorithmic bytes of the ICP iteration kernels from the two PMC passes of
+tools/pmc_batch.sh and the bench line one of them printed (algorithmic bytes per launch of the
+{budget test, searches} pair in that same schedule).
+  python tools/derive_icp_traffic.py <FETCH.json> <WRITE.json> <bench line .json>  > profiles/<tag>_icp_hbm_pmc.json
+FETCH_SIZE / WRITE_SIZE are KB per dispatch as rocprofv3 reports them (TCC_EA request counters x 64 B at the
+fabric side of the L2, Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half
+of the bytes of a wide coalesced streaming read; these kernels read 16-byte probes, 64-320-byte cell runs and
+16-byte rows, a pattern the guide calls uncalibrated, so both the raw figure and the x2-corrected upper bound
+are given."""
+import json
+import sys
+
+
+def main():
+    fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+    line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+
+    def kb(table, name, counter):
+        for k, v in table.items():
+            if k.endswith(name):
+                return v["counters_per_dispatch"].get(counter, 0.0), v["dispatches"], v["mean_duration_us"]
+        return 0.0, 0, 0.0
+
+    out = {"command": "tools/pmc_batch.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py "
+                      "--steps 1 --warmup 1 --no-cpu-baseline --no-stages (the default schedule: batches of 12)",
+           "per_dispatch_KB": {}}
+    pair_f = pair_w = 0.0
+    for name in ("icp_nn_kernel", "icp_nn_search_kernel", "icp_solve_kernel", "icp_apply_kernel"):
+        f, nf, du = kb(fetch, name, "FETCH_SIZE")
+        w, nw, _ = kb(write, name, "WRITE_SIZE")
+        out["per_dispatch_KB"][name] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "dispatches": nf,
+                                        "mean_duration_us_under_pmc": du}
+        if name in ("icp_nn_kernel", "icp_nn_search_kernel"):
+            pair_f += f * 1024.0
+            pair_w += w * 1024.0
+    alg = float(line["roofline"].get("algorithmic_bytes_per_launch") or 0.0)
+    out["icp_nn_pair_fetch_bytes_per_launch"] = round(pair_f, 1)
+    out["icp_nn_pair_write_bytes_per_launch"] = round(pair_w, 1)
+    out["icp_nn_pair_algorithmic_bytes_per_launch"] = alg
+    if alg > 0:
+        out["icp_nn_pair_traffic_over_algorithmic"] = round((pair_f + pair_w) / alg, 3)
+        out["icp_nn_pair_traffic_over_algorithmic_fetch_x2"] = round((2 * pair_f + pair_w) / alg, 3)
+    out["note"] = ("every launch of the pair is counted (live and gated alike), the algorithmic bytes are those of the "
+                   "event-sampled launches of the same run: the ratio describes the schedule, not one launch")
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
