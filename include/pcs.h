@@ -164,6 +164,21 @@ int pcs_indice_maxpool_backward_f32(const float* features, const float* out_feat
                                     int64_t pair_stride, const int32_t* num, int kv, int64_t num_in,
                                     float* in_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);
 
+/* sparse_conv_ext.indice_conv_half / fused_indice_conv_half / indice_maxpool_half (src/all.cc:35-49: the
+ * reference's templates instantiated for at::Half). features / filters / bias / out hold IEEE fp16 bit
+ * patterns. The fp16 arrays are widened once, the fp32 kernels run (fp32 accumulation over all offsets,
+ * where the reference rounds each offset's GEMM to fp16 and adds in fp16) and the result is rounded to
+ * fp16 once; the pooling is exact. bias: [cout] or NULL (NULL = indice_conv_half). */
+size_t pcs_indice_conv_f16_workspace_bytes(int64_t num_in, int cin, int kv, int cout, int64_t num_out);
+int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const void* filters, int kv, int cout,
+                        const void* bias, const int32_t* pairs, int64_t pair_stride, const int32_t* num,
+                        int64_t num_out, int inverse, int subm, void* out, void* ws, size_t ws_bytes,
+                        pcs_stream_t stream);
+size_t pcs_indice_maxpool_f16_workspace_bytes(int64_t num_in, int C, int kv, int64_t num_out);
+int pcs_indice_maxpool_f16(const void* features, int64_t num_in, int C, const int32_t* pairs, int64_t pair_stride,
+                           const int32_t* num, int kv, int64_t num_out, void* out, void* ws, size_t ws_bytes,
+                           pcs_stream_t stream);
+
 /* SparseConvTensor.dense() (pcdet/ops/spconv/structure.py:5-18,55-64) in its channels-first form, as
  * HeightCompression consumes it (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27;
  * SURVEY 8f row f3): features [V,C] at indices [V,4] (b,z,y,x) -> out [B,C,D,H,W] f32, zeros

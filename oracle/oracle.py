@@ -179,6 +179,36 @@ def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
             for i in range(3)]
 
 
+def indice_conv_half(features, filters, pairs, num, num_out, inverse=False, subm=False, bias=None):
+    """indiceConv<at::Half> / fusedIndiceConvBatchNorm<at::Half> (spconv_ops.h:260-361, fused_spconv_ops.h:29-132)
+    in the reference's own order of roundings: fp16 storage, the output starts at zero (or at the bias
+    rows), the subM centre is one GEMM into the output, every other offset gathers its rows, multiplies
+    (fp32 accumulation, result rounded to fp16 as a half GEMM returns it) and scatter-adds in fp16."""
+    f = np.asarray(features, np.float16)
+    kv = pairs.shape[0]
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    W = np.asarray(filters, np.float16).reshape(kv, cin, cout)
+    out = np.zeros((num_out, cout), np.float16)
+    if bias is not None:
+        out[:] = np.asarray(bias, np.float16)[None, :]
+    centre = -1
+    if subm:
+        centre = int(np.argmax(num))
+        out = (out.astype(np.float32) + (f.astype(np.float32) @ W[centre].astype(np.float32)).astype(np.float16)
+               .astype(np.float32)).astype(np.float16) if bias is not None else \
+            (f.astype(np.float32) @ W[centre].astype(np.float32)).astype(np.float16)
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(kv):
+        n = int(num[k])
+        if n == 0 or k == centre:
+            continue
+        src, dst = pairs[k, a, :n], pairs[k, b, :n]
+        prod = (f[src].astype(np.float32) @ W[k].astype(np.float32)).astype(np.float16)
+        for r in range(n):  # scatter-add in fp16 (a destination appears once per offset)
+            out[dst[r]] = (out[dst[r]].astype(np.float32) + prod[r].astype(np.float32)).astype(np.float16)
+    return out
+
+
 def deconv_out_shape(spatial_shape, ksize, stride, padding, dilation, output_padding):
     """get_deconv_output_size, pcdet/ops/spconv/ops.py:33-44."""
     return [(spatial_shape[i] - 1) * stride[i] - 2 * padding[i] + ksize[i] + output_padding[i] for i in range(3)]

@@ -1374,7 +1374,9 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   const int nb_s = gx_for(cmax, kSolveBlock, 1024);  // solve: one thread per component
   // PCS_ICP_MOM_STREAM: the budget test's moments as immediate LDS adds per lane (58 VGPRs, 7 waves per SIMD)
   // instead of the shuffle pre-reduction of runs (123 VGPRs, 4 waves per SIMD)
-  static const bool mom_stream = [] { const char* e = getenv("PCS_ICP_MOM_STREAM"); return !(e && atoi(e) == 0); }();
+  // (measured A/B, batches of 12: 1.50 s either way -- the launch is not short of waves -- so the default
+  // stays the shuffle form, whose workgroups send fewer LDS atomics)
+  static const bool mom_stream = [] { const char* e = getenv("PCS_ICP_MOM_STREAM"); return e && atoi(e) != 0; }();
   // PCS_ICP_SOLVE_STAGED=1: the records through LDS (measured A/B on one box, batches of 12: 1.57 s staged
   // against 1.49 s direct -- the coalesced copies cost more than the 64-line gathers of a one-wave
   // workgroup, which overlap with other waves' arithmetic); default: direct

@@ -750,3 +750,104 @@ extern "C" int pcs_sparse_to_dense(const float* features, const int32_t* indices
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
+
+// ---- half-precision entry points (sparse_conv_ext.indice_conv_half / fused_indice_conv_half /
+// indice_maxpool_half, src/all.cc:35-49) ----------------------------------------------------------
+// The reference instantiates its gather - GEMM - scatter-add templates for at::Half: fp16 storage,
+// each offset's GEMM result rounded to fp16 and added into the fp16 output. Here the fp16 arrays are
+// widened once, the fp32 kernels above run (fp32 accumulation over ALL offsets), and the result is
+// rounded to fp16 once: at least as accurate, the storage format of the caller unchanged. The pooling
+// is exact either way (a maximum of fp16 values is one of them).
+#include <hip/hip_fp16.h>
+namespace pcs {
+__global__ void __launch_bounds__(kBlock)
+half_to_float_kernel(const __half* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = __half2float(in[i]);
+}
+__global__ void __launch_bounds__(kBlock)
+float_to_half_kernel(const float* __restrict__ in, __half* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = __float2half_rn(in[i]);
+}
+struct HalfPlan {
+  float *feat, *filt, *out, *bias;
+  void* table;
+  size_t table_bytes;
+};
+static bool plan_half(Arena& a, int64_t num_in, int cin, int kv, int cout, int64_t num_out, HalfPlan& p) {
+  p.feat = a.take<float>((size_t)(num_in > 0 ? num_in : 1) * cin);
+  p.filt = a.take<float>((size_t)kv * cin * cout);
+  p.out = a.take<float>((size_t)(num_out > 0 ? num_out : 1) * cout);
+  p.bias = a.take<float>(cout);
+  p.table_bytes = pcs_neighbor_table_bytes(num_out, kv);
+  p.table = a.take<char>(p.table_bytes);
+  return a.ok();
+}
+}  // namespace pcs
+
+extern "C" {
+
+size_t pcs_indice_conv_f16_workspace_bytes(int64_t num_in, int cin, int kv, int cout, int64_t num_out) {
+  Arena a(nullptr, 0);
+  HalfPlan p;
+  plan_half(a, num_in, cin, kv, cout, num_out, p);
+  return a.off;
+}
+
+// features [num_in,cin], filters [kv,cin,cout], bias [cout] or NULL (fused_indice_conv_half), out
+// [num_out,cout]: IEEE fp16 bit patterns
+int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const void* filters, int kv, int cout,
+                        const void* bias, const int32_t* pairs, int64_t pair_stride, const int32_t* num,
+                        int64_t num_out, int inverse, int subm, void* out, void* ws, size_t ws_bytes,
+                        hipStream_t s) {
+  if (!features || !filters || !pairs || !num || !out || !ws || num_in < 0 || num_out < 0 || cin < 1 || cout < 1 ||
+      kv < 1)
+    return PCS_ERR_ARG;
+  Arena a(ws, ws_bytes);
+  HalfPlan p;
+  if (!plan_half(a, num_in, cin, kv, cout, num_out, p)) return PCS_ERR_WORKSPACE;
+  if (num_out == 0) return PCS_OK;
+  half_to_float_kernel<<<grid_for(num_in * cin), kBlock, 0, s>>>((const __half*)features, p.feat, num_in * cin);
+  half_to_float_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>((const __half*)filters, p.filt,
+                                                                           (int64_t)kv * cin * cout);
+  if (bias) half_to_float_kernel<<<1, kBlock, 0, s>>>((const __half*)bias, p.bias, cout);
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, inverse, num_out, (int32_t*)p.table, s);
+  if (rc) return rc;
+  const int centre = (subm && (kv & 1)) ? kv / 2 : -1;
+  rc = pcs_indice_conv_table_f32(p.feat, cin, p.filt, kv, cout, centre, (const int32_t*)p.table, num_out,
+                                 bias ? p.bias : nullptr, nullptr, nullptr, 0, p.out, s);
+  if (rc) return rc;
+  float_to_half_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(p.out, (__half*)out, num_out * cout);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+size_t pcs_indice_maxpool_f16_workspace_bytes(int64_t num_in, int C, int kv, int64_t num_out) {
+  Arena a(nullptr, 0);
+  a.take<float>((size_t)(num_in > 0 ? num_in : 1) * C);
+  a.take<float>((size_t)(num_out > 0 ? num_out : 1) * C);
+  a.take<char>(pcs_neighbor_table_bytes(num_out, kv));
+  return a.off;
+}
+
+int pcs_indice_maxpool_f16(const void* features, int64_t num_in, int C, const int32_t* pairs, int64_t pair_stride,
+                           const int32_t* num, int kv, int64_t num_out, void* out, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  if (!features || !pairs || !num || !out || !ws || num_in < 0 || num_out < 0 || C < 1 || kv < 1) return PCS_ERR_ARG;
+  Arena a(ws, ws_bytes);
+  float* f = a.take<float>((size_t)(num_in > 0 ? num_in : 1) * C);
+  float* o = a.take<float>((size_t)(num_out > 0 ? num_out : 1) * C);
+  const size_t tb = pcs_neighbor_table_bytes(num_out, kv);
+  void* table = a.take<char>(tb);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  if (num_out == 0) return PCS_OK;
+  half_to_float_kernel<<<grid_for(num_in * C), kBlock, 0, s>>>((const __half*)features, f, num_in * C);
+  int rc = pcs_indice_maxpool_f32(f, C, pairs, pair_stride, num, kv, num_out, o, table, tb, s);
+  if (rc) return rc;
+  float_to_half_kernel<<<grid_for(num_out * C), kBlock, 0, s>>>(o, (__half*)out, num_out * C);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+}  // extern "C"

@@ -1199,15 +1199,19 @@ class Engine {
   // A device has a few engines (PCS_TRACK_ENGINES, default 3; measured 1 / 2 / 3: 1.88 / 1.75 / 1.67 s per batch of 12: while one chain is in its single-workgroup
   // phases -- sampling sort, smooth_velo, compactions -- the other's iteration launches fill the chip);
   // a call's units all join the engine that has the fewest units at that moment.
-  static constexpr int kMaxEngines = 4;
-  static Engine* get(int device) {
-    static std::mutex mu;
-    static Engine* inst[64][kMaxEngines] = {};
+  static constexpr int kMaxEngines = 8;
+  static int count() {
     static const int n_engines = [] {
       const char* e = getenv("PCS_TRACK_ENGINES");
       int c = e ? atoi(e) : 0;
       return (c >= 1 && c <= kMaxEngines) ? c : 3;
     }();
+    return n_engines;
+  }
+  static Engine* get(int device) {
+    static std::mutex mu;
+    static Engine* inst[64][kMaxEngines] = {};
+    const int n_engines = count();
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     Engine* best = nullptr;
@@ -1927,20 +1931,30 @@ static int run_sequences(const PcsTrackParams* prm, const SeqIn* seqs, int n_seq
   Call call;
   Arena a(ws, ws_bytes);
   int rc = PCS_OK;
+  const int n_eng = Engine::count();
   for (int q = 0; q < n_seqs && rc == PCS_OK; ++q) {
-    Engine* eng = Engine::get(device);  // (the least loaded of the device's engines)
-    if (!eng) { rc = PCS_ERR_HIP; break; }
-    int slots[kMaxCallUnits];
-    rc = eng->reserve(*prm, seqs[q].n_units, slots);
-    if (rc != PCS_OK) break;
-    rc = prepare_sequence(eng, prm, seqs[q].seq_fxyz, seqs[q].frame_offsets, seqs[q].num_frames, seqs[q].units,
-                          seqs[q].n_units, a, ws, slots, s);
-    if (rc != PCS_OK) {
-      (void)hipStreamSynchronize(s);  // nothing of the set-up may still run on the slots / the workspace
-      eng->release(slots, seqs[q].n_units);
-      break;
+    // a sequence's units are dealt to the device's engines in contiguous shares (each share to the engine
+    // that is least loaded at that moment): one sequence alone then runs as several chains side by side
+    // instead of one, and a batch loads the engines evenly
+    const int shares = seqs[q].n_units < n_eng ? seqs[q].n_units : n_eng;
+    int first = 0;
+    for (int g = 0; g < shares && rc == PCS_OK; ++g) {
+      const int n = (seqs[q].n_units - first + (shares - g) - 1) / (shares - g);
+      Engine* eng = Engine::get(device);
+      if (!eng) { rc = PCS_ERR_HIP; break; }
+      int slots[kMaxCallUnits];
+      rc = eng->reserve(*prm, n, slots);
+      if (rc != PCS_OK) break;
+      rc = prepare_sequence(eng, prm, seqs[q].seq_fxyz, seqs[q].frame_offsets, seqs[q].num_frames,
+                            seqs[q].units + first, n, a, ws, slots, s);
+      if (rc != PCS_OK) {
+        (void)hipStreamSynchronize(s);  // nothing of the set-up may still run on the slots / the workspace
+        eng->release(slots, n);
+        break;
+      }
+      eng->submit(&call, slots, n);
+      first += n;
     }
-    eng->submit(&call, slots, seqs[q].n_units);
   }
   {
     std::unique_lock<std::mutex> lk(call.mu);
@@ -1952,8 +1966,10 @@ static int run_sequences(const PcsTrackParams* prm, const SeqIn* seqs, int n_seq
 
 static size_t sequence_workspace_bytes(Arena& a, const int64_t* frame_offsets, int num_frames,
                                        const PcsTrackUnit* units, int n_units) {
-  SeqPlan sq;
-  plan_seq(a, sq);
+  for (int g = 0; g < Engine::kMaxEngines; ++g) {  // (one per share of the sequence's units, see run_sequences)
+    SeqPlan sq;
+    plan_seq(a, sq);
+  }
   for (int i = 0; i < n_units; ++i) {
     const PcsTrackUnit& io = units[i];
     if (io.anchor_frame < 0 || io.anchor_frame >= num_frames || io.min_frame_id < 0 ||

@@ -308,6 +308,43 @@ def indice_conv(features, filters, pairs, num, num_out, inverse=False, subm=Fals
     return out
 
 
+def indice_conv_half(features, filters, pairs, num, num_out, inverse=False, subm=False, bias=None):
+    """sparse_conv_ext.indice_conv_half / fused_indice_conv_half (src/all.cc:35-41): fp16 in, fp16 out,
+    fp32 accumulation (pcs_indice_conv_f16). `bias`: the fused form's [cout] fp16 vector."""
+    L.require_gpu(features, "indice_conv_half")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = pairs.shape[0]
+    W = filters.reshape(kv, cin, cout).half().contiguous()
+    features = features.half().contiguous()
+    b = bias.half().contiguous() if bias is not None else None
+    num_in = features.shape[0]
+    out = torch.empty(num_out, cout, dtype=torch.float16, device=features.device)
+    ws = L.workspace(lib.pcs_indice_conv_f16_workspace_bytes(L.i64(num_in), L.i32(cin), L.i32(kv), L.i32(cout),
+                                                             L.i64(num_out)), features.device)
+    L.check(lib.pcs_indice_conv_f16(L.ptr(features), L.i64(num_in), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                    L.ptr(b), L.ptr(pairs.contiguous()), L.i64(pairs.shape[2]), L.ptr(num),
+                                    L.i64(num_out), L.i32(int(inverse)), L.i32(int(subm)), L.ptr(out), L.ptr(ws),
+                                    L.i64(ws.numel()), L.stream()), "pcs_indice_conv_f16")
+    return out
+
+
+def indice_maxpool_half(features, pairs, num, num_out):
+    """sparse_conv_ext.indice_maxpool_half (src/all.cc:46-47): exact (a maximum of fp16 values is one of them)."""
+    L.require_gpu(features, "indice_maxpool_half")
+    lib = L.load()
+    features = features.half().contiguous()
+    pairs = pairs.contiguous()
+    kv, C, num_in = pairs.shape[0], features.shape[1], features.shape[0]
+    out = torch.empty(num_out, C, dtype=torch.float16, device=features.device)
+    ws = L.workspace(lib.pcs_indice_maxpool_f16_workspace_bytes(L.i64(num_in), L.i32(C), L.i32(kv), L.i64(num_out)),
+                     features.device)
+    L.check(lib.pcs_indice_maxpool_f16(L.ptr(features), L.i64(num_in), L.i32(C), L.ptr(pairs), L.i64(pairs.shape[2]),
+                                       L.ptr(num), L.i32(kv), L.i64(num_out), L.ptr(out), L.ptr(ws), L.i64(ws.numel()),
+                                       L.stream()), "pcs_indice_maxpool_f16")
+    return out
+
+
 # ---------------------------------------------------------------- radius graph
 def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, dframe_min=0, dframe_max=0,
                  cell_size=0.0, want_dists=False):

@@ -44,8 +44,22 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,
                 subm=False):
+    """ops.py:105-120 of the reference: dispatch on the filters' dtype (fp32 / half)."""
+    import torch
+    if filters.dtype == torch.float16:
+        return _ops.indice_conv_half(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse, subm)
     return _ops.indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
                             inverse, subm)
+
+
+def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse, subm):
+    """ops.py:123-135 of the reference (fused_indice_conv_fp32 / _half): conv + bias in one call."""
+    import torch
+    if filters.dtype == torch.float16:
+        return _ops.indice_conv_half(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse, subm,
+                                     bias=bias)
+    table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, num_activate_out, inverse)
+    return _ops.indice_conv_table(features, filters, table, num_activate_out, subm and not inverse, bias=bias)
 
 
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
@@ -53,6 +67,9 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
 
 
 def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    import torch
+    if features.dtype == torch.float16:
+        return _ops.indice_maxpool_half(features, indice_pairs, indice_pair_num, num_activate_out)
     return _ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
 
 

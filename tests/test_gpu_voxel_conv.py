@@ -332,3 +332,39 @@ def test_deconv_rulebook_and_transposed_conv(oracle):
     W = conv.weight.detach().cpu().numpy()
     ref = oracle.indice_conv(feat, W, want[1], want[2], want[0].shape[0], False, False) + conv.bias.detach().cpu().numpy()
     np.testing.assert_allclose(y.features.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_half_precision_conv_and_maxpool(oracle):
+    """indice_conv_half / fused_indice_conv_half / indice_maxpool_half (src/all.cc:35-49). The HIP entries keep
+    fp16 storage and accumulate in fp32 over all offsets; the oracle restates the reference's order of
+    roundings (each offset's GEMM rounded to fp16, fp16 scatter-add): agreement to a few fp16 units of the
+    result's scale; against the fp32 conv of the same fp16 values to one fp16 rounding; pooling bit-exact."""
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(41)
+    shape = [9, 24, 24]
+    idx = random_indices(rng, shape, 1500, batch=2)
+    V = idx.shape[0]
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        feat = rng.normal(0, 1, (V, 16)).astype(np.float16)
+        W = rng.normal(0, 0.1, (27, 16, 32)).astype(np.float16)
+        bias = rng.normal(0, 0.5, 32).astype(np.float16)
+        for b in (None, bias):
+            got = ops.indice_conv_half(dev(feat), dev(W), dev(pairs), dev(num), n_out, False, subm,
+                                       bias=None if b is None else dev(b))
+            assert got.dtype == torch.float16
+            got = got.cpu().numpy().astype(np.float32)
+            want = oracle.indice_conv_half(feat, W, pairs, num, n_out, False, subm, bias=b).astype(np.float32)
+            scale = float(np.abs(want).max())
+            assert float(np.abs(got - want).max()) <= 8 * 2.0 ** -10 * scale
+            exact = oracle.indice_conv(feat.astype(np.float32), W.astype(np.float32), pairs, num, n_out, False, subm)
+            if b is not None:
+                exact = exact + b.astype(np.float32)
+            np.testing.assert_allclose(got, exact, rtol=2.0 ** -10, atol=2.0 ** -11 * scale)
+        if not subm:
+            pooled = ops.indice_maxpool_half(dev(feat), dev(pairs), dev(num), n_out)
+            want = oracle.indice_maxpool(feat.astype(np.float32), pairs, num, n_out)
+            assert pooled.dtype == torch.float16
+            np.testing.assert_array_equal(pooled.cpu().numpy().astype(np.float32), want)
