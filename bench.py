@@ -325,6 +325,12 @@ def main():
         with torch.no_grad():
             model(batch)
 
+    if args.warmup > 0 and batch is not batch1:
+        # the first sequence alone, on one host thread, before the first batch: every code object the path
+        # uses is loaded by one thread (twelve threads taking first launches of the same torch / rocPRIM
+        # kernels at once have crashed rocprofv3's tool library twice; a plain run does not need this)
+        with torch.no_grad():
+            model(batch1)
     for _ in range(args.warmup):
         step()
 

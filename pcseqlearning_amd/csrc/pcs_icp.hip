@@ -55,7 +55,7 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
   b.Rt = a.take<double>(C * 12);
-  b.lossfx = a.take<long long>(2 * kLossParts);
+  b.lossfx = a.take<long long>(4 * kLossParts);  // [2][kLossParts] fine sums, then [2][kLossParts] coarse check sums
   b.corg = a.take<float4>(C);
   b.first = a.take<int32_t>(C);
   b.cov = a.take<int32_t>(C);
@@ -188,7 +188,7 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) pr.acc[q] = 0;
   for (int64_t q = i; q < 2 * kStepH; q += stride) pr.sstep[q] = 0u;
   for (int64_t q = i; q < C; q += stride) { pr.cov[q] = 0; pr.first[q] = INT_MAX; }
-  if (i < 2 * kLossParts) pr.lossfx[i] = 0;
+  if (i < 4 * kLossParts) pr.lossfx[i] = 0;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   g2_clear(g2_view(pr.gr, Rn), i, stride);
@@ -298,14 +298,24 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
   if (k_done < 1 || st->decided >= k_done || st->stop_iter != INT_MAX) return;  // uniform per workgroup
   if (threadIdx.x >= 64) return;
   long long* part = pr.lossfx + (size_t)(k_done & 1) * kLossParts;
-  long long v = 0;
+  long long* chk = pr.lossfx + (size_t)(2 + (k_done & 1)) * kLossParts;
+  long long v = 0, vc = 0;
   if (threadIdx.x < kLossParts) {
     v = part[threadIdx.x];
-    part[threadIdx.x] = 0;  // (the apply launch of iteration k_done + 2 adds here next)
+    vc = chk[threadIdx.x];
+    part[threadIdx.x] = 0;  // (the solve launch of iteration k_done + 2 adds here next)
+    chk[threadIdx.x] = 0;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o, 64);
+    vc += __shfl_xor(vc, o, 64);
+  }
   if (threadIdx.x == 0) {
+    // every component's term is within the fixed-point range, their SUM over many large components need
+    // not be (2^27 in total at 36 fractional bits): the same terms also add up at 10 fractional bits
+    // (range 2^53), and a fine sum that wrapped disagrees with the coarse one by ~2^28
+    if (fabs((double)v * kFxInv - (double)vc * (1.0 / 1024.0)) > 1.0 + (double)pr.C * (1.0 / 1024.0)) st->err = 1;
     const double loss = (double)v * kFxInv;
     st->loss = loss;
     if (st->last_error - loss < pr.delta) st->countdown -= 1;
@@ -535,7 +545,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 // Exact: the same neighbours as a full search, always.
 template <bool STREAM>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int lds_steps) {
   WGT_BEGIN();
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   const int k = kbase.v[blockIdx.y] + 1 + j;
@@ -560,7 +570,8 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
   if (blockIdx.x == 0) icp_decide(pr, k - 1);
   WGT_MARK(wg_m1);
-  if (k == 1) {  // no neighbours yet: every query takes the cooperative search
+  if (k == 1) {  // no neighbours yet: every query is searched for
+    if (lds_steps & 2) return;  // (icp_first_kernel has dealt them to the two kinds of search)
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
     return;
@@ -584,6 +595,17 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
   // steps of the moving points in iteration k-1, by the place they moved into
   const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
+  // A backward query looks up eight hashed slots of the 16 KB step table: eight scattered requests where
+  // the rest of the query has three. A workgroup that serves backward queries (its last round reaches past
+  // Mn) copies the table into LDS once -- coalesced, L2-resident: every workgroup of the unit reads it.
+  __shared__ unsigned int s_step[kStepH];
+  {
+    const int r_last = blockIdx.x + ((nround - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
+    if ((lds_steps & 1) && k > 1 && (r_last + 1) * kBlock > Mn) {
+      for (int q = threadIdx.x; q < kStepH / 4; q += kBlock) ((uint4*)s_step)[q] = ((const uint4*)sstep)[q];
+      __syncthreads();
+    }
+  }
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
@@ -614,9 +636,15 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
                   cz = (int)floorf((p.w - g.lo[2]) / g.h);
         const int sx = (4 * ((cx >> 2) - 1)) >> 3, sy = (4 * ((cy >> 2) - 1)) >> 3, sz = (4 * ((cz >> 2) - 1)) >> 3;
         unsigned int m = 0u;
+        if (lds_steps & 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          m = max(m, sstep[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
+          for (int q = 0; q < 8; ++q)
+            m = max(m, s_step[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            m = max(m, sstep[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
+        }
         disp = __uint_as_float(m);
       }
       bud = bud - disp * 1.000001f - 1e-7f;
@@ -681,6 +709,82 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   WGT_MARK(wg_m2);
   mom_flush(mt);
   WGT_END(1, k, wg_m1, wg_m2);
+}
+
+// Iteration 1 of a registration: no partner yet. Half of all cooperative searches are these -- 32 lanes
+// walking 27 coarse blocks per query. A point of the OTHER cloud that lies in the query's own fine cell is a
+// seed as good as an old partner: where the search's own admission test accepts it, the query goes to the
+// eight-lane search around it (exact: the same result as the cooperative search), the seed's index parked in
+// the neighbour buffer that an iteration 0 would have written; the others take the cooperative search.
+// A launch of its own (entries not in their first iteration leave at once) so that the budget test keeps
+// its registers.
+__global__ void __launch_bounds__(kBlock)
+icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  IcpState* st = pr.st;
+  if (k != 1 || k > pr.max_iter || k > st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int nq = Mn + Rn;
+  const int nround = (nq + kBlock - 1) / kBlock;
+  const GridDesc g = pr.geom->g;
+  const int lane = threadIdx.x & 63;
+  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[1], Mn);
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+    const int qid = r * kBlock + threadIdx.x;
+    const bool valid = qid < nq;
+    const bool fwd = qid < Mn;
+    bool to_seeded = false;
+    if (valid) {
+      const float4 p = fwd ? pr.mov[qid] : pr.ref[qid - Mn];
+      Grid2 gh = g_ref;  // (a copy selected field by field: a reference to either would live in scratch memory)
+      if (!fwd) gh = g_mov;
+      const int dfq = fwd ? pr.df : -pr.df;
+      const int fc = frame_cell(g, p.x) + dfq;
+      const int cx = (int)floorf((p.y - g.lo[0]) / g.h), cy = (int)floorf((p.z - g.lo[1]) / g.h),
+                cz = (int)floorf((p.w - g.lo[2]) / g.h);
+      if (fc >= 0 && fc < kFrameCells && cx >= 0 && cy >= 0 && cz >= 0) {
+        uint32_t cnt_w = 0, pad_w = 0;
+        const int fs = g2_find(gh.fslot, gh.Hf - 1, pack_cell(fc, cx, cy, cz), &cnt_w, &pad_w);
+        if (fs >= 0 && cnt_w > 0) {
+          const float4 sp = gh.spts[(size_t)fs * kCellCap];
+          const int sidx = gh.sidx[(size_t)fs * kCellCap];
+          const float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
+          float dist2 = 0.f;
+          dist2 = dist2 + d0 * d0;
+          dist2 = dist2 + d1 * d1;
+          dist2 = dist2 + d2 * d2;
+          dist2 = dist2 + d3 * d3;
+          if (g2_seed_admissible(g, gh, p, dfq, dist2, pr.mu)) {
+            to_seeded = true;
+            if (fwd) pr.nn_f[qid] = sidx;  // buffer (k - 1) & 1 = 0: where the searches read their seeds
+            else pr.nn_b[qid - Mn] = sidx;
+          }
+        }
+      }
+    }
+    const bool to_coop = valid && !to_seeded;
+    const unsigned long long mf = __ballot(fwd);
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const unsigned long long md = dir ? ~mf : mf;
+      const unsigned long long ms = __ballot(to_seeded) & md, mc = __ballot(to_coop) & md;
+      const int off = dir ? Mn : 0;
+      if (ms) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&st->ws_n[dir], __popcll(ms));
+        base = __shfl(base, 0, 64);
+        if (to_seeded && fwd == (dir == 0)) pr.wls[off + base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
+      }
+      if (mc) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&st->wl_n[dir], __popcll(mc));
+        base = __shfl(base, 0, 64);
+        if (to_coop && fwd == (dir == 0)) pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
+      }
+    }
+  }
 }
 
 // The searches of one iteration for ALL entries of the batch, as a queue: a work item is one round of
@@ -1106,6 +1210,7 @@ icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   const double* __restrict__ T_in = pr.Tb + (size_t)((k - 1) & 1) * C * 16;
   double* __restrict__ T_out = pr.Tb + (size_t)(k & 1) * C * 16;
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
+  long long loss_ck = 0;  // the same at 10 fractional bits (overflow check of the sum, see icp_decide)
   const int nround = (int)((C + kSolveBlock - 1) / kSolveBlock);
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {
     const int64_t c0 = (int64_t)r * kSolveBlock;
@@ -1129,8 +1234,11 @@ icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
         const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
         double ls;
         icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
-        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of the sum)
-        else loss_fx += to_fx(ls);
+        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of a term)
+        else {
+          loss_fx += to_fx(ls);
+          loss_ck += __double2ll_rn(ls * 1024.0);
+        }
       } else {  // nothing moves: the transform stays what it is (the identity the reset wrote)
 #pragma unroll
         for (int q = 0; q < 16; ++q) Tn[q] = Tc[q];
@@ -1164,10 +1272,16 @@ icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   }
   // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) loss_fx += __shfl_xor(loss_fx, o, 64);
-  if ((threadIdx.x & 63) == 0 && loss_fx != 0)
+  for (int o = 32; o > 0; o >>= 1) {
+    loss_fx += __shfl_xor(loss_fx, o, 64);
+    loss_ck += __shfl_xor(loss_ck, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (loss_fx != 0 || loss_ck != 0)) {
     atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts + (blockIdx.x & (kLossParts - 1))],
               (unsigned long long)loss_fx);
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(2 + (k & 1)) * kLossParts + (blockIdx.x & (kLossParts - 1))],
+              (unsigned long long)loss_ck);
+  }
 }
 
 // iteration k, last launch: every moving point moves by its component's step. The previous positions are
@@ -1377,6 +1491,13 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   // (measured A/B, batches of 12: 1.50 s either way -- the launch is not short of waves -- so the default
   // stays the shuffle form, whose workgroups send fewer LDS atomics)
   static const bool mom_stream = [] { const char* e = getenv("PCS_ICP_MOM_STREAM"); return e && atoi(e) != 0; }();
+  // bit 0 (PCS_ICP_LDS_STEPS, default on): the step table in LDS for the backward queries; bit 1
+  // (PCS_ICP_SEED_FIRST, default on): iteration 1 seeds its searches from the query's own fine cell
+  static const int lds_steps = [] {
+    const char* e = getenv("PCS_ICP_LDS_STEPS");
+    const char* f = getenv("PCS_ICP_SEED_FIRST");
+    return ((e && atoi(e) == 0) ? 0 : 1) | ((f && atoi(f) == 0) ? 0 : 2);
+  }();
   // PCS_ICP_SOLVE_STAGED=1: the records through LDS (measured A/B on one box, batches of 12: 1.57 s staged
   // against 1.49 s direct -- the coalesced copies cost more than the 64-line gathers of a one-wave
   // workgroup, which overlap with other waves' arithmetic); default: direct
@@ -1407,15 +1528,17 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   t_ev_used = prof ? js + 1 : 0;
   for (int j = 0; j < n_it; ++j) {
     const int nb_c = (j == 0 && any_first) ? nb_c1 : nb_cs;
+    if (j == 0 && any_first && (lds_steps & 2))
+      icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
     if (j == js) {
       // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
       // kernel's own begin-to-end time, as rocprofv3 reports it
       hipEvent_t* e = &t_ev.ev[0];
       // (the search is two launches; the pair is timed as one kernel, first start to last stop)
       if (mom_stream)
-        hipExtLaunchKernelGGL(icp_nn_kernel<true>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+        hipExtLaunchKernelGGL(icp_nn_kernel<true>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j, lds_steps);
       else
-        hipExtLaunchKernelGGL(icp_nn_kernel<false>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j);
+        hipExtLaunchKernelGGL(icp_nn_kernel<false>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j, lds_steps);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
                             bt, kbase, j);
       if (solve_staged)
@@ -1427,8 +1550,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
                             kbase, j);
     } else {
-      if (mom_stream) icp_nn_kernel<true><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
-      else icp_nn_kernel<false><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      if (mom_stream) icp_nn_kernel<true><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
+      else icp_nn_kernel<false><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
       icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
       if (solve_staged) icp_solve_kernel<true><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
       else icp_solve_kernel<false><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);

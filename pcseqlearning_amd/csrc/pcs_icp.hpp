@@ -89,7 +89,7 @@ struct IcpProblem {
   long long* acc;       // [2, C, kAcc]
   double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
   double* Rt;           // [C, 12] rotation (9) and translation (3) of the current iteration's step
-  long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity)
+  long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity), then [2][kLossParts] the same at 10 fractional bits (overflow check)
   float4* corg;         // [C] origin of the component's fixed-point moments
   int32_t* cov;         // [C] matched moving points in the final coverage query
   IcpState* st;

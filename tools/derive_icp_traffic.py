@@ -16,10 +16,13 @@ def main():
     line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
 
     def kb(table, name, counter):
+        tot, n, dur = 0.0, 0, 0.0  # (template instances of a kernel are separate rows: dispatch-weighted mean)
         for k, v in table.items():
-            if k.endswith(name):
-                return v["counters_per_dispatch"].get(counter, 0.0), v["dispatches"], v["mean_duration_us"]
-        return 0.0, 0, 0.0
+            if ("::" + name) in k:
+                tot += v["counters_per_dispatch"].get(counter, 0.0) * v["dispatches"]
+                dur += v["mean_duration_us"] * v["dispatches"]
+                n += v["dispatches"]
+        return (tot / n, n, dur / n) if n else (0.0, 0, 0.0)
 
     out = {"command": "tools/pmc_batch.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py "
                       "--steps 1 --warmup 1 --no-cpu-baseline --no-stages (the default schedule: batches of 12)",
