@@ -102,7 +102,11 @@ int pcs_hard_voxelize(const float* pts, int64_t n, int ncol, const float* range6
  * rulebook of a transposed conv (getIndicePairsDeConv, geometry.h:197-245: out = in * stride - pad
  * + k * dilation, out_shape3 = get_deconv_output_size), same orders. The capacity / workspace
  * queries take `subm` = 0 strided, 1 submanifold, 2 transposed.
- * All *3 arrays are host int[3] in (z,y,x) order. KV <= 32. */
+ * All *3 arrays are host int[3] in (z,y,x) order. KV <= 32.
+ * The strided and transposed forms synchronise `stream` once inside the call: the number of output voxels
+ * decides the size of the remaining work (and whether the first, small coordinate table was large enough;
+ * if not the claims are redone on a table of two slots per possible output). The reference's caller reads
+ * that count on the host straight after the call in any case (ops.py:97-99). */
 int64_t pcs_indice_pairs_out_capacity(int64_t V, const int* ksize3, const int* stride3, int subm);
 size_t pcs_get_indice_pairs_workspace_bytes(int64_t V, const int* ksize3, const int* stride3,
                                             int subm);
@@ -111,6 +115,17 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
                          const int* pad3, const int* dil3, int subm, int transpose,
                          int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
                          int64_t* d_num_out, void* ws, size_t ws_bytes, pcs_stream_t stream);
+/* The same call, and -- where pcs_indice_pairs_gives_table() returns 1: submanifold, odd kernel sizes, no
+ * dilation -- row j of `table` [V,KV] int32 = the inputs of output j by kernel offset, -1 where none:
+ * what pcs_build_neighbor_table makes of the pairs, taken from the rulebook's own probing pass. `table`
+ * may be NULL (then this IS pcs_get_indice_pairs). */
+int pcs_indice_pairs_gives_table(const int* ksize3, const int* dil3, int subm);
+int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
+                               const int* spatial_shape3, const int* ksize3, const int* stride3,
+                               const int* pad3, const int* dil3, int subm, int transpose,
+                               int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
+                               int64_t* d_num_out, int32_t* table, void* ws, size_t ws_bytes,
+                               pcs_stream_t stream);
 
 /* sparse_conv_ext.indice_conv_fp32, src/all.cc:30-33 -> indiceConv<float>,
  * spconv_ops.h:260-361. features [num_in,cin], filters [kv,cin,cout], out [num_out,cout].

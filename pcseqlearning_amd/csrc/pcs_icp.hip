@@ -527,6 +527,23 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
   }
 }
 
+// XCD-aware placement (flag bit 2, PCS_ICP_XCD): workgroups are dealt round-robin over the eight XCDs in
+// dispatch order (x fastest), each XCD with its own L2. The (x, entry) grid is re-read so that the
+// workgroups that share an XCD (equal linear id mod 8) serve a CONTIGUOUS eighth of the (entry, x) space:
+// an entry's clouds, grids and neighbour buffers are then fetched into one or two L2s instead of eight.
+// A bijection of the grid whatever its size (the last n mod 8 workgroups keep their place); speed only.
+struct WgXY { int x, y; };
+__device__ __forceinline__ WgXY xcd_wg(bool on) {
+  WgXY w = {(int)blockIdx.x, (int)blockIdx.y};
+  if (!on) return w;
+  const unsigned gx = gridDim.x, n = gx * gridDim.y, cpx = n >> 3, lin = blockIdx.y * gx + blockIdx.x;
+  if (lin >= (cpx << 3)) return w;
+  const unsigned swz = (lin & 7u) * cpx + (lin >> 3);
+  w.y = (int)(swz / gx);
+  w.x = (int)(swz - (unsigned)w.y * gx);
+  return w;
+}
+
 // Queries [0,Mn): forward (moving -> reference, df = +frame_offset); queries [Mn, Mn+Rn): backward
 // (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED CACHE: every search also
 // returns how far things may move before its answer can change (half the gap to the runner-up, or
@@ -547,8 +564,9 @@ template <bool STREAM>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int lds_steps) {
   WGT_BEGIN();
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
+  const WgXY wg = xcd_wg((lds_steps & 4) != 0);
+  const IcpProblem& pr = tab[bt.idx[wg.y]];
+  const int k = kbase.v[wg.y] + 1 + j;
   IcpState* st = pr.st;
   // The gate is read ONCE per workgroup. Workgroup 0 lowers stop_iter during this very launch (below),
   // and the waves of a workgroup do not start together: with a per-thread gate some waves of a
@@ -564,16 +582,16 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
   const int nround = (nq + kBlock - 1) / kBlock;
-  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  if (wg.x != 0 && wg.x >= nround) return;
   // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
   // were written by the previous launch). The other workgroups may run before the stop is known:
   // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  if (wg.x == 0) icp_decide(pr, k - 1);
   WGT_MARK(wg_m1);
   if (k == 1) {  // no neighbours yet: every query is searched for
     if (lds_steps & 2) return;  // (icp_first_kernel has dealt them to the two kinds of search)
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
+    for (int q = wg.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
+    if (wg.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
     return;
   }
   __shared__ int skey[kMomSlots];
@@ -600,13 +618,13 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   // Mn) copies the table into LDS once -- coalesced, L2-resident: every workgroup of the unit reads it.
   __shared__ unsigned int s_step[kStepH];
   {
-    const int r_last = blockIdx.x + ((nround - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
+    const int r_last = wg.x + ((nround - 1 - wg.x) / (int)gridDim.x) * (int)gridDim.x;
     if ((lds_steps & 1) && k > 1 && (r_last + 1) * kBlock > Mn) {
       for (int q = threadIdx.x; q < kStepH / 4; q += kBlock) ((uint4*)s_step)[q] = ((const uint4*)sstep)[q];
       __syncthreads();
     }
   }
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
@@ -719,9 +737,10 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
 // A launch of its own (entries not in their first iteration leave at once) so that the budget test keeps
 // its registers.
 __global__ void __launch_bounds__(kBlock)
-icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
+icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
+  const WgXY wg = xcd_wg((flags & 4) != 0);
+  const IcpProblem& pr = tab[bt.idx[wg.y]];
+  const int k = kbase.v[wg.y] + 1 + j;
   IcpState* st = pr.st;
   if (k != 1 || k > pr.max_iter || k > st->stop_iter) return;
   int Mn, Rn, Ra;
@@ -731,7 +750,7 @@ icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   const GridDesc g = pr.geom->g;
   const int lane = threadIdx.x & 63;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[1], Mn);
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
+  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
     const int qid = r * kBlock + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
@@ -797,7 +816,7 @@ icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
 // percentile, 187 us at the 99th, the first iteration of a registration, whose seeded slices are all
 // empty), in a launch whose mean workgroup lasts 25 us (tools/wg_trace.py).
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
   WGT_BEGIN();
   static_assert(4 * kMaxBatch <= 2 * kBlock, "two lists per thread");
   __shared__ int s_pref[4 * kMaxBatch + 1];
@@ -845,7 +864,16 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
     __syncthreads();
   }
   const int R = s_pref[nlist];
-  for (int w = blockIdx.x; w < R; w += gridDim.x) {
+  int w_first = blockIdx.x, w_step = gridDim.x, w_end = R;
+  if ((flags & 4) && (gridDim.x & 7u) == 0) {
+    // (see xcd_wg) the workgroups that share an XCD take a contiguous eighth of the items: the lists are
+    // concatenated entry by entry, so an XCD's L2 sees the grids of an eighth of the entries
+    const int lab = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    w_first = (int)(((int64_t)R * lab) >> 3) + slot;
+    w_end = (int)(((int64_t)R * (lab + 1)) >> 3);
+    w_step = gridDim.x >> 3;
+  }
+  for (int w = w_first; w < w_end; w += w_step) {
     int lo = 0, hi = nlist - 1;  // the list of item w: the last t with s_pref[t] <= w
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -926,7 +954,7 @@ icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kba
     __syncthreads();  // (the table is initialised again for the next item)
   }
 #ifdef PCS_WG_TRACE
-  if ((int)blockIdx.x < R) WGT_END(2, 0, 0ULL, 0ULL);
+  if (w_first < w_end) WGT_END(2, 0, 0ULL, 0ULL);
 #endif
 }
 
@@ -1288,10 +1316,11 @@ icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
 // kept for the l1 passes. The moved points go straight into the grid of the next iteration (the moving
 // grid is double-buffered: no separate build launch), and the grid this iteration searched is reset.
 __global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
+icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
   WGT_BEGIN();
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
+  const WgXY wg = xcd_wg((flags & 4) != 0);
+  const IcpProblem& pr = tab[bt.idx[wg.y]];
+  const int k = kbase.v[wg.y] + 1 + j;
   IcpState* st = pr.st;
   if (k > pr.max_iter || k > st->stop_iter) return;
   int Mn, Rn, Ra;
@@ -1302,7 +1331,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   const double* __restrict__ Rt = pr.Rt;
   const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
   const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
-  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t tid = wg.x * (int64_t)blockDim.x + threadIdx.x;
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
   g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
@@ -1324,7 +1353,7 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
 #ifdef PCS_WG_TRACE
   int wgt_rounds = 0, wgt_owner = 0;
 #endif
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
+  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
     const int i = r * kBlock + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef PCS_WG_TRACE
@@ -1496,7 +1525,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   static const int lds_steps = [] {
     const char* e = getenv("PCS_ICP_LDS_STEPS");
     const char* f = getenv("PCS_ICP_SEED_FIRST");
-    return ((e && atoi(e) == 0) ? 0 : 1) | ((f && atoi(f) == 0) ? 0 : 2);
+    const char* x = getenv("PCS_ICP_XCD");  // bit 2: XCD-aware placement of the iteration kernels (xcd_wg)
+    return ((e && atoi(e) == 0) ? 0 : 1) | ((f && atoi(f) == 0) ? 0 : 2) | ((x && atoi(x) != 0) ? 4 : 0);
   }();
   // PCS_ICP_SOLVE_STAGED=1: the records through LDS (measured A/B on one box, batches of 12: 1.57 s staged
   // against 1.49 s direct -- the coalesced copies cost more than the 64-line gathers of a one-wave
@@ -1512,8 +1542,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   const int nb_q = gx_for((q + rounds_per_wg - 1) / rounds_per_wg, kBlock, 1024);
   // the searches are a queue over the work lists of all entries (items of 8 cooperative / 32 seeded
   // queries): iteration 1 searches for every query, later ones for ~6 % + ~12 % of them
-  const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8));
-  const int nb_cs = (int)(qsum / 48 < 64 ? 64 : (qsum / 48 > 2048 ? 2048 : qsum / 48));
+  const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8)) & ~7;  // (multiples of 8: xcd_wg)
+  const int nb_cs = (int)(qsum / 48 < 64 ? 64 : (qsum / 48 > 2048 ? 2048 : qsum / 48)) & ~7;
   const int nb_m = gx_for(m, kBlock, 4096);
   bool prof = g_prof_on;
   if (prof && !t_ev.have) {
@@ -1529,7 +1559,7 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   for (int j = 0; j < n_it; ++j) {
     const int nb_c = (j == 0 && any_first) ? nb_c1 : nb_cs;
     if (j == 0 && any_first && (lds_steps & 2))
-      icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
     if (j == js) {
       // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
       // kernel's own begin-to-end time, as rocprofv3 reports it
@@ -1540,7 +1570,7 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       else
         hipExtLaunchKernelGGL(icp_nn_kernel<false>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j, lds_steps);
       hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
-                            bt, kbase, j);
+                            bt, kbase, j, lds_steps);
       if (solve_staged)
         hipExtLaunchKernelGGL(icp_solve_kernel<true>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
                               bt, kbase, j);
@@ -1548,14 +1578,14 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
         hipExtLaunchKernelGGL(icp_solve_kernel<false>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
                               bt, kbase, j);
       hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
-                            kbase, j);
+                            kbase, j, lds_steps);
     } else {
       if (mom_stream) icp_nn_kernel<true><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
       else icp_nn_kernel<false><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
-      icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
       if (solve_staged) icp_solve_kernel<true><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
       else icp_solve_kernel<false><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
-      icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j);
+      icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
     }
   }
   // the stop rule of the chunk's last iteration (the others were settled by the next search)

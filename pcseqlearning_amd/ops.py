@@ -143,9 +143,11 @@ def hard_voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels)
 
 # ---------------------------------------------------------------- rulebook + conv
 def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding,
-                     dilation, subm, transpose=False):
+                     dilation, subm, transpose=False, with_table=False):
     """sparse_conv_ext.get_indice_pairs_3d. Returns (out_ids [V',4] int32, pairs [KV,2,V] int32,
-    num [KV] int32)."""
+    num [KV] int32); with_table: a fourth value, the output-major neighbour table [V',KV] the conv kernels
+    read when the rulebook's own probing pass can leave it (submanifold, odd kernel, no dilation), else None
+    (build it from the pairs: build_neighbor_table)."""
     L.require_gpu(indices, "get_indice_pairs")
     lib = L.load()
     if indices.dtype != torch.int32:
@@ -162,15 +164,18 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
     out_ids = None if subm else torch.empty(max(cap, 1), 4, dtype=torch.int32, device=dev)
     d_num = _dev_scalar(dev)
     ws = L.workspace(lib.pcs_get_indice_pairs_workspace_bytes(L.i64(V), ks, st, L.i32(kind)), dev)
-    L.check(lib.pcs_get_indice_pairs(L.ptr(indices), L.i64(V), L.i32(batch_size),
-                                     L.host_ints(out_shape), L.host_ints(spatial_shape), ks, st,
-                                     L.host_ints(padding), L.host_ints(dilation), L.i32(int(subm)),
-                                     L.i32(int(transpose)), L.ptr(out_ids), L.i64(cap),
-                                     L.ptr(pairs), L.ptr(num), L.ptr(d_num), L.ptr(ws),
-                                     L.i64(ws.numel()), L.stream()), "pcs_get_indice_pairs")
-    if subm:
-        return indices, pairs, num
-    return out_ids[:int(d_num.item())], pairs, num
+    dl = L.host_ints(dilation)
+    table = None
+    if with_table and V > 0 and lib.pcs_indice_pairs_gives_table(ks, dl, L.i32(int(subm))):
+        table = torch.empty(V, kv, dtype=torch.int32, device=dev)
+    L.check(lib.pcs_get_indice_pairs_table(L.ptr(indices), L.i64(V), L.i32(batch_size),
+                                           L.host_ints(out_shape), L.host_ints(spatial_shape), ks, st,
+                                           L.host_ints(padding), dl, L.i32(int(subm)),
+                                           L.i32(int(transpose)), L.ptr(out_ids), L.i64(cap),
+                                           L.ptr(pairs), L.ptr(num), L.ptr(d_num), L.ptr(table), L.ptr(ws),
+                                           L.i64(ws.numel()), L.stream()), "pcs_get_indice_pairs_table")
+    out = (indices, pairs, num) if subm else (out_ids[:int(d_num.item())], pairs, num)
+    return (*out, table) if with_table else out
 
 
 def indice_conv_backward(features, filters, out_bp, pairs, num, inverse=False, subm=False):

@@ -89,10 +89,13 @@ class SparseConvolution(SparseModule):
             outids, _, indice_pairs, indice_pair_num, _ = datas[:5]
             table = datas[5] if len(datas) > 5 else None
         else:
-            outids, indice_pairs, indice_pair_num = ops.get_indice_pairs(
+            # (a submanifold rulebook leaves the conv kernels' neighbour table itself; the others' is built
+            # from the pairs)
+            outids, indice_pairs, indice_pair_num, table = ops.get_indice_pairs(
                 indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
-                self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid)
-            table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0])
+                self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid, with_table=True)
+            if table is None:
+                table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0])
             input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num,
                                                   spatial_shape, table)
         if table is None:

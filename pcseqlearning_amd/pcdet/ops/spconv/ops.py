@@ -24,7 +24,7 @@ def _list(v, ndim):
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
-                     out_padding=0, subm=False, transpose=False, grid=None):
+                     out_padding=0, subm=False, transpose=False, grid=None, with_table=False):
     ndim = indices.shape[1] - 1
     if ndim != 3:
         raise NotImplementedError("only 3-D rulebooks are on the hot path")
@@ -39,7 +39,7 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     else:
         out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
     return _ops.get_indice_pairs(indices, batch_size, out_shape, list(spatial_shape), ksize, stride,
-                                 padding, dilation, subm, transpose)
+                                 padding, dilation, subm, transpose, with_table=with_table)
 
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,

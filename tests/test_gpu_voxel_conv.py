@@ -126,6 +126,74 @@ def test_rulebook_and_conv_full_frame(oracle):
         np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("ks", [[3, 3, 3], [3, 1, 1], [1, 3, 5], [2, 3, 3]])
+def test_submanifold_rulebook_leaves_the_neighbour_table(oracle, ks):
+    """The submanifold rulebook's own probing pass writes the conv kernels' neighbour table: the same table
+    pcs_build_neighbor_table makes of the pairs; the pairs themselves stay bit-exact against the oracle.
+    Even kernel sizes have no mirrored offset: no table (the caller builds it)."""
+    pts = synthetic.gen_voxel_frame(3, 60000)
+    _, coords, _ = ops.dynamic_voxelize(dev(pts), synthetic.PC_RANGE, synthetic.VOXEL_SIZE, synthetic.GRID_SIZE)
+    shape = [41, 1504, 1504]
+    idx = coords.cpu().numpy()
+    idx = idx[np.random.default_rng(2).permutation(len(idx))]  # (not in key order)
+    dl, st = [1, 1, 1], [1, 1, 1]
+    pd = [k // 2 for k in ks]
+    out_ids, pairs, num, table = ops.get_indice_pairs(dev(idx), 1, shape, shape, ks, st, pd, dl, True, with_table=True)
+    want = oracle.get_indice_pairs(idx, shape, ks, st, pd, dl, True)
+    np.testing.assert_array_equal(num.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(pairs.cpu().numpy(), want[1])
+    if any(k % 2 == 0 for k in ks):
+        assert table is None
+        return
+    built = ops.build_neighbor_table(pairs, num, idx.shape[0])
+    np.testing.assert_array_equal(table.cpu().numpy(), built.cpu().numpy())
+    assert (table >= 0).sum().item() == int(want[2].sum())
+
+
+@pytest.mark.parametrize("case", ["crowded", "isolated", "grid_beyond_32_bits", "one_voxel", "no_valid_output"])
+def test_strided_rulebook_table_regimes(oracle, case):
+    """The strided rulebook's three table regimes, bit-exact against the oracle: a first table of 4-8 slots
+    per input (crowded: adjacent voxels, 0.2 outputs per input), the retry with two slots per POSSIBLE output
+    (isolated odd coordinates: 8 outputs per input), and the two-array form of grids whose keys pass 32 bits."""
+    rng = np.random.default_rng(11)
+    ks, st, pd, dl = [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]
+    batch = 3
+    if case == "crowded":
+        shape = [24, 40, 40]
+        full = np.stack(np.meshgrid(np.arange(batch), np.arange(24), np.arange(40), np.arange(40), indexing="ij"), -1).reshape(-1, 4)
+        idx = full[rng.permutation(len(full))[: len(full) // 2]].astype(np.int32)
+    elif case == "isolated":
+        shape = [41, 400, 400]
+        n = 30000
+        idx = np.unique(np.stack([rng.integers(0, batch, n), 4 * rng.integers(0, 10, n) + 1, 4 * rng.integers(1, 99, n) + 1,
+                                  4 * rng.integers(1, 99, n) + 1], 1), axis=0).astype(np.int32)
+        idx = idx[rng.permutation(len(idx))]
+    elif case == "grid_beyond_32_bits":
+        shape = [400, 4000, 4000]  # 200 x 2000 x 2000 outputs x 8 batches = 6.4e9 keys
+        batch = 8
+        n = 20000
+        idx = np.unique(np.stack([rng.integers(0, batch, n), rng.integers(0, 400, n), rng.integers(0, 4000, n),
+                                  rng.integers(0, 4000, n)], 1), axis=0).astype(np.int32)
+        idx = idx[rng.permutation(len(idx))]
+    elif case == "one_voxel":
+        shape = [8, 8, 8]
+        idx = np.array([[1, 3, 3, 3]], np.int32)
+    else:  # every emission falls outside the output grid
+        shape = [8, 8, 8]
+        ks, st, pd = [1, 1, 1], [4, 4, 4], [0, 0, 0]
+        idx = np.array([[0, 1, 1, 1], [2, 3, 2, 1]], np.int32)
+    out_shape = oracle.conv_out_shape(shape, ks, st, pd, dl)
+    got = _rulebook_gpu(idx, batch, out_shape, shape, ks, st, pd, dl, False)
+    want = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, dl, False)
+    np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    if case == "isolated":
+        assert got[0].shape[0] == 8 * idx.shape[0]
+    if case == "no_valid_output":
+        assert got[0].shape[0] == 0
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 64), (96, 32), (7, 10)])
 def test_conv_channel_configs(oracle, cin, cout):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rulebook_subm3.npz"))
