@@ -118,14 +118,16 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
 /* The same call, and -- where pcs_indice_pairs_gives_table() returns 1: submanifold, odd kernel sizes, no
  * dilation -- row j of `table` [V,KV] int32 = the inputs of output j by kernel offset, -1 where none:
  * what pcs_build_neighbor_table makes of the pairs, taken from the rulebook's own probing pass. `table`
- * may be NULL (then this IS pcs_get_indice_pairs). */
+ * may be NULL. `h_num_out` (HOST pointer, may be NULL) receives the number of output voxels where the call
+ * knows it on return (submanifold: V; strided / transposed: the call has synchronised the stream for it),
+ * else -1 = read *d_num_out. With both NULL this IS pcs_get_indice_pairs. */
 int pcs_indice_pairs_gives_table(const int* ksize3, const int* dil3, int subm);
 int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
                                const int* spatial_shape3, const int* ksize3, const int* stride3,
                                const int* pad3, const int* dil3, int subm, int transpose,
                                int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
-                               int64_t* d_num_out, int32_t* table, void* ws, size_t ws_bytes,
-                               pcs_stream_t stream);
+                               int64_t* d_num_out, int64_t* h_num_out, int32_t* table, void* ws,
+                               size_t ws_bytes, pcs_stream_t stream);
 
 /* sparse_conv_ext.indice_conv_fp32, src/all.cc:30-33 -> indiceConv<float>,
  * spconv_ops.h:260-361. features [num_in,cin], filters [kv,cin,cout], out [num_out,cout].

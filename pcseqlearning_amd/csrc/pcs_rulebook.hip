@@ -31,35 +31,43 @@ struct ConvGeom {
   int transpose;
 };
 
-// First slot of a key: the four cells of an aligned run along x (the fastest axis of the key) share a
-// 32-byte run of slots, so the three x-neighbours a 3 x 3 x 3 footprint probes per (z, y) mostly come with
-// one sector instead of three (the probes are what these kernels wait for). Tables have >= 64 slots.
-__device__ __forceinline__ uint32_t first_slot(uint64_t key, uint32_t hmask) {
-  return ((mix64(key >> 2) << 2) | ((uint32_t)key & 3u)) & hmask;
+// Probe sequence of a key. First slot: the four cells of an aligned run along x (the fastest axis of the
+// key) share a 32-byte run of slots, so the three x-neighbours a 3 x 3 x 3 footprint probes per (z, y) mostly
+// come with one sector instead of three (the probes are what these kernels wait for). Further slots: a
+// key-dependent stride of 4 * odd (double hashing; every slot of the key's residue class is reached) --
+// occupied runs of x leave runs of full slots, and a +1 walk through them made the LONGEST walk of a wave
+// (what a launch at one frame per batch waits for) 10-20 slots. Tables have >= 64 slots.
+struct Probe { uint32_t slot, step; };
+__device__ __forceinline__ Probe probe_begin(uint64_t key, uint32_t hmask) {
+  const uint32_t m = mix64(key >> 2);
+  Probe p;
+  p.slot = ((m << 2) | ((uint32_t)key & 3u)) & hmask;
+  p.step = ((m >> 13) | 1u) << 2;
+  return p;
 }
 
 __device__ __forceinline__ uint32_t table_find(const uint64_t* __restrict__ keys, uint32_t hmask,
                                                uint64_t key) {
-  uint32_t slot = first_slot(key, hmask);
+  Probe p = probe_begin(key, hmask);
   while (true) {
-    uint64_t k = keys[slot];
-    if (k == key) return slot;
+    uint64_t k = keys[p.slot];
+    if (k == key) return p.slot;
     if (k == kEmptyKey) return 0xFFFFFFFFu;
-    slot = (slot + 1) & hmask;
+    p.slot = (p.slot + p.step) & hmask;
   }
 }
 
 __device__ __forceinline__ uint32_t table_insert(uint64_t* __restrict__ keys, uint32_t hmask,
                                                  uint64_t key, bool* claimed = nullptr) {
-  uint32_t slot = first_slot(key, hmask);
+  Probe p = probe_begin(key, hmask);
   while (true) {
-    uint64_t prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
+    uint64_t prev = atomicCAS((unsigned long long*)&keys[p.slot], (unsigned long long)kEmptyKey,
                               (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) {
       if (claimed) *claimed = prev == kEmptyKey;
-      return slot;
+      return p.slot;
     }
-    slot = (slot + 1) & hmask;
+    p.slot = (p.slot + p.step) & hmask;
   }
 }
 
@@ -184,10 +192,10 @@ assign_outputs_kernel(const int32_t* __restrict__ sslot, const int32_t* __restri
 constexpr int kMaxProbe = 256;  // longer runs mean a table that is (nearly) full: flagged, the host retries larger
 
 __device__ __forceinline__ uint32_t packed_find(const uint64_t* __restrict__ tab, uint32_t hmask, uint32_t key) {
-  uint32_t slot = first_slot(key, hmask);
+  Probe p = probe_begin(key, hmask);
   while (true) {  // (only called for keys that were inserted)
-    if ((uint32_t)(tab[slot] >> 32) == key) return slot;
-    slot = (slot + 1) & hmask;
+    if ((uint32_t)(tab[p.slot] >> 32) == key) return p.slot;
+    p.slot = (p.slot + p.step) & hmask;
   }
 }
 
@@ -227,7 +235,8 @@ insert_outputs_packed_kernel(const int4* __restrict__ idx, int V, ConvGeom g, ui
           const uint32_t key = base + ((uint32_t)oz * g.out_shape[1] + oy) * g.out_shape[2] + ox;
           const uint32_t seq = (uint32_t)j * (uint32_t)g.kv + (uint32_t)(g.transpose ? g.kv - 1 - k : k);
           const uint64_t word = ((uint64_t)key << 32) | seq;
-          uint32_t slot = first_slot(key, hmask);
+          const Probe pb = probe_begin(key, hmask);
+          uint32_t slot = pb.slot;
           int probe = 0;
           for (; probe < kMaxProbe; ++probe) {
             uint64_t cur = tab[slot];
@@ -244,7 +253,7 @@ insert_outputs_packed_kernel(const int4* __restrict__ idx, int V, ConvGeom g, ui
               if ((uint32_t)cur > seq) atomicMin((unsigned long long*)&tab[slot], (unsigned long long)word);
               break;
             }
-            slot = (slot + 1) & hmask;
+            slot = (slot + pb.step) & hmask;
           }
           if (probe == kMaxProbe) { counter[1] = 1; over = true; break; }
         }
@@ -425,11 +434,114 @@ pair_count_table_kernel(const int4* __restrict__ idx, int V, ConvGeom g, const u
   for (int q = threadIdx.x; q < rows * g.kv; q += kBlock) dst[q] = s_rows[q];
 }
 
+// ---- submanifold 3 x 3 x 3 on a packed table (batch * volume < 2^32): a word is  key << 32 | voxel index
+// (the largest index of a coordinate wins, as in insert_inputs_kernel), so a hit needs no second load, and
+// the 27 first probes of a voxel are 27 INDEPENDENT loads issued together -- at one frame per batch the
+// launch is a chain of memory latencies (54 dependent loads per voxel in the loop form: 150 us for 66 k
+// voxels), at twenty frames it is bound by the sectors the probes touch. Only a first slot that holds
+// another key (a collision) walks on serially.
+__global__ void __launch_bounds__(kBlock)
+insert_inputs_packed_kernel(const int4* __restrict__ idx, int V, ConvGeom g, uint64_t* __restrict__ tab, uint32_t hmask) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V) return;
+  const int4 c = idx[j];
+  const uint32_t vol = (uint32_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  const uint32_t key = (uint32_t)c.x * vol + ((uint32_t)c.y * g.out_shape[1] + c.z) * g.out_shape[2] + c.w;
+  const uint64_t word = ((uint64_t)key << 32) | (uint32_t)j;
+  Probe p = probe_begin(key, hmask);
+  while (true) {
+    uint64_t cur = tab[p.slot];
+    if (cur == kEmptyKey) {
+      cur = atomicCAS((unsigned long long*)&tab[p.slot], (unsigned long long)kEmptyKey, (unsigned long long)word);
+      if (cur == kEmptyKey) return;
+    }
+    if ((uint32_t)(cur >> 32) == key) {
+      if ((uint32_t)cur < (uint32_t)j) atomicMax((unsigned long long*)&tab[p.slot], (unsigned long long)word);
+      return;
+    }
+    p.slot = (p.slot + p.step) & hmask;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+pair_count_table333_kernel(const int4* __restrict__ idx, int V, ConvGeom g, const uint64_t* __restrict__ tab,
+                           uint32_t hmask, uint32_t* __restrict__ masks, int32_t* __restrict__ blockcnt, int nblocks,
+                           int32_t* __restrict__ table) {
+  constexpr int KV = 27;
+  __shared__ int wcnt[kBlock / 64][32];
+  __shared__ int32_t s_rows[kBlock * KV];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t mask = 0;
+  if (j < V) {
+    const int4 c = idx[j];
+    const uint32_t vol = (uint32_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+    const uint32_t base = (uint32_t)c.x * vol;
+    uint32_t key[KV], slot[KV];
+    uint64_t wd[KV];
+    uint32_t valid = 0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int z = c.y + 1 - k / 9, y = c.z + 1 - (k / 3) % 3, x = c.w + 1 - k % 3;
+      const bool ok = z >= 0 && z < g.out_shape[0] && y >= 0 && y < g.out_shape[1] && x >= 0 && x < g.out_shape[2];
+      key[k] = base + ((uint32_t)z * g.out_shape[1] + y) * g.out_shape[2] + x;
+      slot[k] = probe_begin(key[k], hmask).slot;
+      if (ok) valid |= 1u << k;
+    }
+    // rounds: every unresolved probe advances one slot per round, the loads of a round issued together (a
+    // probe that walks holds up only itself: the chain is the LONGEST walk of the 27, not their sum)
+    int nb[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) nb[k] = -1;
+    uint32_t pending = valid;
+    while (pending) {
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+        if ((pending >> k) & 1u) wd[k] = tab[slot[k]];
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        if ((pending >> k) & 1u) {
+          const uint64_t cur = wd[k];
+          if (cur == kEmptyKey) {
+            pending &= ~(1u << k);
+          } else if ((uint32_t)(cur >> 32) == key[k]) {
+            nb[k] = (int)(uint32_t)cur;
+            mask |= 1u << k;
+            pending &= ~(1u << k);
+          } else {
+            slot[k] = (slot[k] + probe_begin(key[k], hmask).step) & hmask;
+          }
+        }
+      }
+    }
+    const bool is_output = nb[13] == j;
+    int32_t* row = s_rows + threadIdx.x * KV;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) row[KV - 1 - k] = is_output ? nb[k] : -1;
+    masks[j] = mask;
+  }
+  for (int k = 0; k < KV; ++k) {
+    unsigned long long b = __ballot((mask >> k) & 1u);
+    if (lane == 0) wcnt[w][k] = __popcll(b);
+  }
+  __syncthreads();
+  if (threadIdx.x < KV) {
+    int k = threadIdx.x, sum = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) sum += wcnt[q][k];
+    blockcnt[(int64_t)k * nblocks + blockIdx.x] = sum;
+  }
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x;
+  const int rows = (int)((V - first) < (int64_t)blockDim.x ? (V - first) : (int64_t)blockDim.x);
+  int32_t* __restrict__ dst = table + first * KV;
+  for (int q = threadIdx.x; q < rows * KV; q += kBlock) dst[q] = s_rows[q];
+}
+
 __global__ void __launch_bounds__(kBlock)
 pair_fill_table_kernel(int V, ConvGeom g, const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                        uint32_t hmask, const int4* __restrict__ idx, const uint32_t* __restrict__ masks,
                        const int32_t* __restrict__ blockoff, int nblocks, const int32_t* __restrict__ table,
-                       int32_t* __restrict__ pairs, int32_t* __restrict__ num) {
+                       int32_t* __restrict__ pairs, int32_t* __restrict__ num, int packed) {
   __shared__ int wcnt[kBlock / 64][32];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -452,6 +564,7 @@ pair_fill_table_kernel(int V, ConvGeom g, const uint64_t* __restrict__ keys, con
       const int pos = blockoff[kb + blockIdx.x] - blockoff[kb] + pre;
       int n;
       if (row_ok) n = row[g.kv - 1 - k];
+      else if (packed) n = (int)(uint32_t)keys[packed_find(keys, hmask, (uint32_t)out_key(g, c, k))];
       else n = vals[table_find(keys, hmask, out_key(g, c, k))];
       pairs[((int64_t)k * 2 + 0) * V + pos] = j;
       pairs[((int64_t)k * 2 + 1) * V + pos] = n;
@@ -599,7 +712,9 @@ static int64_t emissions_per_input(const int* ks, const int* st, int transpose =
 static bool plan_rulebook(Arena& a, int64_t V, int kv, int subm, int64_t cap, RulebookPlan& p) {
   if (V < 1) V = 1;
   p.cap = subm ? V : cap;
-  p.H = pow2_at_least(2 * (uint64_t)p.cap);
+  // (submanifold: four slots per voxel -- most of the 27 probes of a voxel MISS, and a miss walks to the next
+  // empty slot; strided: two per possible output, the retry size of the packed form)
+  p.H = pow2_at_least((subm ? 4 : 2) * (uint64_t)p.cap);
   p.nblocks = (int)((V + kBlock - 1) / kBlock);
   p.keys = a.take<uint64_t>(p.H);
   p.vals = a.take<int32_t>(p.H);
@@ -659,7 +774,8 @@ int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, con
                                const int* spatial_shape3, const int* ksize3, const int* stride3,
                                const int* pad3, const int* dil3, int subm, int transpose,
                                int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
-                               int64_t* d_num_out, int32_t* table, void* ws, size_t ws_bytes, hipStream_t s);
+                               int64_t* d_num_out, int64_t* h_num_out, int32_t* table, void* ws, size_t ws_bytes,
+                               hipStream_t s);
 
 int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
                          const int* spatial_shape3, const int* ksize3, const int* stride3,
@@ -667,17 +783,22 @@ int pcs_get_indice_pairs(const int32_t* indices, int64_t V, int batch, const int
                          int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
                          int64_t* d_num_out, void* ws, size_t ws_bytes, hipStream_t s) {
   return pcs_get_indice_pairs_table(indices, V, batch, out_shape3, spatial_shape3, ksize3, stride3, pad3, dil3, subm,
-                                    transpose, out_ids, out_cap, pairs, num, d_num_out, nullptr, ws, ws_bytes, s);
+                                    transpose, out_ids, out_cap, pairs, num, d_num_out, nullptr, nullptr, ws, ws_bytes,
+                                    s);
 }
 
 // The same, and (where pcs_indice_pairs_gives_table says so) row j of `table` [V, kv] = the inputs of
 // output j by kernel offset, -1 where none: what pcs_build_neighbor_table would make of the pairs, from the
 // rulebook's own probing pass (no second pass over the pairs, no reset of the table). `table` may be NULL.
+// `h_num_out` (HOST pointer, may be NULL): the number of output voxels where the call knows it on return
+// (submanifold: V; the packed strided form: it has synchronised the stream for it), else -1 = read *d_num_out.
 int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, const int* out_shape3,
                                const int* spatial_shape3, const int* ksize3, const int* stride3,
                                const int* pad3, const int* dil3, int subm, int transpose,
                                int32_t* out_ids, int64_t out_cap, int32_t* pairs, int32_t* num,
-                               int64_t* d_num_out, int32_t* table, void* ws, size_t ws_bytes, hipStream_t s) {
+                               int64_t* d_num_out, int64_t* h_num_out, int32_t* table, void* ws, size_t ws_bytes,
+                               hipStream_t s) {
+  if (h_num_out) *h_num_out = -1;
   if (!out_shape3 || !spatial_shape3 || !ksize3 || !stride3 || !pad3 || !dil3 || !num ||
       !d_num_out || !ws || V < 0 || batch < 1 || (V > 0 && (!indices || !pairs)))
     return PCS_ERR_ARG;
@@ -703,6 +824,7 @@ int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, con
   if (V == 0) {
     PCS_CHECK_HIP(hipMemsetAsync(num, 0, g.kv * sizeof(int32_t), s));
     PCS_CHECK_HIP(hipMemsetAsync(d_num_out, 0, sizeof(int64_t), s));
+    if (h_num_out) *h_num_out = 0;
     return PCS_OK;
   }
   int64_t cap = pcs_indice_pairs_out_capacity(V, ksize3, stride3, transpose ? 2 : (subm ? 1 : 0));
@@ -778,10 +900,16 @@ int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, con
     pair_fill_packed_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hm, p.masks, p.blockoff, nb, pairs,
                                                   num);
     PCS_LAUNCH_CHECK();
+    if (h_num_out) *h_num_out = U;
     return PCS_OK;
   }
+  if (subm && h_num_out) *h_num_out = V;
+  const bool with_table = table && pcs_indice_pairs_gives_table(ksize3, dil3, subm);
+  const bool sub333 = with_table && g.kv == 27 && g.ks[0] == 3 && g.ks[1] == 3 && vol * (uint64_t)batch < 0xFFFFFFFFULL;
   init(p.H, true);
-  if (subm) {
+  if (sub333) {
+    insert_inputs_packed_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, hmask);
+  } else if (subm) {
     insert_inputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask);
   } else {
     insert_outputs_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.minseq, hmask, p.lslot,
@@ -792,8 +920,9 @@ int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, con
     assign_outputs_kernel<<<grid_for(p.cap), kBlock, 0, s>>>(p.lslot_s, p.counter, p.keys, g,
                                                              p.vals, out_ids, d_num_out);
   }
-  const bool with_table = table && pcs_indice_pairs_gives_table(ksize3, dil3, subm);
-  if (with_table)
+  if (sub333)
+    pair_count_table333_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, hmask, p.masks, p.blockcnt, nb, table);
+  else if (with_table)
     pair_count_table_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask, p.masks, p.blockcnt, nb, table);
   else
     pair_count_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, hmask, p.masks, p.blockcnt, nb);
@@ -805,7 +934,7 @@ int pcs_get_indice_pairs_table(const int32_t* indices, int64_t V, int batch, con
   }
   if (with_table)
     pair_fill_table_kernel<<<nb, kBlock, 0, s>>>((int)V, g, p.keys, p.vals, hmask, idx, p.masks, p.blockoff, nb, table,
-                                                 pairs, num);
+                                                 pairs, num, sub333 ? 1 : 0);
   else
     pair_fill_kernel<<<nb, kBlock, 0, s>>>(idx, (int)V, g, p.keys, p.vals, hmask, p.masks,
                                            p.blockoff, nb, pairs, num);

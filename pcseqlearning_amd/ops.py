@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/pcs.h): torch owns the memory and the stream,
 every computation below runs in the hand-written HIP kernels of csrc/. No CPU fallback."""
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -165,6 +167,7 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
     d_num = _dev_scalar(dev)
     ws = L.workspace(lib.pcs_get_indice_pairs_workspace_bytes(L.i64(V), ks, st, L.i32(kind)), dev)
     dl = L.host_ints(dilation)
+    h_num = ctypes.c_int64(-1)
     table = None
     if with_table and V > 0 and lib.pcs_indice_pairs_gives_table(ks, dl, L.i32(int(subm))):
         table = torch.empty(V, kv, dtype=torch.int32, device=dev)
@@ -172,9 +175,11 @@ def get_indice_pairs(indices, batch_size, out_shape, spatial_shape, ksize, strid
                                            L.host_ints(out_shape), L.host_ints(spatial_shape), ks, st,
                                            L.host_ints(padding), dl, L.i32(int(subm)),
                                            L.i32(int(transpose)), L.ptr(out_ids), L.i64(cap),
-                                           L.ptr(pairs), L.ptr(num), L.ptr(d_num), L.ptr(table), L.ptr(ws),
-                                           L.i64(ws.numel()), L.stream()), "pcs_get_indice_pairs_table")
-    out = (indices, pairs, num) if subm else (out_ids[:int(d_num.item())], pairs, num)
+                                           L.ptr(pairs), L.ptr(num), L.ptr(d_num), ctypes.byref(h_num), L.ptr(table),
+                                           L.ptr(ws), L.i64(ws.numel()), L.stream()), "pcs_get_indice_pairs_table")
+    # (the strided form hands the output count back on the host: no second device read)
+    n_out = int(h_num.value) if h_num.value >= 0 else int(d_num.item())
+    out = (indices, pairs, num) if subm else (out_ids[:n_out], pairs, num)
     return (*out, table) if with_table else out
 
 
