@@ -386,6 +386,11 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
  * handed over as soon as they are prepared; at most 128 units are in flight on a device, further
  * ones wait for free table slots); arrays of n_seqs HOST pointers / counts; `ws` is one workspace of
  * pcs_track_batch_workspace_bytes for all of them. */
+/* Creates the device's lock-step engines (driver threads + streams) now instead of at the first tracking
+ * call; device < 0 = the current device. Speed only: the HIP runtime deals streams to its hardware queues in
+ * creation order, and engines created between the streams of a dozen host threads can end up on one queue
+ * (their chains then run one after the other). Call it before creating other streams. */
+int pcs_track_engines_init(int device);
 typedef struct PcsTrackUnit {
   const int64_t* seq_component;   /* [N] int64 */
   const uint8_t* seq_stationary;  /* [N] uint8 */

@@ -1718,6 +1718,9 @@ void Engine::run() {
     }
   }
   ok = ok && hipEventCreateWithFlags(&ev_, hipEventDisableTiming) == hipSuccess;
+  // (a first command now: whatever the runtime binds to a stream at its first use -- its hardware queue -- is
+  //  bound in the order the engines are created, not in the order their first units arrive)
+  ok = ok && hipMemsetAsync(d_units_, 0, sizeof(int), st_) == hipSuccess && hipStreamSynchronize(st_) == hipSuccess;
   {
     const char* e = getenv("PCS_TRACK_CHUNK");
     int c = e ? atoi(e) : 0;
@@ -1984,6 +1987,21 @@ static size_t sequence_workspace_bytes(Arena& a, const int64_t* frame_offsets, i
 }
 
 extern "C" {
+
+// Create the device's lock-step engines (driver threads, streams) NOW rather than at the first tracking
+// call. The HIP runtime maps streams to a few hardware queues in the order they are created: engines that
+// come into being between the streams of a dozen host threads may end up sharing one queue, and two chains
+// on one queue run one after the other (measured: 1.75 s per batch instead of 1.5 s). A caller that is about
+// to create streams of its own calls this first. `device` < 0: the current device.
+int pcs_track_engines_init(int device) {
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return PCS_ERR_HIP;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return PCS_ERR_HIP;
+  if (cur != device && hipSetDevice(device) != hipSuccess) return PCS_ERR_HIP;
+  Engine* e = Engine::get(device);
+  if (cur != device) (void)hipSetDevice(cur);
+  return e ? PCS_OK : PCS_ERR_HIP;
+}
 
 size_t pcs_track_sequence_workspace_bytes(const int64_t* frame_offsets, int num_frames,
                                           const PcsTrackUnit* units, int n_units) {

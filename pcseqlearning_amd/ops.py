@@ -760,6 +760,14 @@ class TrackParams(__import__("ctypes").Structure):
     ]
 
 
+def track_engines_init(device=None):
+    """pcs_track_engines_init: create the device's lock-step engines now (before other streams are created:
+    the runtime deals streams to its hardware queues in creation order). Cheap once they exist."""
+    lib = L.load()
+    index = -1 if device is None else torch.device(device).index
+    L.check(lib.pcs_track_engines_init(L.i32(-1 if index is None else index)), "pcs_track_engines_init")
+
+
 def track_params(radius_list, voxel_size_list, stopping_delta, angle_regularizer, nn_radius,
                  reg_error_coeff, angle_threshold, min_move_frame, max_iter=80, max_diameter=12.5,
                  smooth=(1.0, 10.0, 300, 1e-3)):

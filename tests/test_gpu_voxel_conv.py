@@ -150,6 +150,32 @@ def test_submanifold_rulebook_leaves_the_neighbour_table(oracle, ks):
     assert (table >= 0).sum().item() == int(want[2].sum())
 
 
+def test_submanifold_rulebook_with_duplicate_coordinates(oracle):
+    """Duplicate input coordinates (the reference's grid keeps the LAST index, geometry.h:262-266): pairs
+    bit-exact against the oracle; a voxel that lost its coordinate is never an output, so its row of the
+    neighbour table is empty, and the winners' rows are what pcs_build_neighbor_table makes of the pairs."""
+    rng = np.random.default_rng(4)
+    shape = [12, 30, 30]
+    base = np.unique(np.stack([rng.integers(0, 2, 3000), rng.integers(0, 12, 3000), rng.integers(0, 30, 3000),
+                               rng.integers(0, 30, 3000)], 1), axis=0).astype(np.int32)
+    idx = np.concatenate([base, base[rng.permutation(len(base))[:400]]])
+    idx = idx[rng.permutation(len(idx))]
+    ks, st, pd, dl = [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1]
+    out_ids, pairs, num, table = ops.get_indice_pairs(dev(idx), 2, shape, shape, ks, st, pd, dl, True, with_table=True)
+    want = oracle.get_indice_pairs(idx, shape, ks, st, pd, dl, True)
+    np.testing.assert_array_equal(num.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(pairs.cpu().numpy(), want[1])
+    t = table.cpu().numpy()
+    keys = (idx[:, 0].astype(np.int64) * 12 + idx[:, 1]) * 900 + idx[:, 2] * 30 + idx[:, 3]
+    last = {}
+    for j, k in enumerate(keys):
+        last[k] = j
+    loser = np.array([last[k] != j for j, k in enumerate(keys)])
+    assert loser.sum() == 400
+    assert (t[loser] == -1).all()
+    assert (t[~loser, 13] == np.nonzero(~loser)[0]).all()  # every winner is its own centre partner
+
+
 @pytest.mark.parametrize("case", ["crowded", "isolated", "grid_beyond_32_bits", "one_voxel", "no_valid_output"])
 def test_strided_rulebook_table_regimes(oracle, case):
     """The strided rulebook's three table regimes, bit-exact against the oracle: a first table of 4-8 slots
