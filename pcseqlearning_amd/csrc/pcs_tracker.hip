@@ -1747,7 +1747,18 @@ void Engine::run() {
       n_pending_ = 0;
     }
     long long t0 = tp ? now_ns() : 0;
+    // The first ticks of a process take their launches one engine at a time: every kernel's FIRST launch loads
+    // it (lazily), and rocprofv3's tool library has crashed three times in exactly that path when several
+    // threads took first launches at once. ~0.2 ms of host time per tick for the first half second.
+    static std::mutex cold_mu;
+    static std::atomic<int> cold_ticks{0};
+    const bool cold = cold_ticks.load(std::memory_order_relaxed) < 1024;
+    if (cold) cold_mu.lock();
     int rc = enqueue_tick();
+    if (cold) {
+      cold_ticks.fetch_add(1, std::memory_order_relaxed);
+      cold_mu.unlock();
+    }
     if (tp) { g_tick_profile.enq_ns += now_ns() - t0; g_tick_profile.ticks += 1; t0 = now_ns(); }
     if (rc == PCS_OK && n_live_ > 0) {
       const long long w0 = now_ns();

@@ -5,6 +5,18 @@
 # then (fetch + write) / algorithmic of the {budget test, searches} pair:
 #   bash tools/pmc_batch.sh <tag>  ->  gpurun_out/prof/<tag>_batch_pmc_{FETCH,WRITE}_SIZE.json, <tag>_icp_hbm_pmc.json
 set -o pipefail
+# rocprofv3's tool library dies now and then (host SIGSEGV inside its copy of a kernel's arguments, in the
+# first seconds, before the GPU has done anything of ours): such a run is started again, three times at most.
+prof_retry() {
+  local n=0 rc=0
+  while :; do
+    "$@"; rc=$?
+    n=$((n + 1))
+    if [ $rc -ne 139 ] || [ $n -ge 3 ]; then return $rc; fi
+    echo "profiler died with SIGSEGV (attempt $n): once more" >&2
+  done
+}
+
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
@@ -17,7 +29,7 @@ export PCS_BENCH_TRACE=1
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmcb_$C
   rm -rf $d
-  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stages > $O/${TAG}_batch_pmc_$C.bench.json 2> $O/pmcb_$C.err || { echo "pmc pass $C failed"; tail -5 $O/pmcb_$C.err; exit 1; }
+  prof_retry timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stages > $O/${TAG}_batch_pmc_$C.bench.json 2> $O/pmcb_$C.err || { echo "pmc pass $C failed"; tail -5 $O/pmcb_$C.err; exit 1; }
   python3 $ROOT/tools/summarize_pmc.py $d/p_counter_collection.csv > $O/${TAG}_batch_pmc_$C.json
   echo "pmc $C: $(wc -l < $d/p_counter_collection.csv) rows" | tee -a $O/pmc.progress
 done

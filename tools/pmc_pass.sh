@@ -2,6 +2,18 @@
 # One rocprofv3 --pmc pass over a one-sequence bench step, summarised per kernel:
 #   bash tools/pmc_pass.sh <tag> <counter> [<counter> ...]   ->  gpurun_out/prof/<tag>.json
 set -o pipefail
+# rocprofv3's tool library dies now and then (host SIGSEGV inside its copy of a kernel's arguments, in the
+# first seconds, before the GPU has done anything of ours): such a run is started again, three times at most.
+prof_retry() {
+  local n=0 rc=0
+  while :; do
+    "$@"; rc=$?
+    n=$((n + 1))
+    if [ $rc -ne 139 ] || [ $n -ge 3 ]; then return $rc; fi
+    echo "profiler died with SIGSEGV (attempt $n): once more" >&2
+  done
+}
+
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
@@ -9,6 +21,6 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 d=/tmp/pmc_$TAG
 rm -rf $d
-timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --batch 1 --steps 1 --warmup 0 --no-cpu-baseline --no-stages > $O/$TAG.out 2> $O/$TAG.err || { echo "pmc pass $TAG failed"; tail -5 $O/$TAG.err; exit 1; }
+prof_retry timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --batch 1 --steps 1 --warmup 0 --no-cpu-baseline --no-stages > $O/$TAG.out 2> $O/$TAG.err || { echo "pmc pass $TAG failed"; tail -5 $O/$TAG.err; exit 1; }
 python3 $ROOT/tools/summarize_pmc.py $d/p_counter_collection.csv > $O/$TAG.json
 echo "pmc $TAG: $(wc -l < $d/p_counter_collection.csv) rows"

@@ -41,8 +41,10 @@ def main():
         v2 = sorted(v)
         print(f"{n[-58:]:58s} {len(v):8d} {sum(v) / 1e6:9.2f} {sum(v) / len(v) / 1e3:8.1f} {v2[len(v2) // 2] / 1e3:7.1f} "
               f"{grid[n] / len(v):9.0f} {100 * sum(v) / tot:6.1f}")
+    icp_q = collections.Counter(q for s_, e_, n, q, g, gy in rows if "icp_apply_kernel" in n)
     for q, (c, b) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
-        print(f"  queue {q}: {c} dispatches, busy {b / 1e6:.1f} ms ({100 * b / span:.1f} % of the window)")
+        print(f"  queue {q}: {c} dispatches, busy {b / 1e6:.1f} ms ({100 * b / span:.1f} % of the window), "
+              f"{icp_q.get(q, 0)} ICP iterations (the engines' chains)")
     ev = []
     for s, e, *_ in rows:
         ev.append((s, 1))
@@ -61,7 +63,7 @@ def main():
     for name in ("pcs::icp_nn_kernel", "pcs::icp_nn_search_kernel", "pcs::icp_apply_kernel", "pcs::smp_sort_kernel"):
         by_n, by_c = collections.defaultdict(list), collections.defaultdict(list)
         for s, e, n, q, g, gy in rows:
-            if n != name:
+            if not (n == name or n.endswith(name) or (name + "<") in n):  # (template instances: "void pcs::k<false>")
                 continue
             by_n[min(gy // 16 * 16, 128)].append(e - s)
             mid = (s + e) // 2
