@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kIrlsWg = 64;  // irls_seg_round_kernel: one wave per (pillar, fit)
 
 // all lanes of a 64-lane xor butterfly end with the same tree; lane 0's value
 template <typename T>
@@ -150,13 +151,13 @@ void orc_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int
         if (r > 2) for (int q = 0; q < 6; ++q) pl2[q] = plane_cur[c * 6 + q];
         float cur_z = 0.f;
         if (r <= 2) cur_z = min_z[c] * ratio + max_z[c] * omr;
-        double acc[11][kBlock];
-        float dws[kBlock];
-        for (int t = 0; t < kBlock; ++t) {
+        double acc[11][kIrlsWg];
+        float dws[kIrlsWg];
+        for (int t = 0; t < kIrlsWg; ++t) {
           double v[11];
           for (int q = 0; q < 11; ++q) v[q] = 0.0;
           float dw = 0.f;
-          for (int i = b + t; i < e; i += kBlock) {
+          for (int i = b + t; i < e; i += kIrlsWg) {
             float x = xyz[(int64_t)i * 3], yy = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
             float wi;
             if (r <= 2) {
@@ -183,11 +184,11 @@ void orc_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int
         double a[11];
         for (int q = 0; q < 11; ++q) {
           double x = butterfly64(acc[q]);
-          for (int k = 1; k < kBlock / 64; ++k) x += butterfly64(acc[q] + 64 * k);
+          for (int k = 1; k < kIrlsWg / 64; ++k) x += butterfly64(acc[q] + 64 * k);
           a[q] = x;
         }
         float m4 = 0.f;
-        for (int t = 0; t < kBlock; ++t) m4 = std::fmax(m4, dws[t]);
+        for (int t = 0; t < kIrlsWg; ++t) m4 = std::fmax(m4, dws[t]);
         if (r > 1) dw_all = std::fmax(dw_all, m4);
         double ws = a[0] + 1e-6;
         double cnt = a[10] > 0.5 ? a[10] : 1.0;
