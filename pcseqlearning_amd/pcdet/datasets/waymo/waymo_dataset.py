@@ -24,8 +24,8 @@ from .... import ops
 from ..dataset import DatasetTemplate
 
 _UNSUPPORTED = {
-    "SPHERICAL_RESAMPLING": False, "WITH_TIME_FEAT": False, "SYNC_MOVING_POINTS": False, "REMOVE_GROUND": False,
-    "DROP_POINTS_BY_SEG_LEN": False, "FILTER_FOREGROUND": None, "MIX3D": None, "INFO_WITH_FAKELIDAR": False,
+    "SPHERICAL_RESAMPLING": False, "SYNC_MOVING_POINTS": False,
+    "DROP_POINTS_BY_SEG_LEN": False, "MIX3D": None, "INFO_WITH_FAKELIDAR": False,
 }
 
 
@@ -70,6 +70,12 @@ class WaymoDataset(DatasetTemplate):
                     raise ValueError(f"{s} not in Sequence List")
             self.sample_sequence_list = wanted
         self.num_sweeps = cfg.get("NUM_SWEEPS", 1)
+        self.with_time_feat = cfg.get("WITH_TIME_FEAT", False)  # waymo_dataset.py:59
+        self.remove_ground = cfg.get("REMOVE_GROUND", False)  # waymo_dataset.py:62 (POINT_HEIGHT_PATH, TRUNCATE_GROUND_HEIGHT)
+        ff = cfg.get("FILTER_FOREGROUND", None)  # waymo_dataset.py:65-69
+        self.filter_foreground = ff is not None
+        if ff is not None:
+            self.pred_label_path, self.filter_class = ff["PRED_LABEL_PATH"], list(ff["FILTER_CLASS"])
         self.sweep_dir = cfg.get("SWEEP_DIR", -1)
         self.max_num_points *= self.num_sweeps
         self.infos = []
@@ -148,6 +154,27 @@ class WaymoDataset(DatasetTemplate):
         if len(kept) == 1:
             return slice(0, int(kept[0]))
         return np.concatenate([np.arange(0, n) for n in kept], axis=0)
+
+    def filter_rows(self, info, sel, n_rows):
+        """FILTER_FOREGROUND then REMOVE_GROUND (waymo_dataset.py:479-492): both drop rows of the frame's points
+        AFTER the lidar selection, by a per-frame file with one entry per remaining row -- predicted labels
+        (`<PRED_LABEL_PATH>/<sequence>/<idx:03d>_pred.npy`, rows of the FILTER_CLASS classes go) and point heights
+        (`<POINT_HEIGHT_PATH>/<sequence>/<idx:04d>_point_height.npy`, rows below TRUNCATE_GROUND_HEIGHT go; its
+        length is that of the rows the foreground filter left). A host-side row selection like kept_rows."""
+        if not (self.filter_foreground or self.remove_ground):
+            return sel
+        seq, idx = info["point_cloud"]["lidar_sequence"], info["point_cloud"]["sample_idx"]
+        rows = np.arange(n_rows)[sel]
+        if self.filter_foreground:
+            pred = np.load(f"{self.pred_label_path}/{seq}/{idx:03d}_pred.npy").astype(np.int64)
+            mask = np.ones(pred.shape[0], dtype=bool)
+            for cls in self.filter_class:
+                mask[pred == cls] = 0
+            rows = rows[mask]
+        if self.remove_ground:
+            height = np.load(Path(self.dataset_cfg["POINT_HEIGHT_PATH"]) / seq / ("%04d_point_height.npy" % idx))
+            rows = rows[~(height < self.dataset_cfg["TRUNCATE_GROUND_HEIGHT"])]
+        return rows
 
     @staticmethod
     def frame_annos(info):
@@ -235,7 +262,7 @@ class WaymoDataset(DatasetTemplate):
         for info in sweeps:
             seq, idx = info["point_cloud"]["lidar_sequence"], info["point_cloud"]["sample_idx"]
             raw = self.read_lidar_file(seq, idx)
-            sel = self.kept_rows(info, raw.shape[0])
+            sel = self.filter_rows(info, self.kept_rows(info, raw.shape[0]), raw.shape[0])
             raws.append((raw, sel))
             if self.load_seg:
                 segs.append((self.get_seg_label(seq, idx), sel))
@@ -262,6 +289,11 @@ class WaymoDataset(DatasetTemplate):
                           pose=np.stack(poses, axis=0))
         # ---- device: one pass over the rows; foreground flags against each sweep's own boxes
         bxyz, feat, sweep, seg_label, inst_label = ops.assemble_sweeps(d_raw, d_seg, d_off, d_T, d_ids, batch_index)
+        if self.num_sweeps > 1 and self.with_time_feat:
+            # waymo_dataset.py:625-630: the sweep's frame index / (sweeps of this sample - 1), formed in f64 like
+            # numpy's int / int, in front of the features; the concatenation is f64 and rounded to f32 once
+            t = sweep.reshape(-1, 1).to(torch.float64) / (F - 1)
+            feat = torch.cat([t, feat.to(torch.float64)], dim=-1).to(torch.float32)
         point_wise = dict(point_bxyz=bxyz, point_feat=feat)
         if self.load_seg:
             point_wise["segmentation_label"] = seg_label

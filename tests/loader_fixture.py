@@ -60,8 +60,9 @@ def dataset_cfg(root, num_sweeps, sweep_dir, sample_range):
     })
 
 
-def build_dataset(root, g):
+def build_dataset(root, g, **overrides):
     from pcseqlearning_amd.pcdet.datasets import WaymoDataset
     s = int(g["start_index"])
-    return WaymoDataset(dataset_cfg(root, int(g["num_sweeps"]), int(g["sweep_dir"]), [s, s + 1]), training=False,
-                        root_path=Path(root), logger=None)
+    cfg = dataset_cfg(root, int(g["num_sweeps"]), int(g["sweep_dir"]), [s, s + 1])
+    cfg.update(overrides)
+    return WaymoDataset(cfg, training=False, root_path=Path(root), logger=None)

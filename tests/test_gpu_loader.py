@@ -70,6 +70,67 @@ def test_loader_vs_reference(name, tmp_path):
     assert both["gt_boxes"].shape[0] == 2
 
 
+def test_loader_with_time_feat(tmp_path):
+    """WITH_TIME_FEAT (waymo_dataset.py:625-630): the sweep's frame index / (sweeps - 1) in front of the features,
+    against a numpy restatement of those lines applied to the loader's own output without the option."""
+    g = np.load(os.path.join(GOLDEN, "loader_fwd.npz"))
+    root = LF.write_sequence(tmp_path, g)
+    plain = LF.build_dataset(root, g).load_batch_to_gpu([0], DEV)
+    timed = LF.build_dataset(root, g, WITH_TIME_FEAT=True).load_batch_to_gpu([0], DEV)
+    F = int(g["num_sweeps"])
+    assert F > 1
+    sweep = plain["point_sweep"].cpu().numpy()
+    # (the feature encoder runs AFTER the concatenation and picks columns by their index in src_feature_list,
+    #  point_feature_encoder.py:41-55: with the time column in front, the fixture's three used features are
+    #  columns 0..2 of [time, intensity, elongation, range, ...] -- the reference's behaviour, reproduced)
+    ncol = plain["point_feat"].shape[1]
+    want = np.concatenate([sweep.reshape(-1, 1) / (F - 1), plain["point_feat"].cpu().numpy()],
+                          axis=-1).astype(np.float32)[:, :ncol]
+    got = timed["point_feat"].cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    for k in ("point_bxyz", "point_sweep", "is_foreground"):
+        assert torch.equal(timed[k], plain[k])
+
+
+def test_loader_filter_foreground_and_remove_ground(tmp_path):
+    """FILTER_FOREGROUND + REMOVE_GROUND (waymo_dataset.py:479-492): per-frame row filters read from files, against
+    the same masks applied to the unfiltered loader output (every point-wise array is row-filtered alike)."""
+    g = np.load(os.path.join(GOLDEN, "loader_fwd.npz"))
+    root = LF.write_sequence(tmp_path, g)
+    plain_ds = LF.build_dataset(root, g)
+    plain = plain_ds.load_batch_to_gpu([0], DEV)
+    rng = np.random.default_rng(9)
+    pred_dir, height_dir = tmp_path / "pred", tmp_path / "height"
+    keep_all = []
+    for info in plain_ds.sweep_infos(0):  # the sample's sweeps in output order
+        seq, idx = info["point_cloud"]["lidar_sequence"], info["point_cloud"]["sample_idx"]
+        n_raw = plain_ds.read_lidar_file(seq, idx).shape[0]
+        sel = plain_ds.kept_rows(info, n_raw)
+        n = len(np.arange(n_raw)[sel])
+        pred = rng.integers(0, 6, n).astype(np.int32)
+        fg_keep = ~np.isin(pred, [1, 4])
+        height = rng.uniform(-0.5, 2.0, int(fg_keep.sum())).astype(np.float32)
+        (pred_dir / seq).mkdir(parents=True, exist_ok=True)
+        (height_dir / seq).mkdir(parents=True, exist_ok=True)
+        np.save(pred_dir / seq / f"{idx:03d}_pred.npy", pred)
+        np.save(height_dir / seq / ("%04d_point_height.npy" % idx), height)
+        keep = fg_keep.copy()
+        keep[np.nonzero(fg_keep)[0][height < 0.3]] = False
+        keep_all.append(keep)
+    keep_all = np.concatenate(keep_all)
+    assert 0 < keep_all.sum() < keep_all.shape[0] == plain["point_bxyz"].shape[0]
+    ds = LF.build_dataset(root, g, FILTER_FOREGROUND={"PRED_LABEL_PATH": str(pred_dir), "FILTER_CLASS": [1, 4]},
+                          REMOVE_GROUND=True, POINT_HEIGHT_PATH=height_dir, TRUNCATE_GROUND_HEIGHT=0.3)
+    got = ds.load_batch_to_gpu([0], DEV)
+    m = torch.from_numpy(keep_all).to(DEV)
+    for k in ("point_bxyz", "point_feat", "point_sweep", "segmentation_label", "instance_label", "is_foreground"):
+        assert torch.equal(got[k], plain[k][m]), k
+    # only one of the two
+    ds = LF.build_dataset(root, g, FILTER_FOREGROUND={"PRED_LABEL_PATH": str(pred_dir), "FILTER_CLASS": [1, 4]})
+    assert ds.load_batch_to_gpu([0], DEV)["point_bxyz"].shape[0] > int(keep_all.sum())
+
+
 def random_sweeps(rng, F, n_per):
     from tests.golden.make_golden_loader import pose_of
     raws, poses = [], []
