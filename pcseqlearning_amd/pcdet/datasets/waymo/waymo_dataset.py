@@ -24,7 +24,7 @@ from .... import ops
 from ..dataset import DatasetTemplate
 
 _UNSUPPORTED = {
-    "SPHERICAL_RESAMPLING": False, "SYNC_MOVING_POINTS": False,
+    "SPHERICAL_RESAMPLING": False,
     "DROP_POINTS_BY_SEG_LEN": False, "MIX3D": None, "INFO_WITH_FAKELIDAR": False,
 }
 
@@ -71,6 +71,7 @@ class WaymoDataset(DatasetTemplate):
             self.sample_sequence_list = wanted
         self.num_sweeps = cfg.get("NUM_SWEEPS", 1)
         self.with_time_feat = cfg.get("WITH_TIME_FEAT", False)  # waymo_dataset.py:59
+        self.sync_moving_points = cfg.get("SYNC_MOVING_POINTS", False)  # waymo_dataset.py:61
         self.remove_ground = cfg.get("REMOVE_GROUND", False)  # waymo_dataset.py:62 (POINT_HEIGHT_PATH, TRUNCATE_GROUND_HEIGHT)
         ff = cfg.get("FILTER_FOREGROUND", None)  # waymo_dataset.py:65-69
         self.filter_foreground = ff is not None
@@ -209,6 +210,51 @@ class WaymoDataset(DatasetTemplate):
         T0_inv = np.linalg.inv(poses[-1])
         return poses, [T0_inv @ T1 for T1 in poses]
 
+    def sync_transforms(self, index, sweeps):
+        """SYNC_MOVING_POINTS, the rigid motion of every box of every sweep onto the box of the same object in
+        the sample's own frame (waymo_dataset.py:513-569): Kabsch on the eight corners (numpy SVD in f64, the
+        reference's own calls), identity for the sample's frame, a 1e4 m translation -- the points are dropped
+        afterwards -- for objects the sample's frame does not have. One [k_s, 4, 4] f64 array per sweep."""
+        cur = self.infos[index]
+        cur_annos = self.frame_annos(cur)
+        cur_boxes = np.array(cur_annos["gt_boxes_lidar"], copy=True)
+        box_corners = boxes_to_corners_3d(cur_boxes)
+        obj_id_to_box = {obj_id: k for k, obj_id in enumerate(cur_annos["obj_ids"])}
+        T0_inv = np.linalg.inv(np.asarray(cur["pose"], dtype=np.float64).reshape(4, 4))
+        out = []
+        for info in sweeps:
+            annos = self.frame_annos(info)
+            if info is cur or info["point_cloud"]["sample_idx"] == cur["point_cloud"]["sample_idx"]:
+                k = len(annos["obj_ids"])
+                out.append(np.stack([np.eye(4).astype(np.float64)] * k, axis=0) if k > 0
+                           else np.zeros((0, 4, 4), dtype=np.float32))
+                continue
+            T_this = T0_inv @ np.asarray(info["pose"], dtype=np.float64).reshape(4, 4)
+            corners = boxes_to_corners_3d(np.array(annos["gt_boxes_lidar"], copy=True))
+            corners = (corners @ T_this[:3, :3].T + T_this[:3, 3]).reshape(-1, 8, 3)
+            global_T = []
+            for obj_idx, obj_id in enumerate(annos["obj_ids"]):
+                T_t = np.eye(4).astype(np.float64)
+                if obj_id not in obj_id_to_box:
+                    T_t[:3, 3] = 1e4
+                else:
+                    last_box_corner = corners[obj_idx]
+                    box_corner = box_corners[obj_id_to_box[obj_id]]
+                    b0 = box_corner.mean(0)
+                    l0 = last_box_corner.mean(0)
+                    q = box_corner - b0
+                    pp = last_box_corner - l0
+                    M = pp.T @ q
+                    U, S, VT = np.linalg.svd(M)
+                    V = VT.T
+                    sign = np.linalg.det(V @ U.T)
+                    R = V @ np.diag([1, 1, sign]) @ U.T
+                    T_t[:3, :3] = R
+                    T_t[:3, 3] = b0 - R @ l0
+                global_T.append(T_t)
+            out.append(np.stack(global_T, axis=0) if global_T else np.zeros((0, 4, 4), dtype=np.float32))
+        return out
+
     def assemble_objects(self, sweeps, Ts):
         """Per-sweep boxes into the last sweep's frame, padded and stacked (waymo_dataset.py:632-665):
         a few dozen boxes per sweep, on the host in the reference's own precision. Also returns every
@@ -307,6 +353,27 @@ class WaymoDataset(DatasetTemplate):
                 d_raw[:, :3], slot, torch.from_numpy(np.concatenate(box_list, axis=0)).to(device),
                 torch.from_numpy(box_off).to(device), int(box_counts.max()), want_member=False, want_first=True)
             point_wise["is_foreground"] = first >= 0
+            if self.sync_moving_points and self.num_sweeps > 1:
+                # waymo_dataset.py:587-618: a point inside a box of its own sweep (the FIRST such box) moves with
+                # that box's global_T -- in f64, on the aligned coordinates as stored (f32) --, then every point of
+                # a sweep that has boxes is kept only if all its coordinates are below 1e3. The sample's
+                # coordinates are f64 from here on, as the reference's are (its concatenation of f32 and f64
+                # sweeps is f64). Term by term, left to right, like numpy's small-matrix product.
+                gT = np.concatenate([g.astype(np.float64).reshape(-1, 4, 4) for g in self.sync_transforms(index, sweeps)], axis=0)
+                d_gT = torch.from_numpy(gT).to(device)
+                has_boxes = torch.from_numpy(box_counts > 0).to(device)[slot]
+                gidx = torch.from_numpy(box_off[:-1].astype(np.int64)).to(device)[slot] + first.long().clamp(min=0)
+                Tp = d_gT[gidx.clamp(max=max(gT.shape[0] - 1, 0))]
+                inside = (first >= 0) & has_boxes
+                xyz = bxyz[:, 1:].to(torch.float64)
+                x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+                moved = torch.stack([Tp[:, i, 0] * x + Tp[:, i, 1] * y + Tp[:, i, 2] * z + Tp[:, i, 3] for i in range(3)], dim=1)
+                xyz = torch.where(inside[:, None], moved, xyz)
+                keep = ~has_boxes | (xyz < 1e3).all(-1)
+                bxyz = torch.cat([bxyz[:, :1].to(torch.float64), xyz], dim=1)[keep]
+                point_wise = {k: v[keep] for k, v in point_wise.items()}
+                point_wise["point_bxyz"] = bxyz
+                sweep = sweep[keep]
         else:
             point_wise["is_foreground"] = torch.zeros(N, dtype=torch.bool, device=device)
         point_wise["point_sweep"] = sweep

@@ -6,6 +6,10 @@ sequence written to a temporary directory in the reference's on-disk layout
 
   loader_fwd.npz   NUM_SWEEPS 5, SWEEP_DIR +1 from sample 0 (the registration configs' direction)
   loader_bwd.npz   NUM_SWEEPS 4, SWEEP_DIR -1 from the last sample
+  loader_sync.npz  (round 3) NUM_SWEEPS 5 forward with SYNC_MOVING_POINTS + WITH_TIME_FEAT, on a sequence whose
+                   boxes hold points (waymo_dataset.py:513-569, 587-618, 625-630)
+  loader_filter.npz (round 3) NUM_SWEEPS 4 forward with FILTER_FOREGROUND + REMOVE_GROUND (waymo_dataset.py:479-492);
+                   the per-frame prediction / height files are part of the inputs (`pred_<f>`, `height_<f>`)
 
 Each file holds the inputs (raw frames, seg labels, poses, boxes, names, ids, per-lidar counts) and
 every array of the collated batch the reference returns. Third-party modules absent from this image
@@ -112,7 +116,10 @@ def pose_of(rng, f):
     return T
 
 
-def write_sequence(root, num_frames, seed):
+def write_sequence(root, num_frames, seed, points_in_boxes=0, side_files=None):
+    """points_in_boxes > 0: that many points of the first lidar are placed inside every present box (so that
+    SYNC_MOVING_POINTS has something to move); side_files = (pred_dir, height_dir, filter_classes, truncate):
+    per-frame prediction / height files for FILTER_FOREGROUND / REMOVE_GROUND."""
     rng = np.random.default_rng(seed)
     seq_dir = Path(root) / TAG / SEQ
     seq_dir.mkdir(parents=True)
@@ -145,7 +152,29 @@ def write_sequence(root, num_frames, seed):
         k = int(present.sum())
         boxes = np.concatenate([obj_pos[present] + obj_vel[present] * f, obj_dim[present],
                                 (obj_yaw[present] + 0.02 * f)[:, None]], axis=1).astype(np.float32)
+        if points_in_boxes > 0:
+            at = 0
+            for b in boxes:
+                m = points_in_boxes
+                loc = rng.uniform(-0.45, 0.45, (m, 3)) * b[3:6]
+                c, s_ = np.cos(b[6]), np.sin(b[6])
+                rot = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+                pts[at:at + m, :3] = (loc @ rot.T + b[:3]).astype(np.float32)
+                at += m
+            pts[:, 5] = np.linalg.norm(pts[:, :3], axis=1)
         pose = pose_of(rng, f)
+        if side_files is not None:
+            pred_dir, height_dir, filter_classes, truncate = side_files
+            n_kept = counts[0]  # DROP_POINTS_BY_LIDAR_INDEX [1, 2, 3, 4] keeps the first lidar's rows
+            pred = rng.integers(0, 6, n_kept).astype(np.int32)
+            n_fg = int((~np.isin(pred, filter_classes)).sum())
+            height = rng.uniform(-0.5, 2.0, n_fg).astype(np.float32)
+            (Path(pred_dir) / SEQ).mkdir(parents=True, exist_ok=True)
+            (Path(height_dir) / SEQ).mkdir(parents=True, exist_ok=True)
+            np.save(Path(pred_dir) / SEQ / f"{f:03d}_pred.npy", pred)
+            np.save(Path(height_dir) / SEQ / ("%04d_point_height.npy" % f), height)
+            inputs[f"pred_{f}"] = pred
+            inputs[f"height_{f}"] = height
         np.save(seq_dir / ("%04d.npy" % f), pts)
         np.save(seq_dir / ("%04d_seg.npy" % f), seg)
         infos.append({
@@ -200,10 +229,12 @@ def dataset_cfg(EasyDict, root, num_sweeps, sweep_dir, sample_range):
     })
 
 
-def run_reference(EasyDict, WaymoDataset, root, num_sweeps, sweep_dir, sample_range):
+def run_reference(EasyDict, WaymoDataset, root, num_sweeps, sweep_dir, sample_range, overrides=None):
     log = logging.getLogger("golden")
-    ds = WaymoDataset(dataset_cfg(EasyDict, root, num_sweeps, sweep_dir, sample_range), training=False,
-                      root_path=Path(root), logger=log)
+    cfg = dataset_cfg(EasyDict, root, num_sweeps, sweep_dir, sample_range)
+    for k, v in (overrides or {}).items():
+        cfg[k] = EasyDict(v) if isinstance(v, dict) else v
+    ds = WaymoDataset(cfg, training=False, root_path=Path(root), logger=log)
     assert len(ds) == 1
     sample = ds[0]
     batch = ds.collate_batch([sample])
@@ -218,17 +249,36 @@ def run_reference(EasyDict, WaymoDataset, root, num_sweeps, sweep_dir, sample_ra
     return out
 
 
+FILTER_CLASSES, TRUNCATE = [1, 4], 0.3
+
+
 def main():
     EasyDict = _install_shims()
     import importlib
     wd = importlib.import_module("pcdet.datasets.waymo.waymo_dataset")
-    for name, frames, sweeps, direction, rng_ in (("loader_fwd", 6, 5, 1, [0, 1]), ("loader_bwd", 5, 4, -1, [4, 5])):
+    only = sys.argv[1:]  # optional: names of the files to (re)generate
+    cases = (("loader_fwd", 6, 5, 1, [0, 1], 11, {}), ("loader_bwd", 5, 4, -1, [4, 5], 12, {}),
+             ("loader_sync", 6, 5, 1, [0, 1], 13, {"SYNC_MOVING_POINTS": True, "WITH_TIME_FEAT": True}),
+             ("loader_filter", 5, 4, 1, [0, 1], 14, {"REMOVE_GROUND": True, "FILTER_FOREGROUND": True}))
+    for name, frames, sweeps, direction, rng_, seed, opts in cases:
+        if only and name not in only:
+            continue
         root = tempfile.mkdtemp(prefix="pcs_golden_loader_")
         try:
-            inputs = write_sequence(root, frames, seed=11 if direction == 1 else 12)
-            out = run_reference(EasyDict, wd.WaymoDataset, root, sweeps, direction, rng_)
+            side = None
+            overrides = dict(opts)
+            if opts.get("REMOVE_GROUND"):
+                side = (os.path.join(root, "pred"), os.path.join(root, "height"), FILTER_CLASSES, TRUNCATE)
+                overrides["FILTER_FOREGROUND"] = {"PRED_LABEL_PATH": side[0], "FILTER_CLASS": FILTER_CLASSES}
+                overrides["POINT_HEIGHT_PATH"] = Path(side[1])
+                overrides["TRUNCATE_GROUND_HEIGHT"] = TRUNCATE
+            inputs = write_sequence(root, frames, seed=seed, points_in_boxes=12 if opts.get("SYNC_MOVING_POINTS") else 0,
+                                    side_files=side)
+            out = run_reference(EasyDict, wd.WaymoDataset, root, sweeps, direction, rng_, overrides)
         finally:
             shutil.rmtree(root, ignore_errors=True)
+        for k in ("SYNC_MOVING_POINTS", "WITH_TIME_FEAT", "REMOVE_GROUND", "FILTER_FOREGROUND"):
+            inputs["opt_" + k] = np.bool_(bool(opts.get(k, False)))
         inputs["num_sweeps"] = np.int64(sweeps)
         inputs["sweep_dir"] = np.int64(direction)
         inputs["start_index"] = np.int64(rng_[0])

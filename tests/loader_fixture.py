@@ -35,7 +35,34 @@ def write_sequence(root, g):
         np.save(seq_dir / ("%04d_seg.npy" % f), g[f"seg_{f}"])
     with open(seq_dir / f"{SEQ}.pkl", "wb") as fh:
         pickle.dump(infos_of(g), fh)
+    if "pred_0" in g.files:  # FILTER_FOREGROUND / REMOVE_GROUND side files (loader_filter.npz)
+        for f in range(int(g["num_frames"])):
+            (root / "pred" / SEQ).mkdir(parents=True, exist_ok=True)
+            (root / "height" / SEQ).mkdir(parents=True, exist_ok=True)
+            np.save(root / "pred" / SEQ / f"{f:03d}_pred.npy", g[f"pred_{f}"])
+            np.save(root / "height" / SEQ / ("%04d_point_height.npy" % f), g[f"height_{f}"])
     return root
+
+
+FILTER_CLASSES, TRUNCATE = [1, 4], 0.3  # as in tests/golden/make_golden_loader.py
+
+
+def options_of(root, g):
+    """The dataset options a golden file was generated with (opt_* flags; none for the round-1 files)."""
+    o = {}
+    if "opt_SYNC_MOVING_POINTS" not in g.files:
+        return o
+    if bool(g["opt_SYNC_MOVING_POINTS"]):
+        o["SYNC_MOVING_POINTS"] = True
+    if bool(g["opt_WITH_TIME_FEAT"]):
+        o["WITH_TIME_FEAT"] = True
+    if bool(g["opt_REMOVE_GROUND"]):
+        o["REMOVE_GROUND"] = True
+        o["POINT_HEIGHT_PATH"] = Path(root) / "height"
+        o["TRUNCATE_GROUND_HEIGHT"] = TRUNCATE
+    if bool(g["opt_FILTER_FOREGROUND"]):
+        o["FILTER_FOREGROUND"] = {"PRED_LABEL_PATH": str(Path(root) / "pred"), "FILTER_CLASS": FILTER_CLASSES}
+    return o
 
 
 def dataset_cfg(root, num_sweeps, sweep_dir, sample_range):

@@ -52,7 +52,7 @@ def test_loader_refuses_what_it_does_not_implement(tmp_path):
     root = LF.write_sequence(tmp_path, g)
     from pcseqlearning_amd.pcdet.datasets import WaymoDataset
     cfg = LF.dataset_cfg(root, 5, 1, [0, 1])
-    cfg["SYNC_MOVING_POINTS"] = True
+    cfg["SPHERICAL_RESAMPLING"] = True  # (SYNC_MOVING_POINTS, WITH_TIME_FEAT, REMOVE_GROUND, FILTER_FOREGROUND are in)
     with pytest.raises(NotImplementedError):
         WaymoDataset(cfg, training=False, root_path=root)
     with pytest.raises(NotImplementedError):
