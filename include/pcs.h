@@ -470,7 +470,10 @@ int pcs_profile_icp_read(double* out9);
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per
  * round instead of ~25 + eigh + a host sync). xyz [n,3] f32; pillar_idx [n] int64 in [0,P);
  * w0 [n] f32; origin [P,3] f32 (a point near each pillar, conditions the raw moments). Outputs:
- * plane [P,6] f32 (centre, unit normal with n_z >= 0), plane_err [n] f32, optional *d_rounds. */
+ * plane [P,6] f32 (centre, unit normal with n_z >= 0), plane_err [n] f32, optional *d_rounds.
+ * This form takes the rows in any order and adds its f64 moments with atomics: the last bits can differ from
+ * run to run. pcs_irls_plane_fit_sorted (rows grouped by pillar) has fixed-order sums and is the one the
+ * pipeline uses; ops.irls_plane_fit groups unsorted rows and calls that. */
 size_t pcs_irls_plane_fit_workspace_bytes(int64_t n, int64_t P);
 int pcs_irls_plane_fit(const float* xyz, const int64_t* pillar_idx, int64_t n, const float* w0,
                        const float* origin, int64_t P, float sigma2, float stopping_delta,

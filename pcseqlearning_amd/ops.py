@@ -675,7 +675,7 @@ def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_de
                    seg_start=None):
     """preprocessor_utils.iterative_reweighted_ransac with the convergence test on the device (no
     host sync). `seg_start` ([P+1] int32 row ranges) says the rows are grouped by pillar: one launch
-    per round with fixed-order sums; without it, two launches per round and f64 atomics.
+    per round with fixed-order sums; without it the rows are grouped here first (same sums).
     Returns (center [P,3], normal [P,3], plane_fitting_error [n])."""
     import ctypes
     L.require_gpu(xyz, "irls_plane_fit")
@@ -695,13 +695,18 @@ def irls_plane_fit(xyz, pillar_idx, w0, origin, num_pillars, sigma2, stopping_de
                                               ctypes.c_void_p(0), L.ptr(ws), L.i64(ws.numel()),
                                               L.stream()), "pcs_irls_plane_fit_sorted")
         return plane[:, :3], plane[:, 3:], perr
+    # rows in any order: grouped by pillar here (stable, so the rows of a pillar keep their order) and given to
+    # the sorted form -- its sums have a fixed order, the unsorted entry (pcs_irls_plane_fit) adds f64 terms with
+    # atomics and can differ in the last bits from run to run
     pidx = pillar_idx.long().contiguous()
-    ws = L.workspace(lib.pcs_irls_plane_fit_workspace_bytes(L.i64(n), L.i64(P)), xyz.device)
-    L.check(lib.pcs_irls_plane_fit(L.ptr(xyz), L.ptr(pidx), L.i64(n), L.ptr(w0), L.ptr(origin), L.i64(P),
-                                   L.f32(sigma2), L.f32(stopping_delta), L.i32(max_rounds), L.ptr(plane),
-                                   L.ptr(perr), ctypes.c_void_p(0), L.ptr(ws), L.i64(ws.numel()),
-                                   L.stream()), "pcs_irls_plane_fit")
-    return plane[:, :3], plane[:, 3:], perr
+    order = torch.argsort(pidx, stable=True)
+    counts = torch.bincount(pidx, minlength=P)
+    seg = torch.zeros(P + 1, dtype=torch.int32, device=xyz.device)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    center, normal, perr_sorted = irls_plane_fit(xyz[order], pidx[order], w0[order], origin, P, sigma2, stopping_delta,
+                                                 max_rounds, seg_start=seg)
+    perr[order] = perr_sorted
+    return center, normal, perr
 
 
 def ransac_plane_hypotheses(xyz, seg_start, min_z, max_z, ratios, origin, sigma2, stopping_delta=1e-2,

@@ -67,6 +67,14 @@ def test_irls_plane_fit_vs_torch():
     # fixed-order sums: the grouped path is bit-reproducible
     c2, n2, e2 = ops.irls_plane_fit(xyz, pidx, w0, origin, P, 0.0025, seg_start=seg_start)
     assert torch.equal(c, c2) and torch.equal(n, n2) and torch.equal(e, e2)
+    # rows in any order: grouped by pillar inside the wrapper, so reproducible too (the C entry for unsorted
+    # rows adds f64 terms with atomics and is not on this path)
+    perm = torch.randperm(xyz.shape[0], generator=g).to(DEV)
+    cs, ns, es = ops.irls_plane_fit(xyz[perm], pidx[perm], w0[perm], origin, P, 0.0025)
+    cs2, ns2, es2 = ops.irls_plane_fit(xyz[perm], pidx[perm], w0[perm], origin, P, 0.0025)
+    assert torch.equal(cs, cs2) and torch.equal(ns, ns2) and torch.equal(es, es2)
+    assert torch.allclose(cs, rc, atol=2e-4) and torch.allclose(ns, rn, atol=2e-4)
+    assert torch.allclose(es, re[perm], atol=3e-4)
 
 
 def test_l1_minimization_vs_torch_adamw():
