@@ -447,7 +447,7 @@ def main():
                              f"batch of {B} independent sequences through SimpleReg.forward, which processes "
                              "the sequences of a batch concurrently (one host thread and stream per sequence "
                              "for the ground / proposal / extraction stages; the tracking units of all "
-                             "sequences in flight share the launches of one lock-step engine)" if B > 1 else
+                             "sequences in flight share the launches of the device's three lock-step engines)" if B > 1 else
                              "configs[2]: one 20-frame x 160k-pt synthetic sequence per step, "
                              "cluster_tracking_TLS_multiradius_every8 end to end"),
                 "batch_size": B,

@@ -354,7 +354,7 @@ typedef struct PcsTrackParams {
   float angle_threshold;   /* TRACKING_PARAMS.ANGLE_THRESHOLD (degrees) */
   float max_diameter;      /* filter_components max_diameter (12.5) */
   float smooth_weight0, smooth_weight, smooth_stopping; /* smooth_velo (1, 10, 1e-3) */
-  int32_t groups;          /* ignored (round 2: lock-step groups per call); units of all calls now share the device's one lock-step engine */
+  int32_t groups;          /* ignored (round 2: lock-step groups per call); units of all calls now share the device's lock-step engines */
 } PcsTrackParams;
 size_t pcs_track_frame_workspace_bytes(int64_t n_anchor, int64_t n_frame_max, int64_t C,
                                        int num_frames);
@@ -371,10 +371,10 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
  * key, for every anchor frame, track_frame) for ALL units of a sequence in one call. The units are
  * independent, and each is a chain of small latency-bound launches, so they advance in lock-step:
  * every launch serves all units that are in the same phase, the ICP iterations of all units share
- * their three launches. The lock-step loop belongs to the DEVICE, not to the call: one driver thread
- * and one stream per device advance every unit that any call (any host thread, any sequence of a
- * batch: SimpleReg.forward loops over independent sequences, simple_reg.py:105-147) has handed
- * over; units join and leave at tick boundaries. The call prepares its units on `stream`, hands them
+ * their four launches. The lock-step loop belongs to the DEVICE, not to the call: the device's engines
+ * (three by default, PCS_TRACK_ENGINES; one driver thread and one stream each) advance every unit that
+ * any call (any host thread, any sequence of a batch: SimpleReg.forward loops over independent sequences,
+ * simple_reg.py:105-147) has handed over; units join and leave at tick boundaries. The call prepares its units on `stream`, hands them
  * over and BLOCKS until they are done. A unit's results are those of pcs_track_frame on the same
  * inputs, bit for bit, whatever other units share its launches. Calls whose PcsTrackParams differ
  * from those of the units in flight wait until the engine is empty.

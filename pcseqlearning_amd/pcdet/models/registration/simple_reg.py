@@ -76,7 +76,7 @@ class SimpleReg(RegistrationTemplate):
         of the preprocessor modules (made per call: they hold no parameters, only small configuration
         objects; nothing of a worker outlives the call). A sequence's tracking stage is a chain of small,
         latency-bound launches whose duration hardly depends on their width: the native tracker merges the
-        units of ALL sequences in flight into the launches of one lock-step engine (pcs_track_sequence),
+        units of ALL sequences in flight into the launches of the device's lock-step engines (pcs_track_sequence),
         while the ground / proposal / extraction stages of the other sequences run on their own streams.
         Results do not depend on what runs beside a sequence (tests/test_gpu_backbone_pipeline.py)."""
         import copy
