@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kIrlsWg = 64;  // irls_seg_round_kernel: one wave per (pillar, fit)
+constexpr int kIrlsWg = 128;  // irls_seg_round_kernel: one wave per (pillar, fit)
 
 // all lanes of a 64-lane xor butterfly end with the same tree; lane 0's value
 template <typename T>

@@ -861,10 +861,12 @@ __global__ void irls_seg_init_kernel(IrlsSegState* st) {
 // compute_min_height_from_ransac, preprocessor_utils.py:120-135): fit y has its own weights
 // w[y*n..], planes, state; with `ratios` != nullptr its initial weights are formed here from
 // cur_z = min_z * ratio + max_z * (1 - ratio) instead of being read from w.
-// ONE WAVE per (pillar, fit): a 2 m pillar holds ~200 rows of the 10 cm voxels, and the round ends with a
-// serial 3 x 3 eigen-solve in lane 0 -- a 256-thread workgroup kept four waves resident through it (5000
-// pillars x 30 ratios = 600 k waves per round, 0.28-0.40 ms per round, 50 rounds per sequence).
-constexpr int kIrlsWg = 64;
+// TWO WAVES per (pillar, fit): a 2 m pillar holds ~200 rows of the 10 cm voxels, and the round ends with a
+// serial 3 x 3 eigen-solve in thread 0 -- a 256-thread workgroup kept four waves resident through it (5000
+// pillars x 30 ratios = 600 k waves per round, 0.28-0.40 ms per round, 50 rounds per sequence). Batches of 12:
+// 256 threads 1494-1510 ms, 64 threads 1451-1473 (but the launch ends with its largest pillar on one wave:
+// the stage alone 20.8 -> 27.8 ms), 128 threads 1445-1448 ms (the stage alone 22 ms).
+constexpr int kIrlsWg = 128;
 __global__ void __launch_bounds__(kIrlsWg)
 irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
                       const int32_t* __restrict__ seg_start, const float* __restrict__ origin,
@@ -946,9 +948,32 @@ irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
     v[10] += 1.0;
   }
   double a[11];
+  float m4;
+  if constexpr (kIrlsWg == 64) {
 #pragma unroll
-  for (int q = 0; q < 11; ++q) a[q] = wave_sum_f64(v[q]);  // (fixed tree: lane l held rows l, l + 64, ...)
-  const float m4 = wave_max(dw);
+    for (int q = 0; q < 11; ++q) a[q] = wave_sum_f64(v[q]);  // (fixed tree: lane l held rows l, l + 64, ...)
+    m4 = wave_max(dw);
+  } else {  // several waves per fit: their sums are added in wave order by thread 0
+    __shared__ double part[kIrlsWg / 64][11];
+    __shared__ float sdw[kIrlsWg / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      double x = wave_sum_f64(v[q]);
+      if (lane == 0) part[wv][q] = x;
+    }
+    float mx = wave_max(dw);
+    if (lane == 0) sdw[wv] = mx;
+    __syncthreads();
+    m4 = sdw[0];
+    for (int k = 1; k < kIrlsWg / 64; ++k) m4 = fmaxf(m4, sdw[k]);
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      double x = part[0][q];
+      for (int k = 1; k < kIrlsWg / 64; ++k) x += part[k][q];
+      a[q] = x;
+    }
+  }
   if (threadIdx.x == 0) {
     if (r > 1) atomicMax(&st->dw[r], __float_as_uint(m4));
     double ws = a[0] + 1e-6;
