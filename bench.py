@@ -222,18 +222,22 @@ def stage_rooflines(records, stats, prof, out):
     e, nn = stats.get("proposal cc edges", 0), stats.get("proposal cc nodes", 0)
     t_cc = sum(val for key, val in records.items() if key.startswith("Propose Cluster for"))
     add("proposal components", t_cc, 16.0 * e + 8.0 * nn, "16 E + 8 N")
-    names = ("icp neighbours + moments (budget test + searches)", None, "icp solve + apply")
-    notes = ("36 (Mn + Rn) + 40 (Mn + Rn) + 272 C per launch", None, "68 Mn + 416 C per launch")
-    for q in (0, 2):
-        ms, launches, nbytes = prof[3 * q], prof[3 * q + 1], prof[3 * q + 2]
-        if q == 0:
-            nbytes += prof[5]  # the moments' share rides in the same launches now
-        if ms > 0:
-            gbs = nbytes / (ms * 1e-3) / 1e9
-            stages.append({"stage": names[q], "ms": round(ms, 3), "launches": int(launches),
-                           "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                           "algorithmic_MB": round(nbytes / 1e6, 2), "achieved_GBs": round(gbs, 2),
-                           "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": notes[q]})
+    # the unit-resident ICP loop: HIP-event kernel time of its launches; the phase rows are CU time (the
+    # workgroups' own s_memrealtime stamps summed over the units), not wall time
+    ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
+    if ms > 0:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        stages.append({"stage": "icp loop (one workgroup per unit: budget test, searches, solve, apply)",
+                       "ms": round(ms, 3), "launches": int(launches),
+                       "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                       "unit_iterations": int(unit_iters), "algorithmic_MB": round(nbytes / 1e6, 2),
+                       "achieved_GBs": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5),
+                       "bytes": "76 (Mn + Rn) + 68 Mn + 688 C per unit and iteration"})
+        phase_us = [prof[4 + q] for q in range(4)]
+        if sum(phase_us) > 0 and unit_iters > 0:
+            stages.append({"stage": "icp loop phases, CU-microseconds per unit-iteration",
+                           "budget_test": round(phase_us[0] / unit_iters, 2), "searches": round(phase_us[1] / unit_iters, 2),
+                           "solve": round(phase_us[2] / unit_iters, 2), "apply": round(phase_us[3] / unit_iters, 2)})
     return stages
 
 
@@ -404,25 +408,25 @@ def main():
             torch.cuda.synchronize()
             timer.SYNC = False
             stages = stage_rooflines(dict(timer.RECORDS), dict(timer.STATS), prof, out)
-        # the dominant kernels: the neighbour kernels of the fused ICP (budget test + searches, moments
-        # included). HIP events attached to the dispatches themselves (hipExtLaunchKernelGGL): first
-        # start to last stop of the pair, the quantity rocprofv3 reports as kernel durations
-        ms, launches, nbytes = prof[0], prof[1], prof[2] + prof[5]
+        # the dominant kernel: the unit-resident ICP loop (one workgroup per tracking unit runs that unit's
+        # iterations back to back). HIP events attached to the dispatch itself (hipExtLaunchKernelGGL): the
+        # quantity rocprofv3 reports as kernel duration. A launch occupies as many CUs as it has units.
+        ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
-        # HBM traffic of the pair per launch from the PMC passes of THIS schedule (tools/pmc_pass.sh ->
-        # profiles/r03_icp_hbm_pmc.json, written by tools/summarize_pmc.py); null when no such file exists
+        # HBM traffic per launch from the PMC passes of THIS schedule (tools/pmc_batch.sh ->
+        # profiles/r04_icp_hbm_pmc.json, written by tools/summarize_pmc.py); null when no such file exists
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_icp_hbm_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r04_icp_hbm_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            ratio = pmc.get("icp_nn_pair_traffic_over_algorithmic")
+            ratio = pmc.get("icp_loop_traffic_over_algorithmic")
             if ratio and launches > 0:
                 traffic = round(ratio * nbytes / launches, 1)
-            traffic_src = ("profiles/r03_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            traffic_src = ("profiles/r04_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                            "this command (same schedule), (fetch + write) / algorithmic = %s (raw FETCH_SIZE; "
                            "%s with the guide's x2 correction for gfx950), times this run's algorithmic bytes "
-                           "per launch" % (ratio, pmc.get("icp_nn_pair_traffic_over_algorithmic_fetch_x2")))
+                           "per launch" % (ratio, pmc.get("icp_loop_traffic_over_algorithmic_fetch_x2")))
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
@@ -469,14 +473,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("icp_nn_kernel + icp_nn_search_kernel (fused ICP: verified-cache budget test, "
-                           "searches around the old partner / cooperative searches, moments)"),
+                "kernel": ("icp_loop_kernel (fused ICP, one 1024-thread workgroup per tracking unit: verified-cache "
+                           "budget test, searches, moments, solve, stop rule, apply -- all iterations of a chunk)"),
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                "timing": ("HIP events on the dispatches themselves, inside the timed steps, on one iteration "
-                           "of every chunk of 8 (rotating position): first start to last stop of the pair"),
+                "timing": ("HIP events on the dispatches themselves, inside the timed steps, every launch of the "
+                           "loop kernel in which at least one unit iterated"),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
+                "unit_iterations_timed": int(unit_iters),
+                "unit_iterations_per_launch": round(unit_iters / max(launches, 1), 1),
                 "stages": stages,
             },
         }

@@ -17,11 +17,6 @@
 namespace pcs {
 
 constexpr int kCellCap = 16;
-#ifdef PCS_WG_TRACE
-// experiment counters of the cooperative search: [0] queries, [1] queries that walk far cells,
-// [2] far rounds (sum), [3] far cells visited (sum), [4] rounds histogram 1,2,3-4,5-8,9+ at [4..8]
-static __device__ unsigned long long g_g2cnt[16];
-#endif
 
 // A table slot is one 16-byte word so that a probe fetches the key and its payload together (one
 // dependent load instead of two): fine = {key, point count}, coarse = {key, 64-bit occupancy mask}.
@@ -291,9 +286,6 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   unsigned long long occ = __ballot(mymask != 0);
   const bool any_block = ((occ >> half_base) & 0xFFFFFFFFULL) != 0;
   valid = valid && any_block;
-#ifdef PCS_WG_TRACE
-  if (BUD && sub == 0 && valid0) atomicAdd(&g_g2cnt[0], 1ULL);
-#endif
   int cand = -1;
   float cd = 0.f;
   float cd2 = __builtin_inff();  // BUD: smallest squared distance seen other than the best's
@@ -425,15 +417,6 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     int total = __shfl(incl, half_base + 31, 64);
     int tot_o = __shfl_xor(total, 32, 64);
     int rounds = ((total > tot_o ? total : tot_o) + 31) >> 5;  // same for both halves of the wave
-#ifdef PCS_WG_TRACE
-    if (BUD && sub == 0 && total > 0) {
-      int myr = (total + 31) >> 5;
-      atomicAdd(&g_g2cnt[1], 1ULL);
-      atomicAdd(&g_g2cnt[2], (unsigned long long)myr);
-      atomicAdd(&g_g2cnt[3], (unsigned long long)total);
-      atomicAdd(&g_g2cnt[4 + (myr <= 1 ? 0 : myr == 2 ? 1 : myr <= 4 ? 2 : myr <= 8 ? 3 : 4)], 1ULL);
-    }
-#endif
     unsigned rem_lo = (unsigned)(rem & 0xFFFFFFFFULL), rem_hi = (unsigned)(rem >> 32);
     for (int rd = 0; rd < rounds; ++rd) {
       int r = rd * 32 + sub;

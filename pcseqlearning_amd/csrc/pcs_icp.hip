@@ -5,29 +5,37 @@
 // builds (4 kernels + scan + 2 host syncs + 4 allocations each), two argsorts, a handful of
 // scatter/segment kernels, a batched cuSOLVER 3x3 SVD and a blocking loss.item().
 //
-// Here a call is a descriptor in a device table (pcs_icp.hpp) and iteration k is THREE launches that
-// serve every problem of the batch (blockIdx.y = batch entry):
-//   nn         1-NN both directions, 32 lanes per query (two-level grid, pcs_grid2.hpp); workgroup
-//              0 of each entry first settles the stop rule of iteration k-1
-//   moments    ONE pass over the matched pairs: n, sum p, sum q, sum p(x)q, sum |p-q|^2 per
-//              component as 64-bit fixed-point integers (LDS table per workgroup, then one integer
-//              atomic per (workgroup, component, accumulator)): order-free, hence bit-reproducible;
-//              the centred covariance and the loss follow algebraically, so the reference's second
-//              pass over the edges is not needed
-//   apply      every moving point solves its own component's regularised Kabsch step from the
-//              completed moments (cov + reg*T_rot -> rotation by Newton's polar iteration, Jacobi SVD
-//              when det <= 0; R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T) -- a
-//              3x3 solve per point is cheaper than another launch --, moves (f64 -> fp32 as the
-//              reference stores them), the component's first point stores T and the loss term; the
-//              moved points go straight into the grid of iteration k+1 (double-buffered) and the grid
-//              just searched is reset
-// Every kernel of iteration k returns immediately when k > state.stop_iter, so the host enqueues
-// iterations in chunks and reads one word per chunk (through pinned memory) instead of one loss per
-// iteration. All kernels are grid-stride: the launch geometry never changes a result.
+// Here a call is a descriptor in a device table (pcs_icp.hpp) and an iteration is four PHASES:
+//   budget     one lane per query: the verified cache (see icp_budget_phase); settled pairs add their
+//              raw moments, the rest is compacted into work lists
+//   search     the listed queries: eight lanes around the old partner, or the cooperative 32-lane
+//              search (two-level grid, pcs_grid2.hpp); their pairs' moments
+//   solve      one thread per component: regularised Kabsch step from the completed moments (cov +
+//              reg*T_rot -> rotation by Newton's polar iteration, Jacobi SVD when det <= 0;
+//              R = V diag(1,1,det(VU^T)) U^T, t = c_ref - R c_mov, T <- T_i T), the loss term
+//   apply      every moving point moves (f64 -> fp32 as the reference stores them) and enters the grid
+//              of the next iteration (double-buffered); the grid just searched is reset
+// The moments are 64-bit fixed-point integers (n, sum p, sum q, sum p(x)q, sum |p-q|^2 per component):
+// order-free, hence bit-reproducible; the centred covariance and the loss follow algebraically, so the
+// reference's second pass over the edges is not needed.
+//
+// Who runs the phases (round 4):
+//   * the UNIT-RESIDENT LOOP (icp_loop_kernel): ONE 1024-thread workgroup owns a registration for a whole
+//     chunk and runs its iterations back to back -- the phases are separated by workgroup barriers, the
+//     stop rule is settled by the workgroup itself, nothing is launched and nothing crosses a CU between
+//     iterations, the unit's state stays in the L2 of one XCD. Rounds 1-3 ran every phase as a launch
+//     of its own over all units (four launches per iteration, ~7000 per sequence, each a chain of cold
+//     dependent loads): the chip spent its time waiting for launches to start and end. Units of a batch
+//     run side by side on CUs of their own instead of taking turns on the whole chip;
+//   * wide launches (icp_first / icp_nn / icp_nn_search / icp_solve / icp_apply kernels, blockIdx.y =
+//     entry) for the first iteration(s) of a registration, whose full searches want the whole chip.
+// Both are the same device functions; every loop is a stride over (workgroup index, workgroup count):
+// the launch geometry never changes a result.
 #include "pcs_icp.hpp"
 
 #include <hip/hip_ext.h>
 
+#include <cstdio>
 #include <mutex>
 
 namespace pcs {
@@ -51,6 +59,9 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.wl = a.take<int32_t>(Mn + Rn);
   b.wls = a.take<int32_t>(Mn + Rn);
   b.sstep = a.take<unsigned int>(2 * kStepH);
+  b.rsrt = a.take<float4>(Rn);
+  b.msrt = a.take<float4>(Mn);
+  b.trow = a.take<int32_t>(kTileRows + 1);
   b.prev = a.take<float>(Mn * 4);
   b.acc = a.take<long long>(2 * C * kAcc);
   b.Tb = a.take<double>(2 * C * 16);
@@ -102,6 +113,9 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.wl = b.wl;
   pr.wls = b.wls;
   pr.sstep = b.sstep;
+  pr.rsrt = b.rsrt;
+  pr.msrt = b.msrt;
+  pr.trow = b.trow;
   pr.acc = b.acc;
   pr.Tb = b.Tb;
   pr.Rt = b.Rt;
@@ -131,33 +145,35 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   return PCS_OK;
 }
 
-__device__ __forceinline__ long long to_fx(double v) { return __double2ll_rn(v * kFx); }
-#ifdef PCS_WG_TRACE
-__device__ unsigned long long* g_wgt = nullptr;
-__device__ unsigned int g_wgt_n = 0;
-constexpr unsigned kWgtCap = 6u << 20;
-#define WGT_BEGIN() const unsigned long long wgt0 = __builtin_amdgcn_s_memrealtime()
-#define WGT_MARK(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
-#define WGT_END(kid, kk, m1, m2)                                                                       \
-  do {                                                                                                 \
-    __syncthreads();                                                                                   \
-    if (threadIdx.x == 0 && g_wgt) {                                                                   \
-      unsigned i_ = atomicAdd(&g_wgt_n, 1u);                                                           \
-      if (i_ < kWgtCap) {                                                                              \
-        g_wgt[5 * (size_t)i_] = ((unsigned long long)(kid) << 56) | ((unsigned long long)(kk) << 40) | \
-                                ((unsigned long long)blockIdx.y << 32) | ((unsigned long long)blockIdx.z << 28) | blockIdx.x; \
-        g_wgt[5 * (size_t)i_ + 1] = wgt0;                                                              \
-        g_wgt[5 * (size_t)i_ + 2] = __builtin_amdgcn_s_memrealtime();                                  \
-        g_wgt[5 * (size_t)i_ + 3] = (m1);                                                              \
-        g_wgt[5 * (size_t)i_ + 4] = (m2);                                                              \
-      }                                                                                                \
-    }                                                                                                  \
-  } while (0)
-#else
-#define WGT_BEGIN()
-#define WGT_MARK(var)
-#define WGT_END(kid, kk, m1, m2)
-#endif
+// Fixed point with kFxBits fractional bits, round to nearest even. For |v| < 2^15 (every moment term: see
+// icp_limit_sq) adding 1.5 * 2^52 leaves the rounded integer in the low mantissa bits: two instructions
+// where the library's double -> long long conversion takes about twenty, the same result bit for bit
+// (v * 2^36 is exact). The components' loss terms use the whole 63-bit range: to_fx_wide.
+__device__ __forceinline__ long long to_fx(double v) {
+  const double magic = 6755399441055744.0;  // 1.5 * 2^52
+  return __double_as_longlong(v * kFx + magic) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ long long to_fx_wide(double v) { return __double2ll_rn(v * kFx); }
+// Sum of a 32-bit word over the 64 lanes, valid in lane 63: row shifts (an inclusive scan of each row of
+// 16 lanes) and the two row broadcasts of GFX9's DPP -- six adds, no LDS crossbar, no address arithmetic.
+__device__ __forceinline__ int wave_sum_i32_lane63(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// The same for a moment term (|v| < 2^51): its low 26 bits and the rest add up separately without carries
+// (64 x 2^26 = 2^32, 64 x 2^25 = 2^31), so a 64-bit sum is two independent 32-bit sums.
+__device__ __forceinline__ long long wave_sum_fx_lane63(long long v) {
+  const int lo = (int)((unsigned long long)v & 0x3FFFFFFULL);
+  const int hi = (int)(v >> 26);
+  const unsigned slo = (unsigned)wave_sum_i32_lane63(lo);
+  const int shi = wave_sum_i32_lane63(hi);
+  return ((long long)shi << 26) + (long long)slo;
+}
 
 // start of a call: bounds <- empty, T <- identity, accumulators and counters <- 0, state <- initial,
 // the four grids <- empty (one launch instead of a dozen memsets)
@@ -180,9 +196,13 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->wl_n[0] = st->wl_n[1] = 0;
     st->ws_n[0] = st->ws_n[1] = 0;
     st->dmax[0] = st->dmax[1] = 0u;
+    st->loop_iters = 0;
+    st->mode = 0;
+    st->phase_ticks[0] = st->phase_ticks[1] = st->phase_ticks[2] = st->phase_ticks[3] = 0ULL;
+    st->dbg[0] = st->dbg[1] = st->dbg[2] = st->dbg[3] = 0ULL;
   }
-  for (int64_t q = i; q < 2 * C * 16; q += stride) {
-    int e = (int)(q & 15);
+  for (int64_t q = i; q < 2 * C * 16; q += stride) {  // (component-minor: word e of every component side by side)
+    int e = (int)((q / C) & 15);
     pr.Tb[q] = (e == 0 || e == 5 || e == 10 || e == 15) ? 1.0 : 0.0;
   }
   for (int64_t q = i; q < 2 * C * kAcc; q += stride) pr.acc[q] = 0;
@@ -303,7 +323,7 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
   if (threadIdx.x < kLossParts) {
     v = part[threadIdx.x];
     vc = chk[threadIdx.x];
-    part[threadIdx.x] = 0;  // (the solve launch of iteration k_done + 2 adds here next)
+    part[threadIdx.x] = 0;  // (the solve phase of iteration k_done + 2 adds here next)
     chk[threadIdx.x] = 0;
   }
 #pragma unroll
@@ -326,42 +346,29 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
   }
 }
 
-// end of a chunk: the stop rule of every entry's last iteration (the others were settled by the
-// next search launch), and the state mirrored where the host reads it (`out` may be pinned host
-// memory: the host then needs no copy, only the stream synchronisation)
-__global__ void __launch_bounds__(kBlock)
-icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int n_it,
-                  IcpState* __restrict__ out) {
-  const IcpProblem& pr = tab[bt.idx[blockIdx.x]];
-  int k_last = kbase.v[blockIdx.x] + n_it;
-  if (k_last > pr.max_iter) k_last = pr.max_iter;
-  if (k_last > pr.st->iters) k_last = pr.st->iters;  // iterations that did not run have no loss
-  icp_decide(pr, k_last);
-  __syncthreads();
-  if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;
-}
-
 // ---- raw moments of the matched pairs per component (n, sum p, sum q, sum p(x)q, sum |p-q|^2),
-// added by whichever kernel settles a query's neighbour: the budget test for the cached ones, the
-// search kernel for the rest -- no launch of their own. Each workgroup first accumulates into a small
-// LDS table keyed by component (64-bit integer LDS adds; neighbouring queries mostly share a
-// component), then flushes one global integer atomic per (component, accumulator). Integer sums:
-// the result does not depend on any arrival order.
-constexpr int kMomSlots = 64;
-constexpr int kMomSlotsSearch = 16;  // a search item settles 8 or 32 pairs: a small table keeps its reset and drain short
+// added by whichever phase settles a query's neighbour: the budget test for the cached ones, the
+// searches for the rest. Each workgroup first accumulates into an LDS table keyed by component
+// (64-bit integer LDS adds; neighbouring queries mostly share a component), then flushes one global
+// integer atomic per (component, accumulator). Integer sums: the result does not depend on any
+// arrival order.
+constexpr int kMomSlots = 64;        // wide budget-test workgroups (256 threads, a few rounds of queries)
+constexpr int kMomSlotsSearch = 16;  // a wide search item settles 8 or 32 pairs: a small table keeps its reset and drain short
+constexpr int kMomSlotsLoop = 512;   // the unit-resident loop: one table for ALL pairs of an iteration
+constexpr int kMomProbes = 8;        // slots a component may be looked for in before its pair goes to global memory
 struct MomTable {
   int* skey;                      // LDS [nslots]
   unsigned long long* sacc;       // LDS [nslots * 17]
   unsigned long long* acc;        // global [C, kAcc] of the iteration
   int C;                          // components (keys outside [0, C) are never flushed)
-  int nslots;                     // power of two <= kMomSlots
+  int nslots;                     // power of two
 };
 __device__ __forceinline__ void mom_init(const MomTable& t) {  // every thread of the workgroup; then a barrier
-  for (int q = threadIdx.x; q < t.nslots; q += kBlock) t.skey[q] = -1;
-  for (int q = threadIdx.x; q < t.nslots * 17; q += kBlock) t.sacc[q] = 0ULL;
+  for (int q = threadIdx.x; q < t.nslots; q += blockDim.x) t.skey[q] = -1;
+  for (int q = threadIdx.x; q < t.nslots * 17; q += blockDim.x) t.sacc[q] = 0ULL;
 }
-// the pair (moving point pf of component c, reference point qf)
-// the 17 fixed-point terms of one pair relative to the component's origin
+// the 17 fixed-point terms of one pair (moving point pf of component c, reference point qf) relative to
+// the component's origin
 __device__ __forceinline__ void mom_terms(const IcpProblem& pr, float4 pf, float4 qf, int c, double lim2,
                                           long long v[17]) {
   const float4 og = pr.corg[c];
@@ -382,69 +389,64 @@ __device__ __forceinline__ void mom_terms(const IcpProblem& pr, float4 pf, float
   }
   v[16] = to_fx(d2);
 }
-// 17 sums of component c into the workgroup's table
-__device__ __forceinline__ void mom_put(const MomTable& t, int c, const long long v[17]) {
-  // claim / find the component's LDS slot (linear probing); fall back to global atomics if full
-  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (t.nslots - 1);
-  int found = -1;
-  for (int i = 0; i < t.nslots; ++i) {
+// the component's LDS slot (linear probing), -1 if the table is full
+__device__ __forceinline__ int mom_slot(const MomTable& t, int c) {
+  int slot = (int)(((unsigned)c * 2654435761u) >> 20) & (t.nslots - 1);
+  // (a bounded walk: a unit with more components than slots fills the table, and the rest of its pairs
+  //  then goes to the global accumulators at once instead of probing every slot first)
+  for (int i = 0; i < kMomProbes; ++i) {
     int old = atomicCAS(&t.skey[slot], -1, c);
-    if (old == -1 || old == c) { found = slot; break; }
+    if (old == -1 || old == c) return slot;
     slot = (slot + 1) & (t.nslots - 1);
   }
+  return -1;
+}
+// 17 sums of component c into the workgroup's table (global atomics if it is full)
+__device__ __forceinline__ void mom_put(const MomTable& t, int c, const long long v[17]) {
+  const int found = mom_slot(t, c);
   if (found >= 0) {
 #pragma unroll
     for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.sacc[found * 17 + q2], (unsigned long long)v[q2]);
   } else {
 #pragma unroll
-    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)c * kAcc + q2], (unsigned long long)v[q2]);
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)q2 * t.C + c], (unsigned long long)v[q2]);
   }
 }
-__device__ __forceinline__ void mom_add(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
-                                        double lim2) {
-  long long v[17];
-  mom_terms(pr, pf, qf, c, lim2, v);
-  mom_put(t, c, v);
-}
-// Register-lean form: the component's slot first, then every term is formed and added at once (no array
-// of 17 64-bit terms kept alive across shuffles). Lanes of one component meet at the same 17 LDS words;
-// the adds are fire-and-forget.
+// Register-lean form for single lanes (the searches' result lanes): the slot first, then every term is
+// formed and added at once (no array of 17 64-bit terms kept alive across shuffles).
 __device__ __forceinline__ void mom_add_stream(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
                                                double lim2) {
-  int slot = (int)(((unsigned)c * 2654435761u) >> 26) & (t.nslots - 1);
-  int found = -1;
-  for (int i = 0; i < t.nslots; ++i) {
-    int old = atomicCAS(&t.skey[slot], -1, c);
-    if (old == -1 || old == c) { found = slot; break; }
-    slot = (slot + 1) & (t.nslots - 1);
-  }
-  unsigned long long* base = found >= 0 ? t.sacc + found * 17 : t.acc + (int64_t)c * kAcc;
+  const int found = mom_slot(t, c);
+  unsigned long long* base = found >= 0 ? t.sacc + found * 17 : t.acc + c;
+  const int64_t sd = found >= 0 ? 1 : t.C;  // (the global accumulators are component-minor)
   const float4 og = pr.corg[c];
   const double p0 = (double)pf.y - (double)og.y, p1 = (double)pf.z - (double)og.z, p2 = (double)pf.w - (double)og.w;
   const double q0 = (double)qf.y - (double)og.y, q1 = (double)qf.z - (double)og.z, q2 = (double)qf.w - (double)og.w;
   if (p0 * p0 + p1 * p1 + p2 * p2 > lim2 || q0 * q0 + q1 * q1 + q2 * q2 > lim2) pr.st->err = 1;
-  atomicAdd(base + 0, 1ULL);
-  atomicAdd(base + 1, (unsigned long long)to_fx(p0));
-  atomicAdd(base + 2, (unsigned long long)to_fx(p1));
-  atomicAdd(base + 3, (unsigned long long)to_fx(p2));
-  atomicAdd(base + 4, (unsigned long long)to_fx(q0));
-  atomicAdd(base + 5, (unsigned long long)to_fx(q1));
-  atomicAdd(base + 6, (unsigned long long)to_fx(q2));
-  atomicAdd(base + 7, (unsigned long long)to_fx(p0 * q0));
-  atomicAdd(base + 8, (unsigned long long)to_fx(p0 * q1));
-  atomicAdd(base + 9, (unsigned long long)to_fx(p0 * q2));
-  atomicAdd(base + 10, (unsigned long long)to_fx(p1 * q0));
-  atomicAdd(base + 11, (unsigned long long)to_fx(p1 * q1));
-  atomicAdd(base + 12, (unsigned long long)to_fx(p1 * q2));
-  atomicAdd(base + 13, (unsigned long long)to_fx(p2 * q0));
-  atomicAdd(base + 14, (unsigned long long)to_fx(p2 * q1));
-  atomicAdd(base + 15, (unsigned long long)to_fx(p2 * q2));
+  atomicAdd(base + 0 * sd, 1ULL);
+  atomicAdd(base + 1 * sd, (unsigned long long)to_fx(p0));
+  atomicAdd(base + 2 * sd, (unsigned long long)to_fx(p1));
+  atomicAdd(base + 3 * sd, (unsigned long long)to_fx(p2));
+  atomicAdd(base + 4 * sd, (unsigned long long)to_fx(q0));
+  atomicAdd(base + 5 * sd, (unsigned long long)to_fx(q1));
+  atomicAdd(base + 6 * sd, (unsigned long long)to_fx(q2));
+  atomicAdd(base + 7 * sd, (unsigned long long)to_fx(p0 * q0));
+  atomicAdd(base + 8 * sd, (unsigned long long)to_fx(p0 * q1));
+  atomicAdd(base + 9 * sd, (unsigned long long)to_fx(p0 * q2));
+  atomicAdd(base + 10 * sd, (unsigned long long)to_fx(p1 * q0));
+  atomicAdd(base + 11 * sd, (unsigned long long)to_fx(p1 * q1));
+  atomicAdd(base + 12 * sd, (unsigned long long)to_fx(p1 * q2));
+  atomicAdd(base + 13 * sd, (unsigned long long)to_fx(p2 * q0));
+  atomicAdd(base + 14 * sd, (unsigned long long)to_fx(p2 * q1));
+  atomicAdd(base + 15 * sd, (unsigned long long)to_fx(p2 * q2));
   const double e0 = p0 - q0, e1 = p1 - q1, e2 = p2 - q2;
-  atomicAdd(base + 16, (unsigned long long)to_fx(e0 * e0 + e1 * e1 + e2 * e2));
+  atomicAdd(base + 16 * sd, (unsigned long long)to_fx(e0 * e0 + e1 * e1 + e2 * e2));
 }
-// The same for a whole wave (every lane calls; `active` lanes hold a pair). Neighbouring queries
-// mostly belong to one component: when all active lanes agree on it their terms are summed by
-// shuffles first and ONE lane adds the 17 totals (otherwise 64 lanes queue up on the same 17 words).
+// The same for a whole wave (every lane calls; `active` lanes hold a pair). Neighbouring queries mostly
+// belong to one component: when all active lanes agree on it their terms are summed over the wave first
+// (DPP, wave_sum_fx_lane63) and ONE lane adds the 17 totals -- otherwise 64 lanes queue up on the same 17
+// words. Several components in the wave (the keys with thousands of small clusters: always): every lane
+// adds its own terms; lanes of one component meet at the same words, a few deep.
 __device__ __forceinline__ void mom_add_wave(const IcpProblem& pr, const MomTable& t, bool active, float4 pf,
                                              float4 qf, int c, double lim2) {
   const unsigned long long am = __ballot(active);
@@ -452,155 +454,49 @@ __device__ __forceinline__ void mom_add_wave(const IcpProblem& pr, const MomTabl
   const int leader = __ffsll((long long)am) - 1;
   const int c0 = __shfl(c, leader, 64);
   const bool uniform = __ballot(active && c != c0) == 0 && __popcll(am) >= 8;
-  if (!uniform) {
-    // Several components in the wave (the keys with thousands of small clusters: always). The points
-    // come in voxel order, so a component's points sit next to each other row by row: the RUNS of equal
-    // component add up by shuffles first and only a run's first lane goes to the table -- 64 lanes with
-    // 17 LDS adds each on a handful of slots queued up eight deep (the budget-test launch of those keys
-    // took 20.6 us against 11.5 us for the others).
-    const int lane = threadIdx.x & 63;
-    const int c_prev = __shfl_up(c, 1, 64);
-    const bool a_prev = ((am >> (lane > 0 ? lane - 1 : 0)) & 1ULL) != 0 && lane > 0;
-    const bool head = active && (!a_prev || c_prev != c);
-    const unsigned long long hm = __ballot(head);
-    const int rid = active ? __popcll(hm & ((2ULL << lane) - 1ULL)) : -1 - lane;  // run number (inactive: unique)
-    long long v[17];
-#pragma unroll
-    for (int q = 0; q < 17; ++q) v[q] = 0;
-    if (active) mom_terms(pr, pf, qf, c, lim2, v);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int rid_o = __shfl_down(rid, o, 64);
-      const bool take = lane + o < 64 && rid_o == rid;
-#pragma unroll
-      for (int q = 0; q < 17; ++q) {
-        const long long tq = __shfl_down(v[q], o, 64);
-        if (take) v[q] += tq;
-      }
-    }
-    if (head) mom_put(t, c, v);
-    return;
-  }
-  const float4 og = pr.corg[c0];
   long long v[17];
 #pragma unroll
   for (int q = 0; q < 17; ++q) v[q] = 0;
-  if (active) {
-    double p[3] = {(double)pf.y - (double)og.y, (double)pf.z - (double)og.z, (double)pf.w - (double)og.w};
-    double q[3] = {(double)qf.y - (double)og.y, (double)qf.z - (double)og.z, (double)qf.w - (double)og.w};
-    if (p[0] * p[0] + p[1] * p[1] + p[2] * p[2] > lim2 || q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > lim2)
-      pr.st->err = 1;  // a component too large for the fixed-point range
-    v[0] = 1;
-    double d2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      v[1 + a] = to_fx(p[a]);
-      v[4 + a] = to_fx(q[a]);
-#pragma unroll
-      for (int b = 0; b < 3; ++b) v[7 + a * 3 + b] = to_fx(p[a] * q[b]);
-      double e = p[a] - q[a];
-      d2 += e * e;
-    }
-    v[16] = to_fx(d2);
+  if (active) mom_terms(pr, pf, qf, c, lim2, v);
+  if (!uniform) {
+    if (active) mom_put(t, c, v);
+    return;
   }
 #pragma unroll
-  for (int q = 0; q < 17; ++q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
-  }
-  // lanes 0..16 add one total each
-  const int lane = threadIdx.x & 63;
-  if (lane < 17) {
-    long long mine = v[0];
-#pragma unroll
-    for (int q = 1; q < 17; ++q)
-      if (lane == q) mine = v[q];
-    atomicAdd(&t.acc[(int64_t)c0 * kAcc + lane], (unsigned long long)mine);
-  }
+  for (int q = 0; q < 17; ++q) v[q] = wave_sum_fx_lane63(v[q]);
+  if ((threadIdx.x & 63) == 63) mom_put(t, c0, v);
 }
 
 __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barrier; every thread
-  for (int q = threadIdx.x; q < t.nslots * 17; q += kBlock) {
+  for (int q = threadIdx.x; q < t.nslots * 17; q += blockDim.x) {
     int sl = q / 17, a = q - sl * 17;
     int key = t.skey[sl];
-    if (key >= 0 && key < t.C) atomicAdd(&t.acc[(int64_t)key * kAcc + a], t.sacc[q]);
+    if (key >= 0 && key < t.C) {
+      const unsigned long long v = t.sacc[q];
+      if (v) atomicAdd(&t.acc[(int64_t)a * t.C + key], v);
+    }
   }
 }
 
-// XCD-aware placement (flag bit 2, PCS_ICP_XCD): workgroups are dealt round-robin over the eight XCDs in
-// dispatch order (x fastest), each XCD with its own L2. The (x, entry) grid is re-read so that the
-// workgroups that share an XCD (equal linear id mod 8) serve a CONTIGUOUS eighth of the (entry, x) space:
-// an entry's clouds, grids and neighbour buffers are then fetched into one or two L2s instead of eight.
-// A bijection of the grid whatever its size (the last n mod 8 workgroups keep their place); speed only.
-struct WgXY { int x, y; };
-__device__ __forceinline__ WgXY xcd_wg(bool on) {
-  WgXY w = {(int)blockIdx.x, (int)blockIdx.y};
-  if (!on) return w;
-  const unsigned gx = gridDim.x, n = gx * gridDim.y, cpx = n >> 3, lin = blockIdx.y * gx + blockIdx.x;
-  if (lin >= (cpx << 3)) return w;
-  const unsigned swz = (lin & 7u) * cpx + (lin >> 3);
-  w.y = (int)(swz / gx);
-  w.x = (int)(swz - (unsigned)w.y * gx);
-  return w;
-}
-
-// Queries [0,Mn): forward (moving -> reference, df = +frame_offset); queries [Mn, Mn+Rn): backward
-// (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED CACHE: every search also
-// returns how far things may move before its answer can change (half the gap to the runner-up, or
-// the distance by which the nearest point misses the radius). From iteration 2 on a query first
-// subtracts what has moved since -- its own last step (forward) or the largest step of any moving
-// point (backward) -- and keeps its neighbour without touching the grid while the budget lasts
-// (98 % of the searches of a converging loop return the partner they returned before).
-//   icp_nn_kernel         one LANE per query: the budget test; the queries that must search again
-//                         are compacted into two work lists (one atomic per wave and list)
-//   icp_nn_search_kernel  blockIdx.z & 1 = 0: eight lanes per query around the old partner
-//                         (g2_nearest_seeded8) for the list of queries whose partner is within a
-//                         cell or so; 1: the cooperative search (32 lanes per query) for the rest --
-//                         and for every query in iteration 1. blockIdx.z >> 1 = the direction: a
-//                         workgroup serves forward OR backward queries (one grid, one copy of the
-//                         search in the code: the two-direction form spilled ~400 scalar registers).
-// Exact: the same neighbours as a full search, always.
-template <bool STREAM>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int lds_steps) {
-  WGT_BEGIN();
-  const WgXY wg = xcd_wg((lds_steps & 4) != 0);
-  const IcpProblem& pr = tab[bt.idx[wg.y]];
-  const int k = kbase.v[wg.y] + 1 + j;
-  IcpState* st = pr.st;
-  // The gate is read ONCE per workgroup. Workgroup 0 lowers stop_iter during this very launch (below),
-  // and the waves of a workgroup do not start together: with a per-thread gate some waves of a
-  // workgroup could leave while the others go on with a moment table in LDS that is only partly
-  // initialised -- whatever another stream's kernel left there then served as component ids in
-  // mom_flush (an out-of-range atomic: the memory fault seen once in ~50 sequences with two or more
-  // lock-step groups in flight, never with one).
-  __shared__ int s_go;
-  if (threadIdx.x == 0) s_go = (k > pr.max_iter || k > st->stop_iter) ? 0 : 1;
-  __syncthreads();
-  if (!s_go) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
+// ---- phase 1: the budget test. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
+// queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED
+// CACHE: every search also returns how far things may move before its answer can change (half the gap
+// to the runner-up, or the distance by which the nearest point misses the radius). From iteration 2 on
+// a query first subtracts what has moved since -- its own last step (forward) or the largest step of any
+// moving point near it (backward: the 8^3-cell blocks around it in the lossy step table, which can only
+// over-estimate) -- and keeps its neighbour without touching a grid while the budget lasts (98 % of
+// the searches of a converging loop return the partner they returned before). The rest is compacted into
+// work lists, by direction: cnt4[0..1] queries for the cooperative search, cnt4[2..3] queries whose old
+// partner is near enough to be searched around (g2_nearest_seeded8). Exact: the same neighbours as a
+// full search, always. Workgroup wgx of nwg takes the rounds wgx, wgx + nwg, ... of BS queries; s_step
+// is the step table of iteration k-1 (in LDS when the workgroup serves backward queries).
+template <int BS>
+__device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, int Mn, int Rn, int wgx, int nwg,
+                                                 const GridDesc& g, const MomTable& mt,
+                                                 const unsigned int* __restrict__ s_step, int* cnt4) {
   const int nq = Mn + Rn;
-  const int nround = (nq + kBlock - 1) / kBlock;
-  if (wg.x != 0 && wg.x >= nround) return;
-  // iteration k, first launch: workgroup 0 settles the stop rule of iteration k-1 (its loss terms
-  // were written by the previous launch). The other workgroups may run before the stop is known:
-  // they only write this iteration's neighbour buffers, which nothing reads after a stop.
-  if (wg.x == 0) icp_decide(pr, k - 1);
-  WGT_MARK(wg_m1);
-  if (k == 1) {  // no neighbours yet: every query is searched for
-    if (lds_steps & 2) return;  // (icp_first_kernel has dealt them to the two kinds of search)
-    for (int q = wg.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) pr.wl[q] = q;
-    if (wg.x == 0 && threadIdx.x == 0) { st->wl_n[0] = Mn; st->wl_n[1] = Rn; }
-    return;
-  }
-  __shared__ int skey[kMomSlots];
-  __shared__ unsigned long long sacc[kMomSlots * 17];
-  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C, kMomSlots};
+  const int nround = (nq + BS - 1) / BS;
   const double lim2 = icp_limit_sq(nq);
-  mom_init(mt);
-  __syncthreads();
-  GridDesc g = pr.geom->g;
   const int lane = threadIdx.x & 63;
   int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
   int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
@@ -611,21 +507,8 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   const float* __restrict__ sbud_f = pr.bud_f + (size_t)((k - 1) & 1) * pr.capM;
   const float* __restrict__ sbud_b = pr.bud_b + (size_t)((k - 1) & 1) * pr.capR;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
-  // steps of the moving points in iteration k-1, by the place they moved into
-  const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
-  // A backward query looks up eight hashed slots of the 16 KB step table: eight scattered requests where
-  // the rest of the query has three. A workgroup that serves backward queries (its last round reaches past
-  // Mn) copies the table into LDS once -- coalesced, L2-resident: every workgroup of the unit reads it.
-  __shared__ unsigned int s_step[kStepH];
-  {
-    const int r_last = wg.x + ((nround - 1 - wg.x) / (int)gridDim.x) * (int)gridDim.x;
-    if ((lds_steps & 1) && k > 1 && (r_last + 1) * kBlock > Mn) {
-      for (int q = threadIdx.x; q < kStepH / 4; q += kBlock) ((uint4*)s_step)[q] = ((const uint4*)sstep)[q];
-      __syncthreads();
-    }
-  }
-  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
-    const int qid = r * kBlock + threadIdx.x;
+  for (int r = wgx; r < nround; r += nwg) {  // whole waves stay together (ballots below)
+    const int qid = r * BS + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
     bool to_seeded = false, to_coop = false;
@@ -654,15 +537,9 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
                   cz = (int)floorf((p.w - g.lo[2]) / g.h);
         const int sx = (4 * ((cx >> 2) - 1)) >> 3, sy = (4 * ((cy >> 2) - 1)) >> 3, sz = (4 * ((cz >> 2) - 1)) >> 3;
         unsigned int m = 0u;
-        if (lds_steps & 1) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            m = max(m, s_step[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            m = max(m, sstep[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
-        }
+        for (int q = 0; q < 8; ++q)
+          m = max(m, s_step[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
         disp = __uint_as_float(m);
       }
       bud = bud - disp * 1.000001f - 1e-7f;
@@ -697,11 +574,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
         to_coop = true;
       }
     }
-    if (STREAM) {
-      if (m_act) mom_add_stream(pr, mt, m_p, m_q, m_c, lim2);
-    } else {
-      mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
-    }
+    mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
     // the work lists, by direction (a wave is all forward or all backward, except the one at Mn)
     const unsigned long long mf = __ballot(fwd);
 #pragma unroll
@@ -711,22 +584,18 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
       const int off = dir ? Mn : 0;
       if (ms) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&st->ws_n[dir], __popcll(ms));
+        if (lane == 0) base = atomicAdd(&cnt4[2 + dir], __popcll(ms));
         base = __shfl(base, 0, 64);
         if (to_seeded && fwd == (dir == 0)) pr.wls[off + base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
       }
       if (mc) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&st->wl_n[dir], __popcll(mc));
+        if (lane == 0) base = atomicAdd(&cnt4[dir], __popcll(mc));
         base = __shfl(base, 0, 64);
         if (to_coop && fwd == (dir == 0)) pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
       }
     }
   }
-  __syncthreads();
-  WGT_MARK(wg_m2);
-  mom_flush(mt);
-  WGT_END(1, k, wg_m1, wg_m2);
 }
 
 // Iteration 1 of a registration: no partner yet. Half of all cooperative searches are these -- 32 lanes
@@ -734,24 +603,15 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
 // seed as good as an old partner: where the search's own admission test accepts it, the query goes to the
 // eight-lane search around it (exact: the same result as the cooperative search), the seed's index parked in
 // the neighbour buffer that an iteration 0 would have written; the others take the cooperative search.
-// A launch of its own (entries not in their first iteration leave at once) so that the budget test keeps
-// its registers.
-__global__ void __launch_bounds__(kBlock)
-icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
-  const WgXY wg = xcd_wg((flags & 4) != 0);
-  const IcpProblem& pr = tab[bt.idx[wg.y]];
-  const int k = kbase.v[wg.y] + 1 + j;
-  IcpState* st = pr.st;
-  if (k != 1 || k > pr.max_iter || k > st->stop_iter) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
+template <int BS>
+__device__ __forceinline__ void icp_first_phase(const IcpProblem& pr, int Mn, int Rn, int wgx, int nwg,
+                                                const GridDesc& g, int* cnt4) {
   const int nq = Mn + Rn;
-  const int nround = (nq + kBlock - 1) / kBlock;
-  const GridDesc g = pr.geom->g;
+  const int nround = (nq + BS - 1) / BS;
   const int lane = threadIdx.x & 63;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[1], Mn);
-  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballots below)
-    const int qid = r * kBlock + threadIdx.x;
+  for (int r = wgx; r < nround; r += nwg) {  // whole waves stay together (ballots below)
+    const int qid = r * BS + threadIdx.x;
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
     bool to_seeded = false;
@@ -792,13 +652,13 @@ icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
       const int off = dir ? Mn : 0;
       if (ms) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&st->ws_n[dir], __popcll(ms));
+        if (lane == 0) base = atomicAdd(&cnt4[2 + dir], __popcll(ms));
         base = __shfl(base, 0, 64);
         if (to_seeded && fwd == (dir == 0)) pr.wls[off + base + __popcll(ms & ((1ULL << lane) - 1ULL))] = qid;
       }
       if (mc) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&st->wl_n[dir], __popcll(mc));
+        if (lane == 0) base = atomicAdd(&cnt4[dir], __popcll(mc));
         base = __shfl(base, 0, 64);
         if (to_coop && fwd == (dir == 0)) pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
       }
@@ -806,156 +666,68 @@ icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   }
 }
 
-// The searches of one iteration for ALL entries of the batch, as a queue: a work item is one round of
-// one (entry, direction, kind) work list -- 8 cooperative or 32 seeded queries -- and the workgroups
-// take the items w = blockIdx.x, blockIdx.x + gridDim.x, ... of the concatenated lists (cooperative
-// lists first: they are the long ones). Every workgroup first forms the same table of rounds from the
-// list lengths on the device (4 words per entry). The form this replaces was a (rounds of the largest
-// list) x entries x 4 grid whose ~10 k workgroups mostly found nothing to do: dealing them out took
-// longer than the searches -- the workgroups with work started up to 26 us apart (58 at the 90th
-// percentile, 187 us at the 99th, the first iteration of a registration, whose seeded slices are all
-// empty), in a launch whose mean workgroup lasts 25 us (tools/wg_trace.py).
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
-  WGT_BEGIN();
-  static_assert(4 * kMaxBatch <= 2 * kBlock, "two lists per thread");
-  __shared__ int s_pref[4 * kMaxBatch + 1];
-  __shared__ int s_wsum[kBlock / 64];
-  __shared__ int skey[kMomSlotsSearch];
-  __shared__ unsigned long long sacc[kMomSlotsSearch * 17];
-  const int nlist = 4 * bt.n;  // list t: t < 2n cooperative, else seeded; entry (t mod 2n) / 2, direction t & 1
-  // thread x holds the rounds of lists 2x and 2x + 1 (nlist <= 2 * kBlock)
-  int my_rounds[2] = {0, 0};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int t = 2 * (int)threadIdx.x + h;
-    if (t < nlist) {
-      const bool coop_t = t < 2 * bt.n;
-      const int tt = coop_t ? t : t - 2 * bt.n;
-      const int e = tt >> 1, dir_t = tt & 1;
-      const IcpProblem& pe = tab[bt.idx[e]];
-      const int ke = kbase.v[e] + 1 + j;
-      const IcpState* se = pe.st;
-      if (!(ke > pe.max_iter || ke > se->stop_iter)) {
-        const int nw = coop_t ? se->wl_n[dir_t] : se->ws_n[dir_t];
-        const int per = coop_t ? kBlock / 32 : kBlock / 8;
-        my_rounds[h] = (nw + per - 1) / per;
+// ---- phase 2: one round of one work list -- BS / 32 cooperative or BS / 8 seeded queries of one
+// direction (0: forward queries against the reference grid, 1: backward against the moving grid), so
+// that everything is uniform in the workgroup: one grid, one instance of the search in the code (the
+// two-direction form spilled ~400 scalar registers). nw = length of the list.
+template <int BS>
+__device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* st, int k, int Mn, int Rn,
+                                                const GridDesc& g, bool coop, int dir, int r, int nw,
+                                                const MomTable& mt) {
+  const bool fwd = dir == 0;
+  int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
+  float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
+  const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
+  const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
+  const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
+  const int qoff = fwd ? 0 : Mn;
+  const int df = fwd ? pr.df : -pr.df;
+  const double lim2 = icp_limit_sq(Mn + Rn);
+  if (coop) {
+    const int sub = threadIdx.x & 31;
+    const int32_t* __restrict__ list = pr.wl + qoff;
+    const int wq = r * (BS / 32) + (threadIdx.x >> 5);
+    const bool valid = wq < nw;
+    const int qi = valid ? list[wq] - qoff : 0;  // index in the queries' cloud
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) p = qpts[qi];
+    float bud = 0.f;
+    const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud);
+    if (valid && sub == 0) {
+      nn_o[qi] = res;
+      bud_o[qi] = bud;
+      if (res >= 0) {  // (moving point, reference point, the moving point's component)
+        if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+        else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
+      }
+    }
+  } else {
+    const int32_t* __restrict__ seed = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
+                                           : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+    const int32_t* __restrict__ list = pr.wls + qoff;
+    const int wq = r * (BS / 8) + (threadIdx.x >> 3);
+    const bool valid = wq < nw;
+    const int qi = valid ? list[wq] - qoff : 0;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
+    int sd = -1;
+    if (valid) {
+      p = qpts[qi];
+      sd = seed[qi];
+      sp = hpts[sd];
+    }
+    int res = -1;
+    float bud = 0.f;
+    const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud);
+    if (valid && (threadIdx.x & 7) == 0) {
+      if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
+      nn_o[qi] = res;
+      bud_o[qi] = bud;
+      if (res >= 0) {
+        if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
+        else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
       }
     }
   }
-  {  // exclusive prefix of the rounds
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int mine = my_rounds[0] + my_rounds[1];
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int q = 0; q < wv; ++q) before += s_wsum[q];
-    const int ex = before + incl - mine;
-    const int t0 = 2 * (int)threadIdx.x;
-    if (t0 < nlist) s_pref[t0] = ex;
-    if (t0 + 1 < nlist) s_pref[t0 + 1] = ex + my_rounds[0];
-    if (t0 == nlist - 2) s_pref[nlist] = ex + mine;  // (nlist = 4 n is even)
-    __syncthreads();
-  }
-  const int R = s_pref[nlist];
-  int w_first = blockIdx.x, w_step = gridDim.x, w_end = R;
-  if ((flags & 4) && (gridDim.x & 7u) == 0) {
-    // (see xcd_wg) the workgroups that share an XCD take a contiguous eighth of the items: the lists are
-    // concatenated entry by entry, so an XCD's L2 sees the grids of an eighth of the entries
-    const int lab = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    w_first = (int)(((int64_t)R * lab) >> 3) + slot;
-    w_end = (int)(((int64_t)R * (lab + 1)) >> 3);
-    w_step = gridDim.x >> 3;
-  }
-  for (int w = w_first; w < w_end; w += w_step) {
-    int lo = 0, hi = nlist - 1;  // the list of item w: the last t with s_pref[t] <= w
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (s_pref[mid] <= w) lo = mid; else hi = mid - 1;
-    }
-    const int r = w - s_pref[lo];
-    const bool coop = lo < 2 * bt.n;
-    const int tt = coop ? lo : lo - 2 * bt.n;
-    const int e = tt >> 1, dir = tt & 1;  // 0: forward queries (moving -> reference grid), 1: backward
-    const IcpProblem& pr = tab[bt.idx[e]];
-    const int k = kbase.v[e] + 1 + j;
-    IcpState* st = pr.st;
-    const int nw = coop ? st->wl_n[dir] : st->ws_n[dir];
-    int Mn, Rn, Ra;
-    icp_sizes(pr, Mn, Rn, Ra);
-    GridDesc g = pr.geom->g;
-    const bool fwd = dir == 0;
-    // everything below is uniform in the workgroup: one direction, one grid, one instance of the search
-    int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
-    float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
-    const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
-    const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
-    const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
-    const int qoff = fwd ? 0 : Mn;
-    const int df = fwd ? pr.df : -pr.df;
-    const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C,
-                         kMomSlotsSearch};
-    const double lim2 = icp_limit_sq(Mn + Rn);
-    mom_init(mt);
-    __syncthreads();
-    if (coop) {
-      const int sub = threadIdx.x & 31;
-      const int32_t* __restrict__ list = pr.wl + qoff;
-      const int wq = r * (kBlock / 32) + (threadIdx.x >> 5);
-      const bool valid = wq < nw;
-      const int qi = valid ? list[wq] - qoff : 0;  // index in the queries' cloud
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid) p = qpts[qi];
-      float bud = 0.f;
-      const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud);
-      if (valid && sub == 0) {
-        nn_o[qi] = res;
-        bud_o[qi] = bud;
-        if (res >= 0) {  // (moving point, reference point, the moving point's component)
-          if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
-          else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
-        }
-      }
-    } else {
-      const int32_t* __restrict__ seed = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
-                                             : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
-      const int32_t* __restrict__ list = pr.wls + qoff;
-      const int wq = r * (kBlock / 8) + (threadIdx.x >> 3);
-      const bool valid = wq < nw;
-      const int qi = valid ? list[wq] - qoff : 0;
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sp = p;
-      int sd = -1;
-      if (valid) {
-        p = qpts[qi];
-        sd = seed[qi];
-        sp = hpts[sd];
-      }
-      int res = -1;
-      float bud = 0.f;
-      const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud);
-      if (valid && (threadIdx.x & 7) == 0) {
-        if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
-        nn_o[qi] = res;
-        bud_o[qi] = bud;
-        if (res >= 0) {
-          if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
-          else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
-        }
-      }
-    }
-    __syncthreads();
-    mom_flush(mt);
-    __syncthreads();  // (the table is initialised again for the next item)
-  }
-#ifdef PCS_WG_TRACE
-  if (w_first < w_end) WGT_END(2, 0, 0ULL, 0ULL);
-#endif
 }
 
 // centre of the matched points: fp32 segment mean, then promoted (registration_utils.py:150-151);
@@ -1006,7 +778,9 @@ icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
     if (!active) continue;
     int c = comp[m];
     float4 p = mov[m], q = ref[r];
-    const long long* a = acc + (int64_t)c * kAcc;
+    long long a[7];  // n, sum p, sum q
+#pragma unroll
+    for (int q = 0; q < 7; ++q) a[q] = acc[(int64_t)q * pr.C + c];
     const float4 og = pr.corg[c];
     const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
     double cm[3], cr[3], sp[3], sq[3];
@@ -1019,10 +793,10 @@ icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
     if (MODE == 0) {
       v = dist;
     } else {
-      double mean = ((double)a[17] * kFxInv) / (double)a[0];
+      double mean = ((double)acc[(int64_t)17 * pr.C + c] * kFxInv) / (double)a[0];
       v = fmin(fmax(dist, mean - trunc), mean + trunc);
     }
-    atomicAdd((unsigned long long*)&acc[(int64_t)c * kAcc + (MODE == 0 ? 17 : 18)],
+    atomicAdd((unsigned long long*)&acc[(int64_t)(MODE == 0 ? 17 : 18) * pr.C + c],
               (unsigned long long)to_fx(v));
   }
 }
@@ -1167,15 +941,6 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
       }
     }
   }
-#ifdef PCS_WG_TRACE
-  {
-    const unsigned long long need = __ballot(!have_R);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&g_g2cnt[11], 1ULL);
-      if (need) { atomicAdd(&g_g2cnt[10], 1ULL); atomicAdd(&g_g2cnt[9], (unsigned long long)__popcll(need)); }
-    }
-  }
-#endif
   if (!have_R) {
     double U[9], S[3], V[9];
     svd3(M, U, S, V);
@@ -1207,30 +972,13 @@ __device__ inline void icp_solve_component(const long long* __restrict__ a, cons
   *ls_out = ls;
 }
 
-// iteration k, third launch: one THREAD per component solves the regularised Kabsch step from the
-// completed moments: rotation and translation of the step (Rt, read by every point of the component
-// in the next launch), the updated transform (read buffer k-1, write buffer k), the loss term; the
-// other moment buffer is zeroed for the next iteration. (Until round 3 every moving POINT solved its
-// own component's step inside the apply launch -- one launch fewer, fine for a handful of units per
-// launch, but ~50 redundant 3x3 solves per component and 182 registers per lane once a launch carries
-// a hundred units.)
-constexpr int kSolveBlock = 64;  // one wave per workgroup: 24 KB of LDS, six workgroups per CU beside the other kernels
-template <bool STAGED>
-__global__ void __launch_bounds__(kSolveBlock)
-icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j) {
-  // The per-component records (20 moment words, 16 transform words in, 12 + 16 out) are read and written
-  // by one thread each: 64 cache lines per wave and load instruction. With 256-thread workgroups that
-  // made the launch as long as the budget test (38 us at 24 units); one-wave workgroups spread the same
-  // gathers over four times as many workgroups. STAGED (off by default, see icp_enqueue_chunk): the
-  // records pass through LDS -- those of a workgroup's 64 consecutive components are contiguous, so the
-  // copies are coalesced.
-  __shared__ long long s_acc[STAGED ? kSolveBlock * kAcc : 1];
-  __shared__ double s_T[STAGED ? kSolveBlock * 16 : 1];    // transform in, then transform out
-  __shared__ double s_rt[STAGED ? kSolveBlock * 12 : 1];
-  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
-  const int k = kbase.v[blockIdx.y] + 1 + j;
-  IcpState* st = pr.st;
-  if (k > pr.max_iter || k > st->stop_iter) return;  // (one wave per workgroup: uniform)
+// ---- phase 3: one THREAD per component solves the regularised Kabsch step from the completed moments:
+// rotation and translation of the step (Rt, read by every point of the component in the apply phase),
+// the updated transform (read buffer k-1, write buffer k), the loss term; the other moment buffer is
+// zeroed for the next iteration. The components' loss terms leave as one fixed-point integer add per
+// wave, spread over kLossParts words (`part` picks the word): order-free.
+template <int BS>
+__device__ __forceinline__ void icp_solve_phase(const IcpProblem& pr, IcpState* st, int k, int wgx, int nwg, int part) {
   const int64_t C = pr.C;
   const double reg = pr.reg;
   long long* __restrict__ acc_k = pr.acc + (size_t)(k & 1) * C * kAcc;
@@ -1239,130 +987,93 @@ icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
   double* __restrict__ T_out = pr.Tb + (size_t)(k & 1) * C * 16;
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   long long loss_ck = 0;  // the same at 10 fractional bits (overflow check of the sum, see icp_decide)
-  const int nround = (int)((C + kSolveBlock - 1) / kSolveBlock);
-  for (int r = blockIdx.x; r < nround; r += gridDim.x) {
-    const int64_t c0 = (int64_t)r * kSolveBlock;
-    const int nc = (int)(C - c0 < kSolveBlock ? C - c0 : kSolveBlock);
-    const int64_t c = c0 + threadIdx.x;
-    if (STAGED) {
-      for (int q = threadIdx.x; q < nc * kAcc; q += kSolveBlock) {
-        s_acc[q] = acc_k[c0 * kAcc + q];
-        acc_n[c0 * kAcc + q] = 0;  // the other moment buffer, for the next iteration (nothing reads it now)
-      }
-      for (int q = threadIdx.x; q < nc * 16; q += kSolveBlock) s_T[q] = T_in[c0 * 16 + q];
-      __syncthreads();
-    }
-    if ((int)threadIdx.x < nc) {
-      const long long* a = STAGED ? s_acc + threadIdx.x * kAcc : acc_k + c * kAcc;
-      const double* Tc = STAGED ? s_T + threadIdx.x * 16 : T_in + c * 16;
+  const int nround = (int)((C + BS - 1) / BS);
+  for (int r = wgx; r < nround; r += nwg) {
+    const int64_t c = (int64_t)r * BS + threadIdx.x;
+    if (c < C && pr.first[c] != INT_MAX) {  // components with a moving point (the others keep the identity the reset wrote)
+      // the records are component-minor: thread c reads word q of its component next to its neighbours'
+      long long a[17];
+      double Tc[16];
+#pragma unroll
+      for (int q = 0; q < 17; ++q) a[q] = acc_k[(int64_t)q * C + c];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Tc[q] = T_in[(int64_t)q * C + c];
       double R[9], t[3], Tn[16];
-      const bool has = pr.first[c] != INT_MAX;  // components with a moving point
-      if (has) {
-        const float4 og = pr.corg[c];
-        const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
-        double ls;
-        icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
-        if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of a term)
-        else {
-          loss_fx += to_fx(ls);
-          loss_ck += __double2ll_rn(ls * 1024.0);
-        }
-      } else {  // nothing moves: the transform stays what it is (the identity the reset wrote)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Tn[q] = Tc[q];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) R[q] = (q % 4 == 0) ? 1.0 : 0.0;
-        t[0] = t[1] = t[2] = 0.0;
+      const float4 og = pr.corg[c];
+      const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
+      double ls;
+      icp_solve_component(a, org, Tc, reg, R, t, Tn, &ls);
+      if (!(fabs(ls) < 6.0e7)) st->err = 1;  // (beyond the fixed-point range of a term)
+      else {
+        loss_fx += to_fx_wide(ls);
+        loss_ck += __double2ll_rn(ls * 1024.0);
       }
-      if (STAGED) {
+      double* rt = pr.Rt + c;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s_T[threadIdx.x * 16 + q] = Tn[q];  // (a thread's own record: read above)
+      for (int q = 0; q < 9; ++q) rt[(int64_t)q * C] = R[q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) s_rt[threadIdx.x * 12 + q] = R[q];
+      for (int q = 0; q < 3; ++q) rt[(int64_t)(9 + q) * C] = t[q];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) s_rt[threadIdx.x * 12 + 9 + q] = t[q];
-      } else if (has) {
-        double* rt = pr.Rt + c * 12;
+      for (int q = 0; q < 16; ++q) T_out[(int64_t)q * C + c] = Tn[q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) rt[q] = R[q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) rt[9 + q] = t[q];
-        for (int q = 0; q < 16; ++q) T_out[c * 16 + q] = Tn[q];
-        for (int q = 0; q < kAcc; ++q) acc_n[c * kAcc + q] = 0;
-      }
-    }
-    if (STAGED) {
-      __syncthreads();
-      for (int q = threadIdx.x; q < nc * 16; q += kSolveBlock) T_out[c0 * 16 + q] = s_T[q];
-      for (int q = threadIdx.x; q < nc * 12; q += kSolveBlock) pr.Rt[c0 * 12 + q] = s_rt[q];
-      __syncthreads();  // (the buffers are filled again by the next round)
+      for (int q = 0; q < kAcc; ++q) acc_n[(int64_t)q * C + c] = 0;
     }
   }
-  // the iteration's loss: one integer add per wave that owns a component, spread over kLossParts words
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     loss_fx += __shfl_xor(loss_fx, o, 64);
     loss_ck += __shfl_xor(loss_ck, o, 64);
   }
   if ((threadIdx.x & 63) == 0 && (loss_fx != 0 || loss_ck != 0)) {
-    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts + (blockIdx.x & (kLossParts - 1))],
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(k & 1) * kLossParts + (part & (kLossParts - 1))],
               (unsigned long long)loss_fx);
-    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(2 + (k & 1)) * kLossParts + (blockIdx.x & (kLossParts - 1))],
+    atomicAdd((unsigned long long*)&pr.lossfx[(size_t)(2 + (k & 1)) * kLossParts + (part & (kLossParts - 1))],
               (unsigned long long)loss_ck);
   }
 }
 
-// iteration k, last launch: every moving point moves by its component's step. The previous positions are
-// kept for the l1 passes. The moved points go straight into the grid of the next iteration (the moving
-// grid is double-buffered: no separate build launch), and the grid this iteration searched is reset.
-__global__ void __launch_bounds__(kBlock)
-icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int flags) {
-  WGT_BEGIN();
-  const WgXY wg = xcd_wg((flags & 4) != 0);
-  const IcpProblem& pr = tab[bt.idx[wg.y]];
-  const int k = kbase.v[wg.y] + 1 + j;
-  IcpState* st = pr.st;
-  if (k > pr.max_iter || k > st->stop_iter) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
+// ---- phase 4: every moving point moves by its component's step. The previous positions are kept for the
+// l1 passes. The moved points go straight into the grid of the next iteration (the moving grid is
+// double-buffered), and the grid this iteration searched is reset; the step table of iteration k takes
+// every point's step under the place it moved to.
+template <int BS>
+__device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* st, int k, int Mn, int wgx, int nwg,
+                                                const GridDesc& d) {
   float4* __restrict__ mov = pr.mov;
   float4* __restrict__ prev = pr.prev;
   const int32_t* __restrict__ comp = pr.comp;
   const double* __restrict__ Rt = pr.Rt;
+  const int64_t C = pr.C;
   const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
   const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
-  const int64_t tid = wg.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t tid = wgx * (int64_t)BS + threadIdx.x;
+  const int64_t nthreads = (int64_t)nwg * BS;
   // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
   // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
-  g2_clear(gm_done, tid, (int64_t)gridDim.x * blockDim.x);
+  g2_clear(gm_done, tid, nthreads);
   if (tid == 0) {
     st->iters = k;
     st->wl_n[0] = st->wl_n[1] = 0;  // the work lists of iteration k have been served
     st->ws_n[0] = st->ws_n[1] = 0;
     st->dmax[(k + 1) & 1] = 0u;   // takes the steps of iteration k+1
   }
-  {  // the step table of iteration k+1 (nothing reads it during this launch)
+  {  // the step table of iteration k+1 (nothing reads it during this phase)
     unsigned int* nxt = pr.sstep + (size_t)((k + 1) & 1) * kStepH;
-    for (int64_t q = tid; q < kStepH; q += (int64_t)gridDim.x * blockDim.x) nxt[q] = 0u;
+    for (int64_t q = tid; q < kStepH; q += nthreads) nxt[q] = 0u;
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
-  WGT_MARK(wg_m1);
   float step = 0.f;  // largest step of this thread's points
-  const GridDesc d = pr.geom->g;
-  const int nround = (Mn + kBlock - 1) / kBlock;
-#ifdef PCS_WG_TRACE
-  int wgt_rounds = 0, wgt_owner = 0;
-#endif
-  for (int r = wg.x; r < nround; r += gridDim.x) {  // whole workgroups stay together (shuffles)
-    const int i = r * kBlock + threadIdx.x;
+  const int nround = (Mn + BS - 1) / BS;
+  for (int r = wgx; r < nround; r += nwg) {  // whole workgroups stay together (shuffles)
+    const int i = r * BS + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef PCS_WG_TRACE
-    ++wgt_rounds;
-    if (i < Mn && pr.first[pr.comp[i]] == i) ++wgt_owner;
-#endif
     if (i < Mn) {
-      const double* __restrict__ R = Rt + (int64_t)comp[i] * 12;
-      const double* __restrict__ t = R + 9;
+      const double* __restrict__ rc = Rt + comp[i];  // (component-minor: word e of the step at rc[e * C])
+      double R[9], t[3];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) R[q] = rc[(int64_t)q * C];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) t[q] = rc[(int64_t)(9 + q) * C];
       float4 p = mov[i];
       prev[i] = p;
       double x = p.y, y = p.z, z = p.w;
@@ -1383,38 +1094,759 @@ icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, 
     }
     g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
   }
-  WGT_MARK(wg_m2);
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
-#ifdef PCS_WG_TRACE
-  {
-    __shared__ int s_own;
-    if (threadIdx.x == 0) s_own = 0;
-    __syncthreads();
-    atomicAdd(&s_own, wgt_owner);
-    __syncthreads();
-    const unsigned long long info = ((unsigned long long)wgt_rounds << 32) | (unsigned)s_own;
-    WGT_END(4, k, info, wg_m2);
-  }
-#endif
 }
 
-#ifdef PCS_WG_TRACE
-extern "C" int pcs_wg_trace_set(unsigned long long* buf) {
-  unsigned z = 0;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgt), &buf, sizeof(buf)) != hipSuccess) return -3;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgt_n), &z, sizeof(z)) != hipSuccess) return -3;
-  return 0;
+// ============================================================ wide launches (blockIdx.y = batch entry)
+// Entry e runs iteration kbase[e] + 1 + j, unless that is past wide_limit (the iterations from there on belong
+// to the unit-resident loop).
+// The gate is read ONCE per workgroup: workgroup 0 of the budget-test launch lowers stop_iter during that
+// very launch, and the waves of a workgroup do not start together -- with a per-thread gate some waves of
+// a workgroup could leave while the others go on with a moment table in LDS that is only partly
+// initialised (the memory fault of round 2: whatever another stream's kernel had left in LDS then served
+// as component ids in mom_flush).
+__global__ void __launch_bounds__(kBlock)
+icp_first_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  IcpState* st = pr.st;
+  if (kbase.v[blockIdx.y] != 0 || 1 > pr.max_iter || 1 > st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  if ((int64_t)blockIdx.x * kBlock >= (int64_t)Mn + Rn) return;
+  const GridDesc g = pr.geom->g;
+  icp_first_phase<kBlock>(pr, Mn, Rn, blockIdx.x, gridDim.x, g, &st->wl_n[0]);
 }
-extern "C" int pcs_g2_counters(unsigned long long* out16) {
-  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_g2cnt), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int wide_limit) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  IcpState* st = pr.st;
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  __shared__ int s_go;
+  if (threadIdx.x == 0) s_go = (k == 1 || k > wide_limit || k > pr.max_iter || k > st->stop_iter) ? 0 : 1;  // (iteration 1: icp_first_kernel)
+  __syncthreads();
+  if (!s_go) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const int nq = Mn + Rn;
+  const int nround = (nq + kBlock - 1) / kBlock;
+  if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  // workgroup 0 settles the stop rule of iteration k-1 (its loss terms were written by the previous
+  // launch). The other workgroups may run before the stop is known: they only write this iteration's
+  // neighbour buffers, which nothing reads after a stop.
+  if (blockIdx.x == 0) icp_decide(pr, k - 1);
+  __shared__ int skey[kMomSlots];
+  __shared__ unsigned long long sacc[kMomSlots * 17];
+  __shared__ unsigned int s_step[kStepH];
+  const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C, kMomSlots};
+  mom_init(mt);
+  {
+    // a workgroup that serves backward queries (its last round reaches past Mn) copies the 16 KB step table
+    // into LDS once -- coalesced, L2-resident: eight hashed slots per query were eight scattered requests
+    const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
+    const int r_last = blockIdx.x + ((nround - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
+    if ((r_last + 1) * kBlock > Mn)
+      for (int q = threadIdx.x; q < kStepH / 4; q += kBlock) ((uint4*)s_step)[q] = ((const uint4*)sstep)[q];
+  }
+  __syncthreads();
+  const GridDesc g = pr.geom->g;
+  icp_budget_phase<kBlock>(pr, k, Mn, Rn, blockIdx.x, gridDim.x, g, mt, s_step, &st->wl_n[0]);
+  __syncthreads();
+  mom_flush(mt);
 }
-extern "C" unsigned pcs_wg_trace_count() {
-  unsigned n = 0;
-  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof(n));
-  return n;
+
+// The searches of one iteration for ALL entries of the batch, as a queue: a work item is one round of
+// one (entry, direction, kind) work list -- 8 cooperative or 32 seeded queries -- and the workgroups
+// take the items w = blockIdx.x, blockIdx.x + gridDim.x, ... of the concatenated lists (cooperative
+// lists first: they are the long ones). Every workgroup first forms the same table of rounds from the
+// list lengths on the device (4 words per entry).
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+icp_nn_search_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int wide_limit) {
+  static_assert(4 * kMaxBatch <= 2 * kBlock, "two lists per thread");
+  __shared__ int s_pref[4 * kMaxBatch + 1];
+  __shared__ int s_wsum[kBlock / 64];
+  __shared__ int skey[kMomSlotsSearch];
+  __shared__ unsigned long long sacc[kMomSlotsSearch * 17];
+  const int nlist = 4 * bt.n;  // list t: t < 2n cooperative, else seeded; entry (t mod 2n) / 2, direction t & 1
+  // thread x holds the rounds of lists 2x and 2x + 1 (nlist <= 2 * kBlock)
+  int my_rounds[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int t = 2 * (int)threadIdx.x + h;
+    if (t < nlist) {
+      const bool coop_t = t < 2 * bt.n;
+      const int tt = coop_t ? t : t - 2 * bt.n;
+      const int e = tt >> 1, dir_t = tt & 1;
+      const IcpProblem& pe = tab[bt.idx[e]];
+      const IcpState* se = pe.st;
+      const int ke = kbase.v[e] + 1 + j;
+      if (!(ke > wide_limit || ke > pe.max_iter || ke > se->stop_iter)) {
+        const int nw = coop_t ? se->wl_n[dir_t] : se->ws_n[dir_t];
+        const int per = coop_t ? kBlock / 32 : kBlock / 8;
+        my_rounds[h] = (nw + per - 1) / per;
+      }
+    }
+  }
+  {  // exclusive prefix of the rounds
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mine = my_rounds[0] + my_rounds[1];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += s_wsum[q];
+    const int ex = before + incl - mine;
+    const int t0 = 2 * (int)threadIdx.x;
+    if (t0 < nlist) s_pref[t0] = ex;
+    if (t0 + 1 < nlist) s_pref[t0 + 1] = ex + my_rounds[0];
+    if (t0 == nlist - 2) s_pref[nlist] = ex + mine;  // (nlist = 4 n is even)
+    __syncthreads();
+  }
+  const int R = s_pref[nlist];
+  for (int w = blockIdx.x; w < R; w += gridDim.x) {
+    int lo = 0, hi = nlist - 1;  // the list of item w: the last t with s_pref[t] <= w
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_pref[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const int r = w - s_pref[lo];
+    const bool coop = lo < 2 * bt.n;
+    const int tt = coop ? lo : lo - 2 * bt.n;
+    const int e = tt >> 1, dir = tt & 1;
+    const IcpProblem& pr = tab[bt.idx[e]];
+    IcpState* st = pr.st;
+    const int k = kbase.v[e] + 1 + j;
+    const int nw = coop ? st->wl_n[dir] : st->ws_n[dir];
+    int Mn, Rn, Ra;
+    icp_sizes(pr, Mn, Rn, Ra);
+    const GridDesc g = pr.geom->g;
+    const MomTable mt = {skey, sacc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C,
+                         kMomSlotsSearch};
+    mom_init(mt);
+    __syncthreads();
+    icp_search_item<kBlock>(pr, st, k, Mn, Rn, g, coop, dir, r, nw, mt);
+    __syncthreads();
+    mom_flush(mt);
+    __syncthreads();  // (the table is initialised again for the next item)
+  }
 }
-#endif
+
+// The per-component records (20 moment words, 16 transform words in, 12 + 16 out) are read and written by
+// one thread each: 64 cache lines per wave and load instruction. One-wave workgroups spread those gathers
+// over four times as many workgroups as 256-thread ones (which made the launch as long as the budget test).
+constexpr int kSolveBlock = 64;
+__global__ void __launch_bounds__(kSolveBlock)
+icp_solve_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int wide_limit) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  IcpState* st = pr.st;
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  if (k > wide_limit || k > pr.max_iter || k > st->stop_iter) return;  // (one wave per workgroup: uniform)
+  icp_solve_phase<kSolveBlock>(pr, st, k, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(kBlock)
+icp_apply_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int j, int wide_limit) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  IcpState* st = pr.st;
+  const int k = kbase.v[blockIdx.y] + 1 + j;
+  if (k > wide_limit || k > pr.max_iter || k > st->stop_iter) return;
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
+  const GridDesc d = pr.geom->g;
+  icp_apply_phase<kBlock>(pr, st, k, Mn, blockIdx.x, gridDim.x, d);
+}
+
+// ============================================================ the unit-resident loop
+// ONE workgroup of 1024 threads per batch entry runs that entry's iterations st->iters + 1, + 2, ... back to
+// back: budget test, searches, solve, stop rule, apply -- separated by workgroup barriers only. It leaves
+// when the stop rule has fired, at max_iter, after n_it iterations, or when budget_ticks (100 MHz ticks of
+// s_memrealtime; 0: no limit) have passed since it started; the entry's state is mirrored to out[entry]
+// (may be pinned host memory). Everything the iterations of one entry exchange -- neighbour buffers, work
+// lists, moments, transforms, the moving grid -- is written and read by this one workgroup, i.e. through
+// one CU's L1 and one XCD's L2: no cross-CU visibility is needed between phases, a workgroup barrier
+// (which waits for the wave's outstanding memory operations) orders them.
+// The phases are separate (not inlined) functions: each gets the 128 registers of a 1024-thread workgroup
+// for itself -- inlined into one body the compiler kept values of every phase alive across all of them
+// (256 registers at 512 threads, and spills into scratch memory on top). Their LDS lives at namespace scope.
+constexpr int kLoopBlock = 1024;
+__shared__ int l_cnt[4];  // work-list lengths of the iteration: cooperative fwd / bwd, seeded fwd / bwd
+__shared__ int l_key[kMomSlotsLoop];
+__shared__ unsigned long long l_acc[kMomSlotsLoop * 17];
+__shared__ unsigned int l_step[kStepH];
+
+__device__ __forceinline__ MomTable loop_mom_table(const IcpProblem& pr, int k) {
+  return MomTable{l_key, l_acc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C, kMomSlotsLoop};
+}
+// start of an iteration: empty moment table, the step table of iteration k-1 in LDS
+__device__ __noinline__ void loop_begin_phase(const IcpProblem* __restrict__ prp, int k) {
+  const IcpProblem& pr = *prp;
+  mom_init(loop_mom_table(pr, k));
+  if (k > 1) {
+    const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
+    for (int q = threadIdx.x; q < kStepH / 4; q += kLoopBlock) ((uint4*)l_step)[q] = ((const uint4*)sstep)[q];
+  }
+}
+__device__ __noinline__ void loop_budget_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
+  const IcpProblem& pr = *prp;
+  const GridDesc g = pr.geom->g;
+  // (iteration 1: every query is dealt to one of the searches)
+  if (k == 1) icp_first_phase<kLoopBlock>(pr, Mn, Rn, 0, 1, g, l_cnt);
+  else icp_budget_phase<kLoopBlock>(pr, k, Mn, Rn, 0, 1, g, loop_mom_table(pr, k), l_step, l_cnt);
+}
+// the rounds of the four lists; the waves run free (no barrier between rounds)
+__device__ __noinline__ void loop_search_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
+  const IcpProblem& pr = *prp;
+  const GridDesc g = pr.geom->g;
+  const MomTable mt = loop_mom_table(pr, k);
+#pragma unroll 1
+  for (int li = 0; li < 4; ++li) {
+    const bool coop = li < 2;
+    const int dir = li & 1;
+    const int nw = l_cnt[li];
+    const int per = coop ? kLoopBlock / 32 : kLoopBlock / 8;
+    const int rounds = (nw + per - 1) / per;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) icp_search_item<kLoopBlock>(pr, pr.st, k, Mn, Rn, g, coop, dir, r, nw, mt);
+  }
+}
+__device__ __noinline__ void loop_flush_phase(const IcpProblem* __restrict__ prp, int k) {
+  mom_flush(loop_mom_table(*prp, k));
+}
+__device__ __noinline__ void loop_solve_phase(const IcpProblem* __restrict__ prp, int k) {
+  icp_solve_phase<kLoopBlock>(*prp, prp->st, k, 0, 1, threadIdx.x >> 6);
+}
+__device__ __noinline__ void loop_apply_phase(const IcpProblem* __restrict__ prp, int k, int Mn) {
+  const IcpProblem& pr = *prp;
+  const GridDesc g = pr.geom->g;
+  icp_apply_phase<kLoopBlock>(pr, pr.st, k, Mn, 0, 1, g);
+}
+
+__global__ void __launch_bounds__(kLoopBlock)
+icp_loop_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, int wide_limit, unsigned int budget_ticks,
+                IcpState* __restrict__ out) {
+  const IcpProblem* prp = tab + bt.idx[blockIdx.x];
+  IcpState* st = prp->st;
+  __shared__ int s_go;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  int Mn, Rn, Ra;
+  icp_sizes(*prp, Mn, Rn, Ra);
+  int k = st->iters + 1;  // (uniform: the last launch's apply phase wrote it)
+  const int k_end = k + n_it;
+  // the stop rule of the last iteration a wide launch ran (nothing to do when this loop ran it)
+  icp_decide(*prp, k - 1);
+  unsigned long long ticks[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+  int done = 0;
+  for (; k < k_end; ++k) {
+    __syncthreads();  // (the decision above / below, the previous iteration's apply phase)
+    unsigned long long t0 = 0ULL;
+    if (threadIdx.x == 0) {
+      t0 = __builtin_amdgcn_s_memrealtime();
+      bool go = !(k <= wide_limit || k > prp->max_iter || k > st->stop_iter);  // (k <= wide_limit: a wide launch's)
+      if (st->mode == 1) go = false;  // a registration of the tile path: icp_tile_kernel's
+      if (go && budget_ticks && done > 0 && t0 - t_begin > (unsigned long long)budget_ticks) go = false;
+      s_go = go ? 1 : 0;
+      l_cnt[0] = l_cnt[1] = l_cnt[2] = l_cnt[3] = 0;
+    }
+    loop_begin_phase(prp, k);
+    __syncthreads();
+    if (!s_go) break;
+    loop_budget_phase(prp, k, Mn, Rn);
+    __syncthreads();
+    unsigned long long t1 = 0ULL;
+    if (threadIdx.x == 0) { t1 = __builtin_amdgcn_s_memrealtime(); ticks[0] += t1 - t0; }
+    loop_search_phase(prp, k, Mn, Rn);
+    __syncthreads();
+    loop_flush_phase(prp, k);
+    __syncthreads();
+    unsigned long long t2 = 0ULL;
+    if (threadIdx.x == 0) { t2 = __builtin_amdgcn_s_memrealtime(); ticks[1] += t2 - t1; }
+    // solve, then the stop rule of this iteration (it still admits the apply phase of iteration k)
+    loop_solve_phase(prp, k);
+    __syncthreads();
+    icp_decide(*prp, k);
+    unsigned long long t3 = 0ULL;
+    if (threadIdx.x == 0) { t3 = __builtin_amdgcn_s_memrealtime(); ticks[2] += t3 - t2; }
+    loop_apply_phase(prp, k, Mn);
+    if (threadIdx.x == 0) ticks[3] += __builtin_amdgcn_s_memrealtime() - t3;
+    ++done;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->loop_iters += done;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st->phase_ticks[q] += ticks[q];
+    if (out) out[blockIdx.x] = *st;
+  }
+}
+
+// ============================================================ the tile path of the unit-resident loop
+// The searches above walk hash grids in global memory: every probe and every row of candidates is a
+// scattered 16-byte request through the CU's L1 (~250 per searched query) and a chain of dependent
+// loads -- one CU spent ~900 us per iteration of a 24 k-query unit in them. The tile path keeps the
+// candidates in LDS instead:
+//   * both clouds are kept SORTED BY BLOCK ROW (a block = 4 x 4 fine cells in x / y, all z; a row = the
+//     blocks of one y range): the static reference cloud once per registration, the moving cloud after
+//     every apply (a counting sort with the row counters in LDS). h = (spatial radius + margin) / 4, so a
+//     query's search ball lies inside its own row and the two next to it;
+//   * a BAND = as many consecutive rows as fit: their points and the rows on either side -- one contiguous,
+//     coalesced range of the sorted cloud, at most kTileCap points -- are copied into LDS and threaded into
+//     direct-mapped cell buckets (bucket = hash of the fine cell -> chain of staged points; cells that
+//     share a bucket share a chain: a query then looks at a few points more, never at fewer) and
+//     direct-mapped 64-bit occupancy masks of the 4 x 4 x 4-cell blocks (OR of whatever shares the slot);
+//   * the queries of the band's rows -- a contiguous range of the OTHER cloud's sorted copy -- then search
+//     with ONE LANE each, in LDS only: the 27 cells around the query; if the best point so far (or the
+//     radius) still admits something further out, the occupied cells of the 27 blocks around it, each
+//     pruned by its distance bound. No hash keys, no probing loops, no global memory in the search.
+// The search is exact (conservative pruning; the canonical order (dist2, original index) decides), so it
+// returns what the cooperative search returns, bit for bit -- and it is cheap enough that every query
+// searches in every iteration: the tile path has no verified cache, no work lists, no step table and no
+// global grid of the moving points. Forward queries (moving -> reference) and backward queries take their
+// turns on the same LDS. Preconditions (one frame value per cloud, at most kTileRows rows, no three rows
+// with more than kTileCap points) are checked by the first launch; registrations that fail them take
+// the cache path (icp_loop_kernel), decided on the device, no host round trip.
+constexpr int kTileCap = 4096;      // candidates staged at once
+constexpr int kTileBuckets = 8192;  // cell buckets (>= 2 per staged point)
+constexpr int kTileBlocks = 2048;   // block occupancy masks
+constexpr int kTileMomSlots = 64;
+__shared__ float4 t_pts[kTileCap];              // staged candidates: (original index bits, x, y, z)
+__shared__ unsigned int t_head[kTileBuckets];   // bucket -> last staged point + 1 (0: none); scratch of the binning
+__shared__ unsigned short t_next[kTileCap];     // chain: next staged point + 1
+__shared__ unsigned long long t_bmask[kTileBlocks];
+__shared__ int t_rowr[kTileRows + 1];           // first sorted reference point of every block row
+__shared__ int t_rowm[kTileRows + 1];           // the same for the moving points of this iteration
+__shared__ int t_key[kTileMomSlots];
+__shared__ unsigned long long t_acc[kTileMomSlots * 17];
+__shared__ int t_wsum[kLoopBlock / 64 + 1];
+__shared__ int t_flag[4];
+__shared__ unsigned long long t_dbg[4];
+
+struct TileGeom {
+  float lo0, lo1, lo2, inv_h, h;
+  float radius2, margin;
+  int nrows;
+};
+__device__ __forceinline__ TileGeom tile_geom(const IcpProblem& pr) {
+  const GridDesc g = pr.geom->g;
+  TileGeom t;
+  t.lo0 = g.lo[0]; t.lo1 = g.lo[1]; t.lo2 = g.lo[2];
+  t.h = g.h;
+  t.inv_h = 1.f / g.h;
+  t.radius2 = g.radius2;
+  t.margin = 1e-5f * g.radius2 + 1e-6f;
+  // block rows: the y extent of both clouds as they arrive, plus the pad the grid origin was given
+  const float ymax = fmaxf(pr.bounds[6], pr.bounds[14]);
+  const float cyf = floorf((ymax + pr.pad - g.lo[1]) * t.inv_h);
+  t.nrows = cyf < 4.f * (float)kTileRows ? (((int)cyf) >> 2) + 2 : kTileRows + 1;
+  return t;
+}
+__device__ __forceinline__ MomTable tile_mom_table(const IcpProblem& pr, int k) {
+  return MomTable{t_key, t_acc, (unsigned long long*)pr.acc + (size_t)(k & 1) * pr.C * kAcc, (int)pr.C, kTileMomSlots};
+}
+// cells by multiplication with 1 / h (every cell of the tile path comes from here, so the buckets are
+// consistent; the pruning bounds below carry the slack for its rounding)
+__device__ __forceinline__ int tile_cell(float v, float lo, float inv_h) { return (int)floorf((v - lo) * inv_h); }
+constexpr unsigned kTP1 = 73856093u, kTP2 = 19349663u, kTP3 = 83492791u;
+__device__ __forceinline__ unsigned tile_mix(unsigned h) { return h ^ (h >> 15); }
+
+// counting sort of a cloud by block row: dst = (index bits, x, y, z) row by row, rows[r] = first point of
+// row r (rows[r] = n from the last occupied row on, for every r <= kTileRows). Points of a row arrive in
+// arbitrary order: nothing downstream depends on it.
+__device__ __forceinline__ void tile_bin(const float4* __restrict__ src, int n, float4* __restrict__ dst, int* rows,
+                                         const TileGeom& t, int* __restrict__ err) {
+  int* hist = (int*)t_head;
+  int* cur = hist + kTileRows;
+  for (int q = threadIdx.x; q < 2 * kTileRows; q += kLoopBlock) hist[q] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += kLoopBlock) {
+    const float4 p = src[i];
+    const int cy = tile_cell(p.z, t.lo1, t.inv_h), cx = tile_cell(p.y, t.lo0, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
+    int r = cy >> 2;
+    if (cx < 0 || cy < 0 || cz < 0 || r >= t.nrows || cx >= kCoordMax || cz >= kCoordMax) { *err = 1; r = 0; }
+    atomicAdd(&hist[r], 1);
+  }
+  __syncthreads();
+  {  // exclusive prefix of the kTileRows = kLoopBlock counters, one per thread
+    static_assert(kTileRows == kLoopBlock, "one row counter per thread");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mine = hist[threadIdx.x];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) t_wsum[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wv; ++q) before += t_wsum[q];
+    const int ex = before + incl - mine;
+    rows[threadIdx.x] = ex;
+    cur[threadIdx.x] = ex;
+    if (threadIdx.x == 0) rows[kTileRows] = n;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += kLoopBlock) {
+    const float4 p = src[i];
+    const int cy = tile_cell(p.z, t.lo1, t.inv_h), cx = tile_cell(p.y, t.lo0, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
+    int r = cy >> 2;
+    if (cx < 0 || cy < 0 || cz < 0 || r >= t.nrows || cx >= kCoordMax || cz >= kCoordMax) r = 0;
+    const int pos = atomicAdd(&cur[r], 1);
+    if (pos < 0 || pos >= n) { atomicExch(err, 103); continue; }
+    dst[pos] = make_float4(__int_as_float(i), p.y, p.z, p.w);
+  }
+  __syncthreads();
+}
+
+// largest number of points in three consecutive rows (what a band of one row stages)
+__device__ __forceinline__ int tile_max_triple(const int* rows, int nrows) {
+  int v = 0;
+  for (int r = threadIdx.x; r < nrows; r += kLoopBlock) {
+    const int a = rows[r > 0 ? r - 1 : 0], b = rows[r + 2 < nrows ? r + 2 : nrows];
+    v = max(v, b - a);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;  // (per wave; the caller combines)
+}
+
+// a band's candidates: rows of the sorted cloud [s0, s0 + ns) into LDS, cell buckets and block masks
+__device__ __forceinline__ void tile_stage(const float4* __restrict__ srt, int s0, int ns, const TileGeom& t) {
+  for (int q = threadIdx.x; q < kTileBuckets; q += kLoopBlock) t_head[q] = 0u;
+  for (int q = threadIdx.x; q < kTileBlocks; q += kLoopBlock) t_bmask[q] = 0ULL;
+  __syncthreads();
+  for (int j = threadIdx.x; j < ns; j += kLoopBlock) {
+    const float4 p = srt[s0 + j];
+    t_pts[j] = p;
+    const int cx = tile_cell(p.y, t.lo0, t.inv_h), cy = tile_cell(p.z, t.lo1, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
+    const unsigned b = tile_mix((unsigned)cx * kTP1 ^ (unsigned)cy * kTP2 ^ (unsigned)cz * kTP3) & (kTileBuckets - 1);
+    const unsigned old = atomicExch(&t_head[b], (unsigned)(j + 1));
+    t_next[j] = (unsigned short)old;
+    const unsigned bs = tile_mix((unsigned)(cx >> 2) * kTP2 ^ (unsigned)(cy >> 2) * kTP3 ^ (unsigned)(cz >> 2) * kTP1) &
+                        (kTileBlocks - 1);
+    const int bit = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
+    atomicOr(&t_bmask[bs], 1ULL << bit);
+  }
+  __syncthreads();
+}
+
+// The nearest staged point of (px, py, pz) within the radius under the canonical order (dist2, original
+// index); dist2 is formed exactly as the cooperative search forms it: ((c0 + dx^2) + dy^2) + dz^2 with
+// c0 = (frame difference)^2, the same for every pair of the direction. One lane per query, LDS only.
+struct TileHit {
+  float d2;
+  int idx;  // original index of the point, -1: none within the radius
+  int j;    // where it is staged
+};
+__device__ __forceinline__ TileHit tile_nearest(const TileGeom& t, float px, float py, float pz, float c0, int rings) {
+  const int cx = tile_cell(px, t.lo0, t.inv_h), cy = tile_cell(py, t.lo1, t.inv_h), cz = tile_cell(pz, t.lo2, t.inv_h);
+  float bd = 0.f;
+  int bi = -1, bj = -1;
+  int ncand = 0;
+  auto scan_bucket = [&](unsigned hsh) {
+    unsigned j = t_head[tile_mix(hsh) & (kTileBuckets - 1)];
+    while (j) {
+      const float4 c = t_pts[j - 1];
+      const float d1 = c.y - px, d2 = c.z - py, d3 = c.w - pz;
+      float dist2 = c0;
+      dist2 = dist2 + d1 * d1;
+      dist2 = dist2 + d2 * d2;
+      dist2 = dist2 + d3 * d3;
+      const int oi = __float_as_int(c.x);
+      ++ncand;
+      if (dist2 <= t.radius2 && (bi < 0 || dist2 < bd || (dist2 == bd && oi < bi))) {
+        bd = dist2;
+        bi = oi;
+        bj = (int)j - 1;
+      }
+      j = t_next[j - 1];
+    }
+  };
+  // ---- the 27 cells around the query
+  {
+    const unsigned hx0 = (unsigned)(cx - 1) * kTP1, hy0 = (unsigned)(cy - 1) * kTP2, hz0 = (unsigned)(cz - 1) * kTP3;
+#pragma unroll 1
+    for (int dz = 0; dz < 3; ++dz) {
+      const unsigned hz = hz0 + (unsigned)dz * kTP3;
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned hyz = hz ^ (hy0 + (unsigned)dy * kTP2);
+        scan_bucket(hyz ^ hx0);
+        scan_bucket(hyz ^ (hx0 + kTP1));
+        scan_bucket(hyz ^ (hx0 + 2u * kTP1));
+      }
+    }
+  }
+  // ---- further out: everything at Chebyshev distance >= 2 cells is at least h away. The slack (0.2 %) covers
+  //      the rounding of the cell coordinates (a point may sit a few 1e-5 cells outside its nominal cell)
+  const float h2s = t.h * t.h * 0.998f;
+  float bound = (bi >= 0 ? bd - c0 : t.radius2 - c0) + t.margin;  // admissible |dxyz|^2 of a point that matters
+  if (rings >= 2 && !(h2s > bound)) {
+    atomicAdd(&t_dbg[1], 1ULL);
+    const int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+#pragma unroll 1
+    for (int q = 0; q < 27; ++q) {
+      const int X = bx + q % 3 - 1, Y = by + (q / 3) % 3 - 1, Z = bz + q / 9 - 1;
+      unsigned long long m =
+          t_bmask[tile_mix((unsigned)X * kTP2 ^ (unsigned)Y * kTP3 ^ (unsigned)Z * kTP1) & (kTileBlocks - 1)];
+      while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ULL;
+        const int x = 4 * X + (bit & 3), y = 4 * Y + ((bit >> 2) & 3), z = 4 * Z + (bit >> 4);
+        const int ax = abs(x - cx), ay = abs(y - cy), az = abs(z - cz);
+        if (max(max(ax, ay), az) <= 1) continue;  // (looked at above)
+        const float fx = (float)max(ax - 1, 0), fy = (float)max(ay - 1, 0), fz = (float)max(az - 1, 0);
+        const float lb2 = ((fx * fx + fy * fy) + fz * fz) * h2s;
+        if (lb2 > bound) continue;
+        scan_bucket((unsigned)x * kTP1 ^ (unsigned)y * kTP2 ^ (unsigned)z * kTP3);
+        bound = (bi >= 0 ? bd - c0 : t.radius2 - c0) + t.margin;
+      }
+    }
+  }
+  atomicAdd(&t_dbg[0], 1ULL);
+  if (bi < 0) atomicAdd(&t_dbg[2], 1ULL);
+  atomicAdd(&t_dbg[3], (unsigned long long)ncand);
+  TileHit hit;
+  hit.d2 = bd;
+  hit.idx = bi;
+  hit.j = bj;
+  return hit;
+}
+
+// per direction: do the frames of the two clouds meet at all (the reference's frame-cell walk:
+// round((f - lo0) / vs0) + 1 of the query, plus the frame offset, must be the candidates' frame cell), the
+// constant frame term of every distance, the number of cell rings the radius reaches
+struct TileDir {
+  bool ok;
+  float c0;
+  int rings;
+};
+__device__ __forceinline__ TileDir tile_dir(const IcpProblem& pr, const TileGeom& t, float f_query, float f_cand, int df) {
+  const GridDesc g = pr.geom->g;
+  TileDir d;
+  const int fq = frame_cell(g, f_query) + df, fc = frame_cell(g, f_cand);
+  const float dfl = fabsf(f_cand - f_query);
+  d.c0 = dfl * dfl;
+  const float budget = (t.radius2 - d.c0) + t.margin;
+  d.ok = fq == fc && fc >= 0 && fc < kFrameCells && budget >= 0.f;
+  d.rings = d.ok ? (int)ceilf(sqrtf(budget) / t.h) : 0;
+  if (d.rings > 4) {  // (cannot happen with the cell size icp_describe chooses)
+    if (threadIdx.x == 0) atomicExch(&pr.st->err, 1);
+    d.rings = 4;
+  }
+  return d;
+}
+
+// One direction of an iteration: FWD: candidates = reference rows, queries = moving points; else the roles
+// are swapped. Bands are formed greedily over the candidates' rows; every thread forms the same bands from
+// the row tables in LDS.
+template <bool FWD>
+__device__ __forceinline__ void tile_pass(const IcpProblem& pr, int k, int Mn, int Rn, const TileGeom& t) {
+  const float4* __restrict__ csrt = FWD ? pr.rsrt : pr.msrt;   // candidates
+  const float4* __restrict__ qsrt = FWD ? pr.msrt : pr.rsrt;   // queries
+  const int* crow = FWD ? t_rowr : t_rowm;
+  const int* qrow = FWD ? t_rowm : t_rowr;
+  int32_t* __restrict__ nn_o = FWD ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
+  const float f_ref = pr.bounds[0], f_mov = pr.bounds[8];  // (one frame value per cloud: checked before)
+  const TileDir dir = FWD ? tile_dir(pr, t, f_mov, f_ref, pr.df) : tile_dir(pr, t, f_ref, f_mov, -pr.df);
+  if (!dir.ok) return;  // (uniform) nothing in range: every neighbour stays -1
+  const MomTable mt = tile_mom_table(pr, k);
+  const double lim2 = icp_limit_sq(Mn + Rn);
+  const int nrows = t.nrows;
+  int r0 = 0;
+  while (r0 < nrows) {
+    const int s0 = crow[r0 > 0 ? r0 - 1 : 0];
+    int r1 = r0 + 1;
+    while (r1 < nrows && crow[r1 + 2 < nrows ? r1 + 2 : nrows] - s0 <= kTileCap) ++r1;
+    const int s1 = crow[r1 + 1 < nrows ? r1 + 1 : nrows];
+    const int ns = s1 - s0;
+    const int q0 = qrow[r0], q1 = qrow[r1];
+    if (ns > kTileCap) {  // three rows that do not fit (the moving cloud has contracted since the check)
+      if (threadIdx.x == 0) atomicExch(&pr.st->err, 1);
+    } else if (ns > 0 && q1 > q0) {
+      if (s0 < 0 || s1 > (FWD ? Rn : Mn)) { if (threadIdx.x == 0) atomicExch(&pr.st->err, 104); break; }
+      tile_stage(csrt, s0, ns, t);
+      for (int base = q0; base < q1; base += kLoopBlock) {  // whole waves stay together (mom_add_wave)
+        const int i = base + (int)threadIdx.x;
+        const bool valid = i < q1;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) p = qsrt[i];
+        TileHit hit;
+        hit.idx = -1;
+        hit.j = 0;
+        if (valid) hit = tile_nearest(t, p.y, p.z, p.w, dir.c0, dir.rings);
+        const int qi = __float_as_int(p.x);
+        const int nq_ = FWD ? Mn : Rn, nc_ = FWD ? Rn : Mn;
+        if (valid && (qi < 0 || qi >= nq_)) { atomicExch(&pr.st->err, 102); hit.idx = -1; }
+        else if (valid && (hit.idx < -1 || hit.idx >= nc_ || (hit.idx >= 0 && (hit.j < 0 || hit.j >= ns)))) { atomicExch(&pr.st->err, 101); hit.idx = -1; hit.j = 0; }
+        else if (valid) nn_o[qi] = hit.idx;
+        const bool m_act = valid && hit.idx >= 0;
+        const float4 cpt = m_act ? t_pts[hit.j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // the pair as (moving point, reference point, the moving point's component)
+        const int m_idx = FWD ? qi : hit.idx;
+        int m_c = m_act ? pr.comp[m_idx] : 0;
+        if (m_c < 0 || m_c >= (int)pr.C) { atomicExch(&pr.st->err, 105); m_c = 0; }
+        mom_add_wave(pr, mt, m_act, FWD ? p : cpt, FWD ? cpt : p, m_c, lim2);
+      }
+      __syncthreads();  // (the LDS is staged again)
+    }
+    r0 = r1;
+  }
+}
+
+// ---- the phases of a tile iteration (separate functions: each gets the registers of a 1024-thread workgroup)
+// first launch of a registration: the reference cloud by rows, the path's preconditions, the mode word
+__device__ __noinline__ void tile_prepare_phase(const IcpProblem* __restrict__ prp, int Mn, int Rn) {
+  const IcpProblem& pr = *prp;
+  IcpState* st = pr.st;
+  const TileGeom t = tile_geom(pr);
+  bool ok = Mn >= 1 && Rn >= 1 && t.nrows <= kTileRows && pr.bounds[0] == pr.bounds[4] && pr.bounds[8] == pr.bounds[12];
+  if (threadIdx.x == 0) { t_flag[0] = 0; t_flag[1] = 0; }
+  __syncthreads();
+  if (ok) {
+    int err_r = 0;
+    tile_bin(pr.ref, Rn, pr.rsrt, t_rowr, t, &t_flag[1]);
+    const int mr = tile_max_triple(t_rowr, t.nrows);
+    if ((threadIdx.x & 63) == 0) atomicMax(&t_flag[0], mr);
+    tile_bin((const float4*)pr.mov, Mn, pr.msrt, t_rowm, t, &t_flag[1]);
+    const int mm = tile_max_triple(t_rowm, t.nrows);
+    if ((threadIdx.x & 63) == 0) atomicMax(&t_flag[0], mm + mm / 3);  // (the moving cloud may contract a little)
+    (void)err_r;
+    __syncthreads();
+    ok = t_flag[0] <= kTileCap && t_flag[1] == 0;
+  }
+  if (ok) {
+    for (int r = threadIdx.x; r <= kTileRows; r += kLoopBlock) pr.trow[r] = t_rowr[r];
+  }
+  if (threadIdx.x == 0) {
+    st->mode = ok ? 1 : 2;
+    t_flag[2] = ok ? 1 : 2;  // (the workgroup reads the decision here, behind the barrier)
+  }
+  __syncthreads();
+}
+// start of an iteration: the row table of the reference cloud (a later launch of the registration), the
+// moving cloud by rows, every neighbour of the iteration <- none, an empty moment table
+__device__ __noinline__ void tile_begin_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn, int load_rows) {
+  const IcpProblem& pr = *prp;
+  const TileGeom t = tile_geom(pr);
+  if (load_rows)
+    for (int r = threadIdx.x; r <= kTileRows; r += kLoopBlock) t_rowr[r] = pr.trow[r];
+  tile_bin((const float4*)pr.mov, Mn, pr.msrt, t_rowm, t, &pr.st->err);
+  int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
+  int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
+  for (int q = threadIdx.x; q < Mn; q += kLoopBlock) nn_f[q] = -1;
+  for (int q = threadIdx.x; q < Rn; q += kLoopBlock) nn_b[q] = -1;
+  mom_init(tile_mom_table(pr, k));
+  __syncthreads();
+}
+__device__ __noinline__ void tile_forward_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
+  const TileGeom t = tile_geom(*prp);
+  tile_pass<true>(*prp, k, Mn, Rn, t);
+}
+__device__ __noinline__ void tile_backward_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
+  const TileGeom t = tile_geom(*prp);
+  tile_pass<false>(*prp, k, Mn, Rn, t);
+}
+__device__ __noinline__ void tile_flush_phase(const IcpProblem* __restrict__ prp, int k) {
+  mom_flush(tile_mom_table(*prp, k));
+}
+// every moving point moves by its component's step; the previous positions are kept for the l1 passes
+__device__ __noinline__ void tile_apply_phase(const IcpProblem* __restrict__ prp, int k, int Mn) {
+  const IcpProblem& pr = *prp;
+  float4* __restrict__ mov = pr.mov;
+  float4* __restrict__ prev = pr.prev;
+  const int32_t* __restrict__ comp = pr.comp;
+  const double* __restrict__ Rt = pr.Rt;
+  const int64_t C = pr.C;
+  if (threadIdx.x == 0) pr.st->iters = k;
+  for (int i = threadIdx.x; i < Mn; i += kLoopBlock) {
+    const double* __restrict__ rc = Rt + comp[i];
+    double R[9], t[3];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) R[q] = rc[(int64_t)q * C];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) t[q] = rc[(int64_t)(9 + q) * C];
+    const float4 p = mov[i];
+    prev[i] = p;
+    const double x = p.y, y = p.z, z = p.w;
+    const float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
+    const float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
+    const float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
+    mov[i] = make_float4(p.x, nx, ny, nz);
+  }
+}
+
+// One workgroup per batch entry, like icp_loop_kernel; phase_ticks: [0] rows of the moving cloud + forward
+// pass, [1] backward pass + moment flush, [2] solve + stop rule, [3] apply.
+__global__ void __launch_bounds__(kLoopBlock)
+icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, unsigned int budget_ticks,
+                IcpState* __restrict__ out) {
+  const IcpProblem* prp = tab + bt.idx[blockIdx.x];
+  IcpState* st = prp->st;
+  __shared__ int s_go;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  if (st->mode == 2) return;  // (uniform) a registration of the cache path: icp_loop_kernel's
+  int Mn, Rn, Ra;
+  icp_sizes(*prp, Mn, Rn, Ra);
+  int k = st->iters + 1;
+  const int k_end = k + n_it;
+  icp_decide(*prp, k - 1);
+  int load_rows = 1;
+  if (st->mode == 0) {
+    tile_prepare_phase(prp, Mn, Rn);
+    load_rows = 0;
+    if (t_flag[2] == 2) return;  // (uniform: written before the barrier that ends the phase)
+  }
+  unsigned long long ticks[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+  int done = 0;
+  if (threadIdx.x < 4) t_dbg[threadIdx.x] = 0ULL;
+  for (; k < k_end; ++k) {
+    __syncthreads();
+    unsigned long long t0 = 0ULL;
+    if (threadIdx.x == 0) {
+      t0 = __builtin_amdgcn_s_memrealtime();
+      bool go = !(k > prp->max_iter || k > st->stop_iter);
+      if (go && budget_ticks && done > 0 && t0 - t_begin > (unsigned long long)budget_ticks) go = false;
+      s_go = go ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_go) break;
+    tile_begin_phase(prp, k, Mn, Rn, load_rows);
+    load_rows = 0;
+    tile_forward_phase(prp, k, Mn, Rn);
+    __syncthreads();
+    unsigned long long t1 = 0ULL;
+    if (threadIdx.x == 0) { t1 = __builtin_amdgcn_s_memrealtime(); ticks[0] += t1 - t0; }
+    tile_backward_phase(prp, k, Mn, Rn);
+    __syncthreads();
+    tile_flush_phase(prp, k);
+    __syncthreads();
+    unsigned long long t2 = 0ULL;
+    if (threadIdx.x == 0) { t2 = __builtin_amdgcn_s_memrealtime(); ticks[1] += t2 - t1; }
+    loop_solve_phase(prp, k);
+    __syncthreads();
+    icp_decide(*prp, k);
+    unsigned long long t3 = 0ULL;
+    if (threadIdx.x == 0) { t3 = __builtin_amdgcn_s_memrealtime(); ticks[2] += t3 - t2; }
+    tile_apply_phase(prp, k, Mn);
+    if (threadIdx.x == 0) ticks[3] += __builtin_amdgcn_s_memrealtime() - t3;
+    ++done;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->loop_iters += done;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st->phase_ticks[q] += ticks[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st->dbg[q] += t_dbg[q];
+    if (out) out[blockIdx.x] = *st;
+  }
+}
 
 // coverage: moving points (final positions) with a reference point (stationary included) in range
 __global__ void __launch_bounds__(kBlock)
@@ -1446,31 +1878,32 @@ icp_finish_kernel(const IcpProblem* __restrict__ tab, Batch bt, IcpState* __rest
   const double* Tfin = pr.Tb + (size_t)(iters & 1) * C * 16;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
-    double n = (double)acc[c * kAcc];
-    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[c * kAcc + 18] * kFxInv) / n : 0.0;
+    double n = (double)acc[c];
+    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[(int64_t)18 * C + c] * kFxInv) / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
     pr.ratio_out[c] = (float)pr.cov[c] / ((float)pr.comp_deg[c] + 1e-6f);
-    for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[c * 16 + q];
+    for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[(int64_t)q * C + c];
   }
 }
 
-// ---- optional HIP-event timing of the three iteration kernels, for bench.py's roofline ----
+// ---- optional HIP-event timing of the loop kernel, for bench.py's roofline ----
 struct KernelProfile {
   double ms = 0.0;
   double launches = 0.0;
   double bytes = 0.0;
+  double unit_iters = 0.0;
+  double phase_us[4] = {0.0, 0.0, 0.0, 0.0};  // budget test, searches, solve, apply: summed over the units (CU time)
 };
 static bool g_prof_on = false;
-static KernelProfile g_prof[3];
+static KernelProfile g_prof;
 static std::mutex g_prof_mu;
-constexpr int kProfChunk = 16;  // chunk limit of the stand-alone entry point
 struct ProfEvents {
-  hipEvent_t ev[6];  // one iteration of a chunk carries events
+  hipEvent_t ev[2];
   bool have = false;
+  bool used = false;  // the slot's last chunk carried the events
 };
-constexpr int kProfSlots = 8;  // chunks one thread may have in flight (one per lock-step group)
+constexpr int kProfSlots = 8;  // chunks one thread may have in flight
 static thread_local ProfEvents t_evs[kProfSlots];
-static thread_local int t_ev_useds[kProfSlots];  // iterations of the slot's last chunk that carried events
 
 static inline int gx_for(int64_t items, int per_block, int cap) {
   int64_t g = (items + per_block - 1) / per_block;
@@ -1500,119 +1933,126 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
   return PCS_OK;
 }
 
+// PCS_ICP_WIDE_ITERS (experiment switch of round 4): how many iterations of a registration run as wide launches
+// before the unit-resident loop takes over (default kIcpWideIters; >= max_iter: every iteration, in chunks of 8,
+// the schedule of rounds 1-3)
+static int icp_wide_limit() {
+  static const int v = [] {
+    const char* e = getenv("PCS_ICP_WIDE_ITERS");
+    return e ? atoi(e) : kIcpWideIters;
+  }();
+  return v;
+}
+// PCS_ICP_TILES=0 (experiment switch of round 4): every registration on the cache path
+static bool icp_use_tiles() {
+  static const bool v = [] {
+    const char* e = getenv("PCS_ICP_TILES");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot) {
+                      unsigned budget_us, const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot) {
   if (bt.n < 1 || n_it < 1) return PCS_OK;
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
-  int& t_ev_used = t_ev_useds[prof_slot];
-  int64_t q = 1, m = 1, qsum = 0, cmax = 1;
-  for (int e = 0; e < bt.n; ++e) {
-    int64_t qe = (int64_t)hints[e].Mn + hints[e].Rn;
-    if (qe > q) q = qe;
-    qsum += qe;
-    if (hints[e].Mn > m) m = hints[e].Mn;
-    if (hints[e].C > cmax) cmax = hints[e].C;
-  }
-  const int nb_s = gx_for(cmax, kSolveBlock, 1024);  // solve: one thread per component
-  // PCS_ICP_MOM_STREAM: the budget test's moments as immediate LDS adds per lane (58 VGPRs, 7 waves per SIMD)
-  // instead of the shuffle pre-reduction of runs (123 VGPRs, 4 waves per SIMD)
-  // (measured A/B, batches of 12: 1.50 s either way -- the launch is not short of waves -- so the default
-  // stays the shuffle form, whose workgroups send fewer LDS atomics)
-  static const bool mom_stream = [] { const char* e = getenv("PCS_ICP_MOM_STREAM"); return e && atoi(e) != 0; }();
-  // bit 0 (PCS_ICP_LDS_STEPS, default on): the step table in LDS for the backward queries; bit 1
-  // (PCS_ICP_SEED_FIRST, default on): iteration 1 seeds its searches from the query's own fine cell
-  static const int lds_steps = [] {
-    const char* e = getenv("PCS_ICP_LDS_STEPS");
-    const char* f = getenv("PCS_ICP_SEED_FIRST");
-    const char* x = getenv("PCS_ICP_XCD");  // bit 2: XCD-aware placement of the iteration kernels (xcd_wg)
-    return ((e && atoi(e) == 0) ? 0 : 1) | ((f && atoi(f) == 0) ? 0 : 2) | ((x && atoi(x) != 0) ? 4 : 0);
-  }();
-  // PCS_ICP_SOLVE_STAGED=1: the records through LDS (measured A/B on one box, batches of 12: 1.57 s staged
-  // against 1.49 s direct -- the coalesced copies cost more than the 64-line gathers of a one-wave
-  // workgroup, which overlap with other waves' arithmetic); default: direct
-  static const bool solve_staged = [] { const char* e = getenv("PCS_ICP_SOLVE_STAGED"); return e && atoi(e) != 0; }();
+  const int wide_limit = icp_wide_limit();
+  // ---- entries whose next iterations are wide: launches over those entries only
+  static thread_local Batch bf;
+  static thread_local BatchInts kf;
+  static thread_local IcpHint hf[kMaxBatch];
+  bf.n = 0;
+  int n_wide = 0;  // iterations to launch: at most 8 per chunk
   bool any_first = false;
-  for (int e = 0; e < bt.n; ++e) any_first = any_first || kbase.v[e] == 0;
-  // budget test: one lane per query. A workgroup resets and drains its moment table once whatever the
-  // number of rounds it serves (a third of a one-round workgroup's time, profiles/r02_wg_trace.txt):
-  // once the launch is several generations of workgroups wide, each takes 2-4 rounds
-  const int64_t wg_total = (qsum + kBlock - 1) / kBlock;
-  const int rounds_per_wg = wg_total > 7168 ? 4 : (wg_total > 5120 ? 3 : (wg_total > 3072 ? 2 : 1));
-  const int nb_q = gx_for((q + rounds_per_wg - 1) / rounds_per_wg, kBlock, 1024);
-  // the searches are a queue over the work lists of all entries (items of 8 cooperative / 32 seeded
-  // queries): iteration 1 searches for every query, later ones for ~6 % + ~12 % of them
-  const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8)) & ~7;  // (multiples of 8: xcd_wg)
-  const int nb_cs = (int)(qsum / 48 < 64 ? 64 : (qsum / 48 > 2048 ? 2048 : qsum / 48)) & ~7;
-  const int nb_m = gx_for(m, kBlock, 4096);
-  bool prof = g_prof_on;
-  if (prof && !t_ev.have) {
-    for (int i = 0; i < 6; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
-    t_ev.have = true;
-  }
-  // ONE iteration of the chunk carries events (its position rotates from chunk to chunk, so that every
-  // position -- the full search of iteration 1 included -- is sampled at its own rate): timing every
-  // launch cost 7 % of the step (hipExtLaunchKernelGGL + four event records per iteration)
-  static thread_local unsigned t_rot = 0;
-  const int js = prof ? (int)(t_rot++ % (unsigned)n_it) : -1;
-  t_ev_used = prof ? js + 1 : 0;
-  for (int j = 0; j < n_it; ++j) {
-    const int nb_c = (j == 0 && any_first) ? nb_c1 : nb_cs;
-    if (j == 0 && any_first && (lds_steps & 2))
-      icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
-    if (j == js) {
-      // the events ride on the dispatch itself (hipExtLaunchKernelGGL), so their difference is the
-      // kernel's own begin-to-end time, as rocprofv3 reports it
-      hipEvent_t* e = &t_ev.ev[0];
-      // (the search is two launches; the pair is timed as one kernel, first start to last stop)
-      if (mom_stream)
-        hipExtLaunchKernelGGL(icp_nn_kernel<true>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j, lds_steps);
-      else
-        hipExtLaunchKernelGGL(icp_nn_kernel<false>, dim3(nb_q, bt.n), dim3(kBlock), 0, s, e[0], nullptr, 0, tab, bt, kbase, j, lds_steps);
-      hipExtLaunchKernelGGL(icp_nn_search_kernel, dim3(nb_c), dim3(kBlock), 0, s, nullptr, e[1], 0, tab,
-                            bt, kbase, j, lds_steps);
-      if (solve_staged)
-        hipExtLaunchKernelGGL(icp_solve_kernel<true>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
-                              bt, kbase, j);
-      else
-        hipExtLaunchKernelGGL(icp_solve_kernel<false>, dim3(nb_s, bt.n), dim3(kSolveBlock), 0, s, e[4], nullptr, 0, tab,
-                              bt, kbase, j);
-      hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bt.n), dim3(kBlock), 0, s, nullptr, e[5], 0, tab, bt,
-                            kbase, j, lds_steps);
-    } else {
-      if (mom_stream) icp_nn_kernel<true><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
-      else icp_nn_kernel<false><<<dim3(nb_q, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
-      icp_nn_search_kernel<<<nb_c, kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
-      if (solve_staged) icp_solve_kernel<true><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
-      else icp_solve_kernel<false><<<dim3(nb_s, bt.n), kSolveBlock, 0, s>>>(tab, bt, kbase, j);
-      icp_apply_kernel<<<dim3(nb_m, bt.n), kBlock, 0, s>>>(tab, bt, kbase, j, lds_steps);
+  for (int e = 0; e < bt.n; ++e)
+    if (kbase.v[e] < wide_limit) {
+      hf[bf.n] = hints[e];
+      kf.v[bf.n] = kbase.v[e];
+      bf.idx[bf.n++] = bt.idx[e];
+      const int left = wide_limit - kbase.v[e];
+      if (left > n_wide) n_wide = left;
+      any_first = any_first || kbase.v[e] == 0;
+    }
+  if (n_wide > 8) n_wide = 8;
+  if (n_wide > n_it) n_wide = n_it;
+  if (bf.n > 0 && n_wide > 0) {
+    int64_t q = 1, m = 1, qsum = 0, cmax = 1;
+    for (int e = 0; e < bf.n; ++e) {
+      int64_t qe = (int64_t)hf[e].Mn + hf[e].Rn;
+      if (qe > q) q = qe;
+      qsum += qe;
+      if (hf[e].Mn > m) m = hf[e].Mn;
+      if (hf[e].C > cmax) cmax = hf[e].C;
+    }
+    const int nb_s = gx_for(cmax, kSolveBlock, 1024);  // solve: one thread per component
+    // budget test: one lane per query. A workgroup resets and drains its moment table once whatever the
+    // number of rounds it serves: once the launch is several generations of workgroups wide, each takes 2-4 rounds
+    const int64_t wg_total = (qsum + kBlock - 1) / kBlock;
+    const int rounds_per_wg = wg_total > 7168 ? 4 : (wg_total > 5120 ? 3 : (wg_total > 3072 ? 2 : 1));
+    const int nb_q = gx_for((q + rounds_per_wg - 1) / rounds_per_wg, kBlock, 1024);
+    // the searches are a queue over the work lists of all entries (items of 8 cooperative / 32 seeded
+    // queries): iteration 1 searches for every query, later ones for ~6 % + ~12 % of them
+    const int nb_c1 = (int)(qsum / 8 < 64 ? 64 : (qsum / 8 > 2048 ? 2048 : qsum / 8));
+    const int nb_cs = (int)(qsum / 48 < 64 ? 64 : (qsum / 48 > 2048 ? 2048 : qsum / 48));
+    const int nb_m = gx_for(m, kBlock, 4096);
+    for (int j = 0; j < n_wide; ++j) {
+      if (j == 0 && any_first) icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bf.n), kBlock, 0, s>>>(tab, bf, kf);
+      icp_nn_kernel<<<dim3(nb_q, bf.n), kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
+      icp_nn_search_kernel<<<(j == 0 && any_first) ? nb_c1 : nb_cs, kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
+      icp_solve_kernel<<<dim3(nb_s, bf.n), kSolveBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
+      icp_apply_kernel<<<dim3(nb_m, bf.n), kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
     }
   }
-  // the stop rule of the chunk's last iteration (the others were settled by the next search)
-  icp_decide_kernel<<<bt.n, kBlock, 0, s>>>(tab, bt, kbase, n_it, out);
+  // ---- the unit-resident loop: one workgroup per entry (entries that began above go on from where the
+  //      wide launches left them; the kernel also settles their stop rule and mirrors every state)
+  const unsigned long long bt_ticks = (unsigned long long)budget_us * 100ULL;
+  const unsigned int budget_ticks = bt_ticks > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (unsigned int)bt_ticks;
+  const bool prof = g_prof_on;
+  if (prof && !t_ev.have) {
+    for (int i = 0; i < 2; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
+    t_ev.have = true;
+  }
+  t_ev.used = prof;
+  // the tile path first (it decides a new registration's path); the cache path's kernel then serves the
+  // registrations that did not qualify -- and mirrors every state
+  const bool tiles = icp_use_tiles() && wide_limit == 0;
+  if (prof) {
+    // the events ride on the dispatches themselves (hipExtLaunchKernelGGL): first start to last stop, the
+    // kernels' own begin-to-end time as rocprofv3 reports it
+    if (tiles)
+      hipExtLaunchKernelGGL(icp_tile_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, t_ev.ev[0], nullptr, 0, tab, bt, n_it,
+                            budget_ticks, out);
+    hipExtLaunchKernelGGL(icp_loop_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, tiles ? nullptr : t_ev.ev[0], t_ev.ev[1], 0,
+                          tab, bt, n_it, wide_limit, budget_ticks, out);
+  } else {
+    if (tiles) icp_tile_kernel<<<bt.n, kLoopBlock, 0, s>>>(tab, bt, n_it, budget_ticks, out);
+    icp_loop_kernel<<<bt.n, kLoopBlock, 0, s>>>(tab, bt, n_it, wide_limit, budget_ticks, out);
+  }
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
 
-// after the stream has been synchronised: add the chunk's launches to the profile. live[j] = number
-// of entries that really ran iteration position j; bytes3[j*3 + {0,1,2}] = their algorithmic bytes in
-// the search / moments / apply launch. Launches in which no entry was live are not counted.
-void icp_profile_account(int n_it, const int* live, const double* bytes3, int prof_slot) {
+// after the stream has been synchronised: add the chunk's loop launch to the profile
+void icp_profile_account(double unit_iters, double bytes, int prof_slot) {
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
-  int& t_ev_used = t_ev_useds[prof_slot];
-  if (!g_prof_on || t_ev_used < 1) return;
-  const int j = t_ev_used - 1;  // the iteration of the chunk that carried the events
-  t_ev_used = 0;
-  if (j >= n_it || live[j] < 1) return;
+  if (!g_prof_on || !t_ev.used) return;
+  t_ev.used = false;
+  if (!(unit_iters > 0.0)) return;  // (a launch whose entries had all stopped)
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, t_ev.ev[0], t_ev.ev[1]) != hipSuccess) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int q = 0; q < 3; q += 2) {  // 0: the two neighbour kernels (moments included), 2: solve + apply
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t_ev.ev[2 * q], t_ev.ev[2 * q + 1]) != hipSuccess) continue;
-    g_prof[q].ms += ms;
-    g_prof[q].launches += 1.0;
-    g_prof[q].bytes += bytes3[j * 3 + q];
-  }
+  g_prof.ms += ms;
+  g_prof.launches += 1.0;
+  g_prof.bytes += bytes;
+  g_prof.unit_iters += unit_iters;
+}
+
+void icp_profile_phases(const unsigned long long* ticks4) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int q = 0; q < 4; ++q) g_prof.phase_us[q] += (double)ticks4[q] * 0.01;  // 100 MHz ticks
 }
 
 int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
@@ -1642,25 +2082,28 @@ using namespace pcs;
 
 extern "C" {
 
-// bench.py support: HIP-event timing of the three iteration kernels of the fused ICP on their launch
-// stream. enable = 1 resets and starts accumulating.
+// bench.py support: HIP-event timing of the unit-resident loop kernel on its launch stream.
+// enable = 1 resets and starts accumulating.
 int pcs_profile_icp(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
-  for (int q = 0; q < 3; ++q) g_prof[q] = KernelProfile();
+  g_prof = KernelProfile();
   return PCS_OK;
 }
 
-// out9 (host): {milliseconds, launches, algorithmic bytes} of icp_nn_kernel, icp_moments_kernel,
-// icp_apply_kernel accumulated since the last enable.
+// out9 (host): [0..3] = {milliseconds, launches, algorithmic bytes, unit-iterations} of icp_loop_kernel
+// accumulated since the last enable; [4..7] = microseconds its workgroups spent in the budget test, the
+// searches, solve + stop rule, apply (summed over the units: CU time, not wall time; registrations that
+// have ended); [8] = 0.
 int pcs_profile_icp_read(double* out9) {
   if (!out9) return PCS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int q = 0; q < 3; ++q) {
-    out9[3 * q + 0] = g_prof[q].ms;
-    out9[3 * q + 1] = g_prof[q].launches;
-    out9[3 * q + 2] = g_prof[q].bytes;
-  }
+  for (int q = 0; q < 9; ++q) out9[q] = 0.0;
+  out9[0] = g_prof.ms;
+  out9[1] = g_prof.launches;
+  out9[2] = g_prof.bytes;
+  out9[3] = g_prof.unit_iters;
+  for (int q = 0; q < 4; ++q) out9[4 + q] = g_prof.phase_us[q];
   return PCS_OK;
 }
 
@@ -1673,13 +2116,15 @@ size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_
 }
 
 // BLOCKING (the one entry point that synchronises the stream: the reference reads the loss on the
-// host every iteration, this reads one word per `chunk` iterations).
+// host every iteration, this reads one state record per `chunk` iterations; chunk <= 0: the whole loop
+// in one launch).
 //   mov_fxyz [Mn,4]  non-stationary moving points, updated in place
 //   mov_comp [Mn]    int32 component of each moving point, in [0, C)
 //   ref_fxyz [Rn,4]  non-stationary reference points; ref_all [Ra,4] all reference points
 //   comp_deg [C]     int64 number of moving points (stationary included) per component
 //   T [C,16] f64 out; l1_err [C] f64 out (last iteration); edge_ratio [C] f32 out
-//   info[4] host out: iterations run, stop reason (1 = countdown, 0 = max_iter), 0, 0
+//   info[4] host out: iterations run, stop reason (1 = countdown, 0 = max_iter), iterations run by the
+//                     unit-resident loop, 0
 int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
                                const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
                                const int64_t* comp_deg, int64_t C, double radius, int frame_offset,
@@ -1720,8 +2165,7 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
     PCS_CHECK_HIP(hipMemcpyAsync(tab, &host_pr, sizeof(IcpProblem), hipMemcpyHostToDevice, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
   }
-  if (chunk < 1) chunk = 8;
-  if (chunk > kProfChunk) chunk = kProfChunk;
+  if (chunk < 1 || chunk > max_iter) chunk = max_iter > 0 ? max_iter : 1;
   Batch bt;
   bt.n = 1;
   bt.idx[0] = 0;
@@ -1731,37 +2175,27 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   rc = icp_enqueue_begin(tab, bt, &hint, s);
   if (rc) return rc;
   IcpState host;
+  memset(&host, 0, sizeof(host));
   host.stop_iter = INT_MAX;
-  host.iters = 0;
-  host.err = 0;
-  int it = 0;
-  const double by_nn = 76.0 * (double)(Mn + Rn) + 272.0 * (double)C, by_mom = 0.0,
-               by_app = 68.0 * (double)Mn + 416.0 * (double)C;
-  while (it < max_iter) {
-    int n_it = (max_iter - it < chunk) ? (max_iter - it) : chunk;
+  const double by_iter = 76.0 * (double)(Mn + Rn) + 272.0 * (double)C + 68.0 * (double)Mn + 416.0 * (double)C;
+  while (host.iters < max_iter) {
     BatchInts kb;
-    kb.v[0] = it;
-    rc = icp_enqueue_chunk(tab, bt, kb, n_it, &hint, pin, s, 0);
+    kb.v[0] = host.iters;
+    const int loop_before = host.loop_iters;
+    rc = icp_enqueue_chunk(tab, bt, kb, chunk, 0u, &hint, pin, s, 0);
     if (rc) return rc;
     if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (pin) host = *pin;
-    {
-      int live[kProfChunk];
-      double b3[3 * kProfChunk];
-      for (int j = 0; j < n_it; ++j) {
-        live[j] = (it + 1 + j <= host.iters) ? 1 : 0;
-        b3[3 * j] = by_nn; b3[3 * j + 1] = by_mom; b3[3 * j + 2] = by_app;
-      }
-      icp_profile_account(n_it, live, b3, 0);
-    }
-    it += n_it;
-    if (host.err) return PCS_ERR_RANGE;
+    icp_profile_account((double)(host.loop_iters - loop_before), by_iter * (double)(host.loop_iters - loop_before), 0);
+    if (host.err) { fprintf(stderr, "[pcs debug] icp err %d mode %d iters %d\n", host.err, host.mode, host.iters); return PCS_ERR_RANGE; }
     if (host.stop_iter != INT_MAX) break;
   }
+  icp_profile_phases(host.phase_ticks);
   info[0] = host.iters;
   info[1] = host.stop_iter != INT_MAX ? 1 : 0;
-  info[2] = info[3] = 0;
+  info[2] = host.loop_iters;
+  info[3] = 0;
   rc = icp_enqueue_finish(tab, bt, &hint, pin, s);
   if (rc) return rc;
   if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));

@@ -36,8 +36,14 @@ struct IcpState {
   // work lists of the current iteration, one per direction (0: forward queries, moving -> reference,
   // list entries [0, Mn); 1: backward, entries [Mn, Mn + Rn)): a search workgroup serves ONE direction
   int wl_n[2];    // queries waiting for the cooperative search
-  int ws_n[2];    // queries waiting for the search around their old partner
+  int ws_n[2];    // queries waiting for the search around their old partner (directly behind wl_n: the two are addressed as int[4])
   unsigned int dmax[2];  // float bits: largest displacement of a moving point in iteration k (slot k & 1)
+  int loop_iters;        // iterations the unit-resident loops have run (the others were wide launches)
+  int mode;              // 0: not decided yet, 1: tile path (icp_tile_kernel), 2: cache path (icp_loop_kernel)
+  // measurement: 100 MHz ticks (s_memrealtime) the unit-resident loop spent in its four phases -- budget
+  // test, searches, solve, apply -- summed over the iterations of this registration
+  unsigned long long phase_ticks[4];
+  unsigned long long dbg[4];  // EXPERIMENT: queries, far-phase entries, queries without partner, candidates examined
 };
 
 // per-component accumulators of one iteration: n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2,
@@ -57,6 +63,7 @@ constexpr double kFxInv = 1.0 / 68719476736.0;
 // Steps of the moving points, by place: slot = hash of the 8 x 8 x 8-cell block the point moved INTO.
 // Colliding blocks share a slot and hence the larger step: the table can only over-estimate.
 constexpr int kStepH = 4096;
+constexpr int kTileRows = 1024;  // block rows a registration of the tile path may span
 __host__ __device__ inline int icp_step_slot(int sx, int sy, int sz) {
   unsigned h = (unsigned)sx * 73856093u ^ (unsigned)sy * 19349663u ^ (unsigned)sz * 83492791u;
   h ^= h >> 15;
@@ -67,9 +74,11 @@ struct IcpGeom {
   GridDesc g;
 };
 // largest admissible squared distance of a point from its component origin: ne products of that size
-// stay below 2^62 in fixed point
+// stay below 2^62 in fixed point, and a single term (a product, or a squared distance of two such points)
+// below 2^51, the range of the two-instruction rounding (to_fx) and of the carry-free wave sums
 __host__ __device__ inline double icp_limit_sq(int ne) {
-  return 4611686018427387904.0 / kFx / (double)(ne < 1 ? 1 : ne);
+  const double by_sum = 4611686018427387904.0 / kFx / (double)(ne < 1 ? 1 : ne);
+  return by_sum < 4096.0 ? by_sum : 4096.0;
 }
 
 struct IcpProblem {
@@ -86,9 +95,14 @@ struct IcpProblem {
   int32_t* wl;          // [capM + capR] queries handed to the cooperative search
   int32_t* wls;         // [capM + capR] queries handed to the search around their old partner
   unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
-  long long* acc;       // [2, C, kAcc]
-  double* Tb;           // [2, C, 16] accumulated transforms, buffer k & 1 after iteration k
-  double* Rt;           // [C, 12] rotation (9) and translation (3) of the current iteration's step
+  float4* rsrt;         // [capR] tile path: the reference points by block row, (original index bits, x, y, z)
+  float4* msrt;         // [capM] tile path: the moving points by block row, rebuilt every iteration
+  int32_t* trow;        // [kTileRows + 1] tile path: first row of rsrt of every block row
+  // the per-component records are COMPONENT-MINOR (word q of every component side by side): the solve
+  // phase's thread c and the apply phase's points read them next to their neighbours'
+  long long* acc;       // [2, kAcc, C]
+  double* Tb;           // [2, 16, C] accumulated transforms, buffer k & 1 after iteration k
+  double* Rt;           // [12, C] rotation (9) and translation (3) of the current iteration's step
   long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity), then [2][kLossParts] the same at 10 fractional bits (overflow check)
   float4* corg;         // [C] origin of the component's fixed-point moments
   int32_t* cov;         // [C] matched moving points in the final coverage query
@@ -128,6 +142,8 @@ struct IcpBufs {
   Grid2 gr, ga, gm[2];
   int32_t *nn_f, *nn_b, *wl, *wls;
   unsigned int* sstep;
+  float4 *rsrt, *msrt;
+  int32_t* trow;
   float *bud_f, *bud_b;
   float* prev;
   long long* acc;
@@ -165,17 +181,24 @@ struct IcpHint {
   int64_t C;
   size_t clear_words;
 };
-// optional HIP-event timing of the three iteration kernels (bench.py's roofline): after the stream
-// has been synchronised, account the launches of the calling thread's last chunk
-constexpr int kIcpMaxChunk = 16;
-void icp_profile_account(int n_it, const int* live, const double* bytes3, int prof_slot);
+// optional HIP-event timing of the unit-resident loop kernel (bench.py's roofline): after the stream has
+// been synchronised, account the calling thread's last chunk: unit_iters = iterations its entries ran in
+// the loop kernel, bytes = their algorithmic bytes
+void icp_profile_account(double unit_iters, double bytes, int prof_slot);
+// a registration has ended: its IcpState::phase_ticks join the profile
+void icp_profile_phases(const unsigned long long* ticks4);
 // enqueue: reset + bounds + grid description + the three grids of every entry
 int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, hipStream_t s);
-// enqueue n_it iterations (entry e runs iterations kbase[e]+1 .. kbase[e]+n_it, gated by its stop
-// word and max_iter), then the stop rule of the last one; the states are mirrored to out[e] (may be
-// pinned host memory, may be nullptr)
+// enqueue one chunk of iterations for every entry. Entries that have not iterated yet (kbase[e] == 0) first
+// run kIcpWideIters iterations as wide launches (the full searches of a first iteration want the whole
+// chip); then ONE launch of the unit-resident loop: a workgroup per entry runs that entry's iterations
+// back to back -- budget test, searches, solve, apply, stop rule, no launch in between -- until the stop
+// rule fires, max_iter, n_it iterations of this chunk, or budget_us microseconds (0: no limit) have passed.
+// How the iterations are cut into chunks never changes a result. The states are mirrored to out[e]
+// (may be pinned host memory, may be nullptr).
+constexpr int kIcpWideIters = 0;
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
-                      const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot);
+                      unsigned budget_us, const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot);
 // enqueue: l1 error of the last iteration, coverage ratio, outputs
 int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, IcpState* out,
                        hipStream_t s);

@@ -1133,8 +1133,7 @@ struct HostUnit {
   int na, nm, C, F, W, anchor, min_f, max_f;
   int64_t off_a;
   int phase, dir, next, last_col, lv;
-  int it;         // ICP iterations enqueued for the current registration
-  int it_before;  // iterations enqueued before the last chunk
+  int loop_before;  // iterations the unit-resident loop had run before the last chunk (profile accounting)
   int fail;       // error found while collecting a tick (PCS_ERR_*)
   bool any_valid;
   int Cu;
@@ -1340,7 +1339,7 @@ class Engine {
   int live_[kMaxBatch], n_live_ = 0;
   Batch b_all_, b_iter_, b_fin_;
   int64_t ticks_ = 0;
-  int chunk_ = 8;
+  unsigned chunk_us_ = 1000;  // time budget of a chunk of the unit-resident ICP loop
 };
 
 }  // namespace pcs
@@ -1373,7 +1372,6 @@ static int64_t unit_frame_max(const int64_t* frame_offsets, int anchor, int min_
 int Engine::enqueue_tick() {
   const PcsTrackParams* prm = &prm_;
   const int L = prm->num_levels;
-  const int chunk = chunk_;
   hipStream_t gs = st_;
   UnitDev* const d_units = d_units_;
   IcpProblem* const d_icp = d_icp_;
@@ -1430,8 +1428,9 @@ int Engine::enqueue_tick() {
     s_smp.a[b_smp.n] = step_arg(h);
     b_smp.idx[b_smp.n++] = i;
     b_begin.idx[b_begin.n++] = i;
-    h.it = h.it_before = 0;
+    h.loop_before = 0;
     h.icp.iters = 0;
+    h.icp.loop_iters = 0;
     h.icp.stop_iter = INT_MAX;
     h.icp.err = 0;
     h.phase = PH_ICP;
@@ -1466,7 +1465,15 @@ int Engine::enqueue_tick() {
         break;
       }
       case PH_ICP: {
-        if (h.icp.stop_iter != INT_MAX || h.it >= prm->max_iter) {
+        if (h.icp.stop_iter != INT_MAX || h.icp.iters >= prm->max_iter) {
+          icp_profile_phases(h.icp.phase_ticks);
+          if (g_tick_profile.on)  // profiling hook: one line per registration (sizes, iterations, phase microseconds)
+            fprintf(stderr, "[reg] slot %d lv %d C %d Mn %lld Ra %lld Rn %lld iters %d loop %d us %.0f %.0f %.0f %.0f\n", i,
+                    h.lv, h.C, (long long)h.host.counts[1], (long long)h.host.counts[2], (long long)h.host.counts[3],
+                    h.icp.iters, h.icp.loop_iters, h.icp.phase_ticks[0] * 0.01, h.icp.phase_ticks[1] * 0.01,
+                    h.icp.phase_ticks[2] * 0.01, h.icp.phase_ticks[3] * 0.01);
+          if (g_tick_profile.on)
+            fprintf(stderr, "[dbg] lv %d q %llu far %llu nohit %llu cand %llu\n", h.lv, h.icp.dbg[0], h.icp.dbg[1], h.icp.dbg[2], h.icp.dbg[3]);
           s_fin.a[b_fin.n] = step_arg(h);
           h_fin[b_fin.n] = h.hint;
           b_fin.idx[b_fin.n++] = i;
@@ -1644,18 +1651,14 @@ int Engine::enqueue_tick() {
     const int i = live_[e];
     HostUnit& h = hu[i];
     if (h.phase != PH_ICP) continue;
-    kb.v[b_iter.n] = h.it;
+    kb.v[b_iter.n] = h.icp.iters;  // 0: the registration begins (its first iteration is a wide launch)
+    h.loop_before = h.icp.loop_iters;
     h_iter[b_iter.n] = h.hint;
     b_iter.idx[b_iter.n++] = i;
   }
-  if (b_iter.n) {
-    TRK_RC(icp_enqueue_chunk(d_icp, b_iter, kb, chunk, h_iter, pin_icp_, gs, 0));
-    for (int e = 0; e < b_iter.n; ++e) {
-      HostUnit& h = hu[b_iter.idx[e]];
-      h.it_before = h.it;
-      h.it = min(h.it + chunk, prm->max_iter);
-    }
-  }
+  // every registering unit gets a workgroup of its own that iterates until its stop rule fires or the
+  // chunk's time budget has passed (units are not in step with each other inside a chunk)
+  if (b_iter.n) TRK_RC(icp_enqueue_chunk(d_icp, b_iter, kb, prm->max_iter, chunk_us_, h_iter, pin_icp_, gs, 0));
   b_iter_ = b_iter;
   if (g_tick_profile.on) { g_tick_profile.units += n_live_; g_tick_profile.iter_units += b_iter.n; }
   // ---- 7. state mirror; the event tells the host when the tick's words can be read
@@ -1668,7 +1671,6 @@ int Engine::enqueue_tick() {
 // the tick has completed: take its state words
 void Engine::collect_tick() {
   HostUnit* const hu = hu_;
-  const int chunk = chunk_;
   for (int e = 0; e < b_fin_.n; ++e)
     if (pin_fin_[e].err) hu[b_fin_.idx[e]].fail = PCS_ERR_RANGE;  // the coverage query can still overflow a grid
   for (int e = 0; e < b_all_.n; ++e) {
@@ -1681,21 +1683,18 @@ void Engine::collect_tick() {
     }
   }
   if (b_iter_.n) {
-    int live_j[kIcpMaxChunk];
-    double b3[3 * kIcpMaxChunk];
-    for (int j = 0; j < chunk; ++j) { live_j[j] = 0; b3[3 * j] = b3[3 * j + 1] = b3[3 * j + 2] = 0.0; }
+    double unit_iters = 0.0, bytes = 0.0;
     for (int e = 0; e < b_iter_.n; ++e) {
       HostUnit& h = hu[b_iter_.idx[e]];
       h.icp = pin_icp_[e];
       const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
-      for (int j = 0; j < chunk; ++j) {
-        if (h.it_before + 1 + j > h.icp.iters) break;
-        live_j[j] += 1;
-        b3[3 * j] += 76.0 * (Mn + Rn) + 272.0 * C;  // search (36 per query) + moments (40 per query, 272 per component)
-        b3[3 * j + 2] += 68.0 * Mn + 416.0 * C;
-      }
+      const double it = (double)(h.icp.loop_iters - h.loop_before);
+      unit_iters += it;
+      // per unit and iteration: neighbours (36 per query) + moments (40 per query, 272 per component) + solve and
+      // apply (68 per moving point, 416 per component)
+      bytes += it * (76.0 * (Mn + Rn) + 272.0 * C + 68.0 * Mn + 416.0 * C);
     }
-    icp_profile_account(chunk, live_j, b3, 0);
+    icp_profile_account(unit_iters, bytes, 0);
   }
 }
 
@@ -1722,9 +1721,8 @@ void Engine::run() {
   //  bound in the order the engines are created, not in the order their first units arrive)
   ok = ok && hipMemsetAsync(d_units_, 0, sizeof(int), st_) == hipSuccess && hipStreamSynchronize(st_) == hipSuccess;
   {
-    const char* e = getenv("PCS_TRACK_CHUNK");
-    int c = e ? atoi(e) : 0;
-    chunk_ = (c >= 1 && c <= kIcpMaxChunk) ? c : 8;
+    const char* e = getenv("PCS_TRACK_CHUNK_US");  // (experiment switch of round 4; 0 = no limit)
+    if (e) chunk_us_ = (unsigned)atoi(e);
   }
   {
     std::lock_guard<std::mutex> lk(mu_);
@@ -1848,7 +1846,7 @@ static int prepare_sequence(Engine* eng, const PcsTrackParams* prm, const float*
     d.ex_local = io.ex_local;
     d.ex_comp = io.ex_component;
     h.steps = h.reg_calls = 0;
-    h.it = h.it_before = 0;
+    h.loop_before = 0;
     h.fail = 0;
     h.icp.err = 0;
     h.host.err = 0;
