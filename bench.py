@@ -227,7 +227,7 @@ def stage_rooflines(records, stats, prof, out):
     ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
     if ms > 0:
         gbs = nbytes / (ms * 1e-3) / 1e9
-        stages.append({"stage": "icp loop (one workgroup per unit: budget test, searches, solve, apply)",
+        stages.append({"stage": "icp iterations (budget test + moments, searches, solve, apply), per chunk",
                        "ms": round(ms, 3), "launches": int(launches),
                        "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
                        "unit_iterations": int(unit_iters), "algorithmic_MB": round(nbytes / 1e6, 2),
@@ -258,6 +258,15 @@ def main():
                          "< 0 = its default")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rank / sequence assignment and reduction only")
+    ap.add_argument("--schedule", default="wide", choices=("wide", "resident_tiles", "resident_cache"),
+                    help="how the ICP iterations run (ops.icp_set_schedule): wide launches over all registrations in "
+                         "flight (default), or one resident workgroup per registration with LDS-staged / hash-grid searches")
+    ap.add_argument("--engines", type=int, default=-1, help="tracker engines per device (ops.track_configure; default 3)")
+    ap.add_argument("--chunk-us", type=int, default=-1, help="chunk budget of the resident schedules (default 3000)")
+    ap.add_argument("--pre-streams", type=int, default=0,
+                    help="create this many HIP streams before the library creates any (robustness check: the engines' "
+                         "hardware queues must not depend on what the embedding application created first)")
+    ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the extra device-synchronised step")
     args = ap.parse_args()
@@ -312,7 +321,11 @@ def main():
     from tools.run_sequence import build_model
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    from pcseqlearning_amd import synthetic
+    from pcseqlearning_amd import ops, synthetic
+    # streams an embedding application might have created before the library sees the device
+    pre_streams = [torch.cuda.Stream(device) for _ in range(args.pre_streams)]
+    ops.track_configure(args.engines, args.chunk_us)
+    ops.icp_set_schedule(*{"wide": (-1, True), "resident_tiles": (1, True), "resident_cache": (1, False)}[args.schedule])
     host_batch = host_batches[0]
     batch1 = models.load_data_to_gpu(host_batch, device)  # the first sequence alone (latency / stage report)
     batch = batch1 if len(host_batches) == 1 else \
@@ -343,16 +356,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    icp_events = not os.environ.get("PCS_BENCH_NO_ICP_EVENTS")  # (experiment switch: the roofline row is then empty)
-    if icp_events:
-        lib.pcs_profile_icp(ctypes.c_int(1))
-    if os.environ.get("PCS_BENCH_NO_DEFER"):  # (experiment switch: ClusterProposal's evaluation inline, no side stream)
-        model.model_cfg.PREPROCESSORS[1]["DEFER_EVALUATION"] = False
-        model.preprocessors[1].model_cfg["DEFER_EVALUATION"] = False
+    lib.pcs_profile_icp(ctypes.c_int(1))
     timer.RECORDS.clear()
     barrier()
     t0 = time.perf_counter()
-    trace = os.environ.get("PCS_BENCH_TRACE")
+    trace = args.trace
     step_ms = []
     alloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
@@ -456,6 +464,7 @@ def main():
                              "cluster_tracking_TLS_multiradius_every8 end to end"),
                 "batch_size": B,
                 "sequences_in_flight": min(B, int(model.model_cfg.get("SEQUENCES_IN_FLIGHT", 12))),
+                "pre_created_streams": len(pre_streams),
                 "one_sequence_alone_ms": round(single_ms, 2),
                 "one_sequence_alone_sequences_per_s": round(1e3 / single_ms, 4),
                 "frames": args.frames, "points_per_frame": args.points,
@@ -473,13 +482,18 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("icp_loop_kernel (fused ICP, one 1024-thread workgroup per tracking unit: verified-cache "
+                "kernel": ("the iteration launches of the fused ICP, chunk by chunk: icp_nn_kernel (verified-cache budget "
+                           "test, moments) + icp_nn_search_kernel + icp_solve_kernel + icp_apply_kernel, eight "
+                           "iterations of every registration in flight per chunk" if args.schedule == "wide" else
+                           "icp_tile_kernel / icp_loop_kernel (fused ICP, one 1024-thread workgroup per tracking unit: "
                            "budget test, searches, moments, solve, stop rule, apply -- all iterations of a chunk)"),
+                "schedule": args.schedule,
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                "timing": ("HIP events on the dispatches themselves, inside the timed steps, every launch of the "
-                           "loop kernel in which at least one unit iterated"),
+                "timing": ("HIP events on the dispatches themselves, inside the timed steps: start of a chunk's first "
+                           "iteration launch to the stop of its last, every chunk in which at least one unit iterated; "
+                           "a 'launch' below is one chunk"),
                 "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
                 "unit_iterations_timed": int(unit_iters),
                 "unit_iterations_per_launch": round(unit_iters / max(launches, 1), 1),

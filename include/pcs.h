@@ -391,6 +391,10 @@ int pcs_track_frame(const PcsTrackParams* prm, const float* seq_fxyz, const int6
  * creation order, and engines created between the streams of a dozen host threads can end up on one queue
  * (their chains then run one after the other). Call it before creating other streams. */
 int pcs_track_engines_init(int device);
+/* Engines per device (1..8, default 3; for devices whose engines do not exist yet) and the time budget, in
+ * microseconds, of a chunk of the unit-resident ICP schedules (pcs_icp_set_schedule; default 3000, 0: none).
+ * Arguments < 0 keep the current setting. Results never depend on either. */
+int pcs_track_configure(int engines, int chunk_us);
 typedef struct PcsTrackUnit {
   const int64_t* seq_component;   /* [N] int64 */
   const uint8_t* seq_stationary;  /* [N] uint8 */
@@ -457,14 +461,27 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
                         float* height_out, int32_t* d_iters, void* ws, size_t ws_bytes,
                         pcs_stream_t stream);
 
-/* Measurement support for bench.py (not on the data path): HIP-event timing, on the launch
- * stream, of the three kernels of a fused-ICP iteration (two-direction 1-NN search, moments, solve +
- * apply). enable=1 resets and starts accumulating; read returns HOST doubles {milliseconds, launches,
- * algorithmic bytes} x {search, moments, apply}. The milliseconds are begin-to-end times of the
- * launches themselves: the HIP events ride on the dispatch (hipExtLaunchKernelGGL), which is what
- * rocprofv3 reports as the kernel duration. Launches in which no problem was live are not counted. */
+/* Measurement support for bench.py (not on the data path): HIP-event timing, on the launch stream, of the
+ * iteration launches of the fused ICP, chunk by chunk (first iteration launch's start to the last one's stop:
+ * the HIP events ride on the dispatches, hipExtLaunchKernelGGL, which is what rocprofv3 reports as kernel
+ * begin / end). enable=1 resets and starts accumulating; read returns HOST doubles: [0] milliseconds, [1] chunks
+ * timed, [2] algorithmic bytes, [3] unit-iterations of those chunks; [4..7] microseconds the resident loops'
+ * workgroups spent in their four phases (resident schedules only); [8] 0. Chunks in which no registration
+ * iterated are not counted. */
 int pcs_profile_icp(int enable);
 int pcs_profile_icp_read(double* out9);
+
+/* Schedule of the iterations of the fused ICP (pcs_register_to_next_frame and the tracker), process-wide;
+ * takes effect for the chunks enqueued afterwards. Every schedule computes the same iterations (the same
+ * neighbours, the same integer moments), so results do not depend on it; it is a performance choice.
+ *   wide_iters < 0 (default): every iteration = four wide launches that serve all registrations in flight
+ *     (blockIdx.y = registration), eight iterations per host round trip;
+ *   wide_iters >= 1: that many wide iterations per registration (the full searches of a first iteration want
+ *     the whole chip), then ONE resident workgroup per registration runs its iterations back to back (no
+ *     launch between iterations): use_tiles != 0 with the candidates staged in LDS (clouds sorted by block
+ *     row, bands of rows copied into LDS sorted by cell bucket, one lane or one wave per failed query;
+ *     registrations that do not qualify take the cache path), use_tiles == 0 with the hash-grid searches. */
+int pcs_icp_set_schedule(int wide_iters, int use_tiles);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per

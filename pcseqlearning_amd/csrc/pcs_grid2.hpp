@@ -403,11 +403,11 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     }
     rem &= ball;
   }
-  if (__ballot(rem != 0)) {
-    // the surviving cells of the 27 blocks are dealt evenly to the 32 lanes of the half: rank r of
-    // the concatenated set bits goes to lane r % 32, so the walk takes ceil(total / 32) rounds of
-    // memory latency however unevenly the blocks are filled
-    int n_mine = __popcll(rem);
+  // the cells `cells` (bits of this lane's block) of the 27 blocks are dealt evenly to the 32 lanes of the half:
+  // rank r of the concatenated set bits goes to lane r % 32, so the walk takes ceil(total / 32) rounds of
+  // memory latency however unevenly the blocks are filled; prune: skip cells the current bound does not reach
+  auto walk_cells = [&](uint64_t cells, bool prune) {
+    int n_mine = __popcll(cells);
     int incl = n_mine;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
@@ -417,7 +417,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     int total = __shfl(incl, half_base + 31, 64);
     int tot_o = __shfl_xor(total, 32, 64);
     int rounds = ((total > tot_o ? total : tot_o) + 31) >> 5;  // same for both halves of the wave
-    unsigned rem_lo = (unsigned)(rem & 0xFFFFFFFFULL), rem_hi = (unsigned)(rem >> 32);
+    unsigned rem_lo = (unsigned)(cells & 0xFFFFFFFFULL), rem_hi = (unsigned)(cells >> 32);
     for (int rd = 0; rd < rounds; ++rd) {
       int r = rd * 32 + sub;
       bool act = r < total;
@@ -459,7 +459,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
               az = (float)max(abs(z - cz) - 1, 0);
         float lb2 = ((ax * ax + ay * ay) + az * az) * h2;
         float bnd = (cand >= 0 ? widen(cd) : rinf2) + margin;
-        if (!(lb2 > bnd)) scan_cell(x, y, z);
+        if (!prune || !(lb2 > bnd)) scan_cell(x, y, z);
       }
     }
     {
@@ -468,6 +468,20 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       reduce_half();
       if (BUD && mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
     }
+  };
+  if (__ballot(rem != 0)) walk_cells(rem, true);
+  // BUD, a query that has found nothing within the radius: every remaining occupied cell of its 27 blocks as
+  // well. It then knows the distance to the nearest point of the whole region and that everything else lies
+  // beyond the region's boundary -- a budget that usually lasts for the rest of the registration, where the
+  // ball alone says "nothing within mu" and is searched again as soon as something has moved that far.
+  bool region_done = false;
+  if (BUD) {
+    uint64_t rest = 0;
+    // (all of them again, also those of the ball: its walk may have skipped a cell by its distance bound,
+    //  and a point met twice changes nothing while there is no partner)
+    if (valid && cand < 0 && sub < 27) rest = mymask & ~g2_box_mask(X, Y, Z, cx, cy, cz, 1);
+    if (__ballot(rest != 0)) walk_cells(rest, false);
+    region_done = valid0 && cand < 0;
   }
   if (best_dist2) *best_dist2 = cand >= 0 ? cd : d.radius2;
   if (BUD) {
@@ -479,14 +493,15 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       if (cand >= 0) {
         // every point within spatial distance s1 + mu has been looked at: the runner-up is at least that far
         bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, widen(cd)), d.radius2);
-      } else if (!any_block) {
-        // nothing at all in the 3 x 3 x 3 blocks: the nearest point lies beyond their boundary
+      } else if (!any_block || region_done) {
+        // nothing within the radius; every point of the 3 x 3 x 3 blocks has been looked at (cd2; none at
+        // all: +inf), the rest lies beyond their boundary
         float fx = (p.y - d.lo[0]) / d.h, fy = (p.z - d.lo[1]) / d.h, fz = (p.w - d.lo[2]) / d.h;
         float ex = fminf(fx - (float)(4 * (bx - 1)), (float)(4 * (bx + 2)) - fx);
         float ey = fminf(fy - (float)(4 * (by - 1)), (float)(4 * (by + 2)) - fy);
         float ez = fminf(fz - (float)(4 * (bz - 1)), (float)(4 * (bz + 2)) - fz);
-        float e = fmaxf(fminf(fminf(ex, ey), ez), 0.f) * d.h;
-        bud = icp_cache_budget_none(e * e, d.radius2 - dfsq, d.radius2);
+        float e = fmaxf(fminf(fminf(ex, ey), ez), 0.f) * d.h * 0.9999f;
+        bud = icp_cache_budget_none(fminf(cd2 - dfsq, e * e), d.radius2 - dfsq, d.radius2);
       } else {
         bud = icp_cache_budget_none(fminf(cd2 - dfsq, rinf2), d.radius2 - dfsq, d.radius2);
       }

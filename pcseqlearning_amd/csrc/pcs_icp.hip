@@ -35,6 +35,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdio>
 #include <mutex>
 
@@ -199,7 +200,6 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->loop_iters = 0;
     st->mode = 0;
     st->phase_ticks[0] = st->phase_ticks[1] = st->phase_ticks[2] = st->phase_ticks[3] = 0ULL;
-    st->dbg[0] = st->dbg[1] = st->dbg[2] = st->dbg[3] = 0ULL;
   }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {  // (component-minor: word e of every component side by side)
     int e = (int)((q / C) & 15);
@@ -355,6 +355,7 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
 constexpr int kMomSlots = 64;        // wide budget-test workgroups (256 threads, a few rounds of queries)
 constexpr int kMomSlotsSearch = 16;  // a wide search item settles 8 or 32 pairs: a small table keeps its reset and drain short
 constexpr int kMomSlotsLoop = 512;   // the unit-resident loop: one table for ALL pairs of an iteration
+constexpr int kHeavyBit = 1 << 30;   // tile path: flag of a work-list entry (query ids stay below 2^26)
 constexpr int kMomProbes = 8;        // slots a component may be looked for in before its pair goes to global memory
 struct MomTable {
   int* skey;                      // LDS [nslots]
@@ -490,7 +491,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 // partner is near enough to be searched around (g2_nearest_seeded8). Exact: the same neighbours as a
 // full search, always. Workgroup wgx of nwg takes the rounds wgx, wgx + nwg, ... of BS queries; s_step
 // is the step table of iteration k-1 (in LDS when the workgroup serves backward queries).
-template <int BS>
+template <int BS, bool SPLIT = true>
 __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, int Mn, int Rn, int wgx, int nwg,
                                                  const GridDesc& g, const MomTable& mt,
                                                  const unsigned int* __restrict__ s_step, int* cnt4) {
@@ -512,6 +513,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
     const bool valid = qid < nq;
     const bool fwd = qid < Mn;
     bool to_seeded = false, to_coop = false;
+    bool heavy = false;  // (SPLIT = false) a failed query without a partner inside the radius to start from
     bool m_act = false;  // a settled pair whose moments are due: (moving point, reference point, component)
     float4 m_p = make_float4(0.f, 0.f, 0.f, 0.f), m_q = m_p;
     int m_c = 0;
@@ -544,6 +546,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
       }
       bud = bud - disp * 1.000001f - 1e-7f;
       float dist2 = __builtin_inff();
+      float c0s = 0.f;  // the frame term of the distance
       if (s >= 0) {
         sp = fwd ? pr.ref[s] : pr.mov[s];
         float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
@@ -552,6 +555,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
         dist2 = dist2 + d1 * d1;
         dist2 = dist2 + d2 * d2;
         dist2 = dist2 + d3 * d3;
+        c0s = d0 * d0;
       }
       if (bud > 1e-5f) {
         // still exact: nothing has moved far enough to change the answer
@@ -568,10 +572,16 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
           m_q = fwd ? sp : p;
           m_c = pr.comp[fwd ? qid : s];
         }
-      } else if (s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
-        to_seeded = true;
+      } else if (SPLIT && s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
+        to_seeded = true;  // (the tile path has ONE kind of search: SPLIT = false)
       } else {
         to_coop = true;
+        if (!SPLIT) {
+          // a query whose old partner is so near that the ball through it (+ mu) stays inside the 27 cells
+          // around the query is searched by one lane; the others take a wave each (tile_nearest_wave)
+          const float r = sqrtf(fmaxf(dist2 - c0s, 0.f)) + pr.mu;
+          heavy = !(s >= 0 && dist2 <= g.radius2 && g.h * g.h * 0.998f > r * r + (1e-5f * g.radius2 + 1e-6f));
+        }
       }
     }
     mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
@@ -592,7 +602,8 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
         int base = 0;
         if (lane == 0) base = atomicAdd(&cnt4[dir], __popcll(mc));
         base = __shfl(base, 0, 64);
-        if (to_coop && fwd == (dir == 0)) pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid;
+        if (to_coop && fwd == (dir == 0))
+          pr.wl[off + base + __popcll(mc & ((1ULL << lane) - 1ULL))] = qid | (heavy ? kHeavyBit : 0);
       }
     }
   }
@@ -1329,7 +1340,7 @@ __device__ __noinline__ void loop_apply_phase(const IcpProblem* __restrict__ prp
 
 __global__ void __launch_bounds__(kLoopBlock)
 icp_loop_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, int wide_limit, unsigned int budget_ticks,
-                IcpState* __restrict__ out) {
+                int all_modes, IcpState* __restrict__ out) {
   const IcpProblem* prp = tab + bt.idx[blockIdx.x];
   IcpState* st = prp->st;
   __shared__ int s_go;
@@ -1348,7 +1359,7 @@ icp_loop_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, int wide
     if (threadIdx.x == 0) {
       t0 = __builtin_amdgcn_s_memrealtime();
       bool go = !(k <= wide_limit || k > prp->max_iter || k > st->stop_iter);  // (k <= wide_limit: a wide launch's)
-      if (st->mode == 1) go = false;  // a registration of the tile path: icp_tile_kernel's
+      if (st->mode == 1 || (!all_modes && st->mode == 0)) go = false;  // a registration of the tile path: icp_tile_kernel's
       if (go && budget_ticks && done > 0 && t0 - t_begin > (unsigned long long)budget_ticks) go = false;
       s_go = go ? 1 : 0;
       l_cnt[0] = l_cnt[1] = l_cnt[2] = l_cnt[3] = 0;
@@ -1386,49 +1397,54 @@ icp_loop_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, int wide
 }
 
 // ============================================================ the tile path of the unit-resident loop
-// The searches above walk hash grids in global memory: every probe and every row of candidates is a
-// scattered 16-byte request through the CU's L1 (~250 per searched query) and a chain of dependent
-// loads -- one CU spent ~900 us per iteration of a 24 k-query unit in them. The tile path keeps the
-// candidates in LDS instead:
+// The searches of the cache path walk hash grids in global memory: every probe and every row of
+// candidates is a scattered 16-byte request through the CU's L1 (~250 per searched query) and a chain of
+// dependent loads -- one CU spent ~900 us per iteration of a 24 k-query unit in them. The tile path keeps
+// the verified cache (the budget test, lean) and serves the queries that fail it from LDS:
 //   * both clouds are kept SORTED BY BLOCK ROW (a block = 4 x 4 fine cells in x / y, all z; a row = the
-//     blocks of one y range): the static reference cloud once per registration, the moving cloud after
-//     every apply (a counting sort with the row counters in LDS). h = (spatial radius + margin) / 4, so a
-//     query's search ball lies inside its own row and the two next to it;
+//     blocks of one y range): the static reference cloud once per registration, the moving cloud at the
+//     start of every iteration (a counting sort with the row counters in LDS). h = (spatial radius + mu) / 4,
+//     so a query's widened search ball lies inside its own row and the two next to it;
 //   * a BAND = as many consecutive rows as fit: their points and the rows on either side -- one contiguous,
-//     coalesced range of the sorted cloud, at most kTileCap points -- are copied into LDS and threaded into
-//     direct-mapped cell buckets (bucket = hash of the fine cell -> chain of staged points; cells that
-//     share a bucket share a chain: a query then looks at a few points more, never at fewer) and
-//     direct-mapped 64-bit occupancy masks of the 4 x 4 x 4-cell blocks (OR of whatever shares the slot);
-//   * the queries of the band's rows -- a contiguous range of the OTHER cloud's sorted copy -- then search
-//     with ONE LANE each, in LDS only: the 27 cells around the query; if the best point so far (or the
-//     radius) still admits something further out, the occupied cells of the 27 blocks around it, each
-//     pruned by its distance bound. No hash keys, no probing loops, no global memory in the search.
-// The search is exact (conservative pruning; the canonical order (dist2, original index) decides), so it
-// returns what the cooperative search returns, bit for bit -- and it is cheap enough that every query
-// searches in every iteration: the tile path has no verified cache, no work lists, no step table and no
-// global grid of the moving points. Forward queries (moving -> reference) and backward queries take their
-// turns on the same LDS. Preconditions (one frame value per cloud, at most kTileRows rows, no three rows
-// with more than kTileCap points) are checked by the first launch; registrations that fail them take
-// the cache path (icp_loop_kernel), decided on the device, no host round trip.
+//     coalesced range of the sorted cloud, at most kTileCap points -- are copied into LDS SORTED BY CELL
+//     BUCKET (bucket = hash of the fine cell; a counting sort, so a bucket's points are one contiguous run;
+//     cells that share a bucket share a run: a query then looks at a few points more, never at fewer)
+//     beside direct-mapped 64-bit occupancy masks of the 4 x 4 x 4-cell blocks (OR of whatever shares the
+//     slot);
+//   * the failed queries, sorted by the band their row belongs to, then search with ONE LANE each, in LDS
+//     only: the query's own cell, the neighbours whose distance bound admits a point that matters, and --
+//     if the best so far (or the radius) still reaches further -- the occupied cells of the 27 blocks
+//     around it. No hash keys, no probing loops, no pointer chasing, no global memory in the search.
+// The search is exact (conservative pruning; the canonical order (dist2, original index) decides) and
+// returns the same validity budget statement as the cooperative search (everything within the nearest
+// distance + mu has been looked at), so the two paths produce the same neighbours bit for bit. There
+// is no global grid of the moving points any more: apply only moves them. Preconditions (one frame value
+// per cloud, at most kTileRows rows, no three rows with more than kTileCap points) are checked by the
+// first launch; registrations that fail them take the cache path (icp_loop_kernel), decided on the
+// device, no host round trip.
 constexpr int kTileCap = 4096;      // candidates staged at once
 constexpr int kTileBuckets = 8192;  // cell buckets (>= 2 per staged point)
 constexpr int kTileBlocks = 2048;   // block occupancy masks
 constexpr int kTileMomSlots = 64;
-__shared__ float4 t_pts[kTileCap];              // staged candidates: (original index bits, x, y, z)
-__shared__ unsigned int t_head[kTileBuckets];   // bucket -> last staged point + 1 (0: none); scratch of the binning
-__shared__ unsigned short t_next[kTileCap];     // chain: next staged point + 1
+constexpr int kTileBands = 64;      // bands a cloud may be cut into (kTileCap points each: 256 k points)
+__shared__ float4 t_pts[kTileCap];              // staged candidates by bucket: (original index bits, x, y, z)
+__shared__ unsigned int t_head[kTileBuckets];   // bucket -> first staged point << 16 | points; scratch of the binning
 __shared__ unsigned long long t_bmask[kTileBlocks];
 __shared__ int t_rowr[kTileRows + 1];           // first sorted reference point of every block row
 __shared__ int t_rowm[kTileRows + 1];           // the same for the moving points of this iteration
+__shared__ unsigned int t_step[kStepH];         // the step table of iteration k-1 (budget test)
 __shared__ int t_key[kTileMomSlots];
 __shared__ unsigned long long t_acc[kTileMomSlots * 17];
+__shared__ short t_band_lo[kTileBands + 1];     // band b = rows [lo[b], lo[b+1]) of the candidates' cloud
+__shared__ int t_boff[2 * kTileBands + 1];      // the failed queries of band b: [off[2b], off[2b+2]) of the sorted list,
+__shared__ int t_bcur[2 * kTileBands];          // those with a partner to start from first
 __shared__ int t_wsum[kLoopBlock / 64 + 1];
+__shared__ int t_cnt[4];
 __shared__ int t_flag[4];
-__shared__ unsigned long long t_dbg[4];
 
 struct TileGeom {
   float lo0, lo1, lo2, inv_h, h;
-  float radius2, margin;
+  float radius2, margin, mu;
   int nrows;
 };
 __device__ __forceinline__ TileGeom tile_geom(const IcpProblem& pr) {
@@ -1439,6 +1455,7 @@ __device__ __forceinline__ TileGeom tile_geom(const IcpProblem& pr) {
   t.inv_h = 1.f / g.h;
   t.radius2 = g.radius2;
   t.margin = 1e-5f * g.radius2 + 1e-6f;
+  t.mu = pr.mu;
   // block rows: the y extent of both clouds as they arrive, plus the pad the grid origin was given
   const float ymax = fmaxf(pr.bounds[6], pr.bounds[14]);
   const float cyf = floorf((ymax + pr.pad - g.lo[1]) * t.inv_h);
@@ -1453,39 +1470,55 @@ __device__ __forceinline__ MomTable tile_mom_table(const IcpProblem& pr, int k) 
 __device__ __forceinline__ int tile_cell(float v, float lo, float inv_h) { return (int)floorf((v - lo) * inv_h); }
 constexpr unsigned kTP1 = 73856093u, kTP2 = 19349663u, kTP3 = 83492791u;
 __device__ __forceinline__ unsigned tile_mix(unsigned h) { return h ^ (h >> 15); }
+__device__ __forceinline__ unsigned tile_bucket(int cx, int cy, int cz) {
+  return tile_mix((unsigned)cx * kTP1 ^ (unsigned)cy * kTP2 ^ (unsigned)cz * kTP3) & (kTileBuckets - 1);
+}
+__device__ __forceinline__ int tile_row_of(const TileGeom& t, float4 p) {  // block row of a point, -1: outside
+  const int cy = tile_cell(p.z, t.lo1, t.inv_h), cx = tile_cell(p.y, t.lo0, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
+  const int r = cy >> 2;
+  return (cx < 0 || cy < 0 || cz < 0 || r >= t.nrows || cx >= kCoordMax || cz >= kCoordMax) ? -1 : r;
+}
+// exclusive prefix of one int per thread over the workgroup (kLoopBlock threads); *total = the sum
+__device__ __forceinline__ int tile_wg_scan(int mine, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  __syncthreads();  // (t_wsum may still be read from the last call)
+  if (lane == 63) t_wsum[wv] = incl;
+  __syncthreads();
+  int before = 0, all = 0;
+  for (int q = 0; q < kLoopBlock / 64; ++q) {
+    const int v = t_wsum[q];
+    if (q < wv) before += v;
+    all += v;
+  }
+  *total = all;
+  return before + incl - mine;
+}
 
 // counting sort of a cloud by block row: dst = (index bits, x, y, z) row by row, rows[r] = first point of
 // row r (rows[r] = n from the last occupied row on, for every r <= kTileRows). Points of a row arrive in
-// arbitrary order: nothing downstream depends on it.
+// arbitrary order: nothing downstream depends on it. Points outside the rows raise *err.
 __device__ __forceinline__ void tile_bin(const float4* __restrict__ src, int n, float4* __restrict__ dst, int* rows,
                                          const TileGeom& t, int* __restrict__ err) {
+  static_assert(kTileRows == kLoopBlock, "one row counter per thread");
   int* hist = (int*)t_head;
   int* cur = hist + kTileRows;
   for (int q = threadIdx.x; q < 2 * kTileRows; q += kLoopBlock) hist[q] = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += kLoopBlock) {
-    const float4 p = src[i];
-    const int cy = tile_cell(p.z, t.lo1, t.inv_h), cx = tile_cell(p.y, t.lo0, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
-    int r = cy >> 2;
-    if (cx < 0 || cy < 0 || cz < 0 || r >= t.nrows || cx >= kCoordMax || cz >= kCoordMax) { *err = 1; r = 0; }
+    int r = tile_row_of(t, src[i]);
+    if (r < 0) { *err = 1; r = 0; }
     atomicAdd(&hist[r], 1);
   }
   __syncthreads();
-  {  // exclusive prefix of the kTileRows = kLoopBlock counters, one per thread
-    static_assert(kTileRows == kLoopBlock, "one row counter per thread");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int mine = hist[threadIdx.x];
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) t_wsum[wv] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int q = 0; q < wv; ++q) before += t_wsum[q];
-    const int ex = before + incl - mine;
+  {
+    int total;
+    const int ex = tile_wg_scan(hist[threadIdx.x], &total);
     rows[threadIdx.x] = ex;
     cur[threadIdx.x] = ex;
     if (threadIdx.x == 0) rows[kTileRows] = n;
@@ -1493,17 +1526,16 @@ __device__ __forceinline__ void tile_bin(const float4* __restrict__ src, int n, 
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += kLoopBlock) {
     const float4 p = src[i];
-    const int cy = tile_cell(p.z, t.lo1, t.inv_h), cx = tile_cell(p.y, t.lo0, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
-    int r = cy >> 2;
-    if (cx < 0 || cy < 0 || cz < 0 || r >= t.nrows || cx >= kCoordMax || cz >= kCoordMax) r = 0;
+    int r = tile_row_of(t, p);
+    if (r < 0) r = 0;
     const int pos = atomicAdd(&cur[r], 1);
-    if (pos < 0 || pos >= n) { atomicExch(err, 103); continue; }
+    if (pos < 0 || pos >= n) { atomicExch(err, 103); continue; }  // (cannot happen: the same rows as counted)
     dst[pos] = make_float4(__int_as_float(i), p.y, p.z, p.w);
   }
   __syncthreads();
 }
 
-// largest number of points in three consecutive rows (what a band of one row stages)
+// largest number of points in three consecutive rows (what a band of one row stages), per wave
 __device__ __forceinline__ int tile_max_triple(const int* rows, int nrows) {
   int v = 0;
   for (int r = threadIdx.x; r < nrows; r += kLoopBlock) {
@@ -1512,82 +1544,160 @@ __device__ __forceinline__ int tile_max_triple(const int* rows, int nrows) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;  // (per wave; the caller combines)
+  return v;
 }
 
-// a band's candidates: rows of the sorted cloud [s0, s0 + ns) into LDS, cell buckets and block masks
+// The bands of a cloud (candidates): greedily as many rows as fit kTileCap with the rows on either side.
+// Every thread forms the same table; returns the number of bands (t_band_lo[nb] = nrows), -1 if three rows
+// do not fit or there are more than kTileBands.
+__device__ __forceinline__ int tile_plan_bands(const int* crow, int nrows) {
+  int nb = 0, r0 = 0;
+  while (r0 < nrows) {
+    const int s0 = crow[r0 > 0 ? r0 - 1 : 0];
+    int r1 = r0 + 1;
+    if (crow[r1 + 1 < nrows ? r1 + 1 : nrows] - s0 > kTileCap) return -1;
+    while (r1 < nrows && crow[r1 + 2 < nrows ? r1 + 2 : nrows] - s0 <= kTileCap) ++r1;
+    if (nb >= kTileBands) return -1;
+    if (threadIdx.x == 0) t_band_lo[nb] = (short)r0;
+    ++nb;
+    r0 = r1;
+  }
+  if (threadIdx.x == 0) t_band_lo[nb] = (short)nrows;
+  return nb;
+}
+
+// a band's candidates: rows of the sorted cloud [s0, s0 + ns) into LDS, sorted by cell bucket, and the
+// block masks. Three sweeps over the range (count, place; the points come from L2).
 __device__ __forceinline__ void tile_stage(const float4* __restrict__ srt, int s0, int ns, const TileGeom& t) {
   for (int q = threadIdx.x; q < kTileBuckets; q += kLoopBlock) t_head[q] = 0u;
   for (int q = threadIdx.x; q < kTileBlocks; q += kLoopBlock) t_bmask[q] = 0ULL;
   __syncthreads();
   for (int j = threadIdx.x; j < ns; j += kLoopBlock) {
     const float4 p = srt[s0 + j];
-    t_pts[j] = p;
     const int cx = tile_cell(p.y, t.lo0, t.inv_h), cy = tile_cell(p.z, t.lo1, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
-    const unsigned b = tile_mix((unsigned)cx * kTP1 ^ (unsigned)cy * kTP2 ^ (unsigned)cz * kTP3) & (kTileBuckets - 1);
-    const unsigned old = atomicExch(&t_head[b], (unsigned)(j + 1));
-    t_next[j] = (unsigned short)old;
+    atomicAdd(&t_head[tile_bucket(cx, cy, cz)], 1u);
     const unsigned bs = tile_mix((unsigned)(cx >> 2) * kTP2 ^ (unsigned)(cy >> 2) * kTP3 ^ (unsigned)(cz >> 2) * kTP1) &
                         (kTileBlocks - 1);
     const int bit = (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4);
     atomicOr(&t_bmask[bs], 1ULL << bit);
   }
   __syncthreads();
+  {  // starts: thread x owns buckets x, x + 1024, ... (any disjoint layout of the runs will do)
+    unsigned c[kTileBuckets / kLoopBlock];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < kTileBuckets / kLoopBlock; ++q) {
+      c[q] = t_head[threadIdx.x + q * kLoopBlock];
+      mine += (int)c[q];
+    }
+    int total;
+    int run = tile_wg_scan(mine, &total);
+#pragma unroll
+    for (int q = 0; q < kTileBuckets / kLoopBlock; ++q) {
+      t_head[threadIdx.x + q * kLoopBlock] = (unsigned)run << 16;
+      run += (int)c[q];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < ns; j += kLoopBlock) {
+    const float4 p = srt[s0 + j];
+    const int cx = tile_cell(p.y, t.lo0, t.inv_h), cy = tile_cell(p.z, t.lo1, t.inv_h), cz = tile_cell(p.w, t.lo2, t.inv_h);
+    const unsigned old = atomicAdd(&t_head[tile_bucket(cx, cy, cz)], 1u);
+    const unsigned pos = (old >> 16) + (old & 0xFFFFu);
+    if (pos < (unsigned)kTileCap) t_pts[pos] = p;
+  }
+  __syncthreads();
 }
 
 // The nearest staged point of (px, py, pz) within the radius under the canonical order (dist2, original
-// index); dist2 is formed exactly as the cooperative search forms it: ((c0 + dx^2) + dy^2) + dz^2 with
-// c0 = (frame difference)^2, the same for every pair of the direction. One lane per query, LDS only.
+// index), and for how long that answer stays exact (the statement of g2_nearest_coop<true>: everything
+// within the nearest spatial distance + mu -- without a partner: within the spatial radius + mu -- has
+// been looked at, so the runner-up is at least that far). dist2 is formed exactly as the cooperative
+// search forms it: ((c0 + dx^2) + dy^2) + dz^2 with c0 = (frame difference)^2, the same for every pair
+// of the direction. One lane per query, LDS only.
 struct TileHit {
-  float d2;
-  int idx;  // original index of the point, -1: none within the radius
-  int j;    // where it is staged
+  int idx;    // original index of the point, -1: none within the radius
+  int j;      // where it is staged
+  float bud;  // how far things may move before the answer can change
 };
-__device__ __forceinline__ TileHit tile_nearest(const TileGeom& t, float px, float py, float pz, float c0, int rings) {
-  const int cx = tile_cell(px, t.lo0, t.inv_h), cy = tile_cell(py, t.lo1, t.inv_h), cz = tile_cell(pz, t.lo2, t.inv_h);
-  float bd = 0.f;
+// seed_d2: the 4-D squared distance of a point KNOWN to be among the candidates and within the radius (the
+// partner of the last iteration), or +inf: the search then starts from the ball through that point.
+__device__ __forceinline__ TileHit tile_nearest(const TileGeom& t, float px, float py, float pz, float c0, float seed_d2) {
+  const float fx = (px - t.lo0) * t.inv_h, fy = (py - t.lo1) * t.inv_h, fz = (pz - t.lo2) * t.inv_h;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  // squared distance, in cells, from the query to the neighbouring cell at offset -1 / 0 / +1 per axis
+  const float ux = fx - flx, uy = fy - fly, uz = fz - flz;
+  const float gx0 = ux * ux, gx2 = (1.f - ux) * (1.f - ux);
+  const float gy0 = uy * uy, gy2 = (1.f - uy) * (1.f - uy);
+  const float gz0 = uz * uz, gz2 = (1.f - uz) * (1.f - uz);
+  const float rs = sqrtf(fmaxf(t.radius2 - c0, 0.f));
+  const float rinf2 = (rs + t.mu) * (rs + t.mu);
+  // the slack (0.2 %) covers the rounding of the cell coordinates (a point may sit a few 1e-5 cells outside
+  // its nominal cell)
+  const float h2s = t.h * t.h * 0.998f;
+  float bd = 0.f, cd2 = __builtin_inff();
   int bi = -1, bj = -1;
-  int ncand = 0;
-  auto scan_bucket = [&](unsigned hsh) {
-    unsigned j = t_head[tile_mix(hsh) & (kTileBuckets - 1)];
-    while (j) {
-      const float4 c = t_pts[j - 1];
+  float bound = rinf2 + t.margin;  // admissible |dxyz|^2 of a point that matters
+  if (seed_d2 <= t.radius2) {
+    const float r = sqrtf(fmaxf(seed_d2 - c0, 0.f)) + t.mu;
+    bound = r * r + t.margin;
+  }
+  auto scan_bucket = [&](unsigned b) {
+    const unsigned v = t_head[b];
+    const int s = (int)(v >> 16), e = s + (int)(v & 0xFFFFu);
+    bool better = false;
+    for (int j = s; j < e; ++j) {
+      const float4 c = t_pts[j];
       const float d1 = c.y - px, d2 = c.z - py, d3 = c.w - pz;
       float dist2 = c0;
       dist2 = dist2 + d1 * d1;
       dist2 = dist2 + d2 * d2;
       dist2 = dist2 + d3 * d3;
       const int oi = __float_as_int(c.x);
-      ++ncand;
+      if (oi == bi) continue;  // (cells that share a bucket: the best is met again)
       if (dist2 <= t.radius2 && (bi < 0 || dist2 < bd || (dist2 == bd && oi < bi))) {
+        if (bi >= 0) cd2 = fminf(cd2, bd);
         bd = dist2;
         bi = oi;
-        bj = (int)j - 1;
+        bj = j;
+        better = true;
+      } else {
+        cd2 = fminf(cd2, dist2);
       }
-      j = t_next[j - 1];
+    }
+    if (better) {
+      const float r = sqrtf(fmaxf(bd - c0, 0.f)) + t.mu;
+      bound = fminf(bound, r * r + t.margin);
     }
   };
-  // ---- the 27 cells around the query
-  {
-    const unsigned hx0 = (unsigned)(cx - 1) * kTP1, hy0 = (unsigned)(cy - 1) * kTP2, hz0 = (unsigned)(cz - 1) * kTP3;
+  // ---- the query's own cell, then the 26 around it that the bound still reaches
+  scan_bucket(tile_bucket(cx, cy, cz));
 #pragma unroll 1
-    for (int dz = 0; dz < 3; ++dz) {
-      const unsigned hz = hz0 + (unsigned)dz * kTP3;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const float gz = dz < 0 ? gz0 : (dz > 0 ? gz2 : 0.f);
 #pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy) {
-        const unsigned hyz = hz ^ (hy0 + (unsigned)dy * kTP2);
-        scan_bucket(hyz ^ hx0);
-        scan_bucket(hyz ^ (hx0 + kTP1));
-        scan_bucket(hyz ^ (hx0 + 2u * kTP1));
+    for (int dy = -1; dy <= 1; ++dy) {
+      const float gyz = gz + (dy < 0 ? gy0 : (dy > 0 ? gy2 : 0.f));
+      if (gyz * h2s > bound) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        if ((dx | dy | dz) == 0) continue;
+        const float g = gyz + (dx < 0 ? gx0 : (dx > 0 ? gx2 : 0.f));
+        if (g * h2s > bound) continue;
+        scan_bucket(tile_bucket(cx + dx, cy + dy, cz + dz));
       }
     }
   }
-  // ---- further out: everything at Chebyshev distance >= 2 cells is at least h away. The slack (0.2 %) covers
-  //      the rounding of the cell coordinates (a point may sit a few 1e-5 cells outside its nominal cell)
-  const float h2s = t.h * t.h * 0.998f;
-  float bound = (bi >= 0 ? bd - c0 : t.radius2 - c0) + t.margin;  // admissible |dxyz|^2 of a point that matters
-  if (rings >= 2 && !(h2s > bound)) {
-    atomicAdd(&t_dbg[1], 1ULL);
+  // ---- further out: everything at Chebyshev distance >= 2 cells is at least h away. A query that has
+  //      found nothing yet looks at EVERY occupied cell of the 27 blocks around it (whole = true): if it
+  //      stays without partner it then knows the distance to the nearest point of the whole region, and that
+  //      everything else lies beyond the region -- a budget that usually lasts for the rest of the
+  //      registration, where the ball of radius + mu alone says "nothing within mu" and is searched again
+  //      as soon as something has moved that far.
+  float lb_none2 = fminf(cd2 - c0, rinf2);  // without partner: squared lower bound of the nearest point's distance
+  if (!(h2s > bound)) {
+    const bool whole = bi < 0 && !(seed_d2 <= t.radius2);  // (with a seed there IS a point within the bound)
     const int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
 #pragma unroll 1
     for (int q = 0; q < 27; ++q) {
@@ -1599,32 +1709,206 @@ __device__ __forceinline__ TileHit tile_nearest(const TileGeom& t, float px, flo
         m &= m - 1ULL;
         const int x = 4 * X + (bit & 3), y = 4 * Y + ((bit >> 2) & 3), z = 4 * Z + (bit >> 4);
         const int ax = abs(x - cx), ay = abs(y - cy), az = abs(z - cz);
-        if (max(max(ax, ay), az) <= 1) continue;  // (looked at above)
-        const float fx = (float)max(ax - 1, 0), fy = (float)max(ay - 1, 0), fz = (float)max(az - 1, 0);
-        const float lb2 = ((fx * fx + fy * fy) + fz * fz) * h2s;
-        if (lb2 > bound) continue;
-        scan_bucket((unsigned)x * kTP1 ^ (unsigned)y * kTP2 ^ (unsigned)z * kTP3);
-        bound = (bi >= 0 ? bd - c0 : t.radius2 - c0) + t.margin;
+        const float ex = (float)max(ax - 1, 0), ey = (float)max(ay - 1, 0), ez = (float)max(az - 1, 0);
+        const bool reach = !(((ex * ex + ey * ey) + ez * ez) * h2s > bound);
+        if (max(max(ax, ay), az) <= 1) {
+          // a near cell: looked at above unless the bound pruned it -- which only the whole-region scan undoes
+          if (!(whole && bi < 0)) continue;
+          const float g = (x < cx ? gx0 : (x > cx ? gx2 : 0.f)) + (y < cy ? gy0 : (y > cy ? gy2 : 0.f)) +
+                          (z < cz ? gz0 : (z > cz ? gz2 : 0.f));
+          if (!(g * h2s > bound)) continue;  // (it was within the bound, hence looked at)
+        } else if (!reach && !(whole && bi < 0)) {
+          continue;
+        }
+        scan_bucket(tile_bucket(x, y, z));
+      }
+    }
+    if (whole && bi < 0) {
+      // nothing within the radius; every point of the 3 x 3 x 3 blocks has been looked at (cd2), the rest
+      // lies beyond their boundary
+      const float eX = fminf(fx - (float)(4 * (bx - 1)), (float)(4 * (bx + 2)) - fx);
+      const float eY = fminf(fy - (float)(4 * (by - 1)), (float)(4 * (by + 2)) - fy);
+      const float eZ = fminf(fz - (float)(4 * (bz - 1)), (float)(4 * (bz + 2)) - fz);
+      const float e = fmaxf(fminf(fminf(eX, eY), eZ), 0.f) * t.h * 0.999f;
+      lb_none2 = fminf(cd2 - c0, e * e);
+    } else if (bi < 0) {
+      lb_none2 = fminf(cd2 - c0, rinf2);
+    }
+  }
+  TileHit hit;
+  hit.idx = bi;
+  hit.j = bj;
+  hit.bud = bi >= 0 ? icp_cache_budget(bd - c0, fminf(cd2 - c0, bound - t.margin), t.radius2)
+                    : icp_cache_budget_none(lb_none2, t.radius2 - c0, t.radius2);
+  return hit;
+}
+
+// The same search by a WHOLE WAVE for one query (uniform arguments): for the queries that have no partner to
+// start from -- their ball is the full radius + mu, hundreds of cells, and without a partner every occupied
+// cell of the 27 blocks (see above). One lane took ~100 k instructions for such a query, and a wave waits for
+// its slowest lane. Here lanes 0..26 fetch the block masks, keep the cells the bound reaches, and the set bits
+// of all 27 masks are dealt to the 64 lanes (rank r -> lane r % 64), so the walk takes ceil(cells / 64) rounds.
+__device__ __forceinline__ TileHit tile_nearest_wave(const TileGeom& t, float px, float py, float pz, float c0,
+                                                     float seed_d2) {
+  const int lane = threadIdx.x & 63;
+  const float fx = (px - t.lo0) * t.inv_h, fy = (py - t.lo1) * t.inv_h, fz = (pz - t.lo2) * t.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  const int bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+  const float rs = sqrtf(fmaxf(t.radius2 - c0, 0.f));
+  const float rinf2 = (rs + t.mu) * (rs + t.mu);
+  const float h2s = t.h * t.h * 0.998f;
+  float bd = 0.f, cd2 = __builtin_inff();
+  int bi = -1, bj = -1;
+  float bound = rinf2 + t.margin;
+  const bool seeded = seed_d2 <= t.radius2;  // a point known to be among the candidates, inside the radius
+  if (seeded) {
+    const float r = sqrtf(fmaxf(seed_d2 - c0, 0.f)) + t.mu;
+    bound = r * r + t.margin;
+  }
+  auto scan_bucket = [&](unsigned b) {
+    const unsigned v = t_head[b];
+    const int s = (int)(v >> 16), e = s + (int)(v & 0xFFFFu);
+    for (int j = s; j < e; ++j) {
+      const float4 c = t_pts[j];
+      const float d1 = c.y - px, d2 = c.z - py, d3 = c.w - pz;
+      float dist2 = c0;
+      dist2 = dist2 + d1 * d1;
+      dist2 = dist2 + d2 * d2;
+      dist2 = dist2 + d3 * d3;
+      const int oi = __float_as_int(c.x);
+      if (oi == bi) continue;
+      if (dist2 <= t.radius2 && (bi < 0 || dist2 < bd || (dist2 == bd && oi < bi))) {
+        if (bi >= 0) cd2 = fminf(cd2, bd);
+        bd = dist2;
+        bi = oi;
+        bj = j;
+      } else {
+        cd2 = fminf(cd2, dist2);
+      }
+    }
+  };
+  const int X = bx + lane % 3 - 1, Y = by + (lane / 3) % 3 - 1, Z = bz + (lane / 9) % 3 - 1;
+  unsigned long long mymask = 0ULL;
+  if (lane < 27)
+    mymask = t_bmask[tile_mix((unsigned)X * kTP2 ^ (unsigned)Y * kTP3 ^ (unsigned)Z * kTP1) & (kTileBlocks - 1)];
+  // the cells of this lane's block within the bound: the squared bound separates into per-axis terms (small
+  // integers), so the 64 tests are 16 thresholds on 4 values
+  unsigned long long ball = 0ULL;
+  {
+    float ax2[4], ay2[4], az2[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float tx = (float)max(abs(4 * X + a - cx) - 1, 0), ty = (float)max(abs(4 * Y + a - cy) - 1, 0),
+                  tz = (float)max(abs(4 * Z + a - cz) - 1, 0);
+      ax2[a] = tx * tx; ay2[a] = ty * ty; az2[a] = tz * tz;
+    }
+    const float lim = (bound / h2s) * 1.00001f + 1e-5f;
+#pragma unroll
+    for (int zz = 0; zz < 4; ++zz) {
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        const float tt = lim - az2[zz] - ay2[yy];
+        const unsigned xb = (unsigned)(ax2[0] <= tt) | ((unsigned)(ax2[1] <= tt) << 1) |
+                            ((unsigned)(ax2[2] <= tt) << 2) | ((unsigned)(ax2[3] <= tt) << 3);
+        ball |= (unsigned long long)xb << (4 * yy + 16 * zz);
       }
     }
   }
-  atomicAdd(&t_dbg[0], 1ULL);
-  if (bi < 0) atomicAdd(&t_dbg[2], 1ULL);
-  atomicAdd(&t_dbg[3], (unsigned long long)ncand);
+  // deal the cells `cells` (bits of lanes 0..26) to the 64 lanes and scan them
+  auto walk = [&](unsigned long long cells) {
+    const int n_mine = __popcll(cells);
+    int incl = n_mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    const unsigned c_lo = (unsigned)(cells & 0xFFFFFFFFULL), c_hi = (unsigned)(cells >> 32);
+    for (int base = 0; base < total; base += 64) {
+      const int r = base + lane;
+      const bool act = r < total;
+      int lo = 0, hi = 26;  // owner: the first lane whose inclusive count exceeds r
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const int v = __shfl(incl, mid, 64);
+        if (v <= r) lo = mid + 1; else hi = mid;
+      }
+      const int q = act ? min(lo, 26) : 0;
+      const int q_incl = __shfl(incl, q, 64);
+      const unsigned m_lo = __shfl(c_lo, q, 64), m_hi = __shfl(c_hi, q, 64);
+      if (act) {
+        int kk = r - (q_incl - (__popc(m_lo) + __popc(m_hi)));  // rank within the owner's mask
+        unsigned w = m_lo;
+        int pos = 0, c = __popc(m_lo);
+        if (kk >= c) { kk -= c; w = m_hi; pos = 32; }
+        c = __popc(w & 0xFFFFu);
+        if (kk >= c) { kk -= c; w >>= 16; pos += 16; }
+        w &= 0xFFFFu;
+        c = __popc(w & 0xFFu);
+        if (kk >= c) { kk -= c; w >>= 8; pos += 8; }
+        w &= 0xFFu;
+        c = __popc(w & 0xFu);
+        if (kk >= c) { kk -= c; w >>= 4; pos += 4; }
+        w &= 0xFu;
+        c = __popc(w & 0x3u);
+        if (kk >= c) { kk -= c; w >>= 2; pos += 2; }
+        w &= 0x3u;
+        if (kk >= (int)(w & 1u)) pos += 1;
+        const int QX = bx + q % 3 - 1, QY = by + (q / 3) % 3 - 1, QZ = bz + q / 9 - 1;
+        scan_bucket(tile_bucket(4 * QX + (pos & 3), 4 * QY + ((pos >> 2) & 3), 4 * QZ + (pos >> 4)));
+      }
+    }
+  };
+  // best of the wave; a lane whose own best lost keeps it as a non-best distance
+  auto reduce = [&]() {
+    const int mine = bi;
+    const float mine_d = bd;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int oi = __shfl_xor(bi, o, 64);
+      const float od = __shfl_xor(bd, o, 64);
+      const int oj = __shfl_xor(bj, o, 64);
+      const bool take = oi >= 0 && (bi < 0 || od < bd || (od == bd && oi < bi));
+      if (take) { bi = oi; bd = od; bj = oj; }
+    }
+    if (mine >= 0 && mine != bi) cd2 = fminf(cd2, mine_d);
+  };
+  walk(mymask & ball);
+  reduce();
+  bool whole = false;
+  if (bi < 0 && !seeded) {  // (uniform) nothing within the radius: the rest of the 27 blocks, for the budget
+    walk(mymask & ~ball);
+    reduce();
+    whole = bi < 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cd2 = fminf(cd2, __shfl_xor(cd2, o, 64));
   TileHit hit;
-  hit.d2 = bd;
   hit.idx = bi;
   hit.j = bj;
+  if (bi >= 0) {
+    const float r = sqrtf(fmaxf(bd - c0, 0.f)) + t.mu;
+    hit.bud = icp_cache_budget(bd - c0, fminf(cd2 - c0, r * r), t.radius2);
+  } else if (whole) {
+    const float eX = fminf(fx - (float)(4 * (bx - 1)), (float)(4 * (bx + 2)) - fx);
+    const float eY = fminf(fy - (float)(4 * (by - 1)), (float)(4 * (by + 2)) - fy);
+    const float eZ = fminf(fz - (float)(4 * (bz - 1)), (float)(4 * (bz + 2)) - fz);
+    const float e = fmaxf(fminf(fminf(eX, eY), eZ), 0.f) * t.h * 0.999f;
+    hit.bud = icp_cache_budget_none(fminf(cd2 - c0, e * e), t.radius2 - c0, t.radius2);
+  } else {
+    hit.bud = icp_cache_budget_none(fminf(cd2 - c0, rinf2), t.radius2 - c0, t.radius2);
+  }
   return hit;
 }
 
 // per direction: do the frames of the two clouds meet at all (the reference's frame-cell walk:
-// round((f - lo0) / vs0) + 1 of the query, plus the frame offset, must be the candidates' frame cell), the
-// constant frame term of every distance, the number of cell rings the radius reaches
+// round((f - lo0) / vs0) + 1 of the query, plus the frame offset, must be the candidates' frame cell) and
+// the constant frame term of every distance
 struct TileDir {
   bool ok;
   float c0;
-  int rings;
 };
 __device__ __forceinline__ TileDir tile_dir(const IcpProblem& pr, const TileGeom& t, float f_query, float f_cand, int df) {
   const GridDesc g = pr.geom->g;
@@ -1632,70 +1916,169 @@ __device__ __forceinline__ TileDir tile_dir(const IcpProblem& pr, const TileGeom
   const int fq = frame_cell(g, f_query) + df, fc = frame_cell(g, f_cand);
   const float dfl = fabsf(f_cand - f_query);
   d.c0 = dfl * dfl;
-  const float budget = (t.radius2 - d.c0) + t.margin;
-  d.ok = fq == fc && fc >= 0 && fc < kFrameCells && budget >= 0.f;
-  d.rings = d.ok ? (int)ceilf(sqrtf(budget) / t.h) : 0;
-  if (d.rings > 4) {  // (cannot happen with the cell size icp_describe chooses)
+  const float rs = sqrtf(fmaxf(t.radius2 - d.c0, 0.f));
+  const float budget = (rs + t.mu) * (rs + t.mu) + t.margin;
+  d.ok = fq == fc && fc >= 0 && fc < kFrameCells && t.radius2 - d.c0 + t.margin >= 0.f;
+  if (d.ok && (int)ceilf(sqrtf(budget) / t.h) > 4) {  // (cannot happen with the cell size icp_describe chooses)
     if (threadIdx.x == 0) atomicExch(&pr.st->err, 1);
-    d.rings = 4;
+    d.ok = false;
   }
   return d;
 }
 
-// One direction of an iteration: FWD: candidates = reference rows, queries = moving points; else the roles
-// are swapped. Bands are formed greedily over the candidates' rows; every thread forms the same bands from
-// the row tables in LDS.
+// The failed queries of one direction (pr.wl + list offset, n of them, unsorted) against the other cloud:
+// FWD: moving points against the reference rows, else reference points against the moving rows. The list
+// is first sorted by band (pr.wls), then every band with queries is staged and searched. Results: neighbour
+// and budget of iteration k, the pair's moments.
 template <bool FWD>
-__device__ __forceinline__ void tile_pass(const IcpProblem& pr, int k, int Mn, int Rn, const TileGeom& t) {
-  const float4* __restrict__ csrt = FWD ? pr.rsrt : pr.msrt;   // candidates
-  const float4* __restrict__ qsrt = FWD ? pr.msrt : pr.rsrt;   // queries
+__device__ __forceinline__ void tile_search_pass(const IcpProblem& pr, int k, int Mn, int Rn, const TileGeom& t,
+                                                 int n_list) {
+  const float4* __restrict__ csrt = FWD ? pr.rsrt : pr.msrt;                // candidates, by rows
+  const float4* __restrict__ qpts = FWD ? (const float4*)pr.mov : pr.ref;   // the queries' cloud, original order
   const int* crow = FWD ? t_rowr : t_rowm;
-  const int* qrow = FWD ? t_rowm : t_rowr;
+  const int qoff = FWD ? 0 : Mn, nqc = FWD ? Mn : Rn, ncc = FWD ? Rn : Mn;
   int32_t* __restrict__ nn_o = FWD ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
+  float* __restrict__ bud_o = FWD ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
+  const int32_t* __restrict__ list = pr.wl + qoff;
+  int32_t* __restrict__ slist = pr.wls + qoff;
+  const int32_t* __restrict__ seed = FWD ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+  const float4* __restrict__ cpts = FWD ? pr.ref : (const float4*)pr.mov;   // the candidates' cloud, original order
+  if (n_list < 1) return;  // (uniform)
   const float f_ref = pr.bounds[0], f_mov = pr.bounds[8];  // (one frame value per cloud: checked before)
   const TileDir dir = FWD ? tile_dir(pr, t, f_mov, f_ref, pr.df) : tile_dir(pr, t, f_ref, f_mov, -pr.df);
-  if (!dir.ok) return;  // (uniform) nothing in range: every neighbour stays -1
+  if (!dir.ok) {  // nothing can be in range: no neighbour, and nothing that could change that
+    for (int w = threadIdx.x; w < n_list; w += kLoopBlock) {
+      const int qi = (list[w] & ~kHeavyBit) - qoff;
+      nn_o[qi] = -1;
+      bud_o[qi] = 0.f;
+    }
+    return;
+  }
+  const int nb = tile_plan_bands(crow, t.nrows);
+  if (nb < 0) {  // three rows that do not fit (the moving cloud has contracted since the check)
+    if (threadIdx.x == 0) atomicExch(&pr.st->err, 1);
+    return;
+  }
+  __syncthreads();  // (the band table)
+  // ---- the list by band: count, offsets, place
+  auto band_of = [&](int qi) {
+    int r = tile_row_of(t, qpts[qi]);
+    if (r < 0) r = 0;  // (outside the rows: raised as an error when the cloud was sorted; any band will do)
+    int lo = 0, hi = nb - 1;  // the last band that starts at or before row r
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int)t_band_lo[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  // (two classes per band, so that the waves are of a kind: queries that start from their old partner are
+  //  done after a few cells; the others may walk every cell of their 27 blocks)
+  for (int q = threadIdx.x; q < 2 * kTileBands; q += kLoopBlock) t_bcur[q] = 0;
+  __syncthreads();
+  for (int w = threadIdx.x; w < n_list; w += kLoopBlock) {
+    const int q = list[w];
+    atomicAdd(&t_bcur[2 * band_of((q & ~kHeavyBit) - qoff) + ((q & kHeavyBit) ? 1 : 0)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < 2 * nb; ++b) { const int c = t_bcur[b]; t_boff[b] = run; t_bcur[b] = run; run += c; }
+    t_boff[2 * nb] = run;
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < n_list; w += kLoopBlock) {
+    const int q = list[w];
+    slist[atomicAdd(&t_bcur[2 * band_of((q & ~kHeavyBit) - qoff) + ((q & kHeavyBit) ? 1 : 0)], 1)] = q;
+  }
+  __syncthreads();
+  // ---- band by band
   const MomTable mt = tile_mom_table(pr, k);
   const double lim2 = icp_limit_sq(Mn + Rn);
-  const int nrows = t.nrows;
-  int r0 = 0;
-  while (r0 < nrows) {
-    const int s0 = crow[r0 > 0 ? r0 - 1 : 0];
-    int r1 = r0 + 1;
-    while (r1 < nrows && crow[r1 + 2 < nrows ? r1 + 2 : nrows] - s0 <= kTileCap) ++r1;
-    const int s1 = crow[r1 + 1 < nrows ? r1 + 1 : nrows];
+  for (int b = 0; b < nb; ++b) {
+    const int w0 = t_boff[2 * b], w1 = t_boff[2 * b + 2];
+    if (w1 <= w0) continue;  // (uniform)
+    const int r0 = t_band_lo[b], r1 = t_band_lo[b + 1];
+    const int s0 = crow[r0 > 0 ? r0 - 1 : 0], s1 = crow[r1 + 1 < t.nrows ? r1 + 1 : t.nrows];
     const int ns = s1 - s0;
-    const int q0 = qrow[r0], q1 = qrow[r1];
-    if (ns > kTileCap) {  // three rows that do not fit (the moving cloud has contracted since the check)
-      if (threadIdx.x == 0) atomicExch(&pr.st->err, 1);
-    } else if (ns > 0 && q1 > q0) {
-      if (s0 < 0 || s1 > (FWD ? Rn : Mn)) { if (threadIdx.x == 0) atomicExch(&pr.st->err, 104); break; }
-      tile_stage(csrt, s0, ns, t);
-      for (int base = q0; base < q1; base += kLoopBlock) {  // whole waves stay together (mom_add_wave)
-        const int i = base + (int)threadIdx.x;
-        const bool valid = i < q1;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) p = qsrt[i];
-        TileHit hit;
-        hit.idx = -1;
-        hit.j = 0;
-        if (valid) hit = tile_nearest(t, p.y, p.z, p.w, dir.c0, dir.rings);
-        const int qi = __float_as_int(p.x);
-        const int nq_ = FWD ? Mn : Rn, nc_ = FWD ? Rn : Mn;
-        if (valid && (qi < 0 || qi >= nq_)) { atomicExch(&pr.st->err, 102); hit.idx = -1; }
-        else if (valid && (hit.idx < -1 || hit.idx >= nc_ || (hit.idx >= 0 && (hit.j < 0 || hit.j >= ns)))) { atomicExch(&pr.st->err, 101); hit.idx = -1; hit.j = 0; }
-        else if (valid) nn_o[qi] = hit.idx;
-        const bool m_act = valid && hit.idx >= 0;
-        const float4 cpt = m_act ? t_pts[hit.j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // the pair as (moving point, reference point, the moving point's component)
-        const int m_idx = FWD ? qi : hit.idx;
-        int m_c = m_act ? pr.comp[m_idx] : 0;
-        if (m_c < 0 || m_c >= (int)pr.C) { atomicExch(&pr.st->err, 105); m_c = 0; }
-        mom_add_wave(pr, mt, m_act, FWD ? p : cpt, FWD ? cpt : p, m_c, lim2);
-      }
-      __syncthreads();  // (the LDS is staged again)
+    if (s0 < 0 || ns > kTileCap || s1 > ncc) {  // (cannot happen: the bands were planned on these rows)
+      if (threadIdx.x == 0) atomicExch(&pr.st->err, 104);
+      break;
     }
-    r0 = r1;
+    tile_stage(csrt, s0, ns, t);
+    // the queries that start from their old partner: one lane each
+    const int wl1 = t_boff[2 * b + 1];
+    for (int w = w0 + (int)threadIdx.x; w < wl1; w += kLoopBlock) {
+      const int qi = slist[w] - qoff;
+      if (qi < 0 || qi >= nqc) { atomicExch(&pr.st->err, 102); continue; }
+      const float4 p = qpts[qi];
+      float seed_d2 = __builtin_inff();
+      const int sd = seed[qi];
+      if (sd >= 0 && sd < ncc) {  // the old partner, where it is now (inside the radius: the budget test saw it)
+        const float4 sp = cpts[sd];
+        const float d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
+        float dist2 = dir.c0;
+        dist2 = dist2 + d1 * d1;
+        dist2 = dist2 + d2 * d2;
+        dist2 = dist2 + d3 * d3;
+        seed_d2 = dist2;
+      }
+      TileHit hit = tile_nearest(t, p.y, p.z, p.w, dir.c0, seed_d2);
+      if (hit.idx < -1 || hit.idx >= ncc || (hit.idx >= 0 && (hit.j < 0 || hit.j >= ns))) {
+        atomicExch(&pr.st->err, 101);  // (cannot happen: indices of staged points)
+        hit.idx = -1;
+        hit.bud = 0.f;
+      }
+      nn_o[qi] = hit.idx;
+      bud_o[qi] = hit.bud;
+      if (hit.idx >= 0) {  // the pair as (moving point, reference point, the moving point's component)
+        const float4 c = t_pts[hit.j];
+        const int mc = pr.comp[FWD ? qi : hit.idx];
+        if (mc >= 0 && mc < (int)pr.C) {
+          if (FWD) mom_add_stream(pr, mt, p, c, mc, lim2);
+          else mom_add_stream(pr, mt, c, p, mc, lim2);
+        } else {
+          atomicExch(&pr.st->err, 105);
+        }
+      }
+    }
+    // the others: one wave each
+    for (int w = wl1 + (int)(threadIdx.x >> 6); w < w1; w += kLoopBlock / 64) {
+      const int qi = (slist[w] & ~kHeavyBit) - qoff;  // (uniform in the wave)
+      if (qi < 0 || qi >= nqc) { atomicExch(&pr.st->err, 102); continue; }
+      const float4 p = qpts[qi];
+      float seed_d2 = __builtin_inff();
+      const int sd = k > 1 ? seed[qi] : -1;
+      if (sd >= 0 && sd < ncc) {  // the old partner, where it is now
+        const float4 sp = cpts[sd];
+        const float d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
+        float dist2 = dir.c0;
+        dist2 = dist2 + d1 * d1;
+        dist2 = dist2 + d2 * d2;
+        dist2 = dist2 + d3 * d3;
+        seed_d2 = dist2;
+      }
+      TileHit hit = tile_nearest_wave(t, p.y, p.z, p.w, dir.c0, seed_d2);
+      if (hit.idx < -1 || hit.idx >= ncc || (hit.idx >= 0 && (hit.j < 0 || hit.j >= ns))) {
+        atomicExch(&pr.st->err, 101);
+        hit.idx = -1;
+        hit.bud = 0.f;
+      }
+      if ((threadIdx.x & 63) == 0) {
+        nn_o[qi] = hit.idx;
+        bud_o[qi] = hit.bud;
+        if (hit.idx >= 0) {
+          const float4 c = t_pts[hit.j];
+          const int mc = pr.comp[FWD ? qi : hit.idx];
+          if (mc >= 0 && mc < (int)pr.C) {
+            if (FWD) mom_add_stream(pr, mt, p, c, mc, lim2);
+            else mom_add_stream(pr, mt, c, p, mc, lim2);
+          } else {
+            atomicExch(&pr.st->err, 105);
+          }
+        }
+      }
+    }
+    __syncthreads();  // (the LDS is staged again)
   }
 }
 
@@ -1709,16 +2092,14 @@ __device__ __noinline__ void tile_prepare_phase(const IcpProblem* __restrict__ p
   if (threadIdx.x == 0) { t_flag[0] = 0; t_flag[1] = 0; }
   __syncthreads();
   if (ok) {
-    int err_r = 0;
     tile_bin(pr.ref, Rn, pr.rsrt, t_rowr, t, &t_flag[1]);
     const int mr = tile_max_triple(t_rowr, t.nrows);
     if ((threadIdx.x & 63) == 0) atomicMax(&t_flag[0], mr);
     tile_bin((const float4*)pr.mov, Mn, pr.msrt, t_rowm, t, &t_flag[1]);
     const int mm = tile_max_triple(t_rowm, t.nrows);
     if ((threadIdx.x & 63) == 0) atomicMax(&t_flag[0], mm + mm / 3);  // (the moving cloud may contract a little)
-    (void)err_r;
     __syncthreads();
-    ok = t_flag[0] <= kTileCap && t_flag[1] == 0;
+    ok = t_flag[0] <= kTileCap && t_flag[1] == 0 && Rn <= kTileBands * (kTileCap / 2) && Mn <= kTileBands * (kTileCap / 2);
   }
   if (ok) {
     for (int r = threadIdx.x; r <= kTileRows; r += kLoopBlock) pr.trow[r] = t_rowr[r];
@@ -1730,32 +2111,46 @@ __device__ __noinline__ void tile_prepare_phase(const IcpProblem* __restrict__ p
   __syncthreads();
 }
 // start of an iteration: the row table of the reference cloud (a later launch of the registration), the
-// moving cloud by rows, every neighbour of the iteration <- none, an empty moment table
-__device__ __noinline__ void tile_begin_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn, int load_rows) {
+// moving cloud by rows, the step table of iteration k-1, an empty moment table, empty work lists
+__device__ __noinline__ void tile_begin_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int load_rows) {
   const IcpProblem& pr = *prp;
   const TileGeom t = tile_geom(pr);
   if (load_rows)
     for (int r = threadIdx.x; r <= kTileRows; r += kLoopBlock) t_rowr[r] = pr.trow[r];
   tile_bin((const float4*)pr.mov, Mn, pr.msrt, t_rowm, t, &pr.st->err);
-  int32_t* nn_f = pr.nn_f + (size_t)(k & 1) * pr.capM;
-  int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
-  for (int q = threadIdx.x; q < Mn; q += kLoopBlock) nn_f[q] = -1;
-  for (int q = threadIdx.x; q < Rn; q += kLoopBlock) nn_b[q] = -1;
+  if (k > 1) {
+    const unsigned int* __restrict__ sstep = pr.sstep + (size_t)((k - 1) & 1) * kStepH;
+    for (int q = threadIdx.x; q < kStepH / 4; q += kLoopBlock) ((uint4*)t_step)[q] = ((const uint4*)sstep)[q];
+  }
   mom_init(tile_mom_table(pr, k));
+  if (threadIdx.x < 4) t_cnt[threadIdx.x] = 0;
   __syncthreads();
+}
+// the budget test of the cache path; the queries that fail it go to ONE list per direction (t_cnt[0], [1]).
+// Iteration 1: every query.
+__device__ __noinline__ void tile_budget_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
+  const IcpProblem& pr = *prp;
+  if (k == 1) {
+    for (int q = threadIdx.x; q < Mn + Rn; q += kLoopBlock) pr.wl[q] = q | kHeavyBit;
+    if (threadIdx.x == 0) { t_cnt[0] = Mn; t_cnt[1] = Rn; }
+    return;
+  }
+  const GridDesc g = pr.geom->g;
+  icp_budget_phase<kLoopBlock, false>(pr, k, Mn, Rn, 0, 1, g, tile_mom_table(pr, k), t_step, t_cnt);
 }
 __device__ __noinline__ void tile_forward_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
   const TileGeom t = tile_geom(*prp);
-  tile_pass<true>(*prp, k, Mn, Rn, t);
+  tile_search_pass<true>(*prp, k, Mn, Rn, t, t_cnt[0]);
 }
 __device__ __noinline__ void tile_backward_phase(const IcpProblem* __restrict__ prp, int k, int Mn, int Rn) {
   const TileGeom t = tile_geom(*prp);
-  tile_pass<false>(*prp, k, Mn, Rn, t);
+  tile_search_pass<false>(*prp, k, Mn, Rn, t, t_cnt[1]);
 }
 __device__ __noinline__ void tile_flush_phase(const IcpProblem* __restrict__ prp, int k) {
   mom_flush(tile_mom_table(*prp, k));
 }
-// every moving point moves by its component's step; the previous positions are kept for the l1 passes
+// every moving point moves by its component's step; the previous positions are kept (budget test, l1
+// passes); the step table of iteration k takes every point's step under the place it moved to
 __device__ __noinline__ void tile_apply_phase(const IcpProblem* __restrict__ prp, int k, int Mn) {
   const IcpProblem& pr = *prp;
   float4* __restrict__ mov = pr.mov;
@@ -1763,7 +2158,13 @@ __device__ __noinline__ void tile_apply_phase(const IcpProblem* __restrict__ prp
   const int32_t* __restrict__ comp = pr.comp;
   const double* __restrict__ Rt = pr.Rt;
   const int64_t C = pr.C;
+  const GridDesc d = pr.geom->g;
   if (threadIdx.x == 0) pr.st->iters = k;
+  {  // the step table of iteration k+1 (nothing reads it during this phase)
+    unsigned int* nxt = pr.sstep + (size_t)((k + 1) & 1) * kStepH;
+    for (int q = threadIdx.x; q < kStepH; q += kLoopBlock) nxt[q] = 0u;
+  }
+  unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   for (int i = threadIdx.x; i < Mn; i += kLoopBlock) {
     const double* __restrict__ rc = Rt + comp[i];
     double R[9], t[3];
@@ -1778,13 +2179,18 @@ __device__ __noinline__ void tile_apply_phase(const IcpProblem* __restrict__ prp
     const float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
     const float nz = (float)(x * R[6] + y * R[7] + z * R[8] + t[2]);
     mov[i] = make_float4(p.x, nx, ny, nz);
+    const float dx = nx - p.y, dy = ny - p.z, dz = nz - p.w;
+    const float st1 = sqrtf((dx * dx + dy * dy) + dz * dz) * 1.000001f + 1e-7f;
+    const int fx = (int)floorf((nx - d.lo[0]) / d.h), fy = (int)floorf((ny - d.lo[1]) / d.h),
+              fz = (int)floorf((nz - d.lo[2]) / d.h);
+    atomicMax(&sstep[icp_step_slot(fx >> 3, fy >> 3, fz >> 3)], __float_as_uint(st1));
   }
 }
 
-// One workgroup per batch entry, like icp_loop_kernel; phase_ticks: [0] rows of the moving cloud + forward
-// pass, [1] backward pass + moment flush, [2] solve + stop rule, [3] apply.
+// One workgroup per batch entry, like icp_loop_kernel; phase_ticks: [0] rows of the moving cloud + budget
+// test, [1] the two search passes + moment flush, [2] solve + stop rule, [3] apply.
 __global__ void __launch_bounds__(kLoopBlock)
-icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, unsigned int budget_ticks,
+icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, int wide_limit, unsigned int budget_ticks,
                 IcpState* __restrict__ out) {
   const IcpProblem* prp = tab + bt.idx[blockIdx.x];
   IcpState* st = prp->st;
@@ -1797,6 +2203,7 @@ icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, unsigned
   const int k_end = k + n_it;
   icp_decide(*prp, k - 1);
   int load_rows = 1;
+  if (k <= wide_limit || k > prp->max_iter || k > st->stop_iter) return;  // (uniform) nothing for this loop to run now
   if (st->mode == 0) {
     tile_prepare_phase(prp, Mn, Rn);
     load_rows = 0;
@@ -1804,24 +2211,25 @@ icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, unsigned
   }
   unsigned long long ticks[4] = {0ULL, 0ULL, 0ULL, 0ULL};
   int done = 0;
-  if (threadIdx.x < 4) t_dbg[threadIdx.x] = 0ULL;
   for (; k < k_end; ++k) {
     __syncthreads();
     unsigned long long t0 = 0ULL;
     if (threadIdx.x == 0) {
       t0 = __builtin_amdgcn_s_memrealtime();
-      bool go = !(k > prp->max_iter || k > st->stop_iter);
+      bool go = !(k <= wide_limit || k > prp->max_iter || k > st->stop_iter);  // (k <= wide_limit: a wide launch's)
       if (go && budget_ticks && done > 0 && t0 - t_begin > (unsigned long long)budget_ticks) go = false;
       s_go = go ? 1 : 0;
     }
     __syncthreads();
     if (!s_go) break;
-    tile_begin_phase(prp, k, Mn, Rn, load_rows);
+    tile_begin_phase(prp, k, Mn, load_rows);
     load_rows = 0;
-    tile_forward_phase(prp, k, Mn, Rn);
+    tile_budget_phase(prp, k, Mn, Rn);
     __syncthreads();
     unsigned long long t1 = 0ULL;
     if (threadIdx.x == 0) { t1 = __builtin_amdgcn_s_memrealtime(); ticks[0] += t1 - t0; }
+    tile_forward_phase(prp, k, Mn, Rn);
+    __syncthreads();
     tile_backward_phase(prp, k, Mn, Rn);
     __syncthreads();
     tile_flush_phase(prp, k);
@@ -1842,8 +2250,6 @@ icp_tile_kernel(const IcpProblem* __restrict__ tab, Batch bt, int n_it, unsigned
     st->loop_iters += done;
 #pragma unroll
     for (int q = 0; q < 4; ++q) st->phase_ticks[q] += ticks[q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st->dbg[q] += t_dbg[q];
     if (out) out[blockIdx.x] = *st;
   }
 }
@@ -1933,23 +2339,22 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
   return PCS_OK;
 }
 
-// PCS_ICP_WIDE_ITERS (experiment switch of round 4): how many iterations of a registration run as wide launches
-// before the unit-resident loop takes over (default kIcpWideIters; >= max_iter: every iteration, in chunks of 8,
-// the schedule of rounds 1-3)
-static int icp_wide_limit() {
-  static const int v = [] {
-    const char* e = getenv("PCS_ICP_WIDE_ITERS");
-    return e ? atoi(e) : kIcpWideIters;
-  }();
-  return v;
-}
-// PCS_ICP_TILES=0 (experiment switch of round 4): every registration on the cache path
-static bool icp_use_tiles() {
-  static const bool v = [] {
-    const char* e = getenv("PCS_ICP_TILES");
-    return !(e && atoi(e) == 0);
-  }();
-  return v;
+// The schedule of the iterations (pcs_icp_set_schedule, include/pcs.h): how many iterations of a registration
+// run as wide launches before a unit-resident loop takes over (INT_MAX: all of them, in chunks of 8 -- the
+// default, measured fastest: DESIGN.md section 4), and which resident loop (tile path / cache path).
+static std::atomic<int> g_wide_iters{INT_MAX};
+static std::atomic<int> g_use_tiles{1};
+static int icp_wide_limit() { return g_wide_iters.load(std::memory_order_relaxed); }
+static bool icp_use_tiles() { return g_use_tiles.load(std::memory_order_relaxed) != 0; }
+
+// end of a wide chunk: the stop rule of every entry's last iteration (the others were settled by the next
+// budget-test launch), and the state mirrored where the host reads it (`out` may be pinned host memory: the
+// host then needs no copy, only the stream synchronisation)
+__global__ void __launch_bounds__(64)
+icp_decide_kernel(const IcpProblem* __restrict__ tab, Batch bt, IcpState* __restrict__ out) {
+  const IcpProblem& pr = tab[bt.idx[blockIdx.x]];
+  icp_decide(pr, pr.st->iters);  // (iterations that did not run have no loss: iters is the last one that did)
+  if (out && threadIdx.x == 0) out[blockIdx.x] = *pr.st;  // (one wave: thread 0 wrote the decision itself)
 }
 
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
@@ -1958,14 +2363,24 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
   const int wide_limit = icp_wide_limit();
+  const bool prof = g_prof_on;
+  if (prof && !t_ev.have) {
+    for (int i = 0; i < 2; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
+    t_ev.have = true;
+  }
+  t_ev.used = prof;
+  // the events ride on the dispatches themselves (hipExtLaunchKernelGGL): start of the chunk's first iteration
+  // launch to the stop of its last launch, the kernels' own begin-to-end time as rocprofv3 reports it
+  hipEvent_t ev_start = prof ? t_ev.ev[0] : nullptr;
+  hipEvent_t ev_stop = prof ? t_ev.ev[1] : nullptr;
   // ---- entries whose next iterations are wide: launches over those entries only
   static thread_local Batch bf;
   static thread_local BatchInts kf;
   static thread_local IcpHint hf[kMaxBatch];
   bf.n = 0;
   int n_wide = 0;  // iterations to launch: at most 8 per chunk
-  bool any_first = false;
-  for (int e = 0; e < bt.n; ++e)
+  bool any_first = false, all_wide = true;
+  for (int e = 0; e < bt.n; ++e) {
     if (kbase.v[e] < wide_limit) {
       hf[bf.n] = hints[e];
       kf.v[bf.n] = kbase.v[e];
@@ -1974,6 +2389,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       if (left > n_wide) n_wide = left;
       any_first = any_first || kbase.v[e] == 0;
     }
+    if ((int64_t)kbase.v[e] + 8 > (int64_t)wide_limit) all_wide = false;  // (the resident loop may get a turn)
+  }
   if (n_wide > 8) n_wide = 8;
   if (n_wide > n_it) n_wide = n_it;
   if (bf.n > 0 && n_wide > 0) {
@@ -1998,37 +2415,33 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
     const int nb_m = gx_for(m, kBlock, 4096);
     for (int j = 0; j < n_wide; ++j) {
       if (j == 0 && any_first) icp_first_kernel<<<dim3(gx_for(q, kBlock, 1024), bf.n), kBlock, 0, s>>>(tab, bf, kf);
-      icp_nn_kernel<<<dim3(nb_q, bf.n), kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
+      hipExtLaunchKernelGGL(icp_nn_kernel, dim3(nb_q, bf.n), dim3(kBlock), 0, s, j == 0 ? ev_start : nullptr, nullptr, 0, tab,
+                            bf, kf, j, wide_limit);
       icp_nn_search_kernel<<<(j == 0 && any_first) ? nb_c1 : nb_cs, kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
       icp_solve_kernel<<<dim3(nb_s, bf.n), kSolveBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
-      icp_apply_kernel<<<dim3(nb_m, bf.n), kBlock, 0, s>>>(tab, bf, kf, j, wide_limit);
+      hipExtLaunchKernelGGL(icp_apply_kernel, dim3(nb_m, bf.n), dim3(kBlock), 0, s, nullptr,
+                            (all_wide && j == n_wide - 1) ? ev_stop : nullptr, 0, tab, bf, kf, j, wide_limit);
     }
+    ev_start = nullptr;  // (taken)
   }
-  // ---- the unit-resident loop: one workgroup per entry (entries that began above go on from where the
-  //      wide launches left them; the kernel also settles their stop rule and mirrors every state)
+  if (all_wide) {
+    icp_decide_kernel<<<bt.n, 64, 0, s>>>(tab, bt, out);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
+  // ---- the unit-resident loops: one workgroup per entry (entries that began above go on from where the
+  //      wide launches left them). The tile path first (it decides a new registration's path); the cache
+  //      path's kernel then serves the registrations that did not qualify -- and settles every stop rule
+  //      and mirrors every state.
   const unsigned long long bt_ticks = (unsigned long long)budget_us * 100ULL;
   const unsigned int budget_ticks = bt_ticks > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (unsigned int)bt_ticks;
-  const bool prof = g_prof_on;
-  if (prof && !t_ev.have) {
-    for (int i = 0; i < 2; ++i) PCS_CHECK_HIP(hipEventCreate(&t_ev.ev[i]));
-    t_ev.have = true;
+  if (icp_use_tiles()) {
+    hipExtLaunchKernelGGL(icp_tile_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, ev_start, nullptr, 0, tab, bt, n_it, wide_limit,
+                          budget_ticks, out);
+    ev_start = nullptr;
   }
-  t_ev.used = prof;
-  // the tile path first (it decides a new registration's path); the cache path's kernel then serves the
-  // registrations that did not qualify -- and mirrors every state
-  const bool tiles = icp_use_tiles() && wide_limit == 0;
-  if (prof) {
-    // the events ride on the dispatches themselves (hipExtLaunchKernelGGL): first start to last stop, the
-    // kernels' own begin-to-end time as rocprofv3 reports it
-    if (tiles)
-      hipExtLaunchKernelGGL(icp_tile_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, t_ev.ev[0], nullptr, 0, tab, bt, n_it,
-                            budget_ticks, out);
-    hipExtLaunchKernelGGL(icp_loop_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, tiles ? nullptr : t_ev.ev[0], t_ev.ev[1], 0,
-                          tab, bt, n_it, wide_limit, budget_ticks, out);
-  } else {
-    if (tiles) icp_tile_kernel<<<bt.n, kLoopBlock, 0, s>>>(tab, bt, n_it, budget_ticks, out);
-    icp_loop_kernel<<<bt.n, kLoopBlock, 0, s>>>(tab, bt, n_it, wide_limit, budget_ticks, out);
-  }
+  hipExtLaunchKernelGGL(icp_loop_kernel, dim3(bt.n), dim3(kLoopBlock), 0, s, ev_start, ev_stop, 0, tab, bt, n_it, wide_limit,
+                        budget_ticks, !icp_use_tiles(), out);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
@@ -2081,6 +2494,17 @@ int icp_enqueue_finish(const IcpProblem* tab, const Batch& bt, const IcpHint* hi
 using namespace pcs;
 
 extern "C" {
+
+// Schedule of the ICP iterations (process-wide; takes effect for chunks enqueued afterwards; a registration
+// may change schedule between chunks: every schedule computes the same iterations).
+//   wide_iters < 0 or >= max_iter: every iteration as wide launches (default);
+//   wide_iters >= 1: that many wide iterations, then the unit-resident loop: use_tiles != 0 the tile path
+//   (LDS-staged searches; registrations that do not qualify take the cache path), else the cache path.
+int pcs_icp_set_schedule(int wide_iters, int use_tiles) {
+  g_wide_iters.store(wide_iters < 0 ? INT_MAX : wide_iters, std::memory_order_relaxed);
+  g_use_tiles.store(use_tiles != 0 ? 1 : 0, std::memory_order_relaxed);
+  return PCS_OK;
+}
 
 // bench.py support: HIP-event timing of the unit-resident loop kernel on its launch stream.
 // enable = 1 resets and starts accumulating.
@@ -2181,14 +2605,15 @@ int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t
   while (host.iters < max_iter) {
     BatchInts kb;
     kb.v[0] = host.iters;
-    const int loop_before = host.loop_iters;
+    const int iters_before = host.iters;
     rc = icp_enqueue_chunk(tab, bt, kb, chunk, 0u, &hint, pin, s, 0);
     if (rc) return rc;
     if (!pin) PCS_CHECK_HIP(hipMemcpyAsync(&host, host_pr.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     PCS_CHECK_HIP(hipStreamSynchronize(s));
     if (pin) host = *pin;
-    icp_profile_account((double)(host.loop_iters - loop_before), by_iter * (double)(host.loop_iters - loop_before), 0);
-    if (host.err) { fprintf(stderr, "[pcs debug] icp err %d mode %d iters %d\n", host.err, host.mode, host.iters); return PCS_ERR_RANGE; }
+    icp_profile_account((double)(host.iters - iters_before), by_iter * (double)(host.iters - iters_before), 0);
+    if (host.iters == iters_before && host.stop_iter == INT_MAX && !host.err) return PCS_ERR_HIP;  // (no progress: cannot happen)
+    if (host.err) return PCS_ERR_RANGE;
     if (host.stop_iter != INT_MAX) break;
   }
   icp_profile_phases(host.phase_ticks);

@@ -43,7 +43,6 @@ struct IcpState {
   // measurement: 100 MHz ticks (s_memrealtime) the unit-resident loop spent in its four phases -- budget
   // test, searches, solve, apply -- summed over the iterations of this registration
   unsigned long long phase_ticks[4];
-  unsigned long long dbg[4];  // EXPERIMENT: queries, far-phase entries, queries without partner, candidates examined
 };
 
 // per-component accumulators of one iteration: n, sum p (3), sum q (3), sum p(x)q (9), sum |p-q|^2,
@@ -189,14 +188,14 @@ void icp_profile_account(double unit_iters, double bytes, int prof_slot);
 void icp_profile_phases(const unsigned long long* ticks4);
 // enqueue: reset + bounds + grid description + the three grids of every entry
 int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hints, hipStream_t s);
-// enqueue one chunk of iterations for every entry. Entries that have not iterated yet (kbase[e] == 0) first
-// run kIcpWideIters iterations as wide launches (the full searches of a first iteration want the whole
-// chip); then ONE launch of the unit-resident loop: a workgroup per entry runs that entry's iterations
-// back to back -- budget test, searches, solve, apply, stop rule, no launch in between -- until the stop
-// rule fires, max_iter, n_it iterations of this chunk, or budget_us microseconds (0: no limit) have passed.
-// How the iterations are cut into chunks never changes a result. The states are mirrored to out[e]
-// (may be pinned host memory, may be nullptr).
-constexpr int kIcpWideIters = 0;
+// enqueue one chunk of iterations for every entry. By default (pcs_icp_set_schedule) every iteration is a set of
+// wide launches serving all entries (blockIdx.y = entry), 8 iterations per chunk; with a resident schedule the
+// first `wide_iters` iterations of a registration are wide (the full searches of a first iteration want the
+// whole chip) and ONE launch per chunk then gives every entry a workgroup of its own that runs its iterations
+// back to back -- budget test, searches, solve, apply, stop rule, no launch in between -- until the stop rule
+// fires, max_iter, n_it iterations of this chunk, or budget_us microseconds (0: no limit) have passed.
+// How the iterations are cut into chunks and which schedule runs them never changes a result. The states
+// are mirrored to out[e] (may be pinned host memory, may be nullptr).
 int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& kbase, int n_it,
                       unsigned budget_us, const IcpHint* hints, IcpState* out, hipStream_t s, int prof_slot);
 // enqueue: l1 error of the last iteration, coverage ratio, outputs

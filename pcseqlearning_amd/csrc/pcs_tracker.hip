@@ -1133,7 +1133,7 @@ struct HostUnit {
   int na, nm, C, F, W, anchor, min_f, max_f;
   int64_t off_a;
   int phase, dir, next, last_col, lv;
-  int loop_before;  // iterations the unit-resident loop had run before the last chunk (profile accounting)
+  int loop_before;  // iterations run before the last chunk (profile accounting)
   int fail;       // error found while collecting a tick (PCS_ERR_*)
   bool any_valid;
   int Cu;
@@ -1195,18 +1195,14 @@ static bool same_params(const PcsTrackParams& a, const PcsTrackParams& b) {
 // launches (integer moments, exact neighbours, fixed-order sums).
 class Engine {
  public:
-  // A device has a few engines (PCS_TRACK_ENGINES, default 3; measured 1 / 2 / 3: 1.88 / 1.75 / 1.67 s per batch of 12: while one chain is in its single-workgroup
-  // phases -- sampling sort, smooth_velo, compactions -- the other's iteration launches fill the chip);
-  // a call's units all join the engine that has the fewest units at that moment.
+  // A device has a few engines (pcs_track_configure, default 3; measured 1 / 2 / 3 / 4 with early creation: 1747 /
+  // 1537 / 1494 / 1638 ms per batch of 12: while one chain is in its single-workgroup phases -- sampling sort,
+  // smooth_velo, compactions -- the others' iteration launches fill the chip; the runtime has four hardware
+  // queues); a call's units all join the engine that has the fewest units at that moment.
   static constexpr int kMaxEngines = 8;
-  static int count() {
-    static const int n_engines = [] {
-      const char* e = getenv("PCS_TRACK_ENGINES");
-      int c = e ? atoi(e) : 0;
-      return (c >= 1 && c <= kMaxEngines) ? c : 3;
-    }();
-    return n_engines;
-  }
+  static std::atomic<int>& cfg_engines() { static std::atomic<int> v{3}; return v; }
+  static std::atomic<unsigned>& cfg_chunk_us() { static std::atomic<unsigned> v{3000u}; return v; }
+  static int count() { return cfg_engines().load(std::memory_order_relaxed); }
   static Engine* get(int device) {
     static std::mutex mu;
     static Engine* inst[64][kMaxEngines] = {};
@@ -1339,7 +1335,6 @@ class Engine {
   int live_[kMaxBatch], n_live_ = 0;
   Batch b_all_, b_iter_, b_fin_;
   int64_t ticks_ = 0;
-  unsigned chunk_us_ = 1000;  // time budget of a chunk of the unit-resident ICP loop
 };
 
 }  // namespace pcs
@@ -1472,8 +1467,6 @@ int Engine::enqueue_tick() {
                     h.lv, h.C, (long long)h.host.counts[1], (long long)h.host.counts[2], (long long)h.host.counts[3],
                     h.icp.iters, h.icp.loop_iters, h.icp.phase_ticks[0] * 0.01, h.icp.phase_ticks[1] * 0.01,
                     h.icp.phase_ticks[2] * 0.01, h.icp.phase_ticks[3] * 0.01);
-          if (g_tick_profile.on)
-            fprintf(stderr, "[dbg] lv %d q %llu far %llu nohit %llu cand %llu\n", h.lv, h.icp.dbg[0], h.icp.dbg[1], h.icp.dbg[2], h.icp.dbg[3]);
           s_fin.a[b_fin.n] = step_arg(h);
           h_fin[b_fin.n] = h.hint;
           b_fin.idx[b_fin.n++] = i;
@@ -1652,13 +1645,15 @@ int Engine::enqueue_tick() {
     HostUnit& h = hu[i];
     if (h.phase != PH_ICP) continue;
     kb.v[b_iter.n] = h.icp.iters;  // 0: the registration begins (its first iteration is a wide launch)
-    h.loop_before = h.icp.loop_iters;
+    h.loop_before = h.icp.iters;
     h_iter[b_iter.n] = h.hint;
     b_iter.idx[b_iter.n++] = i;
   }
-  // every registering unit gets a workgroup of its own that iterates until its stop rule fires or the
-  // chunk's time budget has passed (units are not in step with each other inside a chunk)
-  if (b_iter.n) TRK_RC(icp_enqueue_chunk(d_icp, b_iter, kb, prm->max_iter, chunk_us_, h_iter, pin_icp_, gs, 0));
+  // (default schedule: 8 iterations as wide launches over all registering units; a resident schedule: every
+  //  unit iterates on a workgroup of its own until its stop rule fires or the chunk's time budget has passed)
+  if (b_iter.n)
+    TRK_RC(icp_enqueue_chunk(d_icp, b_iter, kb, prm->max_iter, cfg_chunk_us().load(std::memory_order_relaxed), h_iter,
+                             pin_icp_, gs, 0));
   b_iter_ = b_iter;
   if (g_tick_profile.on) { g_tick_profile.units += n_live_; g_tick_profile.iter_units += b_iter.n; }
   // ---- 7. state mirror; the event tells the host when the tick's words can be read
@@ -1688,7 +1683,7 @@ void Engine::collect_tick() {
       HostUnit& h = hu[b_iter_.idx[e]];
       h.icp = pin_icp_[e];
       const double Mn = (double)h.host.counts[1], Rn = (double)h.host.counts[3], C = (double)h.C;
-      const double it = (double)(h.icp.loop_iters - h.loop_before);
+      const double it = (double)(h.icp.iters - h.loop_before);
       unit_iters += it;
       // per unit and iteration: neighbours (36 per query) + moments (40 per query, 272 per component) + solve and
       // apply (68 per moving point, 416 per component)
@@ -1699,31 +1694,16 @@ void Engine::collect_tick() {
 }
 
 void Engine::run() {
-  // PCS_TRACK_PRIORITY=1 (experiment, off by default): the engine's stream at the highest priority -- its
-  // launches are one long dependent chain, the other streams carry the wide, throughput-bound kernels of
-  // the other stages. Measured 1.72 against 1.75 s per batch of 12, BUT priority streams get hardware
-  // queues of their own, and with 4 normal + 4 high-priority queues (four engines), or 18 sequences in
-  // flight beside three, the process-wide freezes of DESIGN.md section 4 "The freeze" came back (10-60 s
-  // steps, gpurun_out/r3i). Default priority keeps the process on HIP's four queues.
+  // Default-priority stream: a high-priority one (its launches are one long dependent chain) measured 1.72
+  // against 1.75 s per batch of 12 in round 3, BUT priority streams get hardware queues of their own, and with
+  // 4 normal + 4 high-priority queues the process-wide freezes of DESIGN.md section 4 "The freeze" came back
+  // (10-60 s steps). Default priority keeps the process on HIP's four queues.
   bool ok = hipSetDevice(device_) == hipSuccess;
-  if (ok) {
-    const char* pe = getenv("PCS_TRACK_PRIORITY");
-    if (pe && atoi(pe) != 0) {
-      int lo = 0, hi = 0;
-      ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-           hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, hi) == hipSuccess;
-    } else {
-      ok = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) == hipSuccess;
-    }
-  }
+  ok = ok && hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ev_, hipEventDisableTiming) == hipSuccess;
   // (a first command now: whatever the runtime binds to a stream at its first use -- its hardware queue -- is
   //  bound in the order the engines are created, not in the order their first units arrive)
   ok = ok && hipMemsetAsync(d_units_, 0, sizeof(int), st_) == hipSuccess && hipStreamSynchronize(st_) == hipSuccess;
-  {
-    const char* e = getenv("PCS_TRACK_CHUNK_US");  // (experiment switch of round 4; 0 = no limit)
-    if (e) chunk_us_ = (unsigned)atoi(e);
-  }
   {
     std::lock_guard<std::mutex> lk(mu_);
     ready_ = ok;
@@ -2002,6 +1982,16 @@ extern "C" {
 // come into being between the streams of a dozen host threads may end up sharing one queue, and two chains
 // on one queue run one after the other (measured: 1.75 s per batch instead of 1.5 s). A caller that is about
 // to create streams of its own calls this first. `device` < 0: the current device.
+// engines per device (1..8; takes effect for devices whose engines do not exist yet) and the time budget of a
+// chunk of the unit-resident ICP schedules in microseconds (0: none; see pcs_icp_set_schedule); values < 0 keep
+// the current setting
+int pcs_track_configure(int engines, int chunk_us) {
+  if (engines > Engine::kMaxEngines) return PCS_ERR_ARG;
+  if (engines >= 1) Engine::cfg_engines().store(engines, std::memory_order_relaxed);
+  if (chunk_us >= 0) Engine::cfg_chunk_us().store((unsigned)chunk_us, std::memory_order_relaxed);
+  return PCS_OK;
+}
+
 int pcs_track_engines_init(int device) {
   if (device < 0 && hipGetDevice(&device) != hipSuccess) return PCS_ERR_HIP;
   int cur = 0;

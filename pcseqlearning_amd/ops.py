@@ -765,6 +765,22 @@ class TrackParams(__import__("ctypes").Structure):
     ]
 
 
+def icp_set_schedule(wide_iters=-1, use_tiles=True):
+    """pcs_icp_set_schedule: how the iterations of the fused ICP are run (process-wide). wide_iters < 0: every
+    iteration as wide launches over all registrations in flight (default, fastest measured); >= 1: that many wide
+    iterations, then one resident workgroup per registration -- with LDS-staged searches (use_tiles) or the
+    hash-grid searches of the cache path. Every schedule computes the same iterations, bit for bit."""
+    lib = L.load()
+    L.check(lib.pcs_icp_set_schedule(L.i32(int(wide_iters)), L.i32(1 if use_tiles else 0)), "pcs_icp_set_schedule")
+
+
+def track_configure(engines=-1, chunk_us=-1):
+    """pcs_track_configure: tracker engines per device (before they are created) and the chunk budget of the
+    resident ICP schedules; negative = unchanged."""
+    lib = L.load()
+    L.check(lib.pcs_track_configure(L.i32(int(engines)), L.i32(int(chunk_us))), "pcs_track_configure")
+
+
 def track_engines_init(device=None):
     """pcs_track_engines_init: create the device's lock-step engines now (before other streams are created:
     the runtime deals streams to its hardware queues in creation order). Cheap once they exist."""

@@ -192,7 +192,7 @@ class SimpleReg(RegistrationTemplate):
 
     def forward(self, batch_dict):
         batch_size = batch_dict["batch_size"]
-        if batch_dict["point_bxyz"].is_cuda and not os.environ.get("PCS_NO_EARLY_ENGINES"):
+        if batch_dict["point_bxyz"].is_cuda:
             # the tracker's engines before any worker creates a stream of its own (see pcs_track_engines_init)
             ops.track_engines_init(batch_dict["point_bxyz"].device)
         save_dir = self.model_cfg.get("SAVE_DIR", None)

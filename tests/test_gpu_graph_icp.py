@@ -255,6 +255,42 @@ def test_icp_vs_reference_golden(path):
     np.testing.assert_allclose(T2, T, rtol=0, atol=1e-9)
 
 
+# the three schedules of the iterations (pcs_icp_set_schedule): every one computes the same iterations
+SCHEDULES = {"wide": (-1, True), "resident_tiles": (1, True), "resident_cache": (1, False)}
+
+
+@pytest.fixture(params=sorted(SCHEDULES))
+def icp_schedule(request):
+    wide_iters, tiles = SCHEDULES[request.param]
+    ops.icp_set_schedule(wide_iters, tiles)
+    yield request.param
+    ops.icp_set_schedule(-1, True)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "reg_icp_*.npz"))))
+def test_icp_schedules_agree_bit_for_bit(path, icp_schedule):
+    """Wide launches, the resident loop with LDS-staged searches and the resident loop on the hash grids run the
+    same iterations: transforms, errors, ratios, moved points and iteration counts are IDENTICAL (integer
+    moments, exact neighbours), also across chunk lengths."""
+    g = np.load(path)
+    ops.icp_set_schedule(-1, True)
+    T0, l0, r0, m0, it0 = _run_icp(g, float(g["radius"]))
+    ops.icp_set_schedule(*SCHEDULES[icp_schedule])
+    for chunk in (8, 3, 80):
+        T, l1, ratio, moved, iters = _run_icp(g, float(g["radius"]), chunk=chunk)
+        assert iters == it0
+        np.testing.assert_array_equal(T, T0)
+        np.testing.assert_array_equal(l1, l0)
+        np.testing.assert_array_equal(ratio, r0)
+        np.testing.assert_array_equal(moved, m0)
+
+
+def test_icp_larger_all_schedules(oracle, icp_schedule):
+    """The larger pair (several bands of rows in the tile path, open queries, an empty component) on every
+    schedule against the oracle."""
+    test_icp_vs_oracle_larger(oracle)
+
+
 def test_icp_vs_oracle_larger(oracle):
     """Bigger synthetic pair (stationary parts, empty component, negative frame offset)."""
     from oracle import reg_oracle as R

@@ -145,6 +145,17 @@ def test_track_frame_vs_oracle(native):
     np.testing.assert_array_equal(sp.extracted.cpu().numpy(), seq["extracted"])
 
 
+@pytest.mark.parametrize("schedule", [(1, True), (1, False)], ids=["resident_tiles", "resident_cache"])
+def test_track_frame_vs_oracle_resident_schedules(schedule):
+    """The native tracking loop with the ICP iterations on the unit-resident loops (one workgroup per
+    registration; LDS-staged searches / hash-grid searches): the same ids as the oracle, bit for bit."""
+    ops.icp_set_schedule(*schedule)
+    try:
+        test_track_frame_vs_oracle(True)
+    finally:
+        ops.icp_set_schedule(-1, True)
+
+
 def test_track_frame_vs_reference():
     """Against the reference's own track_frame output: the extraction overlaps > 90 % and the
     first tracked frames agree to fp32 noise (see tests/test_oracle_tracking.py for why the
