@@ -701,9 +701,27 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
     const bool valid = wq < nw;
     const int qi = valid ? list[wq] - qoff : 0;  // index in the queries' cloud
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) p = qpts[qi];
+    float seed_d2 = __builtin_inff();
+    if (valid) {
+      p = qpts[qi];
+      if (k > 1) {  // the partner of the last iteration, where it is now: an upper bound of the nearest distance
+        const int32_t* __restrict__ seedc = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
+                                                : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
+        const int sd = seedc[qi];
+        if (sd >= 0) {
+          const float4 sp = hpts[sd];
+          const float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
+          float dist2 = 0.f;
+          dist2 = dist2 + d0 * d0;
+          dist2 = dist2 + d1 * d1;
+          dist2 = dist2 + d2 * d2;
+          dist2 = dist2 + d3 * d3;
+          seed_d2 = dist2;
+        }
+      }
+    }
     float bud = 0.f;
-    const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud);
+    const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud, seed_d2);
     if (valid && sub == 0) {
       nn_o[qi] = res;
       bud_o[qi] = bud;

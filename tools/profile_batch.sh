@@ -26,7 +26,7 @@ python3 -c "import bench; bench.load_sequences(list(range(12)), 20, 160000)" || 
 echo "sequences ready" | tee -a $O/batch.progress
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b
-export PCS_BENCH_TRACE=1  # step lines (and Python stacks of a step that takes > 5 s) in batch.err
-prof_retry timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stages "$@" > $O/${TAG}_batch_bench_under_rocprofv3.json 2> $O/batch.err || { echo "failed"; tail -5 $O/batch.err; exit 1; }
+# (bench.py --trace: step lines and Python stacks of a step that takes > 5 s)
+prof_retry timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stages --trace "$@" > $O/${TAG}_batch_bench_under_rocprofv3.json 2> $O/batch.err || { echo "failed"; tail -5 $O/batch.err; exit 1; }
 cp /tmp/prof_b/ks_kernel_stats.csv $O/${TAG}_batch_kernel_stats.csv
 python3 $ROOT/tools/trace_summary.py /tmp/prof_b/ks_kernel_trace.csv 45 | tee $O/${TAG}_batch_trace_summary.txt
