@@ -58,6 +58,19 @@ def reduce_metrics(dist, device, seconds, values):
     return float(t.item()), [float(x) for x in v.tolist()]
 
 
+def gather_rank_steps(dist, device, step_ms):
+    """Every rank's step times on rank 0 (one all-gather of `steps` doubles): the reduced line then shows a
+    straggler rank instead of hiding it behind the MAX of the wall time. Returns a list (per rank) of
+    step_stats dictionaries; with one rank: that rank's."""
+    import torch
+    if dist is None:
+        return [step_stats(step_ms)]
+    t = torch.tensor(list(step_ms), dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [step_stats([float(x) for x in p.tolist()]) for p in parts]
+
+
 def spawn_ranks(args):
     """Start the N ranks as a child job and pass its output / exit code through. Nothing in this
     process has touched the GPU yet (no torch.cuda call), and the child is a fresh process: a
@@ -139,21 +152,29 @@ def cpu_model():
 
 
 def cpu_baseline(batch, out, n_reg_calls):
-    """The C++ oracle timed on a bounded sample of this sequence, once on ONE core and once with
-    OpenMP over all cores: the 8 cm subsample of the whole sequence, one 10-frame proposal chunk
-    (32-NN radius graph + components at r = 0.25), and -- the bulk of the job -- the registrations
-    of anchor frame 8 against frames 7 and 9 for all three component keys and all three levels
-    (18 of the sequence's ~315 register_to_next_frame calls). Scaled by the call counts of the GPU
-    run. Ground removal has no CPU oracle and is left out, which flatters the CPU."""
+    """The CPU oracle timed on a bounded sample of this sequence, once on ONE core and once with
+    OpenMP over all cores: the 8 cm subsample of the whole sequence, ground removal on its first two
+    frames (oracle/pcs_oracle_ground.cpp behind ground_plane_removal_canonical; scaled by points), one
+    10-frame proposal chunk (32-NN radius graph + components at r = 0.25), and -- the bulk of the job --
+    the registrations of anchor frame 8 against frames 7 and 9 for all three component keys and all
+    three levels (18 of the sequence's ~315 register_to_next_frame calls) with the voxel sampling of
+    both frames in front of each (sample_frame). Scaled by the call counts of the GPU run."""
     import numpy as np
+    from oracle import ground_oracle as GO
     from oracle import oracle as O
     from oracle import reg_oracle as R
     from oracle import track_oracle as T
+    from tools.run_sequence import ground_cfg
     t_all = time.perf_counter()
     fxyz = np.concatenate([batch["point_sweep"].astype(np.float32), batch["point_bxyz"][:, 1:]], 1)
     t0 = time.perf_counter()
     O.grid_sample(fxyz, [0.08, 0.08, 0.08])
     t_sub = time.perf_counter() - t0
+    full = out["full_point_fxyz"].cpu().numpy().astype(np.float32)
+    g_sel = full[:, 0] < 2  # the ground stage of two frames, scaled to the sequence by points
+    t0 = time.perf_counter()
+    GO.ground_plane_removal_canonical(np.ascontiguousarray(full[g_sel]), ground_cfg())
+    t_ground = (time.perf_counter() - t0) * (full.shape[0] / max(int(g_sel.sum()), 1))
     pts = out["point_fxyz"].cpu().numpy()
     frame = pts[:, 0].astype(np.int64)
     m = frame < 10
@@ -165,6 +186,7 @@ def cpu_baseline(batch, out, n_reg_calls):
     levels = ((2.5, (0.4, 0.4, 0.6)), (1.25, (0.2, 0.2, 0.3)), (1.0, (0.1, 0.1, 0.15)))
     threads_all = R.cpu_threads()
     t_reg = {1: 0.0, threads_all: 0.0}
+    t_smp = 0.0
     n_timed = 0
     for key in ("point_component_rad1x25", "point_component_rad0x75", "point_component_rad0x25"):
         comp = out[key].cpu().numpy()
@@ -181,7 +203,9 @@ def cpu_baseline(batch, out, n_reg_calls):
             f1 = dict(fxyz=pts[frame == fb], component=comp[frame == fb], stationary=stat[frame == fb],
                       frame=frame[frame == fb])
             for radius, vs in levels:
+                t0 = time.perf_counter()
                 a, b = T.sample_frame(vs, f0), T.sample_frame(vs, f1)
+                t_smp += time.perf_counter() - t0
                 for th in t_reg:
                     t0 = time.perf_counter()
                     R.register_to_next_frame_cpp(radius, a, b, C, 10.0, 80, 0.05, threads=th)
@@ -189,15 +213,16 @@ def cpu_baseline(batch, out, n_reg_calls):
                 n_timed += 1
     res = {}
     for th, t in t_reg.items():
-        est = t_sub + t_prop * 2 * 3 + t / max(n_timed, 1) * n_reg_calls  # 2 chunks x 3 radii
+        est = t_sub + t_ground + t_prop * 2 * 3 + (t + t_smp) / max(n_timed, 1) * n_reg_calls  # 2 chunks x 3 radii
         res[th] = 1.0 / est
     return {"value": round(res[threads_all], 6), "unit": "sequences/s", "cores": threads_all, "kind": "port",
             "value_1_core": round(res[1], 6), "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
-            "sample": (f"C++ oracle timed {time.perf_counter() - t_all:.1f}s: 8cm subsample ({t_sub:.2f}s), one "
+            "sample": (f"CPU oracle timed {time.perf_counter() - t_all:.1f}s: 8cm subsample ({t_sub:.2f}s), ground "
+                       f"removal of frames 0-1 (scaled by points: {t_ground:.1f}s per sequence), one "
                        f"10-frame r=0.25 proposal chunk ({t_prop:.2f}s, x6), {n_timed} of the sequence's "
                        f"{n_reg_calls} registrations (anchor 8 <-> frames 7 / 9, 3 keys x 3 levels: "
-                       f"{t_reg[1]:.2f}s on 1 core, {t_reg[threads_all]:.2f}s on {threads_all}); sampling between "
-                       "registrations and ground removal excluded; scaled to one sequence")}
+                       f"{t_reg[1]:.2f}s on 1 core, {t_reg[threads_all]:.2f}s on {threads_all}; the voxel sampling "
+                       f"of both frames in front of each: {t_smp:.2f}s); scaled to one sequence")}
 
 
 def stage_rooflines(records, stats, prof, out):
@@ -299,15 +324,20 @@ def main():
         # the N > 1 logic without a GPU: a rank "tracks" for 10 ms x (1 + rank) per step
         device = torch.device("cpu")
         t0 = time.perf_counter()
+        dry_steps = []
         for _ in range(args.steps):
+            ts = time.perf_counter()
             time.sleep(0.01 * (1 + rank))
+            dry_steps.append((time.perf_counter() - ts) * 1e3)
         dt = time.perf_counter() - t0
         dt, (nseq, seed_sum) = reduce_metrics(dist, device, dt, [float(args.steps), float(seeds[0])])
+        per_rank = gather_rank_steps(dist, device, dry_steps)
         if rank == 0:
             print(json.dumps({"metric": baseline_metric(), "value": round(nseq / dt, 5), "unit": "sequences/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "data": "none (dry run)",
+                              "per_rank_step_ms": per_rank,
                               "config": {"workload": "dry run: rank / sequence assignment and metric reduction",
                                          "sequence_seed_sum": seed_sum, "backend": args.backend}}), flush=True)
         if dist is not None:
@@ -392,6 +422,7 @@ def main():
     tracker = model.preprocessors[2]
     dt, (total_sequences, points_in) = reduce_metrics(
         dist, device, dt, [float(args.steps * B), float(args.steps) * float(n_points_in)])
+    per_rank_steps = gather_rank_steps(dist, device, step_ms)
     # one sequence alone through the same model (its 9 units in the engine, nothing beside it): its latency,
     # and the outputs / tracker counters the report below quotes (the batch's worker copies are gone)
     with torch.no_grad():
@@ -444,6 +475,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "step_ms": step_stats(step_ms),
+            "per_rank_step_ms": per_rank_steps,
             "host_fallbacks": int(host_fallbacks),
             "device_allocations_in_timed_steps": int(device_allocs),
             "reserved_GiB": round(torch.cuda.memory_reserved() / 2**30, 1),

@@ -36,6 +36,9 @@ def test_bench_launches_two_ranks_and_reduces():
     # 6 sequences in the time of the slower rank (rank 1 sleeps 20 ms per step)
     assert res["ms_per_step"] >= 19.0
     assert abs(res["value"] - 6.0 / (res["ms_per_step"] * 3e-3)) / res["value"] < 1e-3
+    # every rank's own step times travel with the reduced line: a straggler shows (rank 1 sleeps twice as long)
+    pr = res["per_rank_step_ms"]
+    assert len(pr) == 2 and pr[0]["median"] >= 9.0 and pr[1]["median"] >= 19.0 and pr[1]["median"] > pr[0]["median"] * 1.5
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

@@ -43,7 +43,7 @@ def test_summarize_pmc_on_a_synthetic_csv(tmp_path):
 
 
 def test_shell_recipes_parse():
-    for name in ("profile_sequence.sh", "profile_concurrent.sh", "pmc_pass.sh", "wg_trace.sh"):
+    for name in ("profile_sequence.sh", "profile_concurrent.sh", "profile_batch.sh", "pmc_pass.sh", "pmc_batch.sh", "ab_bench.sh"):
         r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", name)], capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr)
 
@@ -53,6 +53,7 @@ def test_bench_defaults():
     assert r.returncode == 0, r.stderr
     text = " ".join(r.stdout.split())
     assert "--batch" in text and "--inflight" in text and "--gpus" in text
+    assert "--schedule" in text and "--pre-streams" in text and "--engines" in text
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'add_argument("--batch", type=int, default=12' in src
     assert 'add_argument("--steps", type=int, default=3' in src

@@ -35,6 +35,15 @@ def build_model(save=False, verbose=False, device="cuda", units_per_call=None):
     return model.to(device).eval()
 
 
+def ground_cfg():
+    """The GroundPlaneRemover entry of cluster_tracking_TLS_multiradius_every8.yaml as the plain dictionary the
+    ground stage (and its CPU oracle) takes."""
+    cfg = config.cfg_from_yaml_file(config.CLUSTER_TRACKING_TLS_MULTIRADIUS_EVERY8)
+    g = dict(cfg.MODEL.PREPROCESSORS[0])
+    return {k: g[k] for k in ("PILLAR_SIZE", "RANSAC", "SIGMA2", "K", "JointOpt", "LR", "DECAY_STEPS", "RIGID_WEIGHT",
+                              "MAX_NUM_ITERS", "TRUNCATE_HEIGHT")}
+
+
 def loader_cfg(root, num_sweeps):
     """tools/cfgs/dataset_configs/waymo/PCsequence/registration/all_sequence.yaml of the reference."""
     from pcseqlearning_amd.pcdet.utils.common_utils import EasyDict

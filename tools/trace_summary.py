@@ -3,7 +3,8 @@
 Per kernel: launches, total ms, mean / median us, mean grid size (workgroups), and the share of the
 window; per queue: launches, busy ms; overall: time-weighted mean number of kernels running. For the
 three ICP iteration kernels: mean duration by number of batch entries (gridDim.y where it is the
-entry count) and by how many other kernels ran beside them."""
+entry count) and by how many other kernels ran beside them; the spans of the ICP chunks (what bench.py's
+roofline row times, so that its frac can be recomputed from the trace alone)."""
 import bisect
 import collections
 import csv
@@ -73,6 +74,49 @@ def main():
             by_c[min(c, 8)].append(e - s)
         print(name, "by entries (gridDim.y, bins of 16):", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_n.items())})
         print(name, "by kernels beside it:", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_c.items())})
+    chunk_spans(rows)
+
+
+def chunk_spans(rows):
+    """The quantity bench.py's roofline row times with HIP events, recomputed from the trace: a CHUNK of the fused
+    ICP = the iteration launches between two icp_decide_kernel dispatches of one queue; its span = start of its
+    first icp_nn_kernel to the end of its last icp_apply_kernel (resident schedules: start of icp_tile_kernel /
+    icp_loop_kernel to the end of icp_loop_kernel). Entries = gridDim.y of the budget-test launches."""
+    by_q = collections.defaultdict(list)
+    for s, e, n, q, g, gy in rows:
+        if "icp_" in n:
+            by_q[q].append((s, e, n, gy))
+    spans, entries, inner = [], [], []
+    for q, v in by_q.items():
+        first, last, ent, ksum = None, None, 0, 0
+        for s, e, n, gy in v:
+            if "icp_decide_kernel" in n:
+                if first is not None and last is not None:
+                    spans.append(last - first)
+                    entries.append(ent)
+                    inner.append(ksum)
+                first, last, ent, ksum = None, None, 0, 0
+                continue
+            it = any(t in n for t in ("icp_nn_kernel", "icp_nn_search_kernel", "icp_solve_kernel", "icp_apply_kernel"))
+            if not it:
+                continue
+            if "icp_nn_kernel" in n and "search" not in n:
+                if first is None:
+                    first = s
+                ent = max(ent, gy)
+            if first is not None:
+                ksum += e - s
+                if "icp_apply_kernel" in n:
+                    last = e
+    if spans:
+        m = sum(spans) / len(spans)
+        print(f"ICP chunks (wide schedule): {len(spans)} chunks, mean span {m / 1e3:.1f} us (first budget-test start to last "
+              f"apply end; bench.py's roofline 'avg_us_per_launch'), sum of their kernels' durations {sum(inner) / len(inner) / 1e3:.1f} us, "
+              f"mean entries {sum(entries) / len(entries):.1f}")
+        by_e = collections.defaultdict(list)
+        for sp, en in zip(spans, entries):
+            by_e[min(en // 8 * 8, 64)].append(sp)
+        print("  chunk span by entries (bins of 8):", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_e.items())})
 
 
 if __name__ == "__main__":
