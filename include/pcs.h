@@ -181,20 +181,38 @@ int pcs_indice_maxpool_backward_f32(const float* features, const float* out_feat
                                     int64_t pair_stride, const int32_t* num, int kv, int64_t num_in,
                                     float* in_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);
 
-/* sparse_conv_ext.indice_conv_half / fused_indice_conv_half / indice_maxpool_half (src/all.cc:35-49: the
- * reference's templates instantiated for at::Half). features / filters / bias / out hold IEEE fp16 bit
- * patterns. The fp16 arrays are widened once, the fp32 kernels run (fp32 accumulation over all offsets,
- * where the reference rounds each offset's GEMM to fp16 and adds in fp16) and the result is rounded to
- * fp16 once; the pooling is exact. bias: [cout] or NULL (NULL = indice_conv_half). */
+/* sparse_conv_ext.indice_conv_half / fused_indice_conv_half / indice_conv_backward_half / indice_maxpool_half /
+ * indice_maxpool_backward_half (src/all.cc:35-50: the reference's templates instantiated for at::Half).
+ * features / filters / bias / gradients / outputs hold IEEE fp16 bit patterns. The fp16 rows are gathered as
+ * they are (half the bytes of the fp32 path), the products run on the fp16 matrix pipe
+ * (v_mfma_f32_16x16x32_f16; Cin % 16 == 0 and Cout in {16,32,64,128}, other shapes one thread per output
+ * element) with fp32 accumulation over ALL offsets, and the result is rounded to fp16 once -- where the
+ * reference rounds each offset's GEMM to fp16 and adds in fp16. The pooling is exact; its backward adds the
+ * selected gradients in fp16 in ascending offset, as the reference's functor does on at::Half.
+ * bias: [cout] or NULL (NULL = indice_conv_half). ws: *_workspace_bytes. */
 size_t pcs_indice_conv_f16_workspace_bytes(int64_t num_in, int cin, int kv, int cout, int64_t num_out);
 int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const void* filters, int kv, int cout,
                         const void* bias, const int32_t* pairs, int64_t pair_stride, const int32_t* num,
                         int64_t num_out, int inverse, int subm, void* out, void* ws, size_t ws_bytes,
                         pcs_stream_t stream);
+/* the same on a cached output-major neighbour table (pcs_build_neighbor_table), with an optional ReLU: the form the
+ * module path uses (an eval-mode BatchNorm folds into filters and bias on the host side) */
+int pcs_indice_conv_table_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                              const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
+                              pcs_stream_t stream);
+size_t pcs_indice_conv_backward_f16_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin, int cout);
+int pcs_indice_conv_backward_f16(const void* features, int cin, const void* filters, int kv, int cout,
+                                 const void* out_grad, const int32_t* pairs, int64_t pair_stride,
+                                 const int32_t* num, int64_t num_in, int64_t num_out, int inverse, int subm,
+                                 void* in_grad, void* filters_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);
 size_t pcs_indice_maxpool_f16_workspace_bytes(int64_t num_in, int C, int kv, int64_t num_out);
 int pcs_indice_maxpool_f16(const void* features, int64_t num_in, int C, const int32_t* pairs, int64_t pair_stride,
                            const int32_t* num, int kv, int64_t num_out, void* out, void* ws, size_t ws_bytes,
                            pcs_stream_t stream);
+/* ws: pcs_neighbor_table_bytes(num_in, kv) */
+int pcs_indice_maxpool_backward_f16(const void* features, const void* out_features, const void* out_grad, int C,
+                                    const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
+                                    int64_t num_in, void* in_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);
 
 /* SparseConvTensor.dense() (pcdet/ops/spconv/structure.py:5-18,55-64) in its channels-first form, as
  * HeightCompression consumes it (pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-27;

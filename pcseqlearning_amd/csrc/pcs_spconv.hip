@@ -752,47 +752,284 @@ extern "C" int pcs_sparse_to_dense(const float* features, const int32_t* indices
 }
 
 // ---- half-precision entry points (sparse_conv_ext.indice_conv_half / fused_indice_conv_half /
-// indice_maxpool_half, src/all.cc:35-49) ----------------------------------------------------------
-// The reference instantiates its gather - GEMM - scatter-add templates for at::Half: fp16 storage,
-// each offset's GEMM result rounded to fp16 and added into the fp16 output. Here the fp16 arrays are
-// widened once, the fp32 kernels above run (fp32 accumulation over ALL offsets), and the result is
-// rounded to fp16 once: at least as accurate, the storage format of the caller unchanged. The pooling
+// indice_conv_backward_half / indice_maxpool_half / indice_maxpool_backward_half, src/all.cc:35-50) ----
+// The reference instantiates its gather - GEMM - scatter-add templates for at::Half: fp16 storage, each
+// offset's GEMM result rounded to fp16 and added into the fp16 output. Here the fp16 rows are gathered
+// as they are (half the bytes of the fp32 path -- the convs are gather-bound), the products run on the
+// matrix cores' fp16 pipe (v_mfma_f32_16x16x32_f16: exact products, fp32 accumulation over ALL offsets and
+// channels) and the result is rounded to fp16 ONCE: at least as accurate as the reference's per-offset
+// roundings, the storage format of the caller unchanged, no conversion sweeps, no fp32 copies. The pooling
 // is exact either way (a maximum of fp16 values is one of them).
 #include <hip/hip_fp16.h>
 namespace pcs {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H_LD = CIN_MAX + 8;  // halves per LDS row: 144 B (a multiple of 16 B; rows start 4 banks apart)
+
+// Cin % 16 == 0, Cout in {16, 32, 64, 128}: the f32 kernel's 64-row output tile and staging scheme. The gathered
+// rows sit in LDS as [row][channel], W[k] TRANSPOSED as [column][channel], so that a lane's eight consecutive
+// k of either operand are one 16-byte LDS read. Fragment maps (cdna_hip_programming.md 3): A[i = l & 15]
+// [k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col = l & 15], D: col = l & 15, row = (l >> 4) * 4 + reg.
+// Channels are staged in slices of at most CIN_MAX, padded with zeros to a multiple of 32 (the K of one MFMA).
+template <int NC>
 __global__ void __launch_bounds__(kBlock)
-half_to_float_kernel(const __half* __restrict__ in, float* __restrict__ out, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = __half2float(in[i]);
+indice_conv_f16_mfma_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
+                            int centre, const int32_t* __restrict__ table, int64_t num_out,
+                            const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+  constexpr int COUT = NC * 16;
+  __shared__ __align__(16) _Float16 As[TM][H_LD];
+  __shared__ __align__(16) _Float16 Wt[COUT][H_LD];
+  __shared__ int Tt[TM][32];   // the tile's rows of the neighbour table (kv <= 32)
+  __shared__ int steps[32];    // active offsets, accumulation order (centre first for subM)
+  __shared__ int nsteps;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TM;
+  for (int e = tid; e < TM * kv; e += kBlock) {
+    int r = e / kv, k = e - r * kv;
+    int64_t gr = row0 + r;
+    Tt[r][k] = gr < num_out ? table[gr * kv + k] : -1;
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wave: which offsets have a partner in this tile, in accumulation order
+    int n = 0;
+    for (int step = 0; step < kv; ++step) {
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      bool any = __ballot(Tt[tid][k] >= 0) != 0;
+      if (any) { if (tid == 0) steps[n] = k; ++n; }
+    }
+    if (tid == 0) nsteps = n;
+  }
+  __syncthreads();
+  const int slices = (cin + CIN_MAX - 1) / CIN_MAX;
+  const int ns = nsteps * slices;
+  f32x4 acc[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint4 zero16 = make_uint4(0u, 0u, 0u, 0u);
+  for (int si = 0; si < ns; ++si) {
+    const int k = steps[si / slices], h = si - (si / slices) * slices;
+    const int cs = min(CIN_MAX, cin - h * CIN_MAX);  // channels of this slice (a multiple of 16)
+    const int cs32 = (cs + 31) & ~31;                // ... as the MFMAs see them
+    const int ch8 = cs32 >> 3;
+    // the gathered rows: 16 bytes (8 channels) per thread and step of the loop, zeros past the slice / the row
+    for (int e = tid; e < TM * ch8; e += kBlock) {
+      const int r = e / ch8, c8 = e - r * ch8;
+      uint4 v = zero16;
+      const int in = Tt[r][k];
+      if (in >= 0 && c8 * 8 < cs) v = *(const uint4*)(feat + (int64_t)in * cin + h * CIN_MAX + c8 * 8);
+      *(uint4*)&As[r][c8 * 8] = v;
+    }
+    // W[k][channel][column] -> Wt[column][channel]: 8 columns of one channel per thread and step
+    const __half* Wk = W + ((int64_t)k * cin + h * CIN_MAX) * COUT;
+    for (int e = tid; e < cs32 * (COUT / 8); e += kBlock) {
+      const int c = e / (COUT / 8), j8 = e - c * (COUT / 8);
+      uint4 v = zero16;
+      if (c < cs) v = *(const uint4*)(Wk + (int64_t)c * COUT + j8 * 8);
+      const _Float16* hv = (const _Float16*)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Wt[j8 * 8 + j][c] = hv[j];
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < cs32; c0 += 32) {
+      const f16x8 a = *(const f16x8*)&As[wv * 16 + fi][c0 + 8 * fk];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const f16x8 b = *(const f16x8*)&Wt[n * 16 + fi][c0 + 8 * fk];
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int col = n * 16 + fi;
+    const float bv = bias ? __half2float(bias[col]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = row0 + wv * 16 + fk * 4 + j;
+      if (r >= num_out) continue;
+      float v = acc[n][j] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      out[r * COUT + col] = __float2half_rn(v);
+    }
+  }
+}
+
+// any (Cin, Cout): one thread per output element, fp32 accumulation in the same order, one rounding
+__global__ void __launch_bounds__(kBlock)
+indice_conv_f16_generic_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
+                               int cout, int centre, const int32_t* __restrict__ table, int64_t num_out,
+                               const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+  const int64_t total = num_out * cout;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / cout;
+    const int col = (int)(t - r * cout);
+    float acc = 0.f;
+    for (int step = 0; step < kv; ++step) {
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      const int in = table[r * kv + k];
+      if (in < 0) continue;
+      const __half* f = feat + (int64_t)in * cin;
+      const __half* w = W + ((int64_t)k * cin) * cout + col;
+      for (int c = 0; c < cin; ++c) acc = fmaf(__half2float(f[c]), __half2float(w[(int64_t)c * cout]), acc);
+    }
+    if (bias) acc = acc + __half2float(bias[col]);
+    if (relu) acc = fmaxf(acc, 0.f);
+    out[t] = __float2half_rn(acc);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+transpose_filters_f16_kernel(const __half* __restrict__ W, int kv, int cin, int cout, __half* __restrict__ Wt) {
+  const int64_t total = (int64_t)kv * cin * cout;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = t / ((int64_t)cin * cout);
+    const int r = (int)(t - k * cin * cout);
+    const int ci = r / cout, co = r - ci * cout;
+    Wt[(k * cout + co) * cin + ci] = W[t];
+  }
+}
+
+// filter gradient from fp16 rows: the fp32 tile kernel's scheme (per (1024-pair chunk, offset, 32 x 32 tile) outer
+// products in fp32 registers, partials in fp32, then the chunks in ascending order), rounded to fp16 at the end
+__global__ void __launch_bounds__(kBlock)
+filter_grad_partial_f16_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ og, int cout,
+                               const int32_t* __restrict__ pairs, int64_t pair_stride,
+                               const int32_t* __restrict__ num, int side_in, int tiles_j,
+                               float* __restrict__ partial, int kv) {
+  const int chunk = blockIdx.x, k = blockIdx.y;
+  const int ti0 = (blockIdx.z / tiles_j) * kGT, tj0 = (blockIdx.z % tiles_j) * kGT;
+  const int n = num[k];
+  const int p0 = chunk * kGradChunk;
+  if (p0 >= n) return;
+  const int p1 = min(n, p0 + kGradChunk);
+  const int32_t* pin = pairs + ((int64_t)k * 2 + side_in) * pair_stride;
+  const int32_t* pout = pairs + ((int64_t)k * 2 + (1 - side_in)) * pair_stride;
+  __shared__ float s_in[kGT][kGT + 1];
+  __shared__ float s_og[kGT][kGT + 1];
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+  for (int pb = p0; pb < p1; pb += kGT) {
+    for (int q = threadIdx.x; q < kGT * kGT; q += kBlock) {
+      const int pr = q >> 5, c = q & 31;
+      const int p = pb + pr;
+      float vi = 0.f, vo = 0.f;
+      if (p < p1) {
+        const int i = pin[p], o = pout[p];
+        if (ti0 + c < cin) vi = __half2float(feat[(int64_t)i * cin + ti0 + c]);
+        if (tj0 + c < cout) vo = __half2float(og[(int64_t)o * cout + tj0 + c]);
+      }
+      s_in[pr][c] = vi;
+      s_og[pr][c] = vo;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int pr = 0; pr < kGT; ++pr) {
+      const float i0 = s_in[pr][2 * ty], i1 = s_in[pr][2 * ty + 1];
+      const float o0 = s_og[pr][2 * tx], o1 = s_og[pr][2 * tx + 1];
+      a00 = fmaf(i0, o0, a00); a01 = fmaf(i0, o1, a01);
+      a10 = fmaf(i1, o0, a10); a11 = fmaf(i1, o1, a11);
+    }
+    __syncthreads();
+  }
+  float* dst = partial + ((int64_t)chunk * kv + k) * cin * cout;
+  const int ci = ti0 + 2 * ty, cj = tj0 + 2 * tx;
+  if (ci < cin && cj < cout) dst[(int64_t)ci * cout + cj] = a00;
+  if (ci < cin && cj + 1 < cout) dst[(int64_t)ci * cout + cj + 1] = a01;
+  if (ci + 1 < cin && cj < cout) dst[(int64_t)(ci + 1) * cout + cj] = a10;
+  if (ci + 1 < cin && cj + 1 < cout) dst[(int64_t)(ci + 1) * cout + cj + 1] = a11;
 }
 __global__ void __launch_bounds__(kBlock)
-float_to_half_kernel(const float* __restrict__ in, __half* __restrict__ out, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = __float2half_rn(in[i]);
+filter_grad_reduce_f16_kernel(const float* __restrict__ partial, const int32_t* __restrict__ num, int kv,
+                              int cin, int cout, __half* __restrict__ dW) {
+  const int64_t per = (int64_t)cin * cout;
+  const int64_t total = (int64_t)kv * per;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / per);
+    const int64_t r = t - (int64_t)k * per;
+    const int chunks = (num[k] + kGradChunk - 1) / kGradChunk;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc = acc + partial[((int64_t)c * kv + k) * per + r];
+    dW[t] = __float2half_rn(acc);
+  }
 }
-struct HalfPlan {
-  float *feat, *filt, *out, *bias;
-  void* table;
-  size_t table_bytes;
-};
-static bool plan_half(Arena& a, int64_t num_in, int cin, int kv, int cout, int64_t num_out, HalfPlan& p) {
-  p.feat = a.take<float>((size_t)(num_in > 0 ? num_in : 1) * cin);
-  p.filt = a.take<float>((size_t)kv * cin * cout);
-  p.out = a.take<float>((size_t)(num_out > 0 ? num_out : 1) * cout);
-  p.bias = a.take<float>(cout);
-  p.table_bytes = pcs_neighbor_table_bytes(num_out, kv);
-  p.table = a.take<char>(p.table_bytes);
-  return a.ok();
+
+// max-pool on the fp16 rows themselves (comparisons of fp16 values are exact in fp32)
+__global__ void __launch_bounds__(kBlock)
+maxpool_fwd_f16_kernel(const __half* __restrict__ feat, int C, const int32_t* __restrict__ table, int kv,
+                       int64_t num_out, __half* __restrict__ out) {
+  const int64_t total = num_out * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / C;
+    const int c = (int)(t - o * C);
+    float acc = 0.f;
+    for (int k = 0; k < kv; ++k) {
+      const int i = table[o * kv + k];
+      if (i < 0) continue;
+      const float v = __half2float(feat[(int64_t)i * C + c]);
+      if (acc < v) acc = v;
+    }
+    out[t] = __float2half_rn(acc);
+  }
+}
+// the reference's half backward adds the selected output gradients in fp16, one offset after the other
+// (maxpool.cc:46-62 on at::Half): the same order and the same rounding after every addition
+__global__ void __launch_bounds__(kBlock)
+maxpool_bwd_f16_kernel(const __half* __restrict__ feat, const __half* __restrict__ outf,
+                       const __half* __restrict__ og, int C, const int32_t* __restrict__ table_t, int kv,
+                       int64_t num_in, __half* __restrict__ din) {
+  const int64_t total = num_in * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    const float v = __half2float(feat[t]);
+    __half acc = __float2half_rn(0.f);
+    for (int k = 0; k < kv; ++k) {
+      const int o = table_t[i * kv + k];
+      if (o < 0) continue;
+      if (__half2float(outf[(int64_t)o * C + c]) == v)
+        acc = __float2half_rn(__half2float(acc) + __half2float(og[(int64_t)o * C + c]));
+    }
+    din[t] = acc;
+  }
+}
+
+// out[o,:] = fp16( (+bias) relu? ( sum_k feat[table[o,k],:] . W[k] ) ) on an output-major table
+static int conv_table_f16(const __half* features, int cin, const __half* filters, int kv, int cout, int centre,
+                          const int32_t* table, int64_t num_out, const __half* bias, int relu, __half* out,
+                          hipStream_t s) {
+  if (num_out == 0) return PCS_OK;
+  const int64_t nb = (num_out + TM - 1) / TM;
+  if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
+  const bool cout_ok = cout == 16 || cout == 32 || cout == 64 || cout == 128;
+  if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX) {
+    switch (cout) {
+      case 16: indice_conv_f16_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 32: indice_conv_f16_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 64: indice_conv_f16_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      default: indice_conv_f16_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+    }
+  } else {
+    indice_conv_f16_generic_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(features, cin, filters, kv, cout, centre,
+                                                                              table, num_out, bias, relu, out);
+  }
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
 }
 }  // namespace pcs
 
 extern "C" {
 
 size_t pcs_indice_conv_f16_workspace_bytes(int64_t num_in, int cin, int kv, int cout, int64_t num_out) {
-  Arena a(nullptr, 0);
-  HalfPlan p;
-  plan_half(a, num_in, cin, kv, cout, num_out, p);
-  return a.off;
+  (void)num_in; (void)cin; (void)cout;
+  return pcs_neighbor_table_bytes(num_out, kv);
 }
 
 // features [num_in,cin], filters [kv,cin,cout], bias [cout] or NULL (fused_indice_conv_half), out
@@ -801,51 +1038,119 @@ int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const voi
                         const void* bias, const int32_t* pairs, int64_t pair_stride, const int32_t* num,
                         int64_t num_out, int inverse, int subm, void* out, void* ws, size_t ws_bytes,
                         hipStream_t s) {
+  using namespace pcs;
   if (!features || !filters || !pairs || !num || !out || !ws || num_in < 0 || num_out < 0 || cin < 1 || cout < 1 ||
       kv < 1)
     return PCS_ERR_ARG;
-  Arena a(ws, ws_bytes);
-  HalfPlan p;
-  if (!plan_half(a, num_in, cin, kv, cout, num_out, p)) return PCS_ERR_WORKSPACE;
+  if (ws_bytes < pcs_neighbor_table_bytes(num_out, kv)) return PCS_ERR_WORKSPACE;
   if (num_out == 0) return PCS_OK;
-  half_to_float_kernel<<<grid_for(num_in * cin), kBlock, 0, s>>>((const __half*)features, p.feat, num_in * cin);
-  half_to_float_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>((const __half*)filters, p.filt,
-                                                                           (int64_t)kv * cin * cout);
-  if (bias) half_to_float_kernel<<<1, kBlock, 0, s>>>((const __half*)bias, p.bias, cout);
-  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, inverse, num_out, (int32_t*)p.table, s);
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, inverse, num_out, (int32_t*)ws, s);
   if (rc) return rc;
   const int centre = (subm && (kv & 1)) ? kv / 2 : -1;
-  rc = pcs_indice_conv_table_f32(p.feat, cin, p.filt, kv, cout, centre, (const int32_t*)p.table, num_out,
-                                 bias ? p.bias : nullptr, nullptr, nullptr, 0, p.out, s);
+  return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, (const int32_t*)ws,
+                        num_out, (const __half*)bias, 0, (__half*)out, s);
+}
+
+// the same on a neighbour table the caller keeps (the module path caches it with the rulebook): out =
+// fp16(relu?(sum_k feat[table[:,k]] . W[k] + bias)); centre >= 0: the offset accumulated first (subM)
+int pcs_indice_conv_table_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                              const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
+                              hipStream_t s) {
+  using namespace pcs;
+  if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 || centre >= kv)
+    return PCS_ERR_ARG;
+  return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, table, num_out,
+                        (const __half*)bias, relu, (__half*)out, s);
+}
+
+// indice_conv_backward_half (src/all.cc:36-37; spconv_ops.h:363-449 on at::Half): in_grad [num_in,cin] and
+// filters_grad [kv,cin,cout] in fp16, both from fp32 accumulations rounded once.
+size_t pcs_indice_conv_backward_f16_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin, int cout) {
+  if (num_in < 1) num_in = 1;
+  if (pair_stride < 1) pair_stride = 1;
+  const int64_t chunks = (pair_stride + pcs::kGradChunk - 1) / pcs::kGradChunk;
+  size_t b = pcs::align_up((size_t)num_in * kv * sizeof(int32_t));
+  b += pcs::align_up((size_t)kv * cin * cout * sizeof(__half));
+  b += pcs::align_up((size_t)chunks * kv * cin * cout * sizeof(float));
+  return b;
+}
+int pcs_indice_conv_backward_f16(const void* features, int cin, const void* filters, int kv, int cout,
+                                 const void* out_grad, const int32_t* pairs, int64_t pair_stride,
+                                 const int32_t* num, int64_t num_in, int64_t num_out, int inverse, int subm,
+                                 void* in_grad, void* filters_grad, void* ws, size_t ws_bytes, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !filters || !out_grad || !pairs || !num || !in_grad || !filters_grad || cin < 1 || cout < 1 ||
+      kv < 1 || num_in < 0 || num_out < 0 || pair_stride < 0)
+    return PCS_ERR_ARG;
+  if (!ws || ws_bytes < pcs_indice_conv_backward_f16_workspace_bytes(num_in, pair_stride, kv, cin, cout))
+    return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemsetAsync(filters_grad, 0, (size_t)kv * cin * cout * sizeof(__half), s));
+  if (num_in == 0) return PCS_OK;
+  if (num_out == 0 || pair_stride == 0) {
+    PCS_CHECK_HIP(hipMemsetAsync(in_grad, 0, (size_t)num_in * cin * sizeof(__half), s));
+    return PCS_OK;
+  }
+  char* w = (char*)ws;
+  int32_t* table_t = (int32_t*)w;
+  w += align_up((size_t)num_in * kv * sizeof(int32_t));
+  __half* Wt = (__half*)w;
+  w += align_up((size_t)kv * cin * cout * sizeof(__half));
+  float* partial = (float*)w;
+  // input gradient: the forward conv over the transposed rulebook with W[k]^T
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, inverse ? 0 : 1, num_in, table_t, s);
   if (rc) return rc;
-  float_to_half_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(p.out, (__half*)out, num_out * cout);
+  transpose_filters_f16_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>((const __half*)filters, kv, cin, cout, Wt);
+  const int centre = (subm && (kv & 1)) ? kv / 2 : -1;
+  rc = conv_table_f16((const __half*)out_grad, cout, Wt, kv, cin, centre, table_t, num_in, nullptr, 0, (__half*)in_grad, s);
+  if (rc) return rc;
+  // filter gradient
+  const int64_t chunks = (pair_stride + kGradChunk - 1) / kGradChunk;
+  const int tiles_i = (cin + kGT - 1) / kGT, tiles_j = (cout + kGT - 1) / kGT;
+  if (chunks >= 65536 || kv >= 65536) return PCS_ERR_RANGE;
+  filter_grad_partial_f16_kernel<<<dim3((unsigned)chunks, kv, tiles_i * tiles_j), kBlock, 0, s>>>(
+      (const __half*)features, cin, (const __half*)out_grad, cout, pairs, pair_stride, num, inverse ? 1 : 0, tiles_j,
+      partial, kv);
+  filter_grad_reduce_f16_kernel<<<grid_for((int64_t)kv * cin * cout), kBlock, 0, s>>>(partial, num, kv, cin, cout,
+                                                                                     (__half*)filters_grad);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
 
 size_t pcs_indice_maxpool_f16_workspace_bytes(int64_t num_in, int C, int kv, int64_t num_out) {
-  Arena a(nullptr, 0);
-  a.take<float>((size_t)(num_in > 0 ? num_in : 1) * C);
-  a.take<float>((size_t)(num_out > 0 ? num_out : 1) * C);
-  a.take<char>(pcs_neighbor_table_bytes(num_out, kv));
-  return a.off;
+  (void)num_in; (void)C;
+  return pcs_neighbor_table_bytes(num_out, kv);
 }
 
 int pcs_indice_maxpool_f16(const void* features, int64_t num_in, int C, const int32_t* pairs, int64_t pair_stride,
                            const int32_t* num, int kv, int64_t num_out, void* out, void* ws, size_t ws_bytes,
                            hipStream_t s) {
+  using namespace pcs;
   if (!features || !pairs || !num || !out || !ws || num_in < 0 || num_out < 0 || C < 1 || kv < 1) return PCS_ERR_ARG;
-  Arena a(ws, ws_bytes);
-  float* f = a.take<float>((size_t)(num_in > 0 ? num_in : 1) * C);
-  float* o = a.take<float>((size_t)(num_out > 0 ? num_out : 1) * C);
-  const size_t tb = pcs_neighbor_table_bytes(num_out, kv);
-  void* table = a.take<char>(tb);
-  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  if (ws_bytes < pcs_neighbor_table_bytes(num_out, kv)) return PCS_ERR_WORKSPACE;
   if (num_out == 0) return PCS_OK;
-  half_to_float_kernel<<<grid_for(num_in * C), kBlock, 0, s>>>((const __half*)features, f, num_in * C);
-  int rc = pcs_indice_maxpool_f32(f, C, pairs, pair_stride, num, kv, num_out, o, table, tb, s);
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, 0, num_out, (int32_t*)ws, s);
   if (rc) return rc;
-  float_to_half_kernel<<<grid_for(num_out * C), kBlock, 0, s>>>(o, (__half*)out, num_out * C);
+  maxpool_fwd_f16_kernel<<<grid_for(num_out * C), kBlock, 0, s>>>((const __half*)features, C, (const int32_t*)ws, kv,
+                                                                 num_out, (__half*)out);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// indice_maxpool_backward_half (src/all.cc:48-50): features [num_in,C], out_features / out_grad [num_out,C],
+// in_grad [num_in,C], all fp16; ws: pcs_neighbor_table_bytes(num_in, kv)
+int pcs_indice_maxpool_backward_f16(const void* features, const void* out_features, const void* out_grad, int C,
+                                    const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
+                                    int64_t num_in, void* in_grad, void* ws, size_t ws_bytes, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !out_features || !out_grad || !pairs || !num || !in_grad || C < 1 || kv < 1 || num_in < 0)
+    return PCS_ERR_ARG;
+  if (num_in == 0) return PCS_OK;
+  if (!ws || ws_bytes < pcs_neighbor_table_bytes(num_in, kv)) return PCS_ERR_WORKSPACE;
+  int rc = pcs_build_neighbor_table(pairs, pair_stride, num, kv, 1, num_in, (int32_t*)ws, s);
+  if (rc) return rc;
+  maxpool_bwd_f16_kernel<<<grid_for(num_in * C), kBlock, 0, s>>>((const __half*)features, (const __half*)out_features,
+                                                                (const __half*)out_grad, C, (const int32_t*)ws, kv,
+                                                                num_in, (__half*)in_grad);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

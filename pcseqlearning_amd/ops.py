@@ -355,6 +355,66 @@ def indice_maxpool_half(features, pairs, num, num_out):
     return out
 
 
+def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, relu=False):
+    """pcs_indice_conv_table_f16: the fp16 conv on a cached neighbour table; filters [..., Cin, Cout], bias [Cout]."""
+    L.require_gpu(features, "indice_conv_table_half")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = table.shape[1]
+    W = filters.reshape(kv, cin, cout).half().contiguous()
+    features = features.half().contiguous()
+    b = bias.half().contiguous() if bias is not None else None
+    out = torch.empty(num_out, cout, dtype=torch.float16, device=features.device)
+    centre = kv // 2 if (subm and kv % 2 == 1) else -1
+    L.check(lib.pcs_indice_conv_table_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout), L.i32(centre),
+                                          L.ptr(table.contiguous()), L.i64(num_out), L.ptr(b), L.i32(int(relu)),
+                                          L.ptr(out), L.stream()), "pcs_indice_conv_table_f16")
+    return out
+
+
+def indice_conv_backward_half(features, filters, out_grad, pairs, num, inverse=False, subm=False):
+    """sparse_conv_ext.indice_conv_backward_half (src/all.cc:36-37): (in_grad [num_in,cin], filters_grad like
+    filters), fp16, from fp32 accumulations rounded once (pcs_indice_conv_backward_f16)."""
+    L.require_gpu(features, "indice_conv_backward_half")
+    lib = L.load()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    kv = pairs.shape[0]
+    W = filters.reshape(kv, cin, cout).half().contiguous()
+    features = features.half().contiguous()
+    out_grad = out_grad.half().contiguous()
+    pairs = pairs.contiguous()
+    num_in, num_out = features.shape[0], out_grad.shape[0]
+    in_grad = torch.empty(num_in, cin, dtype=torch.float16, device=features.device)
+    w_grad = torch.empty(kv, cin, cout, dtype=torch.float16, device=features.device)
+    ws = L.workspace(lib.pcs_indice_conv_backward_f16_workspace_bytes(L.i64(num_in), L.i64(pairs.shape[2]), L.i32(kv),
+                                                                      L.i32(cin), L.i32(cout)), features.device)
+    L.check(lib.pcs_indice_conv_backward_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                             L.ptr(out_grad), L.ptr(pairs), L.i64(pairs.shape[2]), L.ptr(num),
+                                             L.i64(num_in), L.i64(num_out), L.i32(int(inverse)), L.i32(int(subm)),
+                                             L.ptr(in_grad), L.ptr(w_grad), L.ptr(ws), L.i64(ws.numel()), L.stream()),
+            "pcs_indice_conv_backward_f16")
+    return in_grad, w_grad.reshape(filters.shape)
+
+
+def indice_maxpool_backward_half(features, out_features, out_grad, pairs, num):
+    """sparse_conv_ext.indice_maxpool_backward_half (src/all.cc:48-50): fp16 in / out, the selected gradients added
+    in fp16 in ascending offset like the reference's functor on at::Half."""
+    L.require_gpu(features, "indice_maxpool_backward_half")
+    lib = L.load()
+    features = features.half().contiguous()
+    out_features = out_features.half().contiguous()
+    out_grad = out_grad.half().contiguous()
+    pairs = pairs.contiguous()
+    kv, C, num_in = pairs.shape[0], features.shape[1], features.shape[0]
+    in_grad = torch.empty(num_in, C, dtype=torch.float16, device=features.device)
+    ws = L.workspace(lib.pcs_neighbor_table_bytes(L.i64(num_in), L.i32(kv)), features.device)
+    L.check(lib.pcs_indice_maxpool_backward_f16(L.ptr(features), L.ptr(out_features), L.ptr(out_grad), L.i32(C),
+                                                L.ptr(pairs), L.i64(pairs.shape[2]), L.ptr(num), L.i32(kv),
+                                                L.i64(num_in), L.ptr(in_grad), L.ptr(ws), L.i64(ws.numel()),
+                                                L.stream()), "pcs_indice_maxpool_backward_f16")
+    return in_grad
+
+
 # ---------------------------------------------------------------- radius graph
 def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, dframe_min=0, dframe_max=0,
                  cell_size=0.0, want_dists=False):

@@ -112,6 +112,15 @@ class SparseConvolution(SparseModule):
                 out_features = out_features * scale + shift
             if relu:
                 out_features = torch.relu(out_features)
+        elif features.dtype == torch.float16:
+            # half-precision features: the fp16 matrix-core kernel (fp16 rows gathered as they are, fp32
+            # accumulation, one rounding). A folded BatchNorm goes into the filters' columns and the bias.
+            w, b = self.weight.float(), (self.bias.float() if self.bias is not None else None)
+            if scale is not None:
+                w = w * scale
+                b = shift if b is None else b * scale + shift
+            out_features = _ops.indice_conv_table_half(features, w, table, outids.shape[0],
+                                                       self.subm and not self.inverse, bias=b, relu=relu)
         else:
             out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
                                                   self.subm and not self.inverse, bias=self.bias, scale=scale,

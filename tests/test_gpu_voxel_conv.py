@@ -462,3 +462,67 @@ def test_half_precision_conv_and_maxpool(oracle):
             want = oracle.indice_maxpool(feat.astype(np.float32), pairs, num, n_out)
             assert pooled.dtype == torch.float16
             np.testing.assert_array_equal(pooled.cpu().numpy().astype(np.float32), want)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 128), (64, 32), (48, 32), (20, 24)])
+def test_half_conv_matrix_core_tiles_vs_fp32_of_the_same_values(oracle, cin, cout):
+    """pcs_indice_conv_f16 on the fp16 matrix pipe (v_mfma_f32_16x16x32_f16: channel counts that are multiples of
+    16, zero-padded to the K of an MFMA; wider than 64 channels in slices) and on the one-thread-per-element form
+    (48 -> slices of 64 + 16-multiple; 20 / 24: not tile shapes): products of fp16 values are exact in fp32, so the
+    result is the fp32 conv of the same values rounded once -- within one fp16 rounding of the oracle's fp32 sum."""
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(100 + cin + cout)
+    shape = [9, 20, 20]
+    idx = random_indices(rng, shape, 1200, batch=2)
+    V = idx.shape[0]
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        feat = rng.normal(0, 1, (V, cin)).astype(np.float16)
+        W = rng.normal(0, 0.1, (27, cin, cout)).astype(np.float16)
+        got = ops.indice_conv_half(dev(feat), dev(W), dev(pairs), dev(num), n_out, False, subm).cpu().numpy()
+        exact = oracle.indice_conv(feat.astype(np.float32), W.astype(np.float32), pairs, num, n_out, False, subm)
+        scale = float(np.abs(exact).max())
+        np.testing.assert_allclose(got.astype(np.float32), exact, rtol=2.0 ** -10, atol=2.0 ** -10 * scale)
+
+
+def test_half_precision_backward_entries(oracle):
+    """indice_conv_backward_half / indice_maxpool_backward_half (src/all.cc:36-37, 48-50): input and filter gradients
+    from fp16 rows with fp32 accumulation, rounded once -- within fp16 rounding of the oracle's fp32 gradients of
+    the same values; the pooling's backward adds the selected gradients in fp16 in ascending offset (the
+    reference's functor on at::Half), restated here in numpy float16."""
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(77)
+    shape = [9, 20, 20]
+    idx = random_indices(rng, shape, 1000, batch=2)
+    V = idx.shape[0]
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        for cin, cout in ((16, 32), (64, 64), (20, 24)):
+            feat = rng.normal(0, 1, (V, cin)).astype(np.float16)
+            W = rng.normal(0, 0.1, (27, cin, cout)).astype(np.float16)
+            og = rng.normal(0, 1, (n_out, cout)).astype(np.float16)
+            g_in, g_w = ops.indice_conv_backward_half(dev(feat), dev(W), dev(og), dev(pairs), dev(num), False, subm)
+            assert g_in.dtype == torch.float16 and g_w.dtype == torch.float16
+            w_in, w_w = oracle.indice_conv_backward(feat.astype(np.float32), W.astype(np.float32), og.astype(np.float32),
+                                                    pairs, num, False, subm)
+            for got, want in ((g_in, w_in), (g_w, w_w)):
+                want = np.asarray(want, np.float32).reshape(got.shape)
+                scale = float(np.abs(want).max())
+                np.testing.assert_allclose(got.cpu().numpy().astype(np.float32), want, rtol=2.0 ** -9,
+                                           atol=2.0 ** -9 * scale)
+        if not subm:
+            feat = rng.integers(-3, 4, (V, 16)).astype(np.float16)  # (ties: several inputs equal the pooled value)
+            pooled = oracle.indice_maxpool(feat.astype(np.float32), pairs, num, n_out).astype(np.float16)
+            og = rng.normal(0, 1, (n_out, 16)).astype(np.float16)
+            got = ops.indice_maxpool_backward_half(dev(feat), dev(pooled), dev(og), dev(pairs), dev(num))
+            want = np.zeros((V, 16), np.float16)
+            for k in range(pairs.shape[0]):  # the reference's loop (maxpool.cc:46-62) on float16
+                for p in range(int(num[k])):
+                    i, o = int(pairs[k, 0, p]), int(pairs[k, 1, p])
+                    hit = feat[i] == pooled[o]
+                    want[i] = np.where(hit, (want[i] + og[o]).astype(np.float16), want[i])
+            np.testing.assert_array_equal(got.cpu().numpy(), want)

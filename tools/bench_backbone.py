@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--mfma", default="both")
     ap.add_argument("--train", action="store_true", help="also time one forward + backward step")
+    ap.add_argument("--half", action="store_true",
+                    help="fp16 voxel features through the backbone (pcs_indice_conv_table_f16: fp16 rows gathered as "
+                         "they are, v_mfma_f32_16x16x32_f16, fp32 accumulation); reported beside the fp32 forward")
     args = ap.parse_args()
     dev = "cuda:0"
     lib = L.load()
@@ -76,6 +79,28 @@ def main():
     lib.pcs_conv_use_mfma(ctypes.c_int(1))
     if len(modes) == 2:
         assert torch.equal(outs[1], outs[0]), "MFMA and FMA tiles must agree bit for bit"
+    half = None
+    if args.half:
+        def forward_half():
+            batch = vfe({"points": pts, "batch_size": args.batch})
+            batch["voxel_features"] = batch["voxel_features"].half()
+            with torch.no_grad():
+                return net(batch)
+
+        o16 = forward_half()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+            o16 = forward_half()
+        e.record()
+        torch.cuda.synchronize()
+        f16 = o16["encoded_spconv_tensor"].features
+        ref = outs[modes[0]]
+        assert f16.dtype == torch.float16 and f16.shape == ref.shape
+        err = (f16.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+        half = {"ms_per_forward": round(s.elapsed_time(e) / args.reps, 3),
+                "max_abs_error_over_fp32_max": round(err, 5)}
     # flops of the conv layers from the rulebooks of the last forward
     d = out["encoded_spconv_tensor"].indice_dict
     chans = {"subm1": [(5, 16), (16, 16)], "spconv2": [(16, 32)], "subm2": [(32, 32)] * 2,
@@ -116,6 +141,15 @@ def main():
             "conv_gflop": round(flops / 1e9, 3),
             "conv_tflops_mfma_path": round(flops / (results.get("mfma", results.get("fma")) * 1e-3) / 1e12, 3),
             "output_voxels_per_rulebook": voxels, "bit_identical_mfma_vs_fma": len(modes) == 2}
+    if half is not None:
+        t16 = half["ms_per_forward"] * 1e-3
+        hb16 = hbm_bytes / 2.0  # fp16 rows: half the feature and filter bytes (the pair lists stay 8 bytes)
+        half["roofline"] = {"bound": "mfma", "achieved": round(flops / t16 / 1e12, 3), "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": round(flops / t16 / 1e12 / 2500.0, 5),
+                            "hbm": {"algorithmic_MB": round(hb16 / 1e6, 1), "achieved_GBs": round(hb16 / t16 / 1e9, 1),
+                                    "frac_of_8TBs": round(hb16 / t16 / 1e9 / 8000.0, 4)},
+                            "note": "fp16 in, fp32 accumulate (v_mfma_f32_16x16x32_f16); the dense fp16 MFMA peak"}
+        line["half"] = half
     if args.train:
         # one training-mode forward + backward through the same network (batch-stat
         # BatchNorm in torch, conv forward on the table kernel, conv backward on
