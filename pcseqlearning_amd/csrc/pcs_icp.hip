@@ -634,25 +634,43 @@ __device__ __forceinline__ void icp_first_phase(const IcpProblem& pr, int Mn, in
       const int fc = frame_cell(g, p.x) + dfq;
       const int cx = (int)floorf((p.y - g.lo[0]) / g.h), cy = (int)floorf((p.z - g.lo[1]) / g.h),
                 cz = (int)floorf((p.w - g.lo[2]) / g.h);
+      int seed = -1;
+      float seed_d2 = __builtin_inff();
       if (fc >= 0 && fc < kFrameCells && cx >= 0 && cy >= 0 && cz >= 0) {
-        uint32_t cnt_w = 0, pad_w = 0;
-        const int fs = g2_find(gh.fslot, gh.Hf - 1, pack_cell(fc, cx, cy, cz), &cnt_w, &pad_w);
-        if (fs >= 0 && cnt_w > 0) {
+        // the first point of the query's own cell; with an empty cell the nearest of the first points of the 26
+        // cells around it. Any point of the other cloud inside the radius will do: it bounds the search (the
+        // ball through it instead of the ball of the whole radius: most first-iteration searches were the latter)
+        auto probe = [&](int x, int y, int z) {
+          uint32_t cnt_w = 0, pad_w = 0;
+          const int fs = g2_find(gh.fslot, gh.Hf - 1, pack_cell(fc, x, y, z), &cnt_w, &pad_w);
+          if (fs < 0 || cnt_w == 0) return;
           const float4 sp = gh.spts[(size_t)fs * kCellCap];
-          const int sidx = gh.sidx[(size_t)fs * kCellCap];
           const float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
           float dist2 = 0.f;
           dist2 = dist2 + d0 * d0;
           dist2 = dist2 + d1 * d1;
           dist2 = dist2 + d2 * d2;
           dist2 = dist2 + d3 * d3;
-          if (g2_seed_admissible(g, gh, p, dfq, dist2, pr.mu)) {
-            to_seeded = true;
-            if (fwd) pr.nn_f[qid] = sidx;  // buffer (k - 1) & 1 = 0: where the searches read their seeds
-            else pr.nn_b[qid - Mn] = sidx;
+          if (dist2 < seed_d2) {
+            seed_d2 = dist2;
+            seed = gh.sidx[(size_t)fs * kCellCap];
+          }
+        };
+        probe(cx, cy, cz);
+        if (seed < 0) {
+#pragma unroll 1
+          for (int q = 0; q < 27; ++q) {
+            if (q == 13) continue;
+            const int x = cx + q % 3 - 1, y = cy + (q / 3) % 3 - 1, z = cz + q / 9 - 1;
+            if (x >= 0 && y >= 0 && z >= 0) probe(x, y, z);
           }
         }
       }
+      if (!(seed_d2 <= g.radius2)) seed = -1;  // (a seed must lie inside the radius)
+      // buffer (k - 1) & 1 = 0: where BOTH searches read their seeds (-1: none)
+      if (fwd) pr.nn_f[qid] = seed;
+      else pr.nn_b[qid - Mn] = seed;
+      to_seeded = seed >= 0 && g2_seed_admissible(g, gh, p, dfq, seed_d2, pr.mu);
     }
     const bool to_coop = valid && !to_seeded;
     const unsigned long long mf = __ballot(fwd);
@@ -704,7 +722,8 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
     float seed_d2 = __builtin_inff();
     if (valid) {
       p = qpts[qi];
-      if (k > 1) {  // the partner of the last iteration, where it is now: an upper bound of the nearest distance
+      {  // the partner of the last iteration (iteration 1: the seed icp_first_phase found), where it is now: an
+         // upper bound of the nearest distance
         const int32_t* __restrict__ seedc = fwd ? pr.nn_f + (size_t)((k - 1) & 1) * pr.capM
                                                 : pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
         const int sd = seedc[qi];
