@@ -459,13 +459,13 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            ratio = pmc.get("icp_loop_traffic_over_algorithmic")
+            ratio = pmc.get("icp_chunk_traffic_over_algorithmic")
             if ratio and launches > 0:
                 traffic = round(ratio * nbytes / launches, 1)
             traffic_src = ("profiles/r04_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                            "this command (same schedule), (fetch + write) / algorithmic = %s (raw FETCH_SIZE; "
                            "%s with the guide's x2 correction for gfx950), times this run's algorithmic bytes "
-                           "per launch" % (ratio, pmc.get("icp_loop_traffic_over_algorithmic_fetch_x2")))
+                           "per launch" % (ratio, pmc.get("icp_chunk_traffic_over_algorithmic_fetch_x2")))
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),

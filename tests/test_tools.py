@@ -43,7 +43,7 @@ def test_summarize_pmc_on_a_synthetic_csv(tmp_path):
 
 
 def test_shell_recipes_parse():
-    for name in ("profile_sequence.sh", "profile_concurrent.sh", "profile_batch.sh", "pmc_pass.sh", "pmc_batch.sh", "ab_bench.sh"):
+    for name in ("profile_sequence.sh", "profile_batch.sh", "pmc_pass.sh", "pmc_batch.sh", "ab_bench.sh"):
         r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", name)], capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr)
 

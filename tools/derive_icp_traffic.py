@@ -1,6 +1,6 @@
 """(fetch + write) / algorithmic bytes of the ICP iteration kernels from the two PMC passes of
-tools/pmc_batch.sh and the bench line one of them printed (algorithmic bytes per launch of the
-{budget test, searches} pair in that same schedule).
+tools/pmc_batch.sh and the bench line one of them printed (algorithmic bytes per chunk -- eight iterations
+of the four iteration kernels -- in that same schedule).
   python tools/derive_icp_traffic.py <FETCH.json> <WRITE.json> <bench line .json>  > profiles/<tag>_icp_hbm_pmc.json
 FETCH_SIZE / WRITE_SIZE are KB per dispatch as rocprofv3 reports them (TCC_EA request counters x 64 B at the
 fabric side of the L2, Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half
@@ -27,24 +27,26 @@ def main():
     out = {"command": "tools/pmc_batch.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py "
                       "--steps 1 --warmup 1 --no-cpu-baseline --no-stages (the default schedule: batches of 12)",
            "per_dispatch_KB": {}}
-    pair_f = pair_w = 0.0
+    tot_f = tot_w = 0.0
     for name in ("icp_nn_kernel", "icp_nn_search_kernel", "icp_solve_kernel", "icp_apply_kernel"):
         f, nf, du = kb(fetch, name, "FETCH_SIZE")
         w, nw, _ = kb(write, name, "WRITE_SIZE")
         out["per_dispatch_KB"][name] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "dispatches": nf,
                                         "mean_duration_us_under_pmc": du}
-        if name in ("icp_nn_kernel", "icp_nn_search_kernel"):
-            pair_f += f * 1024.0
-            pair_w += w * 1024.0
+        tot_f += f * 1024.0
+        tot_w += w * 1024.0
+    # bench.py's roofline row is per CHUNK (a "launch" there): eight iterations = eight dispatches of each kernel
+    per_chunk = 8.0
     alg = float(line["roofline"].get("algorithmic_bytes_per_launch") or 0.0)
-    out["icp_nn_pair_fetch_bytes_per_launch"] = round(pair_f, 1)
-    out["icp_nn_pair_write_bytes_per_launch"] = round(pair_w, 1)
-    out["icp_nn_pair_algorithmic_bytes_per_launch"] = alg
+    out["icp_chunk_fetch_bytes"] = round(tot_f * per_chunk, 1)
+    out["icp_chunk_write_bytes"] = round(tot_w * per_chunk, 1)
+    out["icp_chunk_algorithmic_bytes"] = alg
     if alg > 0:
-        out["icp_nn_pair_traffic_over_algorithmic"] = round((pair_f + pair_w) / alg, 3)
-        out["icp_nn_pair_traffic_over_algorithmic_fetch_x2"] = round((2 * pair_f + pair_w) / alg, 3)
-    out["note"] = ("every launch of the pair is counted (live and gated alike), the algorithmic bytes are those of the "
-                   "event-sampled launches of the same run: the ratio describes the schedule, not one launch")
+        out["icp_chunk_traffic_over_algorithmic"] = round((tot_f + tot_w) * per_chunk / alg, 3)
+        out["icp_chunk_traffic_over_algorithmic_fetch_x2"] = round((2 * tot_f + tot_w) * per_chunk / alg, 3)
+    out["note"] = ("every dispatch of the four iteration kernels is counted (live and gated alike; eight of each per chunk), "
+                   "the algorithmic bytes are those of the event-timed chunks of the same run (live unit-iterations only): "
+                   "the ratio describes the schedule, not one launch")
     json.dump(out, sys.stdout, indent=1)
 
 

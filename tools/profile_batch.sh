@@ -16,7 +16,7 @@ prof_retry() {
   done
 }
 
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
 mkdir -p $O

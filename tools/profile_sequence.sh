@@ -19,7 +19,7 @@ prof_retry() {
   done
 }
 
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
 mkdir -p $O
