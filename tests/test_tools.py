@@ -12,21 +12,32 @@ def _run(args, **kw):
     return subprocess.run([sys.executable, *args], cwd=ROOT, capture_output=True, text=True, timeout=120, **kw)
 
 
-def test_trace_concurrency_on_a_synthetic_trace(tmp_path):
-    rows = ['"Kind","Agent_Id","Queue_Id","Kernel_Name","Start_Timestamp","End_Timestamp","Grid_Size","Workgroup_Size"']
-    t = 1000
-    for i in range(400):  # two queues, kernels of 10 us, half overlapping
-        for q, off in ((1, 0), (2, 5000)):
-            name = ("pcs::icp_nn_kernel(a)", "pcs::icp_nn_search_kernel(a)", "pcs::icp_apply_kernel(a)")[i % 3]
-            rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},"{name}",{t + off},{t + off + 10000},256,256')
-        t += 12000
+def test_trace_summary_on_a_synthetic_trace(tmp_path):
+    """tools/trace_summary.py: per-kernel table, queue busy time, concurrency, and the ICP chunk spans (what bench.py's
+    roofline row times): two queues, each running chunks of 2 iterations x 4 kernels closed by icp_decide_kernel."""
+    rows = ['"Kind","Agent_Id","Queue_Id","Kernel_Name","Start_Timestamp","End_Timestamp","Grid_Size","Workgroup_Size",'
+            '"Grid_Size_Y","Workgroup_Size_Y"']
+    names = ("pcs::icp_nn_kernel(a)", "pcs::icp_nn_search_kernel(a)", "pcs::icp_solve_kernel(a)", "pcs::icp_apply_kernel(a)")
+    for q, off in ((1, 0), (2, 5000)):
+        t = 1000 + off
+        for chunk in range(200):
+            for it in range(2):
+                for n in names:
+                    rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},"{n}",{t},{t + 10000},2560,256,10,1')
+                    t += 12000
+            rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},"pcs::icp_decide_kernel(a)",{t},{t + 2000},640,64,1,1')
+            t += 5000
     path = tmp_path / "trace.csv"
     path.write_text("\n".join(rows) + "\n")
-    r = _run(["tools/trace_concurrency.py", str(path)])
+    r = _run(["tools/trace_summary.py", str(path)])
     assert r.returncode == 0, r.stderr
     assert "mean kernels running" in r.stdout and "queue 1" in r.stdout
     mean = float(r.stdout.split("mean kernels running:")[1].split()[0])
     assert 1.0 < mean < 2.0
+    # a chunk = 8 kernels of 10 us, 12 us apart: first start to last end = 7 * 12 + 10 = 94 us, 10 entries
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("ICP chunks")][0]
+    span = float(line.split("mean span")[1].split()[0])  # (the summary looks at the second half of the trace: its first chunk is cut)
+    assert 93.0 <= span <= 94.0 and "mean entries 10.0" in line, line
 
 
 def test_summarize_pmc_on_a_synthetic_csv(tmp_path):
