@@ -357,6 +357,15 @@ constexpr int kMomSlotsSearch = 16;  // a wide search item settles 8 or 32 pairs
 constexpr int kMomSlotsLoop = 512;   // the unit-resident loop: one table for ALL pairs of an iteration
 constexpr int kHeavyBit = 1 << 30;   // tile path: flag of a work-list entry (query ids stay below 2^26)
 constexpr int kMomProbes = 8;        // slots a component may be looked for in before its pair goes to global memory
+// Layout of the per-component records. The moment accumulators are RECORD-major ([C, kAcc]): a workgroup's table
+// flush and a search item's pairs add 17 consecutive words of one component -- three cache lines of atomics; in the
+// component-minor form (17 lines per record) the same adds made a chunk of iterations 7 % longer under load
+// (A/B on one box, round 4). The transforms (Tb) and steps (Rt) are component-minor ([16, C], [12, C]): they are read
+// by one thread per component (solve) or through the L1 by every point of the component (apply).
+__device__ __forceinline__ int64_t acc_ix(int q, int c, int64_t C) { return (int64_t)c * kAcc + q; }
+__device__ __forceinline__ int64_t acc_stride(int64_t C) { return 1; }
+__device__ __forceinline__ int64_t rt_ix(int q, int c, int64_t C) { return (int64_t)q * C + c; }
+__device__ __forceinline__ int64_t tb_ix(int q, int c, int64_t C) { return (int64_t)q * C + c; }
 struct MomTable {
   int* skey;                      // LDS [nslots]
   unsigned long long* sacc;       // LDS [nslots * 17]
@@ -410,7 +419,7 @@ __device__ __forceinline__ void mom_put(const MomTable& t, int c, const long lon
     for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.sacc[found * 17 + q2], (unsigned long long)v[q2]);
   } else {
 #pragma unroll
-    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[(int64_t)q2 * t.C + c], (unsigned long long)v[q2]);
+    for (int q2 = 0; q2 < 17; ++q2) atomicAdd(&t.acc[acc_ix(q2, c, t.C)], (unsigned long long)v[q2]);
   }
 }
 // Register-lean form for single lanes (the searches' result lanes): the slot first, then every term is
@@ -418,8 +427,8 @@ __device__ __forceinline__ void mom_put(const MomTable& t, int c, const long lon
 __device__ __forceinline__ void mom_add_stream(const IcpProblem& pr, const MomTable& t, float4 pf, float4 qf, int c,
                                                double lim2) {
   const int found = mom_slot(t, c);
-  unsigned long long* base = found >= 0 ? t.sacc + found * 17 : t.acc + c;
-  const int64_t sd = found >= 0 ? 1 : t.C;  // (the global accumulators are component-minor)
+  unsigned long long* base = found >= 0 ? t.sacc + found * 17 : t.acc + acc_ix(0, c, t.C);
+  const int64_t sd = found >= 0 ? 1 : acc_stride(t.C);  // (the global accumulators: one record per component)
   const float4 og = pr.corg[c];
   const double p0 = (double)pf.y - (double)og.y, p1 = (double)pf.z - (double)og.z, p2 = (double)pf.w - (double)og.w;
   const double q0 = (double)qf.y - (double)og.y, q1 = (double)qf.z - (double)og.z, q2 = (double)qf.w - (double)og.w;
@@ -474,7 +483,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
     int key = t.skey[sl];
     if (key >= 0 && key < t.C) {
       const unsigned long long v = t.sacc[q];
-      if (v) atomicAdd(&t.acc[(int64_t)a * t.C + key], v);
+      if (v) atomicAdd(&t.acc[acc_ix(a, key, t.C)], v);
     }
   }
 }
@@ -828,7 +837,7 @@ icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
     float4 p = mov[m], q = ref[r];
     long long a[7];  // n, sum p, sum q
 #pragma unroll
-    for (int q = 0; q < 7; ++q) a[q] = acc[(int64_t)q * pr.C + c];
+    for (int q = 0; q < 7; ++q) a[q] = acc[acc_ix(q, c, (int)pr.C)];
     const float4 og = pr.corg[c];
     const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
     double cm[3], cr[3], sp[3], sq[3];
@@ -841,10 +850,10 @@ icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
     if (MODE == 0) {
       v = dist;
     } else {
-      double mean = ((double)acc[(int64_t)17 * pr.C + c] * kFxInv) / (double)a[0];
+      double mean = ((double)acc[acc_ix(17, c, (int)pr.C)] * kFxInv) / (double)a[0];
       v = fmin(fmax(dist, mean - trunc), mean + trunc);
     }
-    atomicAdd((unsigned long long*)&acc[(int64_t)(MODE == 0 ? 17 : 18) * pr.C + c],
+    atomicAdd((unsigned long long*)&acc[acc_ix(MODE == 0 ? 17 : 18, c, (int)pr.C)],
               (unsigned long long)to_fx(v));
   }
 }
@@ -1039,13 +1048,14 @@ __device__ __forceinline__ void icp_solve_phase(const IcpProblem& pr, IcpState* 
   for (int r = wgx; r < nround; r += nwg) {
     const int64_t c = (int64_t)r * BS + threadIdx.x;
     if (c < C && pr.first[c] != INT_MAX) {  // components with a moving point (the others keep the identity the reset wrote)
-      // the records are component-minor: thread c reads word q of its component next to its neighbours'
+      // the transforms are component-minor (thread c reads word q next to its neighbours'); the moments one record
+      // per component (see acc_ix)
       long long a[17];
       double Tc[16];
 #pragma unroll
-      for (int q = 0; q < 17; ++q) a[q] = acc_k[(int64_t)q * C + c];
+      for (int q = 0; q < 17; ++q) a[q] = acc_k[acc_ix(q, c, (int)C)];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Tc[q] = T_in[(int64_t)q * C + c];
+      for (int q = 0; q < 16; ++q) Tc[q] = T_in[tb_ix(q, c, C)];
       double R[9], t[3], Tn[16];
       const float4 og = pr.corg[c];
       const double org[3] = {(double)og.y, (double)og.z, (double)og.w};
@@ -1056,15 +1066,15 @@ __device__ __forceinline__ void icp_solve_phase(const IcpProblem& pr, IcpState* 
         loss_fx += to_fx_wide(ls);
         loss_ck += __double2ll_rn(ls * 1024.0);
       }
-      double* rt = pr.Rt + c;
+      double* rt = pr.Rt;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) rt[(int64_t)q * C] = R[q];
+      for (int q = 0; q < 9; ++q) rt[rt_ix(q, c, C)] = R[q];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) rt[(int64_t)(9 + q) * C] = t[q];
+      for (int q = 0; q < 3; ++q) rt[rt_ix(9 + q, c, C)] = t[q];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) T_out[(int64_t)q * C + c] = Tn[q];
+      for (int q = 0; q < 16; ++q) T_out[tb_ix(q, c, C)] = Tn[q];
 #pragma unroll
-      for (int q = 0; q < kAcc; ++q) acc_n[(int64_t)q * C + c] = 0;
+      for (int q = 0; q < kAcc; ++q) acc_n[acc_ix(q, c, (int)C)] = 0;
     }
   }
 #pragma unroll
@@ -1116,12 +1126,12 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
     const int i = r * BS + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < Mn) {
-      const double* __restrict__ rc = Rt + comp[i];  // (component-minor: word e of the step at rc[e * C])
+      const int ci = comp[i];
       double R[9], t[3];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) R[q] = rc[(int64_t)q * C];
+      for (int q = 0; q < 9; ++q) R[q] = Rt[rt_ix(q, ci, C)];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) t[q] = rc[(int64_t)(9 + q) * C];
+      for (int q = 0; q < 3; ++q) t[q] = Rt[rt_ix(9 + q, ci, C)];
       float4 p = mov[i];
       prev[i] = p;
       double x = p.y, y = p.z, z = p.w;
@@ -2203,12 +2213,12 @@ __device__ __noinline__ void tile_apply_phase(const IcpProblem* __restrict__ prp
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   for (int i = threadIdx.x; i < Mn; i += kLoopBlock) {
-    const double* __restrict__ rc = Rt + comp[i];
+    const int ci = comp[i];
     double R[9], t[3];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) R[q] = rc[(int64_t)q * C];
+    for (int q = 0; q < 9; ++q) R[q] = Rt[rt_ix(q, ci, C)];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) t[q] = rc[(int64_t)(9 + q) * C];
+    for (int q = 0; q < 3; ++q) t[q] = Rt[rt_ix(9 + q, ci, C)];
     const float4 p = mov[i];
     prev[i] = p;
     const double x = p.y, y = p.z, z = p.w;
@@ -2321,11 +2331,11 @@ icp_finish_kernel(const IcpProblem* __restrict__ tab, Batch bt, IcpState* __rest
   const double* Tfin = pr.Tb + (size_t)(iters & 1) * C * 16;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
-    double n = (double)acc[c];
-    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[(int64_t)18 * C + c] * kFxInv) / n : 0.0;
+    double n = (double)acc[acc_ix(0, c, (int)C)];
+    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[acc_ix(18, c, (int)C)] * kFxInv) / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
     pr.ratio_out[c] = (float)pr.cov[c] / ((float)pr.comp_deg[c] + 1e-6f);
-    for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[(int64_t)q * C + c];
+    for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[tb_ix(q, c, C)];
   }
 }
 

@@ -97,9 +97,10 @@ struct IcpProblem {
   float4* rsrt;         // [capR] tile path: the reference points by block row, (original index bits, x, y, z)
   float4* msrt;         // [capM] tile path: the moving points by block row, rebuilt every iteration
   int32_t* trow;        // [kTileRows + 1] tile path: first row of rsrt of every block row
-  // the per-component records are COMPONENT-MINOR (word q of every component side by side): the solve
-  // phase's thread c and the apply phase's points read them next to their neighbours'
-  long long* acc;       // [2, kAcc, C]
+  // the moments are one record per component (a flush adds 17 consecutive words: three lines of atomics); the
+  // transforms and steps are COMPONENT-MINOR (word q of every component side by side): the solve phase's thread c
+  // and the apply phase's points read them next to their neighbours' (acc_ix / tb_ix / rt_ix in pcs_icp.hip)
+  long long* acc;       // [2, C, kAcc]
   double* Tb;           // [2, 16, C] accumulated transforms, buffer k & 1 after iteration k
   double* Rt;           // [12, C] rotation (9) and translation (3) of the current iteration's step
   long long* lossfx;    // [2][kLossParts] fixed-point partial sums of the components' loss terms (iteration parity), then [2][kLossParts] the same at 10 fractional bits (overflow check)
