@@ -14,6 +14,8 @@
 #pragma once
 #include "pcs_grid.hpp"
 
+#include <climits>
+
 namespace pcs {
 
 constexpr int kCellCap = 16;
@@ -40,6 +42,7 @@ struct Grid2 {
   int32_t* ovf_idx;   // [N]
   float* fr;          // [2*kFrameCells] frame-value range per frame cell
   uint32_t Hf, Hc;
+  uint32_t ovf_cap;   // rows of ovf_pts / ovf_idx
   size_t slot_words;  // 16-byte words of fslot + cslot (contiguous), for the reset loop
 };
 
@@ -57,6 +60,7 @@ static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   g.sidx = a.take<int32_t>((size_t)g.Hf * kCellCap);
   g.ovf_pts = a.take<float4>(N);
   g.ovf_idx = a.take<int32_t>(N);
+  g.ovf_cap = (uint32_t)N;
   g.fr = a.take<float>(2 * kFrameCells);
 }
 
@@ -70,6 +74,21 @@ __device__ __forceinline__ uint32_t g2_claim(Slot* __restrict__ base, uint32_t h
     if (prev == kEmpty || prev == key) return slot;
     slot = (slot + 1) & hmask;
   }
+}
+
+// the same with a bounded walk: -1 when kClaimProbes slots in a row belong to other keys (a table that fills up
+// beyond its design load: the caller then parks the point in the overflow list, which every query scans)
+constexpr int kClaimProbes = 256;
+template <typename Slot>
+__device__ __forceinline__ int g2_claim_bounded(Slot* __restrict__ base, uint32_t hmask, uint64_t key) {
+  uint32_t slot = mix64(key) & hmask;
+  for (int t = 0; t < kClaimProbes; ++t) {
+    uint64_t prev = atomicCAS((unsigned long long*)&base[slot].key, (unsigned long long)kEmpty,
+                              (unsigned long long)key);
+    if (prev == kEmpty || prev == key) return (int)slot;
+    slot = (slot + 1) & hmask;
+  }
+  return -1;
 }
 
 // one 16-byte load per probe: returns the slot index (or -1) and the payload words in *lo / *hi
@@ -121,15 +140,19 @@ static __global__ void __launch_bounds__(kBlock) g2_clear_kernel(Grid2 g) {
 
 // Build: one thread per point. Gating: the kernels of ICP iteration k do nothing once k > *stop
 // (the stop rule has fired).
+// loc (optional): where point i went -- row of spts (>= 0) or ~(row of the overflow list) (< 0)
 __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& g, bool in, int i,
-                                                float4 p, int* __restrict__ err) {
+                                                float4 p, int* __restrict__ err, int32_t* __restrict__ loc = nullptr) {
   int fc = frame_cell(d, p.x);
   int x = (int)floorf((p.y - d.lo[0]) / d.h);
   int y = (int)floorf((p.z - d.lo[1]) / d.h);
   int z = (int)floorf((p.w - d.lo[2]) / d.h);
   bool ok = in && !(x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax ||
                     fc < 0 || fc >= kFrameCells);
-  if (in && !ok) atomicExch(err, 1);
+  if (in && !ok) {
+    atomicExch(err, 1);
+    if (loc) loc[i] = INT_MIN;  // (nowhere: g2_move_point leaves such a point alone)
+  }
   // frame-value range per frame cell: a cloud is usually ONE frame, so every point would hit
   // the same two words -- reduce across the wave first when the wave agrees on the frame cell
   {
@@ -178,6 +201,70 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
   }
   dp[at] = p;
   di[at] = i;
+  if (loc) loc[i] = pos >= kCellCap ? ~(int32_t)at : (int32_t)at;
+}
+
+// A grid whose points MOVE a little between two searches (the moving cloud of an ICP iteration): a point that stays
+// in its fine cell -- nearly all of them once the loop converges -- only has its stored coordinates replaced: one
+// 16-byte store, no atomics, no reset of the tables (a rebuild is five atomics and two scattered stores per point).
+// A point that changes cell leaves a TOMBSTONE in its row (coordinates no query can reach, index -1: every scan
+// treats it as a far point) and is appended to its new cell like a fresh insert, with bounded claims; rows are never
+// reused, so every row has one writer per launch and the order of arrival still changes nothing. Cells and tables
+// only grow: the caller counts the cell changes and rebuilds the grid from scratch when they add up (icp_solve_phase).
+// loc[i]: as g2_insert_point wrote it. Returns true when the point changed its cell.
+constexpr float kTombCoord = 1.0e18f;
+__device__ __forceinline__ bool g2_move_point(const GridDesc& d, const Grid2& g, bool in, int i, float4 po, float4 pn,
+                                              int32_t* __restrict__ loc, int* __restrict__ err) {
+  if (!in) return false;
+  const int fc = frame_cell(d, pn.x);
+  const int ox = (int)floorf((po.y - d.lo[0]) / d.h), oy = (int)floorf((po.z - d.lo[1]) / d.h),
+            oz = (int)floorf((po.w - d.lo[2]) / d.h);
+  const int x = (int)floorf((pn.y - d.lo[0]) / d.h), y = (int)floorf((pn.z - d.lo[1]) / d.h),
+            z = (int)floorf((pn.w - d.lo[2]) / d.h);
+  const int32_t at0 = loc[i];
+  // (a point that never got a row -- out of the grid's range, the call has failed -- or a word that is no location)
+  if (at0 >= 0 ? (uint64_t)at0 >= (uint64_t)g.Hf * kCellCap : (uint32_t)~at0 >= g.ovf_cap) return false;
+  if (x == ox && y == oy && z == oz) {
+    if (at0 >= 0) g.spts[at0] = pn;
+    else g.ovf_pts[~at0] = pn;
+    return false;
+  }
+  const float4 tomb = make_float4(po.x, kTombCoord, kTombCoord, kTombCoord);
+  if (at0 >= 0) {
+    g.spts[at0] = tomb;
+    g.sidx[at0] = -1;
+  } else {
+    g.ovf_pts[~at0] = tomb;
+    g.ovf_idx[~at0] = -1;
+  }
+  if (x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax || fc < 0 || fc >= kFrameCells) {
+    atomicExch(err, 1);
+    return true;
+  }
+  const uint64_t fkey = pack_cell(fc, x, y, z), ckey = pack_cell(fc, x >> 2, y >> 2, z >> 2);
+  const int fs = g2_claim_bounded(g.fslot, g.Hf - 1, fkey);
+  const int cs = fs >= 0 ? g2_claim_bounded(g.cslot, g.Hc - 1, ckey) : -1;
+  int pos = kCellCap;
+  if (cs >= 0) {
+    pos = atomicAdd(&g.fslot[fs].count, 1);
+    atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << ((x & 3) | ((y & 3) << 2) | ((z & 3) << 4)));
+  }
+  if (pos < kCellCap) {
+    const size_t at = (size_t)fs * kCellCap + (size_t)pos;
+    g.spts[at] = pn;
+    g.sidx[at] = i;
+    loc[i] = (int32_t)at;
+  } else {
+    const int at = atomicAdd(g.ovf, 1);
+    if ((uint32_t)at >= g.ovf_cap) {  // (cannot happen while the caller rebuilds as soon as the list grows)
+      atomicExch(err, 1);
+      return true;
+    }
+    g.ovf_pts[at] = pn;
+    g.ovf_idx[at] = i;
+    loc[i] = ~(int32_t)at;
+  }
+  return true;
 }
 
 static __global__ void __launch_bounds__(kBlock)

@@ -60,6 +60,7 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.wl = a.take<int32_t>(Mn + Rn);
   b.wls = a.take<int32_t>(Mn + Rn);
   b.sstep = a.take<unsigned int>(2 * kStepH);
+  b.mloc = a.take<int32_t>(Mn);
   b.rsrt = a.take<float4>(Rn);
   b.msrt = a.take<float4>(Mn);
   b.trow = a.take<int32_t>(kTileRows + 1);
@@ -114,6 +115,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.wl = b.wl;
   pr.wls = b.wls;
   pr.sstep = b.sstep;
+  pr.mloc = b.mloc;
   pr.rsrt = b.rsrt;
   pr.msrt = b.msrt;
   pr.trow = b.trow;
@@ -199,6 +201,10 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->dmax[0] = st->dmax[1] = 0u;
     st->loop_iters = 0;
     st->mode = 0;
+    st->gcur[0] = st->gcur[1] = 1;  // (icp_insert3_kernel fills gm[1])
+    st->grebuild = 1;               // (a fresh grid: the first solve phase takes its overflow count as the baseline)
+    st->gmoves = 0u;
+    st->govf0 = 0;
     st->phase_ticks[0] = st->phase_ticks[1] = st->phase_ticks[2] = st->phase_ticks[3] = 0ULL;
   }
   for (int64_t q = i; q < 2 * C * 16; q += stride) {  // (component-minor: word e of every component side by side)
@@ -302,7 +308,7 @@ icp_insert3_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     int i = r * kBlock + threadIdx.x;
     bool in = i < n;
     float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    g2_insert_point(d, g, in, i, p, &pr.st->err);
+    g2_insert_point(d, g, in, i, p, &pr.st->err, which == 2 ? pr.mloc : nullptr);
   }
 }
 
@@ -516,7 +522,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
   const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
   const float* __restrict__ sbud_f = pr.bud_f + (size_t)((k - 1) & 1) * pr.capM;
   const float* __restrict__ sbud_b = pr.bud_b + (size_t)((k - 1) & 1) * pr.capR;
-  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[k & 1], Mn);
+  const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[pr.st->gcur[k & 1] & 1], Mn);
   for (int r = wgx; r < nround; r += nwg) {  // whole waves stay together (ballots below)
     const int qid = r * BS + threadIdx.x;
     const bool valid = qid < nq;
@@ -715,7 +721,7 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
   const bool fwd = dir == 0;
   int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
   float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
-  const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[k & 1], Mn);  // the hashed cloud
+  const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[st->gcur[k & 1] & 1], Mn);  // the hashed cloud
   const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
   const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
   const int qoff = fwd ? 0 : Mn;
@@ -1042,6 +1048,21 @@ __device__ __forceinline__ void icp_solve_phase(const IcpProblem& pr, IcpState* 
   long long* __restrict__ acc_n = pr.acc + (size_t)((k + 1) & 1) * C * kAcc;
   const double* __restrict__ T_in = pr.Tb + (size_t)((k - 1) & 1) * C * 16;
   double* __restrict__ T_out = pr.Tb + (size_t)(k & 1) * C * 16;
+  if (wgx == 0 && threadIdx.x == 0) {
+    // the moving grid of the next iteration (nothing of this registration runs beside the solve phase): the apply
+    // phase of this iteration moves the points in place (g2_move_point) unless the cell changes since the last
+    // rebuild have added up to a quarter of the points -- tombstones and visited cells only accumulate -- or the
+    // overflow list has grown (every query scans it): then it rebuilds into the other, empty grid
+    int Mn, Rn, Ra;
+    icp_sizes(pr, Mn, Rn, Ra);
+    const int cur = st->gcur[k & 1] & 1;
+    const int ovf = *pr.gm[cur].ovf;
+    if (st->grebuild) st->govf0 = ovf;  // (the grid is fresh: built by the last apply phase, or by the set-up)
+    const bool reb = (uint64_t)st->gmoves * 4u > (uint64_t)Mn || ovf > st->govf0;
+    st->grebuild = reb ? 1 : 0;
+    if (reb) st->gmoves = 0u;
+    st->gcur[(k + 1) & 1] = reb ? (cur ^ 1) : cur;
+  }
   long long loss_fx = 0;  // loss terms of the components this thread owns (fixed point)
   long long loss_ck = 0;  // the same at 10 fractional bits (overflow check of the sum, see icp_decide)
   const int nround = (int)((C + BS - 1) / BS);
@@ -1102,13 +1123,15 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
   const int32_t* __restrict__ comp = pr.comp;
   const double* __restrict__ Rt = pr.Rt;
   const int64_t C = pr.C;
-  const Grid2 gm_done = g2_view(pr.gm[k & 1], Mn);
-  const Grid2 gm_next = g2_view(pr.gm[(k + 1) & 1], Mn);
+  // the moving grid (IcpState::gcur): in place, or -- decided by this iteration's solve phase -- rebuilt into the
+  // other grid, which is empty, while the one the searches of this iteration used is reset
+  const int cur = st->gcur[k & 1] & 1;
+  const bool rebuild = st->grebuild != 0;
+  const Grid2 gm_cur = g2_view(pr.gm[cur], Mn);
+  const Grid2 gm_oth = g2_view(pr.gm[cur ^ 1], Mn);
   const int64_t tid = wgx * (int64_t)BS + threadIdx.x;
   const int64_t nthreads = (int64_t)nwg * BS;
-  // the searches of this iteration are done with gm_done: reset it (it is filled again by the apply
-  // of iteration k+1); gm_next was reset by the apply of iteration k-1 and takes the moved points
-  g2_clear(gm_done, tid, nthreads);
+  if (rebuild) g2_clear(gm_cur, tid, nthreads);
   if (tid == 0) {
     st->iters = k;
     st->wl_n[0] = st->wl_n[1] = 0;  // the work lists of iteration k have been served
@@ -1121,10 +1144,11 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
   }
   unsigned int* __restrict__ sstep = pr.sstep + (size_t)(k & 1) * kStepH;
   float step = 0.f;  // largest step of this thread's points
+  int changed = 0;   // this thread's points that left their cell
   const int nround = (Mn + BS - 1) / BS;
   for (int r = wgx; r < nround; r += nwg) {  // whole workgroups stay together (shuffles)
     const int i = r * BS + threadIdx.x;
-    float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 moved = make_float4(0.f, 0.f, 0.f, 0.f), before = moved;
     if (i < Mn) {
       const int ci = comp[i];
       double R[9], t[3];
@@ -1134,6 +1158,7 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
       for (int q = 0; q < 3; ++q) t[q] = Rt[rt_ix(9 + q, ci, C)];
       float4 p = mov[i];
       prev[i] = p;
+      before = p;
       double x = p.y, y = p.z, z = p.w;
       float nx = (float)(x * R[0] + y * R[1] + z * R[2] + t[0]);
       float ny = (float)(x * R[3] + y * R[4] + z * R[5] + t[1]);
@@ -1150,10 +1175,15 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
         atomicMax(&sstep[icp_step_slot(fx >> 3, fy >> 3, fz >> 3)], __float_as_uint(st1));
       }
     }
-    g2_insert_point(d, gm_next, i < Mn, i, moved, &st->err);
+    if (rebuild) g2_insert_point(d, gm_oth, i < Mn, i, moved, &st->err, pr.mloc);
+    else if (g2_move_point(d, gm_cur, i < Mn, i, before, moved, pr.mloc, &st->err)) changed += 1;
   }
   step = wave_max(step);
   if ((threadIdx.x & 63) == 0 && step > 0.f) atomicMax(&st->dmax[k & 1], __float_as_uint(step));
+  if (!rebuild) {
+    changed = wave_sum_i32_lane63(changed);
+    if ((threadIdx.x & 63) == 63 && changed > 0) atomicAdd(&st->gmoves, (unsigned int)changed);
+  }
 }
 
 // ============================================================ wide launches (blockIdx.y = batch entry)

@@ -38,6 +38,13 @@ struct IcpState {
   int wl_n[2];    // queries waiting for the cooperative search
   int ws_n[2];    // queries waiting for the search around their old partner (directly behind wl_n: the two are addressed as int[4])
   unsigned int dmax[2];  // float bits: largest displacement of a moving point in iteration k (slot k & 1)
+  // the moving cloud's grid (g2_move_point): gcur[k & 1] = which of gm[0..1] holds the moving points that the
+  // searches of iteration k see; the solve phase of iteration k decides whether its apply phase moves the points
+  // in place or rebuilds them into the other (empty) grid, and writes gcur[(k + 1) & 1] accordingly
+  int gcur[2];
+  int grebuild;          // the apply phase of the current iteration rebuilds (written by its solve phase)
+  unsigned int gmoves;   // points that have changed their cell since the last rebuild
+  int govf0;             // length of the overflow list right after the last rebuild
   int loop_iters;        // iterations the unit-resident loops have run (the others were wide launches)
   int mode;              // 0: not decided yet, 1: tile path (icp_tile_kernel), 2: cache path (icp_loop_kernel)
   // measurement: 100 MHz ticks (s_memrealtime) the unit-resident loop spent in its four phases -- budget
@@ -94,6 +101,7 @@ struct IcpProblem {
   int32_t* wl;          // [capM + capR] queries handed to the cooperative search
   int32_t* wls;         // [capM + capR] queries handed to the search around their old partner
   unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
+  int32_t* mloc;        // [capM] where moving point i lies in the moving grid (g2_insert_point / g2_move_point)
   float4* rsrt;         // [capR] tile path: the reference points by block row, (original index bits, x, y, z)
   float4* msrt;         // [capM] tile path: the moving points by block row, rebuilt every iteration
   int32_t* trow;        // [kTileRows + 1] tile path: first row of rsrt of every block row
@@ -109,7 +117,7 @@ struct IcpProblem {
   IcpState* st;
   IcpGeom* geom;
   float* bounds;        // [24] min/max of ref, mov, all
-  Grid2 gr, ga, gm[2];  // reference (non-stationary / all), moving (double-buffered)
+  Grid2 gr, ga, gm[2];  // reference (non-stationary / all), moving (one in use, one empty for the next rebuild: IcpState::gcur)
   double* T_out;        // [C,16]
   double* l1_out;       // [C]
   float* ratio_out;     // [C]
@@ -142,6 +150,7 @@ struct IcpBufs {
   Grid2 gr, ga, gm[2];
   int32_t *nn_f, *nn_b, *wl, *wls;
   unsigned int* sstep;
+  int32_t* mloc;
   float4 *rsrt, *msrt;
   int32_t* trow;
   float *bud_f, *bud_b;
