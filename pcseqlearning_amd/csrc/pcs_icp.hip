@@ -145,6 +145,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.capR = (int)(a.Rn > 0 ? a.Rn : 1);
   pr.df = a.frame_offset;
   pr.max_iter = a.max_iter;
+  pr.want = (a.want_l1 ? kIcpWantL1 : 0) | (a.want_ratio ? kIcpWantRatio : 0);
   return PCS_OK;
 }
 
@@ -220,7 +221,7 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   g2_clear(g2_view(pr.gr, Rn), i, stride);
   g2_clear(g2_view(pr.gm[0], Mn), i, stride);
   g2_clear(g2_view(pr.gm[1], Mn), i, stride);
-  g2_clear(g2_view(pr.ga, Ra), i, stride);
+  if (pr.want & kIcpWantRatio) g2_clear(g2_view(pr.ga, Ra), i, stride);
 }
 
 // min / max of the three clouds: blockIdx.z selects the cloud; also the owner (smallest index) of
@@ -301,6 +302,7 @@ icp_insert3_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   const float4* pts = which == 0 ? pr.ref : (which == 1 ? pr.all : (const float4*)pr.mov);
   const int n = which == 0 ? Rn : (which == 1 ? Ra : Mn);
   if ((int64_t)blockIdx.x * kBlock >= n) return;
+  if (which == 1 && !(pr.want & kIcpWantRatio)) return;  // (the grid of all reference points serves the coverage query only)
   const Grid2 g = g2_view(which == 0 ? pr.gr : (which == 1 ? pr.ga : pr.gm[1]), n);
   GridDesc d = pr.geom->g;
   const int nround = (n + kBlock - 1) / kBlock;
@@ -823,7 +825,7 @@ __global__ void __launch_bounds__(kBlock)
 icp_l1_kernel(const IcpProblem* __restrict__ tab, Batch bt, double trunc) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   const int iters = pr.st->iters;
-  if (iters < 1) return;
+  if (iters < 1 || !(pr.want & kIcpWantL1)) return;
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
   const int ne = Mn + Rn;
@@ -2337,7 +2339,7 @@ icp_coverage_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   int Mn, Rn, Ra;
   icp_sizes(pr, Mn, Rn, Ra);
-  if (Mn < 1 || Ra < 1) return;
+  if (Mn < 1 || Ra < 1 || !(pr.want & kIcpWantRatio)) return;
   GridDesc g = pr.geom->g;
   const Grid2 g_all = g2_view(pr.ga, Ra);
   const int nround = (Mn + kBlock / 32 - 1) / (kBlock / 32);
@@ -2362,9 +2364,9 @@ icp_finish_kernel(const IcpProblem* __restrict__ tab, Batch bt, IcpState* __rest
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < C;
        c += (int64_t)gridDim.x * blockDim.x) {
     double n = (double)acc[acc_ix(0, c, (int)C)];
-    pr.l1_out[c] = (iters > 0 && n > 0.5) ? ((double)acc[acc_ix(18, c, (int)C)] * kFxInv) / n : 0.0;
+    pr.l1_out[c] = (iters > 0 && n > 0.5 && (pr.want & kIcpWantL1)) ? ((double)acc[acc_ix(18, c, (int)C)] * kFxInv) / n : 0.0;
     // component_edge_count / (component_deg.float() + 1e-6)  (registration_utils.py:197-199)
-    pr.ratio_out[c] = (float)pr.cov[c] / ((float)pr.comp_deg[c] + 1e-6f);
+    pr.ratio_out[c] = (pr.want & kIcpWantRatio) ? (float)pr.cov[c] / ((float)pr.comp_deg[c] + 1e-6f) : 0.f;
     for (int q = 0; q < 16; ++q) pr.T_out[c * 16 + q] = Tfin[tb_ix(q, c, C)];
   }
 }

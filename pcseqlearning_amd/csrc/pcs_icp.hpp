@@ -128,7 +128,9 @@ struct IcpProblem {
   int Mn, Rn, Ra;       // immediates (cnt3 == nullptr) / capacities of nn_f, nn_b (cnt3 != nullptr)
   int capM, capR;
   int df, max_iter;
+  int want;             // outputs the caller will read: bit 0 the l1 error, bit 1 the coverage ratio (the others are written as 0)
 };
+constexpr int kIcpWantL1 = 1, kIcpWantRatio = 2;
 
 __device__ __forceinline__ void icp_sizes(const IcpProblem& pr, int& Mn, int& Rn, int& Ra) {
   if (pr.cnt3) {
@@ -180,6 +182,9 @@ struct IcpArgs {
   float cell_size;
   double *T, *l1;
   float* ratio;
+  // outputs the caller will not read are not computed (their arrays are written as zeros): the l1 error costs two
+  // passes over the matched pairs, the coverage ratio a grid over all reference points and a search per moving point
+  bool want_l1 = true, want_ratio = true;
 };
 // descriptor of a call on workspace `ws` (host side only; the caller uploads it into its table slot)
 int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out);

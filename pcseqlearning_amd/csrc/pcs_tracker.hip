@@ -1623,6 +1623,9 @@ int Engine::enqueue_tick() {
       ia.T = d.Tl;
       ia.l1 = (h.lv == L - 1) ? d.l1 : d.l1_tmp;
       ia.ratio = (h.lv == 0) ? d.ratio : d.ratio_tmp;
+      // (cluster_tracking.py keeps the error of the last level and the edge ratio of the first: the others are not computed)
+      ia.want_l1 = h.lv == L - 1;
+      ia.want_ratio = h.lv == 0;
       // the descriptors of a tick go up together: staged in pinned memory (one half per tick parity: the
       // previous tick's launch has completed before this half is written again), read by one launch
       TRK_RC(icp_describe(ia, h.p.ws_icp, h.p.icp_bytes, pin_desc_ + (size_t)(ticks_ & 1) * kMaxBatch + e));
