@@ -365,7 +365,19 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   uint64_t mymask = 0;
   int X = bx + sub % 3 - 1, Y = by + (sub / 3) % 3 - 1, Z = bz + sub / 9 - 1;
   if (valid && sub < 27) {
-    if (X >= 0 && Y >= 0 && Z >= 0) {
+    bool reach = X >= 0 && Y >= 0 && Z >= 0;
+    if (BUD && seed_d2 <= d.radius2) {
+      // a point of the hashed cloud is known at seed_d2: nothing beyond the ball through it (+ mu) matters, and a
+      // block that ball does not reach is not even asked for its mask (a ball of half the radius meets 8 of the 27)
+      const float r = sqrtf(fmaxf(seed_d2 - dfsq, 0.f)) + mu;
+      const float lim = (r * r + margin) * 1.00001f + 1e-6f;
+      const float fx = (p.y - d.lo[0]) / d.h, fy = (p.z - d.lo[1]) / d.h, fz = (p.w - d.lo[2]) / d.h;
+      const float ax = fmaxf(fmaxf((float)(4 * X) - fx, fx - (float)(4 * X + 4)), 0.f) * d.h;
+      const float ay = fmaxf(fmaxf((float)(4 * Y) - fy, fy - (float)(4 * Y + 4)), 0.f) * d.h;
+      const float az = fmaxf(fmaxf((float)(4 * Z) - fz, fz - (float)(4 * Z + 4)), 0.f) * d.h;
+      reach = reach && !((ax * ax + ay * ay) + az * az > lim);
+    }
+    if (reach) {
       uint32_t lo = 0, hi = 0;
       int cs = g2_find(g.cslot, g.Hc - 1, pack_cell(fc, X, Y, Z), &lo, &hi);
       if (cs >= 0) mymask = ((uint64_t)hi << 32) | lo;

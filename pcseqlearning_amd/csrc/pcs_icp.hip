@@ -1151,6 +1151,8 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
   for (int r = wgx; r < nround; r += nwg) {  // whole workgroups stay together (shuffles)
     const int i = r * BS + threadIdx.x;
     float4 moved = make_float4(0.f, 0.f, 0.f, 0.f), before = moved;
+    float st1 = 0.f;
+    int sslot = -1;
     if (i < Mn) {
       const int ci = comp[i];
       double R[9], t[3];
@@ -1170,12 +1172,29 @@ __device__ __forceinline__ void icp_apply_phase(const IcpProblem& pr, IcpState* 
       {
         // the verified cache's budget unit: how far this point moved, filed under the place it moved to
         float dx = nx - p.y, dy = ny - p.z, dz = nz - p.w;
-        float st1 = sqrtf((dx * dx + dy * dy) + dz * dz) * 1.000001f + 1e-7f;
+        st1 = sqrtf((dx * dx + dy * dy) + dz * dz) * 1.000001f + 1e-7f;
         step = fmaxf(step, st1);
         const int fx = (int)floorf((nx - d.lo[0]) / d.h), fy = (int)floorf((ny - d.lo[1]) / d.h),
                   fz = (int)floorf((nz - d.lo[2]) / d.h);
-        atomicMax(&sstep[icp_step_slot(fx >> 3, fy >> 3, fz >> 3)], __float_as_uint(st1));
+        sslot = icp_step_slot(fx >> 3, fy >> 3, fz >> 3);
       }
+    }
+    {
+      // neighbours in the array are neighbours in space (the clouds arrive in voxel order): a wave's points fall
+      // into a few 8 x 8 x 8-cell blocks, and one lane per block files the largest step of its lanes (four rounds;
+      // what is left goes lane by lane) -- one atomic per block and wave instead of one per point
+      bool pending = sslot >= 0;
+      unsigned long long rem = __ballot(pending);
+      for (int round = 0; round < 4 && rem; ++round) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int ls = __shfl(sslot, leader, 64);
+        const bool mine = pending && sslot == ls;
+        const float m = wave_max(mine ? st1 : 0.f);
+        if ((int)(threadIdx.x & 63) == leader) atomicMax(&sstep[ls], __float_as_uint(m));
+        pending = pending && !mine;
+        rem = __ballot(pending);
+      }
+      if (pending) atomicMax(&sstep[sslot], __float_as_uint(st1));
     }
     if (rebuild) g2_insert_point(d, gm_oth, i < Mn, i, moved, &st->err, pr.mloc);
     else if (g2_move_point(d, gm_cur, i < Mn, i, before, moved, pr.mloc, &st->err)) changed += 1;
