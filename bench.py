@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--schedule", default="wide", choices=("wide", "resident_tiles", "resident_cache"),
                     help="how the ICP iterations run (ops.icp_set_schedule): wide launches over all registrations in "
                          "flight (default), or one resident workgroup per registration with LDS-staged / hash-grid searches")
+    ap.add_argument("--worker-streams", default="", choices=("", "own", "caller"),
+                    help="SimpleReg's WORKER_STREAMS: every sequence worker on a stream of its own (default) or all on the caller's")
     ap.add_argument("--engines", type=int, default=-1, help="tracker engines per device (ops.track_configure; default 3)")
     ap.add_argument("--chunk-us", type=int, default=-1, help="chunk budget of the resident schedules (default 3000)")
     ap.add_argument("--pre-streams", type=int, default=0,
@@ -364,6 +366,8 @@ def main():
     model = build_model(save=False, device=device)
     if args.inflight > 0:
         model.model_cfg["SEQUENCES_IN_FLIGHT"] = args.inflight
+    if args.worker_streams:
+        model.model_cfg["WORKER_STREAMS"] = args.worker_streams
     if args.stagger_ms >= 0:
         model.model_cfg["SEQUENCE_START_STAGGER_MS"] = args.stagger_ms
     lib = L.load()

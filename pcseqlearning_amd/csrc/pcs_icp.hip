@@ -564,6 +564,9 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
       bud = bud - disp * 1.000001f - 1e-7f;
       float dist2 = __builtin_inff();
       float c0s = 0.f;  // the frame term of the distance
+      // (the pair's component is requested together with the partner, not after the distance test: one level less
+      //  in the chain of dependent loads that a settled query is -- point / partner index, partner, origin)
+      const int c_pair = (fwd || s >= 0) ? pr.comp[fwd ? qid : s] : 0;
       if (s >= 0) {
         sp = fwd ? pr.ref[s] : pr.mov[s];
         float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
@@ -587,7 +590,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
           m_act = true;
           m_p = fwd ? p : sp;
           m_q = fwd ? sp : p;
-          m_c = pr.comp[fwd ? qid : s];
+          m_c = c_pair;
         }
       } else if (SPLIT && s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
         to_seeded = true;  // (the tile path has ONE kind of search: SPLIT = false)

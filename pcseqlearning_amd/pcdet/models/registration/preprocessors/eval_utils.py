@@ -5,6 +5,15 @@ quantities are histograms, computed here in a handful of device ops."""
 import torch
 
 
+def count_into(index, size, weight=None):
+    """torch.bincount(index[weight], minlength=size) for indices known to be < size, without bincount's and the mask's
+    host synchronisations (integer adds: the same counts)."""
+    out = torch.zeros(size, dtype=torch.int64, device=index.device)
+    if index.numel():
+        out.index_add_(0, index, torch.ones_like(index) if weight is None else weight.to(torch.int64))
+    return out
+
+
 def component_box_iou(component, bp_mask, point_gt_box_id, gt_count_per_box):
     """For every distinct component of `component` [n]:
       box  = argmax_b #points of the component inside box b   (bp_mask [B,n], 0/1)
@@ -17,9 +26,9 @@ def component_box_iou(component, bp_mask, point_gt_box_id, gt_count_per_box):
     counts.index_add_(0, inv, bp_mask.t().long())
     has_box = counts.sum(1) > 0
     box = counts.argmax(1)
-    size = torch.bincount(inv, minlength=U)
+    size = count_into(inv, U)
     in_gt = point_gt_box_id >= 0
-    hist = torch.bincount(inv[in_gt] * B + point_gt_box_id[in_gt].long(), minlength=U * B).reshape(U, B)
+    hist = count_into(inv * B + point_gt_box_id.long().clamp(min=0), U * B, in_gt).reshape(U, B)
     inter = hist.gather(1, box[:, None])[:, 0]
     union = size + gt_count_per_box.long()[box] - inter
     iou = inter.double() / (union.double() + 1e-6)
@@ -51,9 +60,9 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     counts.index_add_(0, inv, member.long())
     has_box = counts.sum(1) > 0
     box = counts.argmax(1)
-    size = torch.bincount(inv, minlength=G)
+    size = count_into(inv, G)
     in_gt = gt_local >= 0
-    hist = torch.bincount(inv[in_gt] * bmax + gt_local[in_gt].long(), minlength=G * bmax).reshape(G, bmax)
+    hist = count_into(inv * bmax + gt_local.long().clamp(min=0), G * bmax, in_gt).reshape(G, bmax)
     inter = hist.gather(1, box[:, None])[:, 0]
     gbox = (box_offsets[gframe] + box).clamp(max=max(gt_count_all.numel() - 1, 0))
     union = size + gt_count_all.long()[gbox] - inter

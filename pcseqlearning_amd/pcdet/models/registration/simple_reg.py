@@ -93,6 +93,7 @@ class SimpleReg(RegistrationTemplate):
         # in flight: 0 / 5 / 25 ms -> 1.78 / 1.75 / 1.83 s per batch; 25 ms was round 2's value for 4 in
         # flight and leaves the twelfth worker idle for 275 ms)
         stagger = float(self.model_cfg.get("SEQUENCE_START_STAGGER_MS", 5)) * 1e-3
+        shared = str(self.model_cfg.get("WORKER_STREAMS", "own")) == "caller"
 
         def worker(i=0):
             if stagger > 0 and i > 0:
@@ -100,7 +101,11 @@ class SimpleReg(RegistrationTemplate):
                 time.sleep(stagger * i)
             mods = copy.deepcopy(self.preprocessors)
             try:
-                stream = thread_stream(device)  # this worker's own stream, the same at every call
+                # this worker's own stream, the same at every call -- or (WORKER_STREAMS: "caller") the caller's
+                # stream for every worker: the runtime deals streams to its four hardware queues, three of which
+                # carry the tracker's engines, and a worker's 8 ms search kernel on an engine's queue holds up that
+                # engine's chain
+                stream = main if shared else thread_stream(device)
                 stream.wait_stream(main)
                 with torch.cuda.device(device), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
                     while True:

@@ -46,6 +46,13 @@ def main():
     for q, (c, b) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
         print(f"  queue {q}: {c} dispatches, busy {b / 1e6:.1f} ms ({100 * b / span:.1f} % of the window), "
               f"{icp_q.get(q, 0)} ICP iterations (the engines' chains)")
+    by_qk = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0]))
+    for s_, e_, n, q, g, gy in rows:
+        by_qk[q][n][0] += 1
+        by_qk[q][n][1] += e_ - s_
+    for q in sorted(by_qk):  # whose kernels a queue runs (another stream's long kernel on an engine's queue delays its chain)
+        topk = sorted(by_qk[q].items(), key=lambda kv: -kv[1][1])[:8]
+        print(f"  queue {q} by kernel: " + "; ".join(f"{n.split('::')[-1][:28]} {c} x {t / c / 1e3:.0f} us" for n, (c, t) in topk))
     ev = []
     for s, e, *_ in rows:
         ev.append((s, 1))
@@ -75,6 +82,62 @@ def main():
         print(name, "by entries (gridDim.y, bins of 16):", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_n.items())})
         print(name, "by kernels beside it:", {k: (len(v), round(sum(v) / len(v) / 1e3, 1)) for k, v in sorted(by_c.items())})
     chunk_spans(rows)
+    first_iteration_searches(rows)
+    queue_gaps(rows)
+
+
+def first_iteration_searches(rows):
+    """The search launches split by what they serve: the launch that follows an icp_first_kernel on its queue is the
+    full search of the registrations that begin in that chunk (every query of theirs), the others serve the queries
+    whose cached neighbour failed the budget test."""
+    by_q = collections.defaultdict(list)
+    for s, e, n, q, g, gy in rows:
+        if "icp_first_kernel" in n or "icp_nn_search_kernel" in n:
+            by_q[q].append((s, e, n))
+    cls = {"after icp_first": [], "others": []}
+    for q, v in by_q.items():
+        armed = False
+        for s, e, n in v:
+            if "icp_first_kernel" in n:
+                armed = True
+            else:
+                cls["after icp_first" if armed else "others"].append(e - s)
+                armed = False
+    for k, v in cls.items():
+        if v:
+            v2 = sorted(v)
+            print(f"icp_nn_search_kernel, {k}: {len(v)} launches, total {sum(v) / 1e6:.1f} ms, mean {sum(v) / len(v) / 1e3:.1f} us, "
+                  f"median {v2[len(v2) // 2] / 1e3:.1f} us")
+
+
+def queue_gaps(rows):
+    """Idle time of the engines' queues by the length of the gap between two dispatches: short gaps are the cost of
+    one dependent launch after another, long ones the host between two ticks."""
+    icp_q = set(q for s, e, n, q, g, gy in rows if "icp_apply_kernel" in n)
+    by_q = collections.defaultdict(list)
+    for s, e, n, q, g, gy in rows:
+        if q in icp_q:
+            by_q[q].append((s, e))
+    bins = [(0, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1000), (1000, 10 ** 9)]
+    tot = collections.Counter()
+    cnt = collections.Counter()
+    span = 0
+    for q, v in by_q.items():
+        v.sort()
+        span += v[-1][1] - v[0][0]
+        end = v[0][1]
+        for s, e in v[1:]:
+            gap = s - end
+            if gap > 0:
+                for lo, hi in bins:
+                    if lo * 1000 <= gap < hi * 1000:
+                        tot[(lo, hi)] += gap
+                        cnt[(lo, hi)] += 1
+                        break
+            end = max(end, e)
+    if span:
+        print("engine queues, idle time by gap length (us): " + ", ".join(
+            f"{lo}-{hi if hi < 10 ** 9 else 'inf'}: {cnt[(lo, hi)]} gaps = {100 * tot[(lo, hi)] / span:.1f} %" for lo, hi in bins))
 
 
 def chunk_spans(rows):
