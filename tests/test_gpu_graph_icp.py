@@ -291,6 +291,34 @@ def test_icp_larger_all_schedules(oracle, icp_schedule):
     test_icp_vs_oracle_larger(oracle)
 
 
+@pytest.mark.parametrize("case", ["far_steps", "dense_cells"])
+def test_icp_moving_grid_in_place(oracle, case):
+    """The moving cloud's grid is updated in place between iterations (g2_move_point): far_steps -- most points change
+    their cell in the first iterations (tombstones, appends, rebuilds decided by the solve phase); dense_cells -- cells
+    with far more than kCellCap points (rows in the overflow list, moved and tombstoned there). Same result as the
+    oracle's brute-force neighbours either way."""
+    from oracle import reg_oracle as R
+    from tests.golden.make_golden_reg import make_pair
+    rng = np.random.default_rng(314)
+    if case == "far_steps":
+        moving, ref = make_pair(rng, n_obj=24, pts_per_obj=400, frame_a=5, frame_b=6, shift=0.7, rot=0.1)
+        radius, cell = 1.25, 0.0
+    else:
+        moving, ref = make_pair(rng, n_obj=2, pts_per_obj=1500, frame_a=2, frame_b=3, shift=0.2, extra_static=False)
+        radius, cell = 0.75, 0.6  # (hundreds of points per 0.6 m cell)
+    C = int(moving["component"].max()) + 1
+    o_moved, o_T, o_l1, o_ratio, o_it = R.register_to_next_frame(R.Graph(radius), moving, ref, C, 10.0, 80, 0.05)
+    g = dict(mov_fxyz=moving["fxyz"], mov_comp=moving["component"], mov_frame=moving["frame"],
+             mov_stationary=moving["stationary"], ref_fxyz=ref["fxyz"], ref_frame=ref["frame"],
+             ref_stationary=ref["stationary"], C=np.array(C))
+    T, l1, ratio, moved, iters = _run_icp(g, radius, cell=cell)
+    assert iters == o_it and iters > 3
+    np.testing.assert_allclose(T, o_T, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(l1, o_l1, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ratio, o_ratio, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(moved, o_moved, rtol=0, atol=2e-5)
+
+
 def test_icp_vs_oracle_larger(oracle):
     """Bigger synthetic pair (stationary parts, empty component, negative frame offset)."""
     from oracle import reg_oracle as R
