@@ -5,18 +5,8 @@
 # then (fetch + write) / algorithmic of the four iteration kernels per chunk:
 #   bash tools/pmc_batch.sh <tag>  ->  gpurun_out/prof/<tag>_batch_pmc_{FETCH,WRITE}_SIZE.json, <tag>_icp_hbm_pmc.json
 set -o pipefail
-# rocprofv3's tool library dies now and then (host SIGSEGV inside its copy of a kernel's arguments, in the
-# first seconds, before the GPU has done anything of ours): such a run is started again, three times at most.
-prof_retry() {
-  local n=0 rc=0
-  while :; do
-    "$@"; rc=$?
-    n=$((n + 1))
-    if [ $rc -ne 139 ] || [ $n -ge 3 ]; then return $rc; fi
-    echo "profiler died with SIGSEGV (attempt $n): once more" >&2
-  done
-}
-
+# (rocprofv3's tool library dies now and then in the first seconds -- host SIGSEGV, or a malformed packet that aborts
+#  a queue and leaves the process waiting: ONE attempt under a short timeout; a failed run is started again by hand)
 TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
@@ -28,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmcb_$C
   rm -rf $d
-  prof_retry timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stages --trace > $O/${TAG}_batch_pmc_$C.bench.json 2> $O/pmcb_$C.err || { echo "pmc pass $C failed"; tail -5 $O/pmcb_$C.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stages --trace > $O/${TAG}_batch_pmc_$C.bench.json 2> $O/pmcb_$C.err || { echo "pmc pass $C failed"; tail -5 $O/pmcb_$C.err; exit 1; }
   python3 $ROOT/tools/summarize_pmc.py $d/p_counter_collection.csv > $O/${TAG}_batch_pmc_$C.json
   echo "pmc $C: $(wc -l < $d/p_counter_collection.csv) rows" | tee -a $O/pmc.progress
 done

@@ -3,17 +3,8 @@
 #   bash tools/pmc_pass.sh <tag> "<counter> [<counter> ...]" [bench.py arguments ...]   ->  gpurun_out/prof/<tag>.json
 # e.g.  bash tools/pmc_pass.sh r04_pmc_tcp_tiles "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum" --engines 1 --schedule resident_tiles
 set -o pipefail
-# rocprofv3's tool library dies now and then (host SIGSEGV inside its copy of a kernel's arguments, in the
-# first seconds, before the GPU has done anything of ours): such a run is started again, three times at most.
-prof_retry() {
-  local n=0 rc=0
-  while :; do
-    "$@"; rc=$?
-    n=$((n + 1))
-    if [ $rc -ne 139 ] || [ $n -ge 3 ]; then return $rc; fi
-    echo "profiler died with SIGSEGV (attempt $n): once more" >&2
-  done
-}
+# (rocprofv3's tool library dies now and then in the first seconds: ONE attempt under a timeout; a failed run is
+#  started again by hand)
 
 TAG=$1; COUNTERS=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -22,6 +13,6 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 d=/tmp/pmc_$TAG
 rm -rf $d
-prof_retry timeout -k 10 600 rocprofv3 --pmc $COUNTERS --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --batch 1 --steps 1 --warmup 0 --no-cpu-baseline --no-stages "$@" > $O/$TAG.out 2> $O/$TAG.err || { echo "pmc pass $TAG failed"; tail -5 $O/$TAG.err; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc $COUNTERS --kernel-trace --output-format csv -d $d -o p -- python3 $ROOT/bench.py --batch 1 --steps 1 --warmup 0 --no-cpu-baseline --no-stages "$@" > $O/$TAG.out 2> $O/$TAG.err || { echo "pmc pass $TAG failed"; tail -5 $O/$TAG.err; exit 1; }
 python3 $ROOT/tools/summarize_pmc.py $d/p_counter_collection.csv > $O/$TAG.json
 echo "pmc $TAG: $(wc -l < $d/p_counter_collection.csv) rows"

@@ -4,18 +4,8 @@
 #   bash tools/profile_batch.sh <tag> [extra bench args]  ->  gpurun_out/prof/<tag>_batch_kernel_stats.csv,
 #   <tag>_batch_trace_summary.txt, <tag>_batch_bench_under_rocprofv3.json
 set -o pipefail
-# rocprofv3's tool library dies now and then (host SIGSEGV inside its copy of a kernel's arguments, in the
-# first seconds, before the GPU has done anything of ours): such a run is started again, three times at most.
-prof_retry() {
-  local n=0 rc=0
-  while :; do
-    "$@"; rc=$?
-    n=$((n + 1))
-    if [ $rc -ne 139 ] || [ $n -ge 3 ]; then return $rc; fi
-    echo "profiler died with SIGSEGV (attempt $n): once more" >&2
-  done
-}
-
+# (rocprofv3's tool library dies now and then in the first seconds -- host SIGSEGV, or a malformed packet that aborts
+#  a queue and leaves the process waiting: ONE attempt under a short timeout; a failed run is started again by hand)
 TAG=${1:-r04}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof
@@ -27,6 +17,6 @@ echo "sequences ready" | tee -a $O/batch.progress
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b
 # (bench.py --trace: step lines and Python stacks of a step that takes > 5 s)
-prof_retry timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stages --trace "$@" > $O/${TAG}_batch_bench_under_rocprofv3.json 2> $O/batch.err || { echo "failed"; tail -5 $O/batch.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stages --trace "$@" > $O/${TAG}_batch_bench_under_rocprofv3.json 2> $O/batch.err || { echo "failed"; tail -5 $O/batch.err; exit 1; }
 cp /tmp/prof_b/ks_kernel_stats.csv $O/${TAG}_batch_kernel_stats.csv
 python3 $ROOT/tools/trace_summary.py /tmp/prof_b/ks_kernel_trace.csv 45 | tee $O/${TAG}_batch_trace_summary.txt
