@@ -384,6 +384,21 @@ def main():
             model(batch1)
     for _ in range(args.warmup):
         step()
+    # one sequence alone through the same model (its 9 units in the engines, nothing beside it): its latency, and
+    # the outputs / tracker counters the report below quotes (the batch's worker copies do not survive a step).
+    # BEFORE the timed steps: a kernel trace of this command then ends with the timed steps and nothing else
+    # (tools/trace_summary.py looks at the second half of a trace)
+    with torch.no_grad():
+        model(batch1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        model(batch1)
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) * 1e3
+    out = model.last_outputs[0]
+    tracker = model.preprocessors[2]
+    n_reg_calls = int(tracker.num_registration_calls)
 
     def barrier():
         if dist is not None:
@@ -423,21 +438,9 @@ def main():
     B = len(host_batches)
     host_spans = {k: round(v / (args.steps * B), 4) for k, v in timer.RECORDS.items()
                   if not k.startswith(("Tracking Frame", "ground:"))}
-    tracker = model.preprocessors[2]
     dt, (total_sequences, points_in) = reduce_metrics(
         dist, device, dt, [float(args.steps * B), float(args.steps) * float(n_points_in)])
     per_rank_steps = gather_rank_steps(dist, device, step_ms)
-    # one sequence alone through the same model (its 9 units in the engine, nothing beside it): its latency,
-    # and the outputs / tracker counters the report below quotes (the batch's worker copies are gone)
-    with torch.no_grad():
-        model(batch1)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    with torch.no_grad():
-        model(batch1)
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - t1) * 1e3
-    out = model.last_outputs[0]
 
     if rank == 0:
         # one extra, untimed step with device-synchronised stage spans for the per-stage report
@@ -511,7 +514,7 @@ def main():
                                 f"batch of {B} per step"),
                 "tracking_units_per_sequence": int(getattr(tracker, "last_num_workers", 0)),
                 "tracker_host_ticks": int(getattr(tracker, "last_ticks", 0)),
-                "icp_level_calls_per_sequence": int(tracker.num_registration_calls),
+                "icp_level_calls_per_sequence": n_reg_calls,
                 # host wall spans of the timed steps per sequence (not device-synchronised; the sequences of a
                 # batch overlap, so the spans add up to more than the step)
                 "stage_seconds_per_sequence": host_spans,
@@ -537,7 +540,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_batch, out, int(tracker.num_registration_calls))
+            line["cpu_baseline"] = cpu_baseline(host_batch, out, n_reg_calls)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -19,4 +19,6 @@ rm -rf /tmp/prof_b
 # (bench.py --trace: step lines and Python stacks of a step that takes > 5 s)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stages --trace "$@" > $O/${TAG}_batch_bench_under_rocprofv3.json 2> $O/batch.err || { echo "failed"; tail -5 $O/batch.err; exit 1; }
 cp /tmp/prof_b/ks_kernel_stats.csv $O/${TAG}_batch_kernel_stats.csv
-python3 $ROOT/tools/trace_summary.py /tmp/prof_b/ks_kernel_trace.csv 45 | tee $O/${TAG}_batch_trace_summary.txt
+# the summary's window = the timed steps of the line just printed (they are the end of the run)
+LAST_MS=$(python3 -c "import json,sys; d=json.loads(open('$O/${TAG}_batch_bench_under_rocprofv3.json').read().strip().splitlines()[-1]); print(d['steps'] * d['ms_per_step'])")
+python3 $ROOT/tools/trace_summary.py /tmp/prof_b/ks_kernel_trace.csv 45 $LAST_MS | tee $O/${TAG}_batch_trace_summary.txt

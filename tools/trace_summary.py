@@ -1,5 +1,7 @@
-"""Per-kernel and per-queue summary of a rocprofv3 --kernel-trace run (second half = steady state):
-  python tools/trace_summary.py <..._kernel_trace.csv> [top]
+"""Per-kernel and per-queue summary of a rocprofv3 --kernel-trace run (the second half of the trace, or its last
+`last_ms` milliseconds: bench.py's timed steps are the last thing a `--no-stages --no-cpu-baseline` run does, so
+last_ms = steps x ms_per_step of the line it printed selects exactly what the bench line timed):
+  python tools/trace_summary.py <..._kernel_trace.csv> [top] [last_ms]
 Per kernel: launches, total ms, mean / median us, mean grid size (workgroups), and the share of the
 window; per queue: launches, busy ms; overall: time-weighted mean number of kernels running. For the
 three ICP iteration kernels: mean duration by number of batch entries (gridDim.y where it is the
@@ -23,7 +25,10 @@ def main():
                      r.get("Queue_Id", "?"), gs // max(wg, 1), gy // max(wy, 1)))
     rows.sort()
     t0 = rows[0][0]
-    tmid = t0 + (max(r[1] for r in rows) - t0) // 2
+    t_end = max(r[1] for r in rows)
+    tmid = t0 + (t_end - t0) // 2
+    if len(sys.argv) > 3 and float(sys.argv[3]) > 0:
+        tmid = max(t0, t_end - int(float(sys.argv[3]) * 1e6))
     rows = [r for r in rows if r[0] >= tmid]
     span = max(r[1] for r in rows) - rows[0][0]
     print(f"window {span / 1e6:.1f} ms, {len(rows)} dispatches")
