@@ -38,6 +38,13 @@ def test_trace_summary_on_a_synthetic_trace(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("ICP chunks")][0]
     span = float(line.split("mean span")[1].split()[0])  # (the summary looks at the second half of the trace: its first chunk is cut)
     assert 93.0 <= span <= 94.0 and "mean entries 10.0" in line, line
+    # gaps between dependent launches: 2 us (kernels 12 us apart, 10 us long) and 3 us behind the decide kernel
+    gaps = [ln for ln in r.stdout.splitlines() if ln.startswith("engine queues, idle time")][0]
+    assert "0-5:" in gaps and "1000-inf: 0 gaps" in gaps, gaps
+    assert "by kernel: " in r.stdout
+    # a window of the last 100 ms instead of the second half (what profile_batch.sh passes: the timed steps)
+    r2 = _run(["tools/trace_summary.py", str(path), "10", "1.0"])
+    assert r2.returncode == 0 and r2.stdout.startswith("window 1.0 ms"), r2.stdout[:200] + r2.stderr
 
 
 def test_summarize_pmc_on_a_synthetic_csv(tmp_path):
@@ -54,7 +61,8 @@ def test_summarize_pmc_on_a_synthetic_csv(tmp_path):
 
 
 def test_shell_recipes_parse():
-    for name in ("profile_sequence.sh", "profile_batch.sh", "pmc_pass.sh", "pmc_batch.sh", "ab_bench.sh"):
+    for name in ("profile_sequence.sh", "profile_batch.sh", "pmc_pass.sh", "pmc_batch.sh", "ab_bench.sh", "ab_multi.sh",
+                 "ab_trees.sh"):
         r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", name)], capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr)
 
