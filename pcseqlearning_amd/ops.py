@@ -530,8 +530,9 @@ def points_in_radius_gpu(keys, values, reverse_indices, dims, query_keys, query_
 
 
 # ---------------------------------------------------------------- components / medians
-def connected_components(e0, e1, num_nodes):
-    """graph_utils.connected_components: (num_components, component [N] int64)."""
+def connected_components(e0, e1, num_nodes, host_count=True):
+    """graph_utils.connected_components: (num_components, component [N] int64). host_count=False: the count stays
+    on the device (a one-element int64 tensor): no host synchronisation."""
     L.require_gpu(e0, "connected_components")
     lib = L.load()
     dev = e0.device
@@ -542,7 +543,7 @@ def connected_components(e0, e1, num_nodes):
                                          L.i64(e0.shape[0]), L.i64(num_nodes), L.ptr(comp),
                                          L.ptr(d_num), L.ptr(ws), L.i64(ws.numel()), L.stream()),
             "pcs_connected_components")
-    return int(d_num.item()), comp
+    return (int(d_num.item()) if host_count else d_num), comp
 
 
 def segment_median(data, seg):

@@ -9,12 +9,13 @@ from .... import ops
 from ....lib import PcsError
 
 
-def connected_components(edges, num_nodes=None):
+def connected_components(edges, num_nodes=None, host_count=True):
     """edges [2,E] -> (num_components, component [N]); label = rank of the component by its
-    smallest node id, which is what scipy.sparse.csgraph returns in the reference."""
+    smallest node id, which is what scipy.sparse.csgraph returns in the reference. host_count=False: the count is
+    a one-element device tensor (no host synchronisation)."""
     if num_nodes is None:
         num_nodes = int(edges.max().item()) + 1
-    num, comp = ops.connected_components(edges[0].contiguous(), edges[1].contiguous(), num_nodes)
+    num, comp = ops.connected_components(edges[0].contiguous(), edges[1].contiguous(), num_nodes, host_count)
     return num, comp.to(edges.dtype)
 
 

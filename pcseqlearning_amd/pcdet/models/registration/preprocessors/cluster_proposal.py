@@ -41,12 +41,13 @@ class ClusterProposal(nn.Module):
                   and graphs[0].sort_by_dist and not self.model_cfg.get("SEPARATE_GRAPHS", False))
         components = {k: torch.zeros(num_points, dtype=torch.int64, device=pcseq.fxyz.device)
                       for k in self.component_keys}
-        totals = {k: 0 for k in self.component_keys}
+        # (the running component offsets stay on the device: the counts are only ever added to labels)
+        totals = {k: torch.zeros(1, dtype=torch.int64, device=pcseq.fxyz.device) for k in self.component_keys}
         for f0 in range(0, num_frames, self.chunk):
             mask = (frames >= f0) & (frames < f0 + self.chunk)
-            if not bool(mask.any()):
-                continue
             idx = mask.nonzero(as_tuple=True)[0]
+            if idx.numel() == 0:
+                continue
             pcframe = EasyDict(filter_dict(pcseq, idx))
             n_chunk = pcframe.fxyz.shape[0]
             if shared:
@@ -70,15 +71,16 @@ class ClusterProposal(nn.Module):
                         e0, e1 = e0_all[keep], e1_all[keep]
                     else:
                         e0, e1, _ = graph(pcframe, pcframe)
-                    num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0), n_chunk)
+                    num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0), n_chunk,
+                                                                 host_count=False)
                     timer.count("proposal cc edges", e0.shape[0])
                     timer.count("proposal cc nodes", n_chunk)
                     components[key][idx] = comp.to(torch.int64) + totals[key]
-                    totals[key] += num
+                    totals[key] = totals[key] + num.reshape(1)
         for key in self.component_keys:
             seq_dict[f"point_{key}"] = components[key]
             if self.verbose:
-                print(f"Cluster Proposal {key}: num_components={totals[key]}")
+                print(f"Cluster Proposal {key}: num_components={int(totals[key].item())}")
         return seq_dict
 
     def assign_instances_to_boxes(self, point_instance_label, bp_mask):

@@ -42,11 +42,12 @@ class GroundPlaneRemover(nn.Module):
         seq_dict["point_height"] = point_height
         seq_dict["pillar_height"] = pillar_height
         seq_dict["pillar_min_z"] = pillar_min_z
+        kept = (~ground_mask).nonzero(as_tuple=True)[0]  # (one compaction of the mask for all six arrays)
         for key in ("point_fxyz", "segmentation_label", "point_sweep", "point_height",
                     "instance_label", "point_horizon"):
             if key in seq_dict:
                 seq_dict[f"full_{key}"] = seq_dict[key].clone()
-                seq_dict[key] = seq_dict[key][~ground_mask]
+                seq_dict[key] = seq_dict[key][kept]
         return seq_dict
 
     def get_output_feature_dim(self):

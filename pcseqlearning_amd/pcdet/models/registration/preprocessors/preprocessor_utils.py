@@ -63,9 +63,12 @@ def _knn_self(xyz, k):
 def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cfg, window_size=4):
     dev = voxels.bxyz.device
     ar = torch.arange(num_pillars, device=dev)
-    coords = torch.stack([ar // pillar_dims[1], ar % pillar_dims[1]], dim=-1) // window_size
-    new_dims = coords.max(0)[0].long() + 1
-    num_new = int((new_dims[1] * new_dims[0]).item())
+    # pillar_dims: host integers (format_pillars read them once). The pillars enumerate the whole X x Y grid, so the
+    # super-pillar grid's size follows on the host (the reference takes coords.max() + 1: the same numbers)
+    X, Y = int(pillar_dims[0]), int(pillar_dims[1])
+    coords = torch.stack([ar // Y, ar % Y], dim=-1) // window_size
+    new_dims = ((X - 1) // window_size + 1, (Y - 1) // window_size + 1)
+    num_new = new_dims[0] * new_dims[1]
     pillars.pillar_coords = coords
     pillars.pillar_idx = coords[:, 0] * new_dims[1] + coords[:, 1]
     pillars.best_confidence = torch.zeros_like(pillars.density).reshape(-1)
@@ -136,8 +139,8 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
     if cfg.get("PRUNE_KERNEL", True) and xyz.is_cuda and 0 < xyz.shape[0] and cfg["K"] <= 8:
         # the whole loop in one launch (pcs_prune_plane_hypotheses); more than 2048 hypotheses fall through
         try:
-            keep = ops.prune_plane_hypotheses(xyz, normal, thresholds, cfg["K"])
-            xyz, normal, conf = xyz[keep], normal[keep], conf[keep]
+            keep = ops.prune_plane_hypotheses(xyz, normal, thresholds, cfg["K"]).nonzero(as_tuple=True)[0]
+            xyz, normal, conf = xyz[keep], normal[keep], conf[keep]  # (one compaction of the mask, not three)
             pruned = True
         except PcsError as err:
             if "PCS_ERR_RANGE" not in str(err):
@@ -169,17 +172,17 @@ def compute_min_height_from_ransac(pillar_dims, num_pillars, voxels, pillars, cf
         ind = conf[None, :] / (dist + 1)
         best_val, best_idx = ind.max(dim=1)  # (documented: the first maximal value's index)
         mask = best_val > pillars.best_confidence
-        pillars.best_center[mask] = xyz[best_idx[mask]]
-        pillars.best_normal[mask] = normal[best_idx[mask]]
-        pillars.best_confidence[mask] = best_val[mask]
+        # (selects instead of masked assignments: the same values where the mask holds, no host synchronisation)
+        pillars.best_center = torch.where(mask[:, None], xyz[best_idx], pillars.best_center)
+        pillars.best_normal = torch.where(mask[:, None], normal[best_idx], pillars.best_normal)
+        pillars.best_confidence = torch.where(mask, best_val, pillars.best_confidence)
     t_prop.__exit__(None, None, None)
     vn = pillars.best_normal[voxels.pillar_idx]
     vc = pillars.best_center[voxels.pillar_idx]
     vd = voxels.bxyz[:, 1:] - vc
     nz = vn[:, -1].abs().clamp(min=0.01) * ((vn[:, -1] >= 0).float() + 1) / 2
     vh = ((vd[:, 0] * vn[:, 0] + vd[:, 1] * vn[:, 1]) + vd[:, 2] * vn[:, 2]) / nz
-    pillars.min_z = robust_mean(voxels.bxyz[:, -1] - vh, voxels.pillar_idx, num_pillars).reshape(
-        int(pillar_dims[0]), int(pillar_dims[1]))
+    pillars.min_z = robust_mean(voxels.bxyz[:, -1] - vh, voxels.pillar_idx, num_pillars).reshape(X, Y)
     pillars.height = pillars.min_z.clone()
     return voxels, pillars
 
@@ -188,8 +191,8 @@ def format_pillars(points, pillar_size, pc_range_min):
     pillars = EasyDict()
     points["pillar_coords"] = torch.div(points.bxyz[:, 1:3] - pc_range_min, pillar_size,
                                         rounding_mode="floor").round().long()
-    dims = points.pillar_coords.max(0)[0].long() + 1
-    X, Y = int(dims[0].item()), int(dims[1].item())
+    X, Y = (points.pillar_coords.max(0)[0].long() + 1).tolist()  # (one host read; host integers from here on)
+    dims = (X, Y)
     num_pillars = X * Y
     points["pillar_idx"] = points.pillar_coords[:, 0] * Y + points.pillar_coords[:, 1]
     sg = IndexSegments(points.pillar_idx, num_pillars)

@@ -135,12 +135,13 @@ class SimpleReg(RegistrationTemplate):
         """Frame ids of the (frame-major, equally many per frame) GT boxes, track labels from the
         object ids, per-trace velocity from consecutive corner displacement, `moving` flag."""
         sweeps = seq_dict["point_sweep"]
-        num_frames = int(sweeps.max().long().item()) - int(sweeps.min().long().item()) + 1
+        lo, hi = torch.stack([sweeps.min(), sweeps.max()]).long().tolist()  # (one host read)
+        num_frames = hi - lo + 1
         attr = seq_dict["gt_box_attr"].reshape(-1, 7)
         cls = seq_dict["gt_box_cls_label"].reshape(-1)
         assert attr.shape[0] % num_frames == 0, "expects the same number of boxes in every frame"
         frame = torch.repeat_interleave(torch.arange(0, num_frames), cls.numel() // num_frames).to(cls)
-        keep = attr[:, 3:6].norm(p=2, dim=-1) > 1e-5
+        keep = (attr[:, 3:6].norm(p=2, dim=-1) > 1e-5).nonzero(as_tuple=True)[0]  # (one compaction, one host copy)
         attr, cls, frame = attr[keep], cls[keep], frame[keep]
         obj_ids = np.asarray(seq_dict["obj_ids"]).astype(str).reshape(-1)[keep.cpu().numpy()]
         track = torch.from_numpy(np.unique(obj_ids, return_inverse=True)[1]).to(cls).long()
@@ -149,7 +150,8 @@ class SimpleReg(RegistrationTemplate):
         # traces at once on the (trace, frame)-sorted list)
         velo = torch.zeros_like(attr[:, 0])
         if attr.shape[0] > 1:
-            order = torch.argsort(track * (int(frame.max().item()) + 1) + frame.long(), stable=True)
+            # (any multiplier above the largest frame id gives the same (trace, frame) order: no host read for it)
+            order = torch.argsort(track * num_frames + frame.long(), stable=True)
             tr_s = track[order]
             corners = boxes_to_corners_3d(attr[order])
             same = tr_s[1:] == tr_s[:-1]
@@ -171,7 +173,7 @@ class SimpleReg(RegistrationTemplate):
 
     def build_sequence(self, batch_dict, b):
         seq_dict = EasyDict()
-        mask = (batch_dict["point_bxyz"][:, 0] == b).reshape(-1)
+        mask = (batch_dict["point_bxyz"][:, 0] == b).reshape(-1).nonzero(as_tuple=True)[0]  # (one compaction for all keys)
         for key in ("point_bxyz", "point_feat", "segmentation_label", "instance_label",
                     "is_foreground", "point_sweep"):
             if key in batch_dict:
