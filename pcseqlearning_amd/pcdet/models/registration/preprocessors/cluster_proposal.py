@@ -13,7 +13,7 @@ from ....utils import timer
 from ....utils.common_utils import EasyDict, filter_dict
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
-from .eval_utils import component_box_iou, component_box_iou_frames, scatter_max_
+from .eval_utils import component_box_iou, component_box_iou_frames, count_into, scatter_max_
 
 
 class ClusterProposal(nn.Module):
@@ -141,7 +141,7 @@ class ClusterProposal(nn.Module):
         proto = seq_dict[f"point_{self.component_keys[0]}"]
         dev = fxyz.device
         assert bool((seq_boxes.frame[1:] >= seq_boxes.frame[:-1]).all()), "boxes must be grouped by frame"
-        box_cnt = torch.bincount(seq_boxes.frame.long(), minlength=num_frames)
+        box_cnt = count_into(seq_boxes.frame.long(), num_frames)
         box_off = torch.zeros(num_frames + 1, dtype=torch.int64, device=dev)
         box_off[1:] = box_cnt.cumsum(0)
         bmax = int(box_cnt.max().item())
@@ -160,7 +160,7 @@ class ClusterProposal(nn.Module):
         g_global = box_off[s_fr] + gt_local.clamp(min=0)
         gt_box_id[idx] = gt_local
         gt_trace_id[idx] = torch.where(in_box, seq_boxes.trace_id[g_global].to(proto.dtype), gt_local)
-        gt_cnt_all = torch.bincount(g_global[in_box], minlength=seq_boxes.attr.shape[0])
+        gt_cnt_all = count_into(g_global, seq_boxes.attr.shape[0], in_box)
         for comp_key in self.component_keys:
             comp = seq_dict[f"point_{comp_key}"][idx]
             gframe, _, inv, has_box, box, iou = component_box_iou_frames(comp, s_fr, member, gt_local,

@@ -19,7 +19,7 @@ from ....utils.common_utils import EasyDict, filter_dict, run_deferred, thread_s
 from ....utils.timer import Timer
 from ...model_utils import graph_utils
 from ...model_utils.grid_sampling import GridSampling3D
-from .eval_utils import component_box_iou_frames, scatter_max_
+from .eval_utils import component_box_iou_frames, count_into, scatter_max_
 from .registration_utils import (IndexSegments, efficient_robust_sum, register_to_next_frame,
                                  robust_mean, robust_median, segment_max, segment_min)
 
@@ -80,7 +80,8 @@ def _component_stats(frame_points, sg=None):
     deg = efficient_robust_sum(torch.ones_like(xyz[:, 0]), sg, num_components)
     valid = (deg > 0.5).reshape(-1)
     center = efficient_robust_sum(xyz, sg, num_components)
-    center[valid] = center[valid] / deg[valid, None]
+    # (a select, not a masked assignment: the same quotients where the mask holds, no host synchronisation)
+    center = torch.where(valid[:, None], center / deg.reshape(-1, 1), center)
     return num_components, sg, deg, valid, center
 
 
@@ -188,7 +189,7 @@ class ClusterTracking(nn.Module):
         v.frame_start = torch.searchsorted(v.frame, torch.arange(num_frames + 1, device=dev))
         v.frame_start_host = v.frame_start.tolist()
         assert bool((seq_boxes.frame[1:] >= seq_boxes.frame[:-1]).all()), "boxes must be grouped by frame"
-        box_cnt = torch.bincount(seq_boxes.frame.long(), minlength=num_frames)
+        box_cnt = count_into(seq_boxes.frame.long(), num_frames)
         v.box_cnt = box_cnt
         v.box_off = torch.zeros(box_cnt.numel() + 1, dtype=torch.int64, device=dev)
         v.box_off[1:] = box_cnt.cumsum(0)
@@ -199,8 +200,11 @@ class ClusterTracking(nn.Module):
                                              v.box_off32, v.bmax, want_member=False)
         v.gt_local = first.long()
         inb = v.gt_local >= 0
-        v.gt_cnt_all = torch.bincount((v.box_off[v.frame.clamp(max=box_cnt.numel() - 1)] + v.gt_local)[inb],
-                                      minlength=seq_boxes.attr.shape[0])
+        # (rows outside every box carry weight 0; their index is clamped into the table: a frame without boxes
+        #  behind the last box would point one past it)
+        n_box = seq_boxes.attr.shape[0]
+        v.gt_cnt_all = count_into((v.box_off[v.frame.clamp(max=box_cnt.numel() - 1)]
+                                   + v.gt_local.clamp(min=0)).clamp(max=max(n_box - 1, 0)), n_box, inb)
         return v
 
     def extract_traces_and_update_boxes(self, all_points, extracted, seq_boxes, views=None):
@@ -397,7 +401,7 @@ class ClusterTracking(nn.Module):
                                      (out["comp_min_frame_id"] <= frame_id - self.min_move_frame))
         extracted = EasyDict(filter_dict(extracted, valid[extracted.component]))
         extracted.transforms = out["transforms"]
-        seq_points.extracted[extracted.original_indices] = True
+        seq_points.extracted.index_fill_(0, extracted.original_indices.reshape(-1), True)  # (an indexed assignment synchronises)
         self.last_track_debug = dict(ticks=out.get("_ticks", 0), reg_errors=out["reg_errors"],
                                      comp_edge_ratios=out["comp_edge_ratios"],
                                      comp_velos=out["comp_velos"],
@@ -603,7 +607,7 @@ class ClusterTracking(nn.Module):
                                                 (st.comp_min_frame_id <= frame_id - self.min_move_frame))
         extracted = EasyDict(filter_dict(extracted, valid_comp_mask[extracted.component]))
         extracted.transforms = st.transforms
-        seq_points.extracted[extracted.original_indices] = True
+        seq_points.extracted.index_fill_(0, extracted.original_indices.reshape(-1), True)  # (an indexed assignment synchronises)
         self.last_track_debug = dict(reg_errors=st.reg_errors, comp_edge_ratios=st.comp_edge_ratios,
                                      comp_velos=st.comp_velos, comp_min_frame_id=st.comp_min_frame_id,
                                      comp_max_frame_id=st.comp_max_frame_id)
@@ -616,6 +620,7 @@ class ClusterTracking(nn.Module):
         import threading
         descs, dtypes = [], []
         grouped = {}
+        ranges = []
         for comp_key, frame_id in units:
             sp = key_points[comp_key]
             if comp_key not in grouped:
@@ -625,13 +630,16 @@ class ClusterTracking(nn.Module):
                 grouped[comp_key] = (s_comp.long().contiguous(), s_stat.to(torch.uint8).contiguous())
             s_comp, s_stat = grouped[comp_key]
             lo, hi = offsets[frame_id], offsets[frame_id + 1]
-            cmin, cmax = torch.aminmax(s_comp[lo:hi])
-            comp_base = int(cmin.item())
+            ranges.append(torch.stack(torch.aminmax(s_comp[lo:hi])))
+        # the component id ranges of all units in ONE host read (they were two reads per unit)
+        ranges = torch.stack(ranges).tolist()
+        for (comp_key, frame_id), (cmin, cmax) in zip(units, ranges):
+            s_comp, s_stat = grouped[comp_key]
             min_frame_id, max_frame_id = self._native_window(offsets, frame_id)
             descs.append(dict(component=s_comp, stationary=s_stat, anchor_frame=frame_id,
-                              min_frame_id=min_frame_id, max_frame_id=max_frame_id, comp_base=comp_base,
-                              num_components=int(cmax.item()) - comp_base + 1))
-            dtypes.append(sp.component.dtype)
+                              min_frame_id=min_frame_id, max_frame_id=max_frame_id, comp_base=int(cmin),
+                              num_components=int(cmax) - int(cmin) + 1))
+            dtypes.append(key_points[comp_key].component.dtype)
         s_fxyz = key_points[units[0][0]].fxyz
         if perm is not None:
             s_fxyz = s_fxyz[perm].contiguous()
@@ -725,7 +733,11 @@ class ClusterTracking(nn.Module):
             sp.stationary = sp.component_diameter > 12.5
             key_points[comp_key] = sp
         units = []
-        present = torch.unique(seq_points.fxyz[:, 0]).long().tolist()
+        if frame_offsets is not None and bool((seq_points.fxyz[:, 0] == seq_points.frame.reshape(-1).to(seq_points.fxyz)).all()):
+            # (the frame column IS the frame id: the row ranges already on the host say which frames have points)
+            present = [f for f in range(len(frame_offsets) - 1) if frame_offsets[f + 1] > frame_offsets[f]]
+        else:
+            present = torch.unique(seq_points.fxyz[:, 0]).long().tolist()
         for comp_key in self.component_keys:
             for frame_id in range(0, num_frames, self.track_interval):
                 if frame_id in present:
