@@ -29,7 +29,9 @@ namespace pcs {
 constexpr int kMaxK = 32;
 
 // Per-query top-K (sorted ascending by (key, idx)) kept in LDS columns: element e of thread t at
-// [e * BLOCK + t] -> consecutive lanes hit consecutive banks.
+// [e * BLOCK + t] -> consecutive lanes hit consecutive banks. An element is ONE 64-bit word, key bits above the
+// index: squared distances are non-negative floats, whose bit patterns order like their values, so (key, idx)
+// ascending is the word ascending -- one LDS read, one compare and one write per shifted element instead of two each.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ qry, int M,
@@ -39,8 +41,7 @@ radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ 
                      int sort_by_dist, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d,
                      int32_t* __restrict__ deg) {
   extern __shared__ __align__(16) unsigned char smem[];
-  float* sd = (float*)smem;
-  int* si = (int*)(smem + (size_t)K * BLOCK * sizeof(float));
+  unsigned long long* sk = (unsigned long long*)smem;
   int t = threadIdx.x;
   int q = blockIdx.x * BLOCK + t;
   if (q >= M) return;
@@ -64,7 +65,7 @@ radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ 
     for (int s = 0; s <= g.rings; ++s) {
       if (s >= 1) {
         float lb = (float)(s - 1) * g.h;
-        float bound = (sort_by_dist && cnt == K) ? sd[(K - 1) * BLOCK + t] : g.radius2;
+        float bound = (sort_by_dist && cnt == K) ? __uint_as_float((unsigned)(sk[(K - 1) * BLOCK + t] >> 32)) : g.radius2;
         if (lb * lb > bound - dfsq + margin) break;
       }
       for (int dz = -s; dz <= s; ++dz) {
@@ -89,23 +90,18 @@ radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ 
               dist2 = dist2 + d2 * d2;
               dist2 = dist2 + d3 * d3;
               if (dist2 <= g.radius2) {
-                float key = sort_by_dist ? dist2 : 0.f;
+                const unsigned long long word =
+                    ((unsigned long long)(sort_by_dist ? __float_as_uint(dist2) : 0u) << 32) | (unsigned)j;
                 // position among the kept ones: strict (key, idx) order
                 int pos = cnt;
                 while (pos > 0) {
-                  float kd = sd[(pos - 1) * BLOCK + t];
-                  int ki = si[(pos - 1) * BLOCK + t];
-                  bool less = (key < kd) || (key == kd && j < ki);
-                  if (!less) break;
-                  if (pos < K) {
-                    sd[pos * BLOCK + t] = kd;
-                    si[pos * BLOCK + t] = ki;
-                  }
+                  const unsigned long long kw = sk[(pos - 1) * BLOCK + t];
+                  if (!(word < kw)) break;
+                  if (pos < K) sk[pos * BLOCK + t] = kw;
                   --pos;
                 }
                 if (pos < K) {
-                  sd[pos * BLOCK + t] = key;
-                  si[pos * BLOCK + t] = j;
+                  sk[pos * BLOCK + t] = word;
                   if (cnt < K) ++cnt;
                 }
               }
@@ -118,8 +114,9 @@ radius_search_kernel(const float4* __restrict__ ref, const float4* __restrict__ 
   }
   deg[q] = cnt;
   for (int e = 0; e < cnt; ++e) {
-    nbr_idx[(int64_t)q * K + e] = si[e * BLOCK + t];
-    if (nbr_d) nbr_d[(int64_t)q * K + e] = sd[e * BLOCK + t];
+    const unsigned long long w = sk[e * BLOCK + t];
+    nbr_idx[(int64_t)q * K + e] = (int32_t)(unsigned)(w & 0xFFFFFFFFULL);
+    if (nbr_d) nbr_d[(int64_t)q * K + e] = __uint_as_float((unsigned)(w >> 32));
   }
 }
 
