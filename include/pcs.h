@@ -500,6 +500,11 @@ int pcs_profile_icp_read(double* out9);
  *     row, bands of rows copied into LDS sorted by cell bucket, one lane or one wave per failed query;
  *     registrations that do not qualify take the cache path), use_tiles == 0 with the hash-grid searches. */
 int pcs_icp_set_schedule(int wide_iters, int use_tiles);
+/* How the grid of the MOVING points follows them between iterations (process-wide, registrations described after the
+ * call): 0 (default) in place -- a point that stays in its fine cell has its stored row overwritten, cell changes leave
+ * tombstones, the grid is rebuilt when they add up; 1: rebuilt at every iteration (the form of rounds 1-3, kept as the
+ * cross-check of the in-place form: same results, bit for bit). */
+int pcs_icp_set_grid_mode(int rebuild_always);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per

@@ -41,6 +41,11 @@
 
 namespace pcs {
 
+// pcs_icp_set_grid_mode: the moving grid rebuilt at every iteration (the form before the in-place update; the
+// cross-check of tests/test_gpu_tracking.py) instead of when the solve phase finds it due
+static std::atomic<int> g_rebuild_always{0};
+static bool icp_rebuild_always() { return g_rebuild_always.load(std::memory_order_relaxed) != 0; }
+
 bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
   if (Mn < 1) Mn = 1;
   if (Rn < 1) Rn = 1;
@@ -145,7 +150,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.capR = (int)(a.Rn > 0 ? a.Rn : 1);
   pr.df = a.frame_offset;
   pr.max_iter = a.max_iter;
-  pr.want = (a.want_l1 ? kIcpWantL1 : 0) | (a.want_ratio ? kIcpWantRatio : 0);
+  pr.want = (a.want_l1 ? kIcpWantL1 : 0) | (a.want_ratio ? kIcpWantRatio : 0) | (icp_rebuild_always() ? kIcpRebuildAlways : 0);
   return PCS_OK;
 }
 
@@ -1063,7 +1068,7 @@ __device__ __forceinline__ void icp_solve_phase(const IcpProblem& pr, IcpState* 
     const int cur = st->gcur[k & 1] & 1;
     const int ovf = *pr.gm[cur].ovf;
     if (st->grebuild) st->govf0 = ovf;  // (the grid is fresh: built by the last apply phase, or by the set-up)
-    const bool reb = (uint64_t)st->gmoves * 4u > (uint64_t)Mn || ovf > st->govf0;
+    const bool reb = (uint64_t)st->gmoves * 4u > (uint64_t)Mn || ovf > st->govf0 || (pr.want & kIcpRebuildAlways);
     st->grebuild = reb ? 1 : 0;
     if (reb) st->gmoves = 0u;
     st->gcur[(k + 1) & 1] = reb ? (cur ^ 1) : cur;
@@ -2601,6 +2606,11 @@ extern "C" {
 //   wide_iters < 0 or >= max_iter: every iteration as wide launches (default);
 //   wide_iters >= 1: that many wide iterations, then the unit-resident loop: use_tiles != 0 the tile path
 //   (LDS-staged searches; registrations that do not qualify take the cache path), else the cache path.
+int pcs_icp_set_grid_mode(int rebuild_always) {
+  g_rebuild_always.store(rebuild_always != 0 ? 1 : 0, std::memory_order_relaxed);
+  return PCS_OK;
+}
+
 int pcs_icp_set_schedule(int wide_iters, int use_tiles) {
   g_wide_iters.store(wide_iters < 0 ? INT_MAX : wide_iters, std::memory_order_relaxed);
   g_use_tiles.store(use_tiles != 0 ? 1 : 0, std::memory_order_relaxed);

@@ -835,6 +835,13 @@ def icp_set_schedule(wide_iters=-1, use_tiles=True):
     L.check(lib.pcs_icp_set_schedule(L.i32(int(wide_iters)), L.i32(1 if use_tiles else 0)), "pcs_icp_set_schedule")
 
 
+def icp_set_grid_mode(rebuild_always=False):
+    """pcs_icp_set_grid_mode: the moving points' grid updated in place between iterations (default) or rebuilt at
+    every iteration (cross-check; same results)."""
+    lib = L.load()
+    L.check(lib.pcs_icp_set_grid_mode(L.i32(1 if rebuild_always else 0)), "pcs_icp_set_grid_mode")
+
+
 def track_configure(engines=-1, chunk_us=-1):
     """pcs_track_configure: tracker engines per device (before they are created) and the chunk budget of the
     resident ICP schedules; negative = unchanged."""

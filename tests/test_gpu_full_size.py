@@ -39,6 +39,32 @@ def test_full_size_schedules_agree(full_runs):
         assert torch.equal(a[k], b[k]), k
 
 
+def test_full_size_moving_grid_in_place_equals_rebuilt(full_runs):
+    """The moving points' grid updated in place between ICP iterations (default) against the grid rebuilt at every
+    iteration (ops.icp_set_grid_mode, the form of rounds 1-3): the whole full-size sequence, every output, bit for bit."""
+    import bench
+    from pcseqlearning_amd import ops
+    from pcseqlearning_amd.pcdet import models
+    from tools.run_sequence import build_model
+    batch = models.load_data_to_gpu(bench.load_sequence(0, 20, 160000))
+    ops.icp_set_grid_mode(True)
+    try:
+        model = build_model(save=False, device=DEV)
+        with torch.no_grad():
+            model(batch)
+        b = model.last_outputs[0]
+    finally:
+        ops.icp_set_grid_mode(False)
+    a = full_runs[0]
+    assert a["cluster_tracking_results"].keys() == b["cluster_tracking_results"].keys()
+    for key, ra in a["cluster_tracking_results"].items():
+        rb = b["cluster_tracking_results"][key]
+        for field in ("fxyz", "component", "original_indices", "frame_indices", "moving", "component_hit"):
+            assert torch.equal(ra[field], rb[field]), (key, field)
+    for k in ("point_gt_box_id", "gt_box_best_iou_tracking", "point_height"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_full_size_properties(full_runs):
     out = full_runs[0]
     n_sub, n_pts = out["full_point_fxyz"].shape[0], out["point_fxyz"].shape[0]

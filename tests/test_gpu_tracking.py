@@ -156,6 +156,16 @@ def test_track_frame_vs_oracle_resident_schedules(schedule):
         ops.icp_set_schedule(-1, True)
 
 
+def test_track_frame_vs_oracle_grid_rebuilt_every_iteration():
+    """The same with the moving points' grid rebuilt at every ICP iteration (ops.icp_set_grid_mode): the in-place
+    form (default, the tests above) and this one both give the oracle's ids."""
+    ops.icp_set_grid_mode(True)
+    try:
+        test_track_frame_vs_oracle(True)
+    finally:
+        ops.icp_set_grid_mode(False)
+
+
 def test_track_frame_vs_reference():
     """Against the reference's own track_frame output: the extraction overlaps > 90 % and the
     first tracked frames agree to fp32 noise (see tests/test_oracle_tracking.py for why the
