@@ -89,6 +89,7 @@ def main():
     chunk_spans(rows)
     first_iteration_searches(rows)
     queue_gaps(rows)
+    tick_composition(rows)
 
 
 def first_iteration_searches(rows):
@@ -143,6 +144,35 @@ def queue_gaps(rows):
     if span:
         print("engine queues, idle time by gap length (us): " + ", ".join(
             f"{lo}-{hi if hi < 10 ** 9 else 'inf'}: {cnt[(lo, hi)]} gaps = {100 * tot[(lo, hi)] / span:.1f} %" for lo, hi in bins))
+
+
+def tick_composition(rows):
+    """What an engine's tick is made of: a tick = the dispatches of an engine's queue from one icp_decide_kernel to the
+    next (other streams' kernels that the runtime put on the same hardware queue included). Per kernel: launches per
+    tick, their time per tick; then the tick's span, busy time and idle time."""
+    icp_q = set(q for s, e, n, q, g, gy in rows if "icp_decide_kernel" in n)
+    per_k = collections.defaultdict(lambda: [0, 0])
+    ticks = spans = busy = disp = 0
+    for q in icp_q:
+        v = sorted((s, e, n) for s, e, n, qq, g, gy in rows if qq == q)
+        start = None
+        for s, e, n in v:
+            if start is not None:
+                per_k[n][0] += 1
+                per_k[n][1] += e - s
+                busy += e - s
+                disp += 1
+            if "icp_decide_kernel" in n:
+                if start is not None:
+                    ticks += 1
+                    spans += e - start
+                start = e
+    if not ticks:
+        return
+    print(f"engine ticks: {ticks}, mean span {spans / ticks / 1e3:.0f} us, busy {busy / ticks / 1e3:.0f} us, "
+          f"{disp / ticks:.1f} dispatches per tick; per tick and kernel (launches x mean us = us per tick):")
+    for n, (c, t) in sorted(per_k.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"    {n.split('::')[-1][:44]:44s} {c / ticks:6.2f} x {t / c / 1e3:7.1f} = {t / ticks / 1e3:7.1f}")
 
 
 def chunk_spans(rows):
