@@ -5,9 +5,10 @@
 Workload = BASELINE.json configs[2]: a 20-frame x 160k-pt sequence through the reference's
 cluster_tracking_TLS_multiradius_every8 pipeline (8 cm subsample -> GroundPlaneRemover ->
 ClusterProposal at 3 radii -> ClusterTracking: 3 keys x anchors {0, 8, 16} x +-8 frames x 3 ICP
-levels), one sequence per GPU per step, inputs resident in HBM before the timed region, nothing
-written to disk. N GPUs process N different sequences (sequence s -> rank s mod N, weak scaling);
-the only collective is the final all-reduce of the metric vector over RCCL.
+levels); a step = one batch of `--batch` (default 12) independent sequences per GPU, all in flight at once,
+inputs resident in HBM before the timed region, nothing written to disk. N GPUs process different sequences
+(sequence s -> rank s mod N, weak scaling); the only collectives are the final reductions of the metric vector and of
+every rank's step times over RCCL.
 
 With N > 1 and no launcher in the environment, this script starts the N ranks itself
 (`python -m torch.distributed.run --nproc-per-node N ...` as a CHILD process, before anything
@@ -16,13 +17,16 @@ touches the GPU); started by a launcher it checks WORLD_SIZE against --gpus. `--
 a GPU (tests/test_distributed.py).
 
 Rank 0 prints ONE JSON line: whole-job sequences/s plus
-  roofline      dominant kernels of the tracking stage (the fused ICP's neighbour kernels, which
-                also accumulate the moments): HIP events on their launch stream inside the timed
-                steps; achieved = algorithmic bytes / kernel time. `stages` lists the other stages
-                (one extra, untimed, device-synchronised step).
+  roofline      the dominant kernel(s) of the path, the fused ICP's iteration, timed per CHUNK: what a schedule
+                launches for the iterations of all registrations an engine has in flight (wide schedule: 8
+                iterations x {budget test + moments, searches, solve, apply}; resident schedules: one kernel).
+                HIP events on the chunk's first and last dispatch inside the timed steps; achieved = the chunk's
+                algorithmic bytes / its span; traffic from the PMC passes of the same command
+                (profiles/r04_icp_hbm_pmc.json). `stages` lists the other stages (one extra, untimed,
+                device-synchronised step over one sequence).
   cpu_baseline  the CPU oracle (C++ restatement, kind "port"), serial and OpenMP over the host's
-                cores, timed on a bounded sample of the same sequence and scaled to sequences/s
-                (rank 0, N = 1 only).
+                cores, timed on a bounded sample of the same sequence (subsample, ground removal, a proposal
+                chunk, 18 registrations with their sampling) and scaled to sequences/s (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
@@ -247,7 +251,7 @@ def stage_rooflines(records, stats, prof, out):
     e, nn = stats.get("proposal cc edges", 0), stats.get("proposal cc nodes", 0)
     t_cc = sum(val for key, val in records.items() if key.startswith("Propose Cluster for"))
     add("proposal components", t_cc, 16.0 * e + 8.0 * nn, "16 E + 8 N")
-    # the unit-resident ICP loop: HIP-event kernel time of its launches; the phase rows are CU time (the
+    # the ICP chunks: HIP-event time of their launches; the phase rows (resident schedules only) are CU time (the
     # workgroups' own s_memrealtime stamps summed over the units), not wall time
     ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
     if ms > 0:
@@ -454,9 +458,9 @@ def main():
             torch.cuda.synchronize()
             timer.SYNC = False
             stages = stage_rooflines(dict(timer.RECORDS), dict(timer.STATS), prof, out)
-        # the dominant kernel: the unit-resident ICP loop (one workgroup per tracking unit runs that unit's
-        # iterations back to back). HIP events attached to the dispatch itself (hipExtLaunchKernelGGL): the
-        # quantity rocprofv3 reports as kernel duration. A launch occupies as many CUs as it has units.
+        # the dominant kernel(s): the fused ICP's iterations, chunk by chunk (the launches of the schedule in use).
+        # HIP events attached to the dispatches themselves (hipExtLaunchKernelGGL): start of a chunk's first
+        # launch to the stop of its last, the span a kernel trace shows for the same dispatches.
         ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
         achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of THIS schedule (tools/pmc_batch.sh ->
