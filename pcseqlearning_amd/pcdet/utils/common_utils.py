@@ -100,6 +100,15 @@ def thread_stream(device, which=0):
     index = torch.device(device).index
     if index is None:
         index = torch.cuda.current_device()
+    slot = getattr(_THREAD_STREAMS, "slot", None)
+    if slot is not None:
+        # a worker SLOT's streams (stream_slot): the pool's threads take the slots in any order, and the allocator's
+        # pools belong to streams -- keyed by slot, slot i meets the same sizes at every step whichever thread runs it
+        with _SLOT_LOCK:
+            stream = _SLOT_STREAMS.get((slot, index, which))
+            if stream is None:
+                stream = _SLOT_STREAMS[(slot, index, which)] = torch.cuda.Stream(device=index)
+        return stream
     table = getattr(_THREAD_STREAMS, "table", None)
     if table is None:
         table = _THREAD_STREAMS.table = {}
@@ -107,3 +116,23 @@ def thread_stream(device, which=0):
     if stream is None:
         stream = table[(index, which)] = torch.cuda.Stream(device=index)
     return stream
+
+
+_SLOT_STREAMS = {}
+_SLOT_LOCK = threading.Lock()
+
+
+class stream_slot:
+    """Within the block, thread_stream hands out the streams of worker slot `slot` instead of the calling thread's."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        self.prev = getattr(_THREAD_STREAMS, "slot", None)
+        _THREAD_STREAMS.slot = self.slot
+        return self
+
+    def __exit__(self, *exc):
+        _THREAD_STREAMS.slot = self.prev
+        return False
