@@ -419,6 +419,7 @@ def main():
     from pcseqlearning_amd.pcdet.models.registration.preprocessors import cluster_tracking as CT
     fallbacks0 = CT.HOST_FALLBACKS
     for i in range(args.steps):
+        spans0 = dict(timer.RECORDS)
         ts = time.perf_counter()
         if trace:  # a step that hangs shows where: every thread's Python stack after 5 s, then every 5 s
             import faulthandler
@@ -426,6 +427,12 @@ def main():
         step()
         torch.cuda.current_stream().synchronize()  # (a step's outputs are complete when forward returns; this only orders the clock)
         step_ms.append((time.perf_counter() - ts) * 1e3)
+        if len(step_ms) > 3 and step_ms[-1] > 1.8 * sorted(step_ms)[len(step_ms) // 2]:
+            # a step far above the median: which stage's host spans (summed over the batch's sequences) it went into
+            d = {k: round(v - spans0.get(k, 0.0), 3) for k, v in timer.RECORDS.items()
+                 if v - spans0.get(k, 0.0) > 0.05 and not k.startswith(("Tracking Frame", "ground:"))}
+            print(f"slow step {i}: {step_ms[-1]:.0f} ms (median {sorted(step_ms)[len(step_ms) // 2]:.0f}); host spans of its stages, "
+                  f"summed over the batch (s): {d}", file=sys.stderr, flush=True)
         if trace:
             faulthandler.cancel_dump_traceback_later()
             ms_ = torch.cuda.memory_stats()
