@@ -246,7 +246,9 @@ class ClusterTracking(nn.Module):
         fxyz = torch.cat([ex.fxyz for ex in exs]) if len(exs) > 1 else exs[0].fxyz
         comp = torch.cat([ex.component.long() + coff[u] for u, ex in enumerate(exs)])
         moving = torch.cat([ex.moving for ex in exs])
-        unit = torch.repeat_interleave(torch.arange(len(exs), device=dev), torch.tensor(rows, device=dev))
+        # (output_size: the host knows the total, so repeat_interleave does not read the counts back)
+        unit = torch.repeat_interleave(torch.arange(len(exs), device=dev), torch.tensor(rows, device=dev),
+                                       output_size=sum(rows))
         comp_sg = IndexSegments(comp, num_components)
         component_hit = comp.new_zeros(num_components)
         size_min = segment_min(fxyz[:, 0], comp_sg, num_components).round().long()
@@ -269,7 +271,8 @@ class ClusterTracking(nn.Module):
             vox[:, 0] += (unit * stride).to(vox.dtype)
             queries = torch.cat([v.fxyz[a:b] for a, b in zip(q_lo, q_hi)])
             q_unit = torch.repeat_interleave(torch.arange(len(exs), device=dev),
-                                             torch.tensor([b - a for a, b in zip(q_lo, q_hi)], device=dev))
+                                             torch.tensor([b - a for a, b in zip(q_lo, q_hi)], device=dev),
+                                             output_size=q_off[-1])
             queries[:, 0] += (q_unit * stride).to(queries.dtype)
 
         self.nn_graph.radius *= 1.732
@@ -313,9 +316,13 @@ class ClusterTracking(nn.Module):
                     out_comp[sel], s_fr, member, v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all)
                 iou32 = iou.to(seq_boxes.best_iou.dtype)
                 hit = has_box & (iou32 > 0.7)
-                component_hit.index_add_(0, gcomp[hit], torch.ones_like(gcomp[hit]).to(component_hit))
-                scatter_max_(seq_boxes.best_iou, (v.box_off[gframe] + box)[has_box], iou32[has_box])
-        counts = torch.bincount(out_unit, minlength=len(exs)).tolist()
+                # (weights and selects instead of masked indexing: adding 0 / a maximum with 0 changes nothing, the
+                #  IoUs are >= 0, and no mask has to be compacted on the host's clock)
+                component_hit.index_add_(0, gcomp, hit.to(component_hit.dtype))
+                n_box = seq_boxes.best_iou.shape[0]
+                scatter_max_(seq_boxes.best_iou, (v.box_off[gframe] + box).clamp(max=max(n_box - 1, 0)),
+                             torch.where(has_box, iou32, torch.zeros_like(iou32)))
+        counts = count_into(out_unit, len(exs)).tolist()
         start = 0
         for u, ex in enumerate(exs):
             sl = slice(start, start + counts[u])
