@@ -50,8 +50,12 @@ static inline uint32_t g2_pow2(uint64_t x) { uint32_t h = 64; while (h < x) h <<
 
 static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   if (N < 1) N = 1;
-  g.Hf = g2_pow2(2 * (uint64_t)N);
-  g.Hc = g2_pow2(2 * (uint64_t)N);
+  // fine slots: the power of two above 1.5 N for N points (1.5 N .. 3 N slots; rounds 1-3: above 2 N). A cell per
+  // point is the worst case, so a build fills the table to two thirds at most; voxel-sampled clouds put ~3 points in
+  // an occupied cell: a quarter. Every slot owns kCellCap rows (320 bytes with their indices), which is where the
+  // memory of a grid goes. Every walk of a table is bounded by its length, whatever fills it (g2_claim / g2_find).
+  g.Hf = g2_pow2((uint64_t)N + ((uint64_t)N >> 1));
+  g.Hc = g2_pow2((uint64_t)N + ((uint64_t)N >> 1));
   g.fslot = a.take<FineSlot>(g.Hf);    // Hf * 16 bytes is a multiple of the arena alignment, so the
   g.cslot = a.take<CoarseSlot>(g.Hc);  // two tables are contiguous
   g.slot_words = (size_t)g.Hf + g.Hc;
@@ -66,14 +70,15 @@ static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
 
 // claim / find: `base` is an array of 16-byte slots whose first 8 bytes are the key
 template <typename Slot>
-__device__ __forceinline__ uint32_t g2_claim(Slot* __restrict__ base, uint32_t hmask, uint64_t key) {
+__device__ __forceinline__ int g2_claim(Slot* __restrict__ base, uint32_t hmask, uint64_t key) {
   uint32_t slot = mix64(key) & hmask;
-  while (true) {
+  for (uint32_t t = 0; t <= hmask; ++t) {  // (once around at most: -1 = every slot holds another key)
     uint64_t prev = atomicCAS((unsigned long long*)&base[slot].key, (unsigned long long)kEmpty,
                               (unsigned long long)key);
-    if (prev == kEmpty || prev == key) return slot;
+    if (prev == kEmpty || prev == key) return (int)slot;
     slot = (slot + 1) & hmask;
   }
+  return -1;
 }
 
 // the same with a bounded walk: -1 when kClaimProbes slots in a row belong to other keys (a table that fills up
@@ -96,13 +101,14 @@ template <typename Slot>
 __device__ __forceinline__ int g2_find(const Slot* __restrict__ base, uint32_t hmask, uint64_t key,
                                        uint32_t* lo, uint32_t* hi) {
   uint32_t slot = mix64(key) & hmask;
-  while (true) {
+  for (uint32_t t = 0; t <= hmask; ++t) {  // (once around at most: a table without an empty slot ends the walk too)
     uint4 w = ((const uint4*)base)[slot];
     uint64_t k = ((uint64_t)w.y << 32) | w.x;
     if (k == key) { *lo = w.z; *hi = w.w; return (int)slot; }
     if (k == kEmpty) return -1;
     slot = (slot + 1) & hmask;
   }
+  return -1;
 }
 
 // grid-stride reset of one grid (keys <- empty, counters / masks / spill count <- 0, frame ranges):
@@ -126,7 +132,8 @@ __device__ __forceinline__ void g2_clear(const Grid2& g, int64_t tid, int64_t nt
 __device__ __forceinline__ Grid2 g2_view(const Grid2& alloc, int n) {
   Grid2 g = alloc;
   uint32_t h = 64;
-  uint64_t want = 2 * (uint64_t)(n < 1 ? 1 : n);
+  uint64_t want = (uint64_t)(n < 1 ? 1 : n);
+  want += want >> 1;
   while (h < want && h < alloc.Hf) h <<= 1;
   g.Hf = h;
   g.Hc = h < alloc.Hc ? h : alloc.Hc;
@@ -184,8 +191,16 @@ __device__ __forceinline__ void g2_insert_point(const GridDesc& d, const Grid2& 
                           (unsigned long long)fkey);
   uint64_t pc = atomicCAS((unsigned long long*)&g.cslot[cs].key, (unsigned long long)kEmpty,
                           (unsigned long long)ckey);
-  if (!(pf == kEmpty || pf == fkey)) fs = g2_claim(g.fslot, fmask, fkey);
-  if (!(pc == kEmpty || pc == ckey)) cs = g2_claim(g.cslot, cmask, ckey);
+  if (!(pf == kEmpty || pf == fkey)) {
+    const int f2 = g2_claim(g.fslot, fmask, fkey);
+    if (f2 < 0) { atomicExch(err, 1); if (loc) loc[i] = INT_MIN; return; }  // (cannot happen: <= N cells in > 1.5 N slots)
+    fs = (uint32_t)f2;
+  }
+  if (!(pc == kEmpty || pc == ckey)) {
+    const int c2 = g2_claim(g.cslot, cmask, ckey);
+    if (c2 < 0) { atomicExch(err, 1); if (loc) loc[i] = INT_MIN; return; }
+    cs = (uint32_t)c2;
+  }
   int bit = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
   int pos = atomicAdd(&g.fslot[fs].count, 1);
   atomicOr((unsigned long long*)&g.cslot[cs].mask, 1ULL << bit);
