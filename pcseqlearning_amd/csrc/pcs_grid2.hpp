@@ -50,12 +50,13 @@ static inline uint32_t g2_pow2(uint64_t x) { uint32_t h = 64; while (h < x) h <<
 
 static inline void plan_grid2(Arena& a, int64_t N, Grid2& g) {
   if (N < 1) N = 1;
-  // fine slots: the power of two above 1.5 N for N points (1.5 N .. 3 N slots; rounds 1-3: above 2 N). A cell per
-  // point is the worst case, so a build fills the table to two thirds at most; voxel-sampled clouds put ~3 points in
-  // an occupied cell: a quarter. Every slot owns kCellCap rows (320 bytes with their indices), which is where the
-  // memory of a grid goes. Every walk of a table is bounded by its length, whatever fills it (g2_claim / g2_find).
-  g.Hf = g2_pow2((uint64_t)N + ((uint64_t)N >> 1));
-  g.Hc = g2_pow2((uint64_t)N + ((uint64_t)N >> 1));
+  // fine slots: the power of two above 2 N for N points. A cell per point is the worst case, so a build fills the
+  // table to half at most; voxel-sampled clouds put ~3 points in an occupied cell: a sixth. Every slot owns kCellCap
+  // rows (320 bytes with their indices), which is where the memory of a grid goes: the power of two above 1.5 N was
+  // measured too (round 4): a sequence's tracker workspace 1.57 -> 1.08 GiB, its ICP chunks 3 % and a batch 1 % longer
+  // (longer probe walks) -- not taken. Every walk of a table is bounded by its length, whatever fills it.
+  g.Hf = g2_pow2(2 * (uint64_t)N);
+  g.Hc = g2_pow2(2 * (uint64_t)N);
   g.fslot = a.take<FineSlot>(g.Hf);    // Hf * 16 bytes is a multiple of the arena alignment, so the
   g.cslot = a.take<CoarseSlot>(g.Hc);  // two tables are contiguous
   g.slot_words = (size_t)g.Hf + g.Hc;
@@ -133,7 +134,7 @@ __device__ __forceinline__ Grid2 g2_view(const Grid2& alloc, int n) {
   Grid2 g = alloc;
   uint32_t h = 64;
   uint64_t want = (uint64_t)(n < 1 ? 1 : n);
-  want += want >> 1;
+  want *= 2;
   while (h < want && h < alloc.Hf) h <<= 1;
   g.Hf = h;
   g.Hc = h < alloc.Hc ? h : alloc.Hc;
