@@ -246,11 +246,16 @@ def stage_rooflines(records, stats, prof, out):
     n_full = int(out["full_point_fxyz"].shape[0])
     add("ground removal", records.get("Ground Removal"), 50.0 * 16.0 * n_full, "50 x 16 n (IRLS rounds)")
     e, p = stats.get("proposal graph edges", 0), stats.get("proposal graph points", 0)
+    ecc, nn = stats.get("proposal cc edges", 0), stats.get("proposal cc nodes", 0)
     t_graph = sum(val for key, val in records.items() if key.startswith("Propose Cluster: graph"))
-    add("proposal radius graph (32-NN)", t_graph, 16.0 * p + 20.0 * e, "16 N + 16 M + 16 E + 4 E")
-    e, nn = stats.get("proposal cc edges", 0), stats.get("proposal cc nodes", 0)
     t_cc = sum(val for key, val in records.items() if key.startswith("Propose Cluster for"))
-    add("proposal components", t_cc, 16.0 * e + 8.0 * nn, "16 E + 8 N")
+    if t_cc > 0:  # (SEPARATE_GRAPHS: one graph and one labelling per key)
+        add("proposal radius graph (32-NN)", t_graph, 16.0 * p + 20.0 * e, "16 N + 16 M + 16 E + 4 E")
+        add("proposal components", t_cc, 16.0 * ecc + 8.0 * nn, "16 E + 8 N")
+    else:
+        # one search at the largest radius + the components of its three cuts from the neighbour table, one span
+        add("proposal radius graph (32-NN) + components of the three cuts", t_graph,
+            16.0 * p + 20.0 * e + 16.0 * ecc + 8.0 * nn, "16 N + 16 M + 16 E + 4 E (graph) + 16 E + 8 N per cut")
     # the ICP chunks: HIP-event time of their launches; the phase rows (resident schedules only) are CU time (the
     # workgroups' own s_memrealtime stamps summed over the units), not wall time
     ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]

@@ -240,6 +240,27 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
                             size_t ws_bytes, pcs_stream_t stream);
 int pcs_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query,
                           float* dists, const void* ws, size_t ws_bytes, pcs_stream_t stream);
+/* ClusterProposal.propose_cluster, pcdet/models/registration/preprocessors/cluster_proposal.py:57-83: per
+ * radius key a 32-nearest radius graph of the chunk on itself (graph_utils.py:149-209) and its weakly connected
+ * components (graph_utils.py:40-53). The k nearest within r, nearest first, are the k nearest within R >= r cut at
+ * r, so ONE search at the largest radius serves every key: after pcs_radius_graph_search(ref == query, N == M,
+ * sort_by_dist = 1) this entry labels the components of the graph still held in `ws`, cut at each of the n_cut
+ * (<= 8) radii in radius_cut (host array; an edge counts when dist2 <= fl32(r) * fl32(r), the search's own test),
+ * with no edge list in between: component [n_cut, M] int64 = rank of the node's component by its smallest node
+ * id, d_num [n_cut] = number of components (device). */
+size_t pcs_radius_graph_components_workspace_bytes(int64_t M, int n_cut);
+int pcs_radius_graph_components(int64_t N, int64_t M, int max_nbr, const float* radius_cut, int n_cut,
+                                int64_t* component, int64_t* d_num, const void* ws, size_t ws_bytes,
+                                void* ws_cc, size_t ws_cc_bytes, pcs_stream_t stream);
+/* test hooks of the search engines behind pcs_radius_graph_search (both exact, same edges): 1 = every search on
+ * the one-thread-per-query engine (the cell-sorted wave search of max_nbr > 1 switched off); 1 = every query of
+ * the cell-sorted search through its one-thread fallback. */
+int pcs_radius_graph_engine_only(int on);
+/* diagnostics: host_out[8] = the counters the last cell-sorted search (max_nbr > 1) left in `ws`: query runs, work
+ * cursor, queries that took the one-thread fallback, its cursor, four build-dependent statistics. Synchronises. */
+int pcs_radius_graph_counters(int64_t N, int64_t M, int max_nbr, const void* ws, size_t ws_bytes,
+                              int32_t* host_out, pcs_stream_t stream);
+int pcs_knn_force_hard(int on);
 
 /* Literal drop-ins for torch_hash_cuda (pcdet/ops/torch_hash/src/torch_hash_api.cpp:9-15,
  * torch_hash.h:16-32) on the reference's own table layout: keys[H] int64 (-1 empty),

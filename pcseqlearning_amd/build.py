@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "libpcs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off + correctly rounded fp32 divide: voxel / cell coordinates are integers derived
 # from fp32 (p - lo) / size and must match the CPU restatement bit for bit.
-HIP_FLAGS = [
+HIP_FLAGS = [*os.environ.get("PCS_EXTRA_HIP_FLAGS", "").split(),
     "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-Wno-unused-result",
 ]

@@ -89,6 +89,13 @@ size_t scan_i64_temp_bytes(size_t n);
 int exclusive_scan_i64(void* tmp, size_t tmp_bytes, const int64_t* in, int64_t* out, size_t n,
                        hipStream_t s);
 
+// connected components over a neighbour table (pcs_segment.hip): node q -- nbr_idx[q, e] for e < deg[q] with
+// nbr_d[q, e] <= r2cut[i], for n_cut cuts at once; component [n_cut, n], d_num [n_cut]
+size_t cc_table_workspace_bytes(int64_t n, int n_cut);
+int cc_table_components(const int32_t* nbr_idx, const float* nbr_d, const int32_t* deg, int64_t n, int K,
+                        const float* r2cut, int n_cut, int64_t* component, int64_t* d_num, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+
 // 64-lane butterfly reductions (all lanes end with the result).
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

@@ -23,6 +23,7 @@
 //     torch_hash_cuda entry points on the reference's own table layout (keys/values/reverse,
 //     caller-allocated), for callers that bind at the pcdet/ops/torch_hash level.
 #include "pcs_grid2.hpp"
+#include "pcs_knn.hpp"
 
 namespace pcs {
 
@@ -163,6 +164,9 @@ edge_emit_kernel(const int32_t* __restrict__ nbr_idx, const float* __restrict__ 
   }
 }
 
+// test hook (pcs_radius_graph_engine_only): 1 = every search on the one-thread-per-query engine
+static int g_radius_engine_only = 0;
+
 struct RadiusPlan {
   GridDesc* grid;
   float *b_ref, *b_qry;
@@ -174,6 +178,7 @@ struct RadiusPlan {
   void* tmp;
   size_t tmp_bytes;
   uint32_t H;
+  KnnPlan knn;       // max_nbr > 1: the cell-sorted search (pcs_knn.hip)
 };
 
 static inline uint32_t pow2_ge(uint64_t x) {
@@ -203,6 +208,8 @@ static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
   if (K == 1) {
     plan_grid2(a, N, p.g2);
     p.g2_words = a.take<int32_t>(2);
+  } else {
+    plan_knn(a, N, M, p.knn);
   }
   return a.ok();
 }
@@ -404,12 +411,30 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
   // engine whatever max_nbr is. 0: radius / 2 on the general engine.
   float cell = cell_size != 0.f ? fabsf(cell_size) : radius * 0.5f;
   if (cell > radius) cell = radius;
+  // several sorted neighbours under one frame offset (the 32-NN graphs of ClusterProposal): the cell-sorted,
+  // wave-cooperative search of pcs_knn.hip on cells of its own choice (radius / 4), whatever cell_size says
+  const bool tiled = K > 1 && sort_by_dist && dframe_min == dframe_max && !g_radius_engine_only;
+  if (tiled) cell = knn_cell(radius);
   int rc = pcs_minmax4_f32(ref, N, p.b_ref, s);
   if (rc) return rc;
-  rc = pcs_minmax4_f32(query, M, p.b_qry, s);
-  if (rc) return rc;
+  if ((const void*)query == (const void*)ref && M == N) {
+    PCS_CHECK_HIP(hipMemcpyAsync(p.b_qry, p.b_ref, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    rc = pcs_minmax4_f32(query, M, p.b_qry, s);
+    if (rc) return rc;
+  }
   grid_setup_kernel<<<1, 64, 0, s>>>(p.b_ref, p.b_qry, radius, cell, p.grid);
   PCS_CHECK_HIP(hipMemsetAsync(p.err, 0, sizeof(int32_t), s));
+  if (tiled) {
+    rc = knn_tiled_search((const float4*)ref, N, (const float4*)query, M, p.grid, dframe_min, K, p.knn, p.err,
+                          p.nbr_idx, p.nbr_d, p.deg, s);
+    if (rc) return rc;
+    rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
+    if (rc) return rc;
+    edge_total_kernel<<<1, 64, 0, s>>>(p.deg, p.off, (int)M, p.err, d_num_edges);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   if (K == 1 && sort_by_dist && dframe_min == dframe_max && cell_size > 0.f) {
     // cell_size must be (spatial radius) / 4 or more so that the 3x3x3 coarse blocks cover the ball;
     // if the data say otherwise the search raises the overflow flag and *d_num_edges becomes -1
@@ -464,6 +489,47 @@ int pcs_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int
                                                   e_ref, e_query, dists);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
+}
+
+int pcs_radius_graph_engine_only(int on) {
+  g_radius_engine_only = on ? 1 : 0;
+  return PCS_OK;
+}
+
+// diagnostics: the counters the last cell-sorted search left in `ws` (host_out[8]: runs, work cursor, queries that
+// took the one-thread fallback, its cursor, then build-dependent statistics); synchronises the stream
+int pcs_radius_graph_counters(int64_t N, int64_t M, int max_nbr, const void* ws, size_t ws_bytes, int32_t* host_out,
+                              hipStream_t s) {
+  if (!ws || !host_out || max_nbr < 2 || max_nbr > kMaxK) return PCS_ERR_ARG;
+  Arena a((void*)ws, ws_bytes);
+  RadiusPlan p;
+  if (!plan_radius(a, N, M, max_nbr, p)) return PCS_ERR_WORKSPACE;
+  PCS_CHECK_HIP(hipMemcpyAsync(host_out, p.knn.cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PCS_CHECK_HIP(hipStreamSynchronize(s));
+  return PCS_OK;
+}
+
+size_t pcs_radius_graph_components_workspace_bytes(int64_t M, int n_cut) {
+  return cc_table_workspace_bytes(M, n_cut);
+}
+
+// Connected components of the graph the last search left in `ws` (ref and query the SAME cloud, N == M), cut at
+// n_cut radii: an edge (neighbour, query) counts for cut i when its dist2 <= radius_cut[i]^2 (fp32 product of the
+// fp32 radius, as the host's `dists <= r * r` test forms it). component [n_cut, M], d_num [n_cut].
+int pcs_radius_graph_components(int64_t N, int64_t M, int max_nbr, const float* radius_cut, int n_cut,
+                                int64_t* component, int64_t* d_num, const void* ws, size_t ws_bytes, void* ws_cc,
+                                size_t ws_cc_bytes, hipStream_t s) {
+  if (!ws || !ws_cc || !radius_cut || !d_num || N != M || M < 0 || max_nbr < 1 || max_nbr > kMaxK || n_cut < 1 ||
+      n_cut > 8 || (M > 0 && !component))
+    return PCS_ERR_ARG;
+  if (M >= (1LL << 31) / 8) return PCS_ERR_RANGE;
+  if (M == 0) { PCS_CHECK_HIP(hipMemsetAsync(d_num, 0, (size_t)n_cut * sizeof(int64_t), s)); return PCS_OK; }
+  Arena a((void*)ws, ws_bytes);
+  RadiusPlan p;
+  if (!plan_radius(a, N, M, max_nbr, p)) return PCS_ERR_WORKSPACE;
+  float r2[8];
+  for (int i = 0; i < n_cut; ++i) r2[i] = radius_cut[i] * radius_cut[i];
+  return cc_table_components(p.nbr_idx, p.nbr_d, p.deg, M, max_nbr, r2, n_cut, component, d_num, ws_cc, ws_cc_bytes, s);
 }
 
 // ---- torch_hash_cuda drop-ins (pcdet/ops/torch_hash/src/torch_hash_api.cpp:9-15) ----------

@@ -70,6 +70,102 @@ cc_label_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ 
   }
 }
 
+// ---- the same over a neighbour TABLE (the k-nearest search's output) instead of an edge list, for several
+// distance cuts at once: ClusterProposal takes the components of the 32-NN graph at three radii
+// (cluster_proposal.py:57-83 of the reference), and the graph of a smaller radius is the larger one's cut at
+// dist2 <= r^2. Cut c has its own parent array [c * n, (c + 1) * n); one pass over the table hooks all of them.
+struct CcCuts {
+  float r2[8];
+  int n;
+};
+__device__ __forceinline__ void cc_union(int32_t* __restrict__ parent, int u, int v) {
+  int a = cc_find(parent, u), b = cc_find(parent, v);
+  while (a != b) {
+    if (a < b) { int t = a; a = b; b = t; }
+    int old = atomicCAS(&parent[a], a, b);
+    if (old == a) break;
+    a = cc_find(parent, old);
+    b = cc_find(parent, b);
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+cc_init_multi_kernel(int32_t* __restrict__ parent, int64_t n, int n_cut) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * n_cut;
+       i += (int64_t)gridDim.x * blockDim.x)
+    parent[i] = (int32_t)(i % n);
+}
+__global__ void __launch_bounds__(kBlock)
+cc_hook_table_kernel(const int32_t* __restrict__ nbr_idx, const float* __restrict__ nbr_d,
+                     const int32_t* __restrict__ deg, int64_t n, int K, CcCuts cuts, int32_t* __restrict__ parent) {
+  const int64_t total = n * K;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(t / K), e = (int)(t - (int64_t)q * K);
+    if (e >= deg[q]) continue;
+    const int v = nbr_idx[t];
+    if (v < 0 || v >= n || v == q) continue;
+    const float d = nbr_d[t];
+    for (int c = 0; c < cuts.n; ++c)
+      if (d <= cuts.r2[c]) cc_union(parent + (int64_t)c * n, q, v);
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+cc_root_multi_kernel(const int32_t* __restrict__ parent, int64_t n, int n_cut, int32_t* __restrict__ is_root) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * n_cut;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / n;
+    const int x = (int)(i - c * n);
+    is_root[i] = cc_find(parent + c * n, x) == x;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+cc_label_multi_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ rank, int64_t n, int n_cut,
+                      const int32_t* __restrict__ is_root, int64_t* __restrict__ label, int64_t* __restrict__ d_num) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * n_cut;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / n;
+    const int x = (int)(i - c * n);
+    const int r = cc_find(parent + c * n, x);
+    const int base = rank[c * n];  // (the scan runs over all cuts: ranks restart at every cut)
+    label[i] = rank[c * n + r] - base;
+    if (x == n - 1) d_num[c] = (int64_t)(rank[i] - base) + is_root[i];
+  }
+}
+
+size_t cc_table_workspace_bytes(int64_t n, int n_cut) {
+  if (n < 1) n = 1;
+  if (n_cut < 1) n_cut = 1;
+  Arena a(nullptr, 0);
+  a.take<int32_t>(n * n_cut);
+  a.take<int32_t>(n * n_cut);
+  a.take<int32_t>(n * n_cut);
+  a.take<char>(scan_i32_temp_bytes(n * n_cut));
+  return a.off;
+}
+
+int cc_table_components(const int32_t* nbr_idx, const float* nbr_d, const int32_t* deg, int64_t n, int K,
+                        const float* r2cut, int n_cut, int64_t* component, int64_t* d_num, void* ws,
+                        size_t ws_bytes, hipStream_t s) {
+  Arena a(ws, ws_bytes);
+  const int64_t m = n * n_cut;
+  int32_t* parent = a.take<int32_t>(m);
+  int32_t* is_root = a.take<int32_t>(m);
+  int32_t* rank = a.take<int32_t>(m);
+  const size_t tb = scan_i32_temp_bytes(m);
+  void* tmp = a.take<char>(tb);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
+  CcCuts cuts;
+  cuts.n = n_cut;
+  for (int i = 0; i < 8; ++i) cuts.r2[i] = i < n_cut ? r2cut[i] : -1.f;
+  cc_init_multi_kernel<<<grid_for(m), kBlock, 0, s>>>(parent, n, n_cut);
+  cc_hook_table_kernel<<<grid_for(n * K), kBlock, 0, s>>>(nbr_idx, nbr_d, deg, n, K, cuts, parent);
+  cc_root_multi_kernel<<<grid_for(m), kBlock, 0, s>>>(parent, n, n_cut, is_root);
+  int rc = exclusive_scan_i32(tmp, tb, is_root, rank, m, s);
+  if (rc) return rc;
+  cc_label_multi_kernel<<<grid_for(m), kBlock, 0, s>>>(parent, rank, n, n_cut, is_root, component, d_num);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
 // ------------------------------------------------------------------ per-segment median (ints)
 // k-th smallest with k = deg // 2 (upper median), O(deg^2) per segment: segments are voxels.
 __global__ void __launch_bounds__(kBlock)

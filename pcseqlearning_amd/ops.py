@@ -458,6 +458,37 @@ def radius_graph(ref, query, radius, max_nbr, sort_by_dist=True, dframe_min=0, d
     return e_ref, e_query
 
 
+def knn_components(points, radii, max_nbr=32):
+    """ClusterProposal's unit of work (cluster_proposal.py:57-83 of the reference) for several radius keys at once: the
+    max_nbr-nearest radius graph of `points` [n,4] on itself at the LARGEST radius (graph_utils.py:149-209), then the
+    connected components (graph_utils.py:40-53) of its cut at every radius of `radii` -- the k nearest within r,
+    nearest first, are the k nearest within R >= r cut at r -- straight from the neighbour table: no edge list.
+    Returns (component [len(radii), n] int64, num [len(radii)] int64 on the device, E of the largest graph). One host
+    synchronisation (the search's status / edge count)."""
+    L.require_gpu(points, "knn_components")
+    lib = L.load()
+    pts = points.float().contiguous()
+    n = pts.shape[0]
+    dev = pts.device
+    r32 = [float(torch.tensor(float(r), dtype=torch.float32)) for r in radii]
+    big = max(r32)
+    d_num = _dev_scalar(dev)
+    ws = L.workspace(lib.pcs_radius_graph_workspace_bytes(L.i64(n), L.i64(n), L.i32(max_nbr)), dev)
+    L.check(lib.pcs_radius_graph_search(L.ptr(pts), L.i64(n), L.ptr(pts), L.i64(n), L.f32(big), L.f32(-big / 2),
+                                        L.i32(0), L.i32(0), L.i32(max_nbr), L.i32(1), L.ptr(d_num), L.ptr(ws),
+                                        L.i64(ws.numel()), L.stream()), "pcs_radius_graph_search")
+    comp = torch.empty(len(r32), n, dtype=torch.int64, device=dev)
+    num = torch.empty(len(r32), dtype=torch.int64, device=dev)
+    ws_cc = L.workspace(lib.pcs_radius_graph_components_workspace_bytes(L.i64(n), L.i32(len(r32))), dev)
+    L.check(lib.pcs_radius_graph_components(L.i64(n), L.i64(n), L.i32(max_nbr), L.host_floats(r32), L.i32(len(r32)),
+                                            L.ptr(comp), L.ptr(num), L.ptr(ws), L.i64(ws.numel()), L.ptr(ws_cc),
+                                            L.i64(ws_cc.numel()), L.stream()), "pcs_radius_graph_components")
+    E = int(d_num.item())
+    if E < 0:
+        raise L.PcsError("knn_components: extent / cell_size exceeds the 17-bit cell range")
+    return comp, num, E
+
+
 def hash_insert_gpu(keys, values, reverse_indices, dims, insert_keys, insert_values):
     """torch_hash_cuda.hash_insert_gpu (torch_hash_kernel.cu:411-442), same argument order."""
     L.require_gpu(keys, "hash_insert_gpu")

@@ -52,25 +52,25 @@ class ClusterProposal(nn.Module):
             n_chunk = pcframe.fxyz.shape[0]
             if shared:
                 # The k nearest within r, listed nearest first, are the k nearest within R >= r cut at
-                # r: ONE graph at the largest radius serves every key (the reference builds one per
-                # key). The cut uses the engine's own test, dist2 <= fl32(r) * fl32(r) in fp32.
-                big = max(range(len(graphs)), key=lambda i: radii[i])
-                with Timer(f"Propose Cluster: graph r={radii[big]:g}"):
-                    g = graphs[big]
+                # r: ONE search at the largest radius serves every key (the reference builds one graph per
+                # key), and the components of every cut come straight from the neighbour table
+                # (ops.knn_components: no edge list, no masked gathers). The cut uses the engine's own
+                # test, dist2 <= fl32(r) * fl32(r) in fp32.
+                with Timer(f"Propose Cluster: graph r={max(radii):g} + components"):
+                    g = graphs[0]
                     pts = pcframe[g.relative_key]
-                    e0_all, e1_all, d2_all = ops.radius_graph(
-                        pts, pts, radii[big], g.max_num_neighbors, True, 0, 0,
-                        cell_size=-(radii[big] / 2), want_dists=True)
+                    comp_all, num_all, n_edges = ops.knn_components(pts, radii, g.max_num_neighbors)
                     timer.count("proposal graph points", 2 * n_chunk)
-                    timer.count("proposal graph edges", e0_all.shape[0])
+                    timer.count("proposal graph edges", n_edges)
+                    timer.count("proposal cc edges", n_edges * len(radii))
+                    timer.count("proposal cc nodes", n_chunk * len(radii))
+                for i, key in enumerate(self.component_keys):
+                    components[key][idx] = comp_all[i] + totals[key]
+                    totals[key] = totals[key] + num_all[i:i + 1]
+                continue
             for key, graph, radius in zip(self.component_keys, graphs, radii):
                 with Timer(f"Propose Cluster for {key}"):
-                    if shared:
-                        r32 = torch.tensor(radius, dtype=torch.float32)
-                        keep = (d2_all <= float(r32 * r32)).nonzero(as_tuple=True)[0]
-                        e0, e1 = e0_all[keep], e1_all[keep]
-                    else:
-                        e0, e1, _ = graph(pcframe, pcframe)
+                    e0, e1, _ = graph(pcframe, pcframe)
                     num, comp = graph_utils.connected_components(torch.stack([e0, e1], dim=0), n_chunk,
                                                                  host_count=False)
                     timer.count("proposal cc edges", e0.shape[0])

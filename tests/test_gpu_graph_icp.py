@@ -338,3 +338,82 @@ def test_icp_vs_oracle_larger(oracle):
     np.testing.assert_allclose(ratio, o_ratio, rtol=0, atol=1e-6)
     np.testing.assert_allclose(moved, o_moved, rtol=0, atol=2e-5)
 
+
+
+def _lidar_like(rng, n, frames=2):
+    """Points on a few planes and poles (dense surfaces, as a voxel-sampled LiDAR frame has them) plus a thin
+    uniform background (queries with fewer than k points inside the radius)."""
+    n_s, n_p = int(n * 0.7), int(n * 0.2)
+    uv = rng.uniform(-6, 6, (n_s, 2))
+    which = rng.integers(0, 3, n_s)
+    surf = np.stack([np.where(which == 0, uv[:, 0], np.where(which == 1, 3.0 + 0.01 * uv[:, 0], uv[:, 0])),
+                     np.where(which == 0, uv[:, 1], np.where(which == 1, uv[:, 1], -4.0)),
+                     np.where(which == 0, 0.02 * uv[:, 0], np.where(which == 1, 0.3 * uv[:, 0], 0.2 * uv[:, 1]))], 1)
+    poles = np.concatenate([rng.normal(0, 0.03, (n_p, 2)) + rng.integers(-5, 6, (n_p, 2)),
+                            rng.uniform(0, 2, (n_p, 1))], 1)
+    back = rng.uniform(-12, 12, (n - n_s - n_p, 3))
+    xyz = np.concatenate([surf, poles, back], 0).astype(np.float32)
+    rng.shuffle(xyz)
+    return np.concatenate([rng.integers(0, frames, (n, 1)).astype(np.float32), xyz], 1)
+
+
+@pytest.mark.parametrize("case", ["lidar", "ties", "query_cloud"])
+def test_knn_tiled_search_vs_engines(oracle, case):
+    """The cell-sorted wave search (pcs_knn.hip) against the oracle, against the one-thread engine it replaces and
+    against its own one-thread fallback: edges and distances bit for bit. `ties`: points on a lattice (dozens of
+    equal distances at the k-th place: rows overflow, the queries take the fallback)."""
+    from pcseqlearning_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(11)
+    if case == "ties":
+        g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+        ref = np.concatenate([np.zeros((g.shape[0], 1)), g * 0.125], 1).astype(np.float32)
+        rng.shuffle(ref)
+        qry = ref
+        r, k = 0.5, 32
+    elif case == "query_cloud":
+        ref = _lidar_like(rng, 30000)
+        qry = _lidar_like(rng, 7000)
+        r, k = 1.25, 8
+    else:
+        ref = _lidar_like(rng, 40000)
+        qry = ref
+        r, k = 1.25, 32
+    rt = dev(ref)
+    qt = rt if qry is ref else dev(qry)
+    got = {}
+    try:
+        for mode in ("tiled", "engine", "hard"):
+            lib.pcs_radius_graph_engine_only(1 if mode == "engine" else 0)
+            lib.pcs_knn_force_hard(1 if mode == "hard" else 0)
+            got[mode] = [t.cpu().numpy() for t in ops.radius_graph(rt, qt, r, k, True, want_dists=True)]
+    finally:
+        lib.pcs_radius_graph_engine_only(0)
+        lib.pcs_knn_force_hard(0)
+    for mode in ("engine", "hard"):
+        for a, b in zip(got["tiled"], got[mode]):
+            np.testing.assert_array_equal(a, b)
+    if case != "lidar":  # (the oracle's brute force is quadratic)
+        o_ref, o_q, o_d = oracle.radius_graph(ref, qry, r, k, True, want_dists=True)
+        np.testing.assert_array_equal(got["tiled"][0], o_ref)
+        np.testing.assert_array_equal(got["tiled"][1], o_q)
+        np.testing.assert_array_equal(got["tiled"][2], o_d)
+    assert got["tiled"][0].shape[0] > 4 * qry.shape[0]
+
+
+def test_knn_components_of_three_cuts(oracle):
+    """ops.knn_components (one 32-NN search at the largest radius, components of its cuts from the neighbour table)
+    = a graph and a labelling per radius, as ClusterProposal.propose_cluster asks for them."""
+    rng = np.random.default_rng(12)
+    pts = _lidar_like(rng, 30000)
+    p = dev(pts)
+    radii = [1.25, 0.75, 0.25]
+    comp, num, E = ops.knn_components(p, radii, 32)
+    for i, r in enumerate(radii):
+        e0, e1 = ops.radius_graph(p, p, r, 32, True)
+        o_num, o_comp = oracle.connected_components(e0.cpu().numpy(), e1.cpu().numpy(), pts.shape[0])
+        assert int(num[i]) == o_num
+        np.testing.assert_array_equal(comp[i].cpu().numpy(), o_comp)
+        if i == 0:
+            assert E == e0.shape[0]
+    assert int(num[2]) > int(num[1]) > int(num[0]) > 1
