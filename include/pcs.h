@@ -563,6 +563,9 @@ int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int6
                                 int max_rounds, float hit_below, float* best_center,
                                 float* best_normal, float* best_conf, void* ws, size_t ws_bytes,
                                 pcs_stream_t stream);
+/* test hook: 1 = the height-ratio fits of pcs_ransac_plane_hypotheses on one workgroup per (pillar, fit) and round
+ * (the form of rounds 3-4) instead of one per chunk of rows and round; a different summation tree. */
+int pcs_irls_per_fit_rounds(int on);
 
 /* The "truncated least squares" pruning of the plane hypotheses (preprocessor_utils.py:137-160: for
  * each of the T shrinking thresholds (host array, T <= 128) above which nothing lies the loop skips;

@@ -151,44 +151,49 @@ void orc_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int
         if (r > 2) for (int q = 0; q < 6; ++q) pl2[q] = plane_cur[c * 6 + q];
         float cur_z = 0.f;
         if (r <= 2) cur_z = min_z[c] * ratio + max_z[c] * omr;
-        double acc[11][kIrlsWg];
-        float dws[kIrlsWg];
-        for (int t = 0; t < kIrlsWg; ++t) {
-          double v[11];
-          for (int q = 0; q < 11; ++q) v[q] = 0.0;
-          float dw = 0.f;
-          for (int i = b + t; i < e; i += kIrlsWg) {
-            float x = xyz[(int64_t)i * 3], yy = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
-            float wi;
-            if (r <= 2) {
-              float zd = cur_z - z;
-              wi = (1.f / (zd * zd + sigma2)) * sigma2;
-            } else {
-              wi = plane_weight(pl2, x, yy, z, sigma2);
-            }
-            if (r > 1) {
-              float nw = plane_weight(pl, x, yy, z, sigma2);
-              dw = std::fmax(dw, std::fabs(nw - wi));
-              wi = nw;
-            }
-            float ox = x - o0, oy = yy - o1, oz = z - o2;
-            double W = wi;
-            v[0] += W; v[1] += W * ox; v[2] += W * oy; v[3] += W * oz;
-            v[4] += W * ox * ox; v[5] += W * ox * oy; v[6] += W * ox * oz;
-            v[7] += W * oy * oy; v[8] += W * oy * oz; v[9] += W * oz * oz;
-            v[10] += 1.0;
-          }
-          for (int q = 0; q < 11; ++q) acc[q][t] = v[q];
-          dws[t] = dw;
-        }
+        // irls_chunk_round_kernel: chunks of kIrlsChunk rows; in a chunk eight row slices (slice g adds rows g, g + 8,
+        // ...), the slices of a wave pairwise, the four waves in order; the chunks of a pillar in order
+        constexpr int kIrlsChunk = 1024, kSlices = 8;
         double a[11];
-        for (int q = 0; q < 11; ++q) {
-          double x = butterfly64(acc[q]);
-          for (int k = 1; k < kIrlsWg / 64; ++k) x += butterfly64(acc[q] + 64 * k);
-          a[q] = x;
+        for (int q = 0; q < 11; ++q) a[q] = 0.0;
+        float dws_all = 0.f;
+        const int nk = e > b ? (e - b + kIrlsChunk - 1) / kIrlsChunk : 1;
+        for (int k = 0; k < nk; ++k) {
+          const int cb = b + k * kIrlsChunk, ce = std::min(e, cb + kIrlsChunk);
+          double sl[kSlices][11];
+          for (int g = 0; g < kSlices; ++g) {
+            double v[11];
+            for (int q = 0; q < 11; ++q) v[q] = 0.0;
+            for (int i = cb + g; i < ce; i += kSlices) {
+              float x = xyz[(int64_t)i * 3], yy = xyz[(int64_t)i * 3 + 1], z = xyz[(int64_t)i * 3 + 2];
+              float wi;
+              if (r <= 2) {
+                float zd = cur_z - z;
+                wi = (1.f / (zd * zd + sigma2)) * sigma2;
+              } else {
+                wi = plane_weight(pl2, x, yy, z, sigma2);
+              }
+              if (r > 1) {
+                float nw = plane_weight(pl, x, yy, z, sigma2);
+                dws_all = std::fmax(dws_all, std::fabs(nw - wi));
+                wi = nw;
+              }
+              float ox = x - o0, oy = yy - o1, oz = z - o2;
+              double W = wi;
+              v[0] += W; v[1] += W * ox; v[2] += W * oy; v[3] += W * oz;
+              v[4] += W * ox * ox; v[5] += W * ox * oy; v[6] += W * ox * oz;
+              v[7] += W * oy * oy; v[8] += W * oy * oz; v[9] += W * oz * oz;
+              v[10] += 1.0;
+            }
+            for (int q = 0; q < 11; ++q) sl[g][q] = v[q];
+          }
+          for (int q = 0; q < 11; ++q) {
+            double x = sl[0][q] + sl[1][q];
+            for (int w = 1; w < kSlices / 2; ++w) x += sl[2 * w][q] + sl[2 * w + 1][q];
+            a[q] = k == 0 ? x : a[q] + x;
+          }
         }
-        float m4 = 0.f;
-        for (int t = 0; t < kIrlsWg; ++t) m4 = std::fmax(m4, dws[t]);
+        const float m4 = dws_all;
         if (r > 1) dw_all = std::fmax(dw_all, m4);
         double ws = a[0] + 1e-6;
         double cnt = a[10] > 0.5 ? a[10] : 1.0;

@@ -1000,6 +1000,216 @@ irls_seg_round_kernel(int r, int check_only, const float* __restrict__ xyz,
   }
 }
 
+// ---- the 30 height-ratio fits of compute_min_height_from_ransac, CHUNKED (round 5). The form above gives every
+// (pillar, fit) one workgroup per round: an 8 m super-pillar next to the sensor holds 24 000 of the sequence's
+// 650 000 rows (342 super-pillars, 97 of them 94 % of the rows), so a round's launch ended with a few two-wave
+// workgroups walking 190 rows per thread, each followed by a serial 3 x 3 eigen-solve in one lane -- 190 us per
+// round, 51 launches. Here a workgroup owns a CHUNK of kIrlsChunk rows of one pillar for ALL fits:
+//   * prologue: lane f < R adds the chunks' partial moments of round r-1 in chunk order and solves fit f's plane
+//     -- the 30 eigen-solves of a pillar side by side in 30 lanes (every chunk of the pillar repeats them: a few
+//     microseconds, no second launch, no grid barrier); chunk 0 stores the plane;
+//   * the chunk's rows are staged in LDS once and serve all fits: thread (g, f) adds rows g, g + 8, ... of fit f
+//     (32 lanes read one row: a broadcast), the two row slices of a wave meet by one shuffle, the four waves in
+//     LDS in wave order, and the chunk's 11 moments of every fit go to the partial buffer of round r.
+// Sums have a fixed tree (oracle/pcs_oracle_ground.cpp restates it), the convergence word of a round is an
+// order-free maximum, so results do not depend on what runs where. R <= 32 fits.
+static int g_irls_per_fit = 0;  // pcs_irls_per_fit_rounds: the form above for the ratio fits too (cross-check)
+constexpr int kIrlsChunk = 1024;
+constexpr int kIrlsChunkWg = 256;
+constexpr int kIrlsFits = 32;
+__global__ void __launch_bounds__(kBlock)
+irls_chunk_count_kernel(const int32_t* __restrict__ seg_start, int64_t P, int32_t* __restrict__ nchunk) {
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < P; c += (int64_t)gridDim.x * blockDim.x) {
+    const int rows = seg_start[c + 1] - seg_start[c];
+    nchunk[c] = rows > 0 ? (rows + kIrlsChunk - 1) / kIrlsChunk : 1;  // (an empty pillar still has a plane)
+  }
+}
+// moments of one (pillar, fit) -> plane (centre, normal): the tail of irls_seg_round_kernel
+__device__ __forceinline__ void irls_plane_from_moments(const double a[11], float o0, float o1, float o2, float out[6]) {
+  double ws = a[0] + 1e-6;
+  double cnt = a[10] > 0.5 ? a[10] : 1.0;
+  double og[3] = {(double)o0, (double)o1, (double)o2};
+  double m[3];
+  for (int q = 0; q < 3; ++q) m[q] = (a[1 + q] + og[q] * a[0]) / ws - og[q];
+  double So[3] = {a[1], a[2], a[3]};
+  double Soo[6] = {a[4], a[5], a[6], a[7], a[8], a[9]};
+  const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+  float cov[6];
+  for (int q = 0; q < 6; ++q) {
+    int i = ia[q], j = ib[q];
+    double sdd = Soo[q] - m[i] * So[j] - So[i] * m[j] + a[0] * m[i] * m[j];
+    cov[q] = (float)(sdd / cnt);
+  }
+  float nrm[3];
+  eig3_smallest(cov, nrm);
+  out[0] = (float)(m[0] + og[0]);
+  out[1] = (float)(m[1] + og[1]);
+  out[2] = (float)(m[2] + og[2]);
+  out[3] = nrm[0]; out[4] = nrm[1]; out[5] = nrm[2];
+}
+// round r (1-based) of all R fits; r == max_rounds + 1: the plane of the last round and its convergence test only
+// (grid: the chunks; `last` = that final launch). planes: [R][2][P][6] as above; part: [2][chunks][kIrlsFits][12].
+__global__ void __launch_bounds__(kIrlsChunkWg)
+irls_chunk_round_kernel(int r, int last, const float* __restrict__ xyz, const int32_t* __restrict__ seg_start,
+                        const int32_t* __restrict__ chunk_off, const float* __restrict__ origin, float sigma2,
+                        float delta, float* __restrict__ planes, int64_t P, int R, IrlsSegState* __restrict__ st,
+                        double* __restrict__ part, int64_t part_stride, const float* __restrict__ ratios,
+                        const float* __restrict__ min_z, const float* __restrict__ max_z) {
+  __shared__ float s_rows[kIrlsChunk * 3];
+  __shared__ double s_part[kIrlsChunkWg / 64][kIrlsFits][11];
+  __shared__ float s_plane[2][kIrlsFits][6];  // [0] round r-1, [1] round r-2
+  __shared__ int s_active[kIrlsFits];
+  __shared__ int s_c, s_k;
+  const int t = threadIdx.x;
+  const int j = blockIdx.x;
+  if (j >= chunk_off[P]) return;
+  if (t == 0) {
+    int lo = 0, hi = (int)P;  // the pillar of chunk j: chunk_off[lo] <= j < chunk_off[lo + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (chunk_off[mid] <= j) lo = mid; else hi = mid;
+    }
+    s_c = lo;
+    s_k = j - chunk_off[lo];
+  }
+  __syncthreads();
+  const int c = s_c, k = s_k;
+  const int nk = chunk_off[c + 1] - chunk_off[c];
+  const float o0 = origin[c * 3], o1 = origin[c * 3 + 1], o2 = origin[c * 3 + 2];
+  // ---- prologue: which fits still run, and their planes of the two rounds before
+  if (t < kIrlsFits) {
+    const int f = t;
+    int active = 0;
+    if (f < R) {
+      IrlsSegState* sf = st + f;
+      active = r <= sf->stop_round;
+      if (active && r > 2 && __uint_as_float(sf->dw[r - 1]) < delta) {
+        // round r-1's new weights moved by less than delta: the loop ended with the plane of round r-2
+        active = 0;
+        if (j == 0) { sf->stop_round = r - 1; sf->rounds = r - 2; sf->final_buf = r & 1; }
+      }
+      if (active) {
+        float* pf = planes + (size_t)f * P * 12;
+        if (r > 1) {
+          // the plane of round r-1 from its chunks' moments, in chunk order
+          const double* pp = part + (size_t)((r - 1) & 1) * part_stride + ((size_t)chunk_off[c] * kIrlsFits + f) * 12;
+          double a[11];
+#pragma unroll
+          for (int q = 0; q < 11; ++q) a[q] = pp[q];
+          for (int kk = 1; kk < nk; ++kk) {
+            const double* pq = pp + (size_t)kk * kIrlsFits * 12;
+#pragma unroll
+            for (int q = 0; q < 11; ++q) a[q] += pq[q];
+          }
+          float pl[6];
+          irls_plane_from_moments(a, o0, o1, o2, pl);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s_plane[0][f][q] = pl[q];
+          if (k == 0) {
+            float* out = pf + (size_t)((r - 1) & 1) * P * 6 + (int64_t)c * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) out[q] = pl[q];
+          }
+        }
+        if (r > 2) {
+          const float* p2 = pf + (size_t)(r & 1) * P * 6 + (int64_t)c * 6;  // round r-2 (stored by launch r-1)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) s_plane[1][f][q] = p2[q];
+        }
+        if (last && j == 0) { sf->rounds = r - 1; sf->final_buf = (r - 1) & 1; }
+      }
+    }
+    s_active[f] = active;
+  }
+  if (last) return;
+  // ---- the chunk's rows, staged once for all fits
+  const int b = seg_start[c] + k * kIrlsChunk;
+  const int e = min(seg_start[c + 1], b + kIrlsChunk);
+  const int nrow = max(e - b, 0);
+  for (int i = t; i < nrow * 3; i += kIrlsChunkWg) s_rows[i] = xyz[(int64_t)b * 3 + i];
+  __syncthreads();
+  const int f = t & 31, g = t >> 5;
+  const bool on = s_active[f] != 0;
+  float pl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pl2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (on && r > 1) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pl[q] = s_plane[0][f][q];
+  }
+  if (on && r > 2) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pl2[q] = s_plane[1][f][q];
+  }
+  float cur_z = 0.f;
+  if (on && r <= 2) {
+    const float ratio = ratios[f];
+    const float omr = (float)(1.0 - (double)ratio);  // Python forms 1 - ratio in double
+    cur_z = min_z[c] * ratio + max_z[c] * omr;
+  }
+  auto plane_weight = [&](const float* q, float x, float y, float z) {
+    float dx = x - q[0], dy = y - q[1], dz = z - q[2];
+    float er = fabsf(dx * q[3] + dy * q[4] + dz * q[5]);
+    float nw = sigma2 / (er * er + sigma2);
+    float dist_w = 0.25f / (dx * dx + dy * dy + dz * dz + 0.25f);
+    return nw * dist_w;
+  };
+  double v[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) v[q] = 0.0;
+  float dw = 0.f;
+  if (on) {
+    for (int i = g; i < nrow; i += kIrlsChunkWg / 32) {
+      const float x = s_rows[i * 3], y = s_rows[i * 3 + 1], z = s_rows[i * 3 + 2];
+      float wi;
+      if (r <= 2) {  // the initial weight (round 1) / the previous weight of round 2
+        float zd = cur_z - z;
+        wi = (1.f / (zd * zd + sigma2)) * sigma2;  // scalar / tensor is reciprocal() * scalar in torch
+      } else {
+        wi = plane_weight(pl2, x, y, z);
+      }
+      if (r > 1) {
+        float nw = plane_weight(pl, x, y, z);
+        dw = fmaxf(dw, fabsf(nw - wi));
+        wi = nw;
+      }
+      float ox = x - o0, oy = y - o1, oz = z - o2;
+      double W = wi;
+      v[0] += W; v[1] += W * ox; v[2] += W * oy; v[3] += W * oz;
+      v[4] += W * ox * ox; v[5] += W * ox * oy; v[6] += W * ox * oz;
+      v[7] += W * oy * oy; v[8] += W * oy * oz; v[9] += W * oz * oz;
+      v[10] += 1.0;
+    }
+  }
+  // the two row slices of a wave (lanes f and f + 32), then the waves in order
+  const int wv = t >> 6;
+#pragma unroll
+  for (int q = 0; q < 11; ++q) {
+    const double o = __shfl_xor(v[q], 32, 64);
+    const double lo_v = (t & 32) ? o : v[q], hi_v = (t & 32) ? v[q] : o;
+    v[q] = lo_v + hi_v;
+  }
+  dw = fmaxf(dw, __shfl_xor(dw, 32, 64));
+  if ((t & 63) < 32) {
+#pragma unroll
+    for (int q = 0; q < 11; ++q) s_part[wv][f][q] = v[q];
+  }
+  // (the maximum over the chunk's rows of fit f: the four waves' lanes f)
+  __shared__ float s_dw[kIrlsChunkWg / 64][kIrlsFits];
+  if ((t & 63) < 32) s_dw[wv][f] = dw;
+  __syncthreads();
+  if (t < kIrlsFits && t < R && s_active[t]) {
+    double* out = part + (size_t)(r & 1) * part_stride + ((size_t)j * kIrlsFits + t) * 12;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      double x = s_part[0][t][q];
+      for (int w = 1; w < kIrlsChunkWg / 64; ++w) x += s_part[w][t][q];
+      out[q] = x;
+    }
+    float m4 = s_dw[0][t];
+    for (int w = 1; w < kIrlsChunkWg / 64; ++w) m4 = fmaxf(m4, s_dw[w][t]);
+    if (r > 1) atomicMax(&st[t].dw[r], __float_as_uint(m4));
+  }
+}
+
 // result plane -> caller's buffer, point-plane error of every row against it; with `num_hit`
 // also the rows of the pillar whose error is below `hit_below` (the hypothesis' confidence)
 __global__ void __launch_bounds__(kBlock)
@@ -1472,15 +1682,21 @@ int pcs_irls_plane_fit_sorted(const float* xyz, const int32_t* seg_start, int64_
   return PCS_OK;
 }
 
+// most chunks a call can have: every pillar one, and one more per kIrlsChunk rows
+static inline int64_t irls_max_chunks(int64_t n, int64_t P) { return (n > 0 ? n : 0) / kIrlsChunk + (P > 0 ? P : 1); }
 size_t pcs_ransac_plane_hypotheses_workspace_bytes(int64_t n, int64_t P, int R) {
   Arena a(nullptr, 0);
   if (R < 1) R = 1;
+  if (P < 1) P = 1;
   a.take<IrlsSegState>(R);
-  a.take<float>((size_t)R * (P > 0 ? P : 1) * 12);
-  (void)n;
-  a.take<float>((size_t)R * (P > 0 ? P : 1) * 6);
-  a.take<float>((size_t)R * (P > 0 ? P : 1));
+  a.take<float>((size_t)R * P * 12);
+  a.take<float>((size_t)R * P * 6);
+  a.take<float>((size_t)R * P);
   a.take<float>(R);
+  a.take<int32_t>(P + 1);
+  a.take<int32_t>(P + 1);
+  a.take<char>(scan_i32_temp_bytes(P + 1));
+  a.take<double>((size_t)2 * irls_max_chunks(n, P) * kIrlsFits * 12);
   return a.off;
 }
 
@@ -1509,19 +1725,46 @@ int pcs_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int6
   float* d_ratios = a.take<float>(R);
   if (!a.ok()) return PCS_ERR_WORKSPACE;
   PCS_CHECK_HIP(hipMemcpyAsync(d_ratios, ratios, (size_t)R * sizeof(float), hipMemcpyHostToDevice, s));
+  int32_t* nchunk = a.take<int32_t>(P + 1);
+  int32_t* chunk_off = a.take<int32_t>(P + 1);
+  const size_t scan_bytes = scan_i32_temp_bytes(P + 1);
+  void* scan_tmp = a.take<char>(scan_bytes);
+  const int64_t max_chunks = irls_max_chunks(n, P);
+  double* part = a.take<double>((size_t)2 * max_chunks * kIrlsFits * 12);
+  if (!a.ok()) return PCS_ERR_WORKSPACE;
   irls_seg_init_kernel<<<R, 64, 0, s>>>(st);
   dim3 grid((unsigned)P, (unsigned)R);
-  for (int r = 1; r <= max_rounds; ++r)
-    irls_seg_round_kernel<<<grid, kIrlsWg, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta, w,
-                                                  planes, P, st, n, d_ratios, min_z, max_z);
-  irls_seg_round_kernel<<<dim3(1, (unsigned)R), 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin,
-                                                            sigma2, stopping_delta, w, planes, P, st, n,
-                                                            d_ratios, min_z, max_z);
+  if (R <= kIrlsFits && !g_irls_per_fit) {
+    // a workgroup per chunk of rows, all fits (irls_chunk_round_kernel)
+    PCS_CHECK_HIP(hipMemsetAsync(nchunk + P, 0, sizeof(int32_t), s));
+    irls_chunk_count_kernel<<<grid_for(P), kBlock, 0, s>>>(seg_start, P, nchunk);
+    int rc = exclusive_scan_i32(scan_tmp, scan_bytes, nchunk, chunk_off, (size_t)P + 1, s);
+    if (rc) return rc;
+    const size_t part_stride = (size_t)max_chunks * kIrlsFits * 12;
+    for (int r = 1; r <= max_rounds + 1; ++r)
+      irls_chunk_round_kernel<<<(int)max_chunks, kIrlsChunkWg, 0, s>>>(
+          r, r == max_rounds + 1, xyz, seg_start, chunk_off, origin, sigma2, stopping_delta, planes, P, R, st,
+          part, (int64_t)part_stride, d_ratios, min_z, max_z);
+  } else {
+    for (int r = 1; r <= max_rounds; ++r)
+      irls_seg_round_kernel<<<grid, kIrlsWg, 0, s>>>(r, 0, xyz, seg_start, origin, sigma2, stopping_delta, w,
+                                                    planes, P, st, n, d_ratios, min_z, max_z);
+    irls_seg_round_kernel<<<dim3(1, (unsigned)R), 64, 0, s>>>(max_rounds + 1, 1, xyz, seg_start, origin,
+                                                              sigma2, stopping_delta, w, planes, P, st, n,
+                                                              d_ratios, min_z, max_z);
+  }
   irls_seg_finish_kernel<<<grid, kBlock, 0, s>>>(xyz, seg_start, P, planes, st, planes_out, nullptr,
                                                  hit_below, num_hit);
   irls_select_kernel<<<grid_for(P), kBlock, 0, s>>>(R, P, planes_out, num_hit, best_center, best_normal,
                                                     best_conf);
   PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// test hook: 1 = the ratio fits on one workgroup per (pillar, fit) and round (irls_seg_round_kernel), the form before
+// the chunked rounds: another summation tree, results equal to a few last bits
+int pcs_irls_per_fit_rounds(int on) {
+  g_irls_per_fit = on ? 1 : 0;
   return PCS_OK;
 }
 
