@@ -531,17 +531,32 @@ constexpr int L1_MAX_CELLS = 12288;  // 48 KiB of LDS for h
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
+// Round 5: the Adam moments of a thread's cells live in registers (a thread owns cells tid, tid + 1024, ...: the same
+// ones at every step), the stencil weights weight + 1e-2 and min_z in LDS beside h (144 of the CU's 160 KB) -- a
+// step reads one cached global word per cell (it was two loads and two stores of m / v and a dozen weight loads). The same operations in the same order as before: the same bits.
+constexpr int L1_PER_THREAD = L1_MAX_CELLS / L1_BLOCK;
 __global__ void __launch_bounds__(L1_BLOCK)
 l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight, int X, int Y,
               double lr0, const int* __restrict__ decay_steps, int n_decay, float rigid,
-              int max_iters, float* __restrict__ h_out, float* __restrict__ m,
-              float* __restrict__ v, SmoothState* __restrict__ st) {
+              int max_iters, float* __restrict__ h_out, float* __restrict__ m_unused,
+              float* __restrict__ v_unused, SmoothState* __restrict__ st) {
   __shared__ float h[L1_MAX_CELLS];
+  __shared__ float sw[L1_MAX_CELLS];  // weight + 1e-2: the stencils' factor
+  __shared__ float smz[L1_MAX_CELLS];
   __shared__ double red[L1_BLOCK / 64];
   __shared__ int stop_flag;
+  (void)m_unused;
+  (void)v_unused;
   int n = X * Y;
   int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int e = tid; e < n; e += L1_BLOCK) { h[e] = 0.f; m[e] = 0.f; v[e] = 0.f; }
+  float mr[L1_PER_THREAD], vr[L1_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < L1_PER_THREAD; ++k) {
+    const int e = tid + k * L1_BLOCK;
+    mr[k] = 0.f;
+    vr[k] = 0.f;
+    if (e < n) { h[e] = 0.f; sw[e] = weight[e] + 1e-2f; smz[e] = min_z[e]; }
+  }
   if (tid == 0) stop_flag = 0;
   __syncthreads();
   float i1 = 1.f / (float)(X * Y), iL = 1.f / (float)((X - 2) * Y), iU = 1.f / (float)(X * (Y - 2)),
@@ -552,54 +567,59 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
   // (oracle/pcs_oracle_ground.cpp) forms the same bits (pow() is not the same function everywhere)
   double b1p = 1.0, b2p = 1.0;
   auto H = [&](int i, int j) { return h[i * Y + j]; };
-  auto W = [&](int i, int j) { return weight[i * Y + j] + 1e-2f; };
+  auto W = [&](int i, int j) { return sw[i * Y + j]; };
   for (; it < max_iters; ++it) {
     double lr = lr0;
     for (int q = 0; q < n_decay; ++q) if (it >= decay_steps[q]) lr *= 0.1;
     double part = 0.0;
-    // gradient of every cell from the OLD h (kept in registers-free form: written to v-adjacent
-    // moments only after the barrier)
-    for (int e = tid; e < n; e += L1_BLOCK) {
-      int i = e / Y, j = e - i * Y;
-      float g = 0.f;
-      float a = (H(i, j) - min_z[e]) * weight[e];
-      part += (double)(fabsf(a) * i1);
-      g += sgn(a) * weight[e] * i1;
-      // second differences along x: centres ci = i-1, i, i+1
-      for (int dc = -1; dc <= 1; ++dc) {
-        int ci = i + dc;
-        if (ci >= 1 && ci <= X - 2) {
-          float t = (H(ci - 1, j) - 2.f * H(ci, j) + H(ci + 1, j)) * W(ci, j);
-          float coef = dc == 0 ? -2.f : 1.f;
-          g += rigid * sgn(t) * W(ci, j) * coef * iL;
-          if (dc == 0) part += (double)(rigid * fabsf(t) * iL);
+    // gradient of every cell from the OLD h (h is written only after the barrier)
+#pragma unroll
+    for (int k = 0; k < L1_PER_THREAD; ++k) {
+      const int e = tid + k * L1_BLOCK;
+      if (e < n) {
+        int i = e / Y, j = e - i * Y;
+        float g = 0.f;
+        const float wte = weight[e];  // (cached: the one global read of a cell's step)
+        float a = (H(i, j) - smz[e]) * wte;
+        part += (double)(fabsf(a) * i1);
+        g += sgn(a) * wte * i1;
+        // second differences along x: centres ci = i-1, i, i+1
+#pragma unroll 1
+        for (int dc = -1; dc <= 1; ++dc) {
+          int ci = i + dc;
+          if (ci >= 1 && ci <= X - 2) {
+            float t = (H(ci - 1, j) - 2.f * H(ci, j) + H(ci + 1, j)) * W(ci, j);
+            float coef = dc == 0 ? -2.f : 1.f;
+            g += rigid * sgn(t) * W(ci, j) * coef * iL;
+            if (dc == 0) part += (double)(rigid * fabsf(t) * iL);
+          }
+          int cj = j + dc;
+          if (cj >= 1 && cj <= Y - 2) {
+            float t = (H(i, cj - 1) - 2.f * H(i, cj) + H(i, cj + 1)) * W(i, cj);
+            float coef = dc == 0 ? -2.f : 1.f;
+            g += rigid * sgn(t) * W(i, cj) * coef * iU;
+            if (dc == 0) part += (double)(rigid * fabsf(t) * iU);
+          }
+          // diagonal (i-1,j-1),(i,j),(i+1,j+1): this cell is the centre shifted by dc along it
+          int di = i + dc, dj = j + dc;
+          if (di >= 1 && di <= X - 2 && dj >= 1 && dj <= Y - 2) {
+            float t = (H(di - 1, dj - 1) - 2.f * H(di, dj) + H(di + 1, dj + 1)) * W(di, dj);
+            float coef = dc == 0 ? -2.f : 1.f;
+            g += rigid * sgn(t) * W(di, dj) * coef * iT;
+            if (dc == 0) part += (double)(rigid * fabsf(t) * iT);
+          }
+          // anti-diagonal (i+1,j-1),(i,j),(i-1,j+1)
+          int ai = i - dc, aj = j + dc;
+          if (ai >= 1 && ai <= X - 2 && aj >= 1 && aj <= Y - 2) {
+            float t = (H(ai + 1, aj - 1) - 2.f * H(ai, aj) + H(ai - 1, aj + 1)) * W(ai, aj);
+            float coef = dc == 0 ? -2.f : 1.f;
+            g += rigid * sgn(t) * W(ai, aj) * coef * iT;
+            if (dc == 0) part += (double)(rigid * fabsf(t) * iT);
+          }
         }
-        int cj = j + dc;
-        if (cj >= 1 && cj <= Y - 2) {
-          float t = (H(i, cj - 1) - 2.f * H(i, cj) + H(i, cj + 1)) * W(i, cj);
-          float coef = dc == 0 ? -2.f : 1.f;
-          g += rigid * sgn(t) * W(i, cj) * coef * iU;
-          if (dc == 0) part += (double)(rigid * fabsf(t) * iU);
-        }
-        // diagonal (i-1,j-1),(i,j),(i+1,j+1): this cell is the centre shifted by dc along it
-        int di = i + dc, dj = j + dc;
-        if (di >= 1 && di <= X - 2 && dj >= 1 && dj <= Y - 2) {
-          float t = (H(di - 1, dj - 1) - 2.f * H(di, dj) + H(di + 1, dj + 1)) * W(di, dj);
-          float coef = dc == 0 ? -2.f : 1.f;
-          g += rigid * sgn(t) * W(di, dj) * coef * iT;
-          if (dc == 0) part += (double)(rigid * fabsf(t) * iT);
-        }
-        // anti-diagonal (i+1,j-1),(i,j),(i-1,j+1)
-        int ai = i - dc, aj = j + dc;
-        if (ai >= 1 && ai <= X - 2 && aj >= 1 && aj <= Y - 2) {
-          float t = (H(ai + 1, aj - 1) - 2.f * H(ai, aj) + H(ai - 1, aj + 1)) * W(ai, aj);
-          float coef = dc == 0 ? -2.f : 1.f;
-          g += rigid * sgn(t) * W(ai, aj) * coef * iT;
-          if (dc == 0) part += (double)(rigid * fabsf(t) * iT);
-        }
+        mr[k] = mr[k] + 0.1f * (g - mr[k]);
+        vr[k] = vr[k] * 0.999f + 0.001f * g * g;
       }
-      m[e] = m[e] + 0.1f * (g - m[e]);
-      v[e] = v[e] * 0.999f + 0.001f * g * g;
     }
     part = wave_sum_f64(part);
     if (lane == 0) red[w] = part;
@@ -611,10 +631,14 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
     float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
     float decay = (float)(1.0 - lr * 1e-2);
-    for (int e = tid; e < n; e += L1_BLOCK) {
-      float x = h[e] * decay;
-      float denom = sqrtf(v[e]) / bc2_sqrt + 1e-8f;
-      h[e] = x - step_size * (m[e] / denom);
+#pragma unroll
+    for (int k = 0; k < L1_PER_THREAD; ++k) {
+      const int e = tid + k * L1_BLOCK;
+      if (e < n) {
+        float x = h[e] * decay;
+        float denom = sqrtf(vr[k]) / bc2_sqrt + 1e-8f;
+        h[e] = x - step_size * (mr[k] / denom);
+      }
     }
     if (tid == 0) {
       double tot = 0.0;
@@ -629,7 +653,7 @@ l1_min_kernel(const float* __restrict__ min_z, const float* __restrict__ weight,
     if (stop_flag) { ++it; break; }
   }
   for (int e = tid; e < n; e += L1_BLOCK) h_out[e] = h[e];
-  if (tid == 0) { st->iters = it; st->last_loss = last_loss; }
+  if (tid == 0 && st) { st->iters = it; st->last_loss = last_loss; }
 }
 
 
@@ -735,7 +759,7 @@ irls_accumulate_kernel(int r, const float* __restrict__ xyz, const int64_t* __re
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, f32 like the reference's eigh)
-__device__ inline void eig3_smallest(const float A_in[6], float nrm[3]) {
+__device__ __forceinline__ void eig3_smallest(const float A_in[6], float nrm[3]) {
   // A = [[a0 a1 a2],[a1 a3 a4],[a2 a4 a5]]
   double A[3][3] = {{A_in[0], A_in[1], A_in[2]}, {A_in[1], A_in[3], A_in[4]}, {A_in[2], A_in[4], A_in[5]}};
   double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
@@ -766,11 +790,18 @@ __device__ inline void eig3_smallest(const float A_in[6], float nrm[3]) {
         }
       }
   }
+  // (selects, not A[m][m] / V[k][m] with a computed m: indexed, the matrices went through scratch memory)
   int m = 0;
-  if (A[1][1] < A[m][m]) m = 1;
-  if (A[2][2] < A[m][m]) m = 2;
-  double sgn = V[2][m] < 0 ? -1.0 : 1.0;  // canonical sign: normal points up
-  for (int k = 0; k < 3; ++k) nrm[k] = (float)(sgn * V[k][m]);
+  double dm = A[0][0];
+  if (A[1][1] < dm) { m = 1; dm = A[1][1]; }
+  if (A[2][2] < dm) m = 2;
+  const double v0 = m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
+  const double v1 = m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
+  const double v2 = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+  double sgn = v2 < 0 ? -1.0 : 1.0;  // canonical sign: normal points up
+  nrm[0] = (float)(sgn * v0);
+  nrm[1] = (float)(sgn * v1);
+  nrm[2] = (float)(sgn * v2);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1033,13 +1064,12 @@ __device__ __forceinline__ void irls_plane_from_moments(const double a[11], floa
   for (int q = 0; q < 3; ++q) m[q] = (a[1 + q] + og[q] * a[0]) / ws - og[q];
   double So[3] = {a[1], a[2], a[3]};
   double Soo[6] = {a[4], a[5], a[6], a[7], a[8], a[9]};
-  const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
   float cov[6];
-  for (int q = 0; q < 6; ++q) {
-    int i = ia[q], j = ib[q];
-    double sdd = Soo[q] - m[i] * So[j] - So[i] * m[j] + a[0] * m[i] * m[j];
-    cov[q] = (float)(sdd / cnt);
-  }
+  // (written out: with the index pairs in arrays the operands went through scratch memory)
+#define PCS_IRLS_COV(q, i, j) cov[q] = (float)((Soo[q] - m[i] * So[j] - So[i] * m[j] + a[0] * m[i] * m[j]) / cnt)
+  PCS_IRLS_COV(0, 0, 0); PCS_IRLS_COV(1, 0, 1); PCS_IRLS_COV(2, 0, 2);
+  PCS_IRLS_COV(3, 1, 1); PCS_IRLS_COV(4, 1, 2); PCS_IRLS_COV(5, 2, 2);
+#undef PCS_IRLS_COV
   float nrm[3];
   eig3_smallest(cov, nrm);
   out[0] = (float)(m[0] + og[0]);
@@ -1453,51 +1483,55 @@ struct PruneThresholds {
   float v[128];
 };
 
+// Round 5: the k-NN set of a hypothesis changes only when one of its members is dropped (dropping others leaves its
+// k nearest what they were), so after a pruning event only the DIRTY hypotheses -- a handful -- are evaluated again,
+// and an evaluation is a WAVE's job, not a thread's: every lane scans its share of the hypotheses with the same
+// insertion network (f64 squared distances, ties by index), the 64 sorted lists are merged by k rounds of a wave
+// arg-min, and the curvature is added up in that ascending order. The same neighbours and the same sums as the
+// one-thread form (and as oracle/pcs_oracle_ground.cpp): 4.9 -> 0.3 ms per sequence.
 __global__ void __launch_bounds__(kPruneWg)
 prune_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ normal, int H, int K,
                         PruneThresholds thr, int T, uint8_t* __restrict__ keep) {
   __shared__ float sx[kPruneMax], sy[kPruneMax], sz[kPruneMax];
   __shared__ float snx[kPruneMax], sny[kPruneMax], snz[kPruneMax];
+  __shared__ float curv[kPruneMax];
+  __shared__ short nn[kPruneMax * kPruneK];  // the k nearest alive hypotheses of every hypothesis, ascending
+  __shared__ short list[kPruneMax];          // hypotheses to evaluate
   __shared__ uint8_t alive[kPruneMax];
   __shared__ float red[kPruneWg / 64];
   __shared__ int redn[kPruneWg / 64];
   __shared__ float s_max;
-  __shared__ int s_alive;
+  __shared__ int s_alive, s_nlist;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < H; i += kPruneWg) {
     sx[i] = xyz[3 * i]; sy[i] = xyz[3 * i + 1]; sz[i] = xyz[3 * i + 2];
     snx[i] = normal[3 * i]; sny[i] = normal[3 * i + 1]; snz[i] = normal[3 * i + 2];
     alive[i] = 1;
+    curv[i] = 0.f;
+    list[i] = (short)i;
   }
+  if (tid == 0) { s_nlist = H; s_alive = H; }
   __syncthreads();
-  float curv[2] = {0.f, 0.f};
-  // mean curvature of the hypotheses this thread owns over their k nearest alive hypotheses (itself
-  // included, like torch_cluster.knn(x, x, k)); returns through s_max / s_alive the maximum and count
+  // mean curvature of the listed hypotheses over their k nearest alive hypotheses (itself included, like
+  // torch_cluster.knn(x, x, k)); then the maximum over the alive ones and their count (s_max / s_alive)
   auto evaluate = [&]() {
-    float mx = -__builtin_inff();
-    int cnt = 0;
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int i = tid + o * kPruneWg;
-      curv[o] = 0.f;
-      if (i >= H || !alive[i]) continue;
-      ++cnt;
+    const int nl = s_nlist, n_alive = s_alive;
+    const int k = n_alive < K ? n_alive : K;
+    for (int li = w; li < nl; li += kPruneWg / 64) {
+      const int i = list[li];
       double bd[kPruneK];
       int bi[kPruneK];
 #pragma unroll
       for (int q = 0; q < kPruneK; ++q) { bd[q] = 1e300; bi[q] = 0x7fffffff; }
       const double xi = sx[i], yi = sy[i], zi = sz[i];
-      int n_alive = 0;
-      for (int j = 0; j < H; ++j) {
+      for (int j = lane; j < H; j += 64) {
         if (!alive[j]) continue;
-        ++n_alive;
         const double dx = (double)sx[j] - xi, dy = (double)sy[j] - yi, dz = (double)sz[j] - zi;
         double d = dx * dx + dy * dy + dz * dz;
         int id = j;
-        if (d > bd[kPruneK - 1]) continue;  // not among the k nearest so far (ties go through the network)
-        // insert (d, id) into the ascending list: fixed network, no indexed access
+        if (d > bd[kPruneK - 1]) continue;
 #pragma unroll
-        for (int q = 0; q < kPruneK; ++q) {
+        for (int q = 0; q < kPruneK; ++q) {  // insert (d, id) into the lane's ascending list: fixed network
           const bool lt = d < bd[q] || (d == bd[q] && id < bi[q]);
           const double td = lt ? bd[q] : d;
           const int ti = lt ? bi[q] : id;
@@ -1507,20 +1541,41 @@ prune_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__
           id = ti;
         }
       }
-      const int k = n_alive < K ? n_alive : K;
+      // merge: k rounds of (smallest head over the lanes, by (d, id)); the winning lane drops its head
       float sum = 0.f;
+      for (int q = 0; q < k; ++q) {
+        double md = bd[0];
+        int mi = bi[0];
 #pragma unroll
-      for (int q = 0; q < kPruneK; ++q) {
-        if (q < k) {
-          const int j = bi[q];
-          const float dx = sx[j] - sx[i], dy = sy[j] - sy[i], dz = sz[j] - sz[i];
-          const float p2p = fabsf((dx * snx[i] + dy * sny[i]) + dz * snz[i]);
-          sum += p2p / (sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-4f);
+        for (int o = 32; o > 0; o >>= 1) {
+          const double od = __shfl_xor(md, o, 64);
+          const int oi = __shfl_xor(mi, o, 64);
+          const bool take = od < md || (od == md && oi < mi);
+          md = take ? od : md;
+          mi = take ? oi : mi;
         }
+        if (bi[0] == mi) {
+#pragma unroll
+          for (int u = 0; u + 1 < kPruneK; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; }
+          bd[kPruneK - 1] = 1e300;
+          bi[kPruneK - 1] = 0x7fffffff;
+        }
+        const int j = mi;  // (< H: at least k hypotheses are alive)
+        if (lane == 0) nn[i * kPruneK + q] = (short)j;
+        const float dx = sx[j] - sx[i], dy = sy[j] - sy[i], dz = sz[j] - sz[i];
+        const float p2p = fabsf((dx * snx[i] + dy * sny[i]) + dz * snz[i]);
+        sum += p2p / (sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-4f);
       }
-      curv[o] = sum / (float)k;
-      mx = fmaxf(mx, curv[o]);
+      if (lane == 0) {
+        curv[i] = sum / (float)k;
+        for (int q = k; q < kPruneK; ++q) nn[i * kPruneK + q] = -1;
+      }
     }
+    __syncthreads();
+    float mx = -__builtin_inff();
+    int cnt = 0;
+    for (int i = tid; i < H; i += kPruneWg)
+      if (alive[i]) { mx = fmaxf(mx, curv[i]); ++cnt; }
     mx = wave_max(mx);
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     if (lane == 0) { red[w] = mx; redn[w] = cnt; }
@@ -1531,6 +1586,7 @@ prune_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__
       for (int q = 1; q < kPruneWg / 64; ++q) { m = fmaxf(m, red[q]); c += redn[q]; }
       s_max = m;
       s_alive = c;
+      s_nlist = 0;
     }
     __syncthreads();
   };
@@ -1538,10 +1594,30 @@ prune_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__
   for (int t = 0; t < T; ++t) {
     const float th = thr.v[t];
     if (th > s_max) continue;  // (uniform: s_max is only written inside evaluate(), between barriers)
+    const int alive_before = s_alive;
+    int dropped = 0;
+    for (int i = tid; i < H; i += kPruneWg)
+      if (alive[i] && !(curv[i] < th)) { alive[i] = 0; ++dropped; }
+    for (int off = 32; off > 0; off >>= 1) dropped += __shfl_xor(dropped, off, 64);
+    if (lane == 0) redn[w] = dropped;
+    __syncthreads();
+    if (tid == 0) {
+      int c = 0;
+      for (int q = 0; q < kPruneWg / 64; ++q) c += redn[q];
+      s_alive = alive_before - c;  // (evaluate() divides by min(alive, K))
+    }
+    __syncthreads();
+    // dirty: a member of the k nearest was dropped -- or fewer than K are left (the mean's divisor changes)
+    const bool all = s_alive < K;
+    for (int i = tid; i < H; i += kPruneWg) {
+      if (!alive[i]) continue;
+      bool dirty = all;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int i = tid + o * kPruneWg;
-      if (i < H && alive[i] && !(curv[o] < th)) alive[i] = 0;
+      for (int q = 0; q < kPruneK; ++q) {
+        const int j = nn[i * kPruneK + q];
+        dirty = dirty || (j >= 0 && !alive[j]);
+      }
+      if (dirty) list[atomicAdd(&s_nlist, 1)] = (short)i;
     }
     __syncthreads();
     evaluate();
