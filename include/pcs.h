@@ -526,6 +526,10 @@ int pcs_icp_set_schedule(int wide_iters, int use_tiles);
  * tombstones, the grid is rebuilt when they add up; 1: rebuilt at every iteration (the form of rounds 1-3, kept as the
  * cross-check of the in-place form: same results, bit for bit). */
 int pcs_icp_set_grid_mode(int rebuild_always);
+/* diagnostics: counters of the fused ICP's verified cache since the last call (all zero unless the library was built
+ * with -DPCS_ICP_STATS): host_out[4] = queries tested, budgets that had run out, of those kept by the second level
+ * (the four cached points re-ranked), queries handed to a search. Synchronises the device. */
+int pcs_icp_cache_stats(unsigned long long* host_out);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80
  * (per-pillar IRLS plane fit, <= max_rounds rounds, convergence test on the device; two kernels per

@@ -328,6 +328,22 @@ __device__ __forceinline__ float icp_cache_budget_none(float lb2, float rs2, flo
   return bud * 0.999999f - 2e-5f;
 }
 
+// ---- second level of the verified cache (round 5). A search also hands over the (up to three) nearest points OTHER
+// than the partner that it met (`others`), and L: a distance below which no point outside {partner, others} lies,
+// safely rounded. The caller stores others and c = L - budget; while the budget runs down by what has moved, L - moved
+// = budget + c (negative budgets included). A query whose budget has run out then measures its four cached points
+// where they are NOW, exactly, and keeps the nearest of them as long as that one is nearer than budget + c: everything
+// else is at least that far away. Exact -- the same statement as icp_cache_budget, one level up -- and it needs four
+// 16-byte gathers instead of a search.
+struct NnAux {
+  int o1, o2, o3;  // original indices of the other cached points, -1: none
+  float c;         // L - budget at the time of the statement; -inf: no statement
+};
+__device__ __forceinline__ float icp_cache_bound(float lb2, float radius2_4d) {
+  const float E = 1e-6f * radius2_4d + 1e-9f;
+  return sqrtf(fmaxf(lb2 - E, 0.f)) * 0.999999f - 2e-5f;
+}
+
 // Cooperative form: the 32 lanes of a half-wave serve ONE query (two queries per wave).
 //   1. lanes 0..26 fetch the occupancy masks of the 3x3x3 coarse blocks around the query;
 //   2. the 27 fine cells at Chebyshev distance <= 1 are dealt to 27 lanes (one round of memory
@@ -354,7 +370,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
                                                bool valid, int* __restrict__ overflow,
                                                float* __restrict__ best_dist2 = nullptr,
                                                float mu = 0.f, float* __restrict__ bud_out = nullptr,
-                                               float seed_d2 = __builtin_inff()) {
+                                               float seed_d2 = __builtin_inff(), NnAux* __restrict__ aux_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 31;
   const int half_base = lane & 32;
@@ -404,11 +420,24 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   valid = valid && any_block;
   int cand = -1;
   float cd = 0.f;
-  float cd2 = __builtin_inff();  // BUD: smallest squared distance seen other than the best's
+  // BUD: the nearest point this lane has seen other than its best (i2 at d2v), and the smallest squared distance of
+  // everything else it has seen (cd3)
+  int i2 = -1;
+  float d2v = __builtin_inff(), cd3 = __builtin_inff();
   auto widen = [&](float x2) {   // squared SPATIAL radius that must be examined around a best of x2 (4-D)
     if (!BUD) return x2 - dfsq;
     float r = sqrtf(fmaxf(x2 - dfsq, 0.f)) + mu;
     return r * r;
+  };
+  auto other = [&](int oi, float dist2) {  // a point that is not this lane's best
+    if (oi == i2) return;                  // (met again)
+    if (i2 < 0 || dist2 < d2v || (dist2 == d2v && oi < i2)) {
+      if (i2 >= 0) cd3 = fminf(cd3, d2v);
+      i2 = oi;
+      d2v = dist2;
+    } else {
+      cd3 = fminf(cd3, dist2);
+    }
   };
 
   auto consider = [&](float4 c, int oi) {
@@ -418,12 +447,13 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     dist2 = dist2 + d1 * d1;
     dist2 = dist2 + d2 * d2;
     dist2 = dist2 + d3 * d3;
+    if (BUD && oi < 0) return;  // (a tombstone of the moving grid: no point)
     if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) {
-      if (BUD && cand >= 0) cd2 = fminf(cd2, cd);
+      if (BUD && cand >= 0) other(cand, cd);
       cand = oi;
       cd = dist2;
     } else if (BUD) {
-      cd2 = fminf(cd2, dist2);
+      other(oi, dist2);
     }
   };
   // a cell's run is kCellCap contiguous rows: four rows and their indices are requested together
@@ -447,7 +477,9 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   // ---- spilled points (cells with more than kCellCap points; normally none): every lane of the
   //      half takes a stride of the list; same frame cell and radius test as the cell walk
   {
-    int no = valid ? *g.ovf : 0;
+    // (valid0, not valid: a moved point whose cell could not be claimed lies here WITHOUT a bit in the coarse masks,
+    //  g2_move_point; the length is clamped to the list's rows)
+    int no = valid0 ? min(*g.ovf, (int)g.ovf_cap) : 0;
     for (int j = sub; j < no; j += 32) {
       float4 c = g.ovf_pts[j];
       if (frame_cell(d, c.x) != fc) continue;
@@ -479,12 +511,12 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
     }
   };
   // (BUD: the lanes keep their own second-best; the best is exchanged, so a lane may hold the half's
-  //  best without having seen it -- its own former best then counts as a non-best distance)
+  //  best without having seen it -- its own former best then counts as one of its other points)
   {
     const int mine = cand;
     const float mine_d = cd;
     reduce_half();
-    if (BUD && mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
+    if (BUD && mine >= 0 && mine != cand) other(mine, mine_d);
   }
   // ---- far cells: everything at Chebyshev distance >= 2 is at least h away
   // BUD, seed_d2: the 4-D squared distance of a point KNOWN to be in the hashed cloud and inside the radius (the
@@ -587,7 +619,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       const int mine = cand;
       const float mine_d = cd;
       reduce_half();
-      if (BUD && mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
+      if (BUD && mine >= 0 && mine != cand) other(mine, mine_d);
     }
   };
   if (__ballot(rem != 0)) walk_cells(rem, true);
@@ -606,14 +638,40 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
   }
   if (best_dist2) *best_dist2 = cand >= 0 ? cd : d.radius2;
   if (BUD) {
-    // smallest non-best distance over the half
+    // the three nearest of the lanes' other points (by (dist2, index)); what is left -- the lanes' entries not taken
+    // and everything behind them -- bounds the points outside the cache
+    int o[3] = {-1, -1, -1};
+    float od0 = __builtin_inff();  // distance of the nearest other point (the runner-up, if any was taken)
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) cd2 = fminf(cd2, __shfl_xor(cd2, o, 64));
+    for (int q = 0; q < 3; ++q) {
+      int mi = i2;
+      float md = i2 >= 0 ? d2v : __builtin_inff();
+#pragma unroll
+      for (int s2 = 16; s2 > 0; s2 >>= 1) {
+        const int oi = __shfl_xor(mi, s2, 64);
+        const float odd = __shfl_xor(md, s2, 64);
+        const bool take = oi >= 0 && (mi < 0 || odd < md || (odd == md && oi < mi));
+        if (take) { mi = oi; md = odd; }
+      }
+      o[q] = mi;
+      if (q == 0) od0 = md;
+      if (mi >= 0 && i2 == mi) {  // taken: what this lane saw behind it is in cd3
+        i2 = -1;
+        d2v = __builtin_inff();
+      }
+    }
+    float rest2 = fminf(cd3, i2 >= 0 ? d2v : __builtin_inff());
+#pragma unroll
+    for (int s2 = 16; s2 > 0; s2 >>= 1) rest2 = fminf(rest2, __shfl_xor(rest2, s2, 64));
+    const float cd2 = fminf(od0, rest2);  // smallest squared distance seen other than the best's
     float bud = 0.f;
+    NnAux ax = {-1, -1, -1, -__builtin_inff()};
     if (valid0 && fa == fb) {  // (several frame values in the cell: no statement, search again next time)
       if (cand >= 0) {
         // every point within spatial distance s1 + mu has been looked at: the runner-up is at least that far
         bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, widen(cd)), d.radius2);
+        ax.o1 = o[0]; ax.o2 = o[1]; ax.o3 = o[2];
+        ax.c = icp_cache_bound(fminf(rest2 - dfsq, widen(cd)), d.radius2) - bud;
       } else if (!any_block || region_done) {
         // nothing within the radius; every point of the 3 x 3 x 3 blocks has been looked at (cd2; none at
         // all: +inf), the rest lies beyond their boundary
@@ -628,6 +686,7 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       }
     }
     if (bud_out) *bud_out = bud;
+    if (aux_out) *aux_out = ax;
   }
   return cand;
 }
@@ -668,7 +727,8 @@ __device__ __forceinline__ bool g2_seed_admissible(const GridDesc& d, const Grid
 // then runs the cooperative search for this query).
 __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid2& g, float4 p, int df,
                                                    float4 seed_pt, int seed_idx, bool valid, float mu,
-                                                   int* __restrict__ res, float* __restrict__ bud_out) {
+                                                   int* __restrict__ res, float* __restrict__ bud_out,
+                                                   NnAux* __restrict__ aux_out = nullptr) {
   const int sub = threadIdx.x & 7;
   int fc = frame_cell(d, p.x) + df;
   bool ok = valid && seed_idx >= 0 && fc >= 0 && fc < kFrameCells;
@@ -680,7 +740,20 @@ __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid
   const float margin = 1e-5f * d.radius2 + 1e-6f;
   int cand = -1;
   float cd = 0.f;
-  float cd2 = __builtin_inff();  // smallest squared distance seen other than the best's
+  // the nearest point this lane has seen other than its best (i2 at d2v), and the smallest squared distance of
+  // everything else it has seen (cd3): see g2_nearest_coop
+  int i2 = -1;
+  float d2v = __builtin_inff(), cd3 = __builtin_inff();
+  auto other = [&](int oi, float dist2) {
+    if (oi == i2) return;  // (met again: the seed in its cell)
+    if (i2 < 0 || dist2 < d2v || (dist2 == d2v && oi < i2)) {
+      if (i2 >= 0) cd3 = fminf(cd3, d2v);
+      i2 = oi;
+      d2v = dist2;
+    } else {
+      cd3 = fminf(cd3, dist2);
+    }
+  };
   auto consider = [&](float4 c, int oi) {
     float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
     float dist2 = 0.f;
@@ -688,12 +761,13 @@ __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid
     dist2 = dist2 + d1 * d1;
     dist2 = dist2 + d2 * d2;
     dist2 = dist2 + d3 * d3;
+    if (oi < 0) return;  // (a tombstone of the moving grid: no point)
     if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) {
-      if (cand >= 0) cd2 = fminf(cd2, cd);
+      if (cand >= 0) other(cand, cd);
       cand = oi;
       cd = dist2;
     } else if (oi != cand) {  // (the seed is met again in its cell)
-      cd2 = fminf(cd2, dist2);
+      other(oi, dist2);
     }
   };
   if (ok) consider(seed_pt, seed_idx);
@@ -714,7 +788,7 @@ __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid
   const float lim = (bound2 / h2) * 1.00001f + 1e-5f;
   // spilled points (cells with more than kCellCap points; normally none)
   {
-    const int no = ok ? *g.ovf : 0;
+    const int no = ok ? min(*g.ovf, (int)g.ovf_cap) : 0;
     for (int j = sub; j < no; j += 8) {
       float4 c = g.ovf_pts[j];
       if (frame_cell(d, c.x) != fc) continue;
@@ -744,7 +818,7 @@ __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid
       if (j + 3 < cnt) consider(c3, oi.w);
     }
   }
-  // best of the eight lanes; a lane whose own best lost keeps it as a non-best distance
+  // best of the eight lanes; a lane whose own best lost keeps it as one of its other points
   {
     const int mine = cand;
     const float mine_d = cd;
@@ -755,14 +829,43 @@ __device__ __forceinline__ bool g2_nearest_seeded8(const GridDesc& d, const Grid
       bool take = oc >= 0 && (cand < 0 || od < cd || (od == cd && oc < cand));
       if (take) { cand = oc; cd = od; }
     }
-    if (mine >= 0 && mine != cand) cd2 = fminf(cd2, mine_d);
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) cd2 = fminf(cd2, __shfl_xor(cd2, o, 64));
+    if (mine >= 0 && mine != cand) other(mine, mine_d);
   }
+  // the three nearest other points of the group, and the bound of what is left (g2_nearest_coop)
+  int ot[3] = {-1, -1, -1};
+  float od0 = __builtin_inff();
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    int mi = i2;
+    float md = i2 >= 0 ? d2v : __builtin_inff();
+#pragma unroll
+    for (int s2 = 4; s2 > 0; s2 >>= 1) {
+      const int oi = __shfl_xor(mi, s2, 64);
+      const float odd = __shfl_xor(md, s2, 64);
+      const bool take = oi >= 0 && (mi < 0 || odd < md || (odd == md && oi < mi));
+      if (take) { mi = oi; md = odd; }
+    }
+    ot[q] = mi;
+    if (q == 0) od0 = md;
+    if (mi >= 0 && i2 == mi) {
+      i2 = -1;
+      d2v = __builtin_inff();
+    }
+  }
+  float rest2 = fminf(cd3, i2 >= 0 ? d2v : __builtin_inff());
+#pragma unroll
+  for (int s2 = 4; s2 > 0; s2 >>= 1) rest2 = fminf(rest2, __shfl_xor(rest2, s2, 64));
+  const float cd2 = fminf(od0, rest2);
   *res = cand;
   float bud = 0.f;
-  if (ok && cand >= 0) bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, cover2), d.radius2);
+  NnAux ax = {-1, -1, -1, -__builtin_inff()};
+  if (ok && cand >= 0) {
+    bud = icp_cache_budget(cd - dfsq, fminf(cd2 - dfsq, cover2), d.radius2);
+    ax.o1 = ot[0]; ax.o2 = ot[1]; ax.o3 = ot[2];
+    ax.c = icp_cache_bound(fminf(rest2 - dfsq, cover2), d.radius2) - bud;
+  }
   *bud_out = bud;
+  if (aux_out) *aux_out = ax;
   return ok;
 }
 

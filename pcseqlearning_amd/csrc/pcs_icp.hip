@@ -62,6 +62,8 @@ bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& 
   b.nn_b = a.take<int32_t>(2 * Rn);
   b.bud_f = a.take<float>(2 * Mn);
   b.bud_b = a.take<float>(2 * Rn);
+  b.aux_f = a.take<NnAux>(Mn);
+  b.aux_b = a.take<NnAux>(Rn);
   b.wl = a.take<int32_t>(Mn + Rn);
   b.wls = a.take<int32_t>(Mn + Rn);
   b.sstep = a.take<unsigned int>(2 * kStepH);
@@ -117,6 +119,8 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.nn_b = b.nn_b;
   pr.bud_f = b.bud_f;
   pr.bud_b = b.bud_b;
+  pr.aux_f = b.aux_f;
+  pr.aux_b = b.aux_b;
   pr.wl = b.wl;
   pr.wls = b.wls;
   pr.sstep = b.sstep;
@@ -501,6 +505,71 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
   }
 }
 
+// diagnostics (built with -DPCS_ICP_STATS only): [0] queries tested, [1] budgets that had run out, [2] of those kept
+// by the second level, [3] queries handed to a search
+__device__ unsigned long long g_icp_stats[8];
+
+// ---- second level of the verified cache (NnAux, pcs_grid2.hpp): query `qid` (forward: moving point qid against the
+// reference cloud; backward: reference point qid - Mn against the moving cloud) whose budget `bud` (already less
+// what moved in the last iteration) has run out. Everything outside {partner s, the three cached others} is at least
+// bud + c away. The cached points are measured where they are now -- the 4-D squared distance exactly as a search
+// forms it -- and the nearest of them by (dist2, index) is THE nearest point while it is nearer than that bound and
+// inside the radius. Then: neighbour and budget of iteration k and the cache are rewritten (the old partner takes
+// the new one's place among the others), *m_p / *m_q = the pair (moving point, reference point), true. Otherwise
+// nothing is written: the caller sends the query to a search. iteration parity from `nn_o` / `bud_o`.
+__device__ __forceinline__ bool icp_second_level_impl(const IcpProblem& pr, const GridDesc& g, bool fwd, int qi,
+                                                      int32_t* __restrict__ nn_o, float* __restrict__ bud_o,
+                                                      float4 p, int s, float4 sp, float dist2, float c0s, float bud,
+                                                      float4& m_p, float4& m_q) {
+  NnAux* __restrict__ auxp = (fwd ? pr.aux_f : pr.aux_b) + qi;
+  const NnAux ax = *auxp;
+  const float Lrem = bud + ax.c;  // nothing outside the cache is nearer than this (spatial distance)
+  if (!(Lrem > 0.f)) return false;
+  const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;
+  int bi = s;
+  float bd = dist2, second = __builtin_inff();
+  float4 bp = sp;
+  int slot = 0;  // which cached point won: 0 = the partner
+  const int o[3] = {ax.o1, ax.o2, ax.o3};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (o[q] < 0) continue;
+    const float4 c = hpts[o[q]];
+    const float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+    float dd = 0.f;
+    dd = dd + d0 * d0;
+    dd = dd + d1 * d1;
+    dd = dd + d2 * d2;
+    dd = dd + d3 * d3;
+    if (dd < bd || (dd == bd && o[q] < bi)) {
+      second = fminf(second, bd);
+      bd = dd;
+      bi = o[q];
+      bp = c;
+      slot = q + 1;
+    } else {
+      second = fminf(second, dd);
+    }
+  }
+  const float E = 1e-6f * g.radius2 + 1e-9f;
+  const float s1 = sqrtf(fmaxf(bd - c0s, 0.f) + E);
+  if (!(bd <= g.radius2) || !(s1 + 2e-5f < Lrem)) return false;
+  // how long the new partner stays the nearest: half the gap to the runner-up -- the second of the cached points, or
+  // whatever lies outside the cache
+  const float nb = icp_cache_budget(bd - c0s, fminf(second - c0s, Lrem * Lrem), g.radius2);
+  nn_o[qi] = bi;
+  bud_o[qi] = nb;
+  NnAux nx = ax;
+  if (slot == 1) nx.o1 = s;
+  else if (slot == 2) nx.o2 = s;
+  else if (slot == 3) nx.o3 = s;
+  nx.c = Lrem - nb;
+  *auxp = nx;
+  m_p = fwd ? p : bp;
+  m_q = fwd ? bp : p;
+  return true;
+}
+
 // ---- phase 1: the budget test. Queries [0,Mn): forward (moving -> reference, df = +frame_offset);
 // queries [Mn, Mn+Rn): backward (reference -> moving, df = -frame_offset). The neighbours are a VERIFIED
 // CACHE: every search also returns how far things may move before its answer can change (half the gap
@@ -536,6 +605,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
     const bool fwd = qid < Mn;
     bool to_seeded = false, to_coop = false;
     bool heavy = false;  // (SPLIT = false) a failed query without a partner inside the radius to start from
+    bool stat_l1 = false, stat_l2 = false;  // (diagnostics)
     bool m_act = false;  // a settled pair whose moments are due: (moving point, reference point, component)
     float4 m_p = make_float4(0.f, 0.f, 0.f, 0.f), m_q = m_p;
     int m_c = 0;
@@ -597,10 +667,18 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
           m_q = fwd ? sp : p;
           m_c = c_pair;
         }
+      } else if (s >= 0 && icp_second_level_impl(pr, g, fwd, fwd ? qid : qid - Mn, fwd ? nn_f : nn_b, fwd ? bud_f : bud_b, p, s, sp, dist2, c0s, bud, m_p, m_q)) {
+        // the budget has run out, but the nearest of the four cached points, measured where they are now, is still
+        // nearer than anything outside the cache can be (icp_second_level wrote neighbour, budget and cache)
+        m_act = true;
+        stat_l1 = stat_l2 = true;
+        m_c = fwd ? c_pair : pr.comp[nn_b[qid - Mn]];  // (backward: the component of the moving point that won)
       } else if (SPLIT && s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
         to_seeded = true;  // (the tile path has ONE kind of search: SPLIT = false)
+        stat_l1 = true;
       } else {
         to_coop = true;
+        stat_l1 = s >= 0;
         if (!SPLIT) {
           // a query whose old partner is so near that the ball through it (+ mu) stays inside the 27 cells
           // around the query is searched by one lane; the others take a wave each (tile_nearest_wave)
@@ -610,6 +688,18 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
       }
     }
     mom_add_wave(pr, mt, m_act, m_p, m_q, m_c, lim2);
+#ifdef PCS_ICP_STATS
+    {
+      const unsigned long long mv = __ballot(valid), ms_ = __ballot(to_seeded || to_coop), m2 = __ballot(stat_l2),
+                               m1 = __ballot(stat_l1);
+      if (lane == 0) {
+        atomicAdd(&g_icp_stats[0], (unsigned long long)__popcll(mv));
+        atomicAdd(&g_icp_stats[1], (unsigned long long)__popcll(m1));
+        atomicAdd(&g_icp_stats[2], (unsigned long long)__popcll(m2));
+        atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(ms_));
+      }
+    }
+#endif
     // the work lists, by direction (a wave is all forward or all backward, except the one at Mn)
     const unsigned long long mf = __ballot(fwd);
 #pragma unroll
@@ -731,6 +821,7 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
   const bool fwd = dir == 0;
   int32_t* __restrict__ nn_o = fwd ? pr.nn_f + (size_t)(k & 1) * pr.capM : pr.nn_b + (size_t)(k & 1) * pr.capR;
   float* __restrict__ bud_o = fwd ? pr.bud_f + (size_t)(k & 1) * pr.capM : pr.bud_b + (size_t)(k & 1) * pr.capR;
+  NnAux* __restrict__ aux_o = fwd ? pr.aux_f : pr.aux_b;
   const Grid2 gs = fwd ? g2_view(pr.gr, Rn) : g2_view(pr.gm[st->gcur[k & 1] & 1], Mn);  // the hashed cloud
   const float4* __restrict__ qpts = fwd ? (const float4*)pr.mov : pr.ref;    // the queries' cloud
   const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;    // the hashed cloud's points
@@ -765,10 +856,12 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
       }
     }
     float bud = 0.f;
-    const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud, seed_d2);
+    NnAux ax;
+    const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud, seed_d2, &ax);
     if (valid && sub == 0) {
       nn_o[qi] = res;
       bud_o[qi] = bud;
+      aux_o[qi] = ax;
       if (res >= 0) {  // (moving point, reference point, the moving point's component)
         if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
         else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
@@ -790,11 +883,13 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
     }
     int res = -1;
     float bud = 0.f;
-    const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud);
+    NnAux ax;
+    const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud, &ax);
     if (valid && (threadIdx.x & 7) == 0) {
       if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
       nn_o[qi] = res;
       bud_o[qi] = bud;
+      aux_o[qi] = ax;
       if (res >= 0) {
         if (fwd) mom_add_stream(pr, mt, p, hpts[res], pr.comp[qi], lim2);
         else mom_add_stream(pr, mt, hpts[res], p, pr.comp[res], lim2);
@@ -2057,6 +2152,7 @@ __device__ __forceinline__ void tile_search_pass(const IcpProblem& pr, int k, in
       const int qi = (list[w] & ~kHeavyBit) - qoff;
       nn_o[qi] = -1;
       bud_o[qi] = 0.f;
+      (FWD ? pr.aux_f : pr.aux_b)[qi] = NnAux{-1, -1, -1, -__builtin_inff()};
     }
     return;
   }
@@ -2136,6 +2232,7 @@ __device__ __forceinline__ void tile_search_pass(const IcpProblem& pr, int k, in
       }
       nn_o[qi] = hit.idx;
       bud_o[qi] = hit.bud;
+      (FWD ? pr.aux_f : pr.aux_b)[qi] = NnAux{-1, -1, -1, -__builtin_inff()};  // (the tile searches keep no second level)
       if (hit.idx >= 0) {  // the pair as (moving point, reference point, the moving point's component)
         const float4 c = t_pts[hit.j];
         const int mc = pr.comp[FWD ? qi : hit.idx];
@@ -2172,6 +2269,7 @@ __device__ __forceinline__ void tile_search_pass(const IcpProblem& pr, int k, in
       if ((threadIdx.x & 63) == 0) {
         nn_o[qi] = hit.idx;
         bud_o[qi] = hit.bud;
+        (FWD ? pr.aux_f : pr.aux_b)[qi] = NnAux{-1, -1, -1, -__builtin_inff()};
         if (hit.idx >= 0) {
           const float4 c = t_pts[hit.j];
           const int mc = pr.comp[FWD ? qi : hit.idx];
@@ -2606,6 +2704,20 @@ extern "C" {
 //   wide_iters < 0 or >= max_iter: every iteration as wide launches (default);
 //   wide_iters >= 1: that many wide iterations, then the unit-resident loop: use_tiles != 0 the tile path
 //   (LDS-staged searches; registrations that do not qualify take the cache path), else the cache path.
+// diagnostics: the verified cache's counters since the last call (zero unless the library was built with
+// -DPCS_ICP_STATS): host_out[4] = queries tested, budgets run out, of those kept by the second level, searched.
+// Synchronises the device.
+int pcs_icp_cache_stats(unsigned long long* host_out) {
+  if (!host_out) return PCS_ERR_ARG;
+  unsigned long long v[8];
+  PCS_CHECK_HIP(hipDeviceSynchronize());
+  PCS_CHECK_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_icp_stats), sizeof(v)));
+  for (int i = 0; i < 4; ++i) host_out[i] = v[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PCS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)));
+  return PCS_OK;
+}
+
 int pcs_icp_set_grid_mode(int rebuild_always) {
   g_rebuild_always.store(rebuild_always != 0 ? 1 : 0, std::memory_order_relaxed);
   return PCS_OK;

@@ -98,6 +98,7 @@ struct IcpProblem {
   int32_t* first;       // [C] smallest moving-point index of the component (INT_MAX: none)
   int32_t *nn_f, *nn_b; // [2, capM] / [2, capR]: buffer k & 1 holds iteration k's neighbours
   float *bud_f, *bud_b; // same shape: how far things may still move before the neighbour can change
+  NnAux *aux_f, *aux_b; // [capM] / [capR]: second level of the verified cache (the other cached points, c = L - budget)
   int32_t* wl;          // [capM + capR] queries handed to the cooperative search
   int32_t* wls;         // [capM + capR] queries handed to the search around their old partner
   unsigned int* sstep;  // [2, kStepH] float bits: largest step of a moving point per 8x8x8-cell block (lossy hash)
@@ -157,6 +158,7 @@ struct IcpBufs {
   float4 *rsrt, *msrt;
   int32_t* trow;
   float *bud_f, *bud_b;
+  NnAux *aux_f, *aux_b;
   float* prev;
   long long* acc;
   double* Tb;
