@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--pre-streams", type=int, default=0,
                     help="create this many HIP streams before the library creates any (robustness check: the engines' "
                          "hardware queues must not depend on what the embedding application created first)")
+    ap.add_argument("--icp-widening", type=float, default=0.0,
+                    help="pcs_icp_set_widening: searches look radius / this further (0 = the library's default, 16)")
     ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the extra device-synchronised step")
@@ -366,6 +368,8 @@ def main():
     # streams an embedding application might have created before the library sees the device
     pre_streams = [torch.cuda.Stream(device) for _ in range(args.pre_streams)]
     ops.track_configure(args.engines, args.chunk_us)
+    if args.icp_widening > 0:
+        L.check(L.load().pcs_icp_set_widening(ctypes.c_double(args.icp_widening)), "pcs_icp_set_widening")
     ops.icp_set_schedule(*{"wide": (-1, True), "resident_tiles": (1, True), "resident_cache": (1, False)}[args.schedule])
     host_batch = host_batches[0]
     batch1 = models.load_data_to_gpu(host_batch, device)  # the first sequence alone (latency / stage report)
@@ -448,8 +452,8 @@ def main():
     dt = time.perf_counter() - t0
     host_fallbacks = CT.HOST_FALLBACKS - fallbacks0
     device_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0
-    prof = (ctypes.c_double * 9)()
-    lib.pcs_profile_icp_read(prof)
+    prof = (ctypes.c_double * 12)()
+    lib.pcs_profile_icp_read_ex(prof, ctypes.c_int(12))
     lib.pcs_profile_icp(ctypes.c_int(0))
     B = len(host_batches)
     host_spans = {k: round(v / (args.steps * B), 4) for k, v in timer.RECORDS.items()
@@ -474,21 +478,29 @@ def main():
         # HIP events attached to the dispatches themselves (hipExtLaunchKernelGGL): start of a chunk's first
         # launch to the stop of its last, the span a kernel trace shows for the same dispatches.
         ms, launches, nbytes, unit_iters = prof[0], prof[1], prof[2], prof[3]
-        achieved = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        # `achieved` / `frac` price the chunk at SURVEY 8(d)'s algorithmic bytes (112 (Mn + Rn) + 144 C_live per unit and
+        # iteration); `frac_impl` at this implementation's own traffic model (76 (Mn + Rn) + 68 Mn + 688 C: 20-word
+        # fixed-point moment records and double-buffered f64 transforms per component ID, live or not)
+        bytes_8d, many_iters, many_8d = prof[9], prof[10], prof[11]
+        achieved = (bytes_8d / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        achieved_impl = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of THIS schedule (tools/pmc_batch.sh ->
         # profiles/r04_icp_hbm_pmc.json, written by tools/summarize_pmc.py); null when no such file exists
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r04_icp_hbm_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r05_icp_hbm_pmc.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r04_icp_hbm_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
             ratio = pmc.get("icp_chunk_traffic_over_algorithmic")
             if ratio and launches > 0:
                 traffic = round(ratio * nbytes / launches, 1)
-            traffic_src = ("profiles/r04_icp_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                           "this command (same schedule), (fetch + write) / algorithmic = %s (raw FETCH_SIZE; "
-                           "%s with the guide's x2 correction for gfx950), times this run's algorithmic bytes "
-                           "per launch" % (ratio, pmc.get("icp_chunk_traffic_over_algorithmic_fetch_x2")))
+            traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                           "this command (same schedule), (fetch + write) / the implementation's bytes = %s (raw "
+                           "FETCH_SIZE; %s with the guide's x2 correction for gfx950), times this run's "
+                           "impl_bytes_per_launch" % (os.path.basename(pmc_path), ratio,
+                                                      pmc.get("icp_chunk_traffic_over_algorithmic_fetch_x2")))
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
@@ -545,11 +557,26 @@ def main():
                 "schedule": args.schedule,
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "bytes": "SURVEY 8(d): 112 (Mn + Rn) + 144 C_live per unit and iteration",
+                "frac_impl": round(achieved_impl / HBM_PEAK_GBS, 6),
+                "bytes_impl": "76 (Mn + Rn) + 68 Mn + 688 C per unit and iteration (this implementation's own records)",
+                # the same bytes over the whole timed window: what the ICP iterations of ALL engines move per second of
+                # the step (the chunks of the three engines overlap, so this is not the per-chunk figure times three)
+                "chip_level": {"achieved_GBs": round(bytes_8d / dt / 1e9, 2) if dt > 0 else 0.0,
+                               "frac": round(bytes_8d / dt / 1e9 / HBM_PEAK_GBS, 6) if dt > 0 else 0.0,
+                               "note": "8(d) bytes of every chunk of the timed steps / the steps' wall time"},
+                # by component count (chunks mix the keys, so only bytes and iterations split, not time): the 0.25 m
+                # key has ~13 k components of one or two points; the others about a thousand
+                "by_key": {"more_than_5000_components": {"unit_iterations": int(many_iters),
+                                                         "MB_per_unit_iteration": round(many_8d / max(many_iters, 1) / 1e6, 3)},
+                           "others": {"unit_iterations": int(unit_iters - many_iters),
+                                      "MB_per_unit_iteration": round((bytes_8d - many_8d) / max(unit_iters - many_iters, 1) / 1e6, 3)}},
                 "launches_timed": int(launches), "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
                 "timing": ("HIP events on the dispatches themselves, inside the timed steps: start of a chunk's first "
                            "iteration launch to the stop of its last, every chunk in which at least one unit iterated; "
                            "a 'launch' below is one chunk"),
-                "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1), 1),
+                "algorithmic_bytes_per_launch": round(bytes_8d / max(launches, 1), 1),
+                "impl_bytes_per_launch": round(nbytes / max(launches, 1), 1),
                 "unit_iterations_timed": int(unit_iters),
                 "unit_iterations_per_launch": round(unit_iters / max(launches, 1), 1),
                 "stages": stages,

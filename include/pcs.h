@@ -330,7 +330,12 @@ int pcs_segment_minmax_f32(const float* data, int d, const int32_t* order, const
  * comp_deg [C] int64 moving points per component (stationary included). Outputs: T [C,16] f64
  * row-major 4x4, l1_err [C] f64 (truncated mean of the last iteration), edge_ratio [C] f32.
  * info: HOST int32[4] = {iterations, stopped by countdown, 0, 0}. `radius` is the graph's base
- * radius; the frame-offset term is added inside as the reference does. */
+ * radius; the frame-offset term is added inside as the reference does.
+ * RANGE: the matched pairs' moments are summed as 64-bit fixed-point integers about each component's first moving
+ * point, which bounds a component's extent: a moving point or its partner further than 64 m from that origin (4096 m^2;
+ * less for registrations of more than 2^14 queries: 2^26 m^2 / (Mn + Rn)) fails the call with PCS_ERR_RANGE instead
+ * of returning wrong moments. The reference sums in float64 and has no such bound; the tracker's components are at
+ * most 12.5 m across (cluster_tracking.py:123-148). */
 size_t pcs_register_to_next_frame_workspace_bytes(int64_t Mn, int64_t Rn, int64_t Ra, int64_t C);
 int pcs_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int64_t Mn,
                                const float* ref_fxyz, int64_t Rn, const float* ref_all, int64_t Ra,
@@ -509,6 +514,10 @@ int pcs_l1_minimization(const float* pillar_min_z, const float* weight, int X, i
  * iterated are not counted. */
 int pcs_profile_icp(int enable);
 int pcs_profile_icp_read(double* out9);
+/* the same nine values and, behind them: [9] the chunks' algorithmic bytes by SURVEY 8(d)'s formula, 112 (Mn + Rn) +
+ * 144 C_live per unit and iteration ([2] is the implementation's own traffic model), [10] the unit-iterations of
+ * registrations with more than 5000 live components (the 0.25 m key), [11] their 8(d) bytes; n >= 9 doubles. */
+int pcs_profile_icp_read_ex(double* out, int n);
 
 /* Schedule of the iterations of the fused ICP (pcs_register_to_next_frame and the tracker), process-wide;
  * takes effect for the chunks enqueued afterwards. Every schedule computes the same iterations (the same
@@ -526,6 +535,9 @@ int pcs_icp_set_schedule(int wide_iters, int use_tiles);
  * tombstones, the grid is rebuilt when they add up; 1: rebuilt at every iteration (the form of rounds 1-3, kept as the
  * cross-check of the in-place form: same results, bit for bit). */
 int pcs_icp_set_grid_mode(int rebuild_always);
+/* every search of the fused ICP looks radius / radius_divisor further than it must, so that it can say how long its
+ * answer stays exact (default 16; any value >= 1 gives the same results: it trades cells per search against searches). */
+int pcs_icp_set_widening(double radius_divisor);
 /* diagnostics: counters of the fused ICP's verified cache since the last call (all zero unless the library was built
  * with -DPCS_ICP_STATS): host_out[4] = queries tested, budgets that had run out, of those kept by the second level
  * (the four cached points re-ranked), queries handed to a search. Synchronises the device. */

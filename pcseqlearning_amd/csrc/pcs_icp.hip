@@ -44,6 +44,9 @@ namespace pcs {
 // pcs_icp_set_grid_mode: the moving grid rebuilt at every iteration (the form before the in-place update; the
 // cross-check of tests/test_gpu_tracking.py) instead of when the solve phase finds it due
 static std::atomic<int> g_rebuild_always{0};
+// pcs_icp_set_widening: every search is widened by radius / g_mu_div (any value is exact; it trades the cells a
+// search looks at against how long its statement lasts)
+static std::atomic<double> g_mu_div{16.0};
 static bool icp_rebuild_always() { return g_rebuild_always.load(std::memory_order_relaxed) != 0; }
 
 bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
@@ -100,7 +103,7 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   // values (the kernel flags PCS_ERR_RANGE if the data violate that). cell_size may enlarge it.
   // every search is widened by mu (1/16 of the spatial radius) so that it can say how long its
   // answer stays valid; the cells must admit the widened ball
-  pr.mu = (float)(a.radius / 16.0);
+  pr.mu = (float)(a.radius / g_mu_div.load(std::memory_order_relaxed));
   double rad2 = (double)pr.rad * (double)pr.rad;
   double budget = (a.radius + pr.mu) * (a.radius + pr.mu) + (2e-5 * rad2 + 2e-6);
   if (budget < a.radius * a.radius) budget = a.radius * a.radius;
@@ -211,6 +214,7 @@ icp_clear_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
     st->dmax[0] = st->dmax[1] = 0u;
     st->loop_iters = 0;
     st->mode = 0;
+    st->live_c = 0;
     st->gcur[0] = st->gcur[1] = 1;  // (icp_insert3_kernel fills gm[1])
     st->grebuild = 1;               // (a fresh grid: the first solve phase takes its overflow count as the baseline)
     st->gmoves = 0u;
@@ -279,10 +283,14 @@ icp_bounds_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
 __global__ void __launch_bounds__(kBlock)
 icp_setup_kernel(const IcpProblem* __restrict__ tab, Batch bt) {
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
+  int live = 0;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < pr.C; c += (int64_t)gridDim.x * blockDim.x) {
     int f = pr.first[c];
     pr.corg[c] = f != INT_MAX ? pr.mov[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    live += f != INT_MAX;
   }
+  live = wave_sum_i32(live);
+  if ((threadIdx.x & 63) == 0 && live) atomicAdd(&pr.st->live_c, live);
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const float* b_ref = pr.bounds;
   const float* b_mov = pr.bounds + 8;
@@ -2503,6 +2511,9 @@ struct KernelProfile {
   double bytes = 0.0;
   double unit_iters = 0.0;
   double phase_us[4] = {0.0, 0.0, 0.0, 0.0};  // budget test, searches, solve, apply: summed over the units (CU time)
+  double bytes_8d = 0.0;       // SURVEY 8(d)'s figure: 112 (Mn + Rn) + 144 C_live per unit-iteration
+  double many_iters = 0.0;     // unit-iterations of registrations with more than 5000 live components
+  double many_bytes_8d = 0.0;  // their 8(d) bytes
 };
 static bool g_prof_on = false;
 static KernelProfile g_prof;
@@ -2651,7 +2662,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
 }
 
 // after the stream has been synchronised: add the chunk's loop launch to the profile
-void icp_profile_account(double unit_iters, double bytes, int prof_slot) {
+void icp_profile_account(double unit_iters, double bytes, int prof_slot, double bytes_8d, double many_iters,
+                         double many_bytes_8d) {
   if (prof_slot < 0 || prof_slot >= kProfSlots) prof_slot = 0;
   ProfEvents& t_ev = t_evs[prof_slot];
   if (!g_prof_on || !t_ev.used) return;
@@ -2664,6 +2676,9 @@ void icp_profile_account(double unit_iters, double bytes, int prof_slot) {
   g_prof.launches += 1.0;
   g_prof.bytes += bytes;
   g_prof.unit_iters += unit_iters;
+  g_prof.bytes_8d += bytes_8d;
+  g_prof.many_iters += many_iters;
+  g_prof.many_bytes_8d += many_bytes_8d;
 }
 
 void icp_profile_phases(const unsigned long long* ticks4) {
@@ -2718,6 +2733,12 @@ int pcs_icp_cache_stats(unsigned long long* host_out) {
   return PCS_OK;
 }
 
+int pcs_icp_set_widening(double radius_divisor) {
+  if (!(radius_divisor >= 1.0)) return PCS_ERR_ARG;
+  g_mu_div.store(radius_divisor, std::memory_order_relaxed);
+  return PCS_OK;
+}
+
 int pcs_icp_set_grid_mode(int rebuild_always) {
   g_rebuild_always.store(rebuild_always != 0 ? 1 : 0, std::memory_order_relaxed);
   return PCS_OK;
@@ -2742,6 +2763,22 @@ int pcs_profile_icp(int enable) {
 // accumulated since the last enable; [4..7] = microseconds its workgroups spent in the budget test, the
 // searches, solve + stop rule, apply (summed over the units: CU time, not wall time; registrations that
 // have ended); [8] = 0.
+int pcs_profile_icp_read(double* out9);
+// the same and, behind it: [9] the chunks' algorithmic bytes by SURVEY 8(d)'s formula (112 (Mn + Rn) + 144 C_live per
+// unit and iteration; [2] is this implementation's own traffic model), [10] unit-iterations of registrations with
+// more than 5000 live components (the 0.25 m key), [11] their 8(d) bytes. n = doubles the caller's array holds (>= 9).
+int pcs_profile_icp_read_ex(double* out, int n) {
+  if (!out || n < 9) return PCS_ERR_ARG;
+  int rc = pcs_profile_icp_read(out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (n > 9) out[9] = g_prof.bytes_8d;
+  if (n > 10) out[10] = g_prof.many_iters;
+  if (n > 11) out[11] = g_prof.many_bytes_8d;
+  for (int q = 12; q < n; ++q) out[q] = 0.0;
+  return PCS_OK;
+}
+
 int pcs_profile_icp_read(double* out9) {
   if (!out9) return PCS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_prof_mu);

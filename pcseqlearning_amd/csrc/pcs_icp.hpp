@@ -47,6 +47,7 @@ struct IcpState {
   int govf0;             // length of the overflow list right after the last rebuild
   int loop_iters;        // iterations the unit-resident loops have run (the others were wide launches)
   int mode;              // 0: not decided yet, 1: tile path (icp_tile_kernel), 2: cache path (icp_loop_kernel)
+  int live_c;            // components that have a moving point (of the C ids the caller numbers them with)
   // measurement: 100 MHz ticks (s_memrealtime) the unit-resident loop spent in its four phases -- budget
   // test, searches, solve, apply -- summed over the iterations of this registration
   unsigned long long phase_ticks[4];
@@ -201,7 +202,8 @@ struct IcpHint {
 // optional HIP-event timing of the unit-resident loop kernel (bench.py's roofline): after the stream has
 // been synchronised, account the calling thread's last chunk: unit_iters = iterations its entries ran in
 // the loop kernel, bytes = their algorithmic bytes
-void icp_profile_account(double unit_iters, double bytes, int prof_slot);
+void icp_profile_account(double unit_iters, double bytes, int prof_slot, double bytes_8d = 0.0, double many_iters = 0.0,
+                         double many_bytes_8d = 0.0);
 // a registration has ended: its IcpState::phase_ticks join the profile
 void icp_profile_phases(const unsigned long long* ticks4);
 // enqueue: reset + bounds + grid description + the three grids of every entry

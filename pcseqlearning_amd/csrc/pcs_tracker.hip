@@ -1681,7 +1681,7 @@ void Engine::collect_tick() {
     }
   }
   if (b_iter_.n) {
-    double unit_iters = 0.0, bytes = 0.0;
+    double unit_iters = 0.0, bytes = 0.0, bytes_8d = 0.0, many_iters = 0.0, many_8d = 0.0;
     for (int e = 0; e < b_iter_.n; ++e) {
       HostUnit& h = hu[b_iter_.idx[e]];
       h.icp = pin_icp_[e];
@@ -1691,8 +1691,14 @@ void Engine::collect_tick() {
       // per unit and iteration: neighbours (36 per query) + moments (40 per query, 272 per component) + solve and
       // apply (68 per moving point, 416 per component)
       bytes += it * (76.0 * (Mn + Rn) + 272.0 * C + 68.0 * Mn + 416.0 * C);
+      // two graphs 2 (16 N + 16 M) + 2 x 16 E, the P / Q gathers 2 x 24 E, covariance and transform
+      // 2 x 72 C -- with E = N + M (one edge per query at most) and C the components that have a moving point
+      const double Cl = (double)h.icp.live_c;
+      const double b8 = it * (112.0 * (Mn + Rn) + 144.0 * Cl);
+      bytes_8d += b8;
+      if (Cl > 5000.0) { many_iters += it; many_8d += b8; }
     }
-    icp_profile_account(unit_iters, bytes, 0);
+    icp_profile_account(unit_iters, bytes, 0, bytes_8d, many_iters, many_8d);
   }
 }
 

@@ -9,7 +9,7 @@ def count_into(index, size, weight=None):
     """torch.bincount(index[weight], minlength=size) for indices known to be < size, without bincount's and the mask's
     host synchronisations (integer adds: the same counts)."""
     out = torch.zeros(size, dtype=torch.int64, device=index.device)
-    if index.numel():
+    if index.numel() and size:  # (size 0 -- a sequence without GT boxes: bincount(minlength=0) of nothing is empty)
         out.index_add_(0, index, torch.ones_like(index) if weight is None else weight.to(torch.int64))
     return out
 
@@ -37,7 +37,7 @@ def component_box_iou(component, bp_mask, point_gt_box_id, gt_count_per_box):
 
 def scatter_max_(dst, index, values):
     """dst[index] = max(dst[index], values) (values already in dst's dtype)."""
-    if index.numel():
+    if index.numel() and dst.numel():  # (no boxes: nothing to update)
         dst.scatter_reduce_(0, index, values, reduce="amax", include_self=True)
     return dst
 

@@ -72,3 +72,15 @@ def test_component_box_iou_frames_matches_per_frame():
         assert torch.equal(inv[sel] - pos, inv_f)
         pos += k
     assert pos == gframe.numel()
+
+
+def test_no_boxes_is_not_an_error():
+    """A sequence without GT boxes: counting into zero bins and a running maximum over zero boxes
+    are no-ops, as bincount(minlength=0) / an empty best_iou are in the reference."""
+    from pcseqlearning_amd.pcdet.models.registration.preprocessors.eval_utils import count_into, scatter_max_
+    idx = torch.zeros(5, dtype=torch.int64)
+    assert count_into(idx, 0).numel() == 0
+    assert count_into(idx, 0, torch.ones(5, dtype=torch.bool)).numel() == 0
+    best = torch.zeros(0, dtype=torch.float64)
+    assert scatter_max_(best, idx, torch.ones(5, dtype=torch.float64)).numel() == 0
+    assert count_into(torch.tensor([0, 2, 2]), 3).tolist() == [1, 0, 2]

@@ -417,3 +417,26 @@ def test_knn_components_of_three_cuts(oracle):
         if i == 0:
             assert E == e0.shape[0]
     assert int(num[2]) > int(num[1]) > int(num[0]) > 1
+
+
+def test_icp_component_beyond_fixed_point_range_is_refused():
+    """the moments are 64-bit fixed point about each component's first moving point; a component that
+    reaches further than 64 m from it must fail the call (PCS_ERR_RANGE), not return wrong moments (include/pcs.h)."""
+    from pcseqlearning_amd.lib import PcsError
+    rng = np.random.default_rng(21)
+    n = 400
+    xyz = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    xyz[n // 2:, 0] += 70.0  # one component, two blobs 70 m apart
+    mov = np.concatenate([np.full((n, 1), 3, np.float32), xyz], 1)
+    ref = mov.copy()
+    ref[:, 0] = 4
+    ref[:, 1:] += 0.05
+    comp = np.zeros(n, np.int32)
+    with pytest.raises(PcsError):
+        ops.register_to_next_frame(dev(mov), dev(comp), dev(ref), dev(ref), dev(np.array([n], np.int64)), 1, 1.25, 1,
+                                   10.0, 20, 0.05)
+    # the same clouds as two components (each 2 m across) register
+    comp[n // 2:] = 1
+    T, _, _, iters = ops.register_to_next_frame(dev(mov), dev(comp), dev(ref), dev(ref),
+                                                dev(np.array([n // 2, n // 2], np.int64)), 2, 1.25, 1, 10.0, 20, 0.05)
+    assert iters >= 1 and np.isfinite(T.cpu().numpy()).all()

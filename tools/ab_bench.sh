@@ -5,7 +5,9 @@
 A=$1; B=$2; ROUNDS=${3:-2}; shift 3 2>/dev/null
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$ROOT/pcseqlearning_amd/libpcs_hip.so
-cp $LIB /tmp/ab_keep.so
+KEEP=$(mktemp /tmp/ab_keep.XXXXXX.so)
+cp $LIB $KEEP
+trap 'cp $KEEP $LIB; rm -f $KEEP' EXIT  # (an interrupted run puts the tree's own build back too)
 mkdir -p $ROOT/gpurun_out/ab
 python3 -c "import bench; bench.load_sequences(list(range(12)), 20, 160000)" >/dev/null 2>&1
 for r in $(seq 1 $ROUNDS); do
@@ -23,4 +25,3 @@ except Exception as e:
 PY
   done
 done
-cp /tmp/ab_keep.so $LIB

@@ -5,7 +5,9 @@
 ROUNDS=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$ROOT/pcseqlearning_amd/libpcs_hip.so
-cp $LIB /tmp/ab_keep.so
+KEEP=$(mktemp /tmp/ab_keep.XXXXXX.so)
+cp $LIB $KEEP
+trap 'cp $KEEP $LIB; rm -f $KEEP' EXIT  # (an interrupted run puts the tree's own build back too)
 mkdir -p $ROOT/gpurun_out/abm
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
@@ -26,4 +28,3 @@ except Exception as e:
 PY
   done
 done
-cp /tmp/ab_keep.so $LIB

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch, bench
 from pcseqlearning_amd import ops, lib as L
 from pcseqlearning_amd.pcdet import models
