@@ -538,6 +538,10 @@ int pcs_icp_set_grid_mode(int rebuild_always);
 /* every search of the fused ICP looks radius / radius_divisor further than it must, so that it can say how long its
  * answer stays exact (default 16; any value >= 1 gives the same results: it trades cells per search against searches). */
 int pcs_icp_set_widening(double radius_divisor);
+/* the verified cache of the fused ICP: 2 (default) = budgets and the second level (a query whose budget has run out
+ * re-ranks its four cached points before it is searched), 1 = budgets only, the form of rounds 1-4 -- the same results
+ * bit for bit (cross-check of the tests). Takes effect for registrations described afterwards. */
+int pcs_icp_set_cache_levels(int levels);
 /* diagnostics: counters of the fused ICP's verified cache since the last call (all zero unless the library was built
  * with -DPCS_ICP_STATS): host_out[4] = queries tested, budgets that had run out, of those kept by the second level
  * (the four cached points re-ranked), queries handed to a search. Synchronises the device. */

@@ -47,6 +47,7 @@ static std::atomic<int> g_rebuild_always{0};
 // pcs_icp_set_widening: every search is widened by radius / g_mu_div (any value is exact; it trades the cells a
 // search looks at against how long its statement lasts)
 static std::atomic<double> g_mu_div{16.0};
+static std::atomic<int> g_cache_levels{2};
 static bool icp_rebuild_always() { return g_rebuild_always.load(std::memory_order_relaxed) != 0; }
 
 bool plan_icp(Arena& a, int64_t Mn, int64_t Rn, int64_t Ra, int64_t C, IcpBufs& b) {
@@ -157,7 +158,8 @@ int icp_describe(const IcpArgs& a, void* ws, size_t ws_bytes, IcpProblem* out) {
   pr.capR = (int)(a.Rn > 0 ? a.Rn : 1);
   pr.df = a.frame_offset;
   pr.max_iter = a.max_iter;
-  pr.want = (a.want_l1 ? kIcpWantL1 : 0) | (a.want_ratio ? kIcpWantRatio : 0) | (icp_rebuild_always() ? kIcpRebuildAlways : 0);
+  pr.want = (a.want_l1 ? kIcpWantL1 : 0) | (a.want_ratio ? kIcpWantRatio : 0) | (icp_rebuild_always() ? kIcpRebuildAlways : 0) |
+            (g_cache_levels.load(std::memory_order_relaxed) == 1 ? kIcpNoSecondLevel : 0);
   return PCS_OK;
 }
 
@@ -528,37 +530,39 @@ __device__ unsigned long long g_icp_stats[8];
 __device__ __forceinline__ bool icp_second_level_impl(const IcpProblem& pr, const GridDesc& g, bool fwd, int qi,
                                                       int32_t* __restrict__ nn_o, float* __restrict__ bud_o,
                                                       float4 p, int s, float4 sp, float dist2, float c0s, float bud,
-                                                      float4& m_p, float4& m_q) {
+                                                      float4& m_p, float4& m_q, int& winner) {
   NnAux* __restrict__ auxp = (fwd ? pr.aux_f : pr.aux_b) + qi;
+  if (pr.want & kIcpNoSecondLevel) return false;  // (pcs_icp_set_cache_levels(1): the cross-check of the tests)
   const NnAux ax = *auxp;
   const float Lrem = bud + ax.c;  // nothing outside the cache is nearer than this (spatial distance)
   if (!(Lrem > 0.f)) return false;
   const float4* __restrict__ hpts = fwd ? pr.ref : (const float4*)pr.mov;
   int bi = s;
   float bd = dist2, second = __builtin_inff();
-  float4 bp = sp;
+  float bx = sp.x, by = sp.y, bz = sp.z, bw = sp.w;  // the nearest cached point so far (scalars: see below)
   int slot = 0;  // which cached point won: 0 = the partner
   const int o[3] = {ax.o1, ax.o2, ax.o3};
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    if (o[q] < 0) continue;
-    const float4 c = hpts[o[q]];
+    const bool have = o[q] >= 0;
+    const float4 c = hpts[have ? o[q] : s];
     const float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
     float dd = 0.f;
     dd = dd + d0 * d0;
     dd = dd + d1 * d1;
     dd = dd + d2 * d2;
     dd = dd + d3 * d3;
-    if (dd < bd || (dd == bd && o[q] < bi)) {
-      second = fminf(second, bd);
-      bd = dd;
-      bi = o[q];
-      bp = c;
-      slot = q + 1;
-    } else {
-      second = fminf(second, dd);
-    }
+    const bool better = have && (dd < bd || (dd == bd && o[q] < bi));
+    second = have ? fminf(second, better ? bd : dd) : second;
+    bd = better ? dd : bd;
+    bi = better ? o[q] : bi;
+    bx = better ? c.x : bx;
+    by = better ? c.y : by;
+    bz = better ? c.z : bz;
+    bw = better ? c.w : bw;
+    slot = better ? q + 1 : slot;
   }
+  const float4 bp = make_float4(bx, by, bz, bw);
   const float E = 1e-6f * g.radius2 + 1e-9f;
   const float s1 = sqrtf(fmaxf(bd - c0s, 0.f) + E);
   if (!(bd <= g.radius2) || !(s1 + 2e-5f < Lrem)) return false;
@@ -575,6 +579,7 @@ __device__ __forceinline__ bool icp_second_level_impl(const IcpProblem& pr, cons
   *auxp = nx;
   m_p = fwd ? p : bp;
   m_q = fwd ? bp : p;
+  winner = bi;
   return true;
 }
 
@@ -614,6 +619,7 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
     bool to_seeded = false, to_coop = false;
     bool heavy = false;  // (SPLIT = false) a failed query without a partner inside the radius to start from
     bool stat_l1 = false, stat_l2 = false;  // (diagnostics)
+    int win2 = -1;  // the cached point the second level chose
     bool m_act = false;  // a settled pair whose moments are due: (moving point, reference point, component)
     float4 m_p = make_float4(0.f, 0.f, 0.f, 0.f), m_q = m_p;
     int m_c = 0;
@@ -675,12 +681,12 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
           m_q = fwd ? sp : p;
           m_c = c_pair;
         }
-      } else if (s >= 0 && icp_second_level_impl(pr, g, fwd, fwd ? qid : qid - Mn, fwd ? nn_f : nn_b, fwd ? bud_f : bud_b, p, s, sp, dist2, c0s, bud, m_p, m_q)) {
+      } else if (s >= 0 && icp_second_level_impl(pr, g, fwd, fwd ? qid : qid - Mn, fwd ? nn_f : nn_b, fwd ? bud_f : bud_b, p, s, sp, dist2, c0s, bud, m_p, m_q, win2)) {
         // the budget has run out, but the nearest of the four cached points, measured where they are now, is still
         // nearer than anything outside the cache can be (icp_second_level wrote neighbour, budget and cache)
         m_act = true;
         stat_l1 = stat_l2 = true;
-        m_c = fwd ? c_pair : pr.comp[nn_b[qid - Mn]];  // (backward: the component of the moving point that won)
+        m_c = fwd ? c_pair : pr.comp[win2];  // (backward: the component of the moving point that won)
       } else if (SPLIT && s >= 0 && g2_seed_admissible(g, fwd ? g_ref : g_mov, p, fwd ? pr.df : -pr.df, dist2, pr.mu)) {
         to_seeded = true;  // (the tile path has ONE kind of search: SPLIT = false)
         stat_l1 = true;
@@ -767,7 +773,21 @@ __device__ __forceinline__ void icp_first_phase(const IcpProblem& pr, int Mn, in
           uint32_t cnt_w = 0, pad_w = 0;
           const int fs = g2_find(gh.fslot, gh.Hf - 1, pack_cell(fc, x, y, z), &cnt_w, &pad_w);
           if (fs < 0 || cnt_w == 0) return;
-          const float4 sp = gh.spts[(size_t)fs * kCellCap];
+          // the cell's point with the smallest original index (the rows of a cell are in arrival order, which varies
+          // from run to run: with row 0 as the seed the budgets and the work lists of a registration were not
+          // reproducible, only its results)
+          const int cnt = min((int)cnt_w, kCellCap);
+          const int4* __restrict__ iv = (const int4*)(gh.sidx + (size_t)fs * kCellCap);
+          int row = 0, best_i = INT_MAX;
+          for (int j = 0; j < cnt; j += 4) {
+            const int4 o = iv[j >> 2];
+            if (o.x >= 0 && o.x < best_i) { best_i = o.x; row = j; }
+            if (j + 1 < cnt && o.y >= 0 && o.y < best_i) { best_i = o.y; row = j + 1; }
+            if (j + 2 < cnt && o.z >= 0 && o.z < best_i) { best_i = o.z; row = j + 2; }
+            if (j + 3 < cnt && o.w >= 0 && o.w < best_i) { best_i = o.w; row = j + 3; }
+          }
+          if (best_i == INT_MAX) return;
+          const float4 sp = gh.spts[(size_t)fs * kCellCap + row];
           const float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
           float dist2 = 0.f;
           dist2 = dist2 + d0 * d0;
@@ -776,7 +796,7 @@ __device__ __forceinline__ void icp_first_phase(const IcpProblem& pr, int Mn, in
           dist2 = dist2 + d3 * d3;
           if (dist2 < seed_d2) {
             seed_d2 = dist2;
-            seed = gh.sidx[(size_t)fs * kCellCap];
+            seed = best_i;
           }
         };
         probe(cx, cy, cz);
@@ -2730,6 +2750,15 @@ int pcs_icp_cache_stats(unsigned long long* host_out) {
   for (int i = 0; i < 4; ++i) host_out[i] = v[i];
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PCS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)));
+  return PCS_OK;
+}
+
+// pcs_icp_set_cache_levels: 2 (default) = the verified cache with its second level (the cached points re-ranked when
+// a budget has run out), 1 = budgets only: every query whose budget has run out is searched (the form of rounds 1-4;
+// the cross-check of tests/test_gpu_graph_icp.py: same results bit for bit)
+int pcs_icp_set_cache_levels(int levels) {
+  if (levels != 1 && levels != 2) return PCS_ERR_ARG;
+  g_cache_levels.store(levels, std::memory_order_relaxed);
   return PCS_OK;
 }
 

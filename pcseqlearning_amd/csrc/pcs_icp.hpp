@@ -133,6 +133,7 @@ struct IcpProblem {
   int want;             // outputs the caller will read: bit 0 the l1 error, bit 1 the coverage ratio (the others are written as 0)
 };
 constexpr int kIcpWantL1 = 1, kIcpWantRatio = 2;
+constexpr int kIcpNoSecondLevel = 8;  // (same word) budgets only: pcs_icp_set_cache_levels(1)
 constexpr int kIcpRebuildAlways = 4;  // (same word) the moving grid is rebuilt at every iteration: pcs_icp_set_grid_mode
 
 __device__ __forceinline__ void icp_sizes(const IcpProblem& pr, int& Mn, int& Rn, int& Ra) {

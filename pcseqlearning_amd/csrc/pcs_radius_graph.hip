@@ -139,6 +139,101 @@ nn1_search_kernel(const float4* __restrict__ qry, int M, const GridDesc* __restr
   }
 }
 
+// ---- round 5: most queries of the tracker's extraction graph (every full-resolution point of a unit's frames
+// against the unit's tracked voxels, cluster_tracking.py:356-358 of the reference) have NOTHING within the radius,
+// and the cooperative search spends 32 lanes and 27 mask probes on each to find that out. A query can only have a
+// neighbour if one of the 3 x 3 x 3 coarse blocks around it is occupied; those 27 blocks lie in 2 x 2 x 2 SUPER
+// blocks (two coarse blocks per axis), so one thread decides with eight probes of a set of occupied super blocks.
+// Exact: a survivor list that is a superset of the queries with a neighbour; the others get degree 0 here.
+__global__ void __launch_bounds__(kBlock)
+nn1_super_insert_kernel(const float4* __restrict__ ref, int N, const GridDesc* __restrict__ gp,
+                        uint64_t* __restrict__ skeys, uint32_t smask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const GridDesc d = *gp;
+  const float4 p = ref[i];
+  const int fc = frame_cell(d, p.x);
+  const int x = (int)floorf((p.y - d.lo[0]) / d.h), y = (int)floorf((p.z - d.lo[1]) / d.h),
+            z = (int)floorf((p.w - d.lo[2]) / d.h);
+  if (x < 0 || y < 0 || z < 0 || x >= kCoordMax || y >= kCoordMax || z >= kCoordMax || fc < 0 || fc >= kFrameCells)
+    return;  // (g2_insert_kernel raises the call's error word for such a point)
+  const uint64_t key = pack_cell(fc, x >> 3, y >> 3, z >> 3);
+  uint32_t s = mix64(key) & smask;
+  for (uint32_t t = 0; t <= smask; ++t) {
+    const uint64_t prev = atomicCAS((unsigned long long*)&skeys[s], (unsigned long long)kEmpty, (unsigned long long)key);
+    if (prev == kEmpty || prev == key) return;
+    s = (s + 1) & smask;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+nn1_filter_kernel(const float4* __restrict__ qry, int M, const GridDesc* __restrict__ gp,
+                  const uint64_t* __restrict__ skeys, uint32_t smask, int df, int32_t* __restrict__ list,
+                  int32_t* __restrict__ cnt, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d,
+                  int32_t* __restrict__ deg) {
+  const GridDesc d = *gp;
+  const int lane = threadIdx.x & 63;
+  const int nround = (M + kBlock - 1) / kBlock;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballot)
+    const int q = r * kBlock + threadIdx.x;
+    bool keep = false;
+    if (q < M) {
+      const float4 p = qry[q];
+      const int fc = frame_cell(d, p.x) + df;
+      const int bx = (int)floorf((p.y - d.lo[0]) / d.h) >> 2, by = (int)floorf((p.z - d.lo[1]) / d.h) >> 2,
+                bz = (int)floorf((p.w - d.lo[2]) / d.h) >> 2;
+      if (fc >= 0 && fc < kFrameCells) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int sx = ((bx - 1) >> 1) + (c & 1), sy = ((by - 1) >> 1) + ((c >> 1) & 1), sz = ((bz - 1) >> 1) + (c >> 2);
+          if (sx < 0 || sy < 0 || sz < 0) continue;
+          const uint64_t key = pack_cell(fc, sx, sy, sz);
+          uint32_t s = mix64(key) & smask;
+          for (uint32_t t = 0; t <= smask; ++t) {
+            const uint64_t k = skeys[s];
+            if (k == key) { keep = true; break; }
+            if (k == kEmpty) break;
+            s = (s + 1) & smask;
+          }
+        }
+      }
+      if (!keep) {
+        deg[q] = 0;
+        nbr_idx[q] = -1;
+        nbr_d[q] = d.radius2;
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(cnt, __popcll(m));
+      base = __shfl(base, 0, 64);
+      if (keep) list[base + __popcll(m & ((1ULL << lane) - 1ULL))] = q;
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+nn1_search_list_kernel(const float4* __restrict__ qry, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                       const GridDesc* __restrict__ gp, Grid2 g, int df, int32_t* __restrict__ err,
+                       int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d, int32_t* __restrict__ deg) {
+  const GridDesc d = *gp;
+  const int n = *cnt;
+  const int per = kBlock / 32;
+  const int nround = (n + per - 1) / per;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles)
+    const int w = r * per + (threadIdx.x >> 5);
+    const bool valid = w < n;
+    const int qid = valid ? list[w] : 0;
+    const float4 p = valid ? qry[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float bd = 0.f;
+    const int res = g2_nearest_coop(d, g, p, df, valid, err, &bd);
+    if (valid && (threadIdx.x & 31) == 0) {
+      deg[qid] = res >= 0;
+      nbr_idx[qid] = res;
+      nbr_d[qid] = bd;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 edge_total_kernel(const int32_t* __restrict__ deg, const int32_t* __restrict__ off, int M,
                   const int32_t* __restrict__ err, int64_t* __restrict__ d_num) {
@@ -179,6 +274,9 @@ struct RadiusPlan {
   size_t tmp_bytes;
   uint32_t H;
   KnnPlan knn;       // max_nbr > 1: the cell-sorted search (pcs_knn.hip)
+  uint64_t* skeys;   // max_nbr == 1: occupied super blocks (nn1_filter_kernel), [Hs]
+  uint32_t Hs;
+  int32_t* nn1_list; // [M] queries that may have a neighbour
 };
 
 static inline uint32_t pow2_ge(uint64_t x) {
@@ -208,6 +306,9 @@ static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
   if (K == 1) {
     plan_grid2(a, N, p.g2);
     p.g2_words = a.take<int32_t>(2);
+    p.Hs = pow2_ge(2 * (uint64_t)N);
+    p.skeys = a.take<uint64_t>(p.Hs);
+    p.nn1_list = a.take<int32_t>(M);
   } else {
     plan_knn(a, N, M, p.knn);
   }
@@ -441,8 +542,18 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
     g2_clear_kernel<<<grid_for((int64_t)p.g2.slot_words), kBlock, 0, s>>>(p.g2);
     int nb = (int)((N + kBlock - 1) / kBlock);
     g2_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, nullptr, p.err);
-    nn1_search_kernel<<<(int)((M * 32 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
-        (const float4*)query, (int)M, p.grid, p.g2, dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg);
+    // queries with an empty neighbourhood leave after eight probes of one thread; the rest is searched
+    PCS_CHECK_HIP(hipMemsetAsync(p.skeys, 0xFF, (size_t)p.Hs * sizeof(uint64_t), s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.g2_words, 0, 2 * sizeof(int32_t), s));
+    nn1_super_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.skeys, p.Hs - 1);
+    nn1_filter_kernel<<<grid_for(M), kBlock, 0, s>>>((const float4*)query, (int)M, p.grid, p.skeys, p.Hs - 1, dframe_min,
+                                                    p.nn1_list, p.g2_words, p.nbr_idx, p.nbr_d, p.deg);
+    {
+      int64_t blocks = (M * 32 + kBlock - 1) / kBlock;
+      if (blocks > 4096) blocks = 4096;
+      nn1_search_list_kernel<<<(int)blocks, kBlock, 0, s>>>((const float4*)query, p.nn1_list, p.g2_words, p.grid, p.g2,
+                                                            dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg);
+    }
     rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
     if (rc) return rc;
     edge_total_kernel<<<1, 64, 0, s>>>(p.deg, p.off, (int)M, p.err, d_num_edges);

@@ -440,3 +440,38 @@ def test_icp_component_beyond_fixed_point_range_is_refused():
     T, _, _, iters = ops.register_to_next_frame(dev(mov), dev(comp), dev(ref), dev(ref),
                                                 dev(np.array([n // 2, n // 2], np.int64)), 2, 1.25, 1, 10.0, 20, 0.05)
     assert iters >= 1 and np.isfinite(T.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("seed", [4, 9, 13, 15, 28])
+def test_icp_second_level_of_the_cache_is_exact(seed):
+    """Round 5: a query whose budget has run out re-ranks its four cached points instead of searching. The same
+    registration with the second level switched off (every such query searched: the form of rounds 1-4) must give the
+    same transforms, errors, moved points and iteration counts BIT FOR BIT -- on crowded clouds, where partners of
+    neighbouring objects compete and the second level changes partners (five seeds that told a wrong pair apart)."""
+    import ctypes
+    from pcseqlearning_amd import lib as L
+    from tests.golden.make_golden_reg import make_pair
+    lib = L.load()
+    rng = np.random.default_rng(seed)
+    n_obj = int(rng.integers(20, 400))
+    ppo = int(rng.integers(3, 120))
+    radius = [2.5, 1.25, 1.0][seed % 3]
+    moving, refd = make_pair(rng, n_obj=n_obj, pts_per_obj=ppo, shift=float(rng.uniform(0.05, 0.6)), rot=0.05)
+    scale = 0.25 if seed % 2 else 0.5
+    for d in (moving, refd):
+        d["fxyz"][:, 1:3] *= scale
+    nsm, nsr = ~moving["stationary"], ~refd["stationary"]
+    got = {}
+    try:
+        for levels in (2, 1):
+            L.check(lib.pcs_icp_set_cache_levels(ctypes.c_int(levels)), "pcs_icp_set_cache_levels")
+            mov = dev(moving["fxyz"][nsm].copy())
+            T, l1, ratio, iters = ops.register_to_next_frame(
+                mov, dev(moving["component"][nsm]), dev(refd["fxyz"][nsr]), dev(refd["fxyz"]),
+                dev(np.bincount(moving["component"], minlength=n_obj)), n_obj, radius, 1, 10.0, 80, 0.05)
+            got[levels] = (T.cpu().numpy(), l1.cpu().numpy(), ratio.cpu().numpy(), iters, mov.cpu().numpy())
+    finally:
+        lib.pcs_icp_set_cache_levels(ctypes.c_int(2))
+    assert got[2][3] == got[1][3] and got[2][3] >= 5
+    for a, b in zip(got[2], got[1]):
+        np.testing.assert_array_equal(a, b)
