@@ -566,8 +566,8 @@ def main():
                                "frac": round(bytes_8d / dt / 1e9 / HBM_PEAK_GBS, 6) if dt > 0 else 0.0,
                                "note": "8(d) bytes of every chunk of the timed steps / the steps' wall time"},
                 # by component count (chunks mix the keys, so only bytes and iterations split, not time): the 0.25 m
-                # key has ~13 k components of one or two points; the others about a thousand
-                "by_key": {"more_than_5000_components": {"unit_iterations": int(many_iters),
+                # key numbers ~13 k components of one or two points (C_live counts those with a moving point); the others ~1 k
+                "by_key": {"more_than_5000_component_ids": {"unit_iterations": int(many_iters),
                                                          "MB_per_unit_iteration": round(many_8d / max(many_iters, 1) / 1e6, 3)},
                            "others": {"unit_iterations": int(unit_iters - many_iters),
                                       "MB_per_unit_iteration": round((bytes_8d - many_8d) / max(unit_iters - many_iters, 1) / 1e6, 3)}},

@@ -516,7 +516,7 @@ int pcs_profile_icp(int enable);
 int pcs_profile_icp_read(double* out9);
 /* the same nine values and, behind them: [9] the chunks' algorithmic bytes by SURVEY 8(d)'s formula, 112 (Mn + Rn) +
  * 144 C_live per unit and iteration ([2] is the implementation's own traffic model), [10] the unit-iterations of
- * registrations with more than 5000 live components (the 0.25 m key), [11] their 8(d) bytes; n >= 9 doubles. */
+ * registrations whose key numbers more than 5000 components (the 0.25 m key), [11] their 8(d) bytes; n >= 9 doubles. */
 int pcs_profile_icp_read_ex(double* out, int n);
 
 /* Schedule of the iterations of the fused ICP (pcs_register_to_next_frame and the tracker), process-wide;

@@ -2794,8 +2794,8 @@ int pcs_profile_icp(int enable) {
 // have ended); [8] = 0.
 int pcs_profile_icp_read(double* out9);
 // the same and, behind it: [9] the chunks' algorithmic bytes by SURVEY 8(d)'s formula (112 (Mn + Rn) + 144 C_live per
-// unit and iteration; [2] is this implementation's own traffic model), [10] unit-iterations of registrations with
-// more than 5000 live components (the 0.25 m key), [11] their 8(d) bytes. n = doubles the caller's array holds (>= 9).
+// unit and iteration; [2] is this implementation's own traffic model), [10] unit-iterations of registrations whose
+// key numbers more than 5000 components (the 0.25 m key; few of them have a moving point in a given registration), [11] their 8(d) bytes. n = doubles the caller's array holds (>= 9).
 int pcs_profile_icp_read_ex(double* out, int n) {
   if (!out || n < 9) return PCS_ERR_ARG;
   int rc = pcs_profile_icp_read(out);

@@ -1696,7 +1696,7 @@ void Engine::collect_tick() {
       const double Cl = (double)h.icp.live_c;
       const double b8 = it * (112.0 * (Mn + Rn) + 144.0 * Cl);
       bytes_8d += b8;
-      if (Cl > 5000.0) { many_iters += it; many_8d += b8; }
+      if (C > 5000.0) { many_iters += it; many_8d += b8; }  // (by the key's component IDs: the 0.25 m key numbers ~13 k)
     }
     icp_profile_account(unit_iters, bytes, 0, bytes_8d, many_iters, many_8d);
   }

@@ -224,7 +224,12 @@ def test_config0_plumbing_frame():
     # to millimetres: the canonical order changes roundings, not the algorithm
     n_h = GO.ground_plane_removal(fxyz, GROUND_CFG, normal_sign="up")[0]
     c = ground_agreement(h, dict(point_height=n_h))
-    assert c["differ"] <= 50 and c["mean"] < 4e-3 and c["max"] < 0.1, c
+    # measured: 21 of 50 000 points on the other side of the 0.5 m cut, mean |dh| 2.3 mm (the same 21 with round 4's
+    # summation order of the plane fits: without the L1 smoothing the two forms differ on NO point, mean 4e-5 m --
+    # 15 of 5037 pillars take another hypothesis -- and the smoothing's ~2000 AdamW steps, whose stop rule compares
+    # losses to 1e-4, spread those over their neighbourhoods). Round 4's bound was 50.
+    print("configs[0] HIP vs numpy oracle:", c)
+    assert c["differ"] <= 25 and c["mean"] < 3e-3 and c["max"] < 0.06, c
 
 
 def test_prune_plane_hypotheses_kernel_vs_host_loop():
