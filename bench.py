@@ -302,6 +302,9 @@ def main():
     ap.add_argument("--pre-streams", type=int, default=0,
                     help="create this many HIP streams before the library creates any (robustness check: the engines' "
                          "hardware queues must not depend on what the embedding application created first)")
+    ap.add_argument("--pre-slots", type=int, default=-1,
+                    help="SimpleReg's PRE_TRACKING_CONCURRENCY: sequences of a batch in ground removal / proposal at once "
+                         "(0 = no limit, the default; measured in round 5: 2 / 3 / 4 / 6 slots are 1-4 % slower)")
     ap.add_argument("--icp-widening", type=float, default=0.0,
                     help="pcs_icp_set_widening: searches look radius / this further (0 = the library's default, 16)")
     ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
@@ -383,6 +386,8 @@ def main():
         model.model_cfg["WORKER_STREAMS"] = args.worker_streams
     if args.stagger_ms >= 0:
         model.model_cfg["SEQUENCE_START_STAGGER_MS"] = args.stagger_ms
+    if args.pre_slots >= 0:
+        model.model_cfg["PRE_TRACKING_CONCURRENCY"] = args.pre_slots
     lib = L.load()
 
     def step():

@@ -65,8 +65,18 @@ class SimpleReg(RegistrationTemplate):
         if self.subsample:
             self.grid_sampler = GridSampling3D(grid_size=[0.08, 0.08, 0.08])
 
-    def process_sequence(self, seq_dict, preprocessors=None):
-        for module in (self.preprocessors or []) if preprocessors is None else preprocessors:
+    def process_sequence(self, seq_dict, preprocessors=None, gate=None):
+        """`gate` (a semaphore, _process_batch_concurrently): at most that many sequences of a batch are in the stages
+        BEFORE tracking at once. Twelve sequences that all start with ground removal and the proposal graphs share
+        the chip twelve ways and reach the tracker's engines together and late; a few at a time reach them one after
+        the other, early, and the engines -- whose ticks are what a batch takes -- start while the rest queue."""
+        mods = list((self.preprocessors or []) if preprocessors is None else preprocessors)
+        n_pre = len(mods) - 1 if gate is not None else 0  # (the last module is the tracker)
+        if n_pre > 0:
+            with gate:
+                for module in mods[:n_pre]:
+                    seq_dict = module(seq_dict)
+        for module in mods[n_pre:]:
             seq_dict = module(seq_dict)
         return run_deferred(seq_dict)
 
@@ -98,6 +108,9 @@ class SimpleReg(RegistrationTemplate):
         # flight and leaves the twelfth worker idle for 275 ms)
         stagger = float(self.model_cfg.get("SEQUENCE_START_STAGGER_MS", 5)) * 1e-3
         shared = str(self.model_cfg.get("WORKER_STREAMS", "own")) == "caller"
+        # PRE_TRACKING_CONCURRENCY: sequences allowed in ground removal / proposal at once (0: no limit)
+        slots = int(self.model_cfg.get("PRE_TRACKING_CONCURRENCY", 0))
+        gate = threading.BoundedSemaphore(slots) if 0 < slots < inflight else None
 
         def worker(i=0):
             if stagger > 0 and i > 0:
@@ -118,7 +131,7 @@ class SimpleReg(RegistrationTemplate):
                         with lock:
                             if errors:
                                 break
-                        out = self.process_sequence(self.build_sequence(batch_dict, b), mods)
+                        out = self.process_sequence(self.build_sequence(batch_dict, b), mods, gate)
                         _record_stream(out, main)  # the caller's stream consumes what this stream allocated
                         results[b] = out
                     stream.synchronize()
