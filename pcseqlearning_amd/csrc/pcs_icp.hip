@@ -379,7 +379,7 @@ __device__ __forceinline__ void icp_decide(const IcpProblem& pr, int k_done) {
 // (64-bit integer LDS adds; neighbouring queries mostly share a component), then flushes one global
 // integer atomic per (component, accumulator). Integer sums: the result does not depend on any
 // arrival order.
-constexpr int kMomSlots = 64;        // wide budget-test workgroups (256 threads, a few rounds of queries)
+constexpr int kMomSlots = 128;        // wide budget-test workgroups (256 threads, a few rounds of queries)
 constexpr int kMomSlotsSearch = 16;  // a wide search item settles 8 or 32 pairs: a small table keeps its reset and drain short
 constexpr int kMomSlotsLoop = 512;   // the unit-resident loop: one table for ALL pairs of an iteration
 constexpr int kHeavyBit = 1 << 30;   // tile path: flag of a work-list entry (query ids stay below 2^26)
