@@ -56,6 +56,21 @@ int pcs_cpu_register_to_next_frame(float* mov_fxyz, const int32_t* mov_comp, int
                                    float* edge_ratio, int32_t* info, void* ws, size_t ws_bytes,
                                    pcs_stream_t stream);
 
+/* the ground stage's entries (round 5): oracle/pcs_oracle_ground.cpp, the canonical restatement -- the operations of
+ * the HIP kernels in their order, so the twins return the entries' own bits; ws may be NULL */
+int pcs_cpu_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n,
+                                    const float* min_z, const float* max_z, const float* ratios, int R,
+                                    const float* origin, int64_t P, float sigma2, float stopping_delta,
+                                    int max_rounds, float hit_below, float* best_center,
+                                    float* best_normal, float* best_conf, void* ws, size_t ws_bytes,
+                                    pcs_stream_t stream);
+int pcs_cpu_prune_plane_hypotheses(const float* xyz, const float* normal, int64_t H, int K,
+                                   const float* thresholds, int T, uint8_t* keep, pcs_stream_t stream);
+int pcs_cpu_l1_minimization(const float* pillar_min_z, const float* weight, int X, int Y, double lr,
+                            const int* decay_steps, int n_decay, float rigid_weight, int max_iters,
+                            float* height_out, int32_t* d_iters, void* ws, size_t ws_bytes,
+                            pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,14 @@ void orc_indice_conv_f32(const float* feat, int64_t num_in, int cin, const float
                          int inverse, int subm, float* out);
 int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n, int64_t* component);
 void orc_points_in_boxes(const float* pts, int64_t N, const float* boxes, int B, int32_t* out);
+void orc_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n, const float* min_z,
+                                 const float* max_z, const float* ratios, int R, const float* origin, int64_t P,
+                                 float sigma2, float delta, int max_rounds, float hit_below, float* best_center,
+                                 float* best_normal, float* best_conf);
+void orc_prune_plane_hypotheses(const float* xyz, const float* normal, int H, int K, const float* thr, int T,
+                                uint8_t* keep);
+int orc_l1_minimization(const float* min_z, const float* weight, int X, int Y, double lr0, const int* decay_steps,
+                        int n_decay, float rigid, int max_iters, float* h_out);
 
 #define CPU_OK 0
 #define CPU_ERR_ARG (-1)
@@ -123,6 +131,41 @@ int pcs_cpu_points_in_boxes(const float* points, int64_t N, const float* boxes, 
   if (!points || !boxes || !out || N < 0 || B < 0) return CPU_ERR_ARG;
   orc_points_in_boxes(points, N, boxes, B, out);
   return CPU_OK;
+}
+
+// ---- ground stage (round 5): the canonical restatement of oracle/pcs_oracle_ground.cpp behind the entries' own
+// argument lists (workspaces are not needed on the host: may be NULL)
+int pcs_cpu_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n, const float* min_z,
+                                    const float* max_z, const float* ratios, int R, const float* origin, int64_t P,
+                                    float sigma2, float stopping_delta, int max_rounds, float hit_below,
+                                    float* best_center, float* best_normal, float* best_conf, void*, size_t,
+                                    pcs_stream_t) {
+  if (!xyz || !seg_start || !min_z || !max_z || !ratios || !origin || !best_center || !best_normal || !best_conf ||
+      n < 1 || P < 1 || R < 1 || R > 64 || max_rounds < 1)
+    return PCS_ERR_ARG;
+  orc_ransac_plane_hypotheses(xyz, seg_start, n, min_z, max_z, ratios, R, origin, P, sigma2, stopping_delta, max_rounds,
+                              hit_below, best_center, best_normal, best_conf);
+  return PCS_OK;
+}
+
+int pcs_cpu_prune_plane_hypotheses(const float* xyz, const float* normal, int64_t H, int K, const float* thresholds,
+                                   int T, uint8_t* keep, pcs_stream_t) {
+  if (H < 0 || K < 1 || K > 8 || T < 0 || T > 128 || (H > 0 && (!xyz || !normal || !keep)) || (T > 0 && !thresholds))
+    return PCS_ERR_ARG;
+  if (H > 2048) return PCS_ERR_RANGE;
+  if (H > 0) orc_prune_plane_hypotheses(xyz, normal, (int)H, K, thresholds, T, keep);
+  return PCS_OK;
+}
+
+int pcs_cpu_l1_minimization(const float* pillar_min_z, const float* weight, int X, int Y, double lr,
+                            const int* decay_steps, int n_decay, float rigid_weight, int max_iters, float* height_out,
+                            int32_t* d_iters, void*, size_t, pcs_stream_t) {
+  if (!pillar_min_z || !weight || !height_out || X < 3 || Y < 3 || n_decay < 0 || (n_decay > 0 && !decay_steps))
+    return PCS_ERR_ARG;
+  const int it = orc_l1_minimization(pillar_min_z, weight, X, Y, lr, decay_steps, n_decay, rigid_weight, max_iters,
+                                     height_out);
+  if (d_iters) *d_iters = it;
+  return PCS_OK;
 }
 
 }  // extern "C"

@@ -4,3 +4,4 @@ order, on the reference's own table layout."""
 from ....ops import correspondence, hash_insert_gpu, points_in_radius_gpu, radius_graph_gpu  # noqa: F401
 
 torch_hash_cuda = __import__(__name__, fromlist=["hash_insert_gpu"])
+from .torch_hash_modules import ChamferDistance, RadiusGraph  # noqa: F401,E402

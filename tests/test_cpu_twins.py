@@ -104,3 +104,54 @@ def test_twins_give_the_oracle_results():
     assert int(info[0]) == w_it
     np.testing.assert_array_equal(T.reshape(C, 4, 4), w_T)
     np.testing.assert_array_equal(ratio, w_ratio)
+
+
+def test_ground_stage_twins():
+    """The three ground-stage twins (round 5) behind their entries' argument lists: the plane hypotheses of a few
+    synthetic pillars (a tilted plane + clutter: the fitted normal is the plane's), the pruning loop (an outlier
+    hypothesis goes, the coplanar ones stay) and the L1 smoothing (a flat field stays flat, a spike is pulled in)."""
+    main, _ = _libs()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(8)
+    P, per = 6, 300
+    xyz, seg = [], [0]
+    for c in range(P):
+        xy = rng.uniform(0, 8, (per, 2)) + np.array([8.0 * c, 0.0])
+        z = 0.05 * xy[:, 0] - 0.02 * xy[:, 1] + rng.normal(0, 0.005, per)
+        z[: per // 10] += rng.uniform(0.5, 2.0, per // 10)  # clutter above the plane
+        xyz.append(np.concatenate([xy, z[:, None]], 1))
+        seg.append(seg[-1] + per)
+    xyz = np.ascontiguousarray(np.concatenate(xyz), np.float32)
+    seg = np.asarray(seg, np.int32)
+    zmin = np.array([xyz[seg[c]:seg[c + 1], 2].min() for c in range(P)], np.float32)
+    zmax = np.array([xyz[seg[c]:seg[c + 1], 2].max() for c in range(P)], np.float32)
+    origin = np.ascontiguousarray(np.stack([xyz[seg[c]:seg[c + 1]].mean(0) for c in range(P)]), np.float32)
+    ratios = np.linspace(0.3, 1, 30).astype(np.float32)
+    bc, bn, conf = np.zeros((P, 3), np.float32), np.zeros((P, 3), np.float32), np.zeros(P, np.float32)
+    rc = main.pcs_cpu_ransac_plane_hypotheses(p(xyz), p(seg), ctypes.c_int64(len(xyz)), p(zmin), p(zmax), p(ratios),
+                                              ctypes.c_int(30), p(origin), ctypes.c_int64(P), ctypes.c_float(0.0025),
+                                              ctypes.c_float(1e-2), ctypes.c_int(50), ctypes.c_float(0.05), p(bc), p(bn),
+                                              p(conf), None, ctypes.c_size_t(0), None)
+    assert rc == 0
+    want = np.array([-0.05, 0.02, 1.0]) / np.linalg.norm([-0.05, 0.02, 1.0])
+    assert np.abs(bn - want).max() < 5e-3 and (conf > 0.8 * per).all()
+    # pruning: hypothesis 2 gets a wild normal
+    bn2 = bn.copy()
+    bn2[2] = [0.6, 0.0, 0.8]
+    keep = np.zeros(P, np.uint8)
+    thr = np.logspace(np.log10(5), np.log10(0.01), 100).astype(np.float32)
+    assert main.pcs_cpu_prune_plane_hypotheses(p(bc), p(bn2), ctypes.c_int64(P), ctypes.c_int(8), p(thr), ctypes.c_int(100),
+                                               p(keep), None) == 0
+    assert keep[2] == 0 and keep.sum() >= P - 2
+    # smoothing
+    X, Y = 12, 10
+    mz = np.full((X, Y), 0.3, np.float32)
+    mz[5, 5] = 2.0
+    w = np.ones((X, Y), np.float32)
+    h = np.zeros((X, Y), np.float32)
+    iters = np.zeros(1, np.int32)
+    dec = np.array([1600], np.int32)
+    assert main.pcs_cpu_l1_minimization(p(mz), p(w), ctypes.c_int(X), ctypes.c_int(Y), ctypes.c_double(0.01), p(dec),
+                                        ctypes.c_int(1), ctypes.c_float(0.5), ctypes.c_int(10000), p(h), p(iters), None,
+                                        ctypes.c_size_t(0), None) == 0
+    assert 10 < iters[0] <= 10000 and abs(float(np.median(h)) - 0.3) < 0.05 and h[5, 5] < 1.0

@@ -475,3 +475,34 @@ def test_icp_second_level_of_the_cache_is_exact(seed):
     assert got[2][3] == got[1][3] and got[2][3] >= 5
     for a, b in zip(got[2], got[1]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_torch_hash_module_fronts(oracle):
+    """pcdet.ops.torch_hash.RadiusGraph / ChamferDistance (torch_hash_modules.py:10-129 of the reference): the module
+    fronts on the drop-in table ops -- the reference's own hand case (:146-151), its edges against the oracle, and the
+    Chamfer distance against brute force."""
+    from pcseqlearning_amd.pcdet.ops.torch_hash import ChamferDistance, RadiusGraph
+    rg = RadiusGraph(ndim=3).to(DEV)
+    pts = dev(np.array([[0, 0, 0, 0], [0, .1, .1, 0], [0, .2, .2, 0]], np.float32))
+    e = rg(pts, pts, 0.15, 1, sort_by_dist=True)
+    assert e.tolist() == [[0, 1, 2], [0, 1, 2]]
+    rng = np.random.default_rng(31)
+    ref, qry = cloud(rng, 3000, 2, 5.0), cloud(rng, 1200, 2, 5.0)
+    for k, sort in ((16, True), (1, True), (4, False)):
+        e = rg(dev(ref), dev(qry), 0.9, k, sort_by_dist=sort)
+        o_ref, o_q = oracle.radius_graph(ref, qry, 0.9, k, sort)
+        np.testing.assert_array_equal(e[0].cpu().numpy(), o_ref)
+        np.testing.assert_array_equal(e[1].cpu().numpy(), o_q)
+    # per-query radii: a query with radius 0.3 keeps the neighbours within 0.3
+    rad = torch.full((qry.shape[0],), 0.9, device=DEV)
+    rad[::2] = 0.3
+    e = rg(dev(ref), dev(qry), rad, 32, sort_by_dist=True)
+    d = (dev(ref)[e[0]] - dev(qry)[e[1]]).square().sum(-1).sqrt()
+    assert bool((d <= rad[e[1]] + 1e-6).all()) and e.shape[1] > 0
+    cd = ChamferDistance(ndim=3).to(DEV)
+    a, b = dev(ref[ref[:, 0] == 0]), dev(qry[qry[:, 0] == 0])
+    got = float(cd(a, b, 2.0))
+    dm = torch.cdist(a[:, 1:].double(), b[:, 1:].double())
+    f, g = dm.min(1).values, dm.min(0).values
+    want = float((f[f <= 2.0] ** 2).mean() + (g[g <= 2.0] ** 2).mean())
+    assert abs(got - want) < 1e-5 * max(want, 1.0), (got, want)
