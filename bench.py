@@ -307,6 +307,8 @@ def main():
                          "(0 = no limit, the default; measured in round 5: 2 / 3 / 4 / 6 slots are 1-4 % slower)")
     ap.add_argument("--icp-widening", type=float, default=0.0,
                     help="pcs_icp_set_widening: searches look radius / this further (0 = the library's default, 16)")
+    ap.add_argument("--chunk-iterations", type=int, default=0,
+                    help="pcs_icp_set_chunk_iterations: iterations per chunk of wide launches (0 = the library's default, 8)")
     ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the extra device-synchronised step")
@@ -371,6 +373,8 @@ def main():
     # streams an embedding application might have created before the library sees the device
     pre_streams = [torch.cuda.Stream(device) for _ in range(args.pre_streams)]
     ops.track_configure(args.engines, args.chunk_us)
+    if args.chunk_iterations > 0:
+        L.check(L.load().pcs_icp_set_chunk_iterations(ctypes.c_int(args.chunk_iterations)), "pcs_icp_set_chunk_iterations")
     if args.icp_widening > 0:
         L.check(L.load().pcs_icp_set_widening(ctypes.c_double(args.icp_widening)), "pcs_icp_set_widening")
     ops.icp_set_schedule(*{"wide": (-1, True), "resident_tiles": (1, True), "resident_cache": (1, False)}[args.schedule])

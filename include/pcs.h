@@ -538,13 +538,18 @@ int pcs_icp_set_grid_mode(int rebuild_always);
 /* every search of the fused ICP looks radius / radius_divisor further than it must, so that it can say how long its
  * answer stays exact (default 16; any value >= 1 gives the same results: it trades cells per search against searches). */
 int pcs_icp_set_widening(double radius_divisor);
+/* iterations per chunk of the wide schedule's launches (default 8, 1..64): the lock-step engines read their units'
+ * states once per chunk. A scheduling parameter: results do not depend on it. */
+int pcs_icp_set_chunk_iterations(int n);
 /* the verified cache of the fused ICP: 2 (default) = budgets and the second level (a query whose budget has run out
  * re-ranks its four cached points before it is searched), 1 = budgets only, the form of rounds 1-4 -- the same results
  * bit for bit (cross-check of the tests). Takes effect for registrations described afterwards. */
 int pcs_icp_set_cache_levels(int levels);
 /* diagnostics: counters of the fused ICP's verified cache since the last call (all zero unless the library was built
- * with -DPCS_ICP_STATS): host_out[4] = queries tested, budgets that had run out, of those kept by the second level
- * (the four cached points re-ranked), queries handed to a search. Synchronises the device. */
+ * with -DPCS_ICP_STATS): host_out[16] = queries tested, budgets that had run out, of those kept by the second level
+ * (the four cached points re-ranked), queries handed to a search; then the same four counts of the backward queries
+ * (reference -> moving cloud) alone; [8], [9] = queries served by the cooperative / the eight-lane seeded search.
+ * Synchronises the device. */
 int pcs_icp_cache_stats(unsigned long long* host_out);
 
 /* iterative_reweighted_ransac, pcdet/models/registration/preprocessors/preprocessor_utils.py:32-80

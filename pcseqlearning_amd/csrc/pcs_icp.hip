@@ -517,7 +517,7 @@ __device__ __forceinline__ void mom_flush(const MomTable& t) {  // after a barri
 
 // diagnostics (built with -DPCS_ICP_STATS only): [0] queries tested, [1] budgets that had run out, [2] of those kept
 // by the second level, [3] queries handed to a search
-__device__ unsigned long long g_icp_stats[8];
+__device__ unsigned long long g_icp_stats[16];
 
 // ---- second level of the verified cache (NnAux, pcs_grid2.hpp): query `qid` (forward: moving point qid against the
 // reference cloud; backward: reference point qid - Mn against the moving cloud) whose budget `bud` (already less
@@ -706,11 +706,16 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
     {
       const unsigned long long mv = __ballot(valid), ms_ = __ballot(to_seeded || to_coop), m2 = __ballot(stat_l2),
                                m1 = __ballot(stat_l1);
+      const unsigned long long mb = ~__ballot(fwd);  // (the same four of the backward queries alone)
       if (lane == 0) {
         atomicAdd(&g_icp_stats[0], (unsigned long long)__popcll(mv));
         atomicAdd(&g_icp_stats[1], (unsigned long long)__popcll(m1));
         atomicAdd(&g_icp_stats[2], (unsigned long long)__popcll(m2));
         atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(ms_));
+        atomicAdd(&g_icp_stats[4], (unsigned long long)__popcll(mv & mb));
+        atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(m1 & mb));
+        atomicAdd(&g_icp_stats[6], (unsigned long long)__popcll(m2 & mb));
+        atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(ms_ & mb));
       }
     }
 #endif
@@ -886,6 +891,15 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
     float bud = 0.f;
     NnAux ax;
     const int res = g2_nearest_coop<true>(g, gs, p, df, valid, &st->err, nullptr, pr.mu, &bud, seed_d2, &ax);
+#ifdef PCS_ICP_STATS
+    if (valid && sub == 0) {
+      atomicAdd(&g_icp_stats[8], 1ULL);
+      if (k > 1) atomicAdd(&g_icp_stats[seed_d2 < __builtin_inff() ? 11 : 10], 1ULL);
+      if (k > 1 && res < 0) atomicAdd(&g_icp_stats[12], 1ULL);
+      if (k == 1) atomicAdd(&g_icp_stats[13], 1ULL);
+      if (k == 1 && res < 0) atomicAdd(&g_icp_stats[14], 1ULL);
+    }
+#endif
     if (valid && sub == 0) {
       nn_o[qi] = res;
       bud_o[qi] = bud;
@@ -913,6 +927,9 @@ __device__ __forceinline__ void icp_search_item(const IcpProblem& pr, IcpState* 
     float bud = 0.f;
     NnAux ax;
     const bool ok = g2_nearest_seeded8(g, gs, p, df, sp, sd, valid, pr.mu, &res, &bud, &ax);
+#ifdef PCS_ICP_STATS
+    if (valid && (threadIdx.x & 7) == 0) atomicAdd(&g_icp_stats[9], 1ULL);
+#endif
     if (valid && (threadIdx.x & 7) == 0) {
       if (!ok) st->err = 4;  // cannot happen: the admission test is the search's own arithmetic
       nn_o[qi] = res;
@@ -2580,6 +2597,9 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
 static std::atomic<int> g_wide_iters{INT_MAX};
 static std::atomic<int> g_use_tiles{1};
 static int icp_wide_limit() { return g_wide_iters.load(std::memory_order_relaxed); }
+// iterations per chunk of wide launches (pcs_icp_set_chunk_iterations; the lock-step engines read their units' states
+// once per chunk)
+static std::atomic<int> g_chunk_iters{8};
 static bool icp_use_tiles() { return g_use_tiles.load(std::memory_order_relaxed) != 0; }
 
 // end of a wide chunk: the stop rule of every entry's last iteration (the others were settled by the next
@@ -2613,7 +2633,8 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   static thread_local BatchInts kf;
   static thread_local IcpHint hf[kMaxBatch];
   bf.n = 0;
-  int n_wide = 0;  // iterations to launch: at most 8 per chunk
+  const int chunk_iters = g_chunk_iters.load(std::memory_order_relaxed);
+  int n_wide = 0;  // iterations to launch: at most chunk_iters (8) per chunk
   bool any_first = false, all_wide = true;
   for (int e = 0; e < bt.n; ++e) {
     if (kbase.v[e] < wide_limit) {
@@ -2624,9 +2645,9 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
       if (left > n_wide) n_wide = left;
       any_first = any_first || kbase.v[e] == 0;
     }
-    if ((int64_t)kbase.v[e] + 8 > (int64_t)wide_limit) all_wide = false;  // (the resident loop may get a turn)
+    if ((int64_t)kbase.v[e] + chunk_iters > (int64_t)wide_limit) all_wide = false;  // (the resident loop may get a turn)
   }
-  if (n_wide > 8) n_wide = 8;
+  if (n_wide > chunk_iters) n_wide = chunk_iters;
   if (n_wide > n_it) n_wide = n_it;
   if (bf.n > 0 && n_wide > 0) {
     int64_t q = 1, m = 1, qsum = 0, cmax = 1;
@@ -2740,15 +2761,16 @@ extern "C" {
 //   wide_iters >= 1: that many wide iterations, then the unit-resident loop: use_tiles != 0 the tile path
 //   (LDS-staged searches; registrations that do not qualify take the cache path), else the cache path.
 // diagnostics: the verified cache's counters since the last call (zero unless the library was built with
-// -DPCS_ICP_STATS): host_out[4] = queries tested, budgets run out, of those kept by the second level, searched.
-// Synchronises the device.
+// -DPCS_ICP_STATS): host_out[16] = queries tested, budgets run out, of those kept by the second level, searched; then
+// the same four counts of the backward queries (reference -> moving cloud) alone; [8], [9] = queries served by the
+// cooperative / the eight-lane seeded search (every iteration, the first included). Synchronises the device.
 int pcs_icp_cache_stats(unsigned long long* host_out) {
   if (!host_out) return PCS_ERR_ARG;
-  unsigned long long v[8];
+  unsigned long long v[16];
   PCS_CHECK_HIP(hipDeviceSynchronize());
   PCS_CHECK_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_icp_stats), sizeof(v)));
-  for (int i = 0; i < 4; ++i) host_out[i] = v[i];
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 16; ++i) host_out[i] = v[i];
+  unsigned long long z[16] = {0};
   PCS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)));
   return PCS_OK;
 }
@@ -2759,6 +2781,14 @@ int pcs_icp_cache_stats(unsigned long long* host_out) {
 int pcs_icp_set_cache_levels(int levels) {
   if (levels != 1 && levels != 2) return PCS_ERR_ARG;
   g_cache_levels.store(levels, std::memory_order_relaxed);
+  return PCS_OK;
+}
+
+// pcs_icp_set_chunk_iterations: iterations per chunk of the wide schedule (default 8; 1..64). Results do not depend on
+// it: a chunk is a scheduling unit of the lock-step engines.
+int pcs_icp_set_chunk_iterations(int n) {
+  if (n < 1 || n > 64) return PCS_ERR_ARG;
+  g_chunk_iters.store(n, std::memory_order_relaxed);
   return PCS_OK;
 }
 
