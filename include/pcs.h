@@ -200,6 +200,11 @@ int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const voi
 int pcs_indice_conv_table_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
                               const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
                               pcs_stream_t stream);
+/* test hook, forms of the fp16 convs: 0 (default) = partner rows gathered straight into the MFMA fragments, several
+ * offsets' weights in LDS per round (256-thread workgroups; up to 8 input channels: one thread per output row);
+ * 3 = the same on 512-thread workgroups; 2 = 128-row tiles staged through LDS, the next offset prefetched;
+ * 1 = round 4's kernels (64-row tiles, one thread per output element). The same bits in every form. */
+int pcs_indice_conv_f16_short_tiles(int on);
 size_t pcs_indice_conv_backward_f16_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin, int cout);
 int pcs_indice_conv_backward_f16(const void* features, int cin, const void* filters, int kv, int cout,
                                  const void* out_grad, const int32_t* pairs, int64_t pair_stride,

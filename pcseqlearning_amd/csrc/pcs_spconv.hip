@@ -856,6 +856,320 @@ indice_conv_f16_mfma_kernel(const __half* __restrict__ feat, int cin, const __ha
   }
 }
 
+// ---- round 5: the same product on a taller tile, with the next offset's loads in flight under the MFMAs.
+// The 64-row form above waits for its gathers at every offset (loads -> LDS -> barrier -> MFMA -> barrier), stages the
+// weights of an offset once per 64 rows (as many bytes as the rows themselves at 64 channels) and transposes them by
+// 2-byte LDS stores. Here a workgroup owns TMH = 128 output rows (wave w: rows 32 w .. 32 w + 31, two 16-row
+// fragments against every column fragment), the gathered rows and the weights of offset s + 1 are requested into
+// registers before the MFMAs of offset s start, and W[k] is transposed in registers: a thread takes an 8 x 8 block
+// (eight 16-byte rows), v_perm_b32 turns it, eight 16-byte LDS stores put it down. Per output row the offsets,
+// slices and K chunks come in the same order as above: the same bits.
+constexpr int TMH = 128;
+__device__ __forceinline__ unsigned u4_word(const uint4& v, int w) { return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w)); }
+template <int NC>
+__global__ void __launch_bounds__(kBlock)
+indice_conv_f16_mfma_tall_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
+                                 int centre, const int32_t* __restrict__ table, int64_t num_out,
+                                 const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+  constexpr int COUT = NC * 16;
+  constexpr int MT = TMH / 64;                       // 16-row fragments per wave
+  constexpr int NA = TMH * (CIN_MAX / 8) / kBlock;   // 16-byte row pieces per thread at 64 channels
+  constexpr int NWB = (CIN_MAX / 8) * (COUT / 8);    // 8 x 8 weight blocks of a 64-channel slice
+  constexpr int NWT = (NWB + kBlock - 1) / kBlock;   // ... per thread (1)
+  __shared__ __align__(16) _Float16 As[TMH][H_LD];
+  __shared__ __align__(16) _Float16 Wt[COUT][H_LD];
+  __shared__ int Tt[TMH][32];   // the tile's rows of the neighbour table (kv <= 32)
+  __shared__ unsigned s_any[TMH / 64];
+  __shared__ int steps[32];     // active offsets, accumulation order (centre first for subM)
+  __shared__ int nsteps;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TMH;
+  for (int e = tid; e < TMH * kv; e += kBlock) {
+    int r = e / kv, k = e - r * kv;
+    int64_t gr = row0 + r;
+    Tt[r][k] = gr < num_out ? table[gr * kv + k] : -1;
+  }
+  __syncthreads();
+  if (tid < TMH) {  // which offsets have a partner in this tile (one bit per offset and wave of rows)
+    unsigned m = 0u;
+    for (int k = 0; k < kv; ++k)
+      if (__ballot(Tt[tid][k] >= 0) != 0) m |= 1u << k;
+    if (lane == 0) s_any[wv] = m;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned m = 0u;
+    for (int w = 0; w < TMH / 64; ++w) m |= s_any[w];
+    int n = 0;
+    for (int step = 0; step < kv; ++step) {
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      if ((m >> k) & 1u) steps[n++] = k;
+    }
+    nsteps = n;
+  }
+  __syncthreads();
+  // A step stages 64 channels' worth: one offset (or one 64-channel slice of it), or -- up to 32 channels -- TWO
+  // offsets side by side (channels [0, 32) and [32, 64) of the LDS rows), so that a 32-channel layer pays the
+  // barriers and the staging of a step once per two offsets. The MFMAs of an offset stay its own (K = 32 each).
+  const int slices = (cin + CIN_MAX - 1) / CIN_MAX;
+  const int cs_one = min(CIN_MAX, cin);               // channels of a step's (first) offset, single-slice layers
+  const int G = (slices == 1 && cs_one <= 32) ? 2 : 1;  // offsets per step
+  const int ns = slices == 1 ? (nsteps + G - 1) / G : nsteps * slices;
+  f32x4 acc[MT][NC];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 ra[NA];
+  uint4 rw[NWT][8];
+  // geometry of step si: h = slice, cs = channels per offset, ch8 = 16-byte pieces per offset (padded to 32
+  // channels), ng = offsets staged
+  auto step_geom = [&](int si, int& h, int& cs, int& ch8, int& ng) {
+    h = slices == 1 ? 0 : si - (si / slices) * slices;
+    cs = min(CIN_MAX, cin - h * CIN_MAX);
+    ch8 = ((cs + 31) & ~31) >> 3;
+    ng = slices == 1 ? min(G, nsteps - si * G) : 1;
+  };
+  auto prefetch = [&](int si) {
+    int h, cs, ch8, ng;
+    step_geom(si, h, cs, ch8, ng);
+    const int k0 = steps[slices == 1 ? si * G : si / slices];
+    const int k1 = ng > 1 ? steps[si * G + 1] : k0;
+    const int npc = ng * ch8;  // pieces per row
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * kBlock;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (e < TMH * npc) {
+        const int r = e / npc, c8 = e - r * npc;
+        const int g = c8 >= ch8 ? 1 : 0, cl = c8 - g * ch8;
+        const int in = Tt[r][g ? k1 : k0];
+        if (in >= 0 && cl * 8 < cs) v = *(const uint4*)(feat + (int64_t)in * cin + h * CIN_MAX + cl * 8);
+      }
+      ra[i] = v;
+    }
+    // block b = (channel block cb, column block jb): rows cb * 8 .. + 7 of W[k], columns jb * 8 .. + 7
+#pragma unroll
+    for (int i = 0; i < NWT; ++i) {
+      const int b = tid + i * kBlock;
+      const int cb = b / (COUT / 8), jb = b - cb * (COUT / 8);
+      const int g = cb >= ch8 ? 1 : 0, cbl = cb - g * ch8;
+      const __half* Wk = W + ((int64_t)(g ? k1 : k0) * cin + h * CIN_MAX) * COUT;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = cbl * 8 + q;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (b < npc * (COUT / 8) && c < cs) v = *(const uint4*)(Wk + (int64_t)c * COUT + jb * 8);
+        rw[i][q] = v;
+      }
+    }
+  };
+  if (ns > 0) prefetch(0);
+  for (int si = 0; si < ns; ++si) {
+    int h, cs, ch8, ng;
+    step_geom(si, h, cs, ch8, ng);
+    const int npc = ng * ch8;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * kBlock;
+      if (e < TMH * npc) { const int r = e / npc, c8 = e - r * npc; *(uint4*)&As[r][c8 * 8] = ra[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NWT; ++i) {
+      const int b = tid + i * kBlock;
+      if (b < npc * (COUT / 8)) {
+        const int cb = b / (COUT / 8), jb = b - cb * (COUT / 8);
+        // column j of the block = halves j of the eight rows: word (j >> 1), low or high half
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+          unsigned wd[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const unsigned lo = u4_word(rw[i][2 * m], j >> 1), hi = u4_word(rw[i][2 * m + 1], j >> 1);
+            wd[m] = __builtin_amdgcn_perm(hi, lo, sel);
+          }
+          *(uint4*)&Wt[jb * 8 + j][cb * 8] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        }
+      }
+    }
+    __syncthreads();
+    if (si + 1 < ns) prefetch(si + 1);
+    for (int c0 = 0; c0 < npc * 8; c0 += 32) {
+      f16x8 a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = *(const f16x8*)&As[wv * (TMH / 4) + m * 16 + fi][c0 + 8 * fk];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const f16x8 b = *(const f16x8*)&Wt[n * 16 + fi][c0 + 8 * fk];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b, acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int col = n * 16 + fi;
+    const float bv = bias ? __half2float(bias[col]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t r = row0 + wv * (TMH / 4) + m * 16 + fk * 4 + j;
+        if (r >= num_out) continue;
+        float v = acc[m][n][j] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        out[r * COUT + col] = __float2half_rn(v);
+      }
+    }
+  }
+}
+
+// ---- round 5, second form (up to 64 input channels: every layer of VoxelBackBone8x): the gathered rows never touch
+// LDS. An MFMA A fragment is 16 rows x 32 channels with lane (i, kq) holding channels 8 kq .. 8 kq + 7 of row i --
+// exactly one 16-byte piece of a gathered fp16 row, so every lane loads its own piece of its own row's partner
+// straight into the fragment register (zeros where the table says "no partner"). What a workgroup shares are the
+// weights: KW offsets' W[k], transposed in registers as above, sit in a 28 KB LDS buffer per round (3 offsets at
+// 64 x 64, 9 at 32 x 32); the eight waves of a workgroup (256 output rows, 32 per wave) run through a round's offsets
+// without meeting -- three offsets' table entries, then their row pieces, are requested together -- and a wave skips
+// an offset none of its 32 rows has. Barriers: two per ROUND (9 rounds at 64 x 64) instead of two per offset and 64
+// rows; weight bytes per output row: a quarter of the 64-row form's. Per output row the offsets come in the same
+// order (centre first for subM) and every accumulator sees its K chunks in the same order: the same bits.
+constexpr int kDirWHalves = 14336;  // the weights' LDS buffer (28 KB)
+template <int NC, int kDirBlock>
+__global__ void __launch_bounds__(kDirBlock)
+indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
+                              int centre, const int32_t* __restrict__ table, int64_t num_out,
+                              const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+  constexpr int COUT = NC * 16;
+  constexpr int MT = 2;  // 16-row fragments per wave
+  constexpr int kDirRows = kDirBlock / 2;
+  __shared__ __align__(16) _Float16 Wl[kDirWHalves];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kDirRows + wv * 32;
+  const int cs32 = (cin + 31) & ~31;   // channels as the MFMAs see them (32 or 64)
+  const int C0 = cs32 >> 5;
+  const int wld = cs32 + 8;            // halves per LDS row of a transposed W[k] (rows start 4 banks apart)
+  const int bpo = (cs32 >> 3) * (COUT / 8);  // 8 x 8 blocks per offset
+  int KW = min(kv, min(kDirWHalves / (COUT * wld), kDirBlock / bpo));
+  if (KW > 9) KW = 9;
+  KW -= KW % 3 == 0 ? 0 : (KW > 3 ? KW % 3 : 0);  // whole batches of three offsets where it can be
+  const int rounds = (kv + KW - 1) / KW;
+  auto kmap = [&](int step) {  // accumulation order: the centre first for subM
+    return centre >= 0 ? (step == 0 ? centre : (step <= centre ? step - 1 : step)) : step;
+  };
+  int64_t rm[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) rm[m] = row0 + m * 16 + fi;
+  f32x4 acc[MT][NC];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 rw[8];
+  auto prefetch_w = [&](int rd) {
+    const int kw = tid / bpo, b = tid - kw * bpo;
+    const int cb = b / (COUT / 8), jb = b - cb * (COUT / 8);
+    const int step = rd * KW + kw;
+    const bool on = kw < KW && step < kv;
+    const __half* Wk = W + (int64_t)kmap(on ? step : 0) * cin * COUT;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = cb * 8 + q;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (on && c < cin) v = *(const uint4*)(Wk + (int64_t)c * COUT + jb * 8);
+      rw[q] = v;
+    }
+  };
+  prefetch_w(0);
+  for (int rd = 0; rd < rounds; ++rd) {
+    {
+      const int kw = tid / bpo, b = tid - kw * bpo;
+      if (kw < KW) {
+        const int cb = b / (COUT / 8), jb = b - cb * (COUT / 8);
+        _Float16* Wt = Wl + (size_t)kw * COUT * wld;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+          unsigned wd[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const unsigned lo = u4_word(rw[2 * m], j >> 1), hi = u4_word(rw[2 * m + 1], j >> 1);
+            wd[m] = __builtin_amdgcn_perm(hi, lo, sel);
+          }
+          *(uint4*)&Wt[(jb * 8 + j) * wld + cb * 8] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        }
+      }
+    }
+    __syncthreads();
+    if (rd + 1 < rounds) prefetch_w(rd + 1);
+    const int nk = min(KW, kv - rd * KW);
+    for (int kb = 0; kb < nk; kb += 3) {
+      int in[3][MT];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const bool on = kb + g < nk;
+        const int k = kmap(on ? rd * KW + kb + g : 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) in[g][m] = (on && rm[m] < num_out) ? table[rm[m] * kv + k] : -1;
+      }
+      f16x8 a[3][MT][2];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int ch = c * 32 + 8 * fk;
+            if (in[g][m] >= 0 && ch < cin) v = *(const uint4*)(feat + (int64_t)in[g][m] * cin + ch);
+            a[g][m][c] = *(const f16x8*)&v;
+          }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) any = any || in[g][m] >= 0;
+        if (__ballot(any) == 0) continue;  // (none of the wave's 32 rows has this offset)
+        const _Float16* Wt = Wl + (size_t)(kb + g) * COUT * wld;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (c < C0) {
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+              const f16x8 b = *(const f16x8*)&Wt[(n * 16 + fi) * wld + c * 32 + 8 * fk];
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][m][c], b, acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int col = n * 16 + fi;
+    const float bv = bias ? __half2float(bias[col]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t r = row0 + m * 16 + fk * 4 + j;
+        if (r >= num_out) continue;
+        float v = acc[m][n][j] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        out[r * COUT + col] = __float2half_rn(v);
+      }
+    }
+  }
+}
+
 // any (Cin, Cout): one thread per output element, fp32 accumulation in the same order, one rounding
 __global__ void __launch_bounds__(kBlock)
 indice_conv_f16_generic_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
@@ -879,6 +1193,53 @@ indice_conv_f16_generic_kernel(const __half* __restrict__ feat, int cin, const _
     if (bias) acc = acc + __half2float(bias[col]);
     if (relu) acc = fmaxf(acc, 0.f);
     out[t] = __float2half_rn(acc);
+  }
+}
+
+// a few input channels (the backbone's first conv: 5 -> 16): one THREAD per output row, its COUT accumulators in
+// registers, the filters as fp32 in LDS (every thread of a wave reads the same word: a broadcast). The generic form
+// above gives every output ELEMENT a thread, i.e. sixteen threads walk the same 27 table entries and load the same
+// partner rows. Same order of operations per element (offsets centre-first, channels ascending, one fmaf each): the
+// same bits.
+template <int COUT>
+__global__ void __launch_bounds__(kBlock)
+indice_conv_f16_rows_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
+                            int centre, const int32_t* __restrict__ table, int64_t num_out,
+                            const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+  constexpr int kMaxW = 32 * 8 * COUT;  // kv <= 32, cin <= 8
+  __shared__ float Wf[kMaxW];
+  for (int e = threadIdx.x; e < kv * cin * COUT; e += kBlock) Wf[e] = __half2float(W[e]);
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= num_out) return;
+  float acc[COUT];
+#pragma unroll
+  for (int j = 0; j < COUT; ++j) acc[j] = 0.f;
+  for (int step = 0; step < kv; ++step) {
+    int k = step;
+    if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+    const int in = table[r * kv + k];
+    if (in < 0) continue;
+    const __half* f = feat + (int64_t)in * cin;
+    const float* w = Wf + k * cin * COUT;
+    for (int c = 0; c < cin; ++c) {
+      const float fv = __half2float(f[c]);
+#pragma unroll
+      for (int j = 0; j < COUT; ++j) acc[j] = fmaf(fv, w[c * COUT + j], acc[j]);
+    }
+  }
+  __half* o = out + r * COUT;
+#pragma unroll
+  for (int j8 = 0; j8 < COUT / 8; ++j8) {
+    __half h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[j8 * 8 + j];
+      if (bias) v = v + __half2float(bias[j8 * 8 + j]);
+      if (relu) v = fmaxf(v, 0.f);
+      h[j] = __float2half_rn(v);
+    }
+    *(uint4*)(o + j8 * 8) = *(const uint4*)h;
   }
 }
 
@@ -1001,6 +1362,7 @@ maxpool_bwd_f16_kernel(const __half* __restrict__ feat, const __half* __restrict
   }
 }
 
+static int g_f16_short_tiles = 0;  // pcs_indice_conv_f16_short_tiles: 1 = the 64-row form of round 4, 2 = the 128-row staged form (cross-checks)
 // out[o,:] = fp16( (+bias) relu? ( sum_k feat[table[o,k],:] . W[k] ) ) on an output-major table
 static int conv_table_f16(const __half* features, int cin, const __half* filters, int kv, int cout, int centre,
                           const int32_t* table, int64_t num_out, const __half* bias, int relu, __half* out,
@@ -1009,13 +1371,47 @@ static int conv_table_f16(const __half* features, int cin, const __half* filters
   const int64_t nb = (num_out + TM - 1) / TM;
   if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
   const bool cout_ok = cout == 16 || cout == 32 || cout == 64 || cout == 128;
-  if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX) {
+  if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= CIN_MAX && (g_f16_short_tiles == 0 || g_f16_short_tiles == 3)) {
+#define PCS_DIRECT(NCV, BLK)                                                                                          \
+  indice_conv_f16_direct_kernel<NCV, BLK><<<(int)((num_out + BLK / 2 - 1) / (BLK / 2)), BLK, 0, s>>>(                   \
+      features, cin, filters, kv, centre, table, num_out, bias, relu, out)
+    if (g_f16_short_tiles == 3) {
+      switch (cout) {
+        case 16: PCS_DIRECT(1, 512); break;
+        case 32: PCS_DIRECT(2, 512); break;
+        case 64: PCS_DIRECT(4, 512); break;
+        default: PCS_DIRECT(8, 512); break;
+      }
+    } else {
+      switch (cout) {
+        case 16: PCS_DIRECT(1, 256); break;
+        case 32: PCS_DIRECT(2, 256); break;
+        case 64: PCS_DIRECT(4, 256); break;
+        default: PCS_DIRECT(8, 256); break;
+      }
+    }
+#undef PCS_DIRECT
+  } else if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX && g_f16_short_tiles != 1) {
+    const int nbt = (int)((num_out + TMH - 1) / TMH);
+    switch (cout) {
+      case 16: indice_conv_f16_mfma_tall_kernel<1><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 32: indice_conv_f16_mfma_tall_kernel<2><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 64: indice_conv_f16_mfma_tall_kernel<4><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      default: indice_conv_f16_mfma_tall_kernel<8><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+    }
+  } else if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX) {
     switch (cout) {
       case 16: indice_conv_f16_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
       case 32: indice_conv_f16_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
       case 64: indice_conv_f16_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
       default: indice_conv_f16_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
     }
+  } else if (cin <= 8 && kv <= 32 && (cout == 16 || cout == 32) && g_f16_short_tiles != 1) {
+    const int nbr = (int)((num_out + kBlock - 1) / kBlock);
+    if (cout == 16)
+      indice_conv_f16_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out);
+    else
+      indice_conv_f16_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out);
   } else {
     indice_conv_f16_generic_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(features, cin, filters, kv, cout, centre,
                                                                               table, num_out, bias, relu, out);
@@ -1030,6 +1426,13 @@ extern "C" {
 size_t pcs_indice_conv_f16_workspace_bytes(int64_t num_in, int cin, int kv, int cout, int64_t num_out) {
   (void)num_in; (void)cin; (void)cout;
   return pcs_neighbor_table_bytes(num_out, kv);
+}
+
+// test hook: 1 = the fp16 convs on round 4's 64-row tiles (the same bits; tests/test_gpu_voxel_conv.py), 0 = the
+// 128-row tiles with register prefetch (default)
+int pcs_indice_conv_f16_short_tiles(int on) {
+  pcs::g_f16_short_tiles = (on >= 0 && on <= 3) ? on : 0;
+  return PCS_OK;
 }
 
 // features [num_in,cin], filters [kv,cin,cout], bias [cout] or NULL (fused_indice_conv_half), out

@@ -487,6 +487,41 @@ def test_half_conv_matrix_core_tiles_vs_fp32_of_the_same_values(oracle, cin, cou
         np.testing.assert_allclose(got.astype(np.float32), exact, rtol=2.0 ** -10, atol=2.0 ** -10 * scale)
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (128, 128), (64, 32), (48, 32), (5, 16), (8, 32)])
+def test_half_conv_forms_agree_bit_for_bit(oracle, cin, cout):
+    """Round 5's fp16 conv kernels -- rows gathered straight into the MFMA fragments, weights of several offsets in
+    LDS (512- and 256-thread workgroups); 128-row staged tiles with the next offset prefetched -- against round 4's
+    64-row kernel (pcs_indice_conv_f16_short_tiles): per output row the offsets, channel slices and K chunks come in
+    the same order, so the fp16 results are identical -- on a ragged row count, with and without bias, subM (centre
+    first) and strided. Up to 8 input channels (the backbone's first conv): one thread per output row against one per
+    output element."""
+    from pcseqlearning_amd import lib as L
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(500 + cin + cout)
+    shape = [9, 28, 28]
+    idx = random_indices(rng, shape, 3001, batch=2)
+    V = idx.shape[0]
+    lib = L.load()
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        feat = rng.normal(0, 1, (V, cin)).astype(np.float16)
+        W = rng.normal(0, 0.1, (27, cin, cout)).astype(np.float16)
+        bias = rng.normal(0, 0.5, cout).astype(np.float16)
+        for b in (None, bias):
+            res = []
+            for short in (1, 0, 2, 3):
+                L.check(lib.pcs_indice_conv_f16_short_tiles(short), "tiles")
+                try:
+                    res.append(ops.indice_conv_half(dev(feat), dev(W), dev(pairs), dev(num), n_out, False, subm,
+                                                    bias=None if b is None else dev(b)).cpu().numpy())
+                finally:
+                    L.check(lib.pcs_indice_conv_f16_short_tiles(0), "tiles")
+            for other in res[1:]:
+                np.testing.assert_array_equal(res[0].view(np.uint16), other.view(np.uint16))
+
+
 def test_half_precision_backward_entries(oracle):
     """indice_conv_backward_half / indice_maxpool_backward_half (src/all.cc:36-37, 48-50): input and filter gradients
     from fp16 rows with fp32 accumulation, rounded once -- within fp16 rounding of the oracle's fp32 gradients of

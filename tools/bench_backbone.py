@@ -43,9 +43,13 @@ def main():
     ap.add_argument("--half", action="store_true",
                     help="fp16 voxel features through the backbone (pcs_indice_conv_table_f16: fp16 rows gathered as "
                          "they are, v_mfma_f32_16x16x32_f16, fp32 accumulation); reported beside the fp32 forward")
+    ap.add_argument("--f16-tiles", type=int, default=0,
+                    help="pcs_indice_conv_f16_short_tiles: 0 = direct gathers, 256 threads (default), 3 = the same on 512 "
+                         "threads, 2 = 128-row staged tiles, 1 = round 4's 64-row tiles")
     args = ap.parse_args()
     dev = "cuda:0"
     lib = L.load()
+    L.check(lib.pcs_indice_conv_f16_short_tiles(ctypes.c_int(args.f16_tiles)), "pcs_indice_conv_f16_short_tiles")
     torch.manual_seed(0)
     frames = []
     for b in range(args.batch):
