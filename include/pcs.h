@@ -143,7 +143,10 @@ int pcs_indice_conv_f32(const float* features, int cin, const float* filters, in
  * BatchNorm / ReLU (fused_spconv_ops.h:29-132, modules.py:125-187) fold into the epilogue. */
 int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
                              int inverse, int64_t num_out, int32_t* table, pcs_stream_t stream);
-int pcs_conv_use_mfma(int enable); /* 1 (default): MFMA tiles for Cin >= 16; 0: FMA tiles only */
+int pcs_conv_use_mfma(int enable); /* 1 (default): matrix cores for Cin >= 16 (16 / 32 / 64 input channels and 100 000 rows or
+                                    * more: partner rows gathered straight into the operand registers); 2: matrix cores on
+                                    * round 4's staged 64-row tiles everywhere; 3: the direct-gather form at any size (tests);
+                                    * 0: FMA tiles only */
 /* scale / shift [C] f32 of an eval-mode BatchNorm1d for the conv epilogue above (torch.nn.BatchNorm1d in
  * eval mode after every conv of spconv_backbone.py:6-27) from inv_std = rsqrt(running_var + eps):
  * scale = inv_std * weight, shift = -mean * scale + bias, each product / sum rounded to fp32 like the
@@ -200,6 +203,21 @@ int pcs_indice_conv_f16(const void* features, int64_t num_in, int cin, const voi
 int pcs_indice_conv_table_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
                               const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
                               pcs_stream_t stream);
+/* the conv on a cached table with its output rows taken in a given order: order [num_out] int32 from
+ * pcs_neighbor_table_order -- the rows sorted (stably) by the set of offsets they have a partner at, so that the sixteen
+ * rows of a matrix-core fragment want the same offsets (in table order about half of the (fragment, offset) products
+ * of VoxelBackBone8x's layers multiply padding). Every output row is the same sum in the same order: the same bits
+ * as pcs_indice_conv_table_f32 / _f16. order == NULL: table order. kv <= 32. */
+size_t pcs_neighbor_table_order_workspace_bytes(int64_t num_out);
+int pcs_neighbor_table_order(const int32_t* table, int64_t num_out, int kv, int32_t* order, void* ws, size_t ws_bytes,
+                             pcs_stream_t stream);
+int pcs_indice_conv_table_ordered_f32(const float* features, int cin, const float* filters, int kv, int cout, int centre,
+                                      const int32_t* table, int64_t num_out, const float* bias, const float* scale,
+                                      const float* shift, int relu, float* out, const int32_t* order,
+                                      pcs_stream_t stream);
+int pcs_indice_conv_table_ordered_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                                      const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
+                                      const int32_t* order, pcs_stream_t stream);
 /* test hook, forms of the fp16 convs: 0 (default) = partner rows gathered straight into the MFMA fragments, several
  * offsets' weights in LDS per round (256-thread workgroups; up to 8 input channels: one thread per output row);
  * 3 = the same on 512-thread workgroups; 2 = 128-row tiles staged through LDS, the next offset prefetched;

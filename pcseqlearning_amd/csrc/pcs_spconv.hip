@@ -13,6 +13,7 @@
 // intermediate buffers, fixed accumulation order (subM: centre offset first, then k ascending;
 // input channel ascending) -> bitwise reproducible. Bias / folded BN / ReLU run in the epilogue.
 #include "pcs_common.hpp"
+#include "pcs_wgsort.hpp"
 
 namespace pcs {
 
@@ -227,6 +228,203 @@ indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __
   }
 }
 
+// ---- round 5: the gathered rows go straight into the MFMA operand registers (16, 32 or 64 input channels: every
+// matrix-core layer of VoxelBackBone8x). v_mfma_f32_16x16x4_f32 takes A[i = l & 15][k = l >> 4]: four lanes share a
+// row and each supplies ONE channel per instruction. Which channel is free as long as A and B agree: lane group g of
+// a 16-channel chunk loads the row's float4 at channels 4 g .. 4 g + 3 (one 16-byte load) and the chunk's four MFMAs
+// take its components one after the other -- instruction j multiplies channels {4 g + j}. The weights of KW offsets
+// sit in LDS (36 KB; rows permuted so that the four lane groups read neighbouring rows, 8 banks apart), the four
+// waves of a workgroup (128 output rows, 32 each) run through a round's offsets without meeting, two offsets'
+// table entries and row pieces in flight at a time, and a wave skips an offset none of its rows has. Against the
+// staged 64-row form above: no LDS traffic for the rows, a quarter of the weight bytes per output row, two
+// barriers per round instead of two per offset. The products are the same, their order inside a 16-channel chunk is
+// not: results agree with the staged form to fp32 rounding (both are pinned to the oracle by tolerance).
+constexpr int kDirF32Block = 256;
+constexpr int kDirF32Rows = 128;
+constexpr int kDirF32W = 9216;  // floats of the weights' LDS buffer (36 KB)
+template <int NC>
+__global__ void __launch_bounds__(kDirF32Block)
+indice_conv_f32_direct_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W, int kv,
+                              int centre, const int32_t* __restrict__ table, int64_t num_out,
+                              const float* __restrict__ bias, const float* __restrict__ scale,
+                              const float* __restrict__ shift, int relu, float* __restrict__ out,
+                              const int32_t* __restrict__ order) {
+  constexpr int COUT = NC * 16;
+  constexpr int MT = 2;
+  constexpr int WLD = COUT + 8;
+  __shared__ __align__(16) float Wl[kDirF32W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kDirF32Rows + wv * 32;
+  const int C16 = cin >> 4;  // 16-channel chunks (1, 2 or 4)
+  int KW = min(kv, kDirF32W / (cin * WLD));
+  if (KW > 8) KW = 8;
+  if (KW > 1) KW &= ~1;
+  const int rounds = (kv + KW - 1) / KW;
+  auto kmap = [&](int step) {  // accumulation order: the centre first for subM
+    return centre >= 0 ? (step == 0 ? centre : (step <= centre ? step - 1 : step)) : step;
+  };
+  // the fragment rows: positions row0 .. of `order` (rows sorted by their set of occupied offsets, see
+  // pcs_neighbor_table_order: a fragment's sixteen rows then want the same offsets) or the rows themselves
+  int64_t rm[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int64_t pos = row0 + m * 16 + fi;
+    rm[m] = pos < num_out ? (order ? (int64_t)order[pos] : pos) : num_out;
+    if ((uint64_t)rm[m] >= (uint64_t)num_out) rm[m] = num_out;  // (an entry that is no row: nothing read)
+  }
+  f32x4 acc[MT][NC];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int w4 = cin * (COUT / 4);  // float4 pieces of one offset's weights
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int nk = min(KW, kv - rd * KW);
+    // the round's weights: channel ch = 16 c + 4 g + j goes to LDS row 16 c + 4 j + g
+    for (int e = tid; e < nk * w4; e += kDirF32Block) {
+      const int kw = e / w4, r = e - kw * w4;
+      const int ch = r / (COUT / 4), c4 = r - ch * (COUT / 4);
+      const float4 v = *(const float4*)(W + ((int64_t)kmap(rd * KW + kw) * cin + ch) * COUT + c4 * 4);
+      const int lr = (ch & ~15) | ((ch & 3) << 2) | ((ch >> 2) & 3);
+      *(float4*)&Wl[(size_t)(kw * cin + lr) * WLD + c4 * 4] = v;
+    }
+    __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+      int in[2][MT];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const bool on = kb + g < nk;
+        const int k = kmap(on ? rd * KW + kb + g : 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) in[g][m] = (on && rm[m] < num_out) ? table[rm[m] * kv + k] : -1;
+      }
+      float4 a[2][MT][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[g][m] >= 0 && c < C16) v = *(const float4*)(feat + (int64_t)in[g][m] * cin + c * 16 + fg * 4);
+            a[g][m][c] = v;
+          }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bool on_m[MT];  // a 16-row fragment none of whose rows has this offset adds nothing
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { on_m[m] = __ballot(in[g][m] >= 0) != 0; any = any || on_m[m]; }
+        if (!any) continue;
+        const float* Wt = Wl + (size_t)(kb + g) * cin * WLD;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < C16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int n = 0; n < NC; ++n) {
+                const float b = Wt[(c * 16 + j * 4 + fg) * WLD + n * 16 + fi];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                  const float av = j == 0 ? a[g][m][c].x : (j == 1 ? a[g][m][c].y : (j == 2 ? a[g][m][c].z : a[g][m][c].w));
+                  if (on_m[m]) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[m][n], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int col = n * 16 + fi;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t pos = row0 + m * 16 + fg * 4 + j;
+        if (pos >= num_out) continue;
+        const int64_t r = order ? (int64_t)order[pos] : pos;
+        if ((uint64_t)r >= (uint64_t)num_out) continue;
+        float v = acc[m][n][j];
+        if (bias) v = v + bias[col];
+        if (scale) v = fmaf(v, scale[col], shift[col]);
+        if (relu) v = fmaxf(v, 0.f);
+        out[r * COUT + col] = v;
+      }
+    }
+  }
+}
+
+// a few input channels (the backbone's first conv: 5 -> 16): one THREAD per output row, its COUT accumulators in
+// registers, the filters in LDS (every thread of a wave reads the same word: a broadcast), three offsets' table entries
+// and partner channels requested together. The tile kernel stages 64 rows x 27 offsets x 5 channels through LDS with
+// two barriers per offset for 80 multiply-adds per row and offset. Same order of operations per element (offsets
+// centre-first, channels ascending, one fmaf each): the same bits as the tile / generic kernels.
+template <int COUT>
+__global__ void __launch_bounds__(kBlock)
+indice_conv_f32_rows_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W, int kv,
+                            int centre, const int32_t* __restrict__ table, int64_t num_out,
+                            const float* __restrict__ bias, const float* __restrict__ scale,
+                            const float* __restrict__ shift, int relu, float* __restrict__ out) {
+  constexpr int kMaxW = 32 * 8 * COUT;  // kv <= 32, cin <= 8
+  __shared__ float Wf[kMaxW];
+  for (int e = threadIdx.x; e < kv * cin * COUT; e += kBlock) Wf[e] = W[e];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= num_out) return;
+  float acc[COUT];
+#pragma unroll
+  for (int j = 0; j < COUT; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < kv; s0 += 3) {
+    int in[3], kk[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int step = s0 + q;
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      kk[q] = k;
+      in[q] = step < kv ? table[r * kv + k] : -1;
+    }
+    float fv[3][8];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) fv[q][c] = (in[q] >= 0 && c < cin) ? feat[(int64_t)in[q] * cin + c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (in[q] < 0) continue;
+      const float* w = Wf + kk[q] * cin * COUT;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < cin) {
+#pragma unroll
+          for (int j = 0; j < COUT; ++j) acc[j] = fmaf(fv[q][c], w[c * COUT + j], acc[j]);
+        }
+      }
+    }
+  }
+  float* o = out + r * COUT;
+#pragma unroll
+  for (int j4 = 0; j4 < COUT / 4; ++j4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = j4 * 4 + j;
+      float x = acc[col];
+      if (bias) x = x + bias[col];
+      if (scale) x = fmaf(x, scale[col], shift[col]);
+      if (relu) x = fmaxf(x, 0.f);
+      v[j] = x;
+    }
+    *(float4*)(o + j4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 // any (Cin, Cout): one thread per output element, same accumulation order
 __global__ void __launch_bounds__(kBlock)
 indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
@@ -256,6 +454,37 @@ indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float*
   }
 }
 
+// pcs_neighbor_table_order: ONE workgroup per block of kOrderBlock consecutive rows sorts the block's rows (stably)
+// by the bit set of their occupied offsets -- word = set << 12 | row in block, wg_radix_sort_packed on the set's kv bits.
+// Rows of a block are neighbours in space (the tables are in voxel order), so the gathers of a reordered tile still
+// meet in the caches, which a sort over all rows gave away (measured: 13.1 -> 15.2 ms per forward).
+constexpr int kOrderBlock = 4096;
+__global__ void __launch_bounds__(kWg)
+table_order_kernel(const int32_t* __restrict__ table, int64_t num_out, int kv, uint64_t* __restrict__ w0,
+                   uint64_t* __restrict__ w1, int32_t* __restrict__ order) {
+  __shared__ int hist[16 * 256], hist2[16 * 256];
+  __shared__ int sh[kWg / 64 + 1];
+  const int64_t base = (int64_t)blockIdx.x * kOrderBlock;
+  const int n = (int)min((int64_t)kOrderBlock, num_out - base);
+  uint64_t* k0 = w0 + base;
+  uint64_t* k1 = w1 + base;
+  const int tid = threadIdx.x;
+  for (int q = tid; q < 16 * 256; q += kWg) hist[q] = 0;
+  __syncthreads();
+  const int per_wave = ((n + kWg - 1) / kWg) * 64;
+  for (int i = tid; i < n; i += kWg) {
+    uint32_t m = 0u;
+    const int32_t* t = table + (base + i) * kv;
+    for (int k = 0; k < kv; ++k) m |= (t[k] >= 0 ? 1u : 0u) << k;
+    k0[i] = ((uint64_t)m << 12) | (uint64_t)i;
+    atomicAdd(&hist[(i / per_wave) * 256 + (int)(m & 255u)], 1);
+  }
+  __syncthreads();
+  const int which = wg_radix_sort_packed(k0, k1, n, 12, kv, hist, hist2, sh);
+  const uint64_t* sw = which ? k1 : k0;
+  for (int i = tid; i < n; i += kWg) order[base + i] = (int32_t)(base + (int64_t)(sw[i] & 4095ULL));
+}
+
 static int g_use_mfma = 1;
 
 // eval-mode BatchNorm1d as y = x * scale + shift from inv_std = rsqrt(var + eps) (left to the tensor
@@ -280,10 +509,12 @@ using namespace pcs;
 
 extern "C" {
 
-// 1 (default): layers with Cin >= 16, Cin % 4 == 0 run on v_mfma_f32_16x16x4_f32; 0: FMA tiles
-// everywhere (for A/B measurements; both give bit-identical results).
+// 1 (default): layers with Cin >= 16, Cin % 4 == 0 run on v_mfma_f32_16x16x4_f32 (16 / 32 / 64 input channels: rows
+// gathered straight into the operand registers, indice_conv_f32_direct_kernel); 2: the matrix cores on round 4's
+// staged 64-row tiles everywhere; 3: the direct-gather form whatever the number of rows (1 keeps the staged tiles
+// below 100 000 rows); 0: FMA tiles everywhere (for A/B measurements and cross-checks).
 int pcs_conv_use_mfma(int enable) {
-  g_use_mfma = enable != 0;
+  g_use_mfma = (enable == 2 || enable == 3) ? enable : (enable != 0);
   return PCS_OK;
 }
 
@@ -317,10 +548,10 @@ int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const in
 // out[o,:] = epilogue( sum_k feat[table[o,k],:] . W[k] ), W = filters viewed [kv, cin, cout].
 // centre >= 0 selects the offset accumulated first (subM); -1 = plain ascending k.
 // epilogue: (+bias) then (*scale + shift) then relu, each optional (null / 0).
-int pcs_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv,
-                              int cout, int centre, const int32_t* table, int64_t num_out,
-                              const float* bias, const float* scale, const float* shift, int relu,
-                              float* out, hipStream_t s) {
+static int conv_table_f32(const float* features, int cin, const float* filters, int kv,
+                          int cout, int centre, const int32_t* table, int64_t num_out,
+                          const float* bias, const float* scale, const float* shift, int relu,
+                          float* out, const int32_t* order, hipStream_t s) {
   if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 ||
       centre >= kv || (scale && !shift))
     return PCS_ERR_ARG;
@@ -335,6 +566,24 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
   // (the matrix-core kernel stages a tile's rows of the neighbour table in LDS, 32 offsets wide:
   //  wider kernels -- 5x5x5, 3x3x5 ... from an externally built rulebook -- take the tile / generic
   //  kernels, which read the table from memory)
+  // (one frame's layers -- tens of thousands of rows -- do not fill the chip with 128-row workgroups that each walk
+  //  all 27 offsets: there the 64-row staged tiles stay ahead, 1.92 against 2.13 ms per forward at B = 1)
+  if (cout_ok && (g_use_mfma == 3 || (g_use_mfma == 1 && num_out >= 100000)) && kv <= 32 &&
+      (cin == 16 || cin == 32 || cin == 64)) {
+    const int nbd = (int)((num_out + kDirF32Rows - 1) / kDirF32Rows);
+#define PCS_F32_DIRECT(NCV)                                                                                       \
+  indice_conv_f32_direct_kernel<NCV><<<nbd, kDirF32Block, 0, s>>>(features, cin, filters, kv, centre, table, num_out, \
+                                                                 bias, scale, shift, relu, out, order)
+    switch (cout) {
+      case 16: PCS_F32_DIRECT(1); break;
+      case 32: PCS_F32_DIRECT(2); break;
+      case 64: PCS_F32_DIRECT(4); break;
+      default: PCS_F32_DIRECT(8); break;
+    }
+#undef PCS_F32_DIRECT
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   if (cout_ok && g_use_mfma && kv <= 32 && (cin % 4 == 0) && cin >= 16 && cin <= 8 * CIN_MAX) {
 #define PCS_MFMA_LAUNCH(NCV, WIDEV)                                                                   \
   indice_conv_mfma_kernel<NCV, WIDEV><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, \
@@ -358,6 +607,15 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
     PCS_LAUNCH_CHECK();
     return PCS_OK;
   }
+  if (cin <= 8 && kv <= 32 && (cout == 16 || cout == 32) && g_use_mfma != 2) {
+    const int nbr = (int)((num_out + kBlock - 1) / kBlock);
+    if (cout == 16)
+      indice_conv_f32_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+    else
+      indice_conv_f32_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+    PCS_LAUNCH_CHECK();
+    return PCS_OK;
+  }
   if (tiled) {
     switch (cout) {
       case 16:
@@ -377,6 +635,48 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
     indice_conv_generic_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(
         features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out);
   }
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+int pcs_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv,
+                              int cout, int centre, const int32_t* table, int64_t num_out,
+                              const float* bias, const float* scale, const float* shift, int relu,
+                              float* out, hipStream_t s) {
+  return conv_table_f32(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out,
+                        nullptr, s);
+}
+
+// the same with the output rows taken in the order of pcs_neighbor_table_order (rows with the same set of occupied
+// offsets side by side: the matrix-core kernels skip a 16-row fragment at an offset none of its rows has, and in
+// table order only every second (fragment, offset) product is of a pair that exists). Every output row is the same
+// sum in the same order: the same bits as without `order`. order == NULL: table order.
+int pcs_indice_conv_table_ordered_f32(const float* features, int cin, const float* filters, int kv,
+                                      int cout, int centre, const int32_t* table, int64_t num_out,
+                                      const float* bias, const float* scale, const float* shift, int relu,
+                                      float* out, const int32_t* order, hipStream_t s) {
+  return conv_table_f32(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out,
+                        order, s);
+}
+
+// order [num_out] int32: within every block of 4096 consecutive rows, the rows sorted (stably) by the bit set of their
+// occupied offsets; kv <= 32
+size_t pcs_neighbor_table_order_workspace_bytes(int64_t num_out) {
+  const size_t n = (size_t)(num_out > 0 ? num_out : 1);
+  return 2 * align_up(n * sizeof(uint64_t));
+}
+int pcs_neighbor_table_order(const int32_t* table, int64_t num_out, int kv, int32_t* order, void* ws,
+                             size_t ws_bytes, hipStream_t s) {
+  if (!table || !order || !ws || num_out < 0 || kv < 1 || kv > 32) return PCS_ERR_ARG;
+  if (num_out >= (1LL << 31)) return PCS_ERR_RANGE;
+  if (ws_bytes < pcs_neighbor_table_order_workspace_bytes(num_out)) return PCS_ERR_WORKSPACE;
+  if (num_out == 0) return PCS_OK;
+  Arena a(ws, ws_bytes);
+  uint64_t* w0 = a.take<uint64_t>((size_t)num_out);
+  uint64_t* w1 = a.take<uint64_t>((size_t)num_out);
+  if (!w0 || !w1) return PCS_ERR_WORKSPACE;
+  const int64_t nb = (num_out + kOrderBlock - 1) / kOrderBlock;
+  table_order_kernel<<<(int)nb, kWg, 0, s>>>(table, num_out, kv, w0, w1, order);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }
@@ -1043,7 +1343,8 @@ template <int NC, int kDirBlock>
 __global__ void __launch_bounds__(kDirBlock)
 indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                               int centre, const int32_t* __restrict__ table, int64_t num_out,
-                              const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+                              const __half* __restrict__ bias, int relu, __half* __restrict__ out,
+                              const int32_t* __restrict__ order) {
   constexpr int COUT = NC * 16;
   constexpr int MT = 2;  // 16-row fragments per wave
   constexpr int kDirRows = kDirBlock / 2;
@@ -1062,9 +1363,13 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
   auto kmap = [&](int step) {  // accumulation order: the centre first for subM
     return centre >= 0 ? (step == 0 ? centre : (step <= centre ? step - 1 : step)) : step;
   };
-  int64_t rm[MT];
+  int64_t rm[MT];  // (positions of `order`, if given: see indice_conv_f32_direct_kernel)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) rm[m] = row0 + m * 16 + fi;
+  for (int m = 0; m < MT; ++m) {
+    const int64_t pos = row0 + m * 16 + fi;
+    rm[m] = pos < num_out ? (order ? (int64_t)order[pos] : pos) : num_out;
+    if ((uint64_t)rm[m] >= (uint64_t)num_out) rm[m] = num_out;  // (an entry that is no row: nothing read)
+  }
   f32x4 acc[MT][NC];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -1131,10 +1436,11 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
           }
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
+        bool on_m[MT];  // a 16-row fragment none of whose rows has this offset adds nothing
         bool any = false;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) any = any || in[g][m] >= 0;
-        if (__ballot(any) == 0) continue;  // (none of the wave's 32 rows has this offset)
+        for (int m = 0; m < MT; ++m) { on_m[m] = __ballot(in[g][m] >= 0) != 0; any = any || on_m[m]; }
+        if (!any) continue;
         const _Float16* Wt = Wl + (size_t)(kb + g) * COUT * wld;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -1144,7 +1450,7 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
               const f16x8 b = *(const f16x8*)&Wt[(n * 16 + fi) * wld + c * 32 + 8 * fk];
 #pragma unroll
               for (int m = 0; m < MT; ++m)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][m][c], b, acc[m][n], 0, 0, 0);
+                if (on_m[m]) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][m][c], b, acc[m][n], 0, 0, 0);
             }
           }
         }
@@ -1160,8 +1466,10 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t r = row0 + m * 16 + fk * 4 + j;
-        if (r >= num_out) continue;
+        const int64_t pos = row0 + m * 16 + fk * 4 + j;
+        if (pos >= num_out) continue;
+        const int64_t r = order ? (int64_t)order[pos] : pos;
+        if ((uint64_t)r >= (uint64_t)num_out) continue;
         float v = acc[m][n][j] + bv;
         if (relu) v = fmaxf(v, 0.f);
         out[r * COUT + col] = __float2half_rn(v);
@@ -1215,17 +1523,35 @@ indice_conv_f16_rows_kernel(const __half* __restrict__ feat, int cin, const __ha
   float acc[COUT];
 #pragma unroll
   for (int j = 0; j < COUT; ++j) acc[j] = 0.f;
-  for (int step = 0; step < kv; ++step) {
-    int k = step;
-    if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
-    const int in = table[r * kv + k];
-    if (in < 0) continue;
-    const __half* f = feat + (int64_t)in * cin;
-    const float* w = Wf + k * cin * COUT;
-    for (int c = 0; c < cin; ++c) {
-      const float fv = __half2float(f[c]);
+  // three offsets at a time: their table entries, then their partners' channels, are requested together (a chain of
+  // 27 x 2 dependent loads otherwise); the products follow in the offsets' order
+  for (int s0 = 0; s0 < kv; s0 += 3) {
+    int in[3], kk[3];
 #pragma unroll
-      for (int j = 0; j < COUT; ++j) acc[j] = fmaf(fv, w[c * COUT + j], acc[j]);
+    for (int q = 0; q < 3; ++q) {
+      const int step = s0 + q;
+      int k = step;
+      if (centre >= 0) k = (step == 0) ? centre : (step <= centre ? step - 1 : step);
+      kk[q] = k;
+      in[q] = step < kv ? table[r * kv + k] : -1;
+    }
+    float fv[3][8];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        fv[q][c] = (in[q] >= 0 && c < cin) ? __half2float(feat[(int64_t)in[q] * cin + c]) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (in[q] < 0) continue;
+      const float* w = Wf + kk[q] * cin * COUT;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < cin) {
+#pragma unroll
+          for (int j = 0; j < COUT; ++j) acc[j] = fmaf(fv[q][c], w[c * COUT + j], acc[j]);
+        }
+      }
     }
   }
   __half* o = out + r * COUT;
@@ -1366,7 +1692,7 @@ static int g_f16_short_tiles = 0;  // pcs_indice_conv_f16_short_tiles: 1 = the 6
 // out[o,:] = fp16( (+bias) relu? ( sum_k feat[table[o,k],:] . W[k] ) ) on an output-major table
 static int conv_table_f16(const __half* features, int cin, const __half* filters, int kv, int cout, int centre,
                           const int32_t* table, int64_t num_out, const __half* bias, int relu, __half* out,
-                          hipStream_t s) {
+                          hipStream_t s, const int32_t* order = nullptr) {
   if (num_out == 0) return PCS_OK;
   const int64_t nb = (num_out + TM - 1) / TM;
   if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
@@ -1374,7 +1700,7 @@ static int conv_table_f16(const __half* features, int cin, const __half* filters
   if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= CIN_MAX && (g_f16_short_tiles == 0 || g_f16_short_tiles == 3)) {
 #define PCS_DIRECT(NCV, BLK)                                                                                          \
   indice_conv_f16_direct_kernel<NCV, BLK><<<(int)((num_out + BLK / 2 - 1) / (BLK / 2)), BLK, 0, s>>>(                   \
-      features, cin, filters, kv, centre, table, num_out, bias, relu, out)
+      features, cin, filters, kv, centre, table, num_out, bias, relu, out, order)
     if (g_f16_short_tiles == 3) {
       switch (cout) {
         case 16: PCS_DIRECT(1, 512); break;
@@ -1464,6 +1790,17 @@ int pcs_indice_conv_table_f16(const void* features, int cin, const void* filters
     return PCS_ERR_ARG;
   return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, table, num_out,
                         (const __half*)bias, relu, (__half*)out, s);
+}
+
+// ... with the output rows taken in the order of pcs_neighbor_table_order (see pcs_indice_conv_table_ordered_f32)
+int pcs_indice_conv_table_ordered_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                                      const int32_t* table, int64_t num_out, const void* bias, int relu, void* out,
+                                      const int32_t* order, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 || centre >= kv)
+    return PCS_ERR_ARG;
+  return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, table, num_out,
+                        (const __half*)bias, relu, (__half*)out, s, order);
 }
 
 // indice_conv_backward_half (src/all.cc:36-37; spconv_ops.h:363-449 on at::Half): in_grad [num_in,cin] and

@@ -281,9 +281,24 @@ def bn_fold(weight, bias, running_mean, running_var, eps):
     return out[0], out[1]
 
 
+def neighbor_table_order(table, num_out):
+    """pcs_neighbor_table_order: the output rows sorted (stably) by the set of offsets they have a partner at, int32
+    [num_out] -- the order in which the matrix-core conv kernels take the rows of a cached table (a 16-row fragment
+    whose rows want the same offsets multiplies no padding). kv <= 32."""
+    L.require_gpu(table, "neighbor_table_order")
+    lib = L.load()
+    kv = table.shape[1]
+    order = torch.empty(max(num_out, 1), dtype=torch.int32, device=table.device)
+    ws = L.workspace(lib.pcs_neighbor_table_order_workspace_bytes(L.i64(num_out)), table.device)
+    L.check(lib.pcs_neighbor_table_order(L.ptr(table.contiguous()), L.i64(num_out), L.i32(kv), L.ptr(order), L.ptr(ws),
+                                         L.i64(ws.numel()), L.stream()), "pcs_neighbor_table_order")
+    return order[:num_out]
+
+
 def indice_conv_table(features, filters, table, num_out, subm, bias=None, scale=None, shift=None,
-                      relu=False):
-    """out = epilogue(sum_k feat[table[:,k]] @ W[k]); filters [..., Cin, Cout]."""
+                      relu=False, order=None):
+    """out = epilogue(sum_k feat[table[:,k]] @ W[k]); filters [..., Cin, Cout]. order: neighbor_table_order(table) or
+    None (the same results either way)."""
     L.require_gpu(features, "indice_conv")
     lib = L.load()
     cin, cout = filters.shape[-2], filters.shape[-1]
@@ -355,8 +370,9 @@ def indice_maxpool_half(features, pairs, num, num_out):
     return out
 
 
-def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, relu=False):
-    """pcs_indice_conv_table_f16: the fp16 conv on a cached neighbour table; filters [..., Cin, Cout], bias [Cout]."""
+def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, relu=False, order=None):
+    """pcs_indice_conv_table_ordered_f16: the fp16 conv on a cached neighbour table; filters [..., Cin, Cout], bias
+    [Cout]; order: neighbor_table_order(table) or None."""
     L.require_gpu(features, "indice_conv_table_half")
     lib = L.load()
     cin, cout = filters.shape[-2], filters.shape[-1]
@@ -366,9 +382,10 @@ def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, r
     b = bias.half().contiguous() if bias is not None else None
     out = torch.empty(num_out, cout, dtype=torch.float16, device=features.device)
     centre = kv // 2 if (subm and kv % 2 == 1) else -1
-    L.check(lib.pcs_indice_conv_table_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout), L.i32(centre),
-                                          L.ptr(table.contiguous()), L.i64(num_out), L.ptr(b), L.i32(int(relu)),
-                                          L.ptr(out), L.stream()), "pcs_indice_conv_table_f16")
+    L.check(lib.pcs_indice_conv_table_ordered_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                                  L.i32(centre), L.ptr(table.contiguous()), L.i64(num_out), L.ptr(b),
+                                                  L.i32(int(relu)), L.ptr(out), L.ptr(order), L.stream()),
+            "pcs_indice_conv_table_ordered_f16")
     return out
 
 

@@ -16,6 +16,12 @@ from . import ops
 from .modules import SparseModule
 from .structure import SparseConvTensor
 
+# Take the output rows of a cached rulebook in the order of pcs_neighbor_table_order (same results; see
+# ops.neighbor_table_order). OFF: measured in round 5 on VoxelBackBone8x at B = 20 -- the matrix cores multiply a third
+# less padding, but the reordered rows' gathers stop meeting in the caches and the order costs 92 us per rulebook:
+# f32 forward 13.1 -> 13.9 ms, fp16 7.7 -> 9.1 ms (a sort over all rows instead of blocks of 4096: 15.2 / 10.3 ms).
+ORDER_ROWS_BY_OFFSET_SET = False
+
 
 def _fan_in_hwio(weight):
     receptive = weight[..., 0, 0].numel() if weight.dim() > 2 else 1
@@ -80,6 +86,7 @@ class SparseConvolution(SparseModule):
             return out
         datas = input.find_indice_pair(self.indice_key)
         table = None
+        extras = None  # per-rulebook cache beside the table (the row order of the matrix-core kernels)
         if self.inverse:
             assert datas is not None and self.indice_key is not None
             _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas[:5]
@@ -88,6 +95,7 @@ class SparseConvolution(SparseModule):
         elif self.indice_key is not None and datas is not None:
             outids, _, indice_pairs, indice_pair_num, _ = datas[:5]
             table = datas[5] if len(datas) > 5 else None
+            extras = datas[6] if len(datas) > 6 else None
         else:
             # (a submanifold rulebook leaves the conv kernels' neighbour table itself; the others' is built
             # from the pairs)
@@ -96,10 +104,21 @@ class SparseConvolution(SparseModule):
                 self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid, with_table=True)
             if table is None:
                 table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0])
+            extras = {}
             input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num,
-                                                  spatial_shape, table)
+                                                  spatial_shape, table, extras)
         if table is None:
             table = _ops.build_neighbor_table(indice_pairs, indice_pair_num, outids.shape[0], self.inverse)
+
+        def row_order():
+            # the rows sorted by their set of occupied offsets, cached beside the rulebook's table (every conv of the
+            # key takes its rows in this order: the matrix cores multiply fragments of rows that want the same offsets)
+            if not ORDER_ROWS_BY_OFFSET_SET or extras is None or table.shape[1] > 32 or self.inverse:
+                return None
+            if extras.get("order") is None:
+                extras["order"] = _ops.neighbor_table_order(table, outids.shape[0])
+            return extras["order"]
+
         if torch.is_grad_enabled() and (features.requires_grad or self.weight.requires_grad):
             # differentiable path (functional.py): the conv through its autograd function, bias and
             # any epilogue as ordinary tensor ops
@@ -120,11 +139,11 @@ class SparseConvolution(SparseModule):
                 w = w * scale
                 b = shift if b is None else b * scale + shift
             out_features = _ops.indice_conv_table_half(features, w, table, outids.shape[0],
-                                                       self.subm and not self.inverse, bias=b, relu=relu)
+                                                       self.subm and not self.inverse, bias=b, relu=relu, order=row_order())
         else:
             out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
                                                   self.subm and not self.inverse, bias=self.bias, scale=scale,
-                                                  shift=shift, relu=relu)
+                                                  shift=shift, relu=relu, order=row_order())
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

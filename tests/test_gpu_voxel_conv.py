@@ -522,6 +522,90 @@ def test_half_conv_forms_agree_bit_for_bit(oracle, cin, cout):
                 np.testing.assert_array_equal(res[0].view(np.uint16), other.view(np.uint16))
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (64, 128)])
+def test_conv_rows_in_offset_set_order_give_the_same_bits(oracle, cin, cout):
+    """pcs_neighbor_table_order + pcs_indice_conv_table_ordered_f32 / _f16: the output rows taken in the order of their
+    sets of occupied offsets (stable: ties in row order) -- every row is the same sum in the same order, so the
+    outputs equal the table-order call bit for bit; the order is a permutation sorted by the rows' bit sets. The f32
+    direct-gather form against the oracle as well (its order of products inside a 16-channel chunk is its own)."""
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(900 + cin + cout)
+    shape = [9, 28, 28]
+    idx = random_indices(rng, shape, 3001, batch=2)
+    V = idx.shape[0]
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        table = ops.build_neighbor_table(dev(pairs), dev(num), n_out)
+        order = ops.neighbor_table_order(table, n_out)
+        t = table.cpu().numpy()
+        o = order.cpu().numpy()
+        assert sorted(o.tolist()) == list(range(n_out))
+        key = ((t >= 0).astype(np.uint64) << np.arange(27, dtype=np.uint64)).sum(1)
+        np.testing.assert_array_equal(o, np.lexsort((key, np.arange(n_out) // 4096)))
+        feat = rng.normal(0, 1, (V, cin)).astype(np.float32)
+        W = rng.normal(0, 0.1, (27, cin, cout)).astype(np.float32)
+        bias = rng.normal(0, 0.5, cout).astype(np.float32)
+        from pcseqlearning_amd import lib as L
+        L.check(L.load().pcs_conv_use_mfma(3), "mode")  # (the direct-gather form also at this size)
+        try:
+            a = ops.indice_conv_table(dev(feat), dev(W), table, n_out, subm, bias=dev(bias), relu=True).cpu().numpy()
+            b = ops.indice_conv_table(dev(feat), dev(W), table, n_out, subm, bias=dev(bias), relu=True, order=order).cpu().numpy()
+        finally:
+            L.check(L.load().pcs_conv_use_mfma(1), "mode")
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        ref = np.maximum(oracle.indice_conv(feat, W, pairs, num, n_out, False, subm) + bias, 0)
+        np.testing.assert_allclose(a, ref, rtol=1e-4, atol=1e-4)
+        h = ops.indice_conv_table_half(dev(feat).half(), dev(W).half(), table, n_out, subm, bias=dev(bias), relu=True)
+        ho = ops.indice_conv_table_half(dev(feat).half(), dev(W).half(), table, n_out, subm, bias=dev(bias), relu=True,
+                                        order=order)
+        np.testing.assert_array_equal(h.cpu().numpy().view(np.uint16), ho.cpu().numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (3, 32), (8, 16)])
+def test_first_conv_one_thread_per_row_is_the_tile_kernel_bit_for_bit(oracle, cin, cout):
+    """Up to 8 input channels (VoxelBackBone8x's 5 -> 16): round 5's one-thread-per-output-row kernel against round 4's
+    tile kernel (pcs_conv_use_mfma(2) selects the older forms): offsets centre-first, channels ascending, one fmaf
+    each in both, so the f32 outputs are identical; and against the oracle."""
+    from pcseqlearning_amd import lib as L
+    from tests.golden.make_golden import random_indices
+    rng = np.random.default_rng(300 + cin + cout)
+    shape = [9, 28, 28]
+    idx = random_indices(rng, shape, 3001, batch=2)
+    V = idx.shape[0]
+    lib = L.load()
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        out_shape = shape if subm else oracle.conv_out_shape(shape, ks, st, pd, [1, 1, 1])
+        out_ids, pairs, num = oracle.get_indice_pairs(idx, out_shape, ks, st, pd, [1, 1, 1], subm)
+        n_out = V if subm else out_ids.shape[0]
+        table = ops.build_neighbor_table(dev(pairs), dev(num), n_out)
+        feat = rng.normal(0, 1, (V, cin)).astype(np.float32)
+        W = rng.normal(0, 0.1, (27, cin, cout)).astype(np.float32)
+        bias = rng.normal(0, 0.5, cout).astype(np.float32)
+        res = []
+        for mode in (2, 1):
+            L.check(lib.pcs_conv_use_mfma(mode), "mode")
+            try:
+                res.append(ops.indice_conv_table(dev(feat), dev(W), table, n_out, subm, bias=dev(bias), relu=True).cpu().numpy())
+            finally:
+                L.check(lib.pcs_conv_use_mfma(1), "mode")
+        np.testing.assert_array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+        ref = np.maximum(oracle.indice_conv(feat, W, pairs, num, n_out, False, subm) + bias, 0)
+        np.testing.assert_allclose(res[1], ref, rtol=1e-4, atol=1e-4)
+
+
+def test_neighbor_table_order_beyond_one_grid_of_workgroups():
+    """600 001 rows (the mask kernel's launch is capped at 2048 workgroups and strides over the rest): the order is
+    numpy's stable argsort of the rows' bit sets."""
+    rng = np.random.default_rng(77)
+    n = 600001
+    t = np.where(rng.random((n, 27)) < 0.5, rng.integers(0, n, (n, 27)), -1).astype(np.int32)
+    order = ops.neighbor_table_order(dev(t), n).cpu().numpy()
+    key = ((t >= 0).astype(np.uint64) << np.arange(27, dtype=np.uint64)).sum(1)
+    np.testing.assert_array_equal(order, np.lexsort((key, np.arange(n) // 4096)))
+
+
 def test_half_precision_backward_entries(oracle):
     """indice_conv_backward_half / indice_maxpool_backward_half (src/all.cc:36-37, 48-50): input and filter gradients
     from fp16 rows with fp32 accumulation, rounded once -- within fp16 rounding of the oracle's fp32 gradients of
