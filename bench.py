@@ -22,7 +22,7 @@ Rank 0 prints ONE JSON line: whole-job sequences/s plus
                 iterations x {budget test + moments, searches, solve, apply}; resident schedules: one kernel).
                 HIP events on the chunk's first and last dispatch inside the timed steps; achieved = the chunk's
                 algorithmic bytes / its span; traffic from the PMC passes of the same command
-                (profiles/r04_icp_hbm_pmc.json). `stages` lists the other stages (one extra, untimed,
+                (profiles/r05_icp_hbm_pmc.json). `stages` lists the other stages (one extra, untimed,
                 device-synchronised step over one sequence).
   cpu_baseline  the CPU oracle (C++ restatement, kind "port"), serial and OpenMP over the host's
                 cores, timed on a bounded sample of the same sequence (subsample, ground removal, a proposal
@@ -494,22 +494,24 @@ def main():
         achieved = (bytes_8d / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         achieved_impl = (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of THIS schedule (tools/pmc_batch.sh ->
-        # profiles/r04_icp_hbm_pmc.json, written by tools/summarize_pmc.py); null when no such file exists
+        # profiles/r05_icp_hbm_pmc.json, written by tools/derive_icp_traffic.py); null when no such file exists
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r05_icp_hbm_pmc.json")
-        if not os.path.exists(pmc_path):
+        on_8d = os.path.exists(pmc_path)  # (round 5's file: the ratio is taken against SURVEY 8(d)'s bytes)
+        if not on_8d:
             pmc_path = os.path.join(ROOT, "profiles", "r04_icp_hbm_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
             ratio = pmc.get("icp_chunk_traffic_over_algorithmic")
             if ratio and launches > 0:
-                traffic = round(ratio * nbytes / launches, 1)
-            traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                           "this command (same schedule), (fetch + write) / the implementation's bytes = %s (raw "
-                           "FETCH_SIZE; %s with the guide's x2 correction for gfx950), times this run's "
-                           "impl_bytes_per_launch" % (os.path.basename(pmc_path), ratio,
-                                                      pmc.get("icp_chunk_traffic_over_algorithmic_fetch_x2")))
+                traffic = round(ratio * (bytes_8d if on_8d else nbytes) / launches, 1)
+            traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (same schedule), "
+                           "(fetch + write) / %s = %s (raw FETCH_SIZE; %s with the guide's x2 correction for gfx950), times "
+                           "this run's %s" % (os.path.basename(pmc_path),
+                                              "the algorithmic bytes (SURVEY 8(d))" if on_8d else "the implementation's bytes",
+                                              ratio, pmc.get("icp_chunk_traffic_over_algorithmic_fetch_x2"),
+                                              "algorithmic_bytes_per_launch" if on_8d else "impl_bytes_per_launch"))
         line = {
             "metric": baseline_metric(),
             "value": round(total_sequences / dt, 5),
