@@ -105,6 +105,33 @@ def main():
         err = (f16.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
         half = {"ms_per_forward": round(s.elapsed_time(e) / args.reps, 3),
                 "max_abs_error_over_fp32_max": round(err, 5)}
+    # per-layer time of the conv kernels alone (one extra forward per precision, HIP events around every conv call on
+    # the cached table; the rulebooks, the VFE and the BatchNorm folds are what is left of a forward)
+    from pcseqlearning_amd import ops as pops
+
+    def layer_times(fwd):
+        spans = []
+        orig32, orig16 = pops.indice_conv_table, pops.indice_conv_table_half
+
+        def timed(fn):
+            def call(features, filters, table, num_out, *a, **k):
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                r = fn(features, filters, table, num_out, *a, **k)
+                e0.record()
+                spans.append((int(filters.shape[-2]), int(filters.shape[-1]), int(num_out), s0, e0))
+                return r
+            return call
+        pops.indice_conv_table, pops.indice_conv_table_half = timed(orig32), timed(orig16)
+        try:
+            fwd()
+            torch.cuda.synchronize()
+        finally:
+            pops.indice_conv_table, pops.indice_conv_table_half = orig32, orig16
+        return [(ci, co, n, s0.elapsed_time(e0)) for ci, co, n, s0, e0 in spans]
+
+    conv_ms = layer_times(forward)
+    conv_ms16 = layer_times(forward_half) if args.half else None
     # flops of the conv layers from the rulebooks of the last forward
     d = out["encoded_spconv_tensor"].indice_dict
     chans = {"subm1": [(5, 16), (16, 16)], "spconv2": [(16, 32)], "subm2": [(32, 32)] * 2,
@@ -125,8 +152,23 @@ def main():
             by = 4 * v_in * cin + 4 * v_out * cout + 8 * num + 4 * kv * cin * cout
             flops += fl
             hbm_bytes += by
-            layers_out.append({"rulebook": key, "cin": cin, "cout": cout, "pairs": num, "mflop": round(fl / 1e6, 1),
-                               "algorithmic_MB": round(by / 1e6, 2)})
+            row = {"rulebook": key, "cin": cin, "cout": cout, "pairs": num, "mflop": round(fl / 1e6, 1),
+                   "algorithmic_MB": round(by / 1e6, 2)}
+            li = len(layers_out)
+            if li < len(conv_ms) and conv_ms[li][:2] == (cin, cout):
+                ms = conv_ms[li][3]
+                row["conv_kernel_ms"] = round(ms, 4)
+                row["tflops"] = round(fl / (ms * 1e-3) / 1e12, 2)
+                row["frac_of_f32_mfma_peak"] = round(fl / (ms * 1e-3) / 1e12 / 157.3, 4)
+                row["algorithmic_GBs"] = round(by / (ms * 1e-3) / 1e9, 1)
+                row["frac_of_8TBs"] = round(by / (ms * 1e-3) / 1e9 / 8000.0, 4)
+            if conv_ms16 is not None and li < len(conv_ms16) and conv_ms16[li][:2] == (cin, cout):
+                ms = conv_ms16[li][3]
+                by16 = by - (4 * v_in * cin + 4 * v_out * cout + 4 * kv * cin * cout) / 2.0
+                row["fp16"] = {"conv_kernel_ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                               "algorithmic_GBs": round(by16 / (ms * 1e-3) / 1e9, 1),
+                               "frac_of_8TBs": round(by16 / (ms * 1e-3) / 1e9 / 8000.0, 4)}
+            layers_out.append(row)
             v_in = v_out
     t_best = results.get("mfma", results.get("fma")) * 1e-3
     line = {"workload": f"config5: VoxelBackBone8x forward, {args.batch} synthetic frame(s) per batch",
@@ -144,7 +186,9 @@ def main():
             "ms_per_forward": {k: round(v, 3) for k, v in results.items()},
             "conv_gflop": round(flops / 1e9, 3),
             "conv_tflops_mfma_path": round(flops / (results.get("mfma", results.get("fma")) * 1e-3) / 1e12, 3),
-            "output_voxels_per_rulebook": voxels, "bit_identical_mfma_vs_fma": len(modes) == 2}
+            "output_voxels_per_rulebook": voxels, "bit_identical_mfma_vs_fma": len(modes) == 2,
+            "conv_kernels_ms_per_forward": {"fp32": round(sum(x[3] for x in conv_ms), 3),
+                                            "fp16": round(sum(x[3] for x in conv_ms16), 3) if conv_ms16 else None}}
     if half is not None:
         t16 = half["ms_per_forward"] * 1e-3
         hb16 = hbm_bytes / 2.0  # fp16 rows: half the feature and filter bytes (the pair lists stay 8 bytes)
