@@ -5,3 +5,4 @@ from ....ops import correspondence, hash_insert_gpu, points_in_radius_gpu, radiu
 
 torch_hash_cuda = __import__(__name__, fromlist=["hash_insert_gpu"])
 from .torch_hash_modules import ChamferDistance, RadiusGraph  # noqa: F401,E402
+from .torch_hash_utils import HashTable  # noqa: F401,E402

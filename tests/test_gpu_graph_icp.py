@@ -506,3 +506,58 @@ def test_torch_hash_module_fronts(oracle):
     f, g = dm.min(1).values, dm.min(0).values
     want = float((f[f <= 2.0] ** 2).mean() + (g[g <= 2.0] ** 2).mean())
     assert abs(got - want) < 1e-5 * max(want, 1.0), (got, want)
+
+
+def test_torch_hash_table_front():
+    """pcdet.ops.torch_hash.HashTable (torch_hash_utils.py:9-363 of the reference): the stateful front on the drop-in
+    table ops. Points [n, 4] = (x, y, z, frame), cells as wide as the radius, so everything within the radius of a
+    query lies in the 3 x 3 x 3 cells the ops walk: correspondences, points in radius and the voxel graph against brute
+    force; the one-call forms against insert + step 2."""
+    from pcseqlearning_amd.pcdet.ops.torch_hash import HashTable
+    rng = np.random.default_rng(51)
+    n, m = 4000, 1500
+    ref = np.concatenate([rng.uniform(0, 10, (n, 3)), rng.integers(0, 2, (n, 1))], 1).astype(np.float32)
+    qry = np.concatenate([rng.uniform(0, 10, (m, 3)), rng.integers(0, 2, (m, 1))], 1).astype(np.float32)
+    vs = torch.tensor([0.5, 0.5, 0.5, 1.0])
+    pcr = torch.tensor([0.0, 0.0, 0.0, 0.0, 10.0, 10.0, 10.0, 2.0])
+    ht = HashTable(size=2 ** 15, device=DEV)
+    ht.hash_into_gpu(dev(ref), vs, pcr)
+    cells_r = np.round(ref / vs.numpy()).astype(np.int64)
+    cells_q = np.round(qry / vs.numpy()).astype(np.int64)
+    for off in (0, 1):
+        c = ht.find_corres_step2(dev(qry), off).cpu().numpy()
+        # brute force: the nearest reference point among the cells within one step (frame cell + off exactly)
+        found = dict(zip(c[0].tolist(), c[1].tolist()))
+        for q in range(0, m, 7):
+            dc = cells_r[:, :3] - cells_q[q, :3]
+            near = (np.abs(dc).max(1) <= 1) & (cells_r[:, 3] == cells_q[q, 3] + off)
+            if not near.any():
+                assert q not in found
+                continue
+            cand = np.nonzero(near)[0]
+            d = ((ref[cand] - qry[q]) ** 2).sum(1)
+            assert q in found and abs(d.min() - ((ref[found[q]] - qry[q]) ** 2).sum()) < 1e-5
+    # points within 0.5 of some query of the same frame
+    got = set(ht.points_in_radius_step2(dev(qry), 0, radius=0.5).cpu().numpy().tolist())
+    same = ref[:, None, 3] == qry[None, :, 3]
+    d2 = ((ref[:, None, :3] - qry[None, :, :3]) ** 2).sum(-1)
+    want = set(np.nonzero(((d2 < 0.25 - 1e-5) & same).any(1))[0].tolist())
+    maybe = set(np.nonzero(((d2 < 0.25 + 1e-5) & same).any(1))[0].tolist())
+    assert want <= got <= maybe
+    # voxel graph: (query, reference) pairs within the radius, at most k per query
+    e = ht.voxel_graph_step2(dev(qry), 0, radius=0.5, max_num_neighbors=64).cpu().numpy()
+    pairs = set(zip(e[0].tolist(), e[1].tolist()))
+    sure = set(zip(*np.nonzero(((d2 < 0.25 - 1e-5) & same).T)))
+    loose = set(zip(*np.nonzero(((d2 < 0.25 + 1e-5) & same).T)))
+    assert sure <= pairs <= loose
+    # the one-call forms
+    ht2 = HashTable(size=2 ** 15, device=DEV)
+    a = ht2.find_corres(dev(ref), dev(qry), vs, pcr, 0)
+    b = ht.find_corres_step2(dev(qry), 0)
+    assert torch.equal(a, b)
+    g = ht2.voxel_graph(dev(ref), dev(qry), vs, pcr, 0, radius=0.5, max_num_neighbors=64)
+    assert set(zip(g[0].tolist(), g[1].tolist())) == pairs
+    ht2.clear()
+    assert ht2.find_corres_step2(dev(qry), 0).shape == (2, 0)
+    with pytest.raises(ValueError):
+        HashTable(size=1024, device=DEV).find_corres_step2(dev(qry), 0)
