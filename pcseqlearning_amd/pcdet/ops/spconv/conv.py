@@ -177,3 +177,32 @@ class SparseInverseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
         super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
                          indice_key=indice_key)
+
+
+# ---- the 2-D forms (conv.py:207-229, 282-305, 334-349, 370-393 of the reference): the same module on planes; the
+# rulebook of a plane is a one-cell-deep volume's (ops.get_indice_pairs)
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, True, indice_key=indice_key)
+
+
+class SparseConvTranspose2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, transposed=True, indice_key=indice_key)
+
+
+class SparseInverseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(2, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)

@@ -26,8 +26,23 @@ def _list(v, ndim):
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
                      out_padding=0, subm=False, transpose=False, grid=None, with_table=False):
     ndim = indices.shape[1] - 1
+    if ndim == 2:
+        # get_indice_pairs_2d (src/all.cc:22-25 of the reference): a plane is a volume one cell deep -- indices
+        # (b, y, x) -> (b, 0, y, x), window (1, ky, kx). The kernel offsets' row-major numbers, the outputs' linear
+        # indices and the order in which outputs first appear are the 2-D ones, so pairs / counts are the 2-D
+        # rulebook's and the output ids are its ids with the zero column dropped.
+        import torch
+        wide = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1).contiguous()
+        pad3 = lambda v, fill: [fill] + _list(v, 2)  # noqa: E731
+        res = get_indice_pairs(wide, batch_size, [1] + list(spatial_shape), pad3(ksize, 1), pad3(stride, 1),
+                               pad3(padding, 0), pad3(dilation, 1), pad3(out_padding, 0), subm, transpose, grid,
+                               with_table)
+        outids = res[0]
+        outids = indices if subm else torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
+        return (outids, *res[1:])
     if ndim != 3:
-        raise NotImplementedError("only 3-D rulebooks are on the hot path")
+        raise NotImplementedError("2-D and 3-D rulebooks only (the reference's 4-D instantiation, src/all.cc:28-29, "
+                                  "is not on the hot path)")
     ksize, stride, padding = _list(ksize, ndim), _list(stride, ndim), _list(padding, ndim)
     dilation, out_padding = _list(dilation, ndim), _list(out_padding, ndim)
     for d, s in zip(dilation, stride):

@@ -33,3 +33,8 @@ class SparseMaxPool(SparseModule):
 class SparseMaxPool3d(SparseMaxPool):
     def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
         super().__init__(3, kernel_size, stride, padding, dilation)
+
+
+class SparseMaxPool2d(SparseMaxPool):
+    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__(2, kernel_size, stride, padding, dilation)

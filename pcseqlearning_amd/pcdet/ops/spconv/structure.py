@@ -35,7 +35,7 @@ class SparseConvTensor(object):
         shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
         out = torch.zeros(*shape, dtype=self.features.dtype, device=self.features.device)
         idx = self.indices.long()
-        out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = self.features
+        out[tuple(idx[:, d] for d in range(idx.shape[1]))] = self.features  # (2-D and 3-D alike)
         if not channels_first:
             return out
         nd = len(self.spatial_shape)

@@ -645,3 +645,87 @@ def test_half_precision_backward_entries(oracle):
                     hit = feat[i] == pooled[o]
                     want[i] = np.where(hit, (want[i] + og[o]).astype(np.float16), want[i])
             np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def _rulebook_2d(idx, shape, ks, st, pd, subm):
+    """get_indice_pairs_2d restated in plain Python (geometry.h:25-195 for NDim = 2): inputs in order, kernel offsets
+    row-major, an output id is its rank of first appearance; subM: outputs = inputs, an offset pairs a voxel with the
+    input found at (p + offset - centre)."""
+    kv = ks[0] * ks[1]
+    pairs = [[] for _ in range(kv)]
+    if subm:
+        where = {}
+        for j, (b, y, x) in enumerate(idx.tolist()):
+            where[(b, y, x)] = j
+        for j, (b, y, x) in enumerate(idx.tolist()):
+            for ky in range(ks[0]):
+                for kx in range(ks[1]):
+                    # the output that input j reaches through offset (ky, kx): out * 1 - pad + k = in
+                    o = (b, y + pd[0] - ky, x + pd[1] - kx)
+                    if o in where:
+                        pairs[ky * ks[1] + kx].append((j, where[o]))
+        return idx, pairs
+    out_shape = [(shape[d] + 2 * pd[d] - (ks[d] - 1) - 1) // st[d] + 1 for d in range(2)]
+    ids, order = {}, []
+    for j, (b, y, x) in enumerate(idx.tolist()):
+        for ky in range(ks[0]):
+            for kx in range(ks[1]):
+                ny, nx = y + pd[0] - ky, x + pd[1] - kx
+                if ny % st[0] or nx % st[1]:
+                    continue
+                oy, ox = ny // st[0], nx // st[1]
+                if not (0 <= oy < out_shape[0] and 0 <= ox < out_shape[1]):
+                    continue
+                key = (b, oy, ox)
+                if key not in ids:
+                    ids[key] = len(order)
+                    order.append(key)
+                pairs[ky * ks[1] + kx].append((j, ids[key]))
+    return np.array(order, np.int32).reshape(-1, 3), pairs
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_rulebook_and_modules_in_two_dimensions(subm):
+    """get_indice_pairs_2d / SubMConv2d / SparseConv2d / SparseMaxPool2d (src/all.cc:22-25, conv.py:207-229, 370-393,
+    pool.py:74-79 of the reference): a plane goes through the 3-D rulebook as a volume one cell deep. The pairs of
+    every offset, as SETS per offset, and the conv against a plain-Python 2-D restatement; the output ids of the
+    strided form are the restatement's up to the order the reference leaves to its hash walk (compared as sets, the
+    features row by row through the ids)."""
+    from pcseqlearning_amd.pcdet.ops import spconv
+    rng = np.random.default_rng(12 + int(subm))
+    shape = [40, 36]
+    cells = rng.permutation(2 * 40 * 36)[:900]
+    idx = np.stack([cells // (40 * 36), (cells // 36) % 40, cells % 36], 1).astype(np.int32)
+    ks, st, pd = ([3, 3], [1, 1], [1, 1]) if subm else ([3, 3], [2, 2], [1, 1])
+    outids, pairs, num = spconv.ops.get_indice_pairs(dev(idx), 2, shape, ks, st, pd, 1, 0, subm)[:3]
+    want_ids, want_pairs = _rulebook_2d(idx, shape, ks, st, pd, subm)
+    got_ids = outids.cpu().numpy()
+    assert got_ids.shape[1] == 3
+    assert sorted(map(tuple, got_ids.tolist())) == sorted(map(tuple, want_ids.tolist()))
+    p, n = pairs.cpu().numpy(), num.cpu().numpy()
+    to_key = {i: tuple(r) for i, r in enumerate(got_ids.tolist())}
+    want_key = {i: tuple(r) for i, r in enumerate(want_ids.tolist())}
+    for k in range(9):
+        got = {(int(a), to_key[int(b)]) for a, b in zip(p[k, 0, :n[k]], p[k, 1, :n[k]])}
+        want = {(a, want_key[b]) for a, b in want_pairs[k]}
+        assert got == want, k
+    # the module: conv + max-pool on the plane against dense torch ops
+    feat = rng.normal(0, 1, (idx.shape[0], 4)).astype(np.float32)
+    x = spconv.SparseConvTensor(dev(feat), dev(idx), shape, 2)
+    conv = (spconv.SubMConv2d(4, 8, 3, padding=1, bias=True) if subm else
+            spconv.SparseConv2d(4, 8, 3, stride=2, padding=1, bias=True)).to(DEV)
+    with torch.no_grad():
+        y = conv(x)
+        dense_in = x.dense()                                   # [B, C, H, W]
+        w = conv.weight.permute(3, 2, 0, 1).contiguous()       # [Cout, Cin, ky, kx]
+        ref = torch.nn.functional.conv2d(dense_in, w, conv.bias, stride=st, padding=pd)
+        yi = y.indices.long()
+        np.testing.assert_allclose(y.features.cpu().numpy(), ref[yi[:, 0], :, yi[:, 1], yi[:, 2]].cpu().numpy(),
+                                   rtol=1e-4, atol=1e-4)
+        if not subm:
+            pool = spconv.SparseMaxPool2d(3, stride=2, padding=1)
+            z = pool(x)
+            dz = torch.nn.functional.max_pool2d(dense_in.clamp(min=0), 3, stride=2, padding=1)
+            zi = z.indices.long()
+            np.testing.assert_allclose(z.features.cpu().numpy(), dz[zi[:, 0], :, zi[:, 1], zi[:, 2]].cpu().numpy(),
+                                       rtol=1e-6, atol=1e-6)
