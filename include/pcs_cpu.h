@@ -71,6 +71,14 @@ int pcs_cpu_l1_minimization(const float* pillar_min_z, const float* weight, int 
                             float* height_out, int32_t* d_iters, void* ws, size_t ws_bytes,
                             pcs_stream_t stream);
 
+/* the radius graph's two phases (pcs_radius_graph_search / _emit): the workspace carries the edges between them */
+size_t pcs_cpu_radius_graph_workspace_bytes(int64_t N, int64_t M, int max_nbr);
+int pcs_cpu_radius_graph_search(const float* ref, int64_t N, const float* query, int64_t M, float radius,
+                                float cell_size, int dframe_min, int dframe_max, int max_nbr, int sort_by_dist,
+                                int64_t* d_num_edges, void* ws, size_t ws_bytes, pcs_stream_t stream);
+int pcs_cpu_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query, float* dists,
+                              const void* ws, size_t ws_bytes, pcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

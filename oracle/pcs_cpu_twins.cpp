@@ -27,6 +27,8 @@ void orc_indice_conv_f32(const float* feat, int64_t num_in, int cin, const float
                          int inverse, int subm, float* out);
 int64_t orc_connected_components(const int64_t* e0, const int64_t* e1, int64_t E, int64_t n, int64_t* component);
 void orc_points_in_boxes(const float* pts, int64_t N, const float* boxes, int B, int32_t* out);
+int64_t orc_radius_graph(const float* ref, int64_t N, const float* qry, int64_t M, float radius, const int* qmin,
+                         const int* qmax, int max_nbr, int sort_by_dist, int64_t* e_ref, int64_t* e_qry, float* dists);
 void orc_ransac_plane_hypotheses(const float* xyz, const int32_t* seg_start, int64_t n, const float* min_z,
                                  const float* max_z, const float* ratios, int R, const float* origin, int64_t P,
                                  float sigma2, float delta, int max_rounds, float hit_below, float* best_center,
@@ -166,6 +168,47 @@ int pcs_cpu_l1_minimization(const float* pillar_min_z, const float* weight, int 
                                      height_out);
   if (d_iters) *d_iters = it;
   return PCS_OK;
+}
+
+
+// ---- radius graph (round 5): pcs_radius_graph_search / _emit's two phases on the host. The workspace holds the
+// edges between the calls: [E][e_ref M * max_nbr][e_query M * max_nbr][dists M * max_nbr]. cell_size is the device
+// engine's tuning knob and has no effect here (the restatement walks the reference's own cells of one radius).
+size_t pcs_cpu_radius_graph_workspace_bytes(int64_t N, int64_t M, int max_nbr) {
+  (void)N;
+  const size_t cap = (size_t)(M > 0 ? M : 1) * (size_t)(max_nbr > 0 ? max_nbr : 1);
+  return sizeof(int64_t) + cap * (2 * sizeof(int64_t) + sizeof(float));
+}
+int pcs_cpu_radius_graph_search(const float* ref, int64_t N, const float* query, int64_t M, float radius, float,
+                                int dframe_min, int dframe_max, int max_nbr, int sort_by_dist, int64_t* d_num_edges,
+                                void* ws, size_t ws_bytes, pcs_stream_t) {
+  if (!d_num_edges || !ws || N < 0 || M < 0 || (N > 0 && !ref) || (M > 0 && !query) || !(radius > 0.f) ||
+      dframe_min > dframe_max || max_nbr < 1 || max_nbr > 32)
+    return CPU_ERR_ARG;
+  if (ws_bytes < pcs_cpu_radius_graph_workspace_bytes(N, M, max_nbr)) return PCS_ERR_WORKSPACE;
+  const size_t cap = (size_t)(M > 0 ? M : 1) * (size_t)max_nbr;
+  int64_t* head = (int64_t*)ws;
+  int64_t* e_ref = head + 1;
+  int64_t* e_qry = e_ref + cap;
+  float* dists = (float*)(e_qry + cap);
+  const int qmin[4] = {dframe_min, -1, -1, -1}, qmax[4] = {dframe_max, 1, 1, 1};
+  head[0] = orc_radius_graph(ref, N, query, M, radius, qmin, qmax, max_nbr, sort_by_dist, e_ref, e_qry, dists);
+  *d_num_edges = head[0];
+  return CPU_OK;
+}
+int pcs_cpu_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query, float* dists,
+                              const void* ws, size_t ws_bytes, pcs_stream_t) {
+  if (!ws || M < 0 || max_nbr < 1 || max_nbr > 32) return CPU_ERR_ARG;
+  if (ws_bytes < pcs_cpu_radius_graph_workspace_bytes(N, M, max_nbr)) return PCS_ERR_WORKSPACE;
+  const size_t cap = (size_t)(M > 0 ? M : 1) * (size_t)max_nbr;
+  const int64_t* head = (const int64_t*)ws;
+  const int64_t E = head[0];
+  if (E <= 0) return CPU_OK;
+  if (!e_ref || !e_query) return CPU_ERR_ARG;
+  std::memcpy(e_ref, head + 1, (size_t)E * sizeof(int64_t));
+  std::memcpy(e_query, head + 1 + cap, (size_t)E * sizeof(int64_t));
+  if (dists) std::memcpy(dists, (const float*)(head + 1 + 2 * cap), (size_t)E * sizeof(float));
+  return CPU_OK;
 }
 
 }  // extern "C"

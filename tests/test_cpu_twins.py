@@ -155,3 +155,38 @@ def test_ground_stage_twins():
                                         ctypes.c_int(1), ctypes.c_float(0.5), ctypes.c_int(10000), p(h), p(iters), None,
                                         ctypes.c_size_t(0), None) == 0
     assert 10 < iters[0] <= 10000 and abs(float(np.median(h)) - 0.3) < 0.05 and h[5, 5] < 1.0
+
+
+def test_radius_graph_twins():
+    """pcs_cpu_radius_graph_search / _emit (the entries' own argument lists; the workspace carries the edges between the
+    two phases): 16 nearest within the radius, grouped by query, nearest first, against brute force -- one frame offset,
+    ties broken by the reference index."""
+    main, _ = _libs()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(21)
+    N, M, K, r = 1500, 400, 16, 0.8
+    ref = np.concatenate([rng.integers(0, 2, (N, 1)), rng.uniform(0, 6, (N, 3))], 1).astype(np.float32)
+    qry = np.concatenate([rng.integers(0, 2, (M, 1)), rng.uniform(0, 6, (M, 3))], 1).astype(np.float32)
+    main.pcs_cpu_radius_graph_workspace_bytes.restype = ctypes.c_size_t
+    nb = main.pcs_cpu_radius_graph_workspace_bytes(ctypes.c_int64(N), ctypes.c_int64(M), ctypes.c_int(K))
+    ws = np.zeros(nb, np.uint8)
+    E = np.zeros(1, np.int64)
+    assert main.pcs_cpu_radius_graph_search(p(ref), ctypes.c_int64(N), p(qry), ctypes.c_int64(M), ctypes.c_float(r),
+                                            ctypes.c_float(0.0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(K),
+                                            ctypes.c_int(1), p(E), p(ws), ctypes.c_size_t(nb), None) == 0
+    e_ref, e_q, d = np.zeros(E[0], np.int64), np.zeros(E[0], np.int64), np.zeros(E[0], np.float32)
+    assert main.pcs_cpu_radius_graph_emit(ctypes.c_int64(N), ctypes.c_int64(M), ctypes.c_int(K), p(e_ref), p(e_q), p(d),
+                                          p(ws), ctypes.c_size_t(nb), None) == 0
+    d2 = ((ref[None, :, :] - qry[:, None, :]) ** 2).sum(-1)  # 4-D: the frame column counts
+    want_q, want_r = [], []
+    for q in range(M):
+        cand = np.nonzero((d2[q] <= np.float32(r) * np.float32(r)) & (ref[:, 0] == qry[q, 0]))[0]
+        cand = cand[np.lexsort((cand, d2[q, cand]))][:K]
+        want_q += [q] * len(cand)
+        want_r += cand.tolist()
+    assert E[0] == len(want_q) and e_q.tolist() == want_q
+    # (fp32 sums in the restatement's own order: compare the neighbour SETS per query and the sortedness)
+    for q in range(0, M, 13):
+        sel = e_q == q
+        assert set(e_ref[sel].tolist()) == {b for a, b in zip(want_q, want_r) if a == q}
+        assert (np.diff(d[sel]) >= 0).all()
