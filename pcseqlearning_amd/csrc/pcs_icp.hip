@@ -595,10 +595,49 @@ __device__ __forceinline__ bool icp_second_level_impl(const IcpProblem& pr, cons
 // partner is near enough to be searched around (g2_nearest_seeded8). Exact: the same neighbours as a
 // full search, always. Workgroup wgx of nwg takes the rounds wgx, wgx + nwg, ... of BS queries; s_step
 // is the step table of iteration k-1 (in LDS when the workgroup serves backward queries).
+// What the budget test of one query needs from memory before it can decide anything: the query, its partner of the
+// last iteration where it is now, its budget, the pair's component. Two levels of dependent loads (partner and
+// component follow the partner's index) that the wide launch puts in flight BEFORE its workgroup stages the step table
+// and passes its barrier (icp_nn_kernel): the chain of a settled query is then table | query -> partner -> origin
+// instead of table -> query -> partner -> origin.
+struct BudgetPre {
+  float4 p, sp;
+  int s, c_pair;
+  float bud;  // forward queries: already less what the query has moved since the last iteration
+};
+__device__ __forceinline__ BudgetPre icp_budget_load(const IcpProblem& pr, int k, int Mn, int Rn, int qid) {
+  BudgetPre q;
+  q.p = q.sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  q.s = -1;
+  q.c_pair = 0;
+  q.bud = 0.f;
+  if (qid >= Mn + Rn) return q;
+  const bool fwd = qid < Mn;
+  if (fwd) {
+    q.p = pr.mov[qid];
+    const float4 o = pr.prev[qid];
+    q.s = (pr.nn_f + (size_t)((k - 1) & 1) * pr.capM)[qid];
+    q.bud = (pr.bud_f + (size_t)((k - 1) & 1) * pr.capM)[qid];
+    const float dx = q.p.y - o.y, dy = q.p.z - o.z, dz = q.p.w - o.w;
+    const float disp = sqrtf((dx * dx + dy * dy) + dz * dz);
+    q.bud = q.bud - disp * 1.000001f - 1e-7f;
+  } else {
+    q.p = pr.ref[qid - Mn];
+    q.s = (pr.nn_b + (size_t)((k - 1) & 1) * pr.capR)[qid - Mn];
+    q.bud = (pr.bud_b + (size_t)((k - 1) & 1) * pr.capR)[qid - Mn];
+  }
+  // (the pair's component is requested together with the partner, not after the distance test: one level less
+  //  in the chain of dependent loads that a settled query is -- point / partner index, partner, origin)
+  q.c_pair = (fwd || q.s >= 0) ? pr.comp[fwd ? qid : q.s] : 0;
+  if (q.s >= 0) q.sp = fwd ? pr.ref[q.s] : pr.mov[q.s];
+  return q;
+}
+
 template <int BS, bool SPLIT = true>
 __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, int Mn, int Rn, int wgx, int nwg,
                                                  const GridDesc& g, const MomTable& mt,
-                                                 const unsigned int* __restrict__ s_step, int* cnt4) {
+                                                 const unsigned int* __restrict__ s_step, int* cnt4,
+                                                 const BudgetPre* first_round = nullptr) {
   const int nq = Mn + Rn;
   const int nround = (nq + BS - 1) / BS;
   const double lim2 = icp_limit_sq(nq);
@@ -607,10 +646,6 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
   int32_t* nn_b = pr.nn_b + (size_t)(k & 1) * pr.capR;
   float* bud_f = pr.bud_f + (size_t)(k & 1) * pr.capM;
   float* bud_b = pr.bud_b + (size_t)(k & 1) * pr.capR;
-  const int32_t* __restrict__ seed_f = pr.nn_f + (size_t)((k - 1) & 1) * pr.capM;
-  const int32_t* __restrict__ seed_b = pr.nn_b + (size_t)((k - 1) & 1) * pr.capR;
-  const float* __restrict__ sbud_f = pr.bud_f + (size_t)((k - 1) & 1) * pr.capM;
-  const float* __restrict__ sbud_b = pr.bud_b + (size_t)((k - 1) & 1) * pr.capR;
   const Grid2 g_ref = g2_view(pr.gr, Rn), g_mov = g2_view(pr.gm[pr.st->gcur[k & 1] & 1], Mn);
   for (int r = wgx; r < nround; r += nwg) {  // whole waves stay together (ballots below)
     const int qid = r * BS + threadIdx.x;
@@ -623,21 +658,13 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
     bool m_act = false;  // a settled pair whose moments are due: (moving point, reference point, component)
     float4 m_p = make_float4(0.f, 0.f, 0.f, 0.f), m_q = m_p;
     int m_c = 0;
+    // (the first round of a wide launch arrives loaded: see BudgetPre)
+    const BudgetPre ld = (first_round && r == wgx) ? *first_round : icp_budget_load(pr, k, Mn, Rn, qid);
     if (valid) {
-      float4 p, sp = make_float4(0.f, 0.f, 0.f, 0.f);
-      int s;
-      float bud, disp;
-      if (fwd) {
-        p = pr.mov[qid];
-        float4 o = pr.prev[qid];
-        s = seed_f[qid];
-        bud = sbud_f[qid];
-        float dx = p.y - o.y, dy = p.z - o.z, dz = p.w - o.w;
-        disp = sqrtf((dx * dx + dy * dy) + dz * dz);
-      } else {
-        p = pr.ref[qid - Mn];
-        s = seed_b[qid - Mn];
-        bud = sbud_b[qid - Mn];
+      const float4 p = ld.p, sp = ld.sp;
+      const int s = ld.s;
+      float bud = ld.bud;
+      if (!fwd) {
         // a moving point that can matter for this query lies in the 3 x 3 x 3 blocks of 4^3 cells
         // around it -- 12 cells per axis, i.e. at most 2 x 2 x 2 blocks of 8^3 cells: the largest
         // step recorded there bounds how far any such point has moved since iteration k-1
@@ -648,16 +675,12 @@ __device__ __forceinline__ void icp_budget_phase(const IcpProblem& pr, int k, in
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           m = max(m, s_step[icp_step_slot(sx + (q & 1), sy + ((q >> 1) & 1), sz + (q >> 2))]);
-        disp = __uint_as_float(m);
+        bud = bud - __uint_as_float(m) * 1.000001f - 1e-7f;
       }
-      bud = bud - disp * 1.000001f - 1e-7f;
       float dist2 = __builtin_inff();
       float c0s = 0.f;  // the frame term of the distance
-      // (the pair's component is requested together with the partner, not after the distance test: one level less
-      //  in the chain of dependent loads that a settled query is -- point / partner index, partner, origin)
-      const int c_pair = (fwd || s >= 0) ? pr.comp[fwd ? qid : s] : 0;
+      const int c_pair = ld.c_pair;
       if (s >= 0) {
-        sp = fwd ? pr.ref[s] : pr.mov[s];
         float d0 = sp.x - p.x, d1 = sp.y - p.y, d2 = sp.z - p.z, d3 = sp.w - p.w;
         dist2 = 0.f;
         dist2 = dist2 + d0 * d0;
@@ -1380,15 +1403,19 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   const IcpProblem& pr = tab[bt.idx[blockIdx.y]];
   IcpState* st = pr.st;
   const int k = kbase.v[blockIdx.y] + 1 + j;
+  // (the sizes are read beside the gate, not after its barrier: one level of dependent loads less)
+  int Mn, Rn, Ra;
+  icp_sizes(pr, Mn, Rn, Ra);
   __shared__ int s_go;
   if (threadIdx.x == 0) s_go = (k == 1 || k > wide_limit || k > pr.max_iter || k > st->stop_iter) ? 0 : 1;  // (iteration 1: icp_first_kernel)
   __syncthreads();
   if (!s_go) return;
-  int Mn, Rn, Ra;
-  icp_sizes(pr, Mn, Rn, Ra);
   const int nq = Mn + Rn;
   const int nround = (nq + kBlock - 1) / kBlock;
   if (blockIdx.x != 0 && (int)blockIdx.x >= nround) return;
+  // the first round's queries, partners and components are requested now: they are in flight while the workgroup
+  // settles the stop rule, clears its moment table and stages the step table
+  const BudgetPre pre = icp_budget_load(pr, k, Mn, Rn, (int)blockIdx.x * kBlock + (int)threadIdx.x);
   // workgroup 0 settles the stop rule of iteration k-1 (its loss terms were written by the previous
   // launch). The other workgroups may run before the stop is known: they only write this iteration's
   // neighbour buffers, which nothing reads after a stop.
@@ -1408,7 +1435,7 @@ icp_nn_kernel(const IcpProblem* __restrict__ tab, Batch bt, BatchInts kbase, int
   }
   __syncthreads();
   const GridDesc g = pr.geom->g;
-  icp_budget_phase<kBlock>(pr, k, Mn, Rn, blockIdx.x, gridDim.x, g, mt, s_step, &st->wl_n[0]);
+  icp_budget_phase<kBlock>(pr, k, Mn, Rn, blockIdx.x, gridDim.x, g, mt, s_step, &st->wl_n[0], &pre);
   __syncthreads();
   mom_flush(mt);
 }
