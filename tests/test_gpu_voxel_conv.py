@@ -729,3 +729,50 @@ def test_rulebook_and_modules_in_two_dimensions(subm):
             zi = z.indices.long()
             np.testing.assert_allclose(z.features.cpu().numpy(), dz[zi[:, 0], :, zi[:, 1], zi[:, 2]].cpu().numpy(),
                                        rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kv,n_out,cin,cout", [(1, 1, 16, 16), (3, 127, 32, 32), (8, 129, 64, 64), (9, 1000, 16, 32),
+                                               (27, 4097, 64, 128), (32, 300, 32, 64), (27, 100001, 16, 16)])
+def test_conv_kernel_forms_on_random_tables(kv, n_out, cin, cout):
+    """The conv entries on tables that no rulebook would make -- random partners, rows without any, kernel volumes 1 to
+    32, row counts around the tiles' edges (1, 127, 129, 4097, 100 001), with and without a centre offset: round 5's
+    direct-gather kernels against round 4's staged ones (fp16: identical bits; f32: the same sums in another order
+    inside a 16-channel chunk) and against a float64 restatement."""
+    from pcseqlearning_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(kv * 1000 + n_out % 997 + cin + cout)
+    n_in = max(n_out // 2, 3)
+    table = rng.integers(0, n_in, (n_out, kv)).astype(np.int32)
+    table[rng.random((n_out, kv)) < 0.5] = -1
+    table[rng.random(n_out) < 0.1] = -1
+    feat = rng.normal(0, 1, (n_in, cin)).astype(np.float32)
+    W = rng.normal(0, 0.1, (kv, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    for subm in ((True, False) if kv % 2 else (False,)):
+        got32 = {}
+        for mode in (2, 3):
+            L.check(lib.pcs_conv_use_mfma(mode), "mode")
+            try:
+                got32[mode] = ops.indice_conv_table(dev(feat), dev(W), dev(table), n_out, subm, bias=dev(bias),
+                                                    relu=True).cpu().numpy()
+            finally:
+                L.check(lib.pcs_conv_use_mfma(1), "mode")
+        f64 = np.zeros((n_out, cout))
+        for k in range(kv):
+            sel = table[:, k] >= 0
+            f64[sel] += feat[table[sel, k]].astype(np.float64) @ W[k].astype(np.float64)
+        ref = np.maximum(f64 + bias, 0)
+        np.testing.assert_allclose(got32[2], ref, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got32[3], ref, rtol=2e-4, atol=2e-4)
+        got16 = []
+        for tiles in (1, 0, 2, 3):
+            L.check(lib.pcs_indice_conv_f16_short_tiles(tiles), "tiles")
+            try:
+                got16.append(ops.indice_conv_table_half(dev(feat).half(), dev(W).half(), dev(table), n_out, subm,
+                                                        bias=dev(bias), relu=True).cpu().numpy())
+            finally:
+                L.check(lib.pcs_indice_conv_f16_short_tiles(0), "tiles")
+        for other in got16[1:]:
+            np.testing.assert_array_equal(got16[0].view(np.uint16), other.view(np.uint16))
+        scale = max(float(np.abs(ref).max()), 1.0)
+        assert float(np.abs(got16[0].astype(np.float64) - ref).max()) <= 2.0 ** -7 * scale
