@@ -123,16 +123,19 @@ def queue_gaps(rows):
     by_q = collections.defaultdict(list)
     for s, e, n, q, g, gy in rows:
         if q in icp_q:
-            by_q[q].append((s, e))
+            by_q[q].append((s, e, n))
     bins = [(0, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1000), (1000, 10 ** 9)]
     tot = collections.Counter()
     cnt = collections.Counter()
+    around = collections.Counter()   # gaps of 20-1000 us: (kernel before, kernel after) -> idle ns
+    around_n = collections.Counter()
     span = 0
+    short = lambda n: n.split("(")[0].split("::")[-1][:34]  # noqa: E731
     for q, v in by_q.items():
         v.sort()
         span += v[-1][1] - v[0][0]
-        end = v[0][1]
-        for s, e in v[1:]:
+        end, last = v[0][1], v[0][2]
+        for s, e, n in v[1:]:
             gap = s - end
             if gap > 0:
                 for lo, hi in bins:
@@ -140,10 +143,17 @@ def queue_gaps(rows):
                         tot[(lo, hi)] += gap
                         cnt[(lo, hi)] += 1
                         break
-            end = max(end, e)
+                if 20000 <= gap < 1000000:
+                    around[(short(last), short(n))] += gap
+                    around_n[(short(last), short(n))] += 1
+            if e >= end:
+                end, last = e, n
     if span:
         print("engine queues, idle time by gap length (us): " + ", ".join(
             f"{lo}-{hi if hi < 10 ** 9 else 'inf'}: {cnt[(lo, hi)]} gaps = {100 * tot[(lo, hi)] / span:.1f} %" for lo, hi in bins))
+        print("engine queues, gaps of 20-1000 us by the kernels around them (before -> after: gaps, mean us, % of the queues' time):")
+        for (a, b), t in around.most_common(14):
+            print(f"    {a:34s} -> {b:34s} {around_n[(a, b)]:6d} x {t / around_n[(a, b)] / 1e3:7.1f} us = {100.0 * t / span:5.2f} %")
 
 
 def tick_composition(rows):
