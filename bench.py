@@ -307,6 +307,9 @@ def main():
                          "(0 = no limit, the default; measured in round 5: 2 / 3 / 4 / 6 slots are 1-4 % slower)")
     ap.add_argument("--icp-widening", type=float, default=0.0,
                     help="pcs_icp_set_widening: searches look radius / this further (0 = the library's default, 16)")
+    ap.add_argument("--extract-unit-by-unit", type=int, default=0,
+                    help="1: ClusterTracking's EXTRACT_UNITS_TOGETHER off (the final filter and the extraction of traces unit "
+                         "by unit: round 4's form; same results)")
     ap.add_argument("--chunk-iterations", type=int, default=0,
                     help="pcs_icp_set_chunk_iterations: iterations per chunk of wide launches (0 = the library's default, 8)")
     ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
@@ -392,6 +395,8 @@ def main():
         model.model_cfg["SEQUENCE_START_STAGGER_MS"] = args.stagger_ms
     if args.pre_slots >= 0:
         model.model_cfg["PRE_TRACKING_CONCURRENCY"] = args.pre_slots
+    if args.extract_unit_by_unit:
+        model.preprocessors[2].model_cfg["EXTRACT_UNITS_TOGETHER"] = False
     lib = L.load()
 
     def step():

@@ -225,7 +225,6 @@ class ClusterTracking(nn.Module):
         Units without any tracked voxel come back unchanged (the reference skips the call for them)."""
         if views is None:
             views = self.sequence_views(all_points, seq_boxes)
-        v = views
         out = list(extracted_list)
         todo = [i for i, ex in enumerate(extracted_list) if ex.fxyz.shape[0] > 0]
         if not todo:
@@ -236,19 +235,36 @@ class ClusterTracking(nn.Module):
         # one host read for all units: components per unit and the frame range
         stats = torch.stack([torch.stack([ex.component.max().long(), ex.fxyz[:, 0].min().round().long(),
                                           ex.fxyz[:, 0].max().round().long()]) for ex in exs]).tolist()
+        fxyz = torch.cat([ex.fxyz for ex in exs]) if len(exs) > 1 else exs[0].fxyz
+        comp_local = torch.cat([ex.component.long() for ex in exs]) if len(exs) > 1 else exs[0].component.long()
+        moving = torch.cat([ex.moving for ex in exs])
+        full = self._extract_units_core(views, seq_boxes, fxyz, comp_local, moving, rows, stats,
+                                        [ex.component.dtype for ex in exs], transforms)
+        for i, f in zip(todo, full):
+            out[i] = f
+        return out
+
+    def _extract_units_core(self, v, seq_boxes, fxyz, comp_local, moving, rows, stats, dtypes, transforms, unit=None):
+        """The body of extract_traces_of_units on the units' rows already concatenated: fxyz [n, 4], comp_local [n]
+        int64 (each unit's own component ids), moving [n] bool, rows / stats / dtypes / transforms per unit
+        (stats = (largest component id, first frame, last frame) of the unit's rows, host integers; a frame range wider
+        than the rows' own gives the same results: frames without voxels have no edges and empty groups). `rows` (host
+        counts) or `unit` ([n] int64, the unit of every row; rows grouped by unit) says whose rows are whose. What is computed per unit in the reference -- labels, original indices, frame-local indices -- is gathered
+        ONCE for all units; the per-unit results are views of those arrays (a dozen small launches per unit less)."""
+        n_units = len(stats)
         ncomp = [s[0] + 1 for s in stats]
         f_lo, f_hi = min(s[1] for s in stats), max(s[2] for s in stats)
         coff = [0]
         for c in ncomp:
             coff.append(coff[-1] + c)
         num_components = coff[-1]
-        dev = exs[0].fxyz.device
-        fxyz = torch.cat([ex.fxyz for ex in exs]) if len(exs) > 1 else exs[0].fxyz
-        comp = torch.cat([ex.component.long() + coff[u] for u, ex in enumerate(exs)])
-        moving = torch.cat([ex.moving for ex in exs])
+        dev = fxyz.device
         # (output_size: the host knows the total, so repeat_interleave does not read the counts back)
-        unit = torch.repeat_interleave(torch.arange(len(exs), device=dev), torch.tensor(rows, device=dev),
-                                       output_size=sum(rows))
+        if unit is None:
+            unit = torch.repeat_interleave(torch.arange(n_units, device=dev), torch.tensor(rows, device=dev),
+                                           output_size=sum(rows))
+        coff_t = torch.tensor(coff[:-1], device=dev)
+        comp = comp_local + coff_t[unit] if n_units > 1 else comp_local
         comp_sg = IndexSegments(comp, num_components)
         component_hit = comp.new_zeros(num_components)
         size_min = segment_min(fxyz[:, 0], comp_sg, num_components).round().long()
@@ -264,13 +280,13 @@ class ClusterTracking(nn.Module):
         q_off = [0]
         for a, b in zip(q_lo, q_hi):
             q_off.append(q_off[-1] + (b - a))
-        if len(exs) == 1:
+        if n_units == 1:
             vox, queries = fxyz, v.fxyz[q_lo[0]:q_hi[0]]
         else:
             vox = fxyz.clone()
             vox[:, 0] += (unit * stride).to(vox.dtype)
             queries = torch.cat([v.fxyz[a:b] for a, b in zip(q_lo, q_hi)])
-            q_unit = torch.repeat_interleave(torch.arange(len(exs), device=dev),
+            q_unit = torch.repeat_interleave(torch.arange(n_units, device=dev),
                                              torch.tensor([b - a for a, b in zip(q_lo, q_hi)], device=dev),
                                              output_size=q_off[-1])
             queries[:, 0] += (q_unit * stride).to(queries.dtype)
@@ -322,26 +338,40 @@ class ClusterTracking(nn.Module):
                 n_box = seq_boxes.best_iou.shape[0]
                 scatter_max_(seq_boxes.best_iou, (v.box_off[gframe] + box).clamp(max=max(n_box - 1, 0)),
                              torch.where(has_box, iou32, torch.zeros_like(iou32)))
-        counts = count_into(out_unit, len(exs)).tolist()
+        # (the rows are sorted by unit: the units' row ranges are the places where the unit number changes)
+        bounds = torch.searchsorted(out_unit, torch.arange(n_units + 1, device=dev)).tolist()
+        counts = [bounds[u + 1] - bounds[u] for u in range(n_units)]
+        # everything that is a gather or an elementwise step per unit in the reference, once for all units
+        same_dtype = all(d == dtypes[0] for d in dtypes)
+        comp_rows = out_comp - coff_t[out_unit] if n_units > 1 else out_comp
+        frame_rows = g_ref - v.frame_start[out_frame]
+        if same_dtype:
+            comp_rows, frame_rows = comp_rows.to(dtypes[0]), frame_rows.to(dtypes[0])
+            hit_all = component_hit.to(dtypes[0])
+        seg_rows = v.full_segmentation_label[g_ref]
+        inst_rows = v.full_instance_label[g_ref]
+        orig_rows = v.perm[g_ref].reshape(-1, 1)
+        moving_rows = moving[e_ext]
+        res = []
         start = 0
-        for u, ex in enumerate(exs):
+        for u in range(n_units):
             sl = slice(start, start + counts[u])
             start += counts[u]
-            rows_ref = g_ref[sl]
             full = EasyDict(dict(
                 fxyz=full_fxyz[sl],
-                component=(out_comp[sl] - coff[u]).to(ex.component.dtype),
-                segmentation_label=v.full_segmentation_label[rows_ref],
-                instance_label=v.full_instance_label[rows_ref],
-                original_indices=v.perm[rows_ref].reshape(-1, 1),
-                frame_indices=(rows_ref - v.frame_start[out_frame[sl]]).to(ex.component.dtype),
-                moving=moving[e_ext[sl]],
+                component=comp_rows[sl] if same_dtype else comp_rows[sl].to(dtypes[u]),
+                segmentation_label=seg_rows[sl],
+                instance_label=inst_rows[sl],
+                original_indices=orig_rows[sl],
+                frame_indices=frame_rows[sl] if same_dtype else frame_rows[sl].to(dtypes[u]),
+                moving=moving_rows[sl],
             ))
-            full.component_hit = component_hit[coff[u]:coff[u + 1]].to(ex.component.dtype)
+            hit_u = hit_all[coff[u]:coff[u + 1]] if same_dtype else component_hit[coff[u]:coff[u + 1]].to(dtypes[u])
+            full.component_hit = hit_u
             full.component_size = component_size[coff[u]:coff[u + 1]]
             full.transforms = transforms[u]
-            out[todo[u]] = full
-        return out
+            res.append(full)
+        return res
 
     # ------------------------------------------------------------------ tracking of one anchor
     def track_frame(self, seq_points, frame, seq_boxes):
@@ -415,6 +445,66 @@ class ClusterTracking(nn.Module):
                                      comp_min_frame_id=out["comp_min_frame_id"],
                                      comp_max_frame_id=out["comp_max_frame_id"])
         return extracted
+
+    def _extract_units_native(self, seq_fxyz, units, tracked, perm, views, seq_boxes, windows):
+        """extract_traces_of_units straight from the native tracker's outputs of ALL units of a sequence: what
+        `_extracted_from_native` + the head of `extract_traces_of_units` do unit by unit -- the reference's final
+        validity filter (tracked >= MIN_MOVE_FRAME frames, cluster_tracking.py:753 of the reference), the gathers of
+        the tracked voxels, the per-unit component ranges -- done once on the concatenated rows (two host reads per
+        sequence instead of three per unit; the intermediate per-unit dictionaries, whose other fields nothing
+        downstream reads, are not built). `windows`: the units' (first, last) tracked frame, host integers. Same
+        results as the unit-by-unit path, value for value."""
+        dev = seq_fxyz.device
+        outs = [t[0] for t in tracked]
+        n_units = len(outs)
+        n_ex = [o["ex_index"].shape[0] for o in outs]
+        n_c = [o["moving"].shape[0] for o in outs]
+        if sum(n_ex) == 0:
+            return [None] * n_units
+        idx = torch.cat([o["ex_index"] for o in outs])
+        if perm is not None:
+            idx = perm[idx]
+        comp = torch.cat([o["ex_component"] for o in outs])
+        unit0 = torch.repeat_interleave(torch.arange(n_units, device=dev), torch.tensor(n_ex, device=dev),
+                                        output_size=sum(n_ex))
+        cbase = [0]
+        for c in n_c:
+            cbase.append(cbase[-1] + c)
+        comp_g = comp + torch.tensor(cbase[:-1], device=dev)[unit0]  # row of the units' concatenated [C] arrays
+        moving_c = torch.cat([o["moving"] for o in outs])
+        anchor = torch.repeat_interleave(torch.tensor([f for _, f in units], device=dev),
+                                         torch.tensor(n_c, device=dev), output_size=cbase[-1])
+        valid_c = torch.cat([o["valid_comp"] for o in outs]) & (
+            (torch.cat([o["comp_max_frame_id"] for o in outs]) >= anchor + self.min_move_frame) |
+            (torch.cat([o["comp_min_frame_id"] for o in outs]) <= anchor - self.min_move_frame))
+        keep = valid_c[comp_g].nonzero(as_tuple=True)[0]
+        idx, comp, comp_g, unit_k = idx[keep], comp[keep], comp_g[keep], unit0[keep]
+        fxyz = seq_fxyz[idx]
+        moving = moving_c[comp_g]
+        # per unit: the largest component id among its rows (one host read; a unit without rows: -1) -- from the
+        # components that have a row, not from the rows (a reduction of half a million rows into nine words is a
+        # queue of atomics on nine addresses); the frame range is the unit's tracking window, which the host knows
+        present = torch.zeros(cbase[-1], dtype=torch.bool, device=dev)
+        present[comp_g] = True
+        local1 = torch.arange(1, cbase[-1] + 1, device=dev) - torch.repeat_interleave(
+            torch.tensor(cbase[:-1], device=dev), torch.tensor(n_c, device=dev), output_size=cbase[-1])
+        top = torch.segment_reduce(torch.where(present, local1, torch.zeros_like(local1)).float(), "max",
+                                   lengths=torch.tensor(n_c, device=dev), unsafe=True).long().tolist()
+        todo = [u for u in range(n_units) if top[u] > 0]
+        res = [None] * n_units
+        if not todo:
+            return res
+        if len(todo) < n_units:  # (renumber the units that have rows: the rows are already grouped in unit order)
+            remap = torch.full((n_units,), -1, dtype=torch.int64, device=dev)
+            remap[torch.tensor(todo, device=dev)] = torch.arange(len(todo), device=dev)
+            unit_k = remap[unit_k]
+        full = self._extract_units_core(
+            views, seq_boxes, fxyz, comp, moving, None,
+            [(top[u] - 1, windows[u][0], windows[u][1]) for u in todo], [tracked[u][1] for u in todo],
+            [outs[u]["transforms"] for u in todo], unit=unit_k)
+        for u, f in zip(todo, full):
+            res[u] = f
+        return res
 
     def _track_frame_native(self, seq_points, frame, offsets):
         frame_id = int(frame.frame[0].long().item())
@@ -779,21 +869,35 @@ class ClusterTracking(nn.Module):
                 # host loop gives the same results, two orders of magnitude slower -- never silently
                 note_host_fallback(sequence_id, err)
         run_deferred(seq_dict)  # (already done beside the native call when that ran)
-        extracted_list = []
-        for i, (comp_key, frame_id) in enumerate(units):
-            if tracked is not None:
-                out, comp_dtype = tracked[i]
-                extracted_list.append(self._extracted_from_native(unit_points(comp_key), frame_id, out,
-                                                                  frame_perm, comp_dtype))
-            else:
-                extracted_list.append(run_unit_host(comp_key, frame_id))
         # best_iou is a running maximum over the units: one pass over all of them
-        with Timer("Extract Traces from all points"):
-            full_list = self.extract_traces_of_units(all_points, extracted_list, seq_boxes, views)
+        if tracked is not None and self.model_cfg.get("EXTRACT_UNITS_TOGETHER", True):
+            # the native tracker's outputs of all units go through the final filter and the extraction together
+            with Timer("Extract Traces from all points"):
+                full_list = self._extract_units_native(
+                    seq_points.fxyz, units, tracked, frame_perm, views, seq_boxes,
+                    [self._native_window(frame_offsets, frame_id) for _, frame_id in units])
+            for i, (comp_key, frame_id) in enumerate(units):
+                if full_list[i] is None:  # (no tracked voxel survived the filter: the unit's own, empty dictionary)
+                    out, comp_dtype = tracked[i]
+                    full_list[i] = self._extracted_from_native(unit_points(comp_key), frame_id, out, frame_perm,
+                                                               comp_dtype)
+        else:
+            extracted_list = []
+            for i, (comp_key, frame_id) in enumerate(units):
+                if tracked is not None:
+                    out, comp_dtype = tracked[i]
+                    extracted_list.append(self._extracted_from_native(unit_points(comp_key), frame_id, out,
+                                                                      frame_perm, comp_dtype))
+                else:
+                    extracted_list.append(run_unit_host(comp_key, frame_id))
+            with Timer("Extract Traces from all points"):
+                full_list = self.extract_traces_of_units(all_points, extracted_list, seq_boxes, views)
         results = {(frame_id, comp_key): ex for (comp_key, frame_id), ex in zip(units, full_list)}
         for (frame_id, comp_key), extracted in results.items():
             if save:
-                torch.save(dict(extracted), f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
+                # (the per-unit arrays are views of the sequence's arrays: a file takes its own rows only)
+                torch.save({k: (t.clone() if torch.is_tensor(t) and t._base is not None else t)
+                            for k, t in dict(extracted).items()}, f"{outfolder}/{frame_id:03d}_{comp_key}.pth")
             extracted.pop("transforms", None)
         if save:
             torch.save(dict(seq_boxes), outpath)

@@ -141,6 +141,31 @@ def test_full_pipeline_lockstep_vs_unit_by_unit():
             assert torch.equal(outs[0][k], other[k])
 
 
+def test_extraction_of_all_units_together_vs_unit_by_unit():
+    """ClusterTracking's tail on the native tracker's outputs: the final validity filter and the extraction of traces
+    for all units of a sequence at once (EXTRACT_UNITS_TOGETHER, the default: gathers and per-unit statistics on the
+    concatenated rows) against the unit-by-unit form (`_extracted_from_native` per unit, then
+    `extract_traces_of_units`): every field of every unit and the boxes' best IoUs identical."""
+    from pcseqlearning_amd.pcdet import models
+    from tools.run_sequence import build_model
+    batch = models.load_data_to_gpu(synthetic.gen_sequence(9, 10, 12000, n_static=14, n_vehicle=8, n_ped=4), DEV)
+    outs = []
+    for together in (True, False):
+        model = build_model(save=False, device=DEV)
+        model.preprocessors[2].model_cfg["EXTRACT_UNITS_TOGETHER"] = together
+        with torch.no_grad():
+            model(batch)
+        outs.append(model.last_outputs[0])
+    a, b = outs[0]["cluster_tracking_results"], outs[1]["cluster_tracking_results"]
+    assert a.keys() == b.keys() and any(v["fxyz"].shape[0] > 0 for v in a.values())
+    for key in a:
+        assert set(a[key].keys()) == set(b[key].keys()), key
+        for field, t in a[key].items():
+            if torch.is_tensor(t):
+                assert t.dtype == b[key][field].dtype and torch.equal(t, b[key][field]), (key, field)
+    assert torch.equal(outs[0]["gt_box_best_iou_tracking"], outs[1]["gt_box_best_iou_tracking"])
+
+
 def test_batch_of_sequences_concurrently_vs_one_by_one():
     """SimpleReg.forward on a batch of three sequences: processed at once (SEQUENCES_IN_FLIGHT 3: one host
     thread, stream and preprocessor copy per sequence, one lock-step group each) and one after the other
