@@ -313,9 +313,10 @@ class ClusterTracking(nn.Module):
         keep &= dist < diameter[ekey] + 0.05
         keep &= dz > -0.05
         kidx = keep.nonzero(as_tuple=True)[0]
-        # rows in the reference's order: unit by unit, frame by frame ascending, within a frame by voxel
-        num_f = f_hi - f_lo + 1
-        kidx = kidx[torch.argsort(unit[e_ext[kidx]] * num_f + (ext_frame[e_ext[kidx]] - f_lo), stable=True)]
+        # rows in the reference's order: unit by unit, frame by frame ascending, within a frame by full-resolution
+        # point. The edges ARRIVE in that order -- they are grouped by ascending query, the queries are the units'
+        # frame-grouped points one unit after the other, and an edge's voxel has its query's unit and frame -- so the
+        # stable sort by (unit, frame) that used to follow was the identity (a radix sort of a million keys)
         e_ext, g_ref = e_ext[kidx], g_ref[kidx]
         out_frame = v.frame[g_ref]
         out_comp = comp[e_ext]
