@@ -42,7 +42,7 @@ def scatter_max_(dst, index, values):
     return dst
 
 
-def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt_count_all):
+def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt_count_all, span=None):
     """component_box_iou for many frames at once: a group is a (frame, component) pair, boxes are
     indexed within their frame (`member` [n,Bmax] from ops.points_in_frame_boxes, `gt_local` [n] the
     point's gt box within its frame or -1, `box_offsets` [F+1] long, `gt_count_all` [B] per global box).
@@ -51,7 +51,8 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     per-frame loop visits them."""
     n, bmax = member.shape
     comp = component.long()
-    span = int(comp.max().item()) + 1 if n else 1
+    if span is None:  # (any bound above the largest component id gives the same groups in the same order; a caller
+        span = int(comp.max().item()) + 1 if n else 1  # that knows one saves the host read)
     key = frame.long() * span + comp
     uniq, inv = key.unique(return_inverse=True)
     G = uniq.numel()
