@@ -24,6 +24,19 @@ from .registration_utils import (IndexSegments, efficient_robust_sum, register_t
                                  robust_mean, robust_median, segment_max, segment_min)
 
 
+def run_ids(counts, device):
+    """torch.repeat_interleave(arange(len(counts)), counts) for host counts: [sum(counts)] int64, run i holds i. By
+    bucketing a ramp against the runs' end offsets: repeat_interleave's own kernel takes 190 us per million outputs
+    (four of those per sequence in the extraction), a ramp and a bucketize 10 us each."""
+    ends, total = [], 0
+    for c in counts:
+        total += int(c)
+        ends.append(total)
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64, device=device)
+    return torch.bucketize(torch.arange(total, device=device), torch.tensor(ends, device=device), right=True)
+
+
 HOST_FALLBACKS = 0  # sequences that left the native tracker for the op-by-op host loop (bench.py reports it)
 _FALLBACK_LOCK = __import__("threading").Lock()
 
@@ -259,10 +272,8 @@ class ClusterTracking(nn.Module):
             coff.append(coff[-1] + c)
         num_components = coff[-1]
         dev = fxyz.device
-        # (output_size: the host knows the total, so repeat_interleave does not read the counts back)
         if unit is None:
-            unit = torch.repeat_interleave(torch.arange(n_units, device=dev), torch.tensor(rows, device=dev),
-                                           output_size=sum(rows))
+            unit = run_ids(rows, dev)
         coff_t = torch.tensor(coff[:-1], device=dev)
         comp = comp_local + coff_t[unit] if n_units > 1 else comp_local
         comp_sg = IndexSegments(comp, num_components)
@@ -286,9 +297,7 @@ class ClusterTracking(nn.Module):
             vox = fxyz.clone()
             vox[:, 0] += (unit * stride).to(vox.dtype)
             queries = torch.cat([v.fxyz[a:b] for a, b in zip(q_lo, q_hi)])
-            q_unit = torch.repeat_interleave(torch.arange(n_units, device=dev),
-                                             torch.tensor([b - a for a, b in zip(q_lo, q_hi)], device=dev),
-                                             output_size=q_off[-1])
+            q_unit = run_ids([b - a for a, b in zip(q_lo, q_hi)], dev)
             queries[:, 0] += (q_unit * stride).to(queries.dtype)
 
         self.nn_graph.radius *= 1.732
@@ -466,15 +475,14 @@ class ClusterTracking(nn.Module):
         if perm is not None:
             idx = perm[idx]
         comp = torch.cat([o["ex_component"] for o in outs])
-        unit0 = torch.repeat_interleave(torch.arange(n_units, device=dev), torch.tensor(n_ex, device=dev),
-                                        output_size=sum(n_ex))
+        unit0 = run_ids(n_ex, dev)
         cbase = [0]
         for c in n_c:
             cbase.append(cbase[-1] + c)
         comp_g = comp + torch.tensor(cbase[:-1], device=dev)[unit0]  # row of the units' concatenated [C] arrays
         moving_c = torch.cat([o["moving"] for o in outs])
-        anchor = torch.repeat_interleave(torch.tensor([f for _, f in units], device=dev),
-                                         torch.tensor(n_c, device=dev), output_size=cbase[-1])
+        unit_c = run_ids(n_c, dev)  # the unit of every row of the concatenated [C] arrays
+        anchor = torch.tensor([f for _, f in units], device=dev)[unit_c]
         valid_c = torch.cat([o["valid_comp"] for o in outs]) & (
             (torch.cat([o["comp_max_frame_id"] for o in outs]) >= anchor + self.min_move_frame) |
             (torch.cat([o["comp_min_frame_id"] for o in outs]) <= anchor - self.min_move_frame))
@@ -487,8 +495,7 @@ class ClusterTracking(nn.Module):
         # queue of atomics on nine addresses); the frame range is the unit's tracking window, which the host knows
         present = torch.zeros(cbase[-1], dtype=torch.bool, device=dev)
         present[comp_g] = True
-        local1 = torch.arange(1, cbase[-1] + 1, device=dev) - torch.repeat_interleave(
-            torch.tensor(cbase[:-1], device=dev), torch.tensor(n_c, device=dev), output_size=cbase[-1])
+        local1 = torch.arange(1, cbase[-1] + 1, device=dev) - torch.tensor(cbase[:-1], device=dev)[unit_c]
         top = torch.segment_reduce(torch.where(present, local1, torch.zeros_like(local1)).float(), "max",
                                    lengths=torch.tensor(n_c, device=dev), unsafe=True).long().tolist()
         todo = [u for u in range(n_units) if top[u] > 0]

@@ -57,8 +57,10 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     uniq, inv = key.unique(return_inverse=True)
     G = uniq.numel()
     gframe, gcomp = uniq // span, uniq % span
-    counts = torch.zeros(G, bmax, dtype=torch.int64, device=comp.device)
-    counts.index_add_(0, inv, member.long())
+    # (in the membership's own int32: a group holds far fewer than 2^31 points, and the int64 copy of [n, bmax] was
+    #  the largest array of the whole extraction)
+    counts = torch.zeros(G, bmax, dtype=member.dtype, device=comp.device)
+    counts.index_add_(0, inv, member)
     has_box = counts.sum(1) > 0
     box = counts.argmax(1)
     size = count_into(inv, G)
