@@ -276,11 +276,7 @@ class ClusterTracking(nn.Module):
             unit = run_ids(rows, dev)
         coff_t = torch.tensor(coff[:-1], device=dev)
         comp = comp_local + coff_t[unit] if n_units > 1 else comp_local
-        comp_sg = IndexSegments(comp, num_components)
         component_hit = comp.new_zeros(num_components)
-        size_min = segment_min(fxyz[:, 0], comp_sg, num_components).round().long()
-        size_max = segment_max(fxyz[:, 0], comp_sg, num_components).round().long()
-        component_size = size_max - size_min + 1
         ext_frame = fxyz[:, 0].round().long()
         # 1-NN of every full-resolution point among the tracked voxels OF ONE UNIT (the graph's "ref" set
         # is the voxels, its queries the full-resolution points of the unit's frame range): the units
@@ -307,10 +303,22 @@ class ClusterTracking(nn.Module):
         to_row = torch.tensor([a - o for a, o in zip(q_lo, q_off[:-1])], device=dev)
         g_ref = e_ref + to_row[unit[e_ext]]
 
-        # centre and xy-diameter of every (frame, unit component) of the tracked voxels
-        gkey = (ext_frame - f_lo) * num_components + comp
-        num_groups = (f_hi - f_lo + 1) * num_components
+        # centre and xy-diameter of every (unit component, frame) of the tracked voxels. ONE sorted-segment structure,
+        # component-major: the groups of a component are its frames, so the first and the last frame of every component
+        # (component_size, a second sort by component and two segment reductions in the reference's form) are the
+        # first and the last occupied column of the [component, frame] table of groups
+        num_f = f_hi - f_lo + 1
+        gkey = comp * num_f + (ext_frame - f_lo)
+        num_groups = num_f * num_components
         gsg = IndexSegments(gkey, num_groups)
+        occupied = torch.zeros(num_groups, dtype=torch.bool, device=dev)
+        occupied[gsg.ids] = True
+        occupied = occupied.reshape(num_components, num_f)
+        col = torch.arange(num_f, device=dev)
+        first_f = torch.where(occupied, col, num_f).amin(1)
+        last_f = torch.where(occupied, col, -1).amax(1)
+        # (a component id without rows: first = last = frame 0 in the reference's scatter with fill 0, size 1)
+        component_size = torch.where(last_f >= 0, last_f - first_f + 1, torch.ones_like(last_f))
         center = robust_mean(fxyz[:, 1:3], gsg, num_groups)
         spread = (fxyz[:, 1:3] - center[gkey]).norm(p=2, dim=-1)
         diameter = segment_max(spread, gsg, num_groups)
