@@ -164,6 +164,19 @@ def test_extraction_of_all_units_together_vs_unit_by_unit():
             if torch.is_tensor(t):
                 assert t.dtype == b[key][field].dtype and torch.equal(t, b[key][field]), (key, field)
     assert torch.equal(outs[0]["gt_box_best_iou_tracking"], outs[1]["gt_box_best_iou_tracking"])
+    # no component survives the final filter (MIN_MOVE_FRAME beyond the sequence): every unit comes back with its own
+    # empty dictionary in both forms
+    empty = []
+    for together in (True, False):
+        model = build_model(save=False, device=DEV)
+        model.preprocessors[2].model_cfg["EXTRACT_UNITS_TOGETHER"] = together
+        model.preprocessors[2].min_move_frame = 100
+        with torch.no_grad():
+            model(batch)
+        empty.append(model.last_outputs[0]["cluster_tracking_results"])
+    assert empty[0].keys() == empty[1].keys()
+    for key in empty[0]:
+        assert empty[0][key]["fxyz"].shape[0] == 0 and set(empty[0][key].keys()) == set(empty[1][key].keys())
 
 
 def test_batch_of_sequences_concurrently_vs_one_by_one():
