@@ -370,7 +370,12 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
                                                bool valid, int* __restrict__ overflow,
                                                float* __restrict__ best_dist2 = nullptr,
                                                float mu = 0.f, float* __restrict__ bud_out = nullptr,
-                                               float seed_d2 = __builtin_inff(), NnAux* __restrict__ aux_out = nullptr) {
+                                               float seed_d2 = __builtin_inff(), NnAux* __restrict__ aux_out = nullptr,
+                                               const bool ovf_by_cell = false) {
+  // ovf_by_cell (static grids whose spilled points have been sorted by cell, nn1_spill_sort_kernel): a full cell's
+  // slot holds (in `pad`) where its spilled points start in the overflow arrays, + 1 -- they are looked at with the
+  // cell, and only then; otherwise every query scans the whole overflow list (a few hundred spilled points made that
+  // scan 90 % of the extraction graph's search: 557 x 2 loads per query against ~100 for everything else)
   const int lane = threadIdx.x & 63;
   const int sub = lane & 31;
   const int half_base = lane & 32;
@@ -473,13 +478,17 @@ __device__ __forceinline__ int g2_nearest_coop(const GridDesc& d, const Grid2& g
       if (j + 2 < cnt) consider(c2, oi.z);
       if (j + 3 < cnt) consider(c3, oi.w);
     }
+    if (ovf_by_cell && (int)cnt_w > kCellCap) {  // the cell's spilled points
+      const int first = (int)pad_w - 1, extra = min((int)cnt_w - kCellCap, (int)g.ovf_cap - first);
+      for (int j = 0; j < extra; ++j) consider(g.ovf_pts[first + j], g.ovf_idx[first + j]);
+    }
   };
   // ---- spilled points (cells with more than kCellCap points; normally none): every lane of the
   //      half takes a stride of the list; same frame cell and radius test as the cell walk
   {
     // (valid0, not valid: a moved point whose cell could not be claimed lies here WITHOUT a bit in the coarse masks,
     //  g2_move_point; the length is clamped to the list's rows)
-    int no = valid0 ? min(*g.ovf, (int)g.ovf_cap) : 0;
+    int no = (valid0 && !ovf_by_cell) ? min(*g.ovf, (int)g.ovf_cap) : 0;
     for (int j = sub; j < no; j += 32) {
       float4 c = g.ovf_pts[j];
       if (frame_cell(d, c.x) != fc) continue;

@@ -211,12 +211,183 @@ nn1_filter_kernel(const float4* __restrict__ qry, int M, const GridDesc* __restr
     }
   }
 }
+// The static grid of the 1-NN path after its build: the points that did not fit their cell's kCellCap rows (voxels
+// of several sampling levels piled into one 22 cm cell: a few hundred of a million) are sorted by cell -- ONE
+// workgroup, word = slot << 12 | position, bitonic in LDS -- and every full cell's slot learns where its spilled
+// points start (pad = start + 1). flag[0] = 1: done (at most 4096 spilled points; beyond that the searches keep
+// scanning the whole list, as the ICP's grids do).
+constexpr int kSpillSort = 4096;
+__global__ void __launch_bounds__(1024)
+nn1_spill_sort_kernel(const GridDesc* __restrict__ gp, Grid2 g, int32_t* __restrict__ flag) {
+  __shared__ uint64_t key[kSpillSort];
+  __shared__ int s_bad;
+  const int t = threadIdx.x;
+  const int n = *g.ovf;
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  if (n <= 0 || n > kSpillSort || n > (int)g.ovf_cap) {
+    if (t == 0) flag[0] = n <= 0 ? 1 : 0;
+    return;
+  }
+  const GridDesc d = *gp;
+  for (int i = t; i < kSpillSort; i += 1024) {
+    uint64_t k = ~0ULL;
+    if (i < n) {
+      const float4 p = g.ovf_pts[i];
+      const int fc = frame_cell(d, p.x);
+      const int x = (int)floorf((p.y - d.lo[0]) / d.h), y = (int)floorf((p.z - d.lo[1]) / d.h),
+                z = (int)floorf((p.w - d.lo[2]) / d.h);
+      uint32_t c = 0, pw = 0;
+      const int fs = g2_find(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z), &c, &pw);
+      if (fs < 0 || (int)c <= kCellCap) s_bad = 1;  // (cannot be: a spilled point's cell exists and is full)
+      k = ((uint64_t)(uint32_t)max(fs, 0) << 12) | (uint64_t)i;
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  if (s_bad) {  // leave the list as it is: the searches scan all of it
+    if (t == 0) flag[0] = 0;
+    return;
+  }
+  for (int size = 2; size <= kSpillSort; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < kSpillSort / 2; i += 1024) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = key[lo], b = key[hi];
+        if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  // the points in sorted order (read all, then write), the cells' start offsets
+  float4 pp[kSpillSort / 1024];
+  int32_t ii[kSpillSort / 1024];
+#pragma unroll
+  for (int q = 0; q < kSpillSort / 1024; ++q) {
+    const int i = t + q * 1024;
+    if (i < n) { const int src = (int)(key[i] & 4095ULL); pp[q] = g.ovf_pts[src]; ii[q] = g.ovf_idx[src]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kSpillSort / 1024; ++q) {
+    const int i = t + q * 1024;
+    if (i < n) {
+      g.ovf_pts[i] = pp[q];
+      g.ovf_idx[i] = ii[q];
+      const uint32_t fs = (uint32_t)(key[i] >> 12);
+      if (i == 0 || (uint32_t)(key[i - 1] >> 12) != fs) g.fslot[fs].pad = i + 1;
+    }
+  }
+  if (t == 0) flag[0] = 1;
+}
+
+// Most queries that pass the filter lie ON a tracked object: a voxel of it sits in their own fine cell or the one
+// beside it, nearer than one cell width h -- and then nothing outside the 3 x 3 x 3 fine cells around the query can be
+// nearer (it is at least h away along some axis): the cooperative search stops after its first phase too, but it
+// spends 32 lanes, a dozen shuffles and two ballots on that one query (3600 SIMD cycles per query measured: the
+// wave's chain of dependent loads serves two queries). Here ONE THREAD takes a query through the same 27 cells --
+// 27 independent probe chains in flight per lane, 64 queries per wave -- and settles it when the search's own stop
+// rule (g2_nearest_coop: h^2 > dist2 - frame term + margin) holds for the nearest point it found; everything else
+// (no point in the 27 cells, or the nearest not nearer than h, a cell that spilled, a query outside the frame range)
+// goes on to the cooperative search unchanged. Same canonical choice (dist2, original index): same edges.
+__global__ void __launch_bounds__(kBlock)
+nn1_near_kernel(const float4* __restrict__ qry, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                const GridDesc* __restrict__ gp, Grid2 g, int df, int32_t* __restrict__ list2,
+                int32_t* __restrict__ cnt2, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d,
+                int32_t* __restrict__ deg, const int32_t* __restrict__ spill_sorted) {
+  const GridDesc d = *gp;
+  const int n = *cnt;
+  const int lane = threadIdx.x & 63;
+  // (spilled points that are not sorted by cell: only the cooperative search knows how to scan that list)
+  const bool spilled = *g.ovf > 0 && !*spill_sorted;
+  const int nround = (n + kBlock - 1) / kBlock;
+  const float margin = 1e-5f * d.radius2 + 1e-6f;
+  for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (ballot)
+    const int w = r * kBlock + threadIdx.x;
+    const bool valid = w < n;
+    bool later = false;
+    if (valid) {
+      const int qid = list[w];
+      const float4 p = qry[qid];
+      const int fc = frame_cell(d, p.x) + df;
+      const int cx = (int)floorf((p.y - d.lo[0]) / d.h), cy = (int)floorf((p.z - d.lo[1]) / d.h),
+                cz = (int)floorf((p.w - d.lo[2]) / d.h);
+      later = spilled || fc < 0 || fc >= kFrameCells || cx < 1 || cy < 1 || cz < 1;
+      if (!later) {
+        const float fa = g.fr[fc], fb = g.fr[kFrameCells + fc];
+        const float dfl = fmaxf(fmaxf(fa - p.x, p.x - fb), 0.f);
+        const float dfsq = dfl * dfl;
+        later = !(fa <= fb) || !(d.radius2 - dfsq + margin >= 0.f);
+        int cand = -1;
+        float cd = 0.f;
+        if (!later) {
+          // the query's own cell first; a neighbour cell is skipped when its nearest face is farther than the
+          // nearest point found so far (most queries sit within a few centimetres of a voxel: 4-8 cells of 27)
+          const float fx = (p.y - d.lo[0]) / d.h - (float)cx, fy = (p.z - d.lo[1]) / d.h - (float)cy,
+                      fz = (p.w - d.lo[2]) / d.h - (float)cz;
+#pragma unroll 1
+          for (int qq = 0; qq < 27; ++qq) {
+            const int q = qq == 0 ? 13 : (qq <= 13 ? qq - 1 : qq);
+            const int ox = q % 3 - 1, oy = (q / 3) % 3 - 1, oz = q / 9 - 1;
+            if (cand >= 0) {
+              const float ax = ox < 0 ? fx : (ox > 0 ? 1.f - fx : 0.f), ay = oy < 0 ? fy : (oy > 0 ? 1.f - fy : 0.f),
+                          az = oz < 0 ? fz : (oz > 0 ? 1.f - fz : 0.f);
+              // (0.999: the cell coordinates are fp32 quotients; a cell that close is simply looked at)
+              const float lb = ((ax * ax + ay * ay) + az * az) * (d.h * d.h) * 0.999f;
+              if (lb > (cd - dfsq) + margin) continue;
+            }
+            const int x = cx + ox, y = cy + oy, z = cz + oz;
+            uint32_t cnt_w = 0, pad_w = 0;
+            const int fs = g2_find(g.fslot, g.Hf - 1, pack_cell(fc, x, y, z), &cnt_w, &pad_w);
+            if (fs < 0) continue;
+            // (a full cell: its kCellCap rows, then its spilled points where the slot says they start)
+            const float4* run = g.spts + (size_t)fs * kCellCap;
+            const int32_t* idx = g.sidx + (size_t)fs * kCellCap;
+            const int rows = min((int)cnt_w, kCellCap);
+            const int extra = (int)cnt_w > kCellCap ? min((int)cnt_w - kCellCap, (int)g.ovf_cap - ((int)pad_w - 1)) : 0;
+            for (int j = 0; j < rows + extra; ++j) {
+              const float4 c = j < rows ? run[j] : g.ovf_pts[(int)pad_w - 1 + (j - rows)];
+              const int oi = j < rows ? idx[j] : g.ovf_idx[(int)pad_w - 1 + (j - rows)];
+              const float d0 = c.x - p.x, d1 = c.y - p.y, d2 = c.z - p.z, d3 = c.w - p.w;
+              float dist2 = 0.f;
+              dist2 = dist2 + d0 * d0;
+              dist2 = dist2 + d1 * d1;
+              dist2 = dist2 + d2 * d2;
+              dist2 = dist2 + d3 * d3;
+              if (dist2 <= d.radius2 && (cand < 0 || dist2 < cd || (dist2 == cd && oi < cand))) {
+                cand = oi;
+                cd = dist2;
+              }
+            }
+          }
+          // the search's own stop rule after its first phase: nothing outside the 27 cells can be nearer
+          if (!later) later = !(cand >= 0 && d.h * d.h > (cd - dfsq) + margin);
+        }
+        if (!later) {
+          deg[qid] = 1;
+          nbr_idx[qid] = cand;
+          nbr_d[qid] = cd;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(later);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(cnt2, __popcll(m));
+      base = __shfl(base, 0, 64);
+      if (later) list2[base + __popcll(m & ((1ULL << lane) - 1ULL))] = list[w];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 nn1_search_list_kernel(const float4* __restrict__ qry, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                        const GridDesc* __restrict__ gp, Grid2 g, int df, int32_t* __restrict__ err,
-                       int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d, int32_t* __restrict__ deg) {
+                       int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_d, int32_t* __restrict__ deg,
+                       const int32_t* __restrict__ spill_sorted) {
   const GridDesc d = *gp;
   const int n = *cnt;
+  const bool by_cell = *spill_sorted != 0;
   const int per = kBlock / 32;
   const int nround = (n + per - 1) / per;
   for (int r = blockIdx.x; r < nround; r += gridDim.x) {  // whole waves stay together (shuffles)
@@ -225,7 +396,7 @@ nn1_search_list_kernel(const float4* __restrict__ qry, const int32_t* __restrict
     const int qid = valid ? list[w] : 0;
     const float4 p = valid ? qry[qid] : make_float4(0.f, 0.f, 0.f, 0.f);
     float bd = 0.f;
-    const int res = g2_nearest_coop(d, g, p, df, valid, err, &bd);
+    const int res = g2_nearest_coop(d, g, p, df, valid, err, &bd, 0.f, nullptr, __builtin_inff(), nullptr, by_cell);
     if (valid && (threadIdx.x & 31) == 0) {
       deg[qid] = res >= 0;
       nbr_idx[qid] = res;
@@ -261,6 +432,8 @@ edge_emit_kernel(const int32_t* __restrict__ nbr_idx, const float* __restrict__ 
 
 // test hook (pcs_radius_graph_engine_only): 1 = every search on the one-thread-per-query engine
 static int g_radius_engine_only = 0;
+// ... 2 = the 1-NN path without its one-thread near search (every survivor of the filter searched cooperatively)
+static int g_nn1_coop_only = 0;
 
 struct RadiusPlan {
   GridDesc* grid;
@@ -277,6 +450,7 @@ struct RadiusPlan {
   uint64_t* skeys;   // max_nbr == 1: occupied super blocks (nn1_filter_kernel), [Hs]
   uint32_t Hs;
   int32_t* nn1_list; // [M] queries that may have a neighbour
+  int32_t* nn1_list2; // [M] ... of those, the ones the one-thread near search could not settle
 };
 
 static inline uint32_t pow2_ge(uint64_t x) {
@@ -305,10 +479,11 @@ static bool plan_radius(Arena& a, int64_t N, int64_t M, int K, RadiusPlan& p) {
   p.tmp = a.take<char>(p.tmp_bytes);
   if (K == 1) {
     plan_grid2(a, N, p.g2);
-    p.g2_words = a.take<int32_t>(2);
+    p.g2_words = a.take<int32_t>(4);  // ... [2] the 1-NN path: spilled points sorted by cell
     p.Hs = pow2_ge(2 * (uint64_t)N);
     p.skeys = a.take<uint64_t>(p.Hs);
     p.nn1_list = a.take<int32_t>(M);
+    p.nn1_list2 = a.take<int32_t>(M);
   } else {
     plan_knn(a, N, M, p.knn);
   }
@@ -544,15 +719,28 @@ int pcs_radius_graph_search(const float* ref, int64_t N, const float* query, int
     g2_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.g2, 0, nullptr, p.err);
     // queries with an empty neighbourhood leave after eight probes of one thread; the rest is searched
     PCS_CHECK_HIP(hipMemsetAsync(p.skeys, 0xFF, (size_t)p.Hs * sizeof(uint64_t), s));
-    PCS_CHECK_HIP(hipMemsetAsync(p.g2_words, 0, 2 * sizeof(int32_t), s));
+    PCS_CHECK_HIP(hipMemsetAsync(p.g2_words, 0, 4 * sizeof(int32_t), s));
     nn1_super_insert_kernel<<<nb, kBlock, 0, s>>>((const float4*)ref, (int)N, p.grid, p.skeys, p.Hs - 1);
     nn1_filter_kernel<<<grid_for(M), kBlock, 0, s>>>((const float4*)query, (int)M, p.grid, p.skeys, p.Hs - 1, dframe_min,
                                                     p.nn1_list, p.g2_words, p.nbr_idx, p.nbr_d, p.deg);
     {
+      // the survivors: one thread each through the 27 fine cells around them (settles the queries whose nearest point
+      // is nearer than a cell width), the cooperative search for the rest (g2_words[1] counts them)
       int64_t blocks = (M * 32 + kBlock - 1) / kBlock;
       if (blocks > 4096) blocks = 4096;
-      nn1_search_list_kernel<<<(int)blocks, kBlock, 0, s>>>((const float4*)query, p.nn1_list, p.g2_words, p.grid, p.g2,
-                                                            dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg);
+      const int32_t* todo = p.nn1_list;
+      const int32_t* todo_n = p.g2_words;
+      if (!g_nn1_coop_only) {
+        // (the spilled points by cell: the searches then look at them with their cells instead of scanning the list)
+        nn1_spill_sort_kernel<<<1, 1024, 0, s>>>(p.grid, p.g2, p.g2_words + 2);
+        nn1_near_kernel<<<grid_for(M), kBlock, 0, s>>>((const float4*)query, p.nn1_list, p.g2_words, p.grid, p.g2, dframe_min,
+                                                      p.nn1_list2, p.g2_words + 1, p.nbr_idx, p.nbr_d, p.deg,
+                                                      p.g2_words + 2);
+        todo = p.nn1_list2;
+        todo_n = p.g2_words + 1;
+      }
+      nn1_search_list_kernel<<<(int)blocks, kBlock, 0, s>>>((const float4*)query, todo, todo_n, p.grid, p.g2,
+                                                            dframe_min, p.err, p.nbr_idx, p.nbr_d, p.deg, p.g2_words + 2);
     }
     rc = exclusive_scan_i32(p.tmp, p.tmp_bytes, p.deg, p.off, M, s);
     if (rc) return rc;
@@ -603,7 +791,8 @@ int pcs_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int
 }
 
 int pcs_radius_graph_engine_only(int on) {
-  g_radius_engine_only = on ? 1 : 0;
+  g_nn1_coop_only = on == 2 ? 1 : 0;
+  g_radius_engine_only = on == 1 ? 1 : 0;
   return PCS_OK;
 }
 
@@ -611,10 +800,17 @@ int pcs_radius_graph_engine_only(int on) {
 // took the one-thread fallback, its cursor, then build-dependent statistics); synchronises the stream
 int pcs_radius_graph_counters(int64_t N, int64_t M, int max_nbr, const void* ws, size_t ws_bytes, int32_t* host_out,
                               hipStream_t s) {
-  if (!ws || !host_out || max_nbr < 2 || max_nbr > kMaxK) return PCS_ERR_ARG;
+  if (!ws || !host_out || max_nbr < 1 || max_nbr > kMaxK) return PCS_ERR_ARG;
   Arena a((void*)ws, ws_bytes);
   RadiusPlan p;
   if (!plan_radius(a, N, M, max_nbr, p)) return PCS_ERR_WORKSPACE;
+  if (max_nbr == 1) {  // the 1-NN path: [0] = queries that passed the super-block filter (searched cooperatively)
+    for (int i = 0; i < 8; ++i) host_out[i] = 0;
+    PCS_CHECK_HIP(hipMemcpyAsync(host_out, p.g2_words, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PCS_CHECK_HIP(hipMemcpyAsync(host_out + 2, p.g2.ovf, sizeof(int32_t), hipMemcpyDeviceToHost, s));  // spilled points
+    PCS_CHECK_HIP(hipStreamSynchronize(s));
+    return PCS_OK;
+  }
   PCS_CHECK_HIP(hipMemcpyAsync(host_out, p.knn.cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   PCS_CHECK_HIP(hipStreamSynchronize(s));
   return PCS_OK;

@@ -561,3 +561,38 @@ def test_torch_hash_table_front():
     assert ht2.find_corres_step2(dev(qry), 0).shape == (2, 0)
     with pytest.raises(ValueError):
         HashTable(size=1024, device=DEV).find_corres_step2(dev(qry), 0)
+
+
+def test_one_nearest_neighbour_near_search_vs_cooperative_search(oracle):
+    """The 1-NN path of pcs_radius_graph_search (the extraction's and the harvest's graph): survivors of the super-block
+    filter first go one thread each through the 27 fine cells around them, and only the ones that search cannot settle
+    reach the cooperative search -- against the cooperative search for every survivor
+    (pcs_radius_graph_engine_only(2)) and against the oracle: the same edges and distances, on a cloud where most
+    queries sit next to a reference point, some far from any, and some exactly between two."""
+    from pcseqlearning_amd import lib as L
+    rng = np.random.default_rng(77)
+    ref = cloud(rng, 40000, 3, 12.0)
+    near = ref[rng.integers(0, len(ref), 30000)].copy()
+    near[:, 1:] += rng.normal(0, 0.03, (30000, 3)).astype(np.float32)
+    far = cloud(rng, 15000, 3, 30.0)
+    mid = (ref[:2000] + ref[1:2001]) / 2
+    mid[:, 0] = ref[:2000, 0]
+    # a crowd: 60 points within 5 cm of each of 40 places (cells of 20 cm hold 16 rows: the rest spills)
+    crowd = np.repeat(ref[:40], 60, axis=0).copy()
+    crowd[:, 1:] += rng.uniform(-0.05, 0.05, (2400, 3)).astype(np.float32)
+    ref = np.concatenate([ref, crowd]).astype(np.float32)
+    qry = np.concatenate([near, far, mid, crowd[::3] + np.float32(0.01)]).astype(np.float32)
+    qry[:, 0] = np.round(qry[:, 0])
+    lib = L.load()
+    res = []
+    for mode in (2, 0):
+        L.check(lib.pcs_radius_graph_engine_only(mode), "mode")
+        try:
+            res.append(ops.radius_graph(dev(ref), dev(qry), 0.8, 1, True, 0, 0, cell_size=0.8 / 4 * 1.0005, want_dists=True))
+        finally:
+            L.check(lib.pcs_radius_graph_engine_only(0), "mode")
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    o_ref, o_q = oracle.radius_graph(ref, qry, 0.8, 1, True)
+    np.testing.assert_array_equal(res[1][0].cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(res[1][1].cpu().numpy(), o_q)
