@@ -502,6 +502,14 @@ int pcs_points_in_frame_boxes(const float* points, const int64_t* point_frame, i
                               const float* boxes, const int32_t* box_offsets, int F, int Bmax,
                               int32_t* member, int32_t* first, pcs_stream_t stream);
 
+/* The same test summed on the fly: counts [G, Bmax] int32 += 1 for every (point j, box of its frame) that holds, under
+ * row group[j] (int64 [N], values in [0, G): the (frame, component) group of component_box_iou_frames,
+ * cluster_tracking.py:388-407 of the reference) -- the [N, Bmax] membership matrix is never written. The caller zeroes
+ * counts. Integer adds: the table does not depend on the order of the points. */
+int pcs_frame_box_counts(const float* points, const int64_t* point_frame, int64_t N, const float* boxes,
+                         const int32_t* box_offsets, int F, int Bmax, const int64_t* group, int64_t G,
+                         int32_t* counts, pcs_stream_t stream);
+
 /* Sequence loader, device side: WaymoDataset.get_lidar / load_data / __getitem__
  * (pcdet/datasets/waymo/waymo_dataset.py:334-343, 383-391, 584-630) + the point_xyz branch of
  * collate_batch (pcdet/datasets/dataset.py:222-232) for all sweeps of one sample in one pass.

@@ -1368,6 +1368,53 @@ points_in_frame_boxes_kernel(const float* __restrict__ pts, const int64_t* __res
   }
 }
 
+// The same test, but instead of the [N, Bmax] membership matrix (the largest array of the extraction: 1.5 M points x
+// 30 boxes x 4 bytes written, read again by an index_add) the launch adds every hit straight into counts[group[j],
+// box] -- the [G, Bmax] table component_box_iou_frames wants (integer adds: order-free). The boxes' cos / sin are
+// formed once per workgroup (the same double-precision expressions, rounded to fp32 as point_in_box rounds them)
+// instead of once per (point, box).
+constexpr int kBoxTrig = 2048;
+__global__ void __launch_bounds__(kBlock)
+frame_box_counts_kernel(const float* __restrict__ pts, const int64_t* __restrict__ frame, int64_t N,
+                        const float* __restrict__ boxes, const int32_t* __restrict__ box_offsets, int F, int Bmax,
+                        const int64_t* __restrict__ group, int32_t* __restrict__ counts) {
+  __shared__ float s_cos[kBoxTrig], s_sin[kBoxTrig];
+  const int nbox = box_offsets[F];
+  const bool table = nbox <= kBoxTrig;
+  if (table)
+    for (int b = threadIdx.x; b < nbox; b += kBlock) {
+      const float rz = boxes[(int64_t)b * 7 + 6];
+      s_cos[b] = (float)cos((double)(-rz));
+      s_sin[b] = (float)sin((double)(-rz));
+    }
+  __syncthreads();
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < N;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = frame[j];
+    int b0 = 0, nb = 0;
+    if (f >= 0 && f < F) { b0 = box_offsets[f]; nb = box_offsets[f + 1] - b0; }
+    const float x = pts[j * 3], y = pts[j * 3 + 1], z = pts[j * 3 + 2];
+    const int64_t g = group[j];
+    for (int bl = 0; bl < nb && bl < Bmax; ++bl) {
+      const float* __restrict__ bx = boxes + (int64_t)(b0 + bl) * 7;
+      int in;
+      if (table) {
+        const float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5];
+        if ((double)fabsf(z - cz) > (double)dz / 2.0) continue;
+        const float MARGIN = 1e-2;
+        const float cosa = s_cos[b0 + bl], sina = s_sin[b0 + bl];
+        const float sx = x - cx, sy = y - cy;
+        const float lx = sx * cosa + sy * (-sina);
+        const float ly = sx * sina + sy * cosa;
+        in = ((double)fabsf(lx) < (double)dx / 2.0 + (double)MARGIN) & ((double)fabsf(ly) < (double)dy / 2.0 + (double)MARGIN);
+      } else {
+        in = point_in_box(x, y, z, bx);
+      }
+      if (in) atomicAdd(&counts[g * Bmax + bl], 1);
+    }
+  }
+}
+
 // workspace of one problem
 struct SvWs {
   SmoothState* st;
@@ -1684,6 +1731,21 @@ int pcs_points_in_frame_boxes(const float* points, const int64_t* point_frame, i
   if (Bmax > 0 && !boxes) return PCS_ERR_ARG;
   points_in_frame_boxes_kernel<<<grid_for(N), kBlock, 0, s>>>(points, point_frame, N, boxes, box_offsets,
                                                               F, Bmax, member, first);
+  PCS_LAUNCH_CHECK();
+  return PCS_OK;
+}
+
+// counts [G, Bmax] int32 += the hits of pcs_points_in_frame_boxes' test, point j under row group[j] (group [N] int64,
+// values in [0, G)); the caller zeroes counts
+int pcs_frame_box_counts(const float* points, const int64_t* point_frame, int64_t N, const float* boxes,
+                         const int32_t* box_offsets, int F, int Bmax, const int64_t* group, int64_t G,
+                         int32_t* counts, hipStream_t s) {
+  if (N < 0 || F < 0 || Bmax < 0 || G < 0 || (N > 0 && (!points || !point_frame || !box_offsets || !group || !counts)))
+    return PCS_ERR_ARG;
+  if (N == 0 || Bmax == 0) return PCS_OK;
+  if (!boxes) return PCS_ERR_ARG;
+  frame_box_counts_kernel<<<grid_for(N), kBlock, 0, s>>>(points, point_frame, N, boxes, box_offsets, F, Bmax, group,
+                                                         counts);
   PCS_LAUNCH_CHECK();
   return PCS_OK;
 }

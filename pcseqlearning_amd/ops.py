@@ -733,6 +733,23 @@ def points_in_frame_boxes(points, point_frame, boxes, box_offsets, bmax, want_me
     return member, first
 
 
+def frame_box_counts(points, point_frame, boxes, box_offsets, bmax, group, num_groups):
+    """counts [num_groups, bmax] int32: how many points of every group lie in every box of their frame (the test of
+    points_in_frame_boxes, the sum of component_box_iou_frames' index_add) without the [N, bmax] membership matrix."""
+    L.require_gpu(points, "frame_box_counts")
+    lib = L.load()
+    points = points.float().contiguous()
+    frame = point_frame.long().contiguous()
+    boxes = boxes.float().contiguous()
+    group = group.long().contiguous()
+    assert points.shape[1] == 3 and box_offsets.dtype == torch.int32 and box_offsets.is_cuda
+    counts = torch.zeros(num_groups, bmax, dtype=torch.int32, device=points.device)
+    L.check(lib.pcs_frame_box_counts(L.ptr(points), L.ptr(frame), L.i64(points.shape[0]), L.ptr(boxes),
+                                     L.ptr(box_offsets.contiguous()), L.i32(box_offsets.shape[0] - 1), L.i32(bmax),
+                                     L.ptr(group), L.i64(num_groups), L.ptr(counts), L.stream()), "pcs_frame_box_counts")
+    return counts
+
+
 def assemble_sweeps(raw, seg, sweep_offsets, sweep_T, sweep_ids, batch_index=0):
     """Device side of the sequence loader (WaymoDataset.get_lidar / __getitem__ + the point_xyz
     branch of collate_batch): raw [N,8] f32 rows of all sweeps -> (point_bxyz [N,4] f32, point_feat

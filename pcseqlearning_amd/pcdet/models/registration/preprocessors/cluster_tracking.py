@@ -344,10 +344,12 @@ class ClusterTracking(nn.Module):
             sel = (v.box_cnt[out_frame] > 0).nonzero(as_tuple=True)[0]
             if sel.numel():
                 s_fr = out_frame[sel]
-                member, _ = ops.points_in_frame_boxes(full_fxyz[sel, 1:].contiguous(), s_fr, seq_boxes.attr,
-                                                      v.box_off32, v.bmax, want_first=False)
+                # (the hits of every (frame, component) group per box, summed inside the box test: no [n, bmax] matrix)
+                sel_xyz = full_fxyz[sel, 1:].contiguous()
                 gframe, gcomp, _, has_box, box, iou = component_box_iou_frames(
-                    out_comp[sel], s_fr, member, v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all, span=num_components)
+                    out_comp[sel], s_fr,
+                    (v.bmax, lambda inv, G: ops.frame_box_counts(sel_xyz, s_fr, seq_boxes.attr, v.box_off32, v.bmax, inv, G)),
+                    v.gt_local[g_ref[sel]], v.box_off, v.gt_cnt_all, span=num_components)
                 iou32 = iou.to(seq_boxes.best_iou.dtype)
                 hit = has_box & (iou32 > 0.7)
                 # (weights and selects instead of masked indexing: adding 0 / a maximum with 0 changes nothing, the

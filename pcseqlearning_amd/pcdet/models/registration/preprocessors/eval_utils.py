@@ -49,7 +49,13 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     Every point's frame must have boxes. Returns (group_frame [G], group_comp [G], inv [n],
     has_box [G], box_local [G], iou [G] float64), groups ordered by (frame, component) as the
     per-frame loop visits them."""
-    n, bmax = member.shape
+    # `member`: the [n, bmax] matrix, or a pair (bmax, counts_of) with counts_of(inv, G) -> [G, bmax] hits per group
+    # (ops.frame_box_counts: the matrix is then never formed)
+    if isinstance(member, tuple):
+        bmax, counts_of = member
+        n = component.shape[0]
+    else:
+        (n, bmax), counts_of = member.shape, None
     comp = component.long()
     if span is None:  # (any bound above the largest component id gives the same groups in the same order; a caller
         span = int(comp.max().item()) + 1 if n else 1  # that knows one saves the host read)
@@ -59,8 +65,11 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     gframe, gcomp = uniq // span, uniq % span
     # (in the membership's own int32: a group holds far fewer than 2^31 points, and the int64 copy of [n, bmax] was
     #  the largest array of the whole extraction)
-    counts = torch.zeros(G, bmax, dtype=member.dtype, device=comp.device)
-    counts.index_add_(0, inv, member)
+    if counts_of is not None:
+        counts = counts_of(inv, G)
+    else:
+        counts = torch.zeros(G, bmax, dtype=member.dtype, device=comp.device)
+        counts.index_add_(0, inv, member)
     has_box = counts.sum(1) > 0
     box = counts.argmax(1)
     size = count_into(inv, G)

@@ -224,6 +224,13 @@ def test_points_in_frame_boxes_vs_oracle(oracle):
         want_first = np.where(want.any(0), want.argmax(0), -1) if nbox[f] else np.full(len(sel), -1)
         np.testing.assert_array_equal(first[sel], want_first)
     assert member.sum() > 200
+    # the same hits summed per group inside the test (ops.frame_box_counts: no membership matrix)
+    group = rng.integers(0, 37, n)
+    counts = ops.frame_box_counts(dev(pts), dev(frame.astype(np.int64)), dev(boxes), dev(off), bmax,
+                                  dev(group.astype(np.int64)), 37).cpu().numpy()
+    want_counts = np.zeros((37, bmax), np.int64)
+    np.add.at(want_counts, group, member)
+    np.testing.assert_array_equal(counts, want_counts)
 
 
 def _run_icp(g, radius, cell=0.0, chunk=8):
