@@ -60,7 +60,7 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
     if span is None:  # (any bound above the largest component id gives the same groups in the same order; a caller
         span = int(comp.max().item()) + 1 if n else 1  # that knows one saves the host read)
     key = frame.long() * span + comp
-    uniq, inv = key.unique(return_inverse=True)
+    uniq, inv, size = key.unique(return_inverse=True, return_counts=True)  # (the groups' sizes come with the sort)
     G = uniq.numel()
     gframe, gcomp = uniq // span, uniq % span
     # (in the membership's own int32: a group holds far fewer than 2^31 points, and the int64 copy of [n, bmax] was
@@ -72,10 +72,9 @@ def component_box_iou_frames(component, frame, member, gt_local, box_offsets, gt
         counts.index_add_(0, inv, member)
     has_box = counts.sum(1) > 0
     box = counts.argmax(1)
-    size = count_into(inv, G)
-    in_gt = gt_local >= 0
-    hist = count_into(inv * bmax + gt_local.long().clamp(min=0), G * bmax, in_gt).reshape(G, bmax)
-    inter = hist.gather(1, box[:, None])[:, 0]
+    # |component & gt(box)|: the group's points whose own gt box is the group's box (one count per group, not the
+    # [G, bmax] histogram of which only column `box` was read)
+    inter = count_into(inv, G, (gt_local >= 0) & (gt_local.long() == box[inv]))
     gbox = (box_offsets[gframe] + box).clamp(max=max(gt_count_all.numel() - 1, 0))
     union = size + gt_count_all.long()[gbox] - inter
     iou = inter.double() / (union.double() + 1e-6)
