@@ -79,6 +79,73 @@ int pcs_cpu_radius_graph_search(const float* ref, int64_t N, const float* query,
 int pcs_cpu_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query, float* dists,
                               const void* ws, size_t ws_bytes, pcs_stream_t stream);
 
+/* second set (round 5, oracle/pcs_cpu_twins2.cpp): serial restatements of the reference lines each one cites there;
+ * workspaces are not needed on the host (the *_workspace_bytes twins return 0; pass NULL / 0) */
+int pcs_cpu_segment_pick(const int32_t* order, const int32_t* seg_start, int64_t v, int pick_last, int64_t* out,
+                         pcs_stream_t stream);
+int pcs_cpu_segment_median_i64(const int64_t* data, const int32_t* order, const int32_t* seg_start, int64_t v,
+                               int64_t* out, pcs_stream_t stream);
+int pcs_cpu_segment_minmax_f32(const float* data, int d, const int32_t* order, const int32_t* seg_start, int64_t v,
+                               int is_max, float* out, pcs_stream_t stream);
+int pcs_cpu_hash_insert(int64_t* keys, float* values, int64_t* reverse, int64_t H, const int64_t* dims, int D,
+                        const int64_t* insert_keys, const float* insert_values, int64_t n, pcs_stream_t stream);
+size_t pcs_cpu_radius_graph_table_workspace_bytes(int64_t M);
+int pcs_cpu_radius_graph_table_count(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                                     const int64_t* dims, int D, const int64_t* query_keys, const float* query_values,
+                                     int64_t M, const int32_t* qmin, const int32_t* qmax, const float* radius,
+                                     int max_nbr, int32_t* degree, int32_t* offset, int64_t* d_num_edges, void* ws,
+                                     size_t ws_bytes, pcs_stream_t stream);
+int pcs_cpu_radius_graph_table_fill(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                                    const int64_t* dims, int D, const int64_t* query_keys, const float* query_values,
+                                    int64_t M, const int32_t* qmin, const int32_t* qmax, const float* radius,
+                                    int sort_by_dist, const int32_t* degree, const int32_t* offset, int64_t* edges,
+                                    float* dists, pcs_stream_t stream);
+int pcs_cpu_correspondence(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                           const int64_t* dims, int D, const int64_t* query_keys, const float* query_values, int64_t M,
+                           const int32_t* qmin, const int32_t* qmax, int64_t* corres_indices, pcs_stream_t stream);
+int pcs_cpu_points_in_radius(const int64_t* keys, const float* values, const int64_t* reverse, int64_t H,
+                             const int64_t* dims, int D, const int64_t* query_keys, const float* query_values, int64_t M,
+                             const int32_t* qmin, const int32_t* qmax, float radius, int64_t* visited,
+                             pcs_stream_t stream);
+size_t pcs_cpu_neighbor_table_bytes(int64_t num_out, int kv);
+int pcs_cpu_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv, int inverse,
+                                 int64_t num_out, int32_t* table, pcs_stream_t stream);
+int pcs_cpu_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv, int cout, int centre,
+                                  const int32_t* table, int64_t num_out, const float* bias, const float* scale,
+                                  const float* shift, int relu, float* out, pcs_stream_t stream);
+int pcs_cpu_bn_fold_f32(const float* weight, const float* bias, const float* running_mean, const float* inv_std, int C,
+                        float* scale, float* shift, pcs_stream_t stream);
+size_t pcs_cpu_indice_conv_backward_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin, int cout);
+int pcs_cpu_indice_conv_backward_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                                     const float* out_grad, const int32_t* pairs, int64_t pair_stride,
+                                     const int32_t* num, int64_t num_in, int64_t num_out, int inverse, int subm,
+                                     float* in_grad, float* filters_grad, void* ws, size_t ws_bytes,
+                                     pcs_stream_t stream);
+int pcs_cpu_indice_maxpool_f32(const float* features, int C, const int32_t* pairs, int64_t pair_stride,
+                               const int32_t* num, int kv, int64_t num_out, float* out, void* ws, size_t ws_bytes,
+                               pcs_stream_t stream);
+int pcs_cpu_indice_maxpool_backward_f32(const float* features, const float* out_features, const float* out_grad, int C,
+                                        const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
+                                        int64_t num_in, float* in_grad, void* ws, size_t ws_bytes,
+                                        pcs_stream_t stream);
+int pcs_cpu_sparse_to_dense(const float* features, const int32_t* indices, int64_t V, int C, int B, int D, int H, int W,
+                            float* out, int* status, pcs_stream_t stream);
+int pcs_cpu_points_in_frame_boxes(const float* points, const int64_t* point_frame, int64_t N, const float* boxes,
+                                  const int32_t* box_offsets, int F, int Bmax, int32_t* member, int32_t* first,
+                                  pcs_stream_t stream);
+int pcs_cpu_frame_box_counts(const float* points, const int64_t* point_frame, int64_t N, const float* boxes,
+                             const int32_t* box_offsets, int F, int Bmax, const int64_t* group, int64_t G,
+                             int32_t* counts, pcs_stream_t stream);
+int pcs_cpu_assemble_sweeps(const float* raw, const int32_t* seg, const int64_t* sweep_offsets, const double* sweep_T,
+                            const int32_t* sweep_ids, int num_sweeps, int64_t N, int batch_index, float* point_bxyz,
+                            float* point_feat, int32_t* point_sweep, int32_t* segmentation_label,
+                            int32_t* instance_label, pcs_stream_t stream);
+size_t pcs_cpu_smooth_velo_workspace_bytes(int64_t C, int F);
+int pcs_cpu_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64_t C, int F, int frame_lo, int frame_hi,
+                        float weight0, float weight, int num_itr, float stopping, void* ws, size_t ws_bytes,
+                        pcs_stream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif
