@@ -20,7 +20,7 @@ class Buf:
     """one argument array: its host copy (the twin's) and its device copy (the entry's)"""
 
     def __init__(self, a):
-        self.h = np.ascontiguousarray(a)
+        self.h = np.array(a, order="C", copy=True)  # (the twin writes into it)
         self.d = torch.from_numpy(self.h.copy()).to(DEV)
 
     def device(self):
