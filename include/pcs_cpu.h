@@ -78,6 +78,12 @@ int pcs_cpu_radius_graph_search(const float* ref, int64_t N, const float* query,
                                 int64_t* d_num_edges, void* ws, size_t ws_bytes, pcs_stream_t stream);
 int pcs_cpu_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref, int64_t* e_query, float* dists,
                               const void* ws, size_t ws_bytes, pcs_stream_t stream);
+/* the components of that graph cut at n_cut radii (pcs_radius_graph_components; needs sort_by_dist = 1 in the search:
+ * the workspace then holds the squared distances) */
+size_t pcs_cpu_radius_graph_components_workspace_bytes(int64_t M, int n_cut);
+int pcs_cpu_radius_graph_components(int64_t N, int64_t M, int max_nbr, const float* radius_cut, int n_cut,
+                                    int64_t* component, int64_t* d_num, const void* ws, size_t ws_bytes, void* ws_cc,
+                                    size_t ws_cc_bytes, pcs_stream_t stream);
 
 /* second set (round 5, oracle/pcs_cpu_twins2.cpp): serial restatements of the reference lines each one cites there;
  * workspaces are not needed on the host (the *_workspace_bytes twins return 0; pass NULL / 0) */

@@ -211,4 +211,33 @@ int pcs_cpu_radius_graph_emit(int64_t N, int64_t M, int max_nbr, int64_t* e_ref,
   return CPU_OK;
 }
 
+// ClusterProposal.propose_cluster's graphs + components (cluster_proposal.py:57-83, graph_utils.py:40-53) from the edges
+// pcs_cpu_radius_graph_search left in `ws`: per cut radius the edges with dist2 <= fl32(r) * fl32(r), then the
+// components' ranks by smallest node id. component [n_cut, M]; d_num [n_cut].
+size_t pcs_cpu_radius_graph_components_workspace_bytes(int64_t, int) { return 0; }
+int pcs_cpu_radius_graph_components(int64_t N, int64_t M, int max_nbr, const float* radius_cut, int n_cut,
+                                    int64_t* component, int64_t* d_num, const void* ws, size_t ws_bytes, void*, size_t,
+                                    pcs_stream_t) {
+  if (!ws || !radius_cut || !component || !d_num || M < 0 || N != M || max_nbr < 1 || max_nbr > 32 || n_cut < 1 ||
+      n_cut > 8)
+    return CPU_ERR_ARG;
+  if (ws_bytes < pcs_cpu_radius_graph_workspace_bytes(N, M, max_nbr)) return PCS_ERR_WORKSPACE;
+  const size_t cap = (size_t)(M > 0 ? M : 1) * (size_t)max_nbr;
+  const int64_t* head = (const int64_t*)ws;
+  const int64_t E = head[0];
+  const int64_t* e_ref = head + 1;
+  const int64_t* e_qry = e_ref + cap;
+  const float* dists = (const float*)(e_qry + cap);
+  std::vector<int64_t> a, b;
+  for (int c = 0; c < n_cut; ++c) {
+    const float r2 = radius_cut[c] * radius_cut[c];
+    a.clear();
+    b.clear();
+    for (int64_t e = 0; e < E; ++e)
+      if (dists[e] <= r2) { a.push_back(e_ref[e]); b.push_back(e_qry[e]); }
+    d_num[c] = orc_connected_components(a.data(), b.data(), (int64_t)a.size(), M, component + (int64_t)c * M);
+  }
+  return CPU_OK;
+}
+
 }  // extern "C"

@@ -419,3 +419,34 @@ def test_box_loader_and_velocity_twins():
                                         ctypes.c_size_t(0), None) == 0
         assert 3 < it[0] <= 300
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_radius_graph_components_twin():
+    """pcs_cpu_radius_graph_components on the workspace of pcs_cpu_radius_graph_search (a cloud on itself, 32 nearest,
+    nearest first): per cut radius the labels scipy gives the same edge set (rank of the component's smallest node)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    main, _ = _libs()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(41)
+    n, K = 1200, 32
+    centres = rng.uniform(0, 30, (60, 3))
+    pts = np.concatenate([np.zeros((n, 1)), centres[rng.integers(0, 60, n)] + rng.normal(0, 0.35, (n, 3))], 1).astype(np.float32)
+    main.pcs_cpu_radius_graph_workspace_bytes.restype = ctypes.c_size_t
+    nb = main.pcs_cpu_radius_graph_workspace_bytes(_i64(n), _i64(n), ctypes.c_int(K))
+    ws, E = np.zeros(nb, np.uint8), np.zeros(1, np.int64)
+    assert main.pcs_cpu_radius_graph_search(p(pts), _i64(n), p(pts), _i64(n), ctypes.c_float(1.25), ctypes.c_float(0), ctypes.c_int(0),
+                                            ctypes.c_int(0), ctypes.c_int(K), ctypes.c_int(1), p(E), p(ws), ctypes.c_size_t(nb), None) == 0
+    cuts = np.array([1.25, 0.75, 0.25], np.float32)
+    comp, num = np.zeros((3, n), np.int64), np.zeros(3, np.int64)
+    assert main.pcs_cpu_radius_graph_components(_i64(n), _i64(n), ctypes.c_int(K), p(cuts), ctypes.c_int(3), p(comp), p(num), p(ws),
+                                                ctypes.c_size_t(nb), None, ctypes.c_size_t(0), None) == 0
+    e_ref, e_q, d = np.zeros(E[0], np.int64), np.zeros(E[0], np.int64), np.zeros(E[0], np.float32)
+    assert main.pcs_cpu_radius_graph_emit(_i64(n), _i64(n), ctypes.c_int(K), p(e_ref), p(e_q), p(d), p(ws), ctypes.c_size_t(nb), None) == 0
+    assert num[0] < num[1] < num[2] <= n
+    for c, r in enumerate(cuts):
+        keep = d <= r * r
+        g = coo_matrix((np.ones(keep.sum()), (e_ref[keep], e_q[keep])), shape=(n, n))
+        want_n, want = connected_components(g, directed=True, connection="weak")
+        assert num[c] == want_n
+        np.testing.assert_array_equal(comp[c], want)

@@ -227,3 +227,47 @@ def test_smooth_velo_twin_beside_the_entry():
         both("smooth_velo", v, db, I64(C), I32(Fv), I32(lo), I32(hi), F32(1), F32(10), I32(300), F32(1e-3), Ws(sw(I64(C), I32(Fv))))
         assert np.abs(v.device() - v.h).max() < 1e-4
         assert np.abs(v.h - v0).max() > 1e-2
+
+
+def test_radius_graph_twins_beside_the_entries():
+    """pcs_radius_graph_search / _emit / _components and their twins on one cloud: each side keeps the edges in its own
+    workspace between the calls; the edge lists (grouped by query, nearest first, ties by the reference index), the
+    squared distances and the component labels at three cut radii must be identical."""
+    rng = np.random.default_rng(66)
+    n, K = 30000, 32
+    centres = rng.uniform(0, 60, (900, 3))
+    pts = Buf(np.concatenate([rng.integers(0, 2, (n, 1)), centres[rng.integers(0, 900, n)] + rng.normal(0, 0.3, (n, 3))],
+                             1).astype(np.float32))
+    lib, cpu = L.load(), _cpu()
+    cpu.pcs_cpu_radius_graph_workspace_bytes.restype = ctypes.c_size_t
+    nb_g = lib.pcs_radius_graph_workspace_bytes(I64(n), I64(n), I32(K))
+    nb_c = cpu.pcs_cpu_radius_graph_workspace_bytes(I64(n), I64(n), I32(K))
+    ws_g, ws_c = L.workspace(nb_g, DEV), np.zeros(nb_c, np.uint8)
+    E_g, E_c = torch.zeros(1, dtype=torch.int64, device=DEV), np.zeros(1, np.int64)
+    L.check(lib.pcs_radius_graph_search(L.ptr(pts.d), I64(n), L.ptr(pts.d), I64(n), F32(1.25), F32(0), I32(0), I32(0), I32(K), I32(1),
+                                        L.ptr(E_g), L.ptr(ws_g), ctypes.c_size_t(nb_g), L.stream()), "search")
+    hp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert cpu.pcs_cpu_radius_graph_search(hp(pts.h), I64(n), hp(pts.h), I64(n), F32(1.25), F32(0), I32(0), I32(0), I32(K), I32(1),
+                                           hp(E_c), hp(ws_c), ctypes.c_size_t(nb_c), None) == 0
+    E = int(E_g.item())
+    assert E == E_c[0] and E > n
+    eg = [torch.zeros(E, dtype=torch.int64, device=DEV), torch.zeros(E, dtype=torch.int64, device=DEV),
+          torch.zeros(E, dtype=torch.float32, device=DEV)]
+    ec = [np.zeros(E, np.int64), np.zeros(E, np.int64), np.zeros(E, np.float32)]
+    L.check(lib.pcs_radius_graph_emit(I64(n), I64(n), I32(K), *(L.ptr(t) for t in eg), L.ptr(ws_g), ctypes.c_size_t(nb_g),
+                                      L.stream()), "emit")
+    assert cpu.pcs_cpu_radius_graph_emit(I64(n), I64(n), I32(K), *(hp(a) for a in ec), hp(ws_c), ctypes.c_size_t(nb_c), None) == 0
+    for t, a in zip(eg, ec):
+        np.testing.assert_array_equal(t.cpu().numpy(), a)
+    cuts = np.array([1.25, 0.75, 0.25], np.float32)
+    nb_cc = lib.pcs_radius_graph_components_workspace_bytes(I64(n), I32(3))
+    ws_cc = L.workspace(nb_cc, DEV)
+    comp_g, num_g = torch.zeros(3, n, dtype=torch.int64, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV)
+    comp_c, num_c = np.zeros((3, n), np.int64), np.zeros(3, np.int64)
+    L.check(lib.pcs_radius_graph_components(I64(n), I64(n), I32(K), hp(cuts), I32(3), L.ptr(comp_g), L.ptr(num_g), L.ptr(ws_g),
+                                            ctypes.c_size_t(nb_g), L.ptr(ws_cc), ctypes.c_size_t(nb_cc), L.stream()), "components")
+    assert cpu.pcs_cpu_radius_graph_components(I64(n), I64(n), I32(K), hp(cuts), I32(3), hp(comp_c), hp(num_c), hp(ws_c),
+                                               ctypes.c_size_t(nb_c), None, ctypes.c_size_t(0), None) == 0
+    np.testing.assert_array_equal(num_g.cpu().numpy(), num_c)
+    np.testing.assert_array_equal(comp_g.cpu().numpy(), comp_c)
+    assert num_c[0] < num_c[1] < num_c[2]
