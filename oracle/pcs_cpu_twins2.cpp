@@ -481,7 +481,7 @@ int pcs_cpu_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64
   const int a = frame_lo, nf = frame_hi - frame_lo + 1;
   const float inv_fit = 1.0f / (float)(C * nf * 2), inv_sm = 1.0f / (float)(C * (nf - 1) * 2);
   const size_t n = (size_t)C * nf * 2;
-  std::vector<float> m(n, 0.f), s(n, 0.f), g(n);
+  std::vector<float> m(n, 0.f), s(n, 0.f), g(n), sgn(n);
   auto X = [&](int64_t c, int t, int k) -> float& { return comp_velos[(c * F + a + t) * 3 + k]; };
   auto Dd = [&](int64_t c, int t, int k) { return comp_center_diffs[(c * F + a + t) * 3 + k]; };
   float last_loss = 1e10f;
@@ -501,10 +501,15 @@ int pcs_cpu_smooth_velo(float* comp_velos, const float* comp_center_diffs, int64
         for (int k = 0; k < 2; ++k) {
           const float sm = X(c, t, k) - X(c, t + 1, k);
           sm_sum += (double)std::fabs(sm);
-          const float sg = (float)((sm > 0.f) - (sm < 0.f)) * (inv_sm * weight);
-          g[((size_t)c * nf + t) * 2 + k] += sg;
-          g[((size_t)c * nf + t + 1) * 2 + k] -= sg;
+          sgn[((size_t)c * nf + t) * 2 + k] = (float)((sm > 0.f) - (sm < 0.f)) * (inv_sm * weight);
         }
+    // (autograd adds the two branches of |v_t - v_t+1| in this order: every +, then every -)
+    for (int64_t c = 0; c < C; ++c)
+      for (int t = 0; t + 1 < nf; ++t)
+        for (int k = 0; k < 2; ++k) g[((size_t)c * nf + t) * 2 + k] += sgn[((size_t)c * nf + t) * 2 + k];
+    for (int64_t c = 0; c < C; ++c)
+      for (int t = 0; t + 1 < nf; ++t)
+        for (int k = 0; k < 2; ++k) g[((size_t)c * nf + t + 1) * 2 + k] -= sgn[((size_t)c * nf + t) * 2 + k];
     const float loss = (float)(fit_sum * inv_fit * weight0 + sm_sum * inv_sm * weight);
     const double bc1 = 1.0 - std::pow(0.9, it + 1), bc2 = 1.0 - std::pow(0.999, it + 1);
     const float step = (float)(lr / bc1), bc2s = (float)std::sqrt(bc2), decay = (float)(1.0 - lr * 1e-2);

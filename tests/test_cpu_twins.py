@@ -418,7 +418,7 @@ def test_box_loader_and_velocity_twins():
                                         ctypes.c_float(1), ctypes.c_float(10), ctypes.c_int(300), ctypes.c_float(1e-3), None,
                                         ctypes.c_size_t(0), None) == 0
         assert 3 < it[0] <= 300
-        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(got, want)
 
 
 def test_radius_graph_components_twin():

@@ -214,8 +214,8 @@ def test_box_and_loader_twins_beside_the_entries():
 
 
 def test_smooth_velo_twin_beside_the_entry():
-    """AdamW steps in fp32 on both sides; the device sums the loss in another order, so the stop step may differ by
-    one near the 1e-3 threshold: the velocities agree to 1e-4 (a step moves them by <= 1e-2 * lr-decayed)."""
+    """AdamW steps in fp32 on both sides (the twin is oracle/track_oracle.py's arithmetic bit for bit); the device sums the
+    loss and forms the step in its own order: 2e-5, the bound tests/test_gpu_tracking.py holds the entry to."""
     rng = np.random.default_rng(65)
     C, Fv = 40, 17
     d = rng.normal(0, 1, (C, Fv, 3)).astype(np.float32)
@@ -225,7 +225,7 @@ def test_smooth_velo_twin_beside_the_entry():
     for lo, hi in ((2, 12), (0, 16)):
         v, db = Buf(v0), Buf(d)
         both("smooth_velo", v, db, I64(C), I32(Fv), I32(lo), I32(hi), F32(1), F32(10), I32(300), F32(1e-3), Ws(sw(I64(C), I32(Fv))))
-        assert np.abs(v.device() - v.h).max() < 1e-4
+        assert np.abs(v.device() - v.h).max() < 2e-5
         assert np.abs(v.h - v0).max() > 1e-2
 
 
