@@ -311,7 +311,7 @@ def main():
                     help="1: ClusterTracking's EXTRACT_UNITS_TOGETHER off (the final filter and the extraction of traces unit "
                          "by unit: round 4's form; same results)")
     ap.add_argument("--chunk-iterations", type=int, default=0,
-                    help="pcs_icp_set_chunk_iterations: iterations per chunk of wide launches (0 = the library's default, 8)")
+                    help="pcs_icp_set_chunk_iterations: iterations per chunk of wide launches (0 = the library's default, 10)")
     ap.add_argument("--trace", action="store_true", help="per-step memory lines and stack dumps of steps that hang")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the extra device-synchronised step")

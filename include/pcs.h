@@ -569,7 +569,7 @@ int pcs_icp_set_grid_mode(int rebuild_always);
 /* every search of the fused ICP looks radius / radius_divisor further than it must, so that it can say how long its
  * answer stays exact (default 16; any value >= 1 gives the same results: it trades cells per search against searches). */
 int pcs_icp_set_widening(double radius_divisor);
-/* iterations per chunk of the wide schedule's launches (default 8, 1..64): the lock-step engines read their units'
+/* iterations per chunk of the wide schedule's launches (default 10, 1..64): the lock-step engines read their units'
  * states once per chunk. A scheduling parameter: results do not depend on it. */
 int pcs_icp_set_chunk_iterations(int n);
 /* the verified cache of the fused ICP: 2 (default) = budgets and the second level (a query whose budget has run out

@@ -2619,14 +2619,15 @@ int icp_enqueue_begin(const IcpProblem* tab, const Batch& bt, const IcpHint* hin
 }
 
 // The schedule of the iterations (pcs_icp_set_schedule, include/pcs.h): how many iterations of a registration
-// run as wide launches before a unit-resident loop takes over (INT_MAX: all of them, in chunks of 8 -- the
+// run as wide launches before a unit-resident loop takes over (INT_MAX: all of them, in chunks of 10 -- the
 // default, measured fastest: DESIGN.md section 4), and which resident loop (tile path / cache path).
 static std::atomic<int> g_wide_iters{INT_MAX};
 static std::atomic<int> g_use_tiles{1};
 static int icp_wide_limit() { return g_wide_iters.load(std::memory_order_relaxed); }
 // iterations per chunk of wide launches (pcs_icp_set_chunk_iterations; the lock-step engines read their units' states
-// once per chunk)
-static std::atomic<int> g_chunk_iters{8};
+// once per chunk). 10: measured on one box, alternating, 3 rounds: 8 -> 964-979 ms per batch of 12, 10 -> 959-963, 12 ->
+// 954-969 (a registration runs 24 iterations at most: 10 + 10 + 4)
+static std::atomic<int> g_chunk_iters{10};
 static bool icp_use_tiles() { return g_use_tiles.load(std::memory_order_relaxed) != 0; }
 
 // end of a wide chunk: the stop rule of every entry's last iteration (the others were settled by the next
@@ -2661,7 +2662,7 @@ int icp_enqueue_chunk(const IcpProblem* tab, const Batch& bt, const BatchInts& k
   static thread_local IcpHint hf[kMaxBatch];
   bf.n = 0;
   const int chunk_iters = g_chunk_iters.load(std::memory_order_relaxed);
-  int n_wide = 0;  // iterations to launch: at most chunk_iters (8) per chunk
+  int n_wide = 0;  // iterations to launch: at most chunk_iters per chunk
   bool any_first = false, all_wide = true;
   for (int e = 0; e < bt.n; ++e) {
     if (kbase.v[e] < wide_limit) {
@@ -2811,7 +2812,7 @@ int pcs_icp_set_cache_levels(int levels) {
   return PCS_OK;
 }
 
-// pcs_icp_set_chunk_iterations: iterations per chunk of the wide schedule (default 8; 1..64). Results do not depend on
+// pcs_icp_set_chunk_iterations: iterations per chunk of the wide schedule (default 10; 1..64). Results do not depend on
 // it: a chunk is a scheduling unit of the lock-step engines.
 int pcs_icp_set_chunk_iterations(int n) {
   if (n < 1 || n > 64) return PCS_ERR_ARG;

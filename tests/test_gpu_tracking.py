@@ -166,6 +166,20 @@ def test_track_frame_vs_oracle_grid_rebuilt_every_iteration():
         ops.icp_set_grid_mode(False)
 
 
+@pytest.mark.parametrize("chunk", [3, 8, 16])
+def test_track_frame_vs_oracle_chunk_lengths(chunk):
+    """pcs_icp_set_chunk_iterations is a scheduling parameter (default 10): the engines read their units' states every
+    `chunk` iterations, the stop rule is decided on the device at every iteration -- the oracle's ids and transforms
+    for chunks shorter and longer than the default, and for one that does not divide the iteration limit."""
+    from pcseqlearning_amd import lib as L
+    import ctypes
+    L.check(L.load().pcs_icp_set_chunk_iterations(ctypes.c_int(chunk)), "pcs_icp_set_chunk_iterations")
+    try:
+        test_track_frame_vs_oracle(True)
+    finally:
+        L.check(L.load().pcs_icp_set_chunk_iterations(ctypes.c_int(10)), "pcs_icp_set_chunk_iterations")
+
+
 def test_track_frame_vs_reference():
     """Against the reference's own track_frame output: the extraction overlaps > 90 % and the
     first tracked frames agree to fp32 noise (see tests/test_oracle_tracking.py for why the
