@@ -566,8 +566,9 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("the iteration launches of the fused ICP, chunk by chunk: icp_nn_kernel (verified-cache budget "
-                           "test, moments) + icp_nn_search_kernel + icp_solve_kernel + icp_apply_kernel, eight "
-                           "iterations of every registration in flight per chunk" if args.schedule == "wide" else
+                           "test, moments) + icp_nn_search_kernel + icp_solve_kernel + icp_apply_kernel, "
+                           f"{args.chunk_iterations or 10} iterations of every registration in flight per chunk"
+                           if args.schedule == "wide" else
                            "icp_tile_kernel / icp_loop_kernel (fused ICP, one 1024-thread workgroup per tracking unit: "
                            "budget test, searches, moments, solve, stop rule, apply -- all iterations of a chunk)"),
                 "schedule": args.schedule,
