@@ -571,7 +571,7 @@ def main():
                            if args.schedule == "wide" else
                            "icp_tile_kernel / icp_loop_kernel (fused ICP, one 1024-thread workgroup per tracking unit: "
                            "budget test, searches, moments, solve, stop rule, apply -- all iterations of a chunk)"),
-                "schedule": args.schedule,
+                "schedule": args.schedule, "iterations_per_chunk": args.chunk_iterations or 10,
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes": "SURVEY 8(d): 112 (Mn + Rn) + 144 C_live per unit and iteration",

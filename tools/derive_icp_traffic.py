@@ -1,5 +1,5 @@
 """(fetch + write) / algorithmic bytes of the ICP iteration kernels from the two PMC passes of
-tools/pmc_batch.sh and the bench line one of them printed (algorithmic bytes per chunk -- eight iterations
+tools/pmc_batch.sh and the bench line one of them printed (algorithmic bytes per chunk -- a chunk's iterations
 of the four iteration kernels -- in that same schedule).
   python tools/derive_icp_traffic.py <FETCH.json> <WRITE.json> <bench line .json>  > profiles/<tag>_icp_hbm_pmc.json
 FETCH_SIZE / WRITE_SIZE are KB per dispatch as rocprofv3 reports them (TCC_EA request counters x 64 B at the
@@ -35,8 +35,11 @@ def main():
                                         "mean_duration_us_under_pmc": du}
         tot_f += f * 1024.0
         tot_w += w * 1024.0
-    # bench.py's roofline row is per CHUNK (a "launch" there): eight iterations = eight dispatches of each kernel
-    per_chunk = 8.0
+    # bench.py's roofline row is per CHUNK (a "launch" there): a chunk's iterations = that many dispatches of each
+    # kernel (pcs_icp_set_chunk_iterations; the bench line says how many: 8 until the end of round 5, then 10)
+    import re
+    m = re.search(r"(\d+) iterations of every registration", line["roofline"].get("kernel", ""))
+    per_chunk = float(line["roofline"].get("iterations_per_chunk") or (m.group(1) if m else 8))
     alg = float(line["roofline"].get("algorithmic_bytes_per_launch") or 0.0)
     out["icp_chunk_fetch_bytes"] = round(tot_f * per_chunk, 1)
     out["icp_chunk_write_bytes"] = round(tot_w * per_chunk, 1)
@@ -44,7 +47,7 @@ def main():
     if alg > 0:
         out["icp_chunk_traffic_over_algorithmic"] = round((tot_f + tot_w) * per_chunk / alg, 3)
         out["icp_chunk_traffic_over_algorithmic_fetch_x2"] = round((2 * tot_f + tot_w) * per_chunk / alg, 3)
-    out["note"] = ("every dispatch of the four iteration kernels is counted (live and gated alike; eight of each per chunk), "
+    out["note"] = ("every dispatch of the four iteration kernels is counted (live and gated alike; " + str(int(per_chunk)) + " of each per chunk), "
                    "the algorithmic bytes are those of the event-timed chunks of the same run (live unit-iterations only): "
                    "the ratio describes the schedule, not one launch")
     json.dump(out, sys.stdout, indent=1)
