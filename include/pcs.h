@@ -157,6 +157,15 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
                               int cout, int centre, const int32_t* table, int64_t num_out,
                               const float* bias, const float* scale, const float* shift, int relu,
                               float* out, pcs_stream_t stream);
+/* The same with a residual row added before the ReLU: out = relu(((conv + bias) * scale + shift) + residual[o,:]) --
+ * the tail of SparseBasicBlock.forward (pcdet/models/blocks/spconv_blocks.py:47-64: bn2(conv2(.)) + identity, relu) in
+ * the second conv's epilogue instead of two more passes over the block's output; the same operations in the same order
+ * as the separate add and ReLU, hence the same bits. residual [num_out, cout] f32, must not be `out`; NULL = the
+ * entry above. */
+int pcs_indice_conv_table_residual_f32(const float* features, int cin, const float* filters, int kv,
+                                       int cout, int centre, const int32_t* table, int64_t num_out,
+                                       const float* bias, const float* scale, const float* shift,
+                                       const float* residual, int relu, float* out, pcs_stream_t stream);
 
 /* sparse_conv_ext.indice_conv_backward_fp32 (src/all.cc:34-37; indiceConvBackward,
  * include/spconv/spconv_ops.h:363-449): features [num_in,cin], filters [kv,cin,cout],

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(kBlock)
 indice_conv_tile_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
                         int kv, int centre, const int32_t* __restrict__ table, int64_t num_out,
                         const float* __restrict__ bias, const float* __restrict__ scale,
-                        const float* __restrict__ shift, int relu, float* __restrict__ out) {
+                        const float* __restrict__ shift, int relu, const float* __restrict__ residual,
+                        float* __restrict__ out) {
   constexpr int COUT = NC * 16;
   __shared__ float As[TM][CIN_MAX + 1];
   __shared__ float Ws[CIN_MAX][COUT];
@@ -98,6 +99,7 @@ indice_conv_tile_kernel(const float* __restrict__ feat, int cin, const float* __
       float v = acc[i][n];
       if (bias) v = v + bias[col];
       if (scale) v = fmaf(v, scale[col], shift[col]);
+      if (residual) v = v + residual[r * COUT + col];
       if (relu) v = fmaxf(v, 0.f);
       out[r * COUT + col] = v;
     }
@@ -119,7 +121,8 @@ __global__ void __launch_bounds__(kBlock)
 indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W,
                         int kv, int centre, const int32_t* __restrict__ table, int64_t num_out,
                         const float* __restrict__ bias, const float* __restrict__ scale,
-                        const float* __restrict__ shift, int relu, float* __restrict__ out) {
+                        const float* __restrict__ shift, int relu, const float* __restrict__ residual,
+                        float* __restrict__ out) {
   constexpr int COUT = NC * 16;
   constexpr int W_LD = COUT + 16;  // k and k+1 land 16 banks apart: conflict-free 32-lane groups
   constexpr int NA = TM * CIN_MAX / 4 / kBlock;     // float4 A loads per thread at Cin = 64
@@ -222,6 +225,7 @@ indice_conv_mfma_kernel(const float* __restrict__ feat, int cin, const float* __
       float v = acc[n][j];
       if (bias) v = v + bias[col];
       if (scale) v = fmaf(v, scale[col], shift[col]);
+      if (residual) v = v + residual[r * COUT + col];
       if (relu) v = fmaxf(v, 0.f);
       out[r * COUT + col] = v;
     }
@@ -247,7 +251,8 @@ __global__ void __launch_bounds__(kDirF32Block)
 indice_conv_f32_direct_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W, int kv,
                               int centre, const int32_t* __restrict__ table, int64_t num_out,
                               const float* __restrict__ bias, const float* __restrict__ scale,
-                              const float* __restrict__ shift, int relu, float* __restrict__ out,
+                              const float* __restrict__ shift, int relu, const float* __restrict__ residual,
+                        float* __restrict__ out,
                               const int32_t* __restrict__ order) {
   constexpr int COUT = NC * 16;
   constexpr int MT = 2;
@@ -353,6 +358,7 @@ indice_conv_f32_direct_kernel(const float* __restrict__ feat, int cin, const flo
         float v = acc[m][n][j];
         if (bias) v = v + bias[col];
         if (scale) v = fmaf(v, scale[col], shift[col]);
+        if (residual) v = v + residual[r * COUT + col];
         if (relu) v = fmaxf(v, 0.f);
         out[r * COUT + col] = v;
       }
@@ -370,7 +376,8 @@ __global__ void __launch_bounds__(kBlock)
 indice_conv_f32_rows_kernel(const float* __restrict__ feat, int cin, const float* __restrict__ W, int kv,
                             int centre, const int32_t* __restrict__ table, int64_t num_out,
                             const float* __restrict__ bias, const float* __restrict__ scale,
-                            const float* __restrict__ shift, int relu, float* __restrict__ out) {
+                            const float* __restrict__ shift, int relu, const float* __restrict__ residual,
+                        float* __restrict__ out) {
   constexpr int kMaxW = 32 * 8 * COUT;  // kv <= 32, cin <= 8
   __shared__ float Wf[kMaxW];
   for (int e = threadIdx.x; e < kv * cin * COUT; e += kBlock) Wf[e] = W[e];
@@ -418,6 +425,7 @@ indice_conv_f32_rows_kernel(const float* __restrict__ feat, int cin, const float
       float x = acc[col];
       if (bias) x = x + bias[col];
       if (scale) x = fmaf(x, scale[col], shift[col]);
+      if (residual) x = x + residual[r * COUT + col];
       if (relu) x = fmaxf(x, 0.f);
       v[j] = x;
     }
@@ -431,7 +439,7 @@ indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float*
                            int kv, int cout, int centre, const int32_t* __restrict__ table,
                            int64_t num_out, const float* __restrict__ bias,
                            const float* __restrict__ scale, const float* __restrict__ shift,
-                           int relu, float* __restrict__ out) {
+                           int relu, const float* __restrict__ residual, float* __restrict__ out) {
   int64_t total = num_out * cout;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -449,6 +457,7 @@ indice_conv_generic_kernel(const float* __restrict__ feat, int cin, const float*
     }
     if (bias) acc = acc + bias[col];
     if (scale) acc = fmaf(acc, scale[col], shift[col]);
+    if (residual) acc = acc + residual[t];
     if (relu) acc = fmaxf(acc, 0.f);
     out[t] = acc;
   }
@@ -551,7 +560,7 @@ int pcs_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, const in
 static int conv_table_f32(const float* features, int cin, const float* filters, int kv,
                           int cout, int centre, const int32_t* table, int64_t num_out,
                           const float* bias, const float* scale, const float* shift, int relu,
-                          float* out, const int32_t* order, hipStream_t s) {
+                          float* out, const int32_t* order, hipStream_t s, const float* residual = nullptr) {
   if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 ||
       centre >= kv || (scale && !shift))
     return PCS_ERR_ARG;
@@ -573,7 +582,7 @@ static int conv_table_f32(const float* features, int cin, const float* filters, 
     const int nbd = (int)((num_out + kDirF32Rows - 1) / kDirF32Rows);
 #define PCS_F32_DIRECT(NCV)                                                                                       \
   indice_conv_f32_direct_kernel<NCV><<<nbd, kDirF32Block, 0, s>>>(features, cin, filters, kv, centre, table, num_out, \
-                                                                 bias, scale, shift, relu, out, order)
+                                                                 bias, scale, shift, relu, residual, out, order)
     switch (cout) {
       case 16: PCS_F32_DIRECT(1); break;
       case 32: PCS_F32_DIRECT(2); break;
@@ -587,7 +596,7 @@ static int conv_table_f32(const float* features, int cin, const float* filters, 
   if (cout_ok && g_use_mfma && kv <= 32 && (cin % 4 == 0) && cin >= 16 && cin <= 8 * CIN_MAX) {
 #define PCS_MFMA_LAUNCH(NCV, WIDEV)                                                                   \
   indice_conv_mfma_kernel<NCV, WIDEV><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, \
-                                                                 table, num_out, bias, scale, shift, relu, out)
+                                                                 table, num_out, bias, scale, shift, relu, residual, out)
     const bool wide = cin > CIN_MAX;
     switch (cout) {
       case 16:
@@ -610,30 +619,30 @@ static int conv_table_f32(const float* features, int cin, const float* filters, 
   if (cin <= 8 && kv <= 32 && (cout == 16 || cout == 32) && g_use_mfma != 2) {
     const int nbr = (int)((num_out + kBlock - 1) / kBlock);
     if (cout == 16)
-      indice_conv_f32_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+      indice_conv_f32_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
     else
-      indice_conv_f32_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+      indice_conv_f32_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
     PCS_LAUNCH_CHECK();
     return PCS_OK;
   }
   if (tiled) {
     switch (cout) {
       case 16:
-        indice_conv_tile_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        indice_conv_tile_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
         break;
       case 32:
-        indice_conv_tile_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        indice_conv_tile_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
         break;
       case 64:
-        indice_conv_tile_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        indice_conv_tile_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
         break;
       default:
-        indice_conv_tile_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, out);
+        indice_conv_tile_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, scale, shift, relu, residual, out);
         break;
     }
   } else {
     indice_conv_generic_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(
-        features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out);
+        features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, residual, out);
   }
   PCS_LAUNCH_CHECK();
   return PCS_OK;
@@ -645,6 +654,19 @@ int pcs_indice_conv_table_f32(const float* features, int cin, const float* filte
                               float* out, hipStream_t s) {
   return conv_table_f32(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out,
                         nullptr, s);
+}
+
+// the same with a residual row added before the ReLU: relu((conv * scale + shift) + residual[o,:]) -- the tail of
+// SparseBasicBlock.forward (pcdet/models/blocks/spconv_blocks.py:47-64 of the reference: bn2(conv2(.)) + identity,
+// then relu) in the conv's epilogue instead of two more passes over the block's output. residual [num_out, cout],
+// may alias nothing the call writes; NULL = pcs_indice_conv_table_f32.
+int pcs_indice_conv_table_residual_f32(const float* features, int cin, const float* filters, int kv,
+                                       int cout, int centre, const int32_t* table, int64_t num_out,
+                                       const float* bias, const float* scale, const float* shift,
+                                       const float* residual, int relu, float* out, hipStream_t s) {
+  if (residual && residual == out) return PCS_ERR_ARG;
+  return conv_table_f32(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, relu, out,
+                        nullptr, s, residual);
 }
 
 // the same with the output rows taken in the order of pcs_neighbor_table_order (rows with the same set of occupied

@@ -296,9 +296,10 @@ def neighbor_table_order(table, num_out):
 
 
 def indice_conv_table(features, filters, table, num_out, subm, bias=None, scale=None, shift=None,
-                      relu=False, order=None):
+                      relu=False, order=None, residual=None):
     """out = epilogue(sum_k feat[table[:,k]] @ W[k]); filters [..., Cin, Cout]. order: neighbor_table_order(table) or
-    None (the same results either way)."""
+    None (the same results either way). residual [num_out, Cout] f32: added after scale / shift, before the ReLU
+    (pcs_indice_conv_table_residual_f32: a residual block's `+ identity` in the conv's epilogue)."""
     L.require_gpu(features, "indice_conv")
     lib = L.load()
     cin, cout = filters.shape[-2], filters.shape[-1]
@@ -307,6 +308,16 @@ def indice_conv_table(features, filters, table, num_out, subm, bias=None, scale=
     features = features.float().contiguous()
     out = torch.empty(num_out, cout, dtype=torch.float32, device=features.device)
     centre = kv // 2 if (subm and kv % 2 == 1) else -1
+    if residual is not None:
+        L.require_gpu(residual, "indice_conv residual")
+        residual = residual.float().contiguous()
+        assert tuple(residual.shape) == (num_out, cout), "residual must be [num_out, Cout]"
+        L.check(lib.pcs_indice_conv_table_residual_f32(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv),
+                                                       L.i32(cout), L.i32(centre), L.ptr(table.contiguous()),
+                                                       L.i64(num_out), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+                                                       L.ptr(residual), L.i32(int(relu)), L.ptr(out), L.stream()),
+                "pcs_indice_conv_table_residual_f32")
+        return out
     L.check(lib.pcs_indice_conv_table_f32(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv),
                                           L.i32(cout), L.i32(centre), L.ptr(table.contiguous()),
                                           L.i64(num_out), L.ptr(bias), L.ptr(scale), L.ptr(shift),

@@ -15,6 +15,9 @@ from ...ops.spconv.modules import fold_batchnorm
 from ...utils.spconv_utils import replace_feature, spconv
 
 
+FUSE_RESIDUAL_ADD = True  # (False: the add and the ReLU as tensor ops after the folded convs; same bits)
+
+
 def _make_conv(conv_type, cin, cout, ksize, stride, padding, key):
     makers = {
         "subm": lambda: spconv.SubMConv3d(cin, cout, ksize, bias=False, indice_key=key),
@@ -56,6 +59,11 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         skip = x.features
+        if self._folded(x) and self.downsample is None and FUSE_RESIDUAL_ADD:
+            # relu(bn2(conv2(.)) + x) in the second conv's epilogue (pcs_indice_conv_table_residual_f32): the same
+            # operations in the same order as below, two passes over the block's output less
+            return self.conv2(self.conv1(x, *fold_batchnorm(self.bn1), relu=True), *fold_batchnorm(self.bn2), relu=True,
+                              residual=skip)
         if self._folded(x):
             y = self.conv2(self.conv1(x, *fold_batchnorm(self.bn1), relu=True), *fold_batchnorm(self.bn2), relu=False)
         else:

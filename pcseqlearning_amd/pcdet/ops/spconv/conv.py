@@ -59,9 +59,11 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(_fan_in_hwio(self.weight))
             init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, input, scale=None, shift=None, relu=False):
+    def forward(self, input, scale=None, shift=None, relu=False, residual=None):
         """`scale` / `shift` [Cout] and `relu`: an eval-mode BatchNorm (+ ReLU) folded into the conv
-        kernel's epilogue (out = relu((conv + bias) * scale + shift)), see SparseSequential."""
+        kernel's epilogue (out = relu((conv + bias) * scale + shift)), see SparseSequential. `residual`
+        [n_out, Cout]: added after the normalisation and before the ReLU (SparseBasicBlock's `+ identity`): in the
+        fp32 kernel's epilogue, as a tensor op on the other paths."""
         assert isinstance(input, SparseConvTensor)
         features, indices = input.features, input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
@@ -79,6 +81,8 @@ class SparseConvolution(SparseModule):
                 feats = feats + self.bias
             if scale is not None:
                 feats = feats * scale + shift
+            if residual is not None:
+                feats = feats + residual
             if relu:
                 feats = torch.relu(feats)
             out = SparseConvTensor(feats, indices, spatial_shape, batch_size)
@@ -129,6 +133,8 @@ class SparseConvolution(SparseModule):
                 out_features = out_features + self.bias
             if scale is not None:
                 out_features = out_features * scale + shift
+            if residual is not None:
+                out_features = out_features + residual
             if relu:
                 out_features = torch.relu(out_features)
         elif features.dtype == torch.float16:
@@ -139,11 +145,16 @@ class SparseConvolution(SparseModule):
                 w = w * scale
                 b = shift if b is None else b * scale + shift
             out_features = _ops.indice_conv_table_half(features, w, table, outids.shape[0],
-                                                       self.subm and not self.inverse, bias=b, relu=relu, order=row_order())
+                                                       self.subm and not self.inverse, bias=b,
+                                                       relu=relu and residual is None, order=row_order())
+            if residual is not None:  # (the fp16 sum of two fp16 rows, as the reference adds them)
+                out_features = out_features + residual
+                if relu:
+                    out_features = torch.relu(out_features)
         else:
             out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
                                                   self.subm and not self.inverse, bias=self.bias, scale=scale,
-                                                  shift=shift, relu=relu, order=row_order())
+                                                  shift=shift, relu=relu, order=row_order(), residual=residual)
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
         out.indice_dict, out.grid = input.indice_dict, input.grid
         return out

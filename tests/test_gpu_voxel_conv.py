@@ -776,3 +776,66 @@ def test_conv_kernel_forms_on_random_tables(kv, n_out, cin, cout):
             np.testing.assert_array_equal(got16[0].view(np.uint16), other.view(np.uint16))
         scale = max(float(np.abs(ref).max()), 1.0)
         assert float(np.abs(got16[0].astype(np.float64) - ref).max()) <= 2.0 ** -7 * scale
+
+
+@pytest.mark.parametrize("kv,n_out,cin,cout", [(27, 4097, 16, 16), (27, 300, 64, 64), (27, 100001, 32, 32), (27, 2000, 128, 128),
+                                               (27, 5000, 5, 16), (9, 700, 24, 40)])
+def test_conv_residual_epilogue_is_the_separate_add(kv, n_out, cin, cout):
+    """pcs_indice_conv_table_residual_f32: relu(((conv + bias) * scale + shift) + residual) in the conv's epilogue is,
+    bit for bit, the conv without ReLU followed by the tensor add and ReLU -- on every fp32 kernel form (FMA tiles, staged
+    and direct-gather matrix-core kernels, one thread per row, one thread per element)."""
+    from pcseqlearning_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(n_out + cin)
+    n_in = n_out
+    table = rng.integers(0, n_in, (n_out, kv)).astype(np.int32)
+    table[rng.random((n_out, kv)) < 0.6] = -1
+    table[:, kv // 2] = np.arange(n_out)
+    feat, W = rng.normal(0, 1, (n_in, cin)).astype(np.float32), rng.normal(0, 0.1, (kv, cin, cout)).astype(np.float32)
+    bias, scale, shift = (rng.normal(0, 0.5, cout).astype(np.float32) for _ in range(3))
+    res = rng.normal(0, 1, (n_out, cout)).astype(np.float32)
+    for mode in (0, 1, 2, 3):
+        L.check(lib.pcs_conv_use_mfma(mode), "mode")
+        try:
+            plain = ops.indice_conv_table(dev(feat), dev(W), dev(table), n_out, True, bias=dev(bias), scale=dev(scale),
+                                          shift=dev(shift), relu=False)
+            fused = ops.indice_conv_table(dev(feat), dev(W), dev(table), n_out, True, bias=dev(bias), scale=dev(scale),
+                                          shift=dev(shift), relu=True, residual=dev(res))
+        finally:
+            L.check(lib.pcs_conv_use_mfma(1), "mode")
+        assert torch.equal(fused, torch.relu(plain + dev(res))), mode
+
+
+def test_residual_block_fused_add_vs_tensor_ops():
+    """SparseBasicBlock in eval mode: the `+ identity` and the ReLU in the second conv's epilogue (default) against the
+    same block with FUSE_RESIDUAL_ADD off -- the same bits, fp32 and fp16."""
+    from pcseqlearning_amd.pcdet.models.blocks import spconv_blocks as SB
+    from pcseqlearning_amd.pcdet.ops import spconv
+    from functools import partial
+    rng = np.random.default_rng(77)
+    shape = [21, 60, 60]
+    from tests.golden.make_golden import random_indices
+    idx = random_indices(rng, shape, 9000, batch=2)
+    for planes in (16, 64):
+        torch.manual_seed(planes)
+        block = SB.SparseBasicBlock(planes, planes, norm_fn=partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01),
+                                    indice_key="res").to(DEV).eval()
+        for bn in (block.bn1, block.bn2):
+            bn.running_mean.normal_(0, 0.5)
+            bn.running_var.uniform_(0.5, 2.0)
+            bn.weight.data.uniform_(0.5, 1.5)
+            bn.bias.data.normal_(0, 0.3)
+        feat = torch.from_numpy(rng.normal(0, 1, (len(idx), planes)).astype(np.float32)).to(DEV)
+        for half in (False, True):
+            f = feat.half() if half else feat
+            with torch.no_grad():
+                outs = []
+                for fuse in (True, False):
+                    SB.FUSE_RESIDUAL_ADD = fuse
+                    try:
+                        x = spconv.SparseConvTensor(f, dev(idx), shape, 2)
+                        outs.append(block(x).features)
+                    finally:
+                        SB.FUSE_RESIDUAL_ADD = True
+            assert outs[0].dtype == outs[1].dtype and torch.equal(outs[0], outs[1]), (planes, half)
+            assert float(outs[0].float().abs().mean()) > 0.05
