@@ -119,6 +119,10 @@ int pcs_cpu_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, cons
 int pcs_cpu_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv, int cout, int centre,
                                   const int32_t* table, int64_t num_out, const float* bias, const float* scale,
                                   const float* shift, int relu, float* out, pcs_stream_t stream);
+int pcs_cpu_indice_conv_table_residual_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                                           int centre, const int32_t* table, int64_t num_out, const float* bias,
+                                           const float* scale, const float* shift, const float* residual, int relu,
+                                           float* out, pcs_stream_t stream);
 int pcs_cpu_bn_fold_f32(const float* weight, const float* bias, const float* running_mean, const float* inv_std, int C,
                         float* scale, float* shift, pcs_stream_t stream);
 size_t pcs_cpu_indice_conv_backward_workspace_bytes(int64_t num_in, int64_t pair_stride, int kv, int cin, int cout);

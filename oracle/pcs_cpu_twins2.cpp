@@ -244,9 +244,9 @@ int pcs_cpu_build_neighbor_table(const int32_t* pairs, int64_t pair_stride, cons
 // conv + BatchNorm1d(eval) + ReLU, modules.py:125-187): per output row the centre offset first (subM), then the
 // offsets ascending, every offset's product a fresh fp32 dot product over ascending input channels added to the row --
 // the order of the reference's gather / GEMM / scatter-add loop; then (+bias), (*scale + shift), relu
-int pcs_cpu_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv, int cout, int centre,
-                                  const int32_t* table, int64_t num_out, const float* bias, const float* scale,
-                                  const float* shift, int relu, float* out, pcs_stream_t) {
+static int conv_table_host(const float* features, int cin, const float* filters, int kv, int cout, int centre,
+                           const int32_t* table, int64_t num_out, const float* bias, const float* scale,
+                           const float* shift, const float* residual, int relu, float* out) {
   if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 || centre >= kv ||
       (scale && !shift))
     return PCS_ERR_ARG;
@@ -271,11 +271,25 @@ int pcs_cpu_indice_conv_table_f32(const float* features, int cin, const float* f
       float x = row[co];
       if (bias) x = x + bias[co];
       if (scale) x = x * scale[co] + shift[co];
+      if (residual) x = x + residual[o * cout + co];
       if (relu) x = x > 0.f ? x : 0.f;
       row[co] = x;
     }
   }
   return PCS_OK;
+}
+int pcs_cpu_indice_conv_table_f32(const float* features, int cin, const float* filters, int kv, int cout, int centre,
+                                  const int32_t* table, int64_t num_out, const float* bias, const float* scale,
+                                  const float* shift, int relu, float* out, pcs_stream_t) {
+  return conv_table_host(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, nullptr, relu, out);
+}
+// SparseBasicBlock's tail (pcdet/models/blocks/spconv_blocks.py:47-64): relu(bn2(conv2(.)) + identity)
+int pcs_cpu_indice_conv_table_residual_f32(const float* features, int cin, const float* filters, int kv, int cout,
+                                           int centre, const int32_t* table, int64_t num_out, const float* bias,
+                                           const float* scale, const float* shift, const float* residual, int relu,
+                                           float* out, pcs_stream_t) {
+  if (residual && residual == out) return PCS_ERR_ARG;
+  return conv_table_host(features, cin, filters, kv, cout, centre, table, num_out, bias, scale, shift, residual, relu, out);
 }
 
 // scale / shift of an eval-mode BatchNorm1d (torch.nn.functional.batch_norm on running statistics, as after every

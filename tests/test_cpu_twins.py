@@ -318,6 +318,12 @@ def test_sparse_conv_twins():
     fused = np.zeros((V, cout), np.float32)
     assert conv(p(bias), p(scale), p(shift), ctypes.c_int(1), p(fused), None) == 0
     np.testing.assert_array_equal(fused, np.maximum((plain + bias) * scale + shift, 0))
+    skip = rng.normal(0, 1, (V, cout)).astype(np.float32)
+    res_out = np.zeros((V, cout), np.float32)
+    assert main.pcs_cpu_indice_conv_table_residual_f32(p(feat), ctypes.c_int(cin), p(W), ctypes.c_int(kv), ctypes.c_int(cout),
+                                                       ctypes.c_int(centre), p(table), _i64(V), p(bias), p(scale), p(shift),
+                                                       p(skip), ctypes.c_int(1), p(res_out), None) == 0
+    np.testing.assert_array_equal(res_out, np.maximum(((plain + bias) * scale + shift) + skip, 0))
     # strided conv: backward against the numpy restatement (BLAS sums: tolerance), pooling exactly
     oshape = O.conv_out_shape(shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1])
     outids, pairs, num = O.get_indice_pairs(idx, oshape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False)

@@ -156,6 +156,10 @@ def test_sparse_conv_twins_beside_the_entries(oracle):
     both("indice_conv_table_f32", feat, I32(cin), W, I32(kv), I32(cout), I32(centre), table, I64(V), bias, scale, shift,
          I32(1), out)
     np.testing.assert_allclose(out.device(), out.h, rtol=1e-5, atol=2e-5)
+    skip, out_r = Buf(rng.normal(0, 1, (V, cout)).astype(np.float32)), Buf(np.zeros((V, cout), np.float32))
+    both("indice_conv_table_residual_f32", feat, I32(cin), W, I32(kv), I32(cout), I32(centre), table, I64(V), bias, scale,
+         shift, skip, I32(1), out_r)
+    np.testing.assert_allclose(out_r.device(), out_r.h, rtol=1e-5, atol=2e-5)
     # strided window: pooling and its backward exactly, the conv's backward within 1e-4 (two-stage sums on the device)
     oshape = oracle.conv_out_shape(shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1])
     outids, pairs, num = oracle.get_indice_pairs(idx, oshape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False)
