@@ -445,3 +445,80 @@ def ref_hard_voxelize(points, pc_range, voxel_size, max_points, max_voxels):
     v = mod.points_to_voxel_3d_np(pts, voxels, coors, num, c2v, vs.tolist(), rng.tolist(),
                                   max_points, max_voxels)
     return voxels[:v].copy(), coors[:v].copy(), num[:v].copy()
+
+
+# ------------------------------------------------------------------------------------------
+# N-D rulebook (the reference instantiates NDim = 2, 3, 4: src/all.cc:22-29). A literal, loop-by-loop restatement
+# of include/spconv/geometry.h:25-297 for small cases; pinned by running it at NDim = 3 against the compiled
+# restatement above (itself pinned to the reference's own functors, tests/test_oracle_pinning.py).
+def _valid_out_pos(pos, ksize, stride, padding, dilation, out_shape, transpose):
+    """getValidOutPos / getValidOutPosTranspose (geometry.h:25-84, 86-143): (output position, kernel offset) of one
+    input position, in the reference's order of enumeration."""
+    D = len(pos)
+    if transpose:
+        lowers = [pos[i] * stride[i] - padding[i] for i in range(D)]
+        uppers = [lowers[i] + (ksize[i] - 1) * dilation[i] for i in range(D)]
+    else:
+        # (C integer division truncates towards zero)
+        tdiv = lambda a, b: int(a / b) if a * b < 0 else a // b  # noqa: E731
+        lowers = [tdiv(pos[i] - (ksize[i] - 1) * dilation[i] - 1 + stride[i] + padding[i], stride[i]) for i in range(D)]
+        uppers = [tdiv(pos[i] + padding[i], stride[i]) for i in range(D)]
+    sizes = [(uppers[i] - lowers[i]) // dilation[i] + 1 for i in range(D)]
+    n = 1
+    for s in sizes:
+        n *= s
+    counter = [0] * D
+    out = []
+    for _ in range(max(n, 0)):
+        valid, m, offset, vals = True, 1, 0, [0] * D
+        for j in range(D - 1, -1, -1):
+            val = uppers[j] - counter[j] * dilation[j]
+            vals[j] = val
+            if val < 0 or val > out_shape[j] - 1:
+                valid = False
+            if transpose:
+                offset += m * (val - lowers[j]) // dilation[j]
+            else:
+                offset += m * (pos[j] - val * stride[j] + padding[j]) // dilation[j]
+            m *= ksize[j]
+        if valid:
+            out.append((tuple(vals), offset))
+        counter[D - 1] += 1
+        for c in range(D - 1, 0, -1):
+            if counter[c] == sizes[c]:
+                counter[c - 1] += 1
+                counter[c] = 0
+    return out
+
+
+def get_indice_pairs_nd_py(indices, out_shape, ksize, stride, padding, dilation, subm, transpose=False):
+    """getIndicePairsSubM / Conv / DeConv (geometry.h:145-297) for indices [V, 1 + D]: (outids, pairs [KV,2,V] with -1
+    beyond the counts, num [KV])."""
+    idx = np.asarray(indices, np.int64)
+    V, D = idx.shape[0], idx.shape[1] - 1
+    kv = int(np.prod(ksize))
+    pairs = np.full((kv, 2, V), -1, np.int32)
+    num = np.zeros(kv, np.int32)
+    grid = {}
+    if subm:
+        for j in range(V):
+            grid[(int(idx[j, 0]),) + tuple(int(x) for x in idx[j, 1:])] = j
+        for j in range(V):
+            for vals, off in _valid_out_pos([int(x) for x in idx[j, 1:]], ksize, stride, padding, dilation, out_shape, False):
+                o = grid.get((int(idx[j, 0]),) + vals, -1)
+                if o > -1:
+                    pairs[off, 0, num[off]] = j
+                    pairs[off, 1, num[off]] = o
+                    num[off] += 1
+        return np.asarray(indices, np.int32), pairs, num
+    outids = []
+    for j in range(V):
+        for vals, off in _valid_out_pos([int(x) for x in idx[j, 1:]], ksize, stride, padding, dilation, out_shape, transpose):
+            key = (int(idx[j, 0]),) + vals
+            if key not in grid:
+                grid[key] = len(outids)
+                outids.append(key)
+            pairs[off, 0, num[off]] = j
+            pairs[off, 1, num[off]] = grid[key]
+            num[off] += 1
+    return np.asarray(outids, np.int32).reshape(-1, D + 1), pairs, num

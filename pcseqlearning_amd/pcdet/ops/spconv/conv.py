@@ -190,6 +190,23 @@ class SparseInverseConv3d(SparseConvolution):
                          indice_key=indice_key)
 
 
+# ---- the 4-D forms (conv.py:257-279, 422-445 of the reference; get_indice_pairs_4d, src/all.cc:28-29): the rulebook is
+# ops._indice_pairs_nd (tensor operations: nothing on the hot path is 4-D), the convolution over its 81-offset pairs
+# the HIP kernels' any-volume form
+class SparseConv4d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(4, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, indice_key=indice_key)
+
+
+class SubMConv4d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(4, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, True, indice_key=indice_key)
+
+
 # ---- the 2-D forms (conv.py:207-229, 282-305, 334-349, 370-393 of the reference): the same module on planes; the
 # rulebook of a plane is a one-cell-deep volume's (ops.get_indice_pairs)
 class SparseConv2d(SparseConvolution):

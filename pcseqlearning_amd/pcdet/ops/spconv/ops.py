@@ -40,9 +40,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
         outids = res[0]
         outids = indices if subm else torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
         return (outids, *res[1:])
-    if ndim != 3:
-        raise NotImplementedError("2-D and 3-D rulebooks only (the reference's 4-D instantiation, src/all.cc:28-29, "
-                                  "is not on the hot path)")
+    if ndim not in (3, 4):
+        raise NotImplementedError("2-D, 3-D and 4-D rulebooks only (the reference instantiates no others, src/all.cc:22-29)")
     ksize, stride, padding = _list(ksize, ndim), _list(stride, ndim), _list(padding, ndim)
     dilation, out_padding = _list(dilation, ndim), _list(out_padding, ndim)
     for d, s in zip(dilation, stride):
@@ -53,8 +52,88 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
         out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, out_padding)
     else:
         out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    if ndim == 4:
+        res = _indice_pairs_nd(indices, out_shape, ksize, stride, padding, dilation, subm, transpose)
+        return (*res, None) if with_table else res
     return _ops.get_indice_pairs(indices, batch_size, out_shape, list(spatial_shape), ksize, stride,
                                  padding, dilation, subm, transpose, with_table=with_table)
+
+
+def _indice_pairs_nd(indices, out_shape, ksize, stride, padding, dilation, subm, transpose):
+    """get_indice_pairs_4d (src/all.cc:28-29 of the reference -> getIndicePairsSubM / Conv / DeConv<4>,
+    include/spconv/geometry.h:145-297) for any number of dimensions, as tensor operations on the device: the reference
+    instantiates it, nothing on the hot path calls it, so it has no kernel of its own -- the convolutions over its
+    pairs are the HIP ones (any kernel volume). Semantics restated from geometry.h:25-143: for input j (ascending) and
+    kernel position k (getValidOutPos walks the output positions downwards, i.e. the kernel positions in ascending
+    row-major order; getValidOutPosTranspose in descending order) the output position is
+    (pos + pad - k * dil) / stride where that division is exact (transposed: pos * stride - pad + k * dil), kept when
+    it lies inside out_shape; output ids are dealt in the order outputs first appear in that walk; the pairs of an
+    offset are in ascending j. Returns (outids [n_out, 1 + D] int32, pairs [KV, 2, V] int32 (-1 beyond the counts),
+    num [KV] int32)."""
+    import torch
+    dev = indices.device
+    D, V = len(ksize), indices.shape[0]
+    kv = 1
+    for k in ksize:
+        kv *= k
+    idx = indices.long()
+    b, pos = idx[:, 0], idx[:, 1:]
+    t = lambda v: torch.tensor(v, dtype=torch.long, device=dev)  # noqa: E731
+    ks, st, pd, dl, osz = t(ksize), t(stride), t(padding), t(dilation), t(out_shape)
+    grids = torch.stack(torch.meshgrid(*[torch.arange(k, device=dev) for k in ksize], indexing="ij"), -1).reshape(kv, D)
+    if transpose:
+        val = pos[:, None, :] * st - pd + grids[None] * dl
+        valid = torch.ones(V, kv, dtype=torch.bool, device=dev)
+    else:
+        numer = pos[:, None, :] + pd - grids[None] * dl
+        val = torch.div(numer, st, rounding_mode="floor")
+        valid = (numer - val * st == 0).all(-1)
+    valid = valid & ((val >= 0) & (val < osz)).all(-1)
+    mult = torch.ones(D, dtype=torch.long, device=dev)
+    for d in range(D - 2, -1, -1):
+        mult[d] = mult[d + 1] * out_shape[d + 1]
+    vol = int(mult[0]) * out_shape[0]
+    key = (val * mult).sum(-1) + b[:, None] * vol  # [V, KV] linear output index (rowArrayIdx + volume * batch)
+    pairs = torch.full((kv, 2, V), -1, dtype=torch.int32, device=dev)
+    if subm:
+        # gridsOut[index of input j] = j (a later duplicate overwrites an earlier one), outputs = inputs
+        in_key = (pos * mult).sum(-1) + b * vol
+        skey, order = torch.sort(in_key, stable=True)
+        at = torch.searchsorted(skey, key.reshape(-1), right=True) - 1  # the LAST input with that key
+        hit = (at >= 0) & (skey[at.clamp(min=0)] == key.reshape(-1))
+        valid = valid & hit.reshape(V, kv)
+        out_of = order[at.clamp(min=0)].reshape(V, kv)
+        outids = indices
+    else:
+        # output ids by first appearance in the walk: j ascending, kernel positions ascending (transposed: descending)
+        walk = torch.arange(kv, device=dev)
+        if transpose:
+            walk = kv - 1 - walk
+        seq = torch.arange(V, device=dev)[:, None] * kv + walk[None]
+        vk, vs = key[valid], seq[valid]
+        uniq, inv = torch.unique(vk, return_inverse=True)
+        first = torch.full((uniq.shape[0],), V * kv, dtype=torch.long, device=dev)
+        first.scatter_reduce_(0, inv, vs, reduce="amin")
+        rank = torch.empty_like(first)
+        rank[torch.argsort(first)] = torch.arange(uniq.shape[0], device=dev)
+        out_of = torch.zeros(V, kv, dtype=torch.long, device=dev)
+        out_of[valid] = rank[inv]
+        by_rank = torch.argsort(first)
+        ukey = uniq[by_rank]
+        coords = [torch.div(ukey, vol, rounding_mode="floor")]
+        rem = ukey - coords[0] * vol
+        for d in range(D):
+            c = torch.div(rem, mult[d], rounding_mode="floor")
+            coords.append(c)
+            rem = rem - c * mult[d]
+        outids = torch.stack(coords, 1).to(torch.int32)
+    num = valid.sum(0).to(torch.int32)
+    kk, jj = valid.t().nonzero(as_tuple=True)  # grouped by offset, j ascending inside
+    start = torch.cumsum(num.long(), 0) - num.long()
+    slot = torch.arange(kk.shape[0], device=dev) - start[kk]
+    pairs[kk, 0, slot] = jj.to(torch.int32)
+    pairs[kk, 1, slot] = out_of[jj, kk].to(torch.int32)
+    return outids.contiguous(), pairs, num
 
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,

@@ -839,3 +839,41 @@ def test_residual_block_fused_add_vs_tensor_ops():
                         SB.FUSE_RESIDUAL_ADD = True
             assert outs[0].dtype == outs[1].dtype and torch.equal(outs[0], outs[1]), (planes, half)
             assert float(outs[0].float().abs().mean()) > 0.05
+
+
+def test_four_dimensional_conv_modules(oracle):
+    """SubMConv4d / SparseConv4d (conv.py:257-279, 422-445 of the reference; get_indice_pairs_4d): the rulebook of
+    ops._indice_pairs_nd on the device equals the loop restatement of geometry.h (tests/test_rulebook_nd.py pins that
+    one), and the modules' outputs are the sum over its 81 offsets' pairs -- fp32, the conv kernels' any-volume form."""
+    from pcseqlearning_amd.pcdet.ops import spconv
+    from tests.test_rulebook_nd import random_indices_nd
+    rng = np.random.default_rng(91)
+    shape = [5, 8, 9, 7]
+    idx = random_indices_nd(rng, shape, 1500, 2)
+    feat = rng.normal(0, 1, (len(idx), 6)).astype(np.float32)
+    torch.manual_seed(3)
+    for mod, subm, st, pd in ((spconv.SubMConv4d(6, 16, 3, padding=1, indice_key="s4"), True, [1] * 4, [1] * 4),
+                              (spconv.SparseConv4d(6, 16, 3, stride=2, padding=1), False, [2] * 4, [1] * 4)):
+        mod = mod.to(DEV).eval()
+        x = spconv.SparseConvTensor(dev(feat), dev(idx), shape, 2)
+        with torch.no_grad():
+            y = mod(x)
+        osh = shape if subm else spconv.ops.get_conv_output_size(shape, [3] * 4, st, pd, [1] * 4)
+        outids, pairs, num = oracle.get_indice_pairs_nd_py(idx, osh, [3] * 4, st, pd, [1] * 4, subm)
+        assert list(y.spatial_shape) == list(osh)
+        np.testing.assert_array_equal(y.indices.cpu().numpy(), outids)
+        W = mod.weight.detach().cpu().numpy().reshape(81, 6, 16).astype(np.float64)
+        ref = np.zeros((len(outids), 16))
+        for k in range(81):
+            n = int(num[k])
+            np.add.at(ref, pairs[k, 1, :n], feat[pairs[k, 0, :n]].astype(np.float64) @ W[k])
+        ref = ref + mod.bias.detach().cpu().numpy()
+        np.testing.assert_allclose(y.features.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    # the same rulebook twice under one indice_key (the cached pairs and table are used the second time)
+    mod = spconv.SubMConv4d(16, 16, 3, padding=1, indice_key="s4").to(DEV).eval()
+    first = spconv.SubMConv4d(6, 16, 3, padding=1, indice_key="s4").to(DEV).eval()
+    with torch.no_grad():
+        h = first(spconv.SparseConvTensor(dev(feat), dev(idx), shape, 2))
+        assert "s4" in h.indice_dict
+        z = mod(h)
+    assert z.features.shape == (len(idx), 16) and torch.isfinite(z.features).all()
