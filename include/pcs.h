@@ -242,6 +242,12 @@ int pcs_indice_maxpool_f16(const void* features, int64_t num_in, int C, const in
                            const int32_t* num, int kv, int64_t num_out, void* out, void* ws, size_t ws_bytes,
                            pcs_stream_t stream);
 /* ws: pcs_neighbor_table_bytes(num_in, kv) */
+/* pcs_indice_conv_table_f16 with a residual row: fp16(relu(fp16(conv + bias) + residual[o,:])), the sum of the two fp16
+ * rows formed as the tensor library forms it (fp32, one rounding) -- SparseBasicBlock's `+ identity` and ReLU for fp16
+ * features, the bits of the separate tensor ops. residual [num_out, cout] fp16, must not be `out`; NULL = no residual. */
+int pcs_indice_conv_table_residual_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                                       const int32_t* table, int64_t num_out, const void* bias, const void* residual,
+                                       int relu, void* out, pcs_stream_t stream);
 int pcs_indice_maxpool_backward_f16(const void* features, const void* out_features, const void* out_grad, int C,
                                     const int32_t* pairs, int64_t pair_stride, const int32_t* num, int kv,
                                     int64_t num_in, void* in_grad, void* ws, size_t ws_bytes, pcs_stream_t stream);

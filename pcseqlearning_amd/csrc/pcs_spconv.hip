@@ -1096,7 +1096,8 @@ template <int NC>
 __global__ void __launch_bounds__(kBlock)
 indice_conv_f16_mfma_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                             int centre, const int32_t* __restrict__ table, int64_t num_out,
-                            const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+                            const __half* __restrict__ bias, int relu, const __half* __restrict__ residual,
+                            __half* __restrict__ out) {
   constexpr int COUT = NC * 16;
   __shared__ __align__(16) _Float16 As[TM][H_LD];
   __shared__ __align__(16) _Float16 Wt[COUT][H_LD];
@@ -1172,6 +1173,7 @@ indice_conv_f16_mfma_kernel(const __half* __restrict__ feat, int cin, const __ha
       const int64_t r = row0 + wv * 16 + fk * 4 + j;
       if (r >= num_out) continue;
       float v = acc[n][j] + bv;
+      if (residual) v = __half2float(__float2half_rn(v)) + __half2float(residual[r * COUT + col]);
       if (relu) v = fmaxf(v, 0.f);
       out[r * COUT + col] = __float2half_rn(v);
     }
@@ -1192,7 +1194,8 @@ template <int NC>
 __global__ void __launch_bounds__(kBlock)
 indice_conv_f16_mfma_tall_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                                  int centre, const int32_t* __restrict__ table, int64_t num_out,
-                                 const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+                                 const __half* __restrict__ bias, int relu, const __half* __restrict__ residual,
+                            __half* __restrict__ out) {
   constexpr int COUT = NC * 16;
   constexpr int MT = TMH / 64;                       // 16-row fragments per wave
   constexpr int NA = TMH * (CIN_MAX / 8) / kBlock;   // 16-byte row pieces per thread at 64 channels
@@ -1343,6 +1346,7 @@ indice_conv_f16_mfma_tall_kernel(const __half* __restrict__ feat, int cin, const
         const int64_t r = row0 + wv * (TMH / 4) + m * 16 + fk * 4 + j;
         if (r >= num_out) continue;
         float v = acc[m][n][j] + bv;
+        if (residual) v = __half2float(__float2half_rn(v)) + __half2float(residual[r * COUT + col]);
         if (relu) v = fmaxf(v, 0.f);
         out[r * COUT + col] = __float2half_rn(v);
       }
@@ -1365,7 +1369,8 @@ template <int NC, int kDirBlock>
 __global__ void __launch_bounds__(kDirBlock)
 indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                               int centre, const int32_t* __restrict__ table, int64_t num_out,
-                              const __half* __restrict__ bias, int relu, __half* __restrict__ out,
+                              const __half* __restrict__ bias, int relu, const __half* __restrict__ residual,
+                            __half* __restrict__ out,
                               const int32_t* __restrict__ order) {
   constexpr int COUT = NC * 16;
   constexpr int MT = 2;  // 16-row fragments per wave
@@ -1493,6 +1498,7 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
         const int64_t r = order ? (int64_t)order[pos] : pos;
         if ((uint64_t)r >= (uint64_t)num_out) continue;
         float v = acc[m][n][j] + bv;
+        if (residual) v = __half2float(__float2half_rn(v)) + __half2float(residual[r * COUT + col]);
         if (relu) v = fmaxf(v, 0.f);
         out[r * COUT + col] = __float2half_rn(v);
       }
@@ -1504,7 +1510,8 @@ indice_conv_f16_direct_kernel(const __half* __restrict__ feat, int cin, const __
 __global__ void __launch_bounds__(kBlock)
 indice_conv_f16_generic_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                                int cout, int centre, const int32_t* __restrict__ table, int64_t num_out,
-                               const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+                               const __half* __restrict__ bias, int relu, const __half* __restrict__ residual,
+                            __half* __restrict__ out) {
   const int64_t total = num_out * cout;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -1521,6 +1528,7 @@ indice_conv_f16_generic_kernel(const __half* __restrict__ feat, int cin, const _
       for (int c = 0; c < cin; ++c) acc = fmaf(__half2float(f[c]), __half2float(w[(int64_t)c * cout]), acc);
     }
     if (bias) acc = acc + __half2float(bias[col]);
+    if (residual) acc = __half2float(__float2half_rn(acc)) + __half2float(residual[t]);
     if (relu) acc = fmaxf(acc, 0.f);
     out[t] = __float2half_rn(acc);
   }
@@ -1535,7 +1543,8 @@ template <int COUT>
 __global__ void __launch_bounds__(kBlock)
 indice_conv_f16_rows_kernel(const __half* __restrict__ feat, int cin, const __half* __restrict__ W, int kv,
                             int centre, const int32_t* __restrict__ table, int64_t num_out,
-                            const __half* __restrict__ bias, int relu, __half* __restrict__ out) {
+                            const __half* __restrict__ bias, int relu, const __half* __restrict__ residual,
+                            __half* __restrict__ out) {
   constexpr int kMaxW = 32 * 8 * COUT;  // kv <= 32, cin <= 8
   __shared__ float Wf[kMaxW];
   for (int e = threadIdx.x; e < kv * cin * COUT; e += kBlock) Wf[e] = __half2float(W[e]);
@@ -1584,6 +1593,7 @@ indice_conv_f16_rows_kernel(const __half* __restrict__ feat, int cin, const __ha
     for (int j = 0; j < 8; ++j) {
       float v = acc[j8 * 8 + j];
       if (bias) v = v + __half2float(bias[j8 * 8 + j]);
+      if (residual) v = __half2float(__float2half_rn(v)) + __half2float(residual[r * COUT + j8 * 8 + j]);
       if (relu) v = fmaxf(v, 0.f);
       h[j] = __float2half_rn(v);
     }
@@ -1714,7 +1724,7 @@ static int g_f16_short_tiles = 0;  // pcs_indice_conv_f16_short_tiles: 1 = the 6
 // out[o,:] = fp16( (+bias) relu? ( sum_k feat[table[o,k],:] . W[k] ) ) on an output-major table
 static int conv_table_f16(const __half* features, int cin, const __half* filters, int kv, int cout, int centre,
                           const int32_t* table, int64_t num_out, const __half* bias, int relu, __half* out,
-                          hipStream_t s, const int32_t* order = nullptr) {
+                          hipStream_t s, const int32_t* order = nullptr, const __half* residual = nullptr) {
   if (num_out == 0) return PCS_OK;
   const int64_t nb = (num_out + TM - 1) / TM;
   if (nb >= (1LL << 31)) return PCS_ERR_RANGE;
@@ -1722,7 +1732,7 @@ static int conv_table_f16(const __half* features, int cin, const __half* filters
   if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= CIN_MAX && (g_f16_short_tiles == 0 || g_f16_short_tiles == 3)) {
 #define PCS_DIRECT(NCV, BLK)                                                                                          \
   indice_conv_f16_direct_kernel<NCV, BLK><<<(int)((num_out + BLK / 2 - 1) / (BLK / 2)), BLK, 0, s>>>(                   \
-      features, cin, filters, kv, centre, table, num_out, bias, relu, out, order)
+      features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out, order)
     if (g_f16_short_tiles == 3) {
       switch (cout) {
         case 16: PCS_DIRECT(1, 512); break;
@@ -1742,27 +1752,27 @@ static int conv_table_f16(const __half* features, int cin, const __half* filters
   } else if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX && g_f16_short_tiles != 1) {
     const int nbt = (int)((num_out + TMH - 1) / TMH);
     switch (cout) {
-      case 16: indice_conv_f16_mfma_tall_kernel<1><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      case 32: indice_conv_f16_mfma_tall_kernel<2><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      case 64: indice_conv_f16_mfma_tall_kernel<4><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      default: indice_conv_f16_mfma_tall_kernel<8><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 16: indice_conv_f16_mfma_tall_kernel<1><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      case 32: indice_conv_f16_mfma_tall_kernel<2><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      case 64: indice_conv_f16_mfma_tall_kernel<4><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      default: indice_conv_f16_mfma_tall_kernel<8><<<nbt, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
     }
   } else if (cout_ok && kv <= 32 && cin % 16 == 0 && cin <= 8 * CIN_MAX) {
     switch (cout) {
-      case 16: indice_conv_f16_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      case 32: indice_conv_f16_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      case 64: indice_conv_f16_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
-      default: indice_conv_f16_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out); break;
+      case 16: indice_conv_f16_mfma_kernel<1><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      case 32: indice_conv_f16_mfma_kernel<2><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      case 64: indice_conv_f16_mfma_kernel<4><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
+      default: indice_conv_f16_mfma_kernel<8><<<(int)nb, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out); break;
     }
   } else if (cin <= 8 && kv <= 32 && (cout == 16 || cout == 32) && g_f16_short_tiles != 1) {
     const int nbr = (int)((num_out + kBlock - 1) / kBlock);
     if (cout == 16)
-      indice_conv_f16_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out);
+      indice_conv_f16_rows_kernel<16><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out);
     else
-      indice_conv_f16_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, out);
+      indice_conv_f16_rows_kernel<32><<<nbr, kBlock, 0, s>>>(features, cin, filters, kv, centre, table, num_out, bias, relu, residual, out);
   } else {
     indice_conv_f16_generic_kernel<<<grid_for(num_out * cout), kBlock, 0, s>>>(features, cin, filters, kv, cout, centre,
-                                                                              table, num_out, bias, relu, out);
+                                                                              table, num_out, bias, relu, residual, out);
   }
   PCS_LAUNCH_CHECK();
   return PCS_OK;
@@ -1823,6 +1833,20 @@ int pcs_indice_conv_table_ordered_f16(const void* features, int cin, const void*
     return PCS_ERR_ARG;
   return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, table, num_out,
                         (const __half*)bias, relu, (__half*)out, s, order);
+}
+
+// ... with a residual row: fp16(relu(fp16(conv + bias) + residual[o,:])) -- the conv's own fp16 result and the fp16
+// identity row added as the tensor library adds two fp16 rows (in fp32, rounded once), then the ReLU: the bits of
+// SparseBasicBlock's separate add (pcs_indice_conv_table_residual_f32 is the fp32 form). residual must not be `out`.
+int pcs_indice_conv_table_residual_f16(const void* features, int cin, const void* filters, int kv, int cout, int centre,
+                                       const int32_t* table, int64_t num_out, const void* bias, const void* residual,
+                                       int relu, void* out, hipStream_t s) {
+  using namespace pcs;
+  if (!features || !filters || !table || !out || cin < 1 || cout < 1 || kv < 1 || num_out < 0 || centre >= kv ||
+      (residual && residual == out))
+    return PCS_ERR_ARG;
+  return conv_table_f16((const __half*)features, cin, (const __half*)filters, kv, cout, centre, table, num_out,
+                        (const __half*)bias, relu, (__half*)out, s, nullptr, (const __half*)residual);
 }
 
 // indice_conv_backward_half (src/all.cc:36-37; spconv_ops.h:363-449 on at::Half): in_grad [num_in,cin] and

@@ -381,9 +381,10 @@ def indice_maxpool_half(features, pairs, num, num_out):
     return out
 
 
-def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, relu=False, order=None):
+def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, relu=False, order=None, residual=None):
     """pcs_indice_conv_table_ordered_f16: the fp16 conv on a cached neighbour table; filters [..., Cin, Cout], bias
-    [Cout]; order: neighbor_table_order(table) or None."""
+    [Cout]; order: neighbor_table_order(table) or None. residual [num_out, Cout] fp16: added to the conv's fp16 result
+    before the ReLU (pcs_indice_conv_table_residual_f16)."""
     L.require_gpu(features, "indice_conv_table_half")
     lib = L.load()
     cin, cout = filters.shape[-2], filters.shape[-1]
@@ -393,6 +394,15 @@ def indice_conv_table_half(features, filters, table, num_out, subm, bias=None, r
     b = bias.half().contiguous() if bias is not None else None
     out = torch.empty(num_out, cout, dtype=torch.float16, device=features.device)
     centre = kv // 2 if (subm and kv % 2 == 1) else -1
+    if residual is not None:
+        L.require_gpu(residual, "indice_conv_table_half residual")
+        residual = residual.half().contiguous()
+        assert tuple(residual.shape) == (num_out, cout), "residual must be [num_out, Cout]"
+        L.check(lib.pcs_indice_conv_table_residual_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
+                                                       L.i32(centre), L.ptr(table.contiguous()), L.i64(num_out), L.ptr(b),
+                                                       L.ptr(residual), L.i32(int(relu)), L.ptr(out), L.stream()),
+                "pcs_indice_conv_table_residual_f16")
+        return out
     L.check(lib.pcs_indice_conv_table_ordered_f16(L.ptr(features), L.i32(cin), L.ptr(W), L.i32(kv), L.i32(cout),
                                                   L.i32(centre), L.ptr(table.contiguous()), L.i64(num_out), L.ptr(b),
                                                   L.i32(int(relu)), L.ptr(out), L.ptr(order), L.stream()),

@@ -63,7 +63,7 @@ class SparseConvolution(SparseModule):
         """`scale` / `shift` [Cout] and `relu`: an eval-mode BatchNorm (+ ReLU) folded into the conv
         kernel's epilogue (out = relu((conv + bias) * scale + shift)), see SparseSequential. `residual`
         [n_out, Cout]: added after the normalisation and before the ReLU (SparseBasicBlock's `+ identity`): in the
-        fp32 kernel's epilogue, as a tensor op on the other paths."""
+        conv kernels' epilogue (fp32 and fp16), as a tensor op on the differentiable and 1x1 paths."""
         assert isinstance(input, SparseConvTensor)
         features, indices = input.features, input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
@@ -144,13 +144,10 @@ class SparseConvolution(SparseModule):
             if scale is not None:
                 w = w * scale
                 b = shift if b is None else b * scale + shift
+            # (a residual: the fp16 sum of the conv's fp16 rows and the identity's, as the reference adds them)
             out_features = _ops.indice_conv_table_half(features, w, table, outids.shape[0],
-                                                       self.subm and not self.inverse, bias=b,
-                                                       relu=relu and residual is None, order=row_order())
-            if residual is not None:  # (the fp16 sum of two fp16 rows, as the reference adds them)
-                out_features = out_features + residual
-                if relu:
-                    out_features = torch.relu(out_features)
+                                                       self.subm and not self.inverse, bias=b, relu=relu,
+                                                       order=row_order() if residual is None else None, residual=residual)
         else:
             out_features = _ops.indice_conv_table(features, self.weight, table, outids.shape[0],
                                                   self.subm and not self.inverse, bias=self.bias, scale=scale,

@@ -783,7 +783,8 @@ def test_conv_kernel_forms_on_random_tables(kv, n_out, cin, cout):
 def test_conv_residual_epilogue_is_the_separate_add(kv, n_out, cin, cout):
     """pcs_indice_conv_table_residual_f32: relu(((conv + bias) * scale + shift) + residual) in the conv's epilogue is,
     bit for bit, the conv without ReLU followed by the tensor add and ReLU -- on every fp32 kernel form (FMA tiles, staged
-    and direct-gather matrix-core kernels, one thread per row, one thread per element)."""
+    and direct-gather matrix-core kernels, one thread per row, one thread per element), and the same for
+    pcs_indice_conv_table_residual_f16 on the fp16 forms."""
     from pcseqlearning_amd import lib as L
     lib = L.load()
     rng = np.random.default_rng(n_out + cin)
@@ -804,6 +805,17 @@ def test_conv_residual_epilogue_is_the_separate_add(kv, n_out, cin, cout):
         finally:
             L.check(lib.pcs_conv_use_mfma(1), "mode")
         assert torch.equal(fused, torch.relu(plain + dev(res))), mode
+    # fp16: fp16(conv + bias) + fp16 residual as the tensor library adds two fp16 rows, then the ReLU -- on every form
+    # (direct 256 / 512 threads, 128-row staged, round 4's 64-row, one thread per row, one thread per element)
+    f16, W16, r16 = dev(feat).half(), dev(W).half(), dev(res).half()
+    for tiles in (0, 1, 2, 3):
+        L.check(lib.pcs_indice_conv_f16_short_tiles(tiles), "tiles")
+        try:
+            plain = ops.indice_conv_table_half(f16, W16, dev(table), n_out, True, bias=dev(bias), relu=False)
+            fused = ops.indice_conv_table_half(f16, W16, dev(table), n_out, True, bias=dev(bias), relu=True, residual=r16)
+        finally:
+            L.check(lib.pcs_indice_conv_f16_short_tiles(0), "tiles")
+        assert fused.dtype == torch.float16 and torch.equal(fused, torch.relu(plain + r16)), tiles
 
 
 def test_residual_block_fused_add_vs_tensor_ops():

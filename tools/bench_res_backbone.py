@@ -1,7 +1,6 @@
 """VoxelResBackBone8x forward (pcdet/models/backbones_3d/spconv_backbone.py:161-271 of the reference) on
 configs[1]-shaped frames, with the residual blocks' `+ identity` and ReLU in the second conv's epilogue
-(pcs_indice_conv_table_residual_f32, the default) and as tensor ops, alternating; fp32 (and fp16 with --half, where the
-add stays a tensor op):
+(pcs_indice_conv_table_residual_f32 / _f16, the default) and as tensor ops, alternating; fp32 (and fp16 with --half):
   python tools/bench_res_backbone.py --batch 20 [--half] [--reps 20]"""
 import argparse
 import json
